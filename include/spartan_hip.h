@@ -1,0 +1,259 @@
+/*
+ * spartan_hip.h -- C-ABI of libspartan_hip.so, the MI355X (gfx950) tile-kernel
+ * backend for Spartan-style lazy arrays.
+ *
+ * The reference has no FFI for this path: its per-tile "kernels" are NumPy calls
+ * made inside the worker (spartan/expr/operator/local.py:115-127) and its
+ * alternate-backend precedent is ParakeetExpr (local.py:187-209).  Each entry
+ * point below names the reference call site whose *body* it replaces; the
+ * Python host (spartan_amd/backend_hip.py) binds them with ctypes, and
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the failure
+ *     text is available from sp_last_error() (thread-local), mirroring the
+ *     reference's RemoteException-carries-traceback convention
+ *     (spartan/rpc/common.py:43-47,165-167).
+ *   - all pointers named d_* are DEVICE pointers into HBM (tile blobs are
+ *     allocated by the host; the library never owns tile memory).
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on
+ *     that stream; no call synchronises the device.
+ *   - no torch / C++ types cross this boundary.
+ */
+#ifndef SPARTAN_HIP_H_
+#define SPARTAN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_ABI_VERSION 1
+
+/* ---- element types of tile blobs (spartan/array/tile.pyx:34-46: a Tile is
+ *      shape + dtype + dense data) ---- */
+enum sp_dtype {
+  SP_F32 = 0,
+  SP_F64 = 1,
+  SP_I32 = 2,
+  SP_I64 = 3,
+  SP_BOOL = 4, /* numpy bool_: one byte, 0/1 */
+  SP_U8 = 5,
+  SP_DTYPE_COUNT = 6
+};
+
+/* ---- fused LocalExpr program --------------------------------------------
+ * A serialised FnCallExpr tree (spartan/expr/operator/local.py:76-127) after
+ * MapMapFusion / ReduceMapFusion (spartan/expr/operator/optimize.py:133-227).
+ * It is a straight-line register program over SP_NREG virtual registers,
+ * evaluated per element in ONE arithmetic class (`cls`): float (SP_F32),
+ * double (SP_F64) or int64 (SP_I64).  Inputs are converted to the class on
+ * load; SP_OP_TO_* ops re-normalise a value to a narrower NumPy dtype where
+ * the reference's intermediate would have been narrower.  Register j <
+ * n_inputs is pre-loaded with input j.
+ */
+#define SP_MAX_INPUTS 8
+#define SP_MAX_INSTR 64
+#define SP_MAX_CONSTS 16
+#define SP_MAX_DIMS 4
+#define SP_NREG 8
+
+enum sp_opcode {
+  SP_OP_NOP = 0,
+  /* leaves */
+  SP_OP_CONST = 1, /* dst = consts[a] */
+  SP_OP_IOTA = 2,  /* dst = linear element index inside this tile (row-major) */
+  SP_OP_MOV = 3,
+  /* binary arithmetic (numpy ufunc named in comment) */
+  SP_OP_ADD = 10,      /* np.add */
+  SP_OP_SUB = 11,      /* np.subtract */
+  SP_OP_MUL = 12,      /* np.multiply */
+  SP_OP_DIV = 13,      /* np.divide / np.true_divide (float classes) */
+  SP_OP_FLOORDIV = 14, /* np.floor_divide */
+  SP_OP_MOD = 15,      /* np.mod / np.remainder (sign of divisor) */
+  SP_OP_FMOD = 16,     /* np.fmod (sign of dividend) */
+  SP_OP_POW = 17,      /* np.power */
+  SP_OP_MAX = 18,      /* np.maximum (NaN-propagating) */
+  SP_OP_MIN = 19,      /* np.minimum (NaN-propagating) */
+  /* comparisons -> 0/1 */
+  SP_OP_EQ = 20,
+  SP_OP_NE = 21,
+  SP_OP_LT = 22,
+  SP_OP_LE = 23,
+  SP_OP_GT = 24,
+  SP_OP_GE = 25,
+  /* logical on truthiness -> 0/1 */
+  SP_OP_LAND = 26,
+  SP_OP_LOR = 27,
+  SP_OP_LXOR = 28,
+  SP_OP_LNOT = 29,
+  /* unary */
+  SP_OP_NEG = 30,
+  SP_OP_ABS = 31,
+  SP_OP_SQRT = 32,
+  SP_OP_SQUARE = 33,
+  SP_OP_EXP = 34,
+  SP_OP_LOG = 35,
+  SP_OP_RECIP = 36,
+  SP_OP_SIGN = 37,
+  SP_OP_FLOOR = 38,
+  SP_OP_CEIL = 39,
+  SP_OP_TANH = 40,
+  /* ternary: dst = a ? b : c */
+  SP_OP_WHERE = 45,
+  /* dtype normalisation inside a wider class */
+  SP_OP_TO_F32 = 50,  /* round to float32 */
+  SP_OP_TO_I32 = 51,  /* C cast to int32 (wraps / truncates toward zero) */
+  SP_OP_TO_I64 = 52,  /* truncate toward zero */
+  SP_OP_TO_BOOL = 53, /* x != 0 */
+  SP_OP_TO_U8 = 54
+};
+
+typedef struct sp_instr {
+  uint8_t op, dst, a, b, c, pad0, pad1, pad2;
+} sp_instr;
+
+typedef struct sp_program {
+  int32_t cls; /* SP_F32 | SP_F64 | SP_I64 : arithmetic class */
+  int32_t n_inputs;
+  int32_t n_instr;
+  int32_t result_reg; /* register holding the value to store / reduce */
+  int32_t ndim;       /* 1..SP_MAX_DIMS, collapsed row-major OUTPUT index space */
+  int32_t out_dtype;  /* sp_dtype of the output blob (map) */
+  int32_t linear;     /* 1: every input is dense with the output's layout (or a
+                         scalar): offset == linear index, vectorised path */
+  int32_t pad;
+  int64_t shape[SP_MAX_DIMS];                       /* output index space */
+  int64_t in_stride[SP_MAX_INPUTS][SP_MAX_DIMS];    /* in ELEMENTS; 0 = broadcast */
+  int32_t in_dtype[SP_MAX_INPUTS];
+  double consts[SP_MAX_CONSTS];
+  int64_t iconsts[SP_MAX_CONSTS]; /* same constants for the int64 class */
+  sp_instr instr[SP_MAX_INSTR];
+} sp_program;
+
+/* ---- reductions (spartan/expr/operator/reduce.py:21-70: the local reduce
+ *      `op.evaluate(ctx)` e.g. data.sum(axis), mathematics.py:126-127) ---- */
+enum sp_reduce_op {
+  SP_RED_SUM = 0,  /* np.add      */
+  SP_RED_PROD = 1, /* np.multiply */
+  SP_RED_MAX = 2,  /* np.maximum  */
+  SP_RED_MIN = 3,  /* np.minimum  */
+  SP_RED_AND = 4,  /* np.logical_and over truthiness */
+  SP_RED_OR = 5    /* np.logical_or  */
+};
+
+/* ---- combine (spartan/array/tile.pyx:200-297 `merge`) ---- */
+enum sp_reducer {
+  SP_REDUCER_NONE = 0, /* replace */
+  SP_REDUCER_ADD = 1,
+  SP_REDUCER_MUL = 2,
+  SP_REDUCER_MAX = 3,
+  SP_REDUCER_MIN = 4,
+  SP_REDUCER_AND = 5,
+  SP_REDUCER_OR = 6
+};
+
+/* tile mask states: tile.pyx:15-16 MASK_ALL_CLEAR / MASK_ALL_SET, or an
+ * explicit per-element byte mask in HBM */
+enum sp_mask_mode { SP_MASK_ALL_CLEAR = 0, SP_MASK_ALL_SET = 1, SP_MASK_ARRAY = 2 };
+
+/* ------------------------------------------------------------------------ */
+int sp_abi_version(void);
+const char* sp_last_error(void);
+
+/* Number of HIP devices / properties of one (CU count, bytes of HBM). */
+int sp_device_count(int* count);
+int sp_device_info(int device, int* cu_count, int64_t* hbm_bytes, char* name, size_t name_len);
+
+/* sp_map_fused: one coalesced launch evaluating `prog` for every element of
+ * the output tile.  Replaces `op.evaluate(op_ctx)` + `tile.from_data(result)`
+ * in tile_mapper (spartan/expr/operator/map.py:48-88).
+ *   d_inputs[j] : device pointer of input j (element type prog->in_dtype[j])
+ *   d_out       : dense row-major output, prod(shape) elements of out_dtype
+ */
+int sp_map_fused(const sp_program* prog, const void* const* d_inputs, void* d_out, void* stream);
+
+/* sp_reduce: fused map -> reduce over ONE axis of the program's index space
+ * viewed as [outer, axis_len, inner] (prod == prod(prog->shape)); axis=None is
+ * outer=1, inner=1.  Replaces `_reduce_mapper`'s local reduction
+ * (reduce.py:54) incl. the ReduceMapFusion prologue (optimize.py:190-227).
+ *   d_out : [outer, inner] elements of out_dtype.
+ *   d_ws  : scratch of at least sp_reduce_workspace_bytes(...) bytes.
+ */
+size_t sp_reduce_workspace_bytes(int32_t cls, int64_t outer, int64_t axis_len, int64_t inner);
+int sp_reduce(const sp_program* prog, const void* const* d_inputs, int32_t red_op, int64_t outer,
+              int64_t axis_len, int64_t inner, void* d_out, int32_t out_dtype, void* d_ws,
+              size_t ws_bytes, void* stream);
+
+/* sp_argreduce: single-pass argmax/argmin with first-occurrence tie-break,
+ * emitting int64 indices `index_offset + a` (a = position along the reduced
+ * axis) and the extreme values.  Replaces the reference's three-pass
+ * formulation (max-reduce, _arg_mapper, min-reduce:
+ * spartan/expr/sorting.py:67-123); results are bit-identical.
+ *   which: 0 = argmax, 1 = argmin.   nan_index: index reported when the
+ *   extreme is NaN (the reference's `a == b` never matches NaN, so every
+ *   candidate becomes the sentinel prod(array_shape), sorting.py:84).
+ *   d_out_val: [outer, inner] of the program class's dtype (may be NULL).
+ */
+size_t sp_argreduce_workspace_bytes(int32_t cls, int64_t outer, int64_t axis_len, int64_t inner);
+int sp_argreduce(const sp_program* prog, const void* const* d_inputs, int32_t which, int64_t outer,
+                 int64_t axis_len, int64_t inner, int64_t index_offset, int64_t nan_index,
+                 int64_t* d_out_idx, void* d_out_val, void* d_ws, size_t ws_bytes, void* stream);
+
+/* sp_update: Tile.merge(old, subslice, update, reducer), dense->dense branch
+ * (spartan/array/tile.pyx:250-283).  dst is a dense row-major tile of
+ * dst_shape; the update covers the box [ul, lr) of it; src is dense row-major
+ * of the box shape.  mask_mode says what the tile's mask was BEFORE the call;
+ * with SP_MASK_ARRAY d_mask (bytes, tile shape) is read and set to 1 over the
+ * box; otherwise d_mask, if non-NULL, is only written (set to 1 over the box).
+ * Cells whose mask was clear are replaced (`update.astype`), cells whose mask
+ * was set get reducer(old, update) (or replace when reducer == NONE).
+ */
+int sp_update(void* d_dst, int32_t dst_dtype, const int64_t* dst_shape, int32_t ndim,
+              const int64_t* ul, const int64_t* lr, const void* d_src, int32_t src_dtype,
+              int32_t reducer, int32_t mask_mode, uint8_t* d_mask, void* stream);
+
+/* sp_slice_copy: strided <=4-d box copy (element size 1/4/8 bytes) used by
+ * DistArrayImpl.fetch's stitch `tgt[dst_slice] = result`
+ * (spartan/array/distarray.py:355-365), Tile.get(subslice) (tile.pyx:64-113)
+ * and sparse.multiple_slice's dense branch (sparse.pyx:297-301).
+ * Strides are in ELEMENTS.
+ */
+int sp_slice_copy(void* d_dst, const int64_t* dst_stride, const void* d_src,
+                  const int64_t* src_stride, const int64_t* shape, int32_t ndim,
+                  int32_t elem_size, void* stream);
+
+/* sp_gemm_f32: C[M,N] (+)= A[M,K] . B[K,N], fp32 in / fp32 accumulate on the
+ * f32 MFMA (v_mfma_f32_32x32x2_f32).  Row-major with leading dimensions in
+ * elements.  Replaces `tiles[0].dot(tiles[1])` in dot_map2_mapper /
+ * dot_outer_mapper / dot_map2_np_mapper (spartan/expr/dot.py:172-238).
+ * accumulate != 0 computes C += A.B (the np.add reducer of the dot target,
+ * dot.py:289-294, fused into the epilogue).
+ */
+int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C,
+                int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t accumulate, void* stream);
+
+/* Matrix . vector products (dot.py:180-183, dot_map2_np_mapper with a 1-D rhs;
+ * the lreg step X.w and X^T.r) are HBM-bound and have no GEMM entry point:
+ * the host lowers them to sp_reduce with the fused program MUL(in0, in1) and
+ * a broadcast stride on the vector operand (row kernels for A.x, column
+ * kernels for A^T.x). */
+
+/* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
+ * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
+int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);
+
+/* HIP-event timing of work already enqueued on `stream`; used by bench.py so
+ * kernel durations are measured on the stream the kernels were launched on. */
+int sp_event_create(void** ev);
+int sp_event_destroy(void* ev);
+int sp_event_record(void* ev, void* stream);
+int sp_event_synchronize(void* ev);
+int sp_event_elapsed_ms(void* start, void* stop, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARTAN_HIP_H_ */

@@ -1,0 +1,143 @@
+"""ctypes binding of libspartan_hip.so (see include/spartan_hip.h).
+
+This is the thin host side of the drop-in boundary: plain pointers and sizes
+only.  Loading FAILS LOUDLY when the library is missing -- there is no CPU
+fallback in the product path (the NumPy restatement under oracle/ is test
+infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libspartan_hip.so')
+
+# ---- enums (mirror include/spartan_hip.h) ---------------------------------
+SP_F32, SP_F64, SP_I32, SP_I64, SP_BOOL, SP_U8 = range(6)
+SP_MAX_INPUTS, SP_MAX_INSTR, SP_MAX_CONSTS, SP_MAX_DIMS, SP_NREG = 8, 64, 16, 4, 8
+
+OP = dict(
+    NOP=0, CONST=1, IOTA=2, MOV=3,
+    ADD=10, SUB=11, MUL=12, DIV=13, FLOORDIV=14, MOD=15, FMOD=16, POW=17, MAX=18, MIN=19,
+    EQ=20, NE=21, LT=22, LE=23, GT=24, GE=25, LAND=26, LOR=27, LXOR=28, LNOT=29,
+    NEG=30, ABS=31, SQRT=32, SQUARE=33, EXP=34, LOG=35, RECIP=36, SIGN=37, FLOOR=38, CEIL=39,
+    TANH=40, WHERE=45, TO_F32=50, TO_I32=51, TO_I64=52, TO_BOOL=53, TO_U8=54)
+
+RED = dict(SUM=0, PROD=1, MAX=2, MIN=3, AND=4, OR=5)
+REDUCER = dict(NONE=0, ADD=1, MUL=2, MAX=3, MIN=4, AND=5, OR=6)
+MASK_ALL_CLEAR, MASK_ALL_SET, MASK_ARRAY = 0, 1, 2
+
+_NP2SP = {
+    np.dtype(np.float32): SP_F32, np.dtype(np.float64): SP_F64, np.dtype(np.int32): SP_I32,
+    np.dtype(np.int64): SP_I64, np.dtype(np.bool_): SP_BOOL, np.dtype(np.uint8): SP_U8,
+}
+_SP2NP = {v: k for k, v in _NP2SP.items()}
+
+
+def sp_dtype(dt):
+  dt = np.dtype(dt)
+  if dt not in _NP2SP:
+    raise TypeError('dtype %s is not supported by the HIP tile backend '
+                    '(supported: float32 float64 int32 int64 bool uint8)' % dt)
+  return _NP2SP[dt]
+
+
+def np_dtype(code):
+  return _SP2NP[code]
+
+
+class sp_instr(C.Structure):
+  _fields_ = [('op', C.c_uint8), ('dst', C.c_uint8), ('a', C.c_uint8), ('b', C.c_uint8),
+              ('c', C.c_uint8), ('pad0', C.c_uint8), ('pad1', C.c_uint8), ('pad2', C.c_uint8)]
+
+
+class sp_program(C.Structure):
+  _fields_ = [
+      ('cls', C.c_int32), ('n_inputs', C.c_int32), ('n_instr', C.c_int32), ('result_reg', C.c_int32),
+      ('ndim', C.c_int32), ('out_dtype', C.c_int32), ('linear', C.c_int32), ('pad', C.c_int32),
+      ('shape', C.c_int64 * SP_MAX_DIMS),
+      ('in_stride', (C.c_int64 * SP_MAX_DIMS) * SP_MAX_INPUTS),
+      ('in_dtype', C.c_int32 * SP_MAX_INPUTS),
+      ('consts', C.c_double * SP_MAX_CONSTS),
+      ('iconsts', C.c_int64 * SP_MAX_CONSTS),
+      ('instr', sp_instr * SP_MAX_INSTR),
+  ]
+
+
+class HipError(RuntimeError):
+  """A libspartan_hip.so call failed (text from sp_last_error())."""
+
+
+class HipLibraryMissing(ImportError):
+  pass
+
+
+_lib = None
+
+
+def _declare(lib):
+  vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+  pp = C.POINTER(C.c_void_p)
+  p64 = C.POINTER(C.c_int64)
+  lib.sp_abi_version.restype = C.c_int
+  lib.sp_last_error.restype = C.c_char_p
+  lib.sp_device_count.argtypes = [C.POINTER(C.c_int)]
+  lib.sp_device_info.argtypes = [C.c_int, C.POINTER(C.c_int), p64, C.c_char_p, sz]
+  lib.sp_map_fused.argtypes = [C.POINTER(sp_program), pp, vp, vp]
+  lib.sp_reduce_workspace_bytes.argtypes = [i32, i64, i64, i64]
+  lib.sp_reduce_workspace_bytes.restype = sz
+  lib.sp_reduce.argtypes = [C.POINTER(sp_program), pp, i32, i64, i64, i64, vp, i32, vp, sz, vp]
+  lib.sp_argreduce_workspace_bytes.argtypes = [i32, i64, i64, i64]
+  lib.sp_argreduce_workspace_bytes.restype = sz
+  lib.sp_argreduce.argtypes = [C.POINTER(sp_program), pp, i32, i64, i64, i64, i64, i64, vp, vp, vp, sz, vp]
+  lib.sp_update.argtypes = [vp, i32, p64, i32, p64, p64, vp, i32, i32, i32, vp, vp]
+  lib.sp_slice_copy.argtypes = [vp, p64, vp, p64, p64, i32, i32, vp]
+  lib.sp_gemm_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]
+  lib.sp_stream_copy.argtypes = [vp, vp, sz, vp]
+  lib.sp_event_create.argtypes = [pp]
+  lib.sp_event_destroy.argtypes = [vp]
+  lib.sp_event_record.argtypes = [vp, vp]
+  lib.sp_event_synchronize.argtypes = [vp]
+  lib.sp_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+  for name in EXPORTS:
+    fn = getattr(lib, name)
+    if fn.restype is C.c_int and name not in ('sp_abi_version',):
+      pass
+  return lib
+
+
+# every symbol include/spartan_hip.h declares
+EXPORTS = [
+    'sp_abi_version', 'sp_last_error', 'sp_device_count', 'sp_device_info', 'sp_map_fused',
+    'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
+    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_stream_copy', 'sp_event_create',
+    'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',
+]
+
+
+def lib():
+  """Load (once) and return the C-ABI library; raises if it has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise HipLibraryMissing(
+          '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+          '(or `make -C spartan_amd/csrc`). The HIP tile backend has no CPU fallback.' % LIB_PATH)
+    _lib = _declare(C.CDLL(LIB_PATH))
+    if _lib.sp_abi_version() != 1:
+      raise HipError('libspartan_hip.so ABI version mismatch')
+  return _lib
+
+
+def check(rc):
+  if rc != 0:
+    raise HipError(lib().sp_last_error().decode('utf-8', 'replace'))
+
+
+def i64_array(vals):
+  return (C.c_int64 * max(1, len(vals)))(*[int(v) for v in vals])
+
+
+def ptr_array(ptrs):
+  return (C.c_void_p * max(1, len(ptrs)))(*[C.c_void_p(int(p)) for p in ptrs])

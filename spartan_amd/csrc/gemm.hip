@@ -1,0 +1,299 @@
+// fp32 GEMM on the CDNA4 f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32
+// (bitwise an fmaf chain in k order), 157.3 TFLOP/s peak on MI355X.
+//
+// Replaces `tiles[0].dot(tiles[1])` of the reference's dot mappers
+// (spartan/expr/dot.py:195-217 dot_map2_mapper, :222-238 dot_outer_mapper,
+// :172-187 dot_map2_np_mapper); `accumulate` fuses the np.add reducer of the
+// dot target (dot.py:289-294 + tile.pyx:263-266) into the epilogue.
+//
+// Structure (per workgroup of NW waves, one 32x32 MFMA tile grid per wave):
+//   - BM x BN output macro-tile, K walked in steps of BK=16;
+//   - global -> VGPR (16-B loads) -> LDS, LDS double-buffered: the loads of
+//     k-tile t+1 are issued before the MFMAs of k-tile t and written to the
+//     other LDS buffer after them: one workgroup barrier per k-tile;
+//   - A is kept [m][k] in LDS with a 16-B row pad so the per-lane 16-B fragment
+//     reads (ds_read_b128) are bank-conflict free; the MFMA k-slots are
+//     permuted (lane half h takes k = 4h..4h+3 of each 8-wide chunk for both A
+//     and B), which is legal because the contraction index order only has to
+//     agree between A and B;
+//   - B is kept [k][n]; fragments are 4 x ds_read_b32 (lanes along n);
+//   - XCD-aware block -> tile mapping: each XCD walks a contiguous range of a
+//     GROUP_M-grouped tile order so that the 64 workgroups resident on one XCD
+//     share A and B panels in that XCD's private L2.
+#include "sp_common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SP_GEMM_GROUP_M 8
+
+template <int BM, int BN, int BK, int WM, int WN>
+struct GemmCfg {
+  static constexpr int NW = WM * WN;
+  static constexpr int THREADS = NW * 64;
+  static constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+  static constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+  static constexpr int LDA_S = BK + 4;                // padded LDS row (floats)
+  static constexpr int LDB_S = BN;
+  static constexpr int A_FLOATS = BM * LDA_S;
+  static constexpr int B_FLOATS = BK * LDB_S;
+  static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+  static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+  static constexpr int A_VEC = (BM * BK / 4) / THREADS;  // float4 per thread per k-tile
+  static constexpr int B_VEC = (BK * BN / 4) / THREADS;
+  // 2 workgroups per CU when the wave tile needs 128 accumulator registers:
+  // asks the allocator for <= 256 VGPR+AGPR so barrier stalls of one workgroup
+  // are covered by the other's MFMAs.
+  static constexpr int MIN_WAVES = (NW == 4) ? 2 : 1;
+  static_assert(BK % 8 == 0, "BK must be a multiple of 8");
+  static_assert((BM * BK / 4) % THREADS == 0 && (BK * BN / 4) % THREADS == 0, "tile/threads mismatch");
+};
+
+// block id -> (tile_m, tile_n), XCD-aware + grouped
+__device__ __forceinline__ void sp_gemm_tile_of_block(int bid, int nblk, int tiles_m, int tiles_n,
+                                                      int& tm, int& tn) {
+  // bijective XCD remap (guide T1): blocks bid, bid+8, ... run on one XCD
+  const int xcd = bid & 7, local = bid >> 3;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  const int per_group = SP_GEMM_GROUP_M * tiles_n;
+  const int group = t / per_group;
+  const int first_m = group * SP_GEMM_GROUP_M;
+  const int gsize = (tiles_m - first_m) < SP_GEMM_GROUP_M ? (tiles_m - first_m) : SP_GEMM_GROUP_M;
+  const int in_group = t - group * per_group;
+  tm = first_m + (in_group % gsize);
+  tn = in_group / gsize;
+}
+
+// FAST: K % BK == 0, N % 4 == 0, lda/ldb % 4 == 0, 16-B aligned bases.
+// Rows beyond M / columns beyond N are clamped on load and masked on store.
+template <typename Cfg, int BM, int BN, int BK, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(const float* __restrict__ A, int64_t lda,
+                                                               const float* __restrict__ B, int64_t ldb,
+                                                               float* __restrict__ C, int64_t ldc, int M,
+                                                               int N, int K, int accumulate, int tiles_m,
+                                                               int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int THREADS = Cfg::THREADS;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN;
+  constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
+  constexpr int A_VEC = Cfg::A_VEC, B_VEC = Cfg::B_VEC;
+  constexpr int KQ = BK / 4;  // float4 per A row
+  constexpr int NQ = BN / 4;  // float4 per B row
+
+  int tm, tn;
+  sp_gemm_tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // ---- global load assignments: block-relative 32-bit offsets, scalar bases
+  const float* __restrict__ Ablk = A + (int64_t)m0 * lda;
+  const float* __restrict__ Bblk = B + n0;
+  int a_off[A_VEC], a_lds[A_VEC];
+#pragma unroll
+  for (int j = 0; j < A_VEC; ++j) {
+    const int e = tid + j * THREADS;
+    int row = e / KQ;
+    const int kq = e % KQ;
+    a_lds[j] = row * LDA_S + kq * 4;
+    if (m0 + row > M - 1) row = M - 1 - m0;  // clamp (masked on store)
+    a_off[j] = row * (int)lda + kq * 4;
+  }
+  int b_off[B_VEC], b_lds[B_VEC];
+#pragma unroll
+  for (int j = 0; j < B_VEC; ++j) {
+    const int e = tid + j * THREADS;
+    const int row = e / NQ;
+    const int nq = e % NQ;
+    b_lds[j] = row * LDB_S + nq * 4;
+    int gc = nq * 4;
+    if (FAST && n0 + gc > N - 4) gc = N - 4 - n0;
+    b_off[j] = row * (int)ldb + gc;
+  }
+
+  f32x4 ra[A_VEC], rb[B_VEC];
+
+#define SP_GEMM_LOAD_TILE(kt)                                                         \
+  do {                                                                                \
+    const int k0_ = (kt) * BK;                                                        \
+    const float* Ak_ = Ablk + k0_;                                                    \
+    const float* Bk_ = Bblk + (int64_t)k0_ * ldb;                                     \
+    _Pragma("unroll") for (int j = 0; j < A_VEC; ++j) {                               \
+      if constexpr (FAST) {                                                           \
+        ra[j] = *(const f32x4*)(Ak_ + a_off[j]);                                     \
+      } else {                                                                        \
+        const int e_ = tid + j * THREADS;                                             \
+        const bool rok = (m0 + e_ / KQ) < M;                                          \
+        const int kk = k0_ + (e_ % KQ) * 4;                                           \
+        const float* p = Ak_ + a_off[j];                                              \
+        ra[j].x = (rok && kk + 0 < K) ? p[0] : 0.f;                                   \
+        ra[j].y = (rok && kk + 1 < K) ? p[1] : 0.f;                                   \
+        ra[j].z = (rok && kk + 2 < K) ? p[2] : 0.f;                                   \
+        ra[j].w = (rok && kk + 3 < K) ? p[3] : 0.f;                                   \
+      }                                                                               \
+    }                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < B_VEC; ++j) {                               \
+      if constexpr (FAST) {                                                           \
+        rb[j] = *(const f32x4*)(Bk_ + b_off[j]);                                     \
+      } else {                                                                        \
+        const int e_ = tid + j * THREADS;                                             \
+        const bool kok = (k0_ + e_ / NQ) < K;                                         \
+        const int cc = n0 + (e_ % NQ) * 4;                                            \
+        const float* p = Bk_ + b_off[j];                                              \
+        rb[j].x = (kok && cc + 0 < N) ? p[0] : 0.f;                                   \
+        rb[j].y = (kok && cc + 1 < N) ? p[1] : 0.f;                                   \
+        rb[j].z = (kok && cc + 2 < N) ? p[2] : 0.f;                                   \
+        rb[j].w = (kok && cc + 3 < N) ? p[3] : 0.f;                                   \
+      }                                                                               \
+    }                                                                                 \
+  } while (0)
+
+#define SP_GEMM_STORE_TILE(buf)                                                       \
+  do {                                                                                \
+    float* sA_ = smem + (buf) * Cfg::STAGE_FLOATS;                                    \
+    float* sB_ = sA_ + Cfg::A_FLOATS;                                                 \
+    _Pragma("unroll") for (int j = 0; j < A_VEC; ++j) *(f32x4*)(sA_ + a_lds[j]) = ra[j]; \
+    _Pragma("unroll") for (int j = 0; j < B_VEC; ++j) *(f32x4*)(sB_ + b_lds[j]) = rb[j]; \
+  } while (0)
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = (K + BK - 1) / BK;
+  SP_GEMM_LOAD_TILE(0);
+  SP_GEMM_STORE_TILE(0);
+  __syncthreads();
+
+  const int a_frag_off = (wm * Cfg::WTM + l31) * LDA_S + 4 * lh;
+  const int b_frag_off = (4 * lh) * LDB_S + wn * Cfg::WTN + l31;
+
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) SP_GEMM_LOAD_TILE(t + 1);
+    const float* sA = smem + (t & 1) * Cfg::STAGE_FLOATS;
+    const float* sB = sA + Cfg::A_FLOATS;
+#pragma unroll
+    for (int c = 0; c < BK / 8; ++c) {
+      f32x4 af[TM];
+      float bf[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(sA + a_frag_off + i * 32 * LDA_S + c * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag_off + (c * 8 + s) * LDB_S + j * 32];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float av = af[i][s];
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[j][s], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < nt) SP_GEMM_STORE_TILE((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * Cfg::WTN + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M && col < N) {
+          float* p = C + (int64_t)row * ldc + col;
+          float v = acc[i][j][r];
+          if (accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static int sp_gemm_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                          int64_t M, int64_t N, int64_t K, int acc, bool fast, hipStream_t st) {
+  using Cfg = GemmCfg<BM, BN, BK, WM, WN>;
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int64_t nblk = tiles_m * tiles_n;
+  if (nblk > 2147483647LL) SP_FAIL("sp_gemm_f32: too many tiles");
+  static bool attr_set_fast = false, attr_set_gen = false;
+  if (fast) {
+    auto k = sp_gemm_kernel<Cfg, BM, BN, BK, WM, WN, true>;
+    if (!attr_set_fast) {
+      SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+      attr_set_fast = true;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, A, lda, B, ldb, C, ldc,
+                       (int)M, (int)N, (int)K, acc, (int)tiles_m, (int)tiles_n);
+  } else {
+    auto k = sp_gemm_kernel<Cfg, BM, BN, BK, WM, WN, false>;
+    if (!attr_set_gen) {
+      SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+      attr_set_gen = true;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, A, lda, B, ldb, C, ldc,
+                       (int)M, (int)N, (int)K, acc, (int)tiles_m, (int)tiles_n);
+  }
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+// Tuning knob (not part of the ABI contract): SP_GEMM_VARIANT=0..3 picks the
+// macro-tile; unset = the default chosen from rocprof measurements
+// (profiles/).
+static int sp_gemm_variant() {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("SP_GEMM_VARIANT");
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
+
+extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C,
+                           int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t accumulate, void* stream) {
+  if (M < 0 || N < 0 || K < 0) SP_FAIL("sp_gemm_f32: negative dimension");
+  if (M == 0 || N == 0) return 0;
+  if (!d_A || !d_B || !d_C) SP_FAIL("sp_gemm_f32: NULL pointer");
+  if (M > 2147483647LL || N > 2147483647LL || K > 2147483647LL) SP_FAIL("sp_gemm_f32: dimension too large");
+  if (lda < K || ldb < N || ldc < N) SP_FAIL("sp_gemm_f32: leading dimension too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 0) {
+    if (!accumulate) {
+      // empty contraction: C = 0 (numpy: zeros)
+      SP_HIP(hipMemset2DAsync(d_C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, st));
+    }
+    return 0;
+  }
+  const bool fast = (K % 16 == 0) && (N % 4 == 0) && (N >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                    ((((uintptr_t)d_A) | ((uintptr_t)d_B)) & 15) == 0;
+  int v = sp_gemm_variant();
+  if (v < 0) {
+    // default: big macro-tile for big problems, smaller tile to fill the chip otherwise
+    const int64_t big_tiles = ((M + 255) / 256) * ((N + 127) / 128);
+    v = big_tiles >= 256 ? 0 : 1;
+  }
+  switch (v) {
+    case 0: return sp_gemm_launch<256, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+    case 1: return sp_gemm_launch<128, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+    case 2: return sp_gemm_launch<256, 256, 16, 2, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+    case 3: return sp_gemm_launch<128, 256, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+    default: SP_FAIL("sp_gemm_f32: unknown SP_GEMM_VARIANT=%d", v);
+  }
+}

@@ -1,0 +1,470 @@
+// Fused map -> reduce over one axis of a tile, and single-pass arg-reduce.
+//
+// Replaces the per-tile local reduction of _reduce_mapper
+// (reference spartan/expr/operator/reduce.py:21-70, e.g. data.sum(axis) in
+// spartan/expr/mathematics.py:126-127, data.max/min in statistics.py:26-61,
+// np.all/np.any in logic.py:25-46) including the ReduceMapFusion prologue
+// (optimize.py:190-227), and the three-pass argmax/argmin of
+// spartan/expr/sorting.py:67-123.
+//
+// HBM roofline kernels: every input element is read exactly once
+// (algorithmic bytes = sizeof(in) per element).  The index space of
+// the fused program is viewed as [outer, axis_len, inner]:
+//   inner == 1 : "row" kernels  - lanes run along the reduced (contiguous) axis,
+//                64-lane DPP/shuffle reduction, then an LDS stage across the 4
+//                waves of the workgroup, then (if the axis was split over
+//                several workgroups) a tiny second launch over the partials.
+//   inner  > 1 : "column" kernels - lanes run along `inner` (coalesced 16 B per
+//                lane), the 4 waves of a workgroup walk interleaved positions of
+//                the reduced axis and are combined through LDS.
+// Results are deterministic (no atomics; fixed combine order).
+#pragma once
+#include <float.h>
+#include <math.h>
+
+#include "sp_interp.hpp"
+
+int sp_validate_program(const sp_program* p);
+
+// ------------------------------------------------------------------ policies
+template <typename T>
+__device__ __forceinline__ T sp_red_identity(int op) {
+  switch (op) {
+    case SP_RED_SUM: return (T)0;
+    case SP_RED_PROD: return (T)1;
+    case SP_RED_MAX:
+      if constexpr (std::is_integral<T>::value) return (T)INT64_MIN;
+      else return (T)(-INFINITY);
+    case SP_RED_MIN:
+      if constexpr (std::is_integral<T>::value) return (T)INT64_MAX;
+      else return (T)(INFINITY);
+    case SP_RED_AND: return (T)1;
+    default: return (T)0;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T sp_red_combine(int op, T a, T b) {
+  switch (op) {
+    case SP_RED_SUM: return a + b;
+    case SP_RED_PROD: return a * b;
+    case SP_RED_MAX: return sp_nanmax<T>(a, b);
+    case SP_RED_MIN: return sp_nanmin<T>(a, b);
+    case SP_RED_AND: return (T)((a != (T)0) && (b != (T)0));
+    default: return (T)((a != (T)0) || (b != (T)0));
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T sp_shfl_down(T v, int delta) {
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int2 i; } u, w;
+    u.t = v;
+    w.i.x = __shfl_down(u.i.x, delta, 64);
+    w.i.y = __shfl_down(u.i.y, delta, 64);
+    return w.t;
+  } else {
+    return __shfl_down(v, delta, 64);
+  }
+}
+
+// Plain reduction state.
+template <typename T>
+struct PlainAcc {
+  T v;
+  __device__ __forceinline__ void init(int op) { v = sp_red_identity<T>(op); }
+  __device__ __forceinline__ void add(int op, T x, int64_t) { v = sp_red_combine<T>(op, v, x); }
+  __device__ __forceinline__ void merge(int op, const PlainAcc& o) { v = sp_red_combine<T>(op, v, o.v); }
+  __device__ __forceinline__ PlainAcc shfl(int d) const {
+    PlainAcc r;
+    r.v = sp_shfl_down<T>(v, d);
+    return r;
+  }
+};
+
+// (value, first index) state; op: 0 = argmax, 1 = argmin.
+template <typename T>
+struct ArgAcc {
+  T v;
+  int64_t i;
+  __device__ __forceinline__ void init(int) {
+    v = (T)0;
+    i = -1;  // empty
+  }
+  static __device__ __forceinline__ bool better(int op, T bv, int64_t bi, T av, int64_t ai) {
+    // is (bv,bi) strictly preferable to (av,ai)?
+    if (ai < 0) return bi >= 0;
+    if (bi < 0) return false;
+    const bool an = sp_math<T>::isnan_(av), bn = sp_math<T>::isnan_(bv);
+    if (an || bn) {
+      if (an && bn) return bi < ai;
+      return bn;  // NaN dominates (np.max / np.min propagate NaN)
+    }
+    if (op == 0 ? (bv > av) : (bv < av)) return true;
+    return bv == av && bi < ai;
+  }
+  __device__ __forceinline__ void add(int op, T x, int64_t a) {
+    if (better(op, x, a, v, i)) { v = x; i = a; }
+  }
+  __device__ __forceinline__ void merge(int op, const ArgAcc& o) {
+    if (better(op, o.v, o.i, v, i)) { v = o.v; i = o.i; }
+  }
+  __device__ __forceinline__ ArgAcc shfl(int d) const {
+    ArgAcc r;
+    r.v = sp_shfl_down<T>(v, d);
+    r.i = sp_shfl_down<int64_t>(i, d);
+    return r;
+  }
+};
+
+template <typename Acc>
+__device__ __forceinline__ Acc sp_wave_reduce(int op, Acc a) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    Acc o = a.shfl(d);
+    a.merge(op, o);
+  }
+  return a;
+}
+
+// where a finished accumulator goes
+struct RedOut {
+  void* out;         // final output (converted to out_dtype), used when nsplit == 1
+  int32_t out_dtype;
+  void* part_val;    // [..] of T, used when nsplit > 1
+  int64_t* part_idx; // arg only
+  int64_t* out_idx;  // arg only, final
+  int64_t index_offset, nan_index;
+};
+
+template <typename T>
+__device__ __forceinline__ void sp_emit(const RedOut& ro, bool final_, int64_t slot, const PlainAcc<T>& a) {
+  if (final_) {
+    T v = a.v;
+    sp_store_vec<T, 1>(ro.out, ro.out_dtype, slot, &v);
+  } else {
+    ((T*)ro.part_val)[slot] = a.v;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void sp_emit(const RedOut& ro, bool final_, int64_t slot, const ArgAcc<T>& a) {
+  if (final_) {
+    int64_t idx = a.i < 0 ? ro.nan_index : a.i + ro.index_offset;
+    if (sp_math<T>::isnan_(a.v)) idx = ro.nan_index;
+    ro.out_idx[slot] = idx;
+    if (ro.out) ((T*)ro.out)[slot] = a.v;
+  } else {
+    ((T*)ro.part_val)[slot] = a.v;
+    ro.part_idx[slot] = a.i;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void sp_load_partial(const RedOut& ro, int64_t slot, PlainAcc<T>& a) {
+  a.v = ((const T*)ro.part_val)[slot];
+}
+template <typename T>
+__device__ __forceinline__ void sp_load_partial(const RedOut& ro, int64_t slot, ArgAcc<T>& a) {
+  a.v = ((const T*)ro.part_val)[slot];
+  a.i = ro.part_idx[slot];
+}
+
+// --------------------------------------------------------------- row kernels
+// [O, A] with the reduced axis contiguous.  grid = (nsplit, rows).
+template <typename T, int V, bool LINEAR, template <typename> class AccT>
+__global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_program p, const sp_inputs in,
+                                                                 int op, int64_t O, int64_t A,
+                                                                 int64_t chunk, int nsplit, RedOut ro) {
+  using Acc = AccT<T>;
+  __shared__ Acc sm[SP_BLOCK / 64];
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t o = blockIdx.y; o < O; o += gridDim.y) {
+    const int64_t a0 = (int64_t)s * chunk;
+    int64_t a1 = a0 + chunk;
+    if (a1 > A) a1 = A;
+    Acc acc;
+    acc.init(op);
+    for (int64_t a = a0 + (int64_t)threadIdx.x * V; a < a1; a += (int64_t)SP_BLOCK * V) {
+      T x[V];
+      sp_eval<T, V, LINEAR>(p, in, o * A + a, x);
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc.add(op, x[v], a + v);
+    }
+    acc = sp_wave_reduce(op, acc);
+    if (lane == 0) sm[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      Acc t = sm[0];
+#pragma unroll
+      for (int k = 1; k < SP_BLOCK / 64; ++k) t.merge(op, sm[k]);
+      sp_emit<T>(ro, nsplit == 1, nsplit == 1 ? o : o * nsplit + s, t);
+    }
+    __syncthreads();
+  }
+}
+
+// many short rows: one wave per row
+template <typename T, int V, bool LINEAR, template <typename> class AccT>
+__global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_program p,
+                                                                      const sp_inputs in, int op,
+                                                                      int64_t O, int64_t A, RedOut ro) {
+  using Acc = AccT<T>;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wstride = (int64_t)gridDim.x * (SP_BLOCK / 64);
+  for (int64_t o = (int64_t)blockIdx.x * (SP_BLOCK / 64) + w; o < O; o += wstride) {
+    Acc acc;
+    acc.init(op);
+    for (int64_t a = (int64_t)lane * V; a < A; a += 64 * V) {
+      T x[V];
+      sp_eval<T, V, LINEAR>(p, in, o * A + a, x);
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc.add(op, x[v], a + v);
+    }
+    acc = sp_wave_reduce(op, acc);
+    if (lane == 0) sp_emit<T>(ro, true, o, acc);
+  }
+}
+
+// second stage over [O, nsplit] partials: one wave per row
+template <typename T, template <typename> class AccT>
+__global__ __launch_bounds__(SP_BLOCK) void sp_finish_rows_kernel(int op, int64_t O, int nsplit, RedOut ro) {
+  using Acc = AccT<T>;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wstride = (int64_t)gridDim.x * (SP_BLOCK / 64);
+  for (int64_t o = (int64_t)blockIdx.x * (SP_BLOCK / 64) + w; o < O; o += wstride) {
+    Acc acc;
+    acc.init(op);
+    for (int k = lane; k < nsplit; k += 64) {
+      Acc t;
+      sp_load_partial<T>(ro, o * nsplit + k, t);
+      acc.merge(op, t);
+    }
+    acc = sp_wave_reduce(op, acc);
+    if (lane == 0) sp_emit<T>(ro, true, o, acc);
+  }
+}
+
+// ------------------------------------------------------------ column kernels
+// [O, A, I], lanes along I.  grid = (ceil(I / (64 V)), nsplit, O').
+template <typename T, int V, bool LINEAR, template <typename> class AccT>
+__global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_program p, const sp_inputs in,
+                                                                 int op, int64_t O, int64_t A, int64_t I,
+                                                                 int64_t chunk, int nsplit, RedOut ro) {
+  using Acc = AccT<T>;
+  constexpr int NW = SP_BLOCK / 64;
+  __shared__ Acc sm[NW - 1][64 * V];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int s = blockIdx.y;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * V;
+  const bool active = c < I;
+  for (int64_t o = blockIdx.z; o < O; o += gridDim.z) {
+    const int64_t a0 = (int64_t)s * chunk;
+    int64_t a1 = a0 + chunk;
+    if (a1 > A) a1 = A;
+    Acc acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v].init(op);
+    if (active) {
+      for (int64_t a = a0 + w; a < a1; a += NW) {
+        T x[V];
+        sp_eval<T, V, LINEAR>(p, in, (o * A + a) * I + c, x);
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v].add(op, x[v], a);
+      }
+    }
+    if (w > 0) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) sm[w - 1][lane * V + v] = acc[v];
+    }
+    __syncthreads();
+    if (w == 0 && active) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+#pragma unroll
+        for (int k = 0; k < NW - 1; ++k) acc[v].merge(op, sm[k][lane * V + v]);
+        const int64_t slot = nsplit == 1 ? o * I + c + v : ((int64_t)s * O + o) * I + c + v;
+        sp_emit<T>(ro, nsplit == 1, slot, acc[v]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// second stage over [nsplit, E] partials (E = O*I): one thread per output
+template <typename T, template <typename> class AccT>
+__global__ __launch_bounds__(SP_BLOCK) void sp_finish_cols_kernel(int op, int64_t E, int nsplit, RedOut ro) {
+  using Acc = AccT<T>;
+  const int64_t stride = (int64_t)gridDim.x * SP_BLOCK;
+  for (int64_t e = (int64_t)blockIdx.x * SP_BLOCK + threadIdx.x; e < E; e += stride) {
+    Acc acc;
+    acc.init(op);
+    for (int k = 0; k < nsplit; ++k) {
+      Acc t;
+      sp_load_partial<T>(ro, (int64_t)k * E + e, t);
+      acc.merge(op, t);
+    }
+    sp_emit<T>(ro, true, e, acc);
+  }
+}
+
+// ------------------------------------------------------------------- planner
+struct RedPlan {
+  int kind;  // 0 rows-split, 1 rows-wave, 2 cols
+  int nsplit;
+  int64_t chunk;
+  int64_t partial_slots;  // number of (val[,idx]) partial slots needed
+};
+
+static const int64_t kTargetBlocks = (int64_t)SP_CUS * SP_BLOCKS_PER_CU;
+
+static RedPlan sp_plan(int V, int64_t O, int64_t A, int64_t I) {
+  RedPlan pl;
+  memset(&pl, 0, sizeof(pl));
+  if (I == 1) {
+    if (A <= 64 * V * 16 && O >= 1024) {
+      pl.kind = 1;
+      pl.nsplit = 1;
+      pl.chunk = A;
+      return pl;
+    }
+    pl.kind = 0;
+    const int64_t unit = (int64_t)SP_BLOCK * V;  // one pass of the workgroup
+    const int64_t min_chunk = unit * 8;
+    int64_t want = (kTargetBlocks + O - 1) / O;       // splits needed to fill the chip
+    int64_t maxs = (A + min_chunk - 1) / min_chunk;   // splits the row can afford
+    int64_t ns = want < maxs ? want : maxs;
+    if (ns < 1) ns = 1;
+    if (ns > 4096) ns = 4096;
+    int64_t chunk = (A + ns - 1) / ns;
+    chunk = (chunk + unit - 1) / unit * unit;
+    ns = (A + chunk - 1) / chunk;
+    if (ns < 1) ns = 1;
+    pl.nsplit = (int)ns;
+    pl.chunk = chunk;
+    pl.partial_slots = ns > 1 ? O * ns : 0;
+    return pl;
+  }
+  pl.kind = 2;
+  const int64_t bx = (I + 64 * V - 1) / (64 * V);
+  const int64_t min_chunk = (SP_BLOCK / 64) * 16;
+  int64_t want = (kTargetBlocks + bx * O - 1) / (bx * O);
+  int64_t maxs = (A + min_chunk - 1) / min_chunk;
+  int64_t ns = want < maxs ? want : maxs;
+  if (ns < 1) ns = 1;
+  if (ns > 1024) ns = 1024;
+  int64_t chunk = (A + ns - 1) / ns;
+  chunk = (chunk + 3) / 4 * 4;
+  ns = (A + chunk - 1) / chunk;
+  if (ns < 1) ns = 1;
+  pl.nsplit = (int)ns;
+  pl.chunk = chunk;
+  pl.partial_slots = ns > 1 ? ns * O * I : 0;
+  return pl;
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// V-wide evaluation needs every V-group of the [O,A,I] space to be contiguous
+// and 16-B aligned in each dense operand.
+template <int V>
+static bool sp_reduce_can_vec(const sp_program* p, const void* const* in, int64_t A, int64_t I) {
+  if (V == 1) return true;
+  const int nd = p->ndim;
+  if (p->shape[nd - 1] % V != 0) return false;
+  if ((I == 1 ? A : I) % V != 0) return false;
+  for (int j = 0; j < p->n_inputs; ++j) {
+    const int64_t inner = p->in_stride[j][nd - 1];
+    if (inner == 1 || (p->linear && inner != 0)) {
+      if (!aligned16(in[j])) return false;
+      if (!p->linear)
+        for (int d = 0; d < nd - 1; ++d)
+          if (p->in_stride[j][d] % V != 0) return false;
+    }
+  }
+  return true;
+}
+
+static inline int cap_dim(int64_t x, int64_t cap) { return (int)(x < cap ? (x < 1 ? 1 : x) : cap); }
+
+template <typename T, template <typename> class AccT>
+static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void* const* inp, int op,
+                            int64_t O, int64_t A, int64_t I, RedOut ro, void* ws, size_t ws_bytes,
+                            hipStream_t st) {
+  constexpr int VV = sp_cls<T>::V;
+  constexpr bool kArg = sizeof(AccT<T>) > sizeof(T);
+  const bool vec = sp_reduce_can_vec<VV>(p, inp, A, I);
+  const int V = vec ? VV : 1;
+  const RedPlan pl = sp_plan(V, O, A, I);
+  if (pl.partial_slots) {
+    const size_t need = (size_t)pl.partial_slots * (sizeof(T) + (kArg ? sizeof(int64_t) : 0));
+    if (!ws || ws_bytes < need) SP_FAIL("sp_reduce: workspace too small (%zu < %zu)", ws_bytes, need);
+    ro.part_val = ws;
+    ro.part_idx = kArg ? (int64_t*)((char*)ws + (size_t)pl.partial_slots * sizeof(T)) : nullptr;
+  }
+  const bool lin = p->linear != 0;
+#define SP_LAUNCH(KERNEL, GRID, ...)                                                        \
+  do {                                                                                      \
+    if (vec) {                                                                              \
+      if (lin) hipLaunchKernelGGL((KERNEL<T, VV, true, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<T, VV, false, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);    \
+    } else {                                                                                \
+      if (lin) hipLaunchKernelGGL((KERNEL<T, 1, true, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);  \
+      else hipLaunchKernelGGL((KERNEL<T, 1, false, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);     \
+    }                                                                                       \
+    SP_CHECK_LAUNCH();                                                                      \
+  } while (0)
+
+  if (pl.kind == 1) {
+    const int64_t blocks = (O + (SP_BLOCK / 64) - 1) / (SP_BLOCK / 64);
+    SP_LAUNCH(sp_reduce_rows_wave_kernel, dim3(cap_dim(blocks, kTargetBlocks * 4)), *p, in, op, O, A, ro);
+  } else if (pl.kind == 0) {
+    SP_LAUNCH(sp_reduce_rows_kernel, dim3(pl.nsplit, cap_dim(O, 65535)), *p, in, op, O, A, pl.chunk,
+              pl.nsplit, ro);
+    if (pl.nsplit > 1) {
+      const int64_t blocks = (O + (SP_BLOCK / 64) - 1) / (SP_BLOCK / 64);
+      hipLaunchKernelGGL((sp_finish_rows_kernel<T, AccT>), dim3(cap_dim(blocks, kTargetBlocks)),
+                         dim3(SP_BLOCK), 0, st, op, O, pl.nsplit, ro);
+      SP_CHECK_LAUNCH();
+    }
+  } else {
+    const int64_t bx = (I + 64 * V - 1) / (64 * V);
+    if (bx > 2147483647LL) SP_FAIL("sp_reduce: inner dimension too large");
+    SP_LAUNCH(sp_reduce_cols_kernel, dim3((unsigned)bx, pl.nsplit, cap_dim(O, 65535)), *p, in, op, O, A, I,
+              pl.chunk, pl.nsplit, ro);
+    if (pl.nsplit > 1) {
+      const int64_t E = O * I;
+      const int64_t blocks = (E + SP_BLOCK - 1) / SP_BLOCK;
+      hipLaunchKernelGGL((sp_finish_cols_kernel<T, AccT>), dim3(cap_dim(blocks, kTargetBlocks)),
+                         dim3(SP_BLOCK), 0, st, op, E, pl.nsplit, ro);
+      SP_CHECK_LAUNCH();
+    }
+  }
+#undef SP_LAUNCH
+  return 0;
+}
+
+static size_t sp_ws_bytes(int32_t cls, int64_t O, int64_t A, int64_t I, bool arg) {
+  const size_t ts = cls == SP_F32 ? 4 : 8;
+  const int VV = cls == SP_F32 ? 4 : 2;
+  // the vector / scalar decision is made at launch time: size for the larger plan
+  size_t best = 0;
+  const int vs[2] = {VV, 1};
+  for (int k = 0; k < 2; ++k) {
+    RedPlan pl = sp_plan(vs[k], O, A, I);
+    size_t need = (size_t)pl.partial_slots * (ts + (arg ? 8 : 0));
+    if (need > best) best = need;
+  }
+  return best + 256;
+}
+
+static int sp_check_space(const sp_program* p, int64_t O, int64_t A, int64_t I) {
+  if (O < 1 || A < 1 || I < 1) SP_FAIL("sp_reduce: empty index space (outer=%lld axis=%lld inner=%lld)",
+                                       (long long)O, (long long)A, (long long)I);
+  int64_t n = 1;
+  for (int d = 0; d < p->ndim; ++d) n *= p->shape[d];
+  if (n != O * A * I) SP_FAIL("sp_reduce: outer*axis*inner=%lld != prod(shape)=%lld",
+                              (long long)(O * A * I), (long long)n);
+  return 0;
+}
+

@@ -1,0 +1,59 @@
+// Shared host/device helpers for libspartan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/spartan_hip.h"
+
+// ---- error plumbing ------------------------------------------------------
+void sp_set_error(const char* fmt, ...);
+
+#define SP_FAIL(...)          \
+  do {                        \
+    sp_set_error(__VA_ARGS__); \
+    return 1;                 \
+  } while (0)
+
+#define SP_HIP(expr)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      sp_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,             \
+                   hipGetErrorString(e_));                                        \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+
+#define SP_CHECK_LAUNCH()                                                         \
+  do {                                                                            \
+    hipError_t e_ = hipGetLastError();                                            \
+    if (e_ != hipSuccess) {                                                       \
+      sp_set_error("%s:%d: kernel launch failed: %s", __FILE__, __LINE__,         \
+                   hipGetErrorString(e_));                                        \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+
+static inline size_t sp_dtype_size(int32_t dt) {
+  switch (dt) {
+    case SP_F32: return 4;
+    case SP_F64: return 8;
+    case SP_I32: return 4;
+    case SP_I64: return 8;
+    case SP_BOOL: return 1;
+    case SP_U8: return 1;
+    default: return 0;
+  }
+}
+
+// number of CUs on MI355X; grids for streaming kernels are capped at
+// SP_CUS * SP_BLOCKS_PER_CU workgroups and grid-stride the rest.
+#define SP_CUS 256
+#define SP_BLOCKS_PER_CU 8
+#define SP_BLOCK 256
+
+struct sp_inputs {
+  const void* p[SP_MAX_INPUTS];
+};

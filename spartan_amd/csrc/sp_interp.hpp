@@ -1,0 +1,453 @@
+// Device-side evaluator for a fused LocalExpr program (see sp_program in
+// include/spartan_hip.h).  The program is wave-uniform (it lives in the kernel
+// argument segment and is read with scalar loads), so the per-instruction
+// dispatch is scalar control flow and the virtual register file r[SP_NREG][V]
+// stays in VGPRs, addressed with s_set_gpr_idx (checked in the ISA: no scratch).
+//
+// One thread evaluates V consecutive elements of the row-major output index
+// space per call; V*sizeof(T) == 16 B so the dense operands are read with one
+// global_load_dwordx4 per lane (1 KiB per wave-instruction).
+#pragma once
+#include <type_traits>
+
+#include "sp_common.hpp"
+
+template <typename T>
+struct sp_cls;
+template <>
+struct sp_cls<float> {
+  static constexpr int V = 4;
+  static constexpr int id = SP_F32;
+};
+template <>
+struct sp_cls<double> {
+  static constexpr int V = 2;
+  static constexpr int id = SP_F64;
+};
+template <>
+struct sp_cls<int64_t> {
+  static constexpr int V = 2;
+  static constexpr int id = SP_I64;
+};
+
+// ---- typed loads: `n` consecutive elements (n == V, or 1) converted to T ----
+template <typename T, int N>
+__device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_t off, T* dst) {
+  switch (dt) {
+    case SP_F32: {
+      const float* p = (const float*)base + off;
+      if constexpr (N == 4) {
+        float4 v = *(const float4*)p;
+        dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
+      } else if constexpr (N == 2) {
+        float2 v = *(const float2*)p;
+        dst[0] = (T)v.x; dst[1] = (T)v.y;
+      } else {
+        dst[0] = (T)p[0];
+      }
+    } break;
+    case SP_F64: {
+      const double* p = (const double*)base + off;
+      if constexpr (N == 4) {
+        double2 v0 = *(const double2*)p, v1 = *(const double2*)(p + 2);
+        dst[0] = (T)v0.x; dst[1] = (T)v0.y; dst[2] = (T)v1.x; dst[3] = (T)v1.y;
+      } else if constexpr (N == 2) {
+        double2 v = *(const double2*)p;
+        dst[0] = (T)v.x; dst[1] = (T)v.y;
+      } else {
+        dst[0] = (T)p[0];
+      }
+    } break;
+    case SP_I32: {
+      const int32_t* p = (const int32_t*)base + off;
+      if constexpr (N == 4) {
+        int4 v = *(const int4*)p;
+        dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
+      } else if constexpr (N == 2) {
+        int2 v = *(const int2*)p;
+        dst[0] = (T)v.x; dst[1] = (T)v.y;
+      } else {
+        dst[0] = (T)p[0];
+      }
+    } break;
+    case SP_I64: {
+      const int64_t* p = (const int64_t*)base + off;
+      if constexpr (N == 4) {
+        longlong2 v0 = *(const longlong2*)p, v1 = *(const longlong2*)(p + 2);
+        dst[0] = (T)v0.x; dst[1] = (T)v0.y; dst[2] = (T)v1.x; dst[3] = (T)v1.y;
+      } else if constexpr (N == 2) {
+        longlong2 v = *(const longlong2*)p;
+        dst[0] = (T)v.x; dst[1] = (T)v.y;
+      } else {
+        dst[0] = (T)p[0];
+      }
+    } break;
+    default: {  // SP_BOOL / SP_U8
+      const uint8_t* p = (const uint8_t*)base + off;
+      if constexpr (N == 4) {
+        uchar4 v = *(const uchar4*)p;
+        dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
+      } else if constexpr (N == 2) {
+        uchar2 v = *(const uchar2*)p;
+        dst[0] = (T)v.x; dst[1] = (T)v.y;
+      } else {
+        dst[0] = (T)p[0];
+      }
+    } break;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ int64_t sp_to_i64(T x) {
+  return (int64_t)x;
+}
+
+// ---- typed stores with the NumPy cast semantics of ndarray.astype ----
+template <typename T, int N>
+__device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off, const T* src) {
+  switch (dt) {
+    case SP_F32: {
+      float* p = (float*)base + off;
+      if constexpr (N == 4) {
+        *(float4*)p = make_float4((float)src[0], (float)src[1], (float)src[2], (float)src[3]);
+      } else if constexpr (N == 2) {
+        *(float2*)p = make_float2((float)src[0], (float)src[1]);
+      } else {
+        p[0] = (float)src[0];
+      }
+    } break;
+    case SP_F64: {
+      double* p = (double*)base + off;
+#pragma unroll
+      for (int j = 0; j < N; j += 2) {
+        if constexpr (N >= 2) {
+          *(double2*)(p + j) = make_double2((double)src[j], (double)src[j + 1]);
+        } else {
+          p[0] = (double)src[0];
+        }
+      }
+    } break;
+    case SP_I32: {
+      int32_t* p = (int32_t*)base + off;
+      if constexpr (N == 4) {
+        *(int4*)p = make_int4((int32_t)src[0], (int32_t)src[1], (int32_t)src[2], (int32_t)src[3]);
+      } else if constexpr (N == 2) {
+        *(int2*)p = make_int2((int32_t)src[0], (int32_t)src[1]);
+      } else {
+        p[0] = (int32_t)src[0];
+      }
+    } break;
+    case SP_I64: {
+      int64_t* p = (int64_t*)base + off;
+#pragma unroll
+      for (int j = 0; j < N; j += 2) {
+        if constexpr (N >= 2) {
+          longlong2 v;
+          v.x = (int64_t)src[j];
+          v.y = (int64_t)src[j + 1];
+          *(longlong2*)(p + j) = v;
+        } else {
+          p[0] = (int64_t)src[0];
+        }
+      }
+    } break;
+    case SP_BOOL: {
+      uint8_t* p = (uint8_t*)base + off;
+      if constexpr (N == 4) {
+        *(uchar4*)p = make_uchar4(src[0] != (T)0, src[1] != (T)0, src[2] != (T)0, src[3] != (T)0);
+      } else if constexpr (N == 2) {
+        *(uchar2*)p = make_uchar2(src[0] != (T)0, src[1] != (T)0);
+      } else {
+        p[0] = src[0] != (T)0;
+      }
+    } break;
+    default: {  // SP_U8
+      uint8_t* p = (uint8_t*)base + off;
+#pragma unroll
+      for (int j = 0; j < N; ++j) p[j] = (uint8_t)(int64_t)src[j];
+    } break;
+  }
+}
+
+// ---- scalar op semantics (NumPy ufunc semantics; see header enum) ----
+template <typename T>
+struct sp_math;
+
+template <>
+struct sp_math<float> {
+  using T = float;
+  static __device__ __forceinline__ T div(T a, T b) { return a / b; }
+  static __device__ __forceinline__ T fmod_(T a, T b) { return fmodf(a, b); }
+  static __device__ __forceinline__ T mod(T a, T b) {
+    if (b == 0.0f) return fmodf(a, b);
+    T r = fmodf(a, b);
+    if (r != 0.0f) {
+      if ((b < 0.0f) != (r < 0.0f)) r += b;
+    } else {
+      r = copysignf(0.0f, b);
+    }
+    return r;
+  }
+  static __device__ __forceinline__ T floordiv(T a, T b) {
+    // npy_divmod (numpy/core/src/npymath): floor division consistent with mod
+    if (b == 0.0f) return a / b;
+    T m = fmodf(a, b);
+    T d = (a - m) / b;
+    if (m != 0.0f && ((b < 0.0f) != (m < 0.0f))) d -= 1.0f;
+    if (d != 0.0f) {
+      T f = floorf(d);
+      if (d - f > 0.5f) f += 1.0f;
+      return f;
+    }
+    return copysignf(0.0f, a / b);
+  }
+  static __device__ __forceinline__ T pow_(T a, T b) { return powf(a, b); }
+  static __device__ __forceinline__ T sqrt_(T a) { return sqrtf(a); }
+  static __device__ __forceinline__ T exp_(T a) { return expf(a); }
+  static __device__ __forceinline__ T log_(T a) { return logf(a); }
+  static __device__ __forceinline__ T tanh_(T a) { return tanhf(a); }
+  static __device__ __forceinline__ T floor_(T a) { return floorf(a); }
+  static __device__ __forceinline__ T ceil_(T a) { return ceilf(a); }
+  static __device__ __forceinline__ T abs_(T a) { return fabsf(a); }
+  static __device__ __forceinline__ bool isnan_(T a) { return a != a; }
+  static __device__ __forceinline__ T to_f32(T a) { return a; }
+  static __device__ __forceinline__ T to_i32(T a) { return (T)(int32_t)a; }
+  static __device__ __forceinline__ T to_i64(T a) { return (T)(int64_t)a; }
+};
+
+template <>
+struct sp_math<double> {
+  using T = double;
+  static __device__ __forceinline__ T div(T a, T b) { return a / b; }
+  static __device__ __forceinline__ T fmod_(T a, T b) { return fmod(a, b); }
+  static __device__ __forceinline__ T mod(T a, T b) {
+    if (b == 0.0) return fmod(a, b);
+    T r = fmod(a, b);
+    if (r != 0.0) {
+      if ((b < 0.0) != (r < 0.0)) r += b;
+    } else {
+      r = copysign(0.0, b);
+    }
+    return r;
+  }
+  static __device__ __forceinline__ T floordiv(T a, T b) {
+    if (b == 0.0) return a / b;
+    T m = fmod(a, b);
+    T d = (a - m) / b;
+    if (m != 0.0 && ((b < 0.0) != (m < 0.0))) d -= 1.0;
+    if (d != 0.0) {
+      T f = floor(d);
+      if (d - f > 0.5) f += 1.0;
+      return f;
+    }
+    return copysign(0.0, a / b);
+  }
+  static __device__ __forceinline__ T pow_(T a, T b) { return pow(a, b); }
+  static __device__ __forceinline__ T sqrt_(T a) { return sqrt(a); }
+  static __device__ __forceinline__ T exp_(T a) { return exp(a); }
+  static __device__ __forceinline__ T log_(T a) { return log(a); }
+  static __device__ __forceinline__ T tanh_(T a) { return tanh(a); }
+  static __device__ __forceinline__ T floor_(T a) { return floor(a); }
+  static __device__ __forceinline__ T ceil_(T a) { return ceil(a); }
+  static __device__ __forceinline__ T abs_(T a) { return fabs(a); }
+  static __device__ __forceinline__ bool isnan_(T a) { return a != a; }
+  static __device__ __forceinline__ T to_f32(T a) { return (T)(float)a; }
+  static __device__ __forceinline__ T to_i32(T a) { return (T)(int32_t)a; }
+  static __device__ __forceinline__ T to_i64(T a) { return (T)(int64_t)a; }
+};
+
+template <>
+struct sp_math<int64_t> {
+  using T = int64_t;
+  static __device__ __forceinline__ T floordiv(T a, T b) {
+    if (b == 0) return 0;  // numpy: 0 with a RuntimeWarning
+    T q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) q -= 1;
+    return q;
+  }
+  static __device__ __forceinline__ T div(T a, T b) { return floordiv(a, b); }
+  static __device__ __forceinline__ T fmod_(T a, T b) { return b == 0 ? 0 : a % b; }
+  static __device__ __forceinline__ T mod(T a, T b) {
+    if (b == 0) return 0;
+    T r = a % b;
+    if (r != 0 && ((r < 0) != (b < 0))) r += b;
+    return r;
+  }
+  static __device__ __forceinline__ T pow_(T a, T b) {
+    if (b < 0) return 0;
+    T r = 1;
+    while (b) {
+      if (b & 1) r *= a;
+      a *= a;
+      b >>= 1;
+    }
+    return r;
+  }
+  static __device__ __forceinline__ T sqrt_(T a) { return (T)sqrt((double)a); }
+  static __device__ __forceinline__ T exp_(T a) { return (T)exp((double)a); }
+  static __device__ __forceinline__ T log_(T a) { return (T)log((double)a); }
+  static __device__ __forceinline__ T tanh_(T a) { return (T)tanh((double)a); }
+  static __device__ __forceinline__ T floor_(T a) { return a; }
+  static __device__ __forceinline__ T ceil_(T a) { return a; }
+  static __device__ __forceinline__ T abs_(T a) { return a < 0 ? -a : a; }
+  static __device__ __forceinline__ bool isnan_(T) { return false; }
+  static __device__ __forceinline__ T to_f32(T a) { return (T)(float)a; }
+  static __device__ __forceinline__ T to_i32(T a) { return (T)(int32_t)a; }
+  static __device__ __forceinline__ T to_i64(T a) { return a; }
+};
+
+template <typename T>
+__device__ __forceinline__ T sp_nanmax(T a, T b) {
+  if (sp_math<T>::isnan_(a)) return a;
+  if (sp_math<T>::isnan_(b)) return b;
+  return a > b ? a : b;
+}
+template <typename T>
+__device__ __forceinline__ T sp_nanmin(T a, T b) {
+  if (sp_math<T>::isnan_(a)) return a;
+  if (sp_math<T>::isnan_(b)) return b;
+  return a < b ? a : b;
+}
+
+template <typename T>
+__device__ __forceinline__ T sp_const(const sp_program& p, int i) {
+  if constexpr (std::is_integral<T>::value) {
+    return (T)p.iconsts[i];
+  } else {
+    return (T)p.consts[i];
+  }
+}
+
+// ---- the evaluator ----------------------------------------------------------
+// Evaluates the program for the V elements whose row-major linear indices are
+// L .. L+V-1 (callers guarantee they share every coordinate but the last when
+// !LINEAR).  Result in out[0..V).
+template <typename T, int V, bool LINEAR>
+__device__ __forceinline__ void sp_eval(const sp_program& p, const sp_inputs& in, int64_t L,
+                                        T (&out)[V]) {
+  T r[SP_NREG * V];
+#pragma unroll
+  for (int k = 0; k < SP_NREG * V; ++k) r[k] = (T)0;
+
+  // coordinates of L for the strided path
+  int64_t idx[SP_MAX_DIMS] = {0, 0, 0, 0};
+  if constexpr (!LINEAR) {
+    int64_t rem = L;
+#pragma unroll
+    for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
+      if (d < p.ndim) {
+        int64_t s = p.shape[d];
+        if (d == 0) {
+          idx[d] = rem;
+        } else {
+          int64_t q = rem / s;
+          idx[d] = rem - q * s;
+          rem = q;
+        }
+      }
+    }
+  }
+
+  // operand loads: static register slots, so all loads are in flight together
+#pragma unroll
+  for (int j = 0; j < SP_MAX_INPUTS; ++j) {
+    if (j < p.n_inputs) {
+      if constexpr (LINEAR) {
+        // dense operand (stride pattern == output) or scalar (all strides 0)
+        if (p.in_stride[j][p.ndim - 1] != 0) {
+          sp_load_vec<T, V>(in.p[j], p.in_dtype[j], L, &r[j * V]);
+        } else {
+          T s;
+          sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], 0, &s);
+#pragma unroll
+          for (int v = 0; v < V; ++v) r[j * V + v] = s;
+        }
+      } else {
+        int64_t off = 0;
+#pragma unroll
+        for (int d = 0; d < SP_MAX_DIMS; ++d)
+          if (d < p.ndim) off += idx[d] * p.in_stride[j][d];
+        int64_t inner = p.in_stride[j][p.ndim - 1];
+        if (inner == 1 || V == 1) {
+          sp_load_vec<T, V>(in.p[j], p.in_dtype[j], off, &r[j * V]);
+        } else if (inner == 0) {
+          T s;
+          sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], off, &s);
+#pragma unroll
+          for (int v = 0; v < V; ++v) r[j * V + v] = s;
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], off + v * inner, &r[j * V + v]);
+        }
+      }
+    }
+  }
+
+  using M = sp_math<T>;
+  for (int pc = 0; pc < p.n_instr; ++pc) {
+    const sp_instr I = p.instr[pc];
+    T a[V], b[V], d[V];
+    const int ra = (I.a & (SP_NREG - 1)) * V, rb = (I.b & (SP_NREG - 1)) * V;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      a[v] = r[ra + v];
+      b[v] = r[rb + v];
+    }
+#define SP_EACH(expr)              \
+  _Pragma("unroll") for (int v = 0; v < V; ++v) { d[v] = (expr); }
+    switch (I.op) {
+      case SP_OP_CONST: { T c = sp_const<T>(p, I.a); SP_EACH(c); } break;
+      case SP_OP_IOTA: SP_EACH((T)(L + v)); break;
+      case SP_OP_MOV: SP_EACH(a[v]); break;
+      case SP_OP_ADD: SP_EACH(a[v] + b[v]); break;
+      case SP_OP_SUB: SP_EACH(a[v] - b[v]); break;
+      case SP_OP_MUL: SP_EACH(a[v] * b[v]); break;
+      case SP_OP_DIV: SP_EACH(M::div(a[v], b[v])); break;
+      case SP_OP_FLOORDIV: SP_EACH(M::floordiv(a[v], b[v])); break;
+      case SP_OP_MOD: SP_EACH(M::mod(a[v], b[v])); break;
+      case SP_OP_FMOD: SP_EACH(M::fmod_(a[v], b[v])); break;
+      case SP_OP_POW: SP_EACH(M::pow_(a[v], b[v])); break;
+      case SP_OP_MAX: SP_EACH(sp_nanmax<T>(a[v], b[v])); break;
+      case SP_OP_MIN: SP_EACH(sp_nanmin<T>(a[v], b[v])); break;
+      case SP_OP_EQ: SP_EACH((T)(a[v] == b[v])); break;
+      case SP_OP_NE: SP_EACH((T)(a[v] != b[v])); break;
+      case SP_OP_LT: SP_EACH((T)(a[v] < b[v])); break;
+      case SP_OP_LE: SP_EACH((T)(a[v] <= b[v])); break;
+      case SP_OP_GT: SP_EACH((T)(a[v] > b[v])); break;
+      case SP_OP_GE: SP_EACH((T)(a[v] >= b[v])); break;
+      case SP_OP_LAND: SP_EACH((T)((a[v] != (T)0) && (b[v] != (T)0))); break;
+      case SP_OP_LOR: SP_EACH((T)((a[v] != (T)0) || (b[v] != (T)0))); break;
+      case SP_OP_LXOR: SP_EACH((T)((a[v] != (T)0) != (b[v] != (T)0))); break;
+      case SP_OP_LNOT: SP_EACH((T)(a[v] == (T)0)); break;
+      case SP_OP_NEG: SP_EACH(-a[v]); break;
+      case SP_OP_ABS: SP_EACH(M::abs_(a[v])); break;
+      case SP_OP_SQRT: SP_EACH(M::sqrt_(a[v])); break;
+      case SP_OP_SQUARE: SP_EACH(a[v] * a[v]); break;
+      case SP_OP_EXP: SP_EACH(M::exp_(a[v])); break;
+      case SP_OP_LOG: SP_EACH(M::log_(a[v])); break;
+      case SP_OP_RECIP: SP_EACH(M::div((T)1, a[v])); break;
+      case SP_OP_SIGN: SP_EACH((T)((a[v] > (T)0) - (a[v] < (T)0))); break;
+      case SP_OP_FLOOR: SP_EACH(M::floor_(a[v])); break;
+      case SP_OP_CEIL: SP_EACH(M::ceil_(a[v])); break;
+      case SP_OP_TANH: SP_EACH(M::tanh_(a[v])); break;
+      case SP_OP_WHERE: {
+        const int rc = (I.c & (SP_NREG - 1)) * V;
+        SP_EACH(a[v] != (T)0 ? b[v] : r[rc + v]);
+      } break;
+      case SP_OP_TO_F32: SP_EACH(M::to_f32(a[v])); break;
+      case SP_OP_TO_I32: SP_EACH(M::to_i32(a[v])); break;
+      case SP_OP_TO_I64: SP_EACH(M::to_i64(a[v])); break;
+      case SP_OP_TO_BOOL: SP_EACH((T)(a[v] != (T)0)); break;
+      case SP_OP_TO_U8: SP_EACH((T)(uint8_t)(int64_t)a[v]); break;
+      default: SP_EACH(a[v]); break;
+    }
+#undef SP_EACH
+    const int rd = (I.dst & (SP_NREG - 1)) * V;
+#pragma unroll
+    for (int v = 0; v < V; ++v) r[rd + v] = d[v];
+  }
+  const int rr = (p.result_reg & (SP_NREG - 1)) * V;
+#pragma unroll
+  for (int v = 0; v < V; ++v) out[v] = r[rr + v];
+}

@@ -1,0 +1,355 @@
+// Combine (Tile.merge), strided box copy, STREAM copy and the small runtime
+// helpers of the C-ABI (errors, device info, HIP-event timing).
+//
+// sp_update   <- spartan/array/tile.pyx:200-297  merge(), dense->dense branch
+// sp_slice_copy <- spartan/array/distarray.py:355-365 (fetch stitch),
+//                  tile.pyx:64-113 (Tile.get(subslice)),
+//                  sparse.pyx:297-301 (multiple_slice dense branch)
+// All are HBM-bound streaming kernels: 16 B per lane when the innermost
+// extent allows it, grid-stride over at most 8 workgroups per CU.
+#include <stdarg.h>
+
+#include "sp_interp.hpp"
+
+// ------------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+
+void sp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* sp_last_error(void) { return g_err; }
+extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
+
+extern "C" int sp_device_count(int* count) {
+  if (!count) SP_FAIL("sp_device_count: NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    SP_FAIL("hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return 0;
+}
+
+extern "C" int sp_device_info(int device, int* cu_count, int64_t* hbm_bytes, char* name, size_t name_len) {
+  hipDeviceProp_t prop;
+  SP_HIP(hipGetDeviceProperties(&prop, device));
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  if (name && name_len) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------- events
+extern "C" int sp_event_create(void** ev) {
+  if (!ev) SP_FAIL("sp_event_create: NULL");
+  hipEvent_t e;
+  SP_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  return 0;
+}
+extern "C" int sp_event_destroy(void* ev) {
+  SP_HIP(hipEventDestroy((hipEvent_t)ev));
+  return 0;
+}
+extern "C" int sp_event_record(void* ev, void* stream) {
+  SP_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int sp_event_synchronize(void* ev) {
+  SP_HIP(hipEventSynchronize((hipEvent_t)ev));
+  return 0;
+}
+extern "C" int sp_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!ms) SP_FAIL("sp_event_elapsed_ms: NULL");
+  SP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return 0;
+}
+
+static inline int grid_for(int64_t n) {
+  int64_t b = (n + SP_BLOCK - 1) / SP_BLOCK;
+  const int64_t cap = (int64_t)SP_CUS * SP_BLOCKS_PER_CU;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------- STREAM copy
+__global__ __launch_bounds__(SP_BLOCK) void sp_stream_copy_kernel(float4* __restrict__ dst,
+                                                                  const float4* __restrict__ src,
+                                                                  int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * SP_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+__global__ void sp_byte_copy_kernel(uint8_t* dst, const uint8_t* src, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream) {
+  if (!bytes) return 0;
+  if (!d_dst || !d_src) SP_FAIL("sp_stream_copy: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = ((((uintptr_t)d_dst) | ((uintptr_t)d_src)) & 15) == 0;
+  size_t main_bytes = al ? (bytes / 16) * 16 : 0;
+  if (main_bytes) {
+    hipLaunchKernelGGL(sp_stream_copy_kernel, dim3(grid_for(main_bytes / 16)), dim3(SP_BLOCK), 0, st,
+                       (float4*)d_dst, (const float4*)d_src, (int64_t)(main_bytes / 16));
+    SP_CHECK_LAUNCH();
+  }
+  if (bytes - main_bytes) {
+    hipLaunchKernelGGL(sp_byte_copy_kernel, dim3(grid_for(bytes - main_bytes)), dim3(SP_BLOCK), 0, st,
+                       (uint8_t*)d_dst + main_bytes, (const uint8_t*)d_src + main_bytes,
+                       (int64_t)(bytes - main_bytes));
+    SP_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// ----------------------------------------------------------- strided copy
+struct BoxDesc {
+  int32_t ndim;
+  int64_t shape[SP_MAX_DIMS];
+  int64_t dstride[SP_MAX_DIMS];
+  int64_t sstride[SP_MAX_DIMS];
+};
+
+// W = bytes moved per thread step (one element of W bytes; the caller folds
+// contiguous inner runs into 16-B elements when alignment allows).
+template <typename E>
+__global__ __launch_bounds__(SP_BLOCK) void sp_box_copy_kernel(E* __restrict__ dst,
+                                                               const E* __restrict__ src, BoxDesc b,
+                                                               int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * SP_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK + threadIdx.x; i < n; i += stride) {
+    int64_t rem = i, doff = 0, soff = 0;
+#pragma unroll
+    for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
+      if (d < b.ndim) {
+        int64_t c;
+        if (d == 0) {
+          c = rem;
+        } else {
+          int64_t q = rem / b.shape[d];
+          c = rem - q * b.shape[d];
+          rem = q;
+        }
+        doff += c * b.dstride[d];
+        soff += c * b.sstride[d];
+      }
+    }
+    dst[doff] = src[soff];
+  }
+}
+
+struct uint128_t_ { uint32_t a, b, c, d; };
+
+extern "C" int sp_slice_copy(void* d_dst, const int64_t* dst_stride, const void* d_src,
+                             const int64_t* src_stride, const int64_t* shape, int32_t ndim,
+                             int32_t elem_size, void* stream) {
+  if (ndim < 0 || ndim > SP_MAX_DIMS) SP_FAIL("sp_slice_copy: ndim=%d unsupported (max %d)", ndim, SP_MAX_DIMS);
+  if (elem_size != 1 && elem_size != 4 && elem_size != 8) SP_FAIL("sp_slice_copy: elem_size=%d", elem_size);
+  if (!d_dst || !d_src) SP_FAIL("sp_slice_copy: NULL pointer");
+  BoxDesc b;
+  memset(&b, 0, sizeof(b));
+  int64_t n = 1;
+  if (ndim == 0) {
+    b.ndim = 1;
+    b.shape[0] = 1;
+    b.dstride[0] = b.sstride[0] = 1;
+  } else {
+    b.ndim = ndim;
+    for (int d = 0; d < ndim; ++d) {
+      if (shape[d] < 0) SP_FAIL("sp_slice_copy: negative extent");
+      b.shape[d] = shape[d];
+      b.dstride[d] = dst_stride[d];
+      b.sstride[d] = src_stride[d];
+      n *= shape[d];
+    }
+  }
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  // widen: if the innermost run is contiguous on both sides, move 16-B words
+  const int last = b.ndim - 1;
+  int64_t es = elem_size;
+  if (b.dstride[last] == 1 && b.sstride[last] == 1) {
+    const int64_t per16 = 16 / es;
+    bool ok = (b.shape[last] % per16 == 0) && ((((uintptr_t)d_dst) | ((uintptr_t)d_src)) & 15) == 0;
+    for (int d = 0; d < last && ok; ++d)
+      if (b.dstride[d] % per16 != 0 || b.sstride[d] % per16 != 0) ok = false;
+    if (ok) {
+      b.shape[last] /= per16;
+      for (int d = 0; d < last; ++d) {
+        b.dstride[d] /= per16;
+        b.sstride[d] /= per16;
+      }
+      n /= per16;
+      es = 16;
+    }
+  }
+  const dim3 g(grid_for(n)), blk(SP_BLOCK);
+  switch (es) {
+    case 16:
+      hipLaunchKernelGGL((sp_box_copy_kernel<float4>), g, blk, 0, st, (float4*)d_dst, (const float4*)d_src, b, n);
+      break;
+    case 8:
+      hipLaunchKernelGGL((sp_box_copy_kernel<uint64_t>), g, blk, 0, st, (uint64_t*)d_dst, (const uint64_t*)d_src, b, n);
+      break;
+    case 4:
+      hipLaunchKernelGGL((sp_box_copy_kernel<uint32_t>), g, blk, 0, st, (uint32_t*)d_dst, (const uint32_t*)d_src, b, n);
+      break;
+    default:
+      hipLaunchKernelGGL((sp_box_copy_kernel<uint8_t>), g, blk, 0, st, (uint8_t*)d_dst, (const uint8_t*)d_src, b, n);
+      break;
+  }
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+// -------------------------------------------------------------------- merge
+struct UpdDesc {
+  int32_t ndim;
+  int64_t box[SP_MAX_DIMS];      // extents of the updated box
+  int64_t dstride[SP_MAX_DIMS];  // element strides of the tile
+  int64_t doff;                  // element offset of the box origin in the tile
+  int32_t dst_dtype, src_dtype, reducer, mask_mode;
+};
+
+template <typename T>
+__device__ __forceinline__ T sp_apply_reducer(int r, T old, T upd) {
+  switch (r) {
+    case SP_REDUCER_ADD: return old + upd;
+    case SP_REDUCER_MUL: return old * upd;
+    case SP_REDUCER_MAX: return sp_nanmax<T>(old, upd);
+    case SP_REDUCER_MIN: return sp_nanmin<T>(old, upd);
+    case SP_REDUCER_AND: return (T)((old != (T)0) && (upd != (T)0));
+    case SP_REDUCER_OR: return (T)((old != (T)0) || (upd != (T)0));
+    default: return upd;
+  }
+}
+
+// T = arithmetic type of the destination tile (float / double / int64 for all
+// integer + bool tiles).  V consecutive elements of the innermost box
+// dimension per thread (contiguous in both tile and update).
+template <typename T, int V>
+__global__ __launch_bounds__(SP_BLOCK) void sp_update_kernel(void* __restrict__ dst,
+                                                             const void* __restrict__ src,
+                                                             uint8_t* __restrict__ mask, UpdDesc u,
+                                                             int64_t nvec) {
+  const int64_t stride = (int64_t)gridDim.x * SP_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK + threadIdx.x; i < nvec; i += stride) {
+    const int64_t L = i * V;  // linear index inside the box (== offset in src)
+    int64_t rem = L, off = u.doff;
+#pragma unroll
+    for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
+      if (d < u.ndim) {
+        int64_t c;
+        if (d == 0) {
+          c = rem;
+        } else {
+          int64_t q = rem / u.box[d];
+          c = rem - q * u.box[d];
+          rem = q;
+        }
+        off += c * u.dstride[d];
+      }
+    }
+    T upd[V], old[V], res[V];
+    sp_load_vec<T, V>(src, u.src_dtype, L, upd);
+    bool m[V];
+    if (u.mask_mode == SP_MASK_ARRAY) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) m[v] = mask[off + v] != 0;
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) m[v] = u.mask_mode == SP_MASK_ALL_SET;
+    }
+    const bool need_old = u.reducer != SP_REDUCER_NONE && u.mask_mode != SP_MASK_ALL_CLEAR;
+    if (need_old) {
+      sp_load_vec<T, V>(dst, u.dst_dtype, off, old);
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) old[v] = (T)0;
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) res[v] = m[v] ? sp_apply_reducer<T>(u.reducer, old[v], upd[v]) : upd[v];
+    sp_store_vec<T, V>(dst, u.dst_dtype, off, res);
+    if (mask) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) mask[off + v] = 1;
+    }
+  }
+}
+
+template <typename T>
+static int sp_update_launch(void* d_dst, const void* d_src, uint8_t* d_mask, const UpdDesc& u, int64_t n,
+                            hipStream_t st) {
+  constexpr int VV = sp_cls<T>::V;
+  const int last = u.ndim - 1;
+  bool vec = (u.box[last] % VV == 0) && (u.doff % VV == 0) &&
+             ((((uintptr_t)d_dst) | ((uintptr_t)d_src)) & 15) == 0;
+  for (int d = 0; d < last && vec; ++d)
+    if (u.dstride[d] % VV != 0) vec = false;
+  if (vec) {
+    hipLaunchKernelGGL((sp_update_kernel<T, VV>), dim3(grid_for(n / VV)), dim3(SP_BLOCK), 0, st, d_dst, d_src,
+                       d_mask, u, n / VV);
+  } else {
+    hipLaunchKernelGGL((sp_update_kernel<T, 1>), dim3(grid_for(n)), dim3(SP_BLOCK), 0, st, d_dst, d_src,
+                       d_mask, u, n);
+  }
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sp_update(void* d_dst, int32_t dst_dtype, const int64_t* dst_shape, int32_t ndim,
+                         const int64_t* ul, const int64_t* lr, const void* d_src, int32_t src_dtype,
+                         int32_t reducer, int32_t mask_mode, uint8_t* d_mask, void* stream) {
+  if (ndim < 0 || ndim > SP_MAX_DIMS) SP_FAIL("sp_update: ndim=%d unsupported (max %d)", ndim, SP_MAX_DIMS);
+  if (!d_dst || !d_src) SP_FAIL("sp_update: NULL pointer");
+  if (dst_dtype < 0 || dst_dtype >= SP_DTYPE_COUNT || src_dtype < 0 || src_dtype >= SP_DTYPE_COUNT)
+    SP_FAIL("sp_update: bad dtype");
+  if (reducer < SP_REDUCER_NONE || reducer > SP_REDUCER_OR) SP_FAIL("sp_update: bad reducer %d", reducer);
+  if (mask_mode < SP_MASK_ALL_CLEAR || mask_mode > SP_MASK_ARRAY) SP_FAIL("sp_update: bad mask_mode");
+  if (mask_mode == SP_MASK_ARRAY && !d_mask) SP_FAIL("sp_update: SP_MASK_ARRAY needs d_mask");
+  UpdDesc u;
+  memset(&u, 0, sizeof(u));
+  u.dst_dtype = dst_dtype;
+  u.src_dtype = src_dtype;
+  u.reducer = reducer;
+  u.mask_mode = mask_mode;
+  int64_t n = 1;
+  if (ndim == 0) {
+    // zero-dimensional tile (tile.pyx:212-217): a single cell
+    u.ndim = 1;
+    u.box[0] = 1;
+    u.dstride[0] = 1;
+    u.doff = 0;
+  } else {
+    u.ndim = ndim;
+    int64_t stride = 1;
+    for (int d = ndim - 1; d >= 0; --d) {
+      if (ul[d] < 0 || lr[d] > dst_shape[d] || ul[d] > lr[d])
+        SP_FAIL("sp_update: box [%lld,%lld) outside tile extent %lld on dim %d", (long long)ul[d],
+                (long long)lr[d], (long long)dst_shape[d], d);
+      u.box[d] = lr[d] - ul[d];
+      u.dstride[d] = stride;
+      u.doff += ul[d] * stride;
+      stride *= dst_shape[d];
+      n *= u.box[d];
+    }
+  }
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (dst_dtype) {
+    case SP_F32: return sp_update_launch<float>(d_dst, d_src, d_mask, u, n, st);
+    case SP_F64: return sp_update_launch<double>(d_dst, d_src, d_mask, u, n, st);
+    default: return sp_update_launch<int64_t>(d_dst, d_src, d_mask, u, n, st);
+  }
+}

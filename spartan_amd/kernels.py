@@ -1,0 +1,158 @@
+"""Pythonic launchers over the C-ABI (spartan_amd/_hip.py) for tile blobs held
+as torch tensors in HBM.  torch is plumbing here: device memory, the current
+HIP stream, and (elsewhere) torch.distributed; every kernel is ours.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import check
+
+_TORCH2NP = {
+    torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64),
+    torch.int32: np.dtype(np.int32), torch.int64: np.dtype(np.int64),
+    torch.bool: np.dtype(np.bool_), torch.uint8: np.dtype(np.uint8),
+}
+_NP2TORCH = {v: k for k, v in _TORCH2NP.items()}
+
+
+def np_dtype_of(t):
+  return _TORCH2NP[t.dtype]
+
+
+def torch_dtype(np_dtype):
+  return _NP2TORCH[np.dtype(np_dtype)]
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_device(*tensors):
+  for t in tensors:
+    if t is not None and not t.is_cuda:
+      raise _hip.HipError('HIP tile kernels need device (HBM) tensors; got a %s tensor' % t.device)
+
+
+class Workspace(object):
+  """Grow-only scratch blob for reduction partials (one per device)."""
+
+  def __init__(self):
+    self.buf = None
+
+  def get(self, nbytes, device):
+    if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+      self.buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+    return self.buf
+
+
+_ws = Workspace()
+
+
+def map_fused(prog, inputs, out):
+  """Launch the fused map `prog` over dense tensors; `out` is written."""
+  _require_device(out, *inputs)
+  ptrs = _hip.ptr_array([t.data_ptr() for t in inputs])
+  check(_hip.lib().sp_map_fused(C.byref(prog), ptrs, C.c_void_p(out.data_ptr()), _stream()))
+  return out
+
+
+def reduce(prog, inputs, red_op, outer, axis_len, inner, out):
+  _require_device(out, *inputs)
+  lib = _hip.lib()
+  need = lib.sp_reduce_workspace_bytes(prog.cls, outer, axis_len, inner)
+  ws = _ws.get(need, out.device)
+  ptrs = _hip.ptr_array([t.data_ptr() for t in inputs])
+  check(lib.sp_reduce(C.byref(prog), ptrs, _hip.RED[red_op] if isinstance(red_op, str) else red_op,
+                      outer, axis_len, inner, C.c_void_p(out.data_ptr()),
+                      _hip.sp_dtype(np_dtype_of(out)), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
+  return out
+
+
+def argreduce(prog, inputs, which, outer, axis_len, inner, index_offset, nan_index, out_idx, out_val=None):
+  _require_device(out_idx, out_val, *inputs)
+  lib = _hip.lib()
+  need = lib.sp_argreduce_workspace_bytes(prog.cls, outer, axis_len, inner)
+  ws = _ws.get(need, out_idx.device)
+  ptrs = _hip.ptr_array([t.data_ptr() for t in inputs])
+  assert out_idx.dtype == torch.int64
+  check(lib.sp_argreduce(C.byref(prog), ptrs, which, outer, axis_len, inner, int(index_offset),
+                         int(nan_index), C.c_void_p(out_idx.data_ptr()),
+                         C.c_void_p(out_val.data_ptr() if out_val is not None else 0),
+                         C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
+  return out_idx
+
+
+def update(dst, ul, lr, src, reducer, mask_mode, mask=None):
+  """Tile.merge: dst[ul:lr] = merge(dst[ul:lr], src) with the tile's mask state."""
+  _require_device(dst, src, mask)
+  nd = dst.dim()
+  check(_hip.lib().sp_update(
+      C.c_void_p(dst.data_ptr()), _hip.sp_dtype(np_dtype_of(dst)), _hip.i64_array(dst.shape), nd,
+      _hip.i64_array(ul), _hip.i64_array(lr), C.c_void_p(src.data_ptr()), _hip.sp_dtype(np_dtype_of(src)),
+      _hip.REDUCER[reducer] if isinstance(reducer, str) else reducer, mask_mode,
+      C.c_void_p(mask.data_ptr() if mask is not None else 0), _stream()))
+  return dst
+
+
+def slice_copy(dst, dst_offset, dst_strides, src, src_offset, src_strides, shape):
+  """Strided box copy between two blobs of the same element size (strides/offsets in elements)."""
+  _require_device(dst, src)
+  es = dst.element_size()
+  assert es == src.element_size()
+  nd = len(shape)
+  check(_hip.lib().sp_slice_copy(
+      C.c_void_p(dst.data_ptr() + int(dst_offset) * es), _hip.i64_array(dst_strides),
+      C.c_void_p(src.data_ptr() + int(src_offset) * es), _hip.i64_array(src_strides),
+      _hip.i64_array(shape), nd, es, _stream()))
+  return dst
+
+
+def gemm_f32(a, b, c, accumulate=False):
+  """c (+)= a . b for 2-D row-major fp32 tensors (inner stride 1)."""
+  _require_device(a, b, c)
+  assert a.dtype == b.dtype == c.dtype == torch.float32
+  M, K = a.shape
+  K2, N = b.shape
+  assert K == K2 and tuple(c.shape) == (M, N), (a.shape, b.shape, c.shape)
+  assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1
+  check(_hip.lib().sp_gemm_f32(C.c_void_p(a.data_ptr()), a.stride(0) if M > 1 else max(K, 1),
+                               C.c_void_p(b.data_ptr()), b.stride(0) if K > 1 else max(N, 1),
+                               C.c_void_p(c.data_ptr()), c.stride(0) if M > 1 else max(N, 1),
+                               M, N, K, 1 if accumulate else 0, _stream()))
+  return c
+
+
+def stream_copy(dst, src):
+  _require_device(dst, src)
+  n = src.numel() * src.element_size()
+  check(_hip.lib().sp_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, _stream()))
+  return dst
+
+
+class Event(object):
+  """HIP event on the stream the kernels are launched on (bench.py timing)."""
+
+  def __init__(self):
+    self.h = C.c_void_p()
+    check(_hip.lib().sp_event_create(C.byref(self.h)))
+
+  def record(self):
+    check(_hip.lib().sp_event_record(self.h, _stream()))
+
+  def synchronize(self):
+    check(_hip.lib().sp_event_synchronize(self.h))
+
+  def elapsed_ms(self, later):
+    ms = C.c_float()
+    check(_hip.lib().sp_event_elapsed_ms(self.h, later.h, C.byref(ms)))
+    return ms.value
+
+  def __del__(self):
+    try:
+      if self.h:
+        _hip.lib().sp_event_destroy(self.h)
+    except Exception:
+      pass

@@ -1,0 +1,399 @@
+"""C-ABI level parity: every libspartan_hip.so kernel against NumPy on the same
+seeded inputs (bit-exact for integer / index / comparison work, stated
+tolerances for fp32 sums and GEMM)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from spartan_amd import _hip, kernels  # noqa: E402
+from spartan_amd.program import Program, broadcast_strides, collapse, dense_strides  # noqa: E402
+
+DEV = 'cuda:0'
+RNG = np.random.RandomState(20150708)
+
+
+def dev(a):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+  return t.cpu().numpy()
+
+
+def build(cls, shape, inputs, body, out_dtype):
+  """inputs: list of (np dtype, in_shape); body(p) emits instrs and returns the result reg."""
+  p = Program()
+  strides = [broadcast_strides(s, shape) for _, s in inputs]
+  cshape, cstrides = collapse(shape, strides)
+  linear = all(st == dense_strides(cshape) or all(x == 0 for x in st) for st in cstrides)
+  for (dt, _), st in zip(inputs, cstrides):
+    p.add_input(dt, st)
+  p.result_reg = body(p)
+  return p.finish(cls, cshape, out_dtype, linear)
+
+
+def run_map(cls, shape, arrays, body, out_dtype):
+  prog = build(cls, shape, [(a.dtype, a.shape) for a in arrays], body, out_dtype)
+  out = torch.empty(shape, dtype=kernels.torch_dtype(out_dtype), device=DEV)
+  kernels.map_fused(prog, [dev(a) for a in arrays], out)
+  torch.cuda.synchronize()
+  return host(out)
+
+
+@pytest.mark.parametrize('shape', [(1000, 1000), (1003,), (7, 13), (4, 8, 16), (1,), (2, 3, 5, 7)])
+def test_map_add_scalar_f32(shape):
+  x = RNG.rand(*shape).astype(np.float32)
+
+  def body(p):
+    c = p.add_const(1.0)
+    p.emit('CONST', 1, c)
+    p.emit('ADD', 2, 0, 1)
+    return 2
+  got = run_map(_hip.SP_F32, shape, [x], body, np.float32)
+  np.testing.assert_array_equal(got, x + np.float32(1))
+
+
+def test_map_xx_plus_x_large():
+  x = RNG.rand(2048, 4096).astype(np.float32)
+
+  def body(p):
+    p.emit('MUL', 1, 0, 0)
+    p.emit('ADD', 1, 1, 0)
+    return 1
+  got = run_map(_hip.SP_F32, x.shape, [x], body, np.float32)
+  np.testing.assert_array_equal(got, x * x + x)
+
+
+@pytest.mark.parametrize('bshape', [(64, 1), (1, 48), (48,), (1, 1)])
+def test_map_broadcast(bshape):
+  x = RNG.rand(64, 48).astype(np.float32)
+  y = RNG.rand(*bshape).astype(np.float32)
+
+  def body(p):
+    p.emit('SUB', 2, 0, 1)
+    p.emit('MUL', 2, 2, 0)
+    return 2
+  got = run_map(_hip.SP_F32, x.shape, [x, y], body, np.float32)
+  np.testing.assert_array_equal(got, (x - y) * x)
+
+
+def test_map_broadcast_odd_inner():
+  x = RNG.rand(33, 7).astype(np.float32)
+  y = RNG.rand(33, 1).astype(np.float32)
+  z = RNG.rand(7).astype(np.float32)
+
+  def body(p):
+    p.emit('ADD', 3, 0, 1)
+    p.emit('MUL', 3, 3, 2)
+    return 3
+  got = run_map(_hip.SP_F32, x.shape, [x, y, z], body, np.float32)
+  np.testing.assert_array_equal(got, (x + y) * z)
+
+
+def test_map_int64_and_compare():
+  a = RNG.randint(-50, 50, size=(129, 17)).astype(np.int64)
+  b = RNG.randint(1, 9, size=(129, 17)).astype(np.int32)
+
+  def body_mod(p):
+    p.emit('MOD', 2, 0, 1)
+    return 2
+  np.testing.assert_array_equal(run_map(_hip.SP_I64, a.shape, [a, b], body_mod, np.int64), np.mod(a, b))
+
+  def body_fd(p):
+    p.emit('FLOORDIV', 2, 0, 1)
+    return 2
+  np.testing.assert_array_equal(run_map(_hip.SP_I64, a.shape, [a, b], body_fd, np.int64), a // b)
+
+  def body_lt(p):
+    p.emit('LT', 2, 0, 1)
+    return 2
+  np.testing.assert_array_equal(run_map(_hip.SP_I64, a.shape, [a, b], body_lt, np.bool_), a < b)
+
+
+def test_map_f64_mixed_and_transcendental():
+  x = (RNG.rand(300, 5) + 0.5).astype(np.float32)
+  k = RNG.randint(0, 5, size=(300, 5)).astype(np.int64)
+
+  def body(p):
+    p.emit('ADD', 2, 0, 1)
+    p.emit('SQRT', 2, 2)
+    return 2
+  got = run_map(_hip.SP_F64, x.shape, [x, k], body, np.float64)
+  np.testing.assert_allclose(got, np.sqrt(x + k), rtol=1e-15)
+
+  def body2(p):
+    p.emit('LOG', 1, 0)
+    p.emit('EXP', 1, 1)
+    return 1
+  got = run_map(_hip.SP_F32, x.shape, [x], body2, np.float32)
+  np.testing.assert_allclose(got, np.exp(np.log(x)), rtol=3e-7)
+
+
+def test_map_iota_arange():
+  shape = (37, 11)
+
+  def body(p):
+    p.emit('IOTA', 0)
+    c = p.add_const(2.0)
+    p.emit('CONST', 1, c)
+    p.emit('MUL', 0, 0, 1)
+    return 0
+  got = run_map(_hip.SP_F64, shape, [], body, np.float64)
+  np.testing.assert_array_equal(got, (np.arange(37 * 11) * 2.0).reshape(shape))
+
+
+# ---------------------------------------------------------------- reductions
+def run_reduce(x, axis, op, cls, out_dtype, body=None, extra=()):
+  shape = x.shape
+  arrays = [x] + list(extra)
+  if axis is None:
+    O, A, I = 1, x.size, 1
+  else:
+    O = int(np.prod(shape[:axis], dtype=np.int64))
+    A = shape[axis]
+    I = int(np.prod(shape[axis + 1:], dtype=np.int64))
+  p = Program()
+  # the program's index space only has to enumerate the same elements in the
+  # same row-major order as [O, A, I]; it keeps its own (collapsed) shape
+  cshape, cstrides = collapse(shape, [broadcast_strides(a.shape, shape) for a in arrays])
+  linear = all(tuple(st) == dense_strides(cshape) for st in cstrides)
+  for a, st in zip(arrays, cstrides):
+    p.add_input(a.dtype, st)
+  p.result_reg = body(p) if body else 0
+  prog = p.finish(cls, cshape, None, linear)
+  out = torch.empty(max(O * I, 1), dtype=kernels.torch_dtype(out_dtype), device=DEV)
+  kernels.reduce(prog, [dev(a) for a in arrays], op, O, A, I, out)
+  torch.cuda.synchronize()
+  res = host(out)
+  if axis is None:
+    return res[0]
+  return res.reshape(shape[:axis] + shape[axis + 1:])
+
+
+SHAPES = [(64, 64), (1000, 333), (5, 70000), (70000, 5), (17,), (3, 5, 7), (2048, 2048), (1, 1)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_reduce_sum_all_axes(shape):
+  x = RNG.rand(*shape).astype(np.float32)
+  for axis in [None] + list(range(len(shape))):
+    got = run_reduce(x, axis, 'SUM', _hip.SP_F32, np.float32)
+    ref = x.astype(np.float64).sum(axis)
+    tol = 1e-6 * np.abs(x).astype(np.float64).sum(axis)
+    assert np.all(np.abs(got - ref) <= tol + 1e-30), (shape, axis, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_reduce_max_min_exact(shape):
+  x = RNG.randn(*shape).astype(np.float32)
+  for axis in [None] + list(range(len(shape))):
+    np.testing.assert_array_equal(run_reduce(x, axis, 'MAX', _hip.SP_F32, np.float32), x.max(axis))
+    np.testing.assert_array_equal(run_reduce(x, axis, 'MIN', _hip.SP_F32, np.float32), x.min(axis))
+
+
+def test_reduce_integer_exact():
+  x = RNG.randint(-1000, 1000, size=(513, 129)).astype(np.int32)
+  for axis in (None, 0, 1):
+    np.testing.assert_array_equal(run_reduce(x, axis, 'SUM', _hip.SP_I64, np.int64), x.sum(axis, dtype=np.int64))
+  b = RNG.rand(100, 40) > 0.01
+  for axis in (None, 0, 1):
+    np.testing.assert_array_equal(run_reduce(b, axis, 'AND', _hip.SP_I64, np.bool_), np.all(b, axis))
+    np.testing.assert_array_equal(run_reduce(b, axis, 'OR', _hip.SP_I64, np.bool_), np.any(b, axis))
+  small = RNG.randint(1, 3, size=(3, 12)).astype(np.int64)
+  np.testing.assert_array_equal(run_reduce(small, 1, 'PROD', _hip.SP_I64, np.int64), small.prod(1))
+
+
+def test_reduce_fused_map_prologue():
+  # sum(x * (yp - y), axis=0): the lreg gradient (sgd.py:34-39) as ONE launch
+  x = RNG.rand(3000, 64).astype(np.float32)
+  yp = RNG.rand(3000, 1).astype(np.float32)
+  y = RNG.rand(3000, 1).astype(np.float32)
+
+  def body(p):
+    p.emit('SUB', 3, 1, 2)
+    p.emit('MUL', 3, 0, 3)
+    return 3
+  for axis in (0, 1, None):
+    got = run_reduce(x, axis, 'SUM', _hip.SP_F32, np.float32, body, extra=[yp, y])
+    ref = (x.astype(np.float64) * (yp.astype(np.float64) - y)).sum(axis)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-3)
+
+
+def run_arg(x, axis, which, offset=0, sentinel=-7):
+  shape = x.shape
+  if axis is None:
+    O, A, I = 1, x.size, 1
+  else:
+    O = int(np.prod(shape[:axis], dtype=np.int64))
+    A = shape[axis]
+    I = int(np.prod(shape[axis + 1:], dtype=np.int64))
+  p = Program()
+  p.add_input(x.dtype, dense_strides((O, A, I)))
+  prog = p.finish(_hip.SP_F32 if x.dtype == np.float32 else _hip.SP_I64, (O, A, I), None, True)
+  oi = torch.empty(max(O * I, 1), dtype=torch.int64, device=DEV)
+  ov = torch.empty(max(O * I, 1), dtype=torch.float32 if x.dtype == np.float32 else torch.int64, device=DEV)
+  kernels.argreduce(prog, [dev(x)], which, O, A, I, offset, sentinel, oi, ov)
+  torch.cuda.synchronize()
+  idx, val = host(oi), host(ov)
+  if axis is None:
+    return idx[0], val[0]
+  rs = shape[:axis] + shape[axis + 1:]
+  return idx.reshape(rs), val.reshape(rs)
+
+
+@pytest.mark.parametrize('shape', [(64, 64), (1000, 333), (5, 70000), (70000, 5), (17,), (3, 5, 7), (1024, 4096)])
+def test_argreduce_first_occurrence(shape):
+  # few distinct values => many ties: first occurrence must win (sorting.py:67-123)
+  x = RNG.randint(0, 4, size=shape).astype(np.float32)
+  for axis in [None] + list(range(len(shape))):
+    idx, val = run_arg(x, axis, 0, offset=100)
+    np.testing.assert_array_equal(idx, np.argmax(x, axis) + 100)
+    np.testing.assert_array_equal(val, x.max(axis))
+    idx, val = run_arg(x, axis, 1)
+    np.testing.assert_array_equal(idx, np.argmin(x, axis))
+    np.testing.assert_array_equal(val, x.min(axis))
+
+
+def test_argreduce_nan_sentinel():
+  x = RNG.rand(8, 16).astype(np.float32)
+  x[3, 5] = np.nan
+  idx, val = run_arg(x, 1, 0, sentinel=128)
+  ref = np.argmax(np.where(np.isnan(x), -np.inf, x), 1)
+  ref[3] = 128
+  np.testing.assert_array_equal(idx, ref)
+  assert np.isnan(val[3])
+
+
+# --------------------------------------------------------------------- merge
+def test_update_truth_table():
+  # tile.pyx:200-297, dense->dense branch (truth table captured in SURVEY 8c)
+  tile_shape = (6, 8)
+  t = torch.zeros(tile_shape, dtype=torch.float32, device=DEV)
+  mask = torch.zeros(tile_shape, dtype=torch.uint8, device=DEV)
+  u1 = RNG.rand(*tile_shape).astype(np.float32)
+  # full-tile first write on an empty tile: replace
+  kernels.update(t, (0, 0), tile_shape, dev(u1), 'ADD', _hip.MASK_ALL_CLEAR, None)
+  np.testing.assert_array_equal(host(t), u1)
+  # second full-tile write: accumulate
+  u2 = RNG.rand(*tile_shape).astype(np.float32)
+  kernels.update(t, (0, 0), tile_shape, dev(u2), 'ADD', _hip.MASK_ALL_SET, None)
+  np.testing.assert_array_equal(host(t), u1 + u2)
+  # reducer None: replace
+  kernels.update(t, (0, 0), tile_shape, dev(u2), 'NONE', _hip.MASK_ALL_SET, None)
+  np.testing.assert_array_equal(host(t), u2)
+  # sub-slice writes into an empty (zero-initialised) tile with an explicit mask
+  t.zero_()
+  s1 = RNG.rand(3, 4).astype(np.float32)
+  kernels.update(t, (1, 2), (4, 6), dev(s1), 'ADD', _hip.MASK_ARRAY, mask)
+  exp = np.zeros(tile_shape, np.float32)
+  exp[1:4, 2:6] = s1
+  expm = np.zeros(tile_shape, np.uint8)
+  expm[1:4, 2:6] = 1
+  np.testing.assert_array_equal(host(t), exp)
+  np.testing.assert_array_equal(host(mask), expm)
+  # overlapping second sub-slice: written cells reduced, new cells copied
+  s2 = RNG.rand(4, 4).astype(np.float32)
+  kernels.update(t, (2, 4), (6, 8), dev(s2), 'ADD', _hip.MASK_ARRAY, mask)
+  exp2 = exp.copy()
+  region = exp2[2:6, 4:8]
+  m = expm[2:6, 4:8].astype(bool)
+  region[m] = region[m] + s2[m]
+  region[~m] = s2[~m]
+  expm[2:6, 4:8] = 1
+  np.testing.assert_array_equal(host(t), exp2)
+  np.testing.assert_array_equal(host(mask), expm)
+
+
+def test_update_reducers_and_dtypes():
+  a = RNG.randint(-5, 5, size=(33, 17)).astype(np.int64)
+  b = RNG.randint(-5, 5, size=(33, 17)).astype(np.int64)
+  for name, fn in (('MAX', np.maximum), ('MIN', np.minimum), ('MUL', np.multiply), ('ADD', np.add)):
+    t = dev(a.copy())
+    kernels.update(t, (0, 0), a.shape, dev(b), name, _hip.MASK_ALL_SET, None)
+    np.testing.assert_array_equal(host(t), fn(a, b))
+  ba, bb = a > 0, b > 0
+  t = dev(ba.copy())
+  kernels.update(t, (0, 0), a.shape, dev(bb), 'AND', _hip.MASK_ALL_SET, None)
+  np.testing.assert_array_equal(host(t), np.logical_and(ba, bb))
+  # update.astype(old.dtype): float64 update into a float32 tile
+  t = torch.zeros((33, 17), dtype=torch.float32, device=DEV)
+  upd = RNG.rand(33, 17)
+  kernels.update(t, (0, 0), (33, 17), dev(upd), 'ADD', _hip.MASK_ALL_CLEAR, None)
+  np.testing.assert_array_equal(host(t), upd.astype(np.float32))
+  # 1-d and 3-d boxes
+  t = torch.zeros((4, 6, 8), dtype=torch.float64, device=DEV)
+  upd = RNG.rand(2, 3, 4)
+  kernels.update(t, (1, 2, 4), (3, 5, 8), dev(upd), 'NONE', _hip.MASK_ALL_CLEAR, None)
+  exp = np.zeros((4, 6, 8))
+  exp[1:3, 2:5, 4:8] = upd
+  np.testing.assert_array_equal(host(t), exp)
+
+
+def test_slice_copy():
+  src = RNG.rand(40, 48).astype(np.float32)
+  dst = torch.zeros((20, 16), dtype=torch.float32, device=DEV)
+  kernels.slice_copy(dst, 0, (16, 1), dev(src), 5 * 48 + 8, (48, 1), (20, 16))
+  np.testing.assert_array_equal(host(dst), src[5:25, 8:24])
+  src3 = RNG.randint(0, 100, size=(5, 7, 9)).astype(np.int64)
+  dst3 = torch.zeros((5, 7, 9), dtype=torch.int64, device=DEV)
+  kernels.slice_copy(dst3, 1 * 63 + 2 * 9 + 3, (63, 9, 1), dev(src3), 0, (63, 9, 1), (3, 4, 5))
+  exp = np.zeros((5, 7, 9), np.int64)
+  exp[1:4, 2:6, 3:8] = src3[0:3, 0:4, 0:5]
+  np.testing.assert_array_equal(host(dst3), exp)
+  b = RNG.rand(13, 7) > 0.5
+  db = torch.zeros((13, 7), dtype=torch.bool, device=DEV)
+  kernels.slice_copy(db, 0, (7, 1), dev(b), 0, (7, 1), (13, 7))
+  np.testing.assert_array_equal(host(db), b)
+
+
+# ---------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('mnk', [(256, 128, 16), (512, 512, 512), (100, 60, 30), (1000, 24, 37),
+                                 (257, 129, 17), (64, 2000, 2000), (1250, 1024, 256), (1, 1, 1)])
+def test_gemm_integer_valued_exact(mnk):
+  # small-integer operands: every partial sum is exact in fp32, so the result
+  # must be bit-identical to NumPy (the reference tests use arange/ones inputs,
+  # tests/test_dot.py:8-103)
+  M, N, K = mnk
+  a = RNG.randint(-3, 4, size=(M, K)).astype(np.float32)
+  b = RNG.randint(-3, 4, size=(K, N)).astype(np.float32)
+  c = torch.full((M, N), 7.0, dtype=torch.float32, device=DEV)
+  kernels.gemm_f32(dev(a), dev(b), c, accumulate=False)
+  np.testing.assert_array_equal(host(c), a.dot(b))
+  kernels.gemm_f32(dev(a), dev(b), c, accumulate=True)
+  np.testing.assert_array_equal(host(c), 2 * a.dot(b))
+
+
+def test_gemm_random_tolerance_and_transpose_detect():
+  M, N, K = 768, 640, 1024
+  a = (RNG.rand(M, K) * 2 - 1).astype(np.float32)
+  b = (RNG.rand(K, N) * 2 - 1).astype(np.float32)
+  c = torch.empty((M, N), dtype=torch.float32, device=DEV)
+  kernels.gemm_f32(dev(a), dev(b), c)
+  ref = a.astype(np.float64).dot(b.astype(np.float64))
+  # |dC| <= 2 K eps max|a| max|b|
+  assert np.abs(host(c) - ref).max() <= 2 * K * np.finfo(np.float32).eps
+  # A = I with an asymmetric B catches a row/col swap in the C write
+  eye = np.eye(256, dtype=np.float32)
+  bb = np.arange(256 * 128, dtype=np.float32).reshape(256, 128)
+  c2 = torch.empty((256, 128), dtype=torch.float32, device=DEV)
+  kernels.gemm_f32(dev(eye), dev(bb), c2)
+  np.testing.assert_array_equal(host(c2), bb)
+
+
+def test_gemm_strided_views():
+  # K-slab of A and row-slab of B taken as views (the map2 join of dot.py:195-217)
+  a = RNG.randint(-2, 3, size=(128, 512)).astype(np.float32)
+  b = RNG.randint(-2, 3, size=(512, 256)).astype(np.float32)
+  da, db = dev(a), dev(b)
+  c = torch.zeros((128, 256), dtype=torch.float32, device=DEV)
+  for k0 in range(0, 512, 128):
+    kernels.gemm_f32(da[:, k0:k0 + 128], db[k0:k0 + 128, :], c, accumulate=True)
+  np.testing.assert_array_equal(host(c), a.dot(b))
+
+
+def test_errors_are_loud():
+  with pytest.raises(_hip.HipError):
+    kernels.gemm_f32(torch.zeros(4, 4), torch.zeros(4, 4), torch.zeros(4, 4))

@@ -1,0 +1,108 @@
+"""Kernel micro-benchmarks (HIP-event timed on the launch stream).  Prints one
+line per kernel/config; used to pick defaults and to fill profiles/."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spartan_amd import _hip, kernels  # noqa: E402
+from spartan_amd.program import Program, dense_strides  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def timeit(fn, iters=10, warmup=3):
+  for _ in range(warmup):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = kernels.Event(), kernels.Event()
+  e0.record()
+  for _ in range(iters):
+    fn()
+  e1.record()
+  e1.synchronize()
+  return e0.elapsed_ms(e1) / iters
+
+
+def bench_copy(nbytes):
+  a = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+  b = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+  ms = timeit(lambda: kernels.stream_copy(b, a))
+  print('stream_copy  %6.2f GiB  %8.3f ms  %8.1f GB/s (read+write)' % (nbytes / 2**30, ms, 2 * nbytes / ms / 1e6))
+
+
+def map_prog(n, nops, shape=None):
+  p = Program()
+  shape = shape or (n,)
+  p.add_input(np.float32, dense_strides(shape))
+  if nops == 1:
+    c = p.add_const(1.0)
+    p.emit('CONST', 1, c)
+    p.emit('ADD', 1, 0, 1)
+  else:
+    p.emit('MUL', 1, 0, 0)
+    p.emit('ADD', 1, 1, 0)
+    for _ in range(nops - 2):
+      p.emit('ADD', 1, 1, 0)
+  p.result_reg = 1
+  return p.finish(_hip.SP_F32, shape, np.float32, True)
+
+
+def bench_map(n):
+  x = torch.rand(n, dtype=torch.float32, device=DEV)
+  out = torch.empty_like(x)
+  for nops, name in ((1, 'x+1'), (2, 'x*x+x'), (6, '6-op chain'), (12, '12-op chain')):
+    prog = map_prog(n, nops)
+    ms = timeit(lambda: kernels.map_fused(prog, [x], out))
+    print('map %-12s n=%.2e  %8.3f ms  %8.1f GB/s (8 B/elem)' % (name, n, ms, 8.0 * n / ms / 1e6))
+
+
+def bench_reduce(rows, cols):
+  x = torch.rand(rows, cols, dtype=torch.float32, device=DEV)
+  n = rows * cols
+  for axis in (None, 0, 1):
+    if axis is None:
+      O, A, I = 1, n, 1
+    elif axis == 0:
+      O, A, I = 1, rows, cols
+    else:
+      O, A, I = rows, cols, 1
+    p = Program()
+    p.add_input(np.float32, dense_strides((O, A, I)))
+    prog = p.finish(_hip.SP_F32, (O, A, I), None, True)
+    out = torch.empty(O * I, dtype=torch.float32, device=DEV)
+    ms = timeit(lambda: kernels.reduce(prog, [x], 'SUM', O, A, I, out))
+    print('sum axis=%-4s %dx%d  %8.3f ms  %8.1f GB/s (4 B/elem)' % (axis, rows, cols, ms, 4.0 * n / ms / 1e6))
+    oi = torch.empty(O * I, dtype=torch.int64, device=DEV)
+    ms = timeit(lambda: kernels.argreduce(prog, [x], 0, O, A, I, 0, n, oi, out))
+    print('argmax axis=%-4s %dx%d  %8.3f ms  %8.1f GB/s (4 B/elem)' % (axis, rows, cols, ms, 4.0 * n / ms / 1e6))
+
+
+def bench_gemm(M, N, K, variants=(0, 1, 2, 3)):
+  a = torch.rand(M, K, dtype=torch.float32, device=DEV) * 2 - 1
+  b = torch.rand(K, N, dtype=torch.float32, device=DEV) * 2 - 1
+  c = torch.empty(M, N, dtype=torch.float32, device=DEV)
+  for v in variants:
+    os.environ['SP_GEMM_VARIANT'] = str(v)
+    # the variant is latched on first use inside the library: one process per variant
+    ms = timeit(lambda: kernels.gemm_f32(a, b, c), iters=5, warmup=2)
+    print('gemm v%d %dx%dx%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 157.3)' % (
+        v, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9 / 157.3 * 100))
+    break
+
+
+if __name__ == '__main__':
+  what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+  if what in ('all', 'copy'):
+    bench_copy(2 << 30)
+  if what in ('all', 'map'):
+    bench_map(1 << 29)
+  if what in ('all', 'reduce'):
+    bench_reduce(8192, 65536)
+    bench_reduce(125000, 4096)
+  if what == 'gemm':
+    M, N, K = [int(v) for v in sys.argv[2:5]]
+    bench_gemm(M, N, K)
