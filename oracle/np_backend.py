@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE -- not part of the product path.
+
+A NumPy tile-kernel backend for the spartan_amd host framework: it evaluates
+LocalExpr trees the way the reference's worker does (call the local function on
+NumPy tiles, spartan/expr/operator/local.py:115-127) and applies Tile.merge with
+NumPy (spartan/array/tile.pyx:200-297).  It exists so that
+
+  * `-m "not gpu"` tests can run the host logic (tiling, extents, DAG, fusion,
+    fetch/update plans, the gloo world_size-2 exchange) without a GPU, and
+  * bench.py can time a CPU baseline of the same workload on the host cores.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  `spartan_amd.initialize()` never selects it by itself.
+
+Tile payloads are torch CPU tensors (so torch.distributed/gloo can move them);
+all arithmetic is NumPy on views of them.
+"""
+import numpy as np
+import torch
+
+from spartan_amd.array import distarray, tile
+from spartan_amd.expr.local import FnCallExpr, LocalInput, LocalMapLocationExpr
+
+_REDUCERS = {None: 'NONE', np.add: 'ADD', np.multiply: 'MUL', np.maximum: 'MAX', np.minimum: 'MIN',
+             np.logical_and: 'AND', np.logical_or: 'OR'}
+_NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+         np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64,
+         np.dtype(np.bool_): torch.bool, np.dtype(np.uint8): torch.uint8}
+_T2NP = {v: k for k, v in _NP2T.items()}
+
+
+def _np(x):
+  """NumPy view of a local value."""
+  if isinstance(x, torch.Tensor):
+    return x.numpy()
+  if isinstance(x, tile.EmptyBlob):
+    return np.ndarray(x.shape, x.dtype)  # uninitialised, like tile.pyx:72-79
+  return x
+
+
+class NumpyBackend(object):
+  name = 'numpy-oracle'
+
+  def __init__(self):
+    self.launches = 0
+    self._np_cache = {}
+
+  # -- memory
+  def empty(self, shape, dtype):
+    return torch.empty(tuple(int(s) for s in shape), dtype=_NP2T[np.dtype(dtype)])
+
+  def zeros(self, shape, dtype):
+    return torch.zeros(tuple(int(s) for s in shape), dtype=_NP2T[np.dtype(dtype)])
+
+  def from_numpy(self, arr):
+    arr = np.asarray(arr)
+    arr = arr if arr.flags['C_CONTIGUOUS'] else arr.copy(order='C')  # (ascontiguousarray would make 0-d -> 1-d)
+    if arr.dtype not in _NP2T:
+      raise TypeError('unsupported dtype %s' % arr.dtype)
+    return torch.from_numpy(arr.copy())
+
+  def to_numpy(self, t):
+    if isinstance(t, np.ndarray):
+      return t
+    if isinstance(t, tile.EmptyBlob):
+      return np.zeros(t.shape, t.dtype)
+    return t.numpy().copy()
+
+  def dtype_of(self, t):
+    if isinstance(t, torch.Tensor):
+      return _T2NP[t.dtype]
+    if isinstance(t, (tile.EmptyBlob, distarray.Absent, np.ndarray, np.generic)):
+      return np.dtype(t.dtype)
+    return np.asarray(t).dtype
+
+  def same_dtype(self, t, dtype):
+    return self.dtype_of(t) == np.dtype(dtype)
+
+  def contiguous(self, t):
+    return t.contiguous()
+
+  def copy(self, t):
+    return t.clone().contiguous()
+
+  def astype(self, t, dtype):
+    if self.dtype_of(t) == np.dtype(dtype):
+      return t
+    return self.from_numpy(_np(t).astype(dtype))
+
+  def cached_numpy(self, arr, slices):
+    return self.from_numpy(arr[slices])
+
+  def reducer_name(self, fn):
+    return _REDUCERS.get(fn, 'CALLABLE')
+
+  def paste(self, dst, dst_slices, src):
+    view = dst[dst_slices] if dst.dim() else dst
+    view.copy_(src.reshape(view.shape))
+
+  # -- Tile.merge (tile.pyx:250-283), on the box [ul, lr)
+  def update_box(self, dst, ul, lr, src, reducer, mask_mode, mask):
+    self.launches += 1
+    d = dst.numpy()
+    s = _np(src)
+    if d.ndim == 0:
+      d[...] = reducer(d, s) if reducer is not None else s
+      return
+    box = tuple(slice(u, l) for u, l in zip(ul, lr))
+    s = s.reshape(d[box].shape)
+    if mask_mode == 2:
+      m = mask.numpy()[box].astype(bool)
+    else:
+      m = np.full(d[box].shape, mask_mode == tile.MASK_ALL_SET, dtype=bool)
+    region = d[box]
+    replaced = ~m
+    if np.any(replaced):
+      region[replaced] = s[replaced]
+    if np.any(m):
+      if reducer is not None:
+        region[m] = reducer(region[m], s[m])
+      else:
+        region[m] = s[m]
+    if mask is not None:
+      mask.numpy()[box] = 1
+
+  def mask_all_set(self, mask, subslice):
+    return bool(np.all(mask.numpy()[subslice]))
+
+  def mask_first(self, mask):
+    return bool(mask.numpy().reshape(-1)[0])
+
+  # -- LocalExpr evaluation exactly as the reference worker does it
+  def _eval(self, op, inputs, ex):
+    if isinstance(op, LocalInput):
+      if op.idx == 'extent':
+        return ex
+      v = inputs[op.idx]
+      return _np(v)
+    assert isinstance(op, FnCallExpr), op
+    if isinstance(op, LocalMapLocationExpr):
+      deps = []
+      for d in op.deps:
+        if isinstance(d, LocalInput) and d.idx == 'extent':
+          deps.append(ex.to_tuple())  # local.py:137-149
+        else:
+          deps.append(self._eval(d, inputs, ex))
+    else:
+      deps = [self._eval(d, inputs, ex) for d in op.deps]
+    with np.errstate(all='ignore'):
+      return op.fn(*deps, **op.kw)
+
+  def _wrap(self, result, shape=None):
+    result = np.asarray(result)
+    if shape is not None and result.shape != tuple(shape):
+      result = np.broadcast_to(result, shape)
+    return self.from_numpy(result)
+
+  def evaluate_map(self, op, inputs, ex):
+    self.launches += 1
+    return self._wrap(self._eval(op, inputs, ex), ex.shape)
+
+  def evaluate_fn(self, fn, args, kw, out_shape):
+    self.launches += 1
+    return self._wrap(fn(*[_np(a) for a in args], **kw), out_shape)
+
+  def evaluate_reduce(self, op, inputs, ex, axis):
+    self.launches += 1
+    return self._wrap(self._eval(op, inputs, ex))
+
+  def evaluate_argreduce(self, data, ex, axis, which, index_offset, nan_index):
+    """Per-tile part of sorting.py:67-123 (value + first index)."""
+    self.launches += 1
+    x = _np(data)
+    val = x.max(axis) if which == 0 else x.min(axis)
+    idx = (np.argmax(x, axis) if which == 0 else np.argmin(x, axis)).astype(np.int64) + index_offset
+    idx = np.where(np.isnan(val), nan_index, idx) if val.dtype.kind == 'f' else idx
+    return self._wrap(np.asarray(idx, dtype=np.int64)), self._wrap(val)
+
+  def dot(self, a, b):
+    self.launches += 1
+    return self._wrap(_np(a).dot(_np(b)))
+
+  def synchronize(self):
+    pass

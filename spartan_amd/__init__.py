@@ -1,3 +1,80 @@
 """spartan_amd: an MI355X-native tile-execution backend behind the Spartan
-expression-builder API."""
+expression-builder API.
+
+    import spartan_amd as spartan
+    spartan.initialize()                       # one process per GPU (RANK/WORLD_SIZE aware)
+    x = spartan.ones((1000, 1000)) + 1
+    y = x.force()                              # == x.evaluate(): a DistArray of HBM tiles
+    y.glom()                                   # NumPy array
+
+The public names mirror the reference's `spartan` / `spartan.expr` namespaces
+(reference spartan/__init__.py, spartan/expr/__init__.py:26-93).  See DESIGN.md.
+"""
 __version__ = '0.1.0'
+
+import numpy as _np
+
+from . import context as _context
+from .array import distarray, extent, tile  # noqa: F401
+from .comm import World
+from .expr.base import (Expr, NotShapeable, Val, as_array, eager, evaluate, glom, lazify,  # noqa: F401
+                        newaxis, optimized_dag)
+from .expr.broadcast import broadcast  # noqa: F401
+from .expr.builtins import *  # noqa: F401,F403
+from .expr.builtins import (abs, all, any, max, min, sum)  # noqa: F401  (shadow the builtins, like spartan.expr)
+from .expr.dot import dot  # noqa: F401
+from .expr.map import map, map2, map_with_location  # noqa: F401
+from .expr.ndarray import ndarray  # noqa: F401
+from .expr.optimize import optimize  # noqa: F401
+from .expr.outer import outer  # noqa: F401
+from .expr.reduce import reduce  # noqa: F401
+from .expr.shuffle import shuffle  # noqa: F401
+
+# ndarray-style methods on expressions (spartan/expr/__init__.py:66-92)
+Expr.all = all
+Expr.any = any
+Expr.argmax = argmax  # noqa: F405
+Expr.argmin = argmin  # noqa: F405
+Expr.astype = astype  # noqa: F405
+Expr.dot = dot
+Expr.max = max
+Expr.mean = mean  # noqa: F405
+Expr.min = min
+Expr.prod = prod  # noqa: F405
+Expr.std = std  # noqa: F405
+Expr.sum = sum
+distarray.DistArray.evaluate = evaluate
+distarray.DistArray.force = evaluate
+
+
+def initialize(backend='hip', num_workers=None, world=None):
+  """Create the process-wide worker context (reference spartan.initialize,
+  spartan/__init__.py:42-56: start_cluster + blob_ctx).
+
+  backend: 'hip' (the product path: HIP kernels on the local MI355X; raises if
+    the GPU or the built library is missing -- there is no CPU fallback), or a
+    backend OBJECT (the test-suite injects oracle.np_backend.NumpyBackend to
+    exercise the host logic without a GPU).
+  num_workers: logical workers (default: one per process).
+  world: a spartan_amd.World (default: from RANK/WORLD_SIZE, else 1 process).
+  """
+  if world is None:
+    world = World.from_env()
+  if backend == 'hip':
+    from .backend_hip import HipBackend
+    backend = HipBackend()
+  elif isinstance(backend, str):
+    raise ValueError("unknown backend %r: the product backend is 'hip'" % backend)
+  ctx = _context.Context(backend, world, num_workers)
+  _context.set(ctx)
+  from .expr import base as _base
+  _base.eval_cache.clear()
+  return ctx
+
+
+def shutdown():
+  _context.set(None)
+
+
+def get_context():
+  return _context.get()

@@ -1,0 +1,644 @@
+"""Distributed arrays: tiling, fetch (gather + stitch) and update (split +
+scatter-with-reduce).
+
+Host-side mirror of the reference's spartan/array/distarray.py.  Tile payloads
+live in HBM as backend tensors; the reference's per-tile `get`/`update` RPCs
+become grouped RCCL point-to-point transfers or, for the regular patterns of
+the hot path, one collective (see `UpdateBatch.flush` and `DistArrayImpl.glom`).
+"""
+import collections
+import itertools
+
+import numpy as np
+
+from . import extent, tile
+from .. import context
+from ..context import LocalKernelResult, TileId
+from ..util import Assert
+
+# number of elements per tile (distarray.py:19)
+DEFAULT_TILE_SIZE = 100000
+
+
+def take_first(a, b):
+  return a
+
+
+def good_tile_shape(shape, num_shards=-1):
+  """distarray.py:26-48 (Python-2 integer division at :36,:45)."""
+  if num_shards != -1:
+    tile_size = int(np.prod(shape, dtype=np.int64)) // num_shards
+  else:
+    tile_size = DEFAULT_TILE_SIZE
+  tile_shape = [1] * len(shape)
+  idx = len(shape) - 1
+  while tile_size > 1:
+    tile_shape[idx] = min(shape[idx], tile_size)
+    tile_size //= shape[idx]
+    idx -= 1
+  return tile_shape
+
+
+def compute_splits(shape, tile_hint):
+  """distarray.py:51-70."""
+  splits = [None] * len(shape)
+  for dim in range(len(shape)):
+    dim_splits = []
+    step = tile_hint[dim]
+    for i in range(0, shape[dim], step):
+      dim_splits.append((i, min(shape[dim], i + step)))
+    splits[dim] = dim_splits
+  return splits
+
+
+def compute_extents(shape, tile_hint=None, num_shards=-1):
+  """distarray.py:73-110: {extent: shard index}, round-robin in product order."""
+  if len(shape) == 0:
+    return {extent.create([], [], ()): 0}
+  if tile_hint is None:
+    tile_hint = good_tile_shape(shape, num_shards)
+  else:
+    Assert.eq(len(tile_hint), len(shape),
+              '#dimensions in tile hint does not match shape %s vs %s' % (tile_hint, shape))
+  splits = compute_splits(shape, tile_hint)
+  result = collections.OrderedDict()
+  idx = 0
+  for slc in itertools.product(*splits):
+    if num_shards != -1:
+      idx = idx % num_shards
+    ul, lr = zip(*slc)
+    ex = extent.create(ul, lr, shape)
+    result[ex] = idx
+    idx += 1
+  return result
+
+
+def _tile_mapper(tile_id, blob, array=None, user_fn=None, **kw):
+  """distarray.py:113-116."""
+  ex = array.extent_for_blob(tile_id)
+  return user_fn(ex, **kw)
+
+
+class Absent(object):
+  """Stands for tile data that lives on another rank (this rank is not the
+  one executing the current mapper); carries shape/dtype only."""
+  __slots__ = ('shape', 'dtype')
+
+  def __init__(self, shape, dtype):
+    self.shape = tuple(shape)
+    self.dtype = np.dtype(dtype)
+
+  def reshape(self, *shape):
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+      shape = tuple(shape[0])
+    return Absent(shape, self.dtype)
+
+
+def _slices_shape(slices, base_shape):
+  shp = []
+  for slc, n in zip(slices, base_shape):
+    start, stop, _ = slc.indices(n)
+    shp.append(max(stop - start, 0))
+  return tuple(shp)
+
+
+class DistArray(object):
+  """distarray.py:119-215."""
+
+  def fetch(self, ex):
+    raise NotImplementedError
+
+  def update(self, ex, data):
+    raise NotImplementedError
+
+  def foreach_tile(self, mapper_fn, kw):
+    raise NotImplementedError
+
+  def extent_for_blob(self, id):
+    raise NotImplementedError
+
+  def real_size(self):
+    return int(np.prod(self.shape, dtype=np.int64))
+
+  def __len__(self):
+    return self.shape[0]
+
+  def __repr__(self):
+    return '%s(id=%s, shape=%s, dtype=%s)' % (self.__class__.__name__, id(self), self.shape, self.dtype)
+
+  def select(self, idx):
+    if isinstance(idx, extent.TileExtent):
+      return self.fetch(idx)
+    if np.isscalar(idx):
+      result = self.select(slice(idx, idx + 1))
+      return result[0]
+    ex = extent.from_slice(idx, self.shape)
+    return self.fetch(ex)
+
+  def __getitem__(self, idx):
+    return self.select(idx)
+
+  def glom(self):
+    """distarray.py:198-200: the whole array as a NumPy array (on every rank)."""
+    ctx = context.get()
+    return ctx.backend.to_numpy(self.select(np.index_exp[:]))
+
+  def map_to_array(self, mapper_fn, kw=None):
+    """distarray.py:202-208."""
+    results = self.foreach_tile(mapper_fn=mapper_fn, kw=kw)
+    extents = collections.OrderedDict()
+    for tile_id, d in results.items():
+      for ex, id in d:
+        extents[ex] = id
+    return from_table(extents)
+
+  def __hash__(self):
+    return id(self)
+
+  @property
+  def ndim(self):
+    return len(self.shape)
+
+
+class UpdateBatch(object):
+  """Updates issued while one kernel (foreach_tile) runs, joined at its end --
+  the reference collects `target.update(..., wait=False)` futures and joins them
+  after the tile loop (worker.py:266, rpc FutureGroup).  Batching lets the
+  regular patterns of the hot path be carried by ONE RCCL collective instead of
+  per-tile messages:
+
+    every worker contributes a partial covering the WHOLE target, reducer is
+    np.add / maximum / minimum and
+      - the target is one tile             -> reduce to its owner
+      - the target is evenly tiled, one
+        contiguous chunk per rank in order -> reduce-scatter
+    anything else                          -> grouped send/recv + merge at owner,
+                                              in the deterministic tile order.
+  """
+
+  def __init__(self, ctx):
+    self.ctx = ctx
+    self.items = []  # (array, exec_worker, region, data, owned)
+
+  def add(self, array, region, data, owned):
+    self.items.append((array, self.ctx.current_worker, region, data, owned))
+
+  # -- helpers
+  def _collective_plan(self, array, items):
+    """Return ('reduce', dst_rank) / ('reduce_scatter',) / None."""
+    ctx = self.ctx
+    world = ctx.world
+    if not world.distributed:
+      return None
+    red = ctx.backend.reducer_name(array.reducer_fn)
+    if red not in ('ADD', 'MAX', 'MIN', 'MUL'):
+      return None
+    if np.dtype(array.dtype).kind not in 'fiu':
+      return None
+    if ctx.num_workers != world.size:
+      return None
+    # exactly one whole-array contribution per rank, from that rank's own worker
+    if len(items) != world.size:
+      return None
+    seen = set()
+    for (_, worker, region, data, _) in items:
+      if worker is None or region.shape != tuple(array.shape) or region.ul != (0,) * len(array.shape):
+        return None
+      seen.add(ctx.rank_of(worker))
+    if len(seen) != world.size:
+      return None
+    # untouched target only: the first write replaces (tile.pyx:263-268), so
+    # "reduce of the partials" is exactly what arrival-order merging produces
+    # (`_touched` is array metadata kept identically on every rank)
+    if getattr(array, '_touched', False):
+      return None
+    tiles = list(array.tiles.items())
+    if len(tiles) == 1:
+      return ('reduce', ctx.rank_of(tiles[0][1].worker))
+    if len(tiles) == world.size and len(array.shape) >= 1:
+      # contiguous equal chunks in rank order <=> split along dim 0 only
+      n0 = array.shape[0]
+      if n0 % world.size != 0:
+        return None
+      step = n0 // world.size
+      for ex, tid in tiles:
+        r = ctx.rank_of(tid.worker)
+        if ex.ul[0] != r * step or ex.lr[0] != (r + 1) * step:
+          return None
+        if ex.ul[1:] != (0,) * (len(array.shape) - 1) or ex.lr[1:] != tuple(array.shape[1:]):
+          return None
+      return ('reduce_scatter',)
+    return None
+
+  def flush(self):
+    ctx = self.ctx
+    be = ctx.backend
+    world = ctx.world
+    by_array = collections.OrderedDict()
+    for it in self.items:
+      by_array.setdefault(id(it[0]), []).append(it)
+    self.items = []
+    for items in by_array.values():
+      array = items[0][0]
+      plan = self._collective_plan(array, items)
+      if plan is not None:
+        mine = [it for it in items if ctx.is_local_worker(it[1])][0]
+        data = mine[3]
+        red = be.reducer_name(array.reducer_fn)
+        array._touched = True
+        data = be.astype(data, array.dtype)
+        if plan[0] == 'reduce':
+          buf = data if (mine[4] or data is not mine[3]) else be.copy(data)
+          world.reduce(buf, plan[1], red)
+          if world.rank == plan[1]:
+            (ex, tid), = array.tiles.items()
+            ctx.tile(tid).update(be, None, buf, array.reducer_fn, owned=True)
+        else:
+          my_tid = [tid for tid in array.tiles.values() if ctx.is_local(tid)][0]
+          t = ctx.tile(my_tid)
+          out = be.empty(t.shape, t.dtype)
+          world.reduce_scatter(out, be.contiguous(data), red)
+          t.update(be, None, out, array.reducer_fn, owned=True)
+        continue
+      # generic path: explicit transfers, merged in issue order
+      array._touched = True
+      sends, recvs, merges = [], [], []
+      for (_, worker, region, data, owned) in items:
+        exec_rank = world.rank if worker is None else ctx.rank_of(worker)
+        for tile_id, src_slice, dst_slice in array._update_splits(region):
+          owner = ctx.rank_of(tile_id.worker)
+          whole = _slices_shape(src_slice, region.shape) == tuple(region.shape)
+          if exec_rank == world.rank and owner == world.rank:
+            piece = data if whole else data[src_slice]
+            merges.append((tile_id, dst_slice, piece, owned and whole))
+          elif exec_rank == world.rank:
+            piece = data if whole else data[src_slice]
+            sends.append((owner, be.contiguous(be.astype(piece, array.dtype))))
+          elif owner == world.rank:
+            buf = be.empty(_slices_shape(src_slice, region.shape), array.dtype)
+            recvs.append((exec_rank, buf))
+            merges.append((tile_id, dst_slice, buf, True))
+      if sends or recvs:
+        world.exchange(sends, recvs)
+      for tile_id, dst_slice, piece, owned in merges:
+        t = ctx.tile(tile_id)
+        full = tuple(piece.shape) == t.shape
+        t.update(be, None if full else dst_slice, piece, array.reducer_fn, owned=owned and full)
+
+
+class DistArrayImpl(DistArray):
+  """distarray.py:223-422."""
+  _ids = itertools.count()
+
+  def __init__(self, shape, dtype, tiles, reducer_fn, sparse=False):
+    self.shape = tuple(int(s) for s in shape)
+    self.dtype = np.dtype(dtype)
+    self.reducer_fn = reducer_fn
+    self.sparse = sparse
+    self.bad_tiles = []
+    self.ctx = context.get()
+    Assert.not_null(dtype)
+    self.blob_to_ex = {}
+    for k, v in tiles.items():
+      Assert.isinstance(k, extent.TileExtent)
+      Assert.isinstance(v, TileId)
+      self.blob_to_ex[v] = k
+    self.tiles = tiles
+    self.id = next(DistArrayImpl._ids)
+    pend = self.ctx.pending_destructors
+    if pend:
+      self.ctx.destroy_all(pend)
+      del pend[:]
+
+  def __del__(self):
+    # destruction is deferred to the next safe point (distarray.py:256-268)
+    try:
+      self.ctx.pending_destructors.extend(self.tiles.values())
+    except Exception:
+      pass
+
+  def extent_for_blob(self, id):
+    return self.blob_to_ex[id]
+
+  def tile_shape(self):
+    """distarray.py:276-281: most common tile shape."""
+    scounts = collections.defaultdict(int)
+    for ex in self.tiles.keys():
+      scounts[ex.shape] += 1
+    return sorted(scounts.items(), key=lambda kv: (kv[1], kv[0]))[-1][0]
+
+  # -- kernel dispatch ---------------------------------------------------------
+  def foreach_tile(self, mapper_fn, kw=None):
+    """distarray.py:283-292 + blob_ctx.map (blob_ctx.py:256-275) +
+    Worker._run_kernel (worker.py:232-315).  The tile loop runs on every rank
+    in the same order; see context.Context."""
+    if kw is None:
+      kw = {}
+    return run_kernel(self, list(self.tiles.values()), mapper_fn, kw)
+
+  # -- data plane --------------------------------------------------------------
+  def _tile_piece(self, tile_id, ex, intersection):
+    """Tile.get(offset_slice) on the owning rank."""
+    ctx = self.ctx
+    t = ctx.tile(tile_id)
+    return t.get(ctx.backend, extent.offset_slice(ex, intersection))
+
+  def fetch(self, region):
+    """distarray.py:294-367.  Inside a kernel the data is delivered to the rank
+    owning the executing worker (other ranks get `Absent` and just serve their
+    pieces); at driver level every rank receives it (replicated fetch)."""
+    Assert.isinstance(region, extent.TileExtent)
+    Assert.eq(region.array_shape, self.shape)
+    assert all(l <= s for l, s in zip(region.lr, self.shape)), \
+        'Requested region is out of bounds: %s > %s' % (region, self.shape)
+    ctx = self.ctx
+    be = ctx.backend
+    world = ctx.world
+    replicated = ctx.current_worker is None
+    dst_rank = None if replicated else ctx.rank_of(ctx.current_worker)
+    want = replicated or dst_rank == world.rank
+
+    if region in self.tiles:  # exact tile (distarray.py:310-315)
+      splits = [(region, region)]
+    else:
+      splits = list(extent.find_overlapping(self.tiles.keys(), region))
+
+    if not world.distributed:
+      pieces = [self._tile_piece(self.tiles[ex], ex, inter) for ex, inter in splits]
+      if len(splits) == 1:
+        return pieces[0]
+      return self._stitch(region, splits, pieces)
+
+    # distributed: owners serve, the destination(s) assemble
+    if len(splits) == 1:
+      ex, inter = splits[0]
+      tid = self.tiles[ex]
+      owner = ctx.rank_of(tid.worker)
+      shape = inter.shape if inter is not None else region.shape
+      if replicated:
+        pshape = _slices_shape(extent.offset_slice(ex, inter), ex.shape)
+        if owner == world.rank:
+          piece = self._tile_piece(tid, ex, inter)
+          if isinstance(piece, tile.EmptyBlob):
+            piece = be.zeros(pshape, self.dtype)  # never-written tile: serve zeros
+          buf = be.contiguous(piece)
+          world.broadcast(buf, owner)
+          return piece
+        buf = be.empty(pshape, self.dtype)
+        world.broadcast(buf, owner)
+        return buf
+      if owner == dst_rank:
+        if want:
+          return self._tile_piece(tid, ex, inter)
+        return Absent(shape, self.dtype)
+      if owner == world.rank:
+        world.exchange([(dst_rank, be.contiguous(self._tile_piece(tid, ex, inter)))], [])
+        return Absent(shape, self.dtype)
+      if want:
+        buf = be.empty(_slices_shape(extent.offset_slice(ex, inter), ex.shape), self.dtype)
+        world.exchange([], [(owner, buf)])
+        return buf
+      return Absent(shape, self.dtype)
+
+    if replicated:
+      return self._fetch_replicated(region, splits)
+
+    sends, recvs, pieces = [], [], []
+    for ex, inter in splits:
+      tid = self.tiles[ex]
+      owner = ctx.rank_of(tid.worker)
+      if want:
+        if owner == world.rank:
+          pieces.append(self._tile_piece(tid, ex, inter))
+        else:
+          buf = be.empty(inter.shape, self.dtype)
+          recvs.append((owner, buf))
+          pieces.append(buf)
+      elif owner == world.rank:
+        sends.append((dst_rank, be.contiguous(self._tile_piece(tid, ex, inter))))
+    world.exchange(sends, recvs)
+    if not want:
+      return Absent(region.shape, self.dtype)
+    return self._stitch(region, splits, pieces)
+
+  def _stitch(self, region, splits, pieces):
+    """distarray.py:355-365: allocate the region and paste the pieces."""
+    be = self.ctx.backend
+    if any(isinstance(p, tile.EmptyBlob) for p in pieces):
+      return tile.EmptyBlob(region.shape, self.dtype)
+    tgt = be.empty(region.shape, self.dtype)
+    for (ex, inter), piece in zip(splits, pieces):
+      dst_slice = extent.offset_slice(region, inter)
+      if extent.all_nonzero_shape(piece.shape):
+        be.paste(tgt, dst_slice, piece)
+    return tgt
+
+  def _fetch_replicated(self, region, splits):
+    """Every rank assembles `region` (glom and driver-level fetches): one
+    all-gather when the pieces are the equal-size, one-per-rank, rank-ordered
+    row blocks of the default tiling; per-piece broadcasts otherwise."""
+    ctx = self.ctx
+    be = ctx.backend
+    world = ctx.world
+    owners = [ctx.rank_of(self.tiles[ex].worker) for ex, _ in splits]
+    order = sorted(range(len(splits)), key=lambda i: splits[i][1].ul)
+    regular = (len(splits) == world.size and sorted(owners) == list(range(world.size)) and
+               len(set(inter.shape for _, inter in splits)) == 1)
+    if regular:
+      # rank-ordered contiguous row blocks of `region`?
+      for pos, i in enumerate(order):
+        ex, inter = splits[i]
+        if owners[i] != pos or inter.ul[1:] != region.ul[1:] or inter.lr[1:] != region.lr[1:]:
+          regular = False
+          break
+    if regular:
+      mine = [i for i in range(len(splits)) if owners[i] == world.rank][0]
+      ex, inter = splits[mine]
+      piece = be.contiguous(self._tile_piece(self.tiles[ex], ex, inter))
+      tgt = be.empty(region.shape, self.dtype)
+      world.all_gather_into(tgt, piece)
+      return tgt
+    tgt = be.empty(region.shape, self.dtype)
+    for (ex, inter), owner in zip(splits, owners):
+      if owner == world.rank:
+        buf = be.contiguous(self._tile_piece(self.tiles[ex], ex, inter))
+      else:
+        buf = be.empty(inter.shape, self.dtype)
+      world.broadcast(buf, owner)
+      if extent.all_nonzero_shape(buf.shape):
+        be.paste(tgt, extent.offset_slice(region, inter), buf)
+    return tgt
+
+  def update_slice(self, slc, data):
+    return self.update(extent.from_slice(slc, self.shape), data)
+
+  def _update_splits(self, region):
+    """distarray.py:378-408: [(tile_id, src_slice, dst_slice)] sorted by the
+    first-dimension start of the source slice."""
+    if region in self.tiles:
+      return [(self.tiles[region], extent.offset_slice(region, region), extent.offset_slice(region, region))]
+    slices = []
+    if region.shape == self.shape:
+      for ex, tile_id in self.tiles.items():
+        slices.append((tile_id, ex.to_slice(), extent.offset_slice(ex, ex)))
+    else:
+      for dst_extent, intersection in extent.find_overlapping(self.tiles, region):
+        tile_id = self.tiles[dst_extent]
+        src_slice = extent.offset_slice(region, intersection)
+        dst_slice = extent.offset_slice(dst_extent, intersection)
+        shape = [s.stop - s.start for s in dst_slice]
+        if extent.all_nonzero_shape(shape):
+          slices.append((tile_id, src_slice, dst_slice))
+    if slices and len(slices[0][1]) > 0:
+      slices.sort(key=lambda x: x[1][0].start)
+    return slices
+
+  def update(self, region, data, wait=True, owned=False):
+    """distarray.py:372-422.  `data` is a backend tensor on the executing rank
+    (`Absent` elsewhere).  Inside a kernel the update joins the kernel's batch;
+    at driver level it is applied immediately."""
+    Assert.isinstance(region, extent.TileExtent)
+    Assert.eq(region.shape, tuple(data.shape), 'Size of extent does not match size of data')
+    ctx = self.ctx
+    if ctx.pending is not None:
+      ctx.pending.add(self, region, data, owned)
+      return None
+    batch = UpdateBatch(ctx)
+    batch.add(self, region, data, owned)
+    batch.flush()
+    return None
+
+
+def run_kernel(array, tile_ids, mapper_fn, kw):
+  """blob_ctx.map + Worker._run_kernel: call the mapper for every tile (in a
+  deterministic order, on every rank) and join the updates it issued."""
+  ctx = context.get()
+  kw = dict(kw)
+  results = collections.OrderedDict()
+  outer = ctx.pending
+  batch = UpdateBatch(ctx)
+  ctx.pending = batch
+  try:
+    for tile_id in tile_ids:
+      with ctx.on_worker(tile_id.worker):
+        blob = ctx.tile(tile_id) if ctx.is_local(tile_id) else None
+        res = array._invoke_mapper(tile_id, blob, mapper_fn, kw)
+      if res is None:
+        continue
+      results[tile_id] = res.result
+      # a mapper returning an existing tile id shares it (worker.py:285-295)
+      if res.result:
+        for ex, tid in res.result:
+          if tid == tile_id:
+            ctx.incref(tid)
+  finally:
+    ctx.pending = outer
+  batch.flush()
+  return results
+
+
+def _invoke_default(self, tile_id, blob, mapper_fn, kw):
+  return _tile_mapper(tile_id, blob, array=self, user_fn=mapper_fn, **kw)
+
+
+DistArrayImpl._invoke_mapper = _invoke_default
+
+
+def create(shape, dtype=float, sharder=None, reducer=None, tile_hint=None, sparse=False):
+  """distarray.py:425-487 (round_robin tile assignment, the default)."""
+  if sparse:
+    raise NotImplementedError('sparse arrays are outside the GPU tile path (SURVEY 8f.2)')
+  ctx = context.get()
+  dtype = np.dtype(dtype)
+  shape = tuple(int(s) for s in shape)
+  extents = compute_extents(shape, tile_hint, ctx.num_workers)
+  tiles = collections.OrderedDict()
+  for ex, i in extents.items():
+    worker = i % ctx.num_workers
+    t = tile.from_shape(ex.shape, dtype, tile.TYPE_DENSE) if ctx.is_local_worker(worker) else None
+    tiles[ex] = ctx.create(t, hint=worker)
+  return DistArrayImpl(shape=shape, dtype=dtype, tiles=tiles, reducer_fn=reducer, sparse=False)
+
+
+def from_table(extents):
+  """distarray.py:519-550."""
+  Assert.no_duplicates(list(extents.keys()))
+  if not extents:
+    shape = tuple()
+  else:
+    shape = extent.find_shape(list(extents.keys()))
+  if len(extents) > 0:
+    key, tile_id = next(iter(extents.items()))
+    dtype, sparse = context.get().tile_meta(tile_id)
+  else:
+    dtype = np.dtype(float)
+    sparse = False
+  return DistArrayImpl(shape=shape, dtype=dtype, tiles=extents, reducer_fn=None, sparse=sparse)
+
+
+class LocalWrapper(DistArray):
+  """distarray.py:553-602: the DistArray interface for driver-local data
+  (NumPy arrays and scalars, replicated on every rank)."""
+
+  def __init__(self, data):
+    # Python scalars stay "weak" (see SURVEY 8c, NEP-50 note): fp32 + 1 is fp32
+    self._scalar = data if isinstance(data, (bool, int, float)) and not isinstance(data, np.generic) else None
+    self._data = np.asarray(data)
+    self.sparse = False
+    self.bad_tiles = []
+    self._ex = extent.from_slice(np.index_exp[:], self.shape)
+    Assert.isinstance(data, (np.ndarray, int, float, bool, np.generic))
+    self._dev = None
+
+  @property
+  def dtype(self):
+    return self._data.dtype
+
+  @property
+  def shape(self):
+    return self._data.shape
+
+  @property
+  def is_weak_scalar(self):
+    return self._scalar is not None
+
+  @property
+  def tiles(self):
+    return {self._ex: TileId(-1, 0)}
+
+  def extent_for_blob(self, tile_id):
+    return self._ex
+
+  def fetch(self, ex):
+    if self._data.ndim == 0:
+      return self._scalar if self._scalar is not None else self._data
+    return self._data[ex.to_slice()]
+
+  def glom(self):
+    return self._data
+
+  def foreach_tile(self, mapper_fn, kw=None):
+    if kw is None:
+      kw = {}
+    ctx = context.get()
+    map_result = mapper_fn(self._ex, **kw)
+    result = map_result.result
+    assert len(result) == 1
+    result_ex, tile_id = result[0]
+    Assert.isinstance(tile_id, TileId)
+    return from_table({result_ex if result_ex is not None else extent.create((), (), ()): tile_id})
+
+  def map_to_array(self, mapper_fn, kw=None):
+    return self.foreach_tile(mapper_fn=mapper_fn, kw=kw)
+
+
+def as_array(data):
+  """distarray.py:605-617."""
+  if isinstance(data, DistArray):
+    return data
+  return LocalWrapper(data)
+
+
+def largest_value(vals):
+  """distarray.py:636-642."""
+  return max(vals, key=lambda v: v.real_size())

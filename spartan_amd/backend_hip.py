@@ -1,0 +1,305 @@
+"""The HIP tile-kernel backend: the product path.
+
+Implements the backend seam (the role ParakeetExpr.evaluate plays in the
+reference, spartan/expr/operator/local.py:187-209) on top of the C-ABI
+(include/spartan_hip.h) for tile blobs that live in HBM as torch tensors.
+Constructing it without a GPU or without the built library raises: there is no
+CPU fallback in the product path.
+"""
+import numpy as np
+import torch
+
+from . import _hip, kernels, lower
+from .array import distarray, tile
+from .expr.local import FnCallExpr, LocalInput
+from .program import ProgramTooLarge, class_of, join_class
+
+_REDUCER_NAMES = {
+    None: 'NONE', np.add: 'ADD', np.multiply: 'MUL', np.maximum: 'MAX', np.minimum: 'MIN',
+    np.logical_and: 'AND', np.logical_or: 'OR',
+}
+
+
+class HipBackend(object):
+  name = 'hip'
+
+  def __init__(self, device=None):
+    _hip.lib()  # raises HipLibraryMissing if the extension has not been built
+    if not torch.cuda.is_available():
+      raise _hip.HipError('the HIP tile backend needs an AMD GPU (torch.cuda.is_available() is False); '
+                          'there is no CPU fallback')
+    self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    self._np_cache = {}
+    self.launches = 0
+
+  # -- memory -------------------------------------------------------------------
+  def empty(self, shape, dtype):
+    return torch.empty(tuple(int(s) for s in shape), dtype=kernels.torch_dtype(dtype), device=self.device)
+
+  def zeros(self, shape, dtype):
+    return torch.zeros(tuple(int(s) for s in shape), dtype=kernels.torch_dtype(dtype), device=self.device)
+
+  def from_numpy(self, arr):
+    arr = np.asarray(arr)
+    arr = arr if arr.flags['C_CONTIGUOUS'] else arr.copy(order='C')  # (ascontiguousarray would make 0-d -> 1-d)
+    return torch.from_numpy(arr).to(self.device)
+
+  def to_numpy(self, t):
+    if isinstance(t, np.ndarray):
+      return t
+    if isinstance(t, tile.EmptyBlob):
+      return np.zeros(t.shape, t.dtype)
+    return t.detach().cpu().numpy()
+
+  def dtype_of(self, t):
+    if isinstance(t, (tile.EmptyBlob, distarray.Absent, np.ndarray, np.generic)):
+      return np.dtype(t.dtype)
+    if isinstance(t, torch.Tensor):
+      return kernels.np_dtype_of(t)
+    return np.asarray(t).dtype
+
+  def same_dtype(self, t, dtype):
+    return self.dtype_of(t) == np.dtype(dtype)
+
+  def contiguous(self, t):
+    return t if t.is_contiguous() else self.copy(t)
+
+  def copy(self, t):
+    out = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+    if t.numel():
+      self.paste(out, tuple(slice(0, n) for n in t.shape), t)
+    return out
+
+  def astype(self, t, dtype):
+    dtype = np.dtype(dtype)
+    if self.dtype_of(t) == dtype:
+      return t
+    v = lower.cast(lower.V('tensor', dtype=self.dtype_of(t), shape=tuple(t.shape), tensor=t), dtype)
+    return self._run_map(v, tuple(t.shape))
+
+  def cached_numpy(self, arr, slices):
+    """A (slice of a) driver-side NumPy operand, uploaded once (the reference
+    pickles it into every RunKernelReq, dot.py:172-187)."""
+    key = (id(arr), tuple((s.start, s.stop) for s in slices))
+    hit = self._np_cache.get(key)
+    if hit is None or hit[0] is not arr:
+      hit = (arr, self.from_numpy(arr[slices]))
+      self._np_cache[key] = hit
+    return hit[1]
+
+  def reducer_name(self, fn):
+    try:
+      return _REDUCER_NAMES[fn]
+    except (KeyError, TypeError):
+      raise lower.NotLowerable('reducer %r has no GPU combine kernel (supported: None, np.add, '
+                               'np.multiply, np.maximum, np.minimum, np.logical_and, np.logical_or)' % (fn,))
+
+  # -- strided views ----------------------------------------------------------------
+  def paste(self, dst, dst_slices, src):
+    """dst[dst_slices] = src (strided box copy in HBM)."""
+    view = dst[dst_slices] if dst.dim() else dst
+    if tuple(view.shape) != tuple(src.shape):
+      src = src.reshape(view.shape)
+    if view.numel() == 0:
+      return
+    if view.dtype != src.dtype:
+      raise _hip.HipError('paste: dtype mismatch %s vs %s' % (view.dtype, src.dtype))
+    nd = view.dim()
+    if nd > _hip.SP_MAX_DIMS:
+      raise _hip.HipError('paste: more than %d dimensions' % _hip.SP_MAX_DIMS)
+    self.launches += 1
+    kernels.slice_copy(dst, view.storage_offset() - dst.storage_offset(), view.stride(),
+                       src, 0, src.stride(), view.shape)
+
+  # -- combine --------------------------------------------------------------------
+  def update_box(self, dst, ul, lr, src, reducer, mask_mode, mask):
+    self.launches += 1
+    src = self.contiguous(src)
+    if not dst.is_contiguous():
+      raise _hip.HipError('update target must be a dense tile')
+    kernels.update(dst, ul, lr, src, self.reducer_name(reducer), mask_mode, mask)
+
+  def mask_all_set(self, mask, subslice):
+    return bool(self.evaluate_reduce_tensor(mask[subslice], 'AND').item())
+
+  def mask_first(self, mask):
+    return bool(mask.reshape(-1)[0].item())
+
+  # -- kernels from LocalExpr trees ---------------------------------------------------
+  def _prepare(self, v):
+    """Upload NumPy operands of a V tree."""
+    if v.kind == 'tensor' and isinstance(v.tensor, np.ndarray):
+      v.tensor = self.cached_numpy(v.tensor, tuple(slice(0, n) for n in v.tensor.shape))
+    for a in v.args:
+      self._prepare(a)
+
+  def _run_map(self, root, out_shape, out_dtype=None):
+    self._prepare(root)
+    if root.kind == 'const':
+      root = lower.V('op', dtype=root.dtype, shape=(), op='FILL', args=[root])
+    out_dtype = np.dtype(out_dtype or root.dtype)
+    cls = lower.choose_class(root, [class_of(out_dtype)] if out_dtype != np.bool_ else [])
+    em = lower.Emitter(cls, out_shape)
+    prog, tensors = em.finish(root, out_dtype)
+    out = self.empty(out_shape, out_dtype)
+    if out.numel():
+      self.launches += 1
+      kernels.map_fused(prog, [self.contiguous(t) for t in tensors], out)
+    return out
+
+  def evaluate_map(self, op, inputs, ex):
+    """tile_mapper body: the fused map as ONE launch (map.py:74, local.py:115-127)."""
+    try:
+      root = lower.infer(op, inputs, ex, self.dtype_of)
+      return self._run_map(root, root.shape if root.kind != 'const' else ex.shape)
+    except ProgramTooLarge:
+      return self._evaluate_split(op, inputs, ex)
+
+  def _evaluate_split(self, op, inputs, ex):
+    """The tree does not fit one kernel: materialise its sub-expressions first."""
+    if not isinstance(op, FnCallExpr):
+      raise
+    new_deps = []
+    new_inputs = dict(inputs)
+    progressed = False
+    for i, d in enumerate(op.deps):
+      if isinstance(d, FnCallExpr):
+        name = '__split_%d_%d' % (id(op), i)
+        new_inputs[name] = self.evaluate_map(d, inputs, ex)
+        new_deps.append(LocalInput(idx=name))
+        progressed = True
+      else:
+        new_deps.append(d)
+    if not progressed:
+      raise ProgramTooLarge('a single local function call does not fit one kernel')
+    clone = op.__class__(fn=op.fn, kw=op.kw, pretty_fn=op.pretty_fn, deps=new_deps)
+    root = lower.infer(clone, new_inputs, ex, self.dtype_of)
+    return self._run_map(root, root.shape)
+
+  def evaluate_fn(self, fn, args, kw, out_shape):
+    """Apply one registered local function to backend tensors (one launch)."""
+    rule = lower.MAP_RULES[fn]
+    vals = []
+    for a in args:
+      v = lower.value_of_input(a)
+      if v.kind == 'tensor' and v.dtype is None:
+        v.dtype = self.dtype_of(a)
+      vals.append(v)
+    root = rule(vals, kw, None)
+    return self._run_map(root, out_shape)
+
+  def _axis_split(self, shape, axis):
+    if axis is None:
+      return 1, int(np.prod(shape, dtype=np.int64)), 1
+    if axis < 0:
+      axis += len(shape)
+    return (int(np.prod(shape[:axis], dtype=np.int64)), int(shape[axis]),
+            int(np.prod(shape[axis + 1:], dtype=np.int64)))
+
+  def _run_reduce(self, data, red_op, nat_dtype, shape, axis):
+    self._prepare(data)
+    if data.kind in ('const', 'shape'):
+      raise lower.NotLowerable('reduction over a constant')
+    nat_dtype = np.dtype(nat_dtype)
+    extra = [class_of(nat_dtype)] if nat_dtype != np.bool_ else []
+    cls = lower.choose_class(data, extra)
+    full_shape = tuple(np.broadcast_shapes(data.shape, shape))
+    em = lower.Emitter(cls, full_shape)
+    prog, tensors = em.finish(data, None)
+    O, A, I = self._axis_split(full_shape, axis)
+    out = self.empty((O * I,), nat_dtype)
+    if A == 0 or O * I == 0:
+      raise _hip.HipError('reduction over an empty axis')
+    self.launches += 1
+    kernels.reduce(prog, [self.contiguous(t) for t in tensors], red_op, O, A, I, out)
+    if axis is None:
+      return out.reshape(())
+    ax = axis if axis >= 0 else axis + len(full_shape)
+    return out.reshape(full_shape[:ax] + full_shape[ax + 1:])
+
+  def evaluate_reduce(self, op, inputs, ex, axis):
+    """_reduce_mapper's local reduction (reduce.py:54) incl. the fused map prologue."""
+    rule = lower.REDUCE_RULES.get(op.fn)
+    if rule is None:
+      raise lower.NotLowerable('no GPU lowering registered for local reduce function %s' % op.fn_name())
+    data_deps = [d for d in op.deps if not (isinstance(d, LocalInput) and d.idx in ('extent', 'axis'))]
+    if len(data_deps) != 1:
+      raise lower.NotLowerable('reduce over %d operands' % len(data_deps))
+    try:
+      data = lower.infer(data_deps[0], inputs, ex, self.dtype_of)
+    except ProgramTooLarge:
+      raise
+    red_op, data, nat = rule(data, axis, ex)
+    try:
+      return self._run_reduce(data, red_op, nat, ex.shape, axis)
+    except ProgramTooLarge:
+      # materialise the map, then reduce the dense result
+      dense = self.evaluate_map(data_deps[0], inputs, ex)
+      v = lower.V('tensor', dtype=self.dtype_of(dense), shape=tuple(dense.shape), tensor=dense)
+      red_op, v, nat = rule(v, axis, ex)
+      return self._run_reduce(v, red_op, nat, ex.shape, axis)
+
+  def evaluate_reduce_tensor(self, t, red_op):
+    v = lower.V('tensor', dtype=self.dtype_of(t), shape=tuple(t.shape), tensor=t)
+    nat = np.bool_ if red_op in ('AND', 'OR') else self.dtype_of(t)
+    return self._run_reduce(v, red_op, nat, tuple(t.shape), None)
+
+  def evaluate_argreduce(self, data, ex, axis, which, index_offset, nan_index):
+    """Fused (value, first index) reduction of one tile (sorting.py:67-123 in one pass)."""
+    if isinstance(data, tile.EmptyBlob):
+      raise lower.NotLowerable('argmax/argmin of an uninitialised array')
+    v = lower.V('tensor', dtype=self.dtype_of(data), shape=tuple(data.shape), tensor=data)
+    cls = lower.choose_class(v)
+    em = lower.Emitter(cls, v.shape)
+    prog, tensors = em.finish(v, None)
+    O, A, I = self._axis_split(v.shape, axis)
+    out_idx = self.empty((O * I,), np.int64)
+    val_dtype = {_hip.SP_F32: np.float32, _hip.SP_F64: np.float64, _hip.SP_I64: np.int64}[cls]
+    out_val = self.empty((O * I,), val_dtype)
+    self.launches += 1
+    kernels.argreduce(prog, [self.contiguous(t) for t in tensors], which, O, A, I, index_offset,
+                      nan_index, out_idx, out_val)
+    if np.dtype(val_dtype) != v.dtype:
+      out_val = self.astype(out_val, v.dtype)
+    return out_idx, out_val
+
+  # -- contraction ------------------------------------------------------------------
+  def dot(self, a, b):
+    """ndarray.dot for backend tensors: MFMA GEMM for fp32 matrix.matrix, fused
+    multiply-reduce launches for everything else."""
+    a_dt, b_dt = self.dtype_of(a), self.dtype_of(b)
+    res_dt = np.result_type(a_dt, b_dt)
+    if a.dim() == 2 and b.dim() == 2 and a_dt == np.float32 and b_dt == np.float32:
+      M, K = a.shape
+      N = b.shape[1]
+      c = self.empty((M, N), np.float32)
+      if a.stride(1) != 1:
+        a = self.copy(a)
+      if b.stride(1) != 1:
+        b = self.copy(b)
+      self.launches += 1
+      kernels.gemm_f32(a, b, c, accumulate=False)
+      return c
+    va = lower.V('tensor', dtype=a_dt, shape=tuple(a.shape), tensor=self.contiguous(a))
+    vb = lower.V('tensor', dtype=b_dt, shape=tuple(b.shape), tensor=self.contiguous(b))
+    if a.dim() == 2 and b.dim() == 1:      # (M,K).(K,) -> (M,): row kernels
+      prod = lower.apply('MUL', np.multiply, [va, vb])
+      return self._run_reduce(prod, 'SUM', res_dt, prod.shape, 1)
+    if a.dim() == 1 and b.dim() == 1:      # (K,).(K,) -> scalar
+      prod = lower.apply('MUL', np.multiply, [va, vb])
+      return self._run_reduce(prod, 'SUM', res_dt, prod.shape, None)
+    if a.dim() == 1 and b.dim() == 2:      # (K,).(K,N) -> (N,): column kernels
+      va.shape = (a.shape[0], 1)
+      prod = lower.apply('MUL', np.multiply, [va, vb])
+      return self._run_reduce(prod, 'SUM', res_dt, prod.shape, 0)
+    if a.dim() == 2 and b.dim() == 2:      # generic dtype: [M,K,1] * [1,K,N] summed over K
+      M, K = a.shape
+      N = b.shape[1]
+      va.shape = (M, K, 1)
+      vb.shape = (1, K, N)
+      prod = lower.apply('MUL', np.multiply, [va, vb])
+      return self._run_reduce(prod, 'SUM', res_dt, (M, K, N), 1)
+    raise lower.NotLowerable('dot of %d-d and %d-d operands' % (a.dim(), b.dim()))
+
+  def synchronize(self):
+    torch.cuda.synchronize(self.device)

@@ -1,0 +1,161 @@
+"""Worker context: tile store, tile ids, and "who is executing".
+
+Plays the role of the reference's BlobCtx + Worker pair (spartan/blob_ctx.py,
+spartan/worker.py) for a static world of one process per GPU:
+
+  * `num_workers` logical workers are mapped round-robin onto the
+    torch.distributed ranks (worker w lives on rank w % world.size).  With
+    num_workers > world.size one GPU hosts several workers, which is how the
+    reference's multi-worker tests (3/4/8 workers, tests/test_common.py:128-136)
+    run on a single device.
+  * every rank runs the same driver program, so tile ids are allocated by
+    identical per-worker counters on every rank (`create`); only the owning rank
+    stores the blob (`_blobs`, worker.py:70).
+  * the per-tile mapper of an operation is walked on EVERY rank in the same
+    order (`run_kernel`, the analogue of Worker._run_kernel, worker.py:232-315);
+    `executing` says whether this rank is the one that owns the tile being
+    processed and must launch kernels; the other ranks only take part in the
+    transfers the mapper implies.
+"""
+import collections
+import contextlib
+
+import numpy as np
+
+from . import comm
+from .array import tile as tile_mod
+
+
+class TileId(object):
+  """spartan/core.pyx:16-41."""
+  __slots__ = ('worker', 'id')
+
+  def __init__(self, worker, id):
+    self.worker = worker
+    self.id = id
+
+  def __hash__(self):
+    return self.worker ^ self.id
+
+  def __eq__(self, other):
+    return isinstance(other, TileId) and self.worker == other.worker and self.id == other.id
+
+  def __ne__(self, other):
+    return not self.__eq__(other)
+
+  def __repr__(self):
+    return 'B(%d.%d)' % (self.worker, self.id)
+
+
+class LocalKernelResult(object):
+  """spartan/core.pyx:159-169."""
+
+  def __init__(self, result=None, futures=None):
+    self.result = result
+    self.futures = futures
+
+
+class Context(object):
+  def __init__(self, backend, world=None, num_workers=None):
+    self.backend = backend
+    self.world = world if world is not None else comm.World()
+    self.num_workers = int(num_workers) if num_workers else self.world.size
+    if self.num_workers < self.world.size:
+      raise ValueError('num_workers (%d) < number of processes (%d)' % (self.num_workers, self.world.size))
+    self._blobs = {}                                  # TileId -> Tile (local workers only)
+    self._next_id = collections.defaultdict(int)      # worker -> next blob id
+    self._rr = 0                                      # round-robin cursor for hint-less creates
+    self.current_worker = None
+    self.pending = None                               # UpdateBatch while a kernel runs
+    self.pending_destructors = []                     # tiles of dead arrays (distarray.py:219-268)
+
+  # -- placement --------------------------------------------------------------
+  def rank_of(self, worker):
+    return worker % self.world.size
+
+  def is_local_worker(self, worker):
+    return self.rank_of(worker) == self.world.rank
+
+  def is_local(self, tile_id):
+    return self.is_local_worker(tile_id.worker)
+
+  @property
+  def executing(self):
+    """True when this rank owns the worker on whose behalf the current mapper runs."""
+    return self.current_worker is None or self.is_local_worker(self.current_worker)
+
+  @contextlib.contextmanager
+  def on_worker(self, worker):
+    prev = self.current_worker
+    self.current_worker = worker
+    try:
+      yield
+    finally:
+      self.current_worker = prev
+
+  # -- tile store ---------------------------------------------------------------
+  def create(self, tile, hint=-1):
+    """blob_ctx.py:221-254 + worker.py:126-146.  `tile` may be None on ranks that
+    do not own the target worker (only the id is allocated there)."""
+    if hint is None or hint < 0:
+      if self.current_worker is not None:
+        worker = self.current_worker       # a kernel's new tile stays on its worker
+      else:
+        worker = self._rr % self.num_workers
+        self._rr += 1
+    else:
+      worker = hint % self.num_workers
+    tid = TileId(worker, self._next_id[worker])
+    self._next_id[worker] += 1
+    if self.is_local_worker(worker):
+      if tile is None:
+        raise AssertionError('owning rank must supply the tile')
+      self._blobs[tid] = tile
+    return tid
+
+  def tile(self, tile_id):
+    return self._blobs[tile_id]
+
+  def destroy_all(self, tile_ids):
+    """worker.py:152-170 (refcounted)."""
+    for tid in tile_ids:
+      t = self._blobs.get(tid)
+      if t is not None:
+        t.refcnt -= 1
+        if t.refcnt <= 0:
+          del self._blobs[tid]
+
+  def incref(self, tile_id):
+    t = self._blobs.get(tile_id)
+    if t is not None:
+      t.refcnt += 1
+
+  def tile_meta(self, tile_id):
+    """(dtype, is_sparse) of a tile, learnt from its owner (the reference issues a
+    tile_op RPC for this, distarray.py:542)."""
+    src = self.rank_of(tile_id.worker)
+    meta = None
+    if self.world.rank == src:
+      meta = self._blobs[tile_id].dtype.str
+    meta = self.world.broadcast_object(meta, src)
+    return np.dtype(meta), False
+
+
+_ctx = None
+
+
+def get():
+  """blob_ctx.get(): the process-wide context (blob_ctx.py:288-301)."""
+  if _ctx is None:
+    raise RuntimeError('spartan_amd.initialize() has not been called')
+  return _ctx
+
+
+def set(ctx):
+  global _ctx
+  _ctx = ctx
+  return ctx
+
+
+def initialized():
+  return _ctx is not None

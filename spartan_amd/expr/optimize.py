@@ -1,0 +1,159 @@
+"""DAG optimisation: the fusion passes that turn chains of maps (and a reduce
+over maps) into ONE LocalExpr tree = one HIP kernel per tile.
+
+Mirror of the reference's spartan/expr/operator/optimize.py:107-247
+(`fusable`, `merge_var`, MapMapFusion, ReduceMapFusion,
+CollapsedCachedExpressions) and `optimize` (:1072-1081).  Auto-tiling, Parakeet
+generation and slice rotation are outside the tile-kernel path.
+"""
+from . import base
+from .base import AsArray, Expr, ListExpr, Val, expr_like, lazify
+from .local import LocalInput, LocalMapLocationExpr, LocalReduceExpr, make_var
+from .map import MapExpr
+from .ndarray import NdArrayExpr
+from .reduce import ReduceExpr
+from .shuffle import ShuffleExpr
+from ..util import Assert
+
+_not_idempotent_list = set()
+
+FLAGS = {'optimization': True, 'opt_map_fusion': True, 'opt_reduce_fusion': True,
+         'opt_collapse_cached': True}
+
+
+def not_idempotent(fn):
+  """optimize.py:60-68: results of such builders are never fused."""
+  def wrapped(*args, **kw):
+    result = fn(*args, **kw)
+    if isinstance(result, Expr):
+      result.needs_cache = True
+      _not_idempotent_list.add(id(result))
+    return result
+  return wrapped
+
+
+def disable_parakeet(fn):
+  return fn
+
+
+class OptimizePass(object):
+  """optimize.py:79-104."""
+
+  def __init__(self):
+    self.visited = {}
+
+  def visit(self, op):
+    if not isinstance(op, Expr):
+      return op
+    if op.expr_id in self.visited:
+      return self.visited[op.expr_id]
+    if hasattr(self, 'visit_default'):
+      opt_op = self.visit_default(op)
+    elif hasattr(self, 'visit_%s' % op.typename()):
+      opt_op = getattr(self, 'visit_%s' % op.typename())(op)
+    else:
+      opt_op = op.visit(self)
+    self.visited[opt_op.expr_id] = opt_op
+    return opt_op
+
+
+def fusable(v):
+  """optimize.py:107-116 (restricted to the node types that exist here)."""
+  return isinstance(v, (MapExpr, ReduceExpr, ShuffleExpr, NdArrayExpr, Val, AsArray))
+
+
+def merge_var(children, child_to_var, k, v):
+  """optimize.py:119-130."""
+  try:
+    i = child_to_var.index(k)
+    Assert.eq(v.expr_id if isinstance(v, Expr) else id(v),
+              children[i].expr_id if isinstance(children[i], Expr) else id(children[i]))
+  except ValueError:
+    children.append(v)
+    child_to_var.append(k)
+
+
+class MapMapFusion(OptimizePass):
+  """optimize.py:133-187: map(f, map(g, map(h, x))) -> map(f . g . h, x)."""
+  name = 'map_fusion'
+
+  def visit_MapExpr(self, expr):
+    map_children = self.visit(expr.children)
+    all_maps = True
+    Assert.isinstance(map_children, ListExpr)
+    for k, v in zip(expr.child_to_var, map_children):
+      if not fusable(v):
+        all_maps = False
+        break
+    if not all_maps or id(expr) in _not_idempotent_list:
+      return expr_like(expr, children=map_children, child_to_var=expr.child_to_var, op=expr.op)
+
+    children = []
+    child_to_var = []
+    combined_op = expr.op.__class__(fn=expr.op.fn, kw=expr.op.kw, pretty_fn=expr.op.pretty_fn)
+    for child_expr in map_children:
+      if isinstance(child_expr, MapExpr) and id(child_expr) not in _not_idempotent_list:
+        for k, v in zip(child_expr.child_to_var, child_expr.children):
+          merge_var(children, child_to_var, k, v)
+        combined_op.add_dep(child_expr.op)
+      else:
+        children.append(child_expr)
+        key = make_var()
+        combined_op.add_dep(LocalInput(idx=key))
+        child_to_var.append(key)
+    if isinstance(combined_op, LocalMapLocationExpr):
+      combined_op.add_dep(LocalInput(idx='extent'))
+    return expr_like(expr, children=ListExpr(vals=children), child_to_var=child_to_var, op=combined_op)
+
+
+class ReduceMapFusion(OptimizePass):
+  """optimize.py:190-227: reduce(f, map(g, X)) -> reduce(f . g, X)."""
+  name = 'reduce_fusion'
+
+  def visit_ReduceExpr(self, expr):
+    Assert.isinstance(expr.children, ListExpr)
+    old_children = self.visit(expr.children)
+    for v in old_children:
+      if not isinstance(v, MapExpr) or id(v) in _not_idempotent_list:
+        return expr_like(expr, children=old_children, child_to_var=expr.child_to_var, axis=expr.axis,
+                         dtype_fn=expr.dtype_fn, op=expr.op, accumulate_fn=expr.accumulate_fn,
+                         tile_hint=expr.tile_hint)
+    combined_op = LocalReduceExpr(fn=expr.op.fn, kw=expr.op.kw, deps=[expr.op.deps[0]])
+    new_children = []
+    new_child_to_var = []
+    for i in range(len(old_children)):
+      child_expr = old_children[i]
+      for j in range(len(child_expr.children)):
+        k = child_expr.child_to_var[j]
+        v = child_expr.children[j]
+        merge_var(new_children, new_child_to_var, k, v)
+      combined_op.add_dep(child_expr.op)
+    # NB: like the reference (reduce.py:110) dtype_fn is afterwards applied to the
+    # fused map's FIRST INPUT, so the output dtype follows that input.
+    return expr_like(expr, children=ListExpr(vals=new_children), child_to_var=new_child_to_var,
+                     axis=expr.axis, dtype_fn=expr.dtype_fn, accumulate_fn=expr.accumulate_fn,
+                     op=combined_op, tile_hint=expr.tile_hint)
+
+
+class CollapsedCachedExpressions(OptimizePass):
+  """optimize.py:230-247: replace already-evaluated subtrees by their value."""
+  name = 'collapse_cached'
+
+  def visit_default(self, expr):
+    cache = expr.cache()
+    if cache is not None:
+      return lazify(cache)
+    return expr.visit(self)
+
+
+def optimize(dag):
+  """optimize.py:1072-1099 (pass order: collapse cached, map fusion, reduce fusion)."""
+  if not FLAGS['optimization']:
+    return dag
+  if FLAGS['opt_collapse_cached']:
+    dag = CollapsedCachedExpressions().visit(dag)
+  if FLAGS['opt_map_fusion']:
+    dag = MapMapFusion().visit(dag)
+  if FLAGS['opt_reduce_fusion']:
+    dag = ReduceMapFusion().visit(dag)
+  return dag

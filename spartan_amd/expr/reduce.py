@@ -1,0 +1,91 @@
+"""reduce: mirror of the reference's spartan/expr/operator/reduce.py.  The
+local reduction is one fused map->reduce HIP launch; the cross-tile combine is
+`output.update(...)` with the accumulate fn (an RCCL reduce / reduce-scatter for
+the regular patterns, see array/distarray.py UpdateBatch)."""
+import collections
+
+from . import base, broadcast
+from .base import Expr, ListExpr
+from .local import LocalInput, LocalReduceExpr, make_var
+from .. import context
+from ..array import distarray, extent
+from ..context import LocalKernelResult
+from ..util import Assert
+
+
+def _reduce_mapper(ex, children, child_to_var, op, axis, output):
+  """reduce.py:21-70."""
+  ctx = context.get()
+  local_values = {}
+  for i in range(len(children)):
+    if isinstance(children[i], broadcast.Broadcast):
+      lv = children[i].fetch_base_tile(ex)
+    else:
+      lv = children[i].fetch(ex)
+    local_values[child_to_var[i]] = lv
+  local_values['extent'] = ex
+  local_values['axis'] = axis
+  dst_extent = extent.index_for_reduction(ex, axis)
+  if ctx.executing:
+    local_reduction = ctx.backend.evaluate_reduce(op, local_values, ex, axis)
+    Assert.eq(int(local_reduction.numel()) if hasattr(local_reduction, 'numel') else local_reduction.size,
+              dst_extent.size)
+    local_reduction = local_reduction.reshape(dst_extent.shape)
+  else:
+    local_reduction = distarray.Absent(dst_extent.shape, output.dtype)
+  output.update(dst_extent, local_reduction, owned=True)
+  return LocalKernelResult(result=[])
+
+
+class ReduceExpr(Expr):
+  """reduce.py:73-127."""
+  members = ('children', 'child_to_var', 'axis', 'dtype_fn', 'op', 'accumulate_fn', 'tile_hint')
+
+  def dependencies(self):
+    return {'children': self.children}
+
+  def visit(self, visitor):
+    return base.expr_like(self, children=visitor.visit(self.children), child_to_var=self.child_to_var,
+                          axis=self.axis, dtype_fn=self.dtype_fn, op=self.op,
+                          accumulate_fn=self.accumulate_fn, tile_hint=self.tile_hint)
+
+  def compute_shape(self):
+    shapes = [i.shape for i in self.children]
+    child_shape = collections.defaultdict(int)
+    for s in shapes:
+      for i, v in enumerate(s):
+        child_shape[i] = max(child_shape[i], v)
+    input_shape = tuple([child_shape[i] for i in range(len(child_shape))])
+    return tuple(extent.shape_for_reduction(input_shape, self.axis))
+
+  def pretty_str(self):
+    return 'Reduce(%s, axis=%s, %s, hint=%s)' % (getattr(self.op.fn, '__name__', self.op.fn), self.axis,
+                                                 self.children.pretty_str(), self.tile_hint)
+
+  def _evaluate(self, ctx, deps):
+    children = deps['children']
+    children = broadcast.broadcast(list(children))
+    largest = distarray.largest_value(children)
+    dtype = self.dtype_fn(children[0])
+    shape = extent.shape_for_reduction(children[0].shape, self.axis)
+    output_array = distarray.create(shape, dtype, reducer=self.accumulate_fn, tile_hint=self.tile_hint)
+    largest.foreach_tile(_reduce_mapper, kw={'children': children,
+                                             'child_to_var': self.child_to_var,
+                                             'op': self.op,
+                                             'axis': self.axis,
+                                             'output': output_array})
+    return output_array
+
+
+def reduce(v, axis, dtype_fn, local_reduce_fn, accumulate_fn, fn_kw=None, tile_hint=None):
+  """reduce.py:130-167."""
+  if fn_kw is None:
+    fn_kw = {}
+  varname = make_var()
+  assert 'axis' not in fn_kw, '"axis" argument is reserved.'
+  fn_kw['axis'] = axis
+  reduce_op = LocalReduceExpr(fn=local_reduce_fn,
+                              deps=[LocalInput(idx='extent'), LocalInput(idx=varname)],
+                              kw=fn_kw)
+  return ReduceExpr(children=ListExpr(vals=[base.as_array(v)]), child_to_var=[varname], axis=axis,
+                    dtype_fn=dtype_fn, op=reduce_op, accumulate_fn=accumulate_fn, tile_hint=tile_hint)

@@ -1,0 +1,425 @@
+"""Lowering of fused LocalExpr trees to sp_program (the HIP kernel bytecode).
+
+The reference's precedent for a compiled local-op backend is ParakeetExpr /
+the ParakeetGeneration pass (spartan/expr/operator/local.py:187-209,
+optimize.py:321-370): a MapExpr's `op` tree is turned into one compiled
+function when every node is understood, and code generation failure is a soft
+error there.  Here the set of understood callables is a registry
+(`register_map_rule` / `register_reduce_rule`); an unregistered Python callable
+raises `NotLowerable` -- loudly, there is no CPU fallback.
+
+NumPy typing is reproduced exactly: every node's dtype is obtained by applying
+the very same ufunc to zero-dimensional dummies of the operand dtypes (so
+promotion, comparison->bool, int/int->float64 ... are NumPy's own rules), and
+Python scalars stay weak (NEP 50).
+"""
+import numpy as np
+
+from . import _hip
+from .array import distarray, tile
+from .expr import builtins as B
+from .expr.local import FnCallExpr, LocalInput, LocalMapLocationExpr
+from .program import (Program, ProgramTooLarge, broadcast_strides, class_of, collapse, dense_strides,
+                      join_class)
+
+
+class NotLowerable(TypeError):
+  """The local function has no registered GPU lowering."""
+
+
+# --------------------------------------------------------------------- values
+class V(object):
+  """A typed value in the tree being lowered."""
+  __slots__ = ('kind', 'dtype', 'shape', 'tensor', 'value', 'op', 'args', 'weak')
+
+  def __init__(self, kind, dtype=None, shape=(), tensor=None, value=None, op=None, args=(), weak=False):
+    self.kind = kind      # 'tensor' | 'const' | 'shape' | 'op' | 'iota' | 'extent' | 'axis'
+    self.dtype = None if dtype is None else np.dtype(dtype)
+    self.shape = tuple(int(s) for s in shape)
+    self.tensor = tensor
+    self.value = value
+    self.op = op
+    self.args = list(args)
+    self.weak = weak
+
+
+def const(value, dtype=None):
+  """A scalar constant; Python scalars are weak (dtype decided by the other operand)."""
+  if dtype is not None:
+    return V('const', dtype=dtype, value=np.dtype(dtype).type(value).item(), weak=False)
+  if isinstance(value, np.generic):
+    return V('const', dtype=value.dtype, value=value.item(), weak=False)
+  if isinstance(value, bool):
+    return V('const', dtype=np.bool_, value=value, weak=True)
+  if isinstance(value, int):
+    return V('const', dtype=np.int64, value=value, weak=True)
+  if isinstance(value, float):
+    return V('const', dtype=np.float64, value=value, weak=True)
+  raise NotLowerable('cannot use %r as a kernel constant' % (value,))
+
+
+def _dummy(v):
+  if v.kind == 'const' and v.weak:
+    return v.value
+  return np.zeros((), dtype=v.dtype)
+
+
+def _bshape(*shapes):
+  return tuple(np.broadcast_shapes(*shapes))
+
+
+def apply(opname, np_fn, args):
+  """Typed application of an elementwise op; result dtype = NumPy's for np_fn."""
+  if all(a.kind == 'const' for a in args):
+    with np.errstate(all='ignore'):
+      r = np_fn(*[a.value if a.weak else np.dtype(a.dtype).type(a.value) for a in args])
+    if all(a.weak for a in args):
+      return const(r.item() if isinstance(r, np.generic) else r)
+    return const(np.asarray(r)[()])
+  with np.errstate(all='ignore'):
+    res = np_fn(*[_dummy(a) for a in args])
+  dt = np.asarray(res).dtype
+  return V('op', dtype=dt, shape=_bshape(*[a.shape for a in args]), op=opname, args=args)
+
+
+def cast(v, dtype):
+  """ndarray.astype(dtype)."""
+  dtype = np.dtype(dtype)
+  if v.kind == 'const':
+    return const(np.asarray(v.value).astype(dtype)[()])
+  if v.dtype == dtype:
+    return v
+  return V('op', dtype=dtype, shape=v.shape, op='CAST', args=[v])
+
+
+# ---------------------------------------------------------------- rule tables
+MAP_RULES = {}
+REDUCE_RULES = {}
+
+
+def register_map_rule(fn, rule):
+  """rule(args: [V], kw: dict, ex) -> V"""
+  MAP_RULES[fn] = rule
+
+
+def register_reduce_rule(fn, rule):
+  """rule(data: V, axis, ex) -> (red_op, V to reduce, natural result dtype)"""
+  REDUCE_RULES[fn] = rule
+
+
+def _ufunc(opname, fn):
+  def rule(args, kw, ex):
+    if kw:
+      raise NotLowerable('keyword arguments %s of %s are not supported on the GPU' % (list(kw), fn))
+    return apply(opname, fn, args)
+  register_map_rule(fn, rule)
+
+
+for _name, _fn in [
+    ('ADD', np.add), ('SUB', np.subtract), ('MUL', np.multiply), ('DIV', np.divide),
+    ('FLOORDIV', np.floor_divide), ('MOD', np.mod), ('FMOD', np.fmod), ('POW', np.power),
+    ('MAX', np.maximum), ('MIN', np.minimum), ('EQ', np.equal), ('NE', np.not_equal), ('LT', np.less),
+    ('LE', np.less_equal), ('GT', np.greater), ('GE', np.greater_equal), ('LAND', np.logical_and),
+    ('LOR', np.logical_or), ('LXOR', np.logical_xor), ('LNOT', np.logical_not), ('NEG', np.negative),
+    ('ABS', np.abs), ('SQRT', np.sqrt), ('SQUARE', np.square), ('EXP', np.exp), ('LOG', np.log),
+    ('RECIP', np.reciprocal), ('SIGN', np.sign), ('FLOOR', np.floor), ('CEIL', np.ceil),
+    ('TANH', np.tanh)]:
+  _ufunc(_name, _fn)
+# np.true_divide is np.divide, np.remainder is np.mod, np.absolute is np.abs in NumPy 2
+
+
+def _where(args, kw, ex):
+  c, a, b = args
+  with np.errstate(all='ignore'):
+    dt = np.asarray(np.where(True, _dummy(a), _dummy(b))).dtype
+  return V('op', dtype=dt, shape=_bshape(c.shape, a.shape, b.shape), op='WHERE', args=[c, a, b])
+
+
+register_map_rule(np.where, _where)
+
+
+def _like_fill(value):
+  def rule(args, kw, ex):
+    src = args[0]
+    return V('op', dtype=src.dtype, shape=src.shape, op='FILL', args=[const(value, src.dtype)])
+  return rule
+
+
+register_map_rule(B._make_zeros, _like_fill(0))
+register_map_rule(B._make_ones, _like_fill(1))
+
+
+def _full(args, kw, ex):
+  src = args[0]
+  dt = np.dtype(kw.get('dtype') or src.dtype)
+  return V('op', dtype=dt, shape=src.shape, op='FILL', args=[const(kw['fill_value'], dt)])
+
+
+register_map_rule(B._full_mapper, _full)
+
+
+def _astype(args, kw, ex):
+  return cast(args[0], kw['dtype'])
+
+
+register_map_rule(B._astype_mapper, _astype)
+
+
+def _arange(args, kw, ex):
+  """creation.py:134-141: value = (ravelled_pos(ul, array_shape) + local index) * step + start."""
+  from .array import extent as extent_mod
+  src = args[0]
+  dt = np.dtype(kw.get('dtype') or float)
+  pos = extent_mod.ravelled_pos(ex.ul, ex.array_shape)
+  step, start = kw['step'], kw['start']
+  # np.arange(ex_start, ex_stop, step, dtype): element i = ex_start + i*step,
+  # computed in the (float64 / int64) type of the Python arguments, then cast
+  iot = V('iota', dtype=np.int64, shape=src.shape)
+  v = apply('MUL', np.multiply, [iot, const(step)])
+  v = apply('ADD', np.add, [v, const(pos * step + start)])
+  return cast(v, dt)
+
+
+register_map_rule(B._arange_mapper, _arange)
+
+
+def _eye(args, kw, ex):
+  src = args[0]
+  dt = np.dtype(kw.get('dtype') or float)
+  ncols = src.shape[1]
+  iot = V('iota', dtype=np.int64, shape=src.shape)
+  row = apply('FLOORDIV', np.floor_divide, [iot, const(ncols)])
+  col = apply('MOD', np.mod, [iot, const(ncols)])
+  k = ex.ul[0] - ex.ul[1] + kw['k']
+  hit = apply('EQ', np.equal, [col, apply('ADD', np.add, [row, const(k)])])
+  return cast(hit, dt)
+
+
+register_map_rule(B._eye_mapper, _eye)
+
+
+def _arg_candidates(args, kw, ex):
+  idx, val, best = args
+  eq = apply('EQ', np.equal, [val, best])
+  return V('op', dtype=np.int64, shape=_bshape(idx.shape, val.shape, best.shape), op='WHERE',
+           args=[eq, idx, const(np.int64(kw['sentinel']))])
+
+
+register_map_rule(B._arg_candidates, _arg_candidates)
+
+
+def _sum_dtype(dt):
+  dt = np.dtype(dt)
+  if dt.kind in 'bi':
+    return np.dtype(np.int64)
+  if dt.kind == 'u':
+    return np.dtype(np.uint64) if dt.itemsize == 8 else np.dtype(np.int64)
+  return dt
+
+
+register_reduce_rule(B._sum_local, lambda data, axis, ex: ('SUM', data, _sum_dtype(data.dtype)))
+register_reduce_rule(B._prod_local, lambda data, axis, ex: ('PROD', data, _sum_dtype(data.dtype)))
+register_reduce_rule(B._max_local, lambda data, axis, ex: ('MAX', data, data.dtype))
+register_reduce_rule(B._min_local, lambda data, axis, ex: ('MIN', data, data.dtype))
+register_reduce_rule(B._all_reducer, lambda data, axis, ex: ('AND', data, np.dtype(np.bool_)))
+register_reduce_rule(B._any_reducer, lambda data, axis, ex: ('OR', data, np.dtype(np.bool_)))
+
+
+def _count_nonzero(data, axis, ex):
+  # sorting.py:126-133: count_nonzero for axis=None, (data > 0).sum(axis) otherwise
+  if axis is None:
+    return ('SUM', apply('NE', np.not_equal, [data, const(0)]), np.dtype(np.int64))
+  return ('SUM', apply('GT', np.greater, [data, const(0)]), np.dtype(np.int64))
+
+
+def _count_zero(data, axis, ex):
+  return ('SUM', apply('EQ', np.equal, [data, const(0)]), np.dtype(np.int64))
+
+
+register_reduce_rule(B._countnonzero_local, _count_nonzero)
+register_reduce_rule(B._countzero_local, _count_zero)
+
+
+# ------------------------------------------------------------------- inference
+def value_of_input(x):
+  """Wrap a fetched local value (backend tensor, EmptyBlob, NumPy data, scalar)."""
+  if isinstance(x, tile.EmptyBlob):
+    return V('shape', dtype=x.dtype, shape=x.shape)
+  if isinstance(x, (bool, int, float)) and not isinstance(x, np.generic):
+    return const(x)
+  if isinstance(x, np.generic):
+    return const(x)
+  if isinstance(x, np.ndarray):
+    if x.ndim == 0:
+      return const(x[()])
+    return V('tensor', dtype=x.dtype, shape=x.shape, tensor=x)  # uploaded by the backend
+  if isinstance(x, distarray.Absent):
+    raise AssertionError('Absent data reached a kernel on the executing rank')
+  return V('tensor', dtype=None, shape=tuple(x.shape), tensor=x)  # dtype filled by the backend
+
+
+def infer(op, inputs, ex, dtype_of):
+  """LocalExpr tree -> V tree.  `inputs`: var name -> local value."""
+  if isinstance(op, LocalInput):
+    if op.idx == 'extent':
+      return V('extent', value=ex)
+    if op.idx == 'axis':
+      return V('axis', value=inputs.get('axis'))
+    x = inputs[op.idx]
+    v = x if isinstance(x, V) else value_of_input(x)
+    if v.kind == 'tensor' and v.dtype is None:
+      v.dtype = np.dtype(dtype_of(v.tensor))
+    return v
+  if not isinstance(op, FnCallExpr):
+    raise NotLowerable('cannot lower local expression %r' % (op,))
+  rule = MAP_RULES.get(op.fn)
+  if rule is None:
+    raise NotLowerable(
+        'no GPU lowering registered for local function %s; the HIP backend evaluates a closed '
+        'registry of ops (see spartan_amd/lower.py: register_map_rule) and has no CPU fallback'
+        % op.fn_name())
+  args = [infer(d, inputs, ex, dtype_of) for d in op.deps]
+  args = [a for a in args if a.kind != 'extent']
+  return rule(args, dict(op.kw), ex)
+
+
+# -------------------------------------------------------------------- emission
+_NORMALISE = {np.dtype(np.float32): 'TO_F32', np.dtype(np.int32): 'TO_I32', np.dtype(np.uint8): 'TO_U8'}
+_NO_NORMALISE_OPS = set(['EQ', 'NE', 'LT', 'LE', 'GT', 'GE', 'LAND', 'LOR', 'LXOR', 'LNOT', 'WHERE'])
+
+
+def _classes(v, acc):
+  if v.kind in ('tensor', 'op', 'iota') or (v.kind == 'const' and not v.weak):
+    if v.dtype != np.bool_:       # 0/1 is exact in every class
+      acc.append(class_of(v.dtype))
+  elif v.kind == 'const' and v.weak and isinstance(v.value, float):
+    acc.append(None)  # weak float: at least a float class, decided below
+  for a in v.args:
+    _classes(a, acc)
+
+
+def choose_class(root, extra=()):
+  acc = list(extra)
+  _classes(root, acc)
+  concrete = [c for c in acc if c is not None]
+  cls = concrete[0] if concrete else _hip.SP_F64
+  for c in concrete[1:]:
+    cls = join_class(cls, c)
+  if None in acc and cls == _hip.SP_I64:
+    cls = _hip.SP_F64
+  return cls
+
+
+class Emitter(object):
+  def __init__(self, cls, out_shape):
+    self.cls = cls
+    self.out_shape = tuple(out_shape)
+    self.prog = Program()
+    self.tensors = []      # backend tensors, in input order
+    self.in_vals = []      # (V, strides) per input
+    self.free = []
+    self.next_temp = None
+
+  def input_reg(self, v):
+    for i, t in enumerate(self.tensors):
+      if t is v.tensor and self.in_vals[i][0].shape == v.shape:
+        return i
+    self.tensors.append(v.tensor)
+    self.in_vals.append((v, broadcast_strides(v.shape, self.out_shape)))
+    if len(self.tensors) > min(_hip.SP_MAX_INPUTS, _hip.SP_NREG - 1):
+      raise ProgramTooLarge('too many tensor operands')
+    return len(self.tensors) - 1
+
+  def collect_inputs(self, v):
+    if v.kind == 'tensor':
+      self.input_reg(v)
+    for a in v.args:
+      self.collect_inputs(a)
+
+  def alloc(self):
+    if self.free:
+      return self.free.pop()
+    if self.next_temp is None:
+      self.next_temp = len(self.tensors)
+    if self.next_temp >= _hip.SP_NREG:
+      raise ProgramTooLarge('expression needs more than %d registers' % _hip.SP_NREG)
+    r = self.next_temp
+    self.next_temp += 1
+    return r
+
+  def release(self, r):
+    if r >= len(self.tensors) and r not in self.free:
+      self.free.append(r)
+
+  def emit(self, v):
+    p = self.prog
+    if v.kind == 'tensor':
+      return self.input_reg(v)
+    if v.kind == 'const':
+      r = self.alloc()
+      val = v.value
+      if self.cls == _hip.SP_I64:
+        val = int(val)
+      elif self.cls == _hip.SP_F32 and not v.weak and v.dtype == np.float64:
+        raise AssertionError('float64 constant in a float32 program')
+      p.emit('CONST', r, p.add_const(float(val) if self.cls != _hip.SP_I64 else int(val)))
+      return r
+    if v.kind == 'iota':
+      r = self.alloc()
+      p.emit('IOTA', r)
+      return r
+    if v.kind != 'op':
+      raise NotLowerable('value of kind %r cannot be computed in a kernel' % v.kind)
+    if v.op == 'FILL':
+      return self.emit(v.args[0])
+    if v.op == 'CAST':
+      r = self.emit(v.args[0])
+      src_dt, dst_dt = v.args[0].dtype, v.dtype
+      op = None
+      if dst_dt == np.bool_:
+        op = None if src_dt == np.bool_ else 'TO_BOOL'
+      elif dst_dt.kind in 'iu':
+        name = {1: 'TO_U8', 4: 'TO_I32', 8: 'TO_I64'}[dst_dt.itemsize]
+        if src_dt.kind == 'f':
+          op = name                                   # truncate toward zero
+        elif src_dt.kind in 'iu' and src_dt.itemsize > dst_dt.itemsize:
+          op = name                                   # wrap
+      elif dst_dt == np.float32:
+        op = 'TO_F32' if self.cls != _hip.SP_F32 else None
+      if op is None:
+        return r
+      dst = r if r >= len(self.tensors) else self.alloc()
+      p.emit(op, dst, r)
+      return dst
+    regs = [self.emit(a) for a in v.args]
+    for r in regs:
+      self.release(r)
+    dst = self.alloc()
+    if v.op == 'WHERE':
+      p.emit('WHERE', dst, regs[0], regs[1], regs[2])
+    elif len(regs) == 1:
+      p.emit(v.op, dst, regs[0])
+    else:
+      p.emit(v.op, dst, regs[0], regs[1])
+    # keep the value inside its NumPy dtype when the class is wider
+    if v.op not in _NO_NORMALISE_OPS and v.dtype in _NORMALISE and class_of(v.dtype) != self.cls:
+      p.emit(_NORMALISE[v.dtype], dst, dst)
+    elif v.op not in _NO_NORMALISE_OPS and v.dtype == np.int32 and self.cls == _hip.SP_I64:
+      p.emit('TO_I32', dst, dst)
+    elif v.op not in _NO_NORMALISE_OPS and v.dtype == np.uint8:
+      p.emit('TO_U8', dst, dst)
+    return dst
+
+  def finish(self, root, out_dtype):
+    self.collect_inputs(root)   # inputs first: they own registers 0..n-1
+    self.next_temp = len(self.tensors)
+    result = self.emit(root)
+    self.prog.result_reg = result
+    self.prog.inputs = []
+    strides = [st for (_, st) in self.in_vals]
+    cshape, cstrides = collapse(self.out_shape, strides) if strides else collapse(self.out_shape, [])
+    dense = dense_strides(cshape)
+    linear = all(tuple(st) == dense or all(s == 0 for s in st) for st in cstrides)
+    for (v, _), st in zip(self.in_vals, cstrides):
+      self.prog.add_input(v.dtype, st)
+    return self.prog.finish(self.cls, cshape, out_dtype, linear), self.tensors

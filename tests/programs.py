@@ -1,0 +1,135 @@
+"""Shared test programs: each builds an expression with the Spartan API and
+gives the NumPy value it must produce.  They follow the reference's own
+operator tests (tests/test_maptiles.py, test_elementwise.py, test_reduce.py,
+test_dot.py, test_matmul.py, test_optimization.py, test_creation.py) and are run
+against (a) the NumPy tile backend on CPU and (b) the HIP backend on the GPU.
+
+Entry: (name, build(sp) -> Expr, expected() -> ndarray, tol) where tol is None
+for bit-exact results or an (rtol, atol) pair, with the tolerance stated by
+SURVEY 8c for that operator class.
+"""
+import numpy as np
+
+F32 = np.float32
+SUM_TOL = (1e-6, 1e-5)      # |d| <= 1e-6 * sum|x| (different summation tree)
+ULP = (3e-7, 0)             # <= 2 ulp for exp/log/sqrt/div
+
+
+def _ar(shape, dtype=F32):
+  return np.arange(int(np.prod(shape)), dtype=dtype).reshape(shape)
+
+
+def programs():
+  P = []
+  add = P.append
+  # ---- creation / plumbing (BASELINE config 1)
+  add(('ones_plus_one', lambda sp: sp.ones((1000, 1000)) + 1, lambda: np.full((1000, 1000), 2, F32), None))
+  add(('zeros', lambda sp: sp.zeros((33, 7)), lambda: np.zeros((33, 7), F32), None))
+  add(('full', lambda sp: sp.full((12, 5), 3.5), lambda: np.full((12, 5), 3.5, F32), None))
+  add(('arange_2d_f64', lambda sp: sp.arange((40, 30)), lambda: _ar((40, 30), np.float64), None))
+  add(('arange_start_step', lambda sp: sp.arange((13, 5), -1, step=2, dtype=np.int64),
+       lambda: np.arange(-1, -1 + 2 * 65, 2, dtype=np.int64).reshape(13, 5), None))
+  add(('arange_1d', lambda sp: sp.arange(None, stop=100, dtype=F32), lambda: np.arange(100, dtype=F32), None))
+  add(('eye', lambda sp: sp.eye(17, 9, k=1), lambda: np.eye(17, 9, k=1, dtype=F32), None))
+  add(('from_numpy', lambda sp: sp.from_numpy(_ar((31, 11))) * 2, lambda: _ar((31, 11)) * 2, None))
+  # ---- elementwise (tests/test_maptiles.py, test_elementwise.py)
+  add(('add2', lambda sp: sp.ones((100, 10)) + sp.ones((100, 10)), lambda: np.full((100, 10), 2, F32), None))
+  add(('add_many', lambda sp: sp.ones((100, 10)) + sp.ones((100, 10)) + sp.ones((100, 10)) + sp.ones((100, 10)),
+       lambda: np.full((100, 10), 4, F32), None))
+  add(('xx_plus_x', lambda sp: sp.arange((64, 48), dtype=F32) * sp.arange((64, 48), dtype=F32) + sp.arange((64, 48), dtype=F32),
+       lambda: _ar((64, 48)) * _ar((64, 48)) + _ar((64, 48)), None))
+  add(('sub_rsub_neg', lambda sp: -(3 - sp.arange((20, 7), dtype=F32)) - 1.5,
+       lambda: -(3 - _ar((20, 7))) - F32(1.5), None))
+  add(('div', lambda sp: sp.arange((50, 4), dtype=F32) / 7, lambda: _ar((50, 4)) / F32(7), ULP))
+  add(('ln_exp_sqrt', lambda sp: sp.sqrt(sp.exp(sp.ln(sp.arange((30, 10), dtype=F32) + 1))),
+       lambda: np.sqrt(np.exp(np.log(_ar((30, 10)) + 1))), (2e-6, 0)))
+  add(('pow_square_abs', lambda sp: sp.abs(sp.square(sp.arange((9, 9), dtype=F32) - 40) ** 2 - 1000),
+       lambda: np.abs(np.square(_ar((9, 9)) - 40) ** 2 - 1000), (1e-6, 0)))
+  add(('max_min', lambda sp: sp.maximum(sp.arange((10, 10), dtype=F32), 50) + sp.minimum(sp.arange((10, 10), dtype=F32), 20),
+       lambda: np.maximum(_ar((10, 10)), 50) + np.minimum(_ar((10, 10)), 20), None))
+  add(('compare', lambda sp: (sp.arange((25, 8), dtype=F32) > 50), lambda: _ar((25, 8)) > 50, None))
+  add(('logical', lambda sp: (sp.arange((25, 8), dtype=F32) > 50) & (sp.arange((25, 8), dtype=F32) < 100),
+       lambda: (_ar((25, 8)) > 50) & (_ar((25, 8)) < 100), None))
+  add(('astype', lambda sp: sp.astype(sp.arange((25, 8), dtype=F32) * 0.75, np.int32),
+       lambda: (_ar((25, 8)) * F32(0.75)).astype(np.int32), None))
+  add(('int_mod_floordiv', lambda sp: (sp.arange((25, 8), dtype=np.int64) - 100) % 7 + (sp.arange((25, 8), dtype=np.int64) - 100) // 7,
+       lambda: (_ar((25, 8), np.int64) - 100) % 7 + (_ar((25, 8), np.int64) - 100) // 7, None))
+  add(('mixed_f32_i64', lambda sp: sp.arange((25, 8), dtype=F32) + sp.arange((25, 8), dtype=np.int64),
+       lambda: _ar((25, 8)) + _ar((25, 8), np.int64), None))
+  # ---- broadcasting (tests/test_broadcast.py, test_maptiles.py:test_broadcast)
+  add(('bcast_row', lambda sp: sp.arange((64, 10), dtype=F32) + sp.arange((1, 10), dtype=F32),
+       lambda: _ar((64, 10)) + _ar((1, 10)), None))
+  add(('bcast_col', lambda sp: sp.arange((64, 10), dtype=F32) * sp.arange((64, 1), dtype=F32),
+       lambda: _ar((64, 10)) * _ar((64, 1)), None))
+  add(('bcast_vec', lambda sp: sp.arange((64, 10), dtype=F32) - sp.arange((10,), dtype=F32),
+       lambda: _ar((64, 10)) - _ar((10,)), None))
+  add(('bcast_3d', lambda sp: sp.arange((6, 7, 8), dtype=F32) + sp.arange((7, 1), dtype=F32),
+       lambda: _ar((6, 7, 8)) + _ar((7, 1)), None))
+  add(('bcast_numpy', lambda sp: sp.arange((64, 10), dtype=F32) + _ar((10,)), lambda: _ar((64, 10)) + _ar((10,)), None))
+  # ---- reductions (tests/test_reduce.py:14-107)
+  for axis in (None, 0, 1):
+    add(('sum_2d_%s' % axis, (lambda axis: lambda sp: sp.sum(sp.arange((137, 33), dtype=F32) / 1000, axis))(axis),
+         (lambda axis: lambda: (_ar((137, 33)) / F32(1000)).astype(np.float64).sum(axis))(axis), SUM_TOL))
+    add(('max_2d_%s' % axis, (lambda axis: lambda sp: sp.max(sp.arange((137, 33), dtype=F32) % 17, axis))(axis),
+         (lambda axis: lambda: (_ar((137, 33)) % 17).max(axis))(axis), None))
+    add(('min_2d_%s' % axis, (lambda axis: lambda sp: sp.min((sp.arange((137, 33), dtype=F32) - 99) % 17, axis))(axis),
+         (lambda axis: lambda: ((_ar((137, 33)) - 99) % 17).min(axis))(axis), None))
+    add(('argmax_2d_%s' % axis, (lambda axis: lambda sp: sp.argmax(sp.arange((137, 33), dtype=F32) % 19, axis))(axis),
+         (lambda axis: lambda: np.argmax(_ar((137, 33)) % 19, axis))(axis), None))
+    add(('argmin_2d_%s' % axis, (lambda axis: lambda sp: sp.argmin((sp.arange((137, 33), dtype=F32) + 5) % 19, axis))(axis),
+         (lambda axis: lambda: np.argmin((_ar((137, 33)) + 5) % 19, axis))(axis), None))
+    add(('count_nonzero_%s' % axis, (lambda axis: lambda sp: sp.count_nonzero(sp.arange((37, 11), dtype=F32) % 3, axis))(axis),
+         (lambda axis: lambda: np.count_nonzero(_ar((37, 11)) % 3, axis))(axis), None))
+    add(('count_zero_%s' % axis, (lambda axis: lambda sp: sp.count_zero(sp.arange((37, 11), dtype=F32) % 3, axis))(axis),
+         (lambda axis: lambda: (_ar((37, 11)) % 3 == 0).sum(axis))(axis), None))
+    add(('all_any_%s' % axis, (lambda axis: lambda sp: sp.all(sp.arange((37, 11), dtype=F32) > 5, axis) | sp.any(sp.arange((37, 11), dtype=F32) > 400, axis))(axis),
+         (lambda axis: lambda: np.all(_ar((37, 11)) > 5, axis) | np.any(_ar((37, 11)) > 400, axis))(axis), None))
+    add(('mean_%s' % axis, (lambda axis: lambda sp: sp.mean(sp.arange((64, 16), dtype=F32), axis))(axis),
+         (lambda axis: lambda: _ar((64, 16)).astype(np.float64).mean(axis))(axis), SUM_TOL))
+  for axis in (None, 0, 1, 2):
+    add(('sum_3d_%s' % axis, (lambda axis: lambda sp: sp.sum(sp.arange((11, 12, 13), dtype=np.int64), axis))(axis),
+         (lambda axis: lambda: _ar((11, 12, 13), np.int64).sum(axis))(axis), None))
+    add(('argmax_3d_%s' % axis, (lambda axis: lambda sp: sp.argmax(sp.arange((11, 12, 13), dtype=F32) % 23, axis))(axis),
+         (lambda axis: lambda: np.argmax(_ar((11, 12, 13)) % 23, axis))(axis), None))
+  add(('sum_1d', lambda sp: sp.sum(sp.arange((1000,), dtype=np.int64)), lambda: _ar((1000,), np.int64).sum(), None))
+  add(('prod_int32', lambda sp: sp.prod(sp.astype(sp.arange((3, 4), dtype=F32) % 3 + 1, np.int32), 1),
+       lambda: (_ar((3, 4)) % 3 + 1).astype(np.int32).prod(1, dtype=np.int64), None))
+  add(('std', lambda sp: sp.std(sp.arange((64, 16), dtype=F32), 0), lambda: _ar((64, 16)).std(0), (1e-6, 1e-6)))  # E[x^2]-E[x]^2 formula (statistics.py:102)
+  # ---- fusion (tests/test_optimization.py:124-163)
+  add(('opt_map_chain', lambda sp: (sp.ones((50, 50)) + sp.ones((50, 50)) + sp.ones((50, 50)) + sp.ones((50, 50))).optimized(),
+       lambda: np.full((50, 50), 4, F32), None))
+  add(('opt_reduce_map', lambda sp: sp.sum(sp.arange((137, 33), dtype=F32) * sp.arange((137, 33), dtype=F32) / 1e6 + sp.arange((137, 33), dtype=F32) / 1e3, 0).optimized(),
+       lambda: (_ar((137, 33)).astype(np.float64) ** 2 / 1e6 + _ar((137, 33)) / 1e3).sum(0), (1e-5, 1e-5)))
+  # (the broadcast operand is loaded, not generated: a fused map_with_location sees
+  # the DRIVING tile's extent, in the reference too -- optimize.py:180-181)
+  add(('opt_lreg_grad', lambda sp: sp.sum(sp.arange((200, 16), dtype=F32) / 100 * (sp.from_numpy(_ar((200, 1))) / 50 - 1), 0).optimized(),
+       lambda: (_ar((200, 16)).astype(np.float64) / 100 * (_ar((200, 1)) / 50 - 1)).sum(0), (1e-5, 1e-4)))
+  # ---- dot (tests/test_dot.py:8-103, test_matmul.py)
+  small = lambda shape: _ar(shape) % 5 - 2   # small integers: exact in fp32
+  sm = lambda sp, shape: sp.arange(shape, dtype=F32) % 5 - 2
+  add(('dot_tall', lambda sp: sp.dot(sm(sp, (100, 40)), sm(sp, (40, 60))), lambda: small((100, 40)).dot(small((40, 60))), None))
+  add(('dot_wide', lambda sp: sp.dot(sm(sp, (40, 100)), sm(sp, (100, 60))), lambda: small((40, 100)).dot(small((100, 60))), None))
+  add(('dot_square', lambda sp: sp.dot(sm(sp, (128, 128)), sm(sp, (128, 128))), lambda: small((128, 128)).dot(small((128, 128))), None))
+  add(('dot_numpy_rhs', lambda sp: sp.dot(sm(sp, (100, 40)), small((40, 8))), lambda: small((100, 40)).dot(small((40, 8))), None))
+  add(('dot_numpy_vec', lambda sp: sp.dot(sm(sp, (100, 40)), small((40,))), lambda: small((100, 40)).dot(small((40,))), None))
+  add(('dot_2d_vec', lambda sp: sp.dot(sm(sp, (100, 40)), sm(sp, (40,))), lambda: small((100, 40)).dot(small((40,))), None))
+  add(('dot_vec_vec', lambda sp: sp.dot(sm(sp, (333,)), sm(sp, (333,))), lambda: np.asarray([small((333,)).dot(small((333,)))]), None))
+  add(('dot_tile_hint', lambda sp: sp.dot(sm(sp, (64, 128)), sm(sp, (128, 64)), tile_hint=(8, 64)),
+       lambda: small((64, 128)).dot(small((128, 64))), None))
+  add(('dot_f64', lambda sp: sp.dot(sp.arange((30, 20)), sp.arange((20, 10))), lambda: _ar((30, 20), np.float64).dot(_ar((20, 10), np.float64)), None))
+  add(('lreg_step', lambda sp: sp.sum(sm(sp, (256, 16)) * (sp.dot(sm(sp, (256, 16)), small((16, 1))) - sm(sp, (256, 1))), axis=0).optimized(),
+       lambda: (small((256, 16)) * (small((256, 16)).dot(small((16, 1))) - small((256, 1)))).sum(0), None))
+  return P
+
+
+def check(name, got, want, tol):
+  got = np.asarray(got)
+  want = np.asarray(want)
+  assert got.shape == want.shape, '%s: shape %s != %s' % (name, got.shape, want.shape)
+  if tol is None:
+    assert got.dtype.kind == want.dtype.kind or (got.dtype.kind in 'iu' and want.dtype.kind in 'iu'), \
+        '%s: dtype kind %s != %s' % (name, got.dtype, want.dtype)
+    np.testing.assert_array_equal(got, want, err_msg=name)
+  else:
+    rtol, atol = tol
+    np.testing.assert_allclose(got.astype(np.float64), want.astype(np.float64), rtol=rtol, atol=atol, err_msg=name)

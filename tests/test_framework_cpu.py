@@ -1,0 +1,69 @@
+"""Host logic (tiling, extents, DAG, fusion, fetch/update plans) with the
+NumPy tile backend on CPU, for 1/3/8 logical workers -- the reference's tests
+run on 3-worker in-process clusters (tests/test_common.py:128-136)."""
+import numpy as np
+import pytest
+
+import spartan_amd as sp
+from oracle.np_backend import NumpyBackend
+from tests import programs
+
+PROGS = programs.programs()
+
+
+@pytest.fixture(params=[1, 3, 8], ids=lambda n: 'workers%d' % n)
+def ctx(request):
+  c = sp.initialize(backend=NumpyBackend(), num_workers=request.param)
+  yield c
+  sp.shutdown()
+
+
+@pytest.mark.parametrize('prog', PROGS, ids=[p[0] for p in PROGS])
+def test_program(ctx, prog):
+  name, build, expected, tol = prog
+  got = build(sp).glom()
+  programs.check(name, got, expected(), tol)
+
+
+def test_config1_dtype_and_force(ctx):
+  # BASELINE config 1: ones((1000,1000)) + 1 then .force(); fp32 stays fp32
+  r = (sp.ones((1000, 1000)) + 1).force()
+  assert r.dtype == np.float32
+  assert r.shape == (1000, 1000)
+  assert len(r.tiles) == max(1, ctx.num_workers if ctx.num_workers != 3 else 4)
+  g = r.glom()
+  assert g.dtype == np.float32 and np.all(g == 2.0)
+
+
+def test_eval_cache_and_force_alias(ctx):
+  e = sp.ones((10, 10)) + 1
+  a = e.evaluate()
+  assert e.force() is a        # cached by expr_id (base.py:284-287)
+  assert e.optimized().evaluate() is not None
+
+
+def test_fused_op_strings(ctx):
+  # the fused trees the survey observed through the oracle
+  e = (sp.ones((4, 4)) + sp.ones((4, 4)) + sp.ones((4, 4)) + sp.ones((4, 4))).optimized()
+  s = e.op.pretty_str().replace(' ', '')
+  assert s.count('add(') == 3 and s.count('_make_ones(') == 4
+  a = sp.ones((4, 4))
+  r = sp.sum(a * a + a, axis=0).optimized()
+  assert '_sum_local' in r.op.pretty_str() and 'add(' in r.op.pretty_str() and 'multiply(' in r.op.pretty_str()
+  assert len(r.children) == 1     # inputs de-duplicated by variable name (optimize.py:119-130)
+
+
+def test_dot_dispatch(ctx):
+  from spartan_amd.expr.map import Map2Expr
+  from spartan_amd.expr.outer import OuterProductExpr
+  assert isinstance(sp.dot(sp.ones((100, 10)), sp.ones((10, 5))), OuterProductExpr)   # rows > cols
+  assert isinstance(sp.dot(sp.ones((10, 100)), sp.ones((100, 5))), Map2Expr)          # rows <= cols
+  assert isinstance(sp.dot(sp.ones((10, 10)), np.ones((10, 5), np.float32)), Map2Expr)
+  with pytest.raises(ValueError):
+    sp.dot(sp.ones((10, 4)), sp.ones((5, 10)))
+
+
+def test_unknown_reducer_is_loud_on_hip_names():
+  from spartan_amd import backend_hip
+  with pytest.raises(TypeError):
+    backend_hip.HipBackend.reducer_name(None, lambda a, b: a)
