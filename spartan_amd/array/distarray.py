@@ -403,6 +403,17 @@ class DistArrayImpl(DistArray):
     if replicated:
       return self._fetch_replicated(region, splits)
 
+    # Several workers of one kernel asking for the WHOLE array (dot's outer
+    # mapper fetches all of B for every tile, outer.py:21-29): gather it once
+    # on every rank with one all-gather and serve the later requests locally,
+    # instead of one gather-to-one round per worker.
+    cache = ctx.fetch_cache
+    if cache is not None and region.shape == self.shape and region.ul == (0,) * len(self.shape):
+      key = (self.id, region.ul, region.lr)
+      if key not in cache:
+        cache[key] = self._fetch_replicated(region, splits)
+      return cache[key] if want else Absent(region.shape, self.dtype)
+
     sends, recvs, pieces = [], [], []
     for ex, inter in splits:
       tid = self.tiles[ex]
@@ -516,8 +527,10 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
   kw = dict(kw)
   results = collections.OrderedDict()
   outer = ctx.pending
+  outer_cache = ctx.fetch_cache
   batch = UpdateBatch(ctx)
   ctx.pending = batch
+  ctx.fetch_cache = {}
   try:
     for tile_id in tile_ids:
       with ctx.on_worker(tile_id.worker):
@@ -533,6 +546,7 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
             ctx.incref(tid)
   finally:
     ctx.pending = outer
+    ctx.fetch_cache = outer_cache
   batch.flush()
   return results
 

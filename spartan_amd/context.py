@@ -67,6 +67,7 @@ class Context(object):
     self._rr = 0                                      # round-robin cursor for hint-less creates
     self.current_worker = None
     self.pending = None                               # UpdateBatch while a kernel runs
+    self.fetch_cache = None                           # whole-array fetches shared inside one kernel
     self.pending_destructors = []                     # tiles of dead arrays (distarray.py:219-268)
 
   # -- placement --------------------------------------------------------------

@@ -1,0 +1,47 @@
+"""Body of one rank of the world_size-2 gloo tests (launched by test_multiprocess.py).
+Runs the shared Spartan programs with one/two workers per rank and checks every
+result on every rank; prints 'RANK r OK n' on success."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import spartan_amd as sp  # noqa: E402
+from oracle.np_backend import NumpyBackend  # noqa: E402
+from tests import programs  # noqa: E402
+
+
+def main():
+  workers = int(sys.argv[1])
+  world = sp.World.from_env(backend='gloo')
+  assert world.size == 2
+  ctx = sp.initialize(backend=NumpyBackend(), num_workers=workers, world=world)
+  n = 0
+  for name, build, expected, tol in programs.programs():
+    got = build(sp).glom()
+    programs.check(name, got, expected(), tol)
+    n += 1
+  # the regular patterns must have been carried by collectives, not per-tile messages
+  if workers == 2:
+    a = sp.from_numpy(np.arange(64 * 32, dtype=np.float32).reshape(64, 32) % 7)
+    before = dict(world.stats)
+    s = sp.sum(a, axis=0).glom()                 # partial (32,) per rank -> reduce_scatter + all_gather
+    np.testing.assert_array_equal(s, (np.arange(64 * 32, dtype=np.float32).reshape(64, 32) % 7).sum(0))
+    assert world.stats['collectives'] >= before['collectives'] + 2, world.stats
+    assert world.stats['p2p_msgs'] == before['p2p_msgs'], world.stats
+    before = dict(world.stats)
+    b = sp.from_numpy(np.arange(32 * 64, dtype=np.float32).reshape(32, 64) % 5)
+    d = sp.dot(b, a).glom()                      # K-split map2: A slabs by p2p, partials by reduce
+    np.testing.assert_array_equal(d, (np.arange(32 * 64, dtype=np.float32).reshape(32, 64) % 5).dot(
+        np.arange(64 * 32, dtype=np.float32).reshape(64, 32) % 7))
+    assert world.stats['collectives'] > before['collectives'], world.stats
+  world.barrier()
+  print('RANK %d OK %d' % (world.rank, n))
+  sys.stdout.flush()
+
+
+if __name__ == '__main__':
+  main()
