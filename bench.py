@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Headline benchmark: BASELINE.json's metric
+    "spartan.dot TFLOP/s + map/reduce HBM GB/s at 1/2/4/8 MI355X".
+
+One "step" = one `spartan.dot(A, B).force()` through the whole tile path
+(lazy DAG -> per-tile fp32 MFMA GEMM launch -> Tile.merge into the target),
+operands already resident in HBM:
+
+  --gpus 1 : BASELINE configs[1] -- dot 8192 x 8192 x 8192 fp32, one tile.
+  --gpus N : weak scaling, fixed 8192^3 of GEMM per GPU: A is (8192 N) x 8192
+             and B 8192 x 8192, both row-tiled one tile per GPU; rows > cols so
+             the reference takes its outer-product path (dot.py:281-285): every
+             worker fetches all of B (ONE RCCL all-gather per step, the path's
+             real exchange step) and writes a disjoint row block of C.
+
+`value` is whole-job TFLOP/s (2 M N K summed over ranks / max-over-ranks time).
+The same JSON line carries the roofline of the dominant kernel (sp_gemm_kernel,
+MFMA-bound, durations from HIP events on the launch stream), the fused-map and
+reduce HBM rates, and a CPU baseline (the NumPy oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import spartan_amd as sp  # noqa: E402
+from spartan_amd import kernels  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
+SEED = 20150708
+
+
+def device_uniform(ex, lo, hi, seed):
+  g = torch.Generator(device='cuda')
+  g.manual_seed(seed + 1000003 * ex.ul[0])
+  t = torch.rand(ex.shape, dtype=torch.float32, device='cuda', generator=g)
+  return t * (hi - lo) + lo
+
+
+def time_steps(ctx, step, steps, warmup):
+  for _ in range(warmup):
+    step()
+  ctx.world.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step()
+  torch.cuda.synchronize()
+  ctx.world.barrier()
+  dt = time.perf_counter() - t0
+  if ctx.world.distributed:
+    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    ctx.world.all_reduce(t, 'MAX')
+    dt = float(t.item())
+  return dt
+
+
+def event_time(fn, iters, warmup=2):
+  for _ in range(warmup):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = kernels.Event(), kernels.Event()
+  e0.record()
+  for _ in range(iters):
+    fn()
+  e1.record()
+  e1.synchronize()
+  return e0.elapsed_ms(e1) / iters
+
+
+def hbm_section(ctx):
+  """Fused map and reduce rates on one 2 GiB fp32 tile (HBM-bound kernels)."""
+  rows, cols = 8192, 65536            # BASELINE configs[2] tile: 8192 x 65536 fp32
+  n = rows * cols
+  X = sp.from_tile_fn((rows, cols), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 7)).force()
+  Xv = sp.Val(val=X)
+  out = {}
+  t = X.tiles
+  x = ctx.tile(list(t.values())[0]).data
+  y = torch.empty_like(x)
+  ms = event_time(lambda: kernels.stream_copy(y, x), 5)
+  out['stream_copy_GBps'] = round(2 * 4.0 * n / ms / 1e6, 1)
+  del y
+  ms = event_time(lambda: (Xv * Xv + Xv).optimized().force(), 5)
+  out['map_xx_plus_x_GBps'] = round(8.0 * n / ms / 1e6, 1)          # 4*(n_in+1)*E bytes
+  ms = event_time(lambda: (Xv + 1).force(), 5)
+  out['map_x_plus_1_GBps'] = round(8.0 * n / ms / 1e6, 1)
+  for axis in (None, 0, 1):
+    ms = event_time(lambda: sp.sum(Xv, axis).force(), 5)
+    out['sum_axis%s_GBps' % axis] = round(4.0 * n / ms / 1e6, 1)    # 4*E bytes
+  ms = event_time(lambda: sp.argmax(Xv, 1).force(), 5)
+  out['argmax_axis1_GBps'] = round(4.0 * n / ms / 1e6, 1)
+  out['hbm_peak_GBps'] = HBM_PEAK_GBPS
+  out['tile'] = '%dx%d fp32' % (rows, cols)
+  return out
+
+
+def cpu_baseline():
+  """The NumPy oracle (a port of the reference's NumPy-worker path) on the host:
+  one worker == one core (spartan/worker.py:40), BLAS pinned to one thread."""
+  from oracle import spartan_np as O
+  try:
+    from threadpoolctl import threadpool_limits
+  except ImportError:
+    threadpool_limits = None
+  n = 4096
+  rng = np.random.RandomState(SEED)
+  a = (rng.rand(n, n) * 2 - 1).astype(np.float32)
+  b = (rng.rand(n, n) * 2 - 1).astype(np.float32)
+  cl = O.Cluster(1)
+  A, B = cl.from_numpy(a), cl.from_numpy(b)
+
+  def run():
+    t0 = time.perf_counter()
+    cl.dot(A, B).glom()
+    return time.perf_counter() - t0
+  if threadpool_limits is not None:
+    with threadpool_limits(limits=1):
+      run()
+      dt = min(run(), run())
+    cores = 1
+  else:
+    run()
+    dt = min(run(), run())
+    cores = os.cpu_count() or 1
+  x = rng.rand(4096, 16384).astype(np.float32)
+  X = cl.from_numpy(x)
+  t0 = time.perf_counter()
+  cl.map(lambda t: t * t + t, X)
+  t_map = time.perf_counter() - t0
+  t0 = time.perf_counter()
+  cl.sum(X, 0).glom()
+  t_sum = time.perf_counter() - t0
+  return {'value': round(2.0 * n ** 3 / dt / 1e12, 4), 'unit': 'TFLOP/s', 'cores': cores, 'kind': 'port',
+          'sample': 'oracle (NumPy port) spartan.dot %dx%dx%d fp32, 1 worker, %d BLAS thread(s), best of 2 '
+                    '(%.2f s each); map x*x+x %.1f GB/s, sum axis0 %.1f GB/s on 4096x16384 fp32'
+                    % (n, n, n, cores, dt, 8.0 * x.size / t_map / 1e9, 4.0 * x.size / t_sum / 1e9)}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--size', type=int, default=8192)
+  ap.add_argument('--no-extras', action='store_true', help='skip the map/reduce and CPU-baseline sections')
+  args = ap.parse_args()
+
+  world = sp.World.from_env()
+  if world.size != args.gpus:
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)'
+                     % (args.gpus, world.size, args.gpus))
+  ctx = sp.initialize('hip', world=world)
+  n = args.size
+  p = world.size
+  M = n * p
+  if p == 1:
+    A = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED))
+    B = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 1))
+    hint = None
+    workload = 'spartan.dot %dx%dx%d fp32, one tile (BASELINE configs[1])' % (n, n, n)
+    parallelism = 'single tile'
+  else:
+    A = sp.from_tile_fn((M, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED), tile_hint=(n, n))
+    B = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 1))
+    hint = (n, n)
+    workload = ('spartan.dot (%dx%d).(%dx%d) fp32, A and C row-tiled %d x (%dx%d), B all-gathered per step'
+                % (M, n, n, n, p, n, n))
+    parallelism = 'row tiles, 1 worker per GPU, RCCL all-gather of B'
+
+  keep = []
+
+  def step():
+    keep[:] = [sp.dot(A, B, tile_hint=hint).force()]
+
+  ctx.backend.gemm_events = []
+  step()          # first call: library load, allocator warm-up
+  ctx.backend.gemm_events = []
+  dt = time_steps(ctx, step, args.steps, args.warmup)
+  torch.cuda.synchronize()
+  events = ctx.backend.gemm_events[-args.steps:] if world.size == 1 else ctx.backend.gemm_events[-args.steps:]
+  ctx.backend.gemm_events = None
+  kernel_ms = [e0.elapsed_ms(e1) for (e0, e1, _, _, _) in events]
+  flops_launch = 2.0 * events[0][2] * events[0][3] * events[0][4]
+  avg_ms = sum(kernel_ms) / len(kernel_ms)
+  achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+
+  total_flops = 2.0 * M * n * n * args.steps
+  value = total_flops / dt / 1e12
+  line = {
+      'metric': 'spartan.dot TFLOP/s (+ map/reduce HBM GB/s)', 'value': round(value, 2), 'unit': 'TFLOP/s',
+      'n_gpus': p, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': workload, 'parallelism': parallelism, 'flop_per_step': 2.0 * M * n * n,
+                 'inputs': 'uniform[-1,1) fp32 generated on device, resident in HBM'},
+      'roofline': {'bound': 'mfma', 'kernel': 'sp_gemm_kernel<256,128,16,2,2> (v_mfma_f32_32x32x2_f32)',
+                   'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                   'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                   'flop_per_launch': flops_launch, 'avg_launch_ms': round(avg_ms, 4), 'traffic': None},
+  }
+  traffic_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+  if os.path.exists(traffic_file):
+    try:
+      line['roofline']['traffic'] = json.load(open(traffic_file)).get('gemm_%d' % n)
+    except Exception:
+      pass
+  if world.rank == 0 and not args.no_extras:
+    if p == 1:
+      del keep[:]
+      torch.cuda.empty_cache()
+      line['hbm'] = hbm_section(ctx)
+      line['cpu_baseline'] = cpu_baseline()
+  if world.distributed:
+    line['comm'] = dict(world.stats)
+  world.barrier()
+  if world.rank == 0:
+    print(json.dumps(line))
+    sys.stdout.flush()
+  sp.shutdown()
+  if world.distributed:
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,158 @@
+"""TEST INFRASTRUCTURE.  An eager, Spartan-flavoured facade over
+oracle/spartan_np.py so that the shared test programs (tests/programs.py) can
+be run through the oracle unchanged:  `facade(num_workers)` returns an object
+with ones / arange / sum / dot / ... whose results support the arithmetic
+operators and .glom() / .optimized() / .force().  Laziness and fusion do not
+change values, so the facade evaluates every operation immediately."""
+import numpy as np
+
+from . import spartan_np as O
+
+
+class OArr(object):
+  def __init__(self, api, d):
+    self.api = api
+    self.d = d
+
+  shape = property(lambda self: self.d.shape)
+  dtype = property(lambda self: self.d.dtype)
+
+  def glom(self):
+    return self.d.glom()
+
+  def optimized(self):
+    return self
+
+  def force(self):
+    return self
+
+  evaluate = force
+
+  def _bin(self, other, fn, swap=False):
+    a, b = (other, self) if swap else (self, other)
+    return self.api.map((a, b), fn)
+
+  def __add__(self, o): return self._bin(o, np.add)
+  def __radd__(self, o): return self._bin(o, np.add, True)
+  def __sub__(self, o): return self._bin(o, np.subtract)
+  def __rsub__(self, o): return self._bin(o, np.subtract, True)
+  def __mul__(self, o): return self._bin(o, np.multiply)
+  def __rmul__(self, o): return self._bin(o, np.multiply, True)
+  def __truediv__(self, o): return self._bin(o, np.divide)
+  def __rtruediv__(self, o): return self._bin(o, np.divide, True)
+  def __floordiv__(self, o): return self._bin(o, np.floor_divide)
+  def __mod__(self, o): return self._bin(o, np.mod)
+  def __pow__(self, o): return self._bin(o, np.power)
+  def __gt__(self, o): return self._bin(o, np.greater)
+  def __lt__(self, o): return self._bin(o, np.less)
+  def __ge__(self, o): return self._bin(o, np.greater_equal)
+  def __le__(self, o): return self._bin(o, np.less_equal)
+  def __eq__(self, o): return self._bin(o, np.equal)
+  def __ne__(self, o): return self._bin(o, np.not_equal)
+  def __and__(self, o): return self._bin(o, np.logical_and)
+  def __or__(self, o): return self._bin(o, np.logical_or)
+  def __neg__(self): return self.api.map((self,), np.negative)
+  __hash__ = object.__hash__
+
+
+class Facade(object):
+  def __init__(self, num_workers=1):
+    self.c = O.Cluster(num_workers)
+
+  def _w(self, d):
+    return OArr(self, d)
+
+  def _u(self, x):
+    if isinstance(x, OArr):
+      return x.d
+    if isinstance(x, np.ndarray):
+      return self.c.from_numpy(x)
+    return x
+
+  def map(self, inputs, fn):
+    return self._w(self.c.map(fn, *[self._u(i) for i in inputs]))
+
+  # creation
+  def ones(self, shape, dtype=np.float32, tile_hint=None): return self._w(self.c.ones(shape, dtype))
+  def zeros(self, shape, dtype=np.float32, tile_hint=None): return self._w(self.c.zeros(shape, dtype))
+
+  def full(self, shape, fill_value, dtype=np.float32, tile_hint=None):
+    return self._w(self.c.map(lambda t: np.full(t.shape, fill_value, dtype=dtype), self.c.empty(shape, dtype)))
+
+  def arange(self, start=None, stop=None, step=1, dtype=float, tile_hint=None):
+    # creation.py:144-206
+    shape = None
+    if isinstance(start, (tuple, list)):
+      shape = start
+      start = 0
+      if stop is not None:
+        start, stop = stop, None
+    elif start is None:
+      start = 0
+    elif stop is None:
+      stop, start = start, 0
+    if shape is None:
+      shape = (int(np.ceil((stop - start) / float(step))),)
+    return self._w(self.c.arange(tuple(shape), start, step, dtype))
+
+  def eye(self, N, M=None, k=0, dtype=np.float32, tile_hint=None):
+    M = N if M is None else M
+
+    def fn(t, ex):  # creation.py:51-53 (+ column origin)
+      return np.eye(ex.lr[0] - ex.ul[0], M=ex.lr[1] - ex.ul[1], k=ex.ul[0] - ex.ul[1] + k, dtype=dtype)
+    return self._w(self.c.map_with_location(fn, self.c.empty((N, M), dtype)))
+
+  def from_numpy(self, a, tile_hint=None): return self._w(self.c.from_numpy(a))
+
+  # elementwise
+  def sqrt(self, v): return self.map((v,), np.sqrt)
+  def exp(self, v): return self.map((v,), np.exp)
+  def ln(self, v): return self.map((v,), np.log)
+  log = ln
+  def abs(self, v): return self.map((v,), np.abs)
+  def square(self, v): return self.map((v,), np.square)
+  def maximum(self, a, b): return self.map((a, b), np.maximum)
+  def minimum(self, a, b): return self.map((a, b), np.minimum)
+  def astype(self, x, dtype): return self.map((x,), lambda t: t.astype(dtype))
+
+  # reductions
+  def sum(self, x, axis=None, tile_hint=None): return self._w(self.c.sum(self._u(x), axis))
+  def max(self, x, axis=None, tile_hint=None): return self._w(self.c.max(self._u(x), axis))
+  def min(self, x, axis=None, tile_hint=None): return self._w(self.c.min(self._u(x), axis))
+  def argmax(self, x, axis=None): return self._w(self.c.argmax(self._u(x), axis))
+  def argmin(self, x, axis=None): return self._w(self.c.argmin(self._u(x), axis))
+
+  def prod(self, x, axis=None):
+    d = self._u(x)
+    dt = np.int64 if d.dtype == np.int32 else d.dtype          # mathematics.py:150-154
+    return self._w(self.c.reduce(d, axis, dt, lambda ex, t, a: t.prod(a), np.multiply))
+
+  def all(self, x, axis=None):
+    return self._w(self.c.reduce(self._u(x), axis, np.bool_, lambda ex, t, a: np.all(t, axis=a), np.logical_and))
+
+  def any(self, x, axis=None):
+    return self._w(self.c.reduce(self._u(x), axis, np.bool_, lambda ex, t, a: np.any(t, axis=a), np.logical_or))
+
+  def count_nonzero(self, x, axis=None, tile_hint=None):       # sorting.py:126-150
+    fn = lambda ex, t, a: np.asarray(np.count_nonzero(t)) if a is None else (t > 0).sum(a)
+    return self._w(self.c.reduce(self._u(x), axis, np.int64, fn, np.add))
+
+  def count_zero(self, x, axis=None):                           # sorting.py:153-172
+    fn = lambda ex, t, a: np.asarray(np.prod(ex.shape) - np.count_nonzero(t)) if a is None else (t == 0).sum(a)
+    return self._w(self.c.reduce(self._u(x), axis, np.int64, fn, np.add))
+
+  def mean(self, x, axis=None):                                 # statistics.py:64-76
+    if axis is None:
+      return self.sum(x, axis) / int(np.prod(x.shape))
+    return self.sum(x, axis) / int(x.shape[axis])
+
+  def std(self, a, axis=None):                                  # statistics.py:86-102
+    c = self.astype(a, np.float64)
+    return self.sqrt(self.mean(c ** 2, axis) - self.mean(c, axis) ** 2)
+
+  def dot(self, a, b, tile_hint=None):
+    return self._w(self.c.dot(self._u(a), b if isinstance(b, np.ndarray) else self._u(b), tile_hint))
+
+
+def facade(num_workers=1):
+  return Facade(num_workers)

@@ -31,6 +31,7 @@ class HipBackend(object):
     self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     self._np_cache = {}
     self.launches = 0
+    self.gemm_events = None   # set to [] to record (start, stop) HIP events around every GEMM launch
 
   # -- memory -------------------------------------------------------------------
   def empty(self, shape, dtype):
@@ -278,7 +279,14 @@ class HipBackend(object):
       if b.stride(1) != 1:
         b = self.copy(b)
       self.launches += 1
-      kernels.gemm_f32(a, b, c, accumulate=False)
+      if self.gemm_events is not None:
+        e0, e1 = kernels.Event(), kernels.Event()
+        e0.record()
+        kernels.gemm_f32(a, b, c, accumulate=False)
+        e1.record()
+        self.gemm_events.append((e0, e1, M, N, K))
+      else:
+        kernels.gemm_f32(a, b, c, accumulate=False)
       return c
     va = lower.V('tensor', dtype=a_dt, shape=tuple(a.shape), tensor=self.contiguous(a))
     vb = lower.V('tensor', dtype=b_dt, shape=tuple(b.shape), tensor=self.contiguous(b))

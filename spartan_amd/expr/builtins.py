@@ -144,6 +144,20 @@ def from_numpy(npa, tile_hint=None):
   return base.Val(val=arr)
 
 
+def from_tile_fn(shape, dtype, fn, tile_hint=None):
+  """Build a DistArray whose tiles are produced IN PLACE on their owning worker:
+  fn(extent) -> backend tensor of extent.shape (e.g. device-side RNG).  The
+  loader analogue of from_numpy for data that never exists on the host."""
+  ctx = context.get()
+  arr = distarray.create(shape, dtype, tile_hint=tile_hint)
+  for ex, tid in arr.tiles.items():
+    if ctx.is_local(tid):
+      data = fn(ex)
+      ctx.tile(tid).update(ctx.backend, None, data.reshape(ex.shape), None, owned=True)
+  arr._touched = True
+  return base.Val(val=arr)
+
+
 # ------------------------------------------------------------- mathematics.py
 def add(a, b): return map((a, b), fn=np.add)
 def reciprocal(a): return map(a, fn=np.reciprocal)

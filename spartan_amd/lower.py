@@ -310,6 +310,18 @@ def choose_class(root, extra=()):
   return cls
 
 
+def _same_storage(a, b):
+  """Two fetches of the same tile region are distinct view objects over the
+  same HBM bytes: load them once (the reference loads each use separately)."""
+  if a is b:
+    return True
+  try:
+    return (a.data_ptr() == b.data_ptr() and a.dtype == b.dtype and tuple(a.shape) == tuple(b.shape) and
+            tuple(a.stride()) == tuple(b.stride()))
+  except AttributeError:
+    return False
+
+
 class Emitter(object):
   def __init__(self, cls, out_shape):
     self.cls = cls
@@ -322,7 +334,7 @@ class Emitter(object):
 
   def input_reg(self, v):
     for i, t in enumerate(self.tensors):
-      if t is v.tensor and self.in_vals[i][0].shape == v.shape:
+      if self.in_vals[i][0].shape == v.shape and _same_storage(t, v.tensor):
         return i
     self.tensors.append(v.tensor)
     self.in_vals.append((v, broadcast_strides(v.shape, self.out_shape)))
