@@ -41,6 +41,7 @@ class World(object):
     self.size = size
     self.group = group
     self.stats = {'p2p_bytes': 0, 'collective_bytes': 0, 'p2p_msgs': 0, 'collectives': 0}
+    self.staged = False   # debug transport: stage device tensors through the host (see from_env)
 
   @property
   def distributed(self):
@@ -58,20 +59,35 @@ class World(object):
       return World(0, 1, None)
     rank = int(os.environ['RANK'])
     if backend is None:
-      backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+      # SPARTAN_DIST_BACKEND=gloo is a DEBUG transport: HBM blobs are staged through
+      # host memory so that the N>1 code path can be exercised with several ranks
+      # sharing one GPU (RCCL refuses two ranks on one device).  Never the default.
+      backend = os.environ.get('SPARTAN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if backend == 'nccl':
       local = int(os.environ.get('LOCAL_RANK', rank))
       torch.cuda.set_device(local)
       dist.init_process_group(backend, rank=rank, world_size=ws, device_id=torch.device('cuda', local))
     else:
+      if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)) % ndev)
       dist.init_process_group(backend, rank=rank, world_size=ws)
-    return World(rank, ws, None)
+    w = World(rank, ws, None)
+    w.staged = backend != 'nccl'
+    return w
 
   # -- primitives -------------------------------------------------------------
   def barrier(self):
     if self.distributed:
       dist.barrier(group=self.group)
+
+  def _stage(self, t):
+    return t.cpu() if (self.staged and t.is_cuda) else t
+
+  def _unstage(self, dst, host):
+    if host is not dst:
+      dst.copy_(host)
 
   def exchange(self, sends, recvs):
     """sends: [(dst_rank, tensor)], recvs: [(src_rank, tensor)]; contiguous
@@ -81,17 +97,22 @@ class World(object):
       return
     assert self.distributed, 'exchange() with remote peers in a 1-process world'
     ops = []
+    staged = []
     # a single deterministic order on every rank: interleave as listed
     for dst, t in sends:
       assert t.is_contiguous()
-      ops.append(dist.P2POp(dist.isend, t, dst, group=self.group))
+      ops.append(dist.P2POp(dist.isend, self._stage(t), dst, group=self.group))
       self.stats['p2p_bytes'] += t.numel() * t.element_size()
       self.stats['p2p_msgs'] += 1
     for src, t in recvs:
       assert t.is_contiguous()
-      ops.append(dist.P2POp(dist.irecv, t, src, group=self.group))
+      h = self._stage(t)
+      staged.append((t, h))
+      ops.append(dist.P2POp(dist.irecv, h, src, group=self.group))
     for req in dist.batch_isend_irecv(ops):
       req.wait()
+    for t, h in staged:
+      self._unstage(t, h)
 
   def all_gather(self, out_tensors, tensor):
     self.stats['collectives'] += 1
@@ -101,34 +122,45 @@ class World(object):
   def all_gather_into(self, out, tensor):
     self.stats['collectives'] += 1
     self.stats['collective_bytes'] += tensor.numel() * tensor.element_size() * (self.size - 1)
+    if self.staged or not tensor.is_cuda:
+      parts = [torch.empty(tensor.shape, dtype=tensor.dtype) for _ in range(self.size)]
+      dist.all_gather(parts, self._stage(tensor).contiguous(), group=self.group)
+      out.copy_(torch.cat([p.reshape(-1) for p in parts]).view(out.shape))
+      return
     dist.all_gather_into_tensor(out, tensor, group=self.group)
 
   def reduce_scatter(self, out, inp, reducer):
     """out[rank chunk] = reduce over ranks of inp (inp = size equal chunks)."""
     self.stats['collectives'] += 1
     self.stats['collective_bytes'] += inp.numel() * inp.element_size() * (self.size - 1) // self.size
-    if inp.is_cuda:
+    if inp.is_cuda and not self.staged:
       dist.reduce_scatter_tensor(out, inp, op=_red_ops()[reducer], group=self.group)
     else:
-      # gloo has no reduce_scatter: all_reduce + take our chunk (CPU tests only)
-      tmp = inp.clone()
+      # gloo has no reduce_scatter: all_reduce + take our chunk (CPU tests / debug transport)
+      tmp = self._stage(inp).clone()
       dist.all_reduce(tmp, op=_red_ops()[reducer], group=self.group)
       out.copy_(tmp.view(self.size, -1)[self.rank].view_as(out))
 
   def all_reduce(self, tensor, reducer):
     self.stats['collectives'] += 1
     self.stats['collective_bytes'] += 2 * tensor.numel() * tensor.element_size() * (self.size - 1) // self.size
-    dist.all_reduce(tensor, op=_red_ops()[reducer], group=self.group)
+    h = self._stage(tensor)
+    dist.all_reduce(h, op=_red_ops()[reducer], group=self.group)
+    self._unstage(tensor, h)
 
   def reduce(self, tensor, dst, reducer):
     self.stats['collectives'] += 1
     self.stats['collective_bytes'] += tensor.numel() * tensor.element_size()
-    dist.reduce(tensor, dst, op=_red_ops()[reducer], group=self.group)
+    h = self._stage(tensor)
+    dist.reduce(h, dst, op=_red_ops()[reducer], group=self.group)
+    self._unstage(tensor, h)
 
   def broadcast(self, tensor, src):
     self.stats['collectives'] += 1
     self.stats['collective_bytes'] += tensor.numel() * tensor.element_size()
-    dist.broadcast(tensor, src, group=self.group)
+    h = self._stage(tensor)
+    dist.broadcast(h, src, group=self.group)
+    self._unstage(tensor, h)
 
   def broadcast_object(self, obj, src):
     if not self.distributed:

@@ -7,16 +7,30 @@
 // 8 workgroups per CU with a grid-stride loop.
 #include "sp_interp.hpp"
 
-template <typename T, int V, bool LINEAR>
+// One workgroup handles U x 256 vectors of V elements (16 B each): group u of a
+// thread is 256 vectors after group u-1, so every load/store instruction of the
+// workgroup is a fully coalesced 4 KiB.  The grid covers the tile exactly (no
+// grid-stride loop: on MI355X a full grid streams ~25% faster than a capped,
+// grid-striding one -- tools/hbm_probe.hip, profiles/).
+template <typename T, int V, int U, bool LINEAR>
 __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, const sp_inputs in,
                                                           void* __restrict__ out, int64_t start,
                                                           int64_t nvec) {
-  const int64_t stride = (int64_t)gridDim.x * SP_BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK + threadIdx.x; i < nvec; i += stride) {
-    const int64_t L = start + i * V;
-    T res[V];
-    sp_eval<T, V, LINEAR>(p, in, L, res);
-    sp_store_vec<T, V>(out, p.out_dtype, L, res);
+  const int64_t stride = (int64_t)gridDim.x * SP_BLOCK * U;
+  for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK * U + threadIdx.x; i < nvec; i += stride) {
+    int64_t L[U];
+    bool full = true;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t k = i + (int64_t)u * SP_BLOCK;
+      L[u] = start + (k < nvec ? k : i) * V;   // tail groups re-evaluate group 0 (never stored)
+      full = full && (k < nvec);
+    }
+    T res[U][V];
+    sp_eval_u<T, V, U, LINEAR>(p, in, L, res);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u == 0 || full || i + (int64_t)u * SP_BLOCK < nvec) sp_store_vec<T, V>(out, p.out_dtype, L[u], res[u]);
   }
 }
 
@@ -67,12 +81,46 @@ int sp_validate_program(const sp_program* p) {
   return 0;
 }
 
-static inline int sp_grid_for(int64_t nvec) {
-  int64_t blocks = (nvec + SP_BLOCK - 1) / SP_BLOCK;
+static inline unsigned sp_grid_for(int64_t nvec, int U) {
+  int64_t blocks = (nvec + (int64_t)SP_BLOCK * U - 1) / ((int64_t)SP_BLOCK * U);
+  // interpreter kernels pay a per-workgroup prologue (program + strides from the kernel
+  // argument segment): a capped grid that strides measured faster than a full grid
   const int64_t cap = (int64_t)SP_CUS * SP_BLOCKS_PER_CU;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  return (int)blocks;
+  return (unsigned)blocks;
+}
+
+// Tuning knob: groups per lane for the vectorised fp32 paths (SP_MAP_UNROLL=1|2|4).
+static int sp_map_unroll() {
+  static int u = -1;
+  if (u < 0) {
+    const char* e = getenv("SP_MAP_UNROLL");
+    u = e ? atoi(e) : 1;   // measured (profiles/r01_kbench_map_unroll.txt): 1 is fastest for the interpreter
+    if (u != 1 && u != 2 && u != 4) u = 1;
+  }
+  return u;
+}
+
+template <typename T, int V, int U, bool LINEAR>
+static int sp_map_go(const sp_program* p, const sp_inputs& in, void* out, int64_t start, int64_t nvec,
+                     hipStream_t st) {
+  hipLaunchKernelGGL((sp_map_kernel<T, V, U, LINEAR>), dim3(sp_grid_for(nvec, U)), dim3(SP_BLOCK), 0, st, *p, in,
+                     out, start, nvec);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int V, bool LINEAR>
+static int sp_map_go_u(const sp_program* p, const sp_inputs& in, void* out, int64_t start, int64_t nvec,
+                       hipStream_t st) {
+  // multi-group variants are instantiated for the fp32 class only (the hot dtype)
+  if constexpr (std::is_same<T, float>::value && V > 1) {
+    const int u = nvec >= 4 * SP_BLOCK * 64 ? sp_map_unroll() : 1;
+    if (u == 4) return sp_map_go<T, V, 4, LINEAR>(p, in, out, start, nvec, st);
+    if (u == 2) return sp_map_go<T, V, 2, LINEAR>(p, in, out, start, nvec, st);
+  }
+  return sp_map_go<T, V, 1, LINEAR>(p, in, out, start, nvec, st);
 }
 
 template <typename T>
@@ -89,27 +137,12 @@ static int sp_map_launch(const sp_program* p, const sp_inputs& in, const void* c
     for (int j = 0; j < p->n_inputs && vec; ++j)
       if (p->in_stride[j][p->ndim - 1] != 0 && !aligned16(inp[j])) vec = false;
     int64_t nmain = vec ? (n / V) * V : 0;
-    if (nmain) {
-      hipLaunchKernelGGL((sp_map_kernel<T, V, true>), dim3(sp_grid_for(nmain / V)), dim3(SP_BLOCK), 0,
-                         st, *p, in, out, (int64_t)0, nmain / V);
-      SP_CHECK_LAUNCH();
-    }
-    if (n - nmain) {
-      hipLaunchKernelGGL((sp_map_kernel<T, 1, true>), dim3(sp_grid_for(n - nmain)), dim3(SP_BLOCK), 0,
-                         st, *p, in, out, nmain, n - nmain);
-      SP_CHECK_LAUNCH();
-    }
-  } else {
-    if (sp_can_vectorize<V>(p, inp, out)) {
-      hipLaunchKernelGGL((sp_map_kernel<T, V, false>), dim3(sp_grid_for(n / V)), dim3(SP_BLOCK), 0, st,
-                         *p, in, out, (int64_t)0, n / V);
-    } else {
-      hipLaunchKernelGGL((sp_map_kernel<T, 1, false>), dim3(sp_grid_for(n)), dim3(SP_BLOCK), 0, st, *p,
-                         in, out, (int64_t)0, n);
-    }
-    SP_CHECK_LAUNCH();
+    if (nmain && sp_map_go_u<T, V, true>(p, in, out, 0, nmain / V, st)) return 1;
+    if (n - nmain && sp_map_go<T, 1, 1, true>(p, in, out, nmain, n - nmain, st)) return 1;
+    return 0;
   }
-  return 0;
+  if (sp_can_vectorize<V>(p, inp, out)) return sp_map_go_u<T, V, false>(p, in, out, 0, n / V, st);
+  return sp_map_go<T, 1, 1, false>(p, in, out, 0, n, st);
 }
 
 extern "C" int sp_map_fused(const sp_program* prog, const void* const* d_inputs, void* d_out,

@@ -319,30 +319,48 @@ __device__ __forceinline__ T sp_const(const sp_program& p, int i) {
 }
 
 // ---- the evaluator ----------------------------------------------------------
-// Evaluates the program for the V elements whose row-major linear indices are
-// L .. L+V-1 (callers guarantee they share every coordinate but the last when
-// !LINEAR).  Result in out[0..V).
-template <typename T, int V, bool LINEAR>
-__device__ __forceinline__ void sp_eval(const sp_program& p, const sp_inputs& in, int64_t L,
-                                        T (&out)[V]) {
-  T r[SP_NREG * V];
-#pragma unroll
-  for (int k = 0; k < SP_NREG * V; ++k) r[k] = (T)0;
+// Evaluates the program for U groups of V consecutive elements; group u starts
+// at row-major linear index L[u] (callers guarantee the V elements of a group
+// share every coordinate but the last when !LINEAR).  Results in out[u][0..V).
+//
+// U > 1 amortises the scalar dispatch of each interpreted instruction (the
+// shared scalar unit is the bottleneck of long programs) over U*V elements and
+// puts U independent 16-B loads per operand in flight per lane.  Each group has
+// its own 8 x V register file so that every dynamically indexed array stays
+// within the 32 dwords the s_set_gpr_idx path handles.
+template <typename T, int V, int U, bool LINEAR>
+__device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& in, const int64_t (&L)[U],
+                                          T (&out)[U][V]) {
+  // one array per group: a [U][32] array would be a single 32*U-dword alloca that
+  // the compiler cannot keep in registers under dynamic indexing (it goes to scratch)
+  T r0[SP_NREG * V], r1[SP_NREG * V], r2[SP_NREG * V], r3[SP_NREG * V];
+  static_assert(U == 1 || U == 2 || U == 4, "U must be 1, 2 or 4");
+#define SP_U_LIST(X)                 \
+  X(0)                               \
+  if constexpr (U > 1) { X(1) }      \
+  if constexpr (U > 2) { X(2) X(3) }
+#define SP_ZERO(u) _Pragma("unroll") for (int k = 0; k < SP_NREG * V; ++k) r##u[k] = (T)0;
+  SP_U_LIST(SP_ZERO)
+#undef SP_ZERO
 
-  // coordinates of L for the strided path
-  int64_t idx[SP_MAX_DIMS] = {0, 0, 0, 0};
+  // coordinates of L[u] for the strided path
+  int64_t idx[U][SP_MAX_DIMS];
   if constexpr (!LINEAR) {
-    int64_t rem = L;
 #pragma unroll
-    for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
-      if (d < p.ndim) {
-        int64_t s = p.shape[d];
-        if (d == 0) {
-          idx[d] = rem;
-        } else {
-          int64_t q = rem / s;
-          idx[d] = rem - q * s;
-          rem = q;
+    for (int u = 0; u < U; ++u) {
+      int64_t rem = L[u];
+#pragma unroll
+      for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
+        idx[u][d] = 0;
+        if (d < p.ndim) {
+          int64_t s = p.shape[d];
+          if (d == 0) {
+            idx[u][d] = rem;
+          } else {
+            int64_t q = rem / s;
+            idx[u][d] = rem - q * s;
+            rem = q;
+          }
         }
       }
     }
@@ -355,31 +373,35 @@ __device__ __forceinline__ void sp_eval(const sp_program& p, const sp_inputs& in
       if constexpr (LINEAR) {
         // dense operand (stride pattern == output) or scalar (all strides 0)
         if (p.in_stride[j][p.ndim - 1] != 0) {
-          sp_load_vec<T, V>(in.p[j], p.in_dtype[j], L, &r[j * V]);
+#define SP_LD(u) sp_load_vec<T, V>(in.p[j], p.in_dtype[j], L[u], &r##u[j * V]);
+          SP_U_LIST(SP_LD)
+#undef SP_LD
         } else {
           T s;
           sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], 0, &s);
-#pragma unroll
-          for (int v = 0; v < V; ++v) r[j * V + v] = s;
+#define SP_BC(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[j * V + v] = s;
+          SP_U_LIST(SP_BC)
+#undef SP_BC
         }
       } else {
-        int64_t off = 0;
-#pragma unroll
-        for (int d = 0; d < SP_MAX_DIMS; ++d)
-          if (d < p.ndim) off += idx[d] * p.in_stride[j][d];
-        int64_t inner = p.in_stride[j][p.ndim - 1];
-        if (inner == 1 || V == 1) {
-          sp_load_vec<T, V>(in.p[j], p.in_dtype[j], off, &r[j * V]);
-        } else if (inner == 0) {
-          T s;
-          sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], off, &s);
-#pragma unroll
-          for (int v = 0; v < V; ++v) r[j * V + v] = s;
-        } else {
-#pragma unroll
-          for (int v = 0; v < V; ++v)
-            sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], off + v * inner, &r[j * V + v]);
-        }
+        const int64_t inner = p.in_stride[j][p.ndim - 1];
+#define SP_LDS(u)                                                                              \
+  {                                                                                            \
+    int64_t off = 0;                                                                           \
+    _Pragma("unroll") for (int d = 0; d < SP_MAX_DIMS; ++d) if (d < p.ndim) off += idx[u][d] * p.in_stride[j][d]; \
+    if (inner == 1 || V == 1) {                                                                \
+      sp_load_vec<T, V>(in.p[j], p.in_dtype[j], off, &r##u[j * V]);                            \
+    } else if (inner == 0) {                                                                   \
+      T s;                                                                                     \
+      sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], off, &s);                                      \
+      _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[j * V + v] = s;                       \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int v = 0; v < V; ++v)                                            \
+          sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], off + v * inner, &r##u[j * V + v]);        \
+    }                                                                                          \
+  }
+        SP_U_LIST(SP_LDS)
+#undef SP_LDS
       }
     }
   }
@@ -387,67 +409,88 @@ __device__ __forceinline__ void sp_eval(const sp_program& p, const sp_inputs& in
   using M = sp_math<T>;
   for (int pc = 0; pc < p.n_instr; ++pc) {
     const sp_instr I = p.instr[pc];
-    T a[V], b[V], d[V];
+    T a[U][V], b[U][V], d[U][V];
     const int ra = (I.a & (SP_NREG - 1)) * V, rb = (I.b & (SP_NREG - 1)) * V;
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      a[v] = r[ra + v];
-      b[v] = r[rb + v];
-    }
-#define SP_EACH(expr)              \
-  _Pragma("unroll") for (int v = 0; v < V; ++v) { d[v] = (expr); }
+#define SP_RD(u) _Pragma("unroll") for (int v = 0; v < V; ++v) { a[u][v] = r##u[ra + v]; b[u][v] = r##u[rb + v]; }
+    SP_U_LIST(SP_RD)
+#undef SP_RD
+#define SP_EACH(expr)                               \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {   \
+    _Pragma("unroll") for (int v = 0; v < V; ++v) { \
+      const T av = a[u][v], bv = b[u][v];           \
+      (void)av; (void)bv;                           \
+      d[u][v] = (expr);                             \
+    }                                               \
+  }
     switch (I.op) {
       case SP_OP_CONST: { T c = sp_const<T>(p, I.a); SP_EACH(c); } break;
-      case SP_OP_IOTA: SP_EACH((T)(L + v)); break;
-      case SP_OP_MOV: SP_EACH(a[v]); break;
-      case SP_OP_ADD: SP_EACH(a[v] + b[v]); break;
-      case SP_OP_SUB: SP_EACH(a[v] - b[v]); break;
-      case SP_OP_MUL: SP_EACH(a[v] * b[v]); break;
-      case SP_OP_DIV: SP_EACH(M::div(a[v], b[v])); break;
-      case SP_OP_FLOORDIV: SP_EACH(M::floordiv(a[v], b[v])); break;
-      case SP_OP_MOD: SP_EACH(M::mod(a[v], b[v])); break;
-      case SP_OP_FMOD: SP_EACH(M::fmod_(a[v], b[v])); break;
-      case SP_OP_POW: SP_EACH(M::pow_(a[v], b[v])); break;
-      case SP_OP_MAX: SP_EACH(sp_nanmax<T>(a[v], b[v])); break;
-      case SP_OP_MIN: SP_EACH(sp_nanmin<T>(a[v], b[v])); break;
-      case SP_OP_EQ: SP_EACH((T)(a[v] == b[v])); break;
-      case SP_OP_NE: SP_EACH((T)(a[v] != b[v])); break;
-      case SP_OP_LT: SP_EACH((T)(a[v] < b[v])); break;
-      case SP_OP_LE: SP_EACH((T)(a[v] <= b[v])); break;
-      case SP_OP_GT: SP_EACH((T)(a[v] > b[v])); break;
-      case SP_OP_GE: SP_EACH((T)(a[v] >= b[v])); break;
-      case SP_OP_LAND: SP_EACH((T)((a[v] != (T)0) && (b[v] != (T)0))); break;
-      case SP_OP_LOR: SP_EACH((T)((a[v] != (T)0) || (b[v] != (T)0))); break;
-      case SP_OP_LXOR: SP_EACH((T)((a[v] != (T)0) != (b[v] != (T)0))); break;
-      case SP_OP_LNOT: SP_EACH((T)(a[v] == (T)0)); break;
-      case SP_OP_NEG: SP_EACH(-a[v]); break;
-      case SP_OP_ABS: SP_EACH(M::abs_(a[v])); break;
-      case SP_OP_SQRT: SP_EACH(M::sqrt_(a[v])); break;
-      case SP_OP_SQUARE: SP_EACH(a[v] * a[v]); break;
-      case SP_OP_EXP: SP_EACH(M::exp_(a[v])); break;
-      case SP_OP_LOG: SP_EACH(M::log_(a[v])); break;
-      case SP_OP_RECIP: SP_EACH(M::div((T)1, a[v])); break;
-      case SP_OP_SIGN: SP_EACH((T)((a[v] > (T)0) - (a[v] < (T)0))); break;
-      case SP_OP_FLOOR: SP_EACH(M::floor_(a[v])); break;
-      case SP_OP_CEIL: SP_EACH(M::ceil_(a[v])); break;
-      case SP_OP_TANH: SP_EACH(M::tanh_(a[v])); break;
+      case SP_OP_IOTA: SP_EACH((T)(L[u] + v)); break;
+      case SP_OP_MOV: SP_EACH(av); break;
+      case SP_OP_ADD: SP_EACH(av + bv); break;
+      case SP_OP_SUB: SP_EACH(av - bv); break;
+      case SP_OP_MUL: SP_EACH(av * bv); break;
+      case SP_OP_DIV: SP_EACH(M::div(av, bv)); break;
+      case SP_OP_FLOORDIV: SP_EACH(M::floordiv(av, bv)); break;
+      case SP_OP_MOD: SP_EACH(M::mod(av, bv)); break;
+      case SP_OP_FMOD: SP_EACH(M::fmod_(av, bv)); break;
+      case SP_OP_POW: SP_EACH(M::pow_(av, bv)); break;
+      case SP_OP_MAX: SP_EACH(sp_nanmax<T>(av, bv)); break;
+      case SP_OP_MIN: SP_EACH(sp_nanmin<T>(av, bv)); break;
+      case SP_OP_EQ: SP_EACH((T)(av == bv)); break;
+      case SP_OP_NE: SP_EACH((T)(av != bv)); break;
+      case SP_OP_LT: SP_EACH((T)(av < bv)); break;
+      case SP_OP_LE: SP_EACH((T)(av <= bv)); break;
+      case SP_OP_GT: SP_EACH((T)(av > bv)); break;
+      case SP_OP_GE: SP_EACH((T)(av >= bv)); break;
+      case SP_OP_LAND: SP_EACH((T)((av != (T)0) && (bv != (T)0))); break;
+      case SP_OP_LOR: SP_EACH((T)((av != (T)0) || (bv != (T)0))); break;
+      case SP_OP_LXOR: SP_EACH((T)((av != (T)0) != (bv != (T)0))); break;
+      case SP_OP_LNOT: SP_EACH((T)(av == (T)0)); break;
+      case SP_OP_NEG: SP_EACH(-av); break;
+      case SP_OP_ABS: SP_EACH(M::abs_(av)); break;
+      case SP_OP_SQRT: SP_EACH(M::sqrt_(av)); break;
+      case SP_OP_SQUARE: SP_EACH(av * av); break;
+      case SP_OP_EXP: SP_EACH(M::exp_(av)); break;
+      case SP_OP_LOG: SP_EACH(M::log_(av)); break;
+      case SP_OP_RECIP: SP_EACH(M::div((T)1, av)); break;
+      case SP_OP_SIGN: SP_EACH((T)((av > (T)0) - (av < (T)0))); break;
+      case SP_OP_FLOOR: SP_EACH(M::floor_(av)); break;
+      case SP_OP_CEIL: SP_EACH(M::ceil_(av)); break;
+      case SP_OP_TANH: SP_EACH(M::tanh_(av)); break;
       case SP_OP_WHERE: {
         const int rc = (I.c & (SP_NREG - 1)) * V;
-        SP_EACH(a[v] != (T)0 ? b[v] : r[rc + v]);
+        T c[U][V];
+#define SP_RC(u) _Pragma("unroll") for (int v = 0; v < V; ++v) c[u][v] = r##u[rc + v];
+        SP_U_LIST(SP_RC)
+#undef SP_RC
+        SP_EACH(av != (T)0 ? bv : c[u][v]);
       } break;
-      case SP_OP_TO_F32: SP_EACH(M::to_f32(a[v])); break;
-      case SP_OP_TO_I32: SP_EACH(M::to_i32(a[v])); break;
-      case SP_OP_TO_I64: SP_EACH(M::to_i64(a[v])); break;
-      case SP_OP_TO_BOOL: SP_EACH((T)(a[v] != (T)0)); break;
-      case SP_OP_TO_U8: SP_EACH((T)(uint8_t)(int64_t)a[v]); break;
-      default: SP_EACH(a[v]); break;
+      case SP_OP_TO_F32: SP_EACH(M::to_f32(av)); break;
+      case SP_OP_TO_I32: SP_EACH(M::to_i32(av)); break;
+      case SP_OP_TO_I64: SP_EACH(M::to_i64(av)); break;
+      case SP_OP_TO_BOOL: SP_EACH((T)(av != (T)0)); break;
+      case SP_OP_TO_U8: SP_EACH((T)(uint8_t)(int64_t)av); break;
+      default: SP_EACH(av); break;
     }
 #undef SP_EACH
     const int rd = (I.dst & (SP_NREG - 1)) * V;
-#pragma unroll
-    for (int v = 0; v < V; ++v) r[rd + v] = d[v];
+#define SP_WR(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[rd + v] = d[u][v];
+    SP_U_LIST(SP_WR)
+#undef SP_WR
   }
   const int rr = (p.result_reg & (SP_NREG - 1)) * V;
+#define SP_OUT(u) _Pragma("unroll") for (int v = 0; v < V; ++v) out[u][v] = r##u[rr + v];
+  SP_U_LIST(SP_OUT)
+#undef SP_OUT
+#undef SP_U_LIST
+  (void)r1; (void)r2; (void)r3;
+}
+
+template <typename T, int V, bool LINEAR>
+__device__ __forceinline__ void sp_eval(const sp_program& p, const sp_inputs& in, int64_t L, T (&out)[V]) {
+  const int64_t Ls[1] = {L};
+  T o[1][V];
+  sp_eval_u<T, V, 1, LINEAR>(p, in, Ls, o);
 #pragma unroll
-  for (int v = 0; v < V; ++v) out[v] = r[rr + v];
+  for (int v = 0; v < V; ++v) out[v] = o[0][v];
 }

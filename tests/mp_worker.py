@@ -16,9 +16,15 @@ from tests import programs  # noqa: E402
 
 def main():
   workers = int(sys.argv[1])
+  use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
   world = sp.World.from_env(backend='gloo')
   assert world.size == 2
-  ctx = sp.initialize(backend=NumpyBackend(), num_workers=workers, world=world)
+  if use_hip:
+    # two ranks sharing GPU 0, HBM blobs staged through the host by the debug transport
+    world.staged = True
+    ctx = sp.initialize('hip', num_workers=workers, world=world)
+  else:
+    ctx = sp.initialize(backend=NumpyBackend(), num_workers=workers, world=world)
   n = 0
   for name, build, expected, tol in programs.programs():
     got = build(sp).glom()

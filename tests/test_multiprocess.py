@@ -20,8 +20,7 @@ def _free_port():
   return port
 
 
-@pytest.mark.parametrize('workers', [2, 4])
-def test_two_ranks_gloo(workers):
+def _run_two_ranks(workers, extra=()):
   port = _free_port()
   procs = []
   for rank in range(2):
@@ -29,8 +28,8 @@ def test_two_ranks_gloo(workers):
     env.update({'RANK': str(rank), 'WORLD_SIZE': '2', 'LOCAL_RANK': str(rank),
                 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
                 'OMP_NUM_THREADS': '1', 'GLOO_SOCKET_IFNAME': 'lo'})
-    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'mp_worker.py'), str(workers)],
-                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT))
+    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'mp_worker.py'), str(workers)] +
+                                  list(extra), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT))
   outs = []
   for p in procs:
     try:
@@ -43,3 +42,16 @@ def test_two_ranks_gloo(workers):
   for rank, (p, out) in enumerate(zip(procs, outs)):
     assert p.returncode == 0, 'rank %d failed:\n%s' % (rank, out[-4000:])
     assert 'RANK %d OK' % rank in out, out[-2000:]
+
+
+@pytest.mark.parametrize('workers', [2, 4])
+def test_two_ranks_gloo(workers):
+  _run_two_ranks(workers)
+
+
+@pytest.mark.gpu
+def test_two_ranks_hip_backend_shared_gpu():
+  """The N>1 path with the HIP kernels: two ranks share GPU 0 and exchange HBM
+  blobs through the staged debug transport (RCCL needs one GPU per rank, which
+  the driver's 8-GPU run provides)."""
+  _run_two_ranks(2, extra=('hip',))
