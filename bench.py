@@ -63,7 +63,7 @@ def time_steps(ctx, step, steps, warmup):
   return dt
 
 
-def event_time(fn, iters, warmup=2):
+def event_time(fn, iters, warmup=4):
   for _ in range(warmup):
     fn()
   torch.cuda.synchronize()
@@ -86,18 +86,20 @@ def hbm_section(ctx):
   t = X.tiles
   x = ctx.tile(list(t.values())[0]).data
   y = torch.empty_like(x)
-  ms = event_time(lambda: kernels.stream_copy(y, x), 5)
+  ms = event_time(lambda: kernels.stream_copy(y, x), 10)
   out['stream_copy_GBps'] = round(2 * 4.0 * n / ms / 1e6, 1)
   del y
-  ms = event_time(lambda: (Xv * Xv + Xv).optimized().force(), 5)
+  ms = event_time(lambda: (Xv * Xv + Xv).optimized().force(), 10)
   out['map_xx_plus_x_GBps'] = round(8.0 * n / ms / 1e6, 1)          # 4*(n_in+1)*E bytes
-  ms = event_time(lambda: (Xv + 1).force(), 5)
+  ms = event_time(lambda: (Xv + 1).force(), 10)
   out['map_x_plus_1_GBps'] = round(8.0 * n / ms / 1e6, 1)
   for axis in (None, 0, 1):
-    ms = event_time(lambda: sp.sum(Xv, axis).force(), 5)
+    ms = event_time(lambda: sp.sum(Xv, axis).force(), 10)
     out['sum_axis%s_GBps' % axis] = round(4.0 * n / ms / 1e6, 1)    # 4*E bytes
-  ms = event_time(lambda: sp.argmax(Xv, 1).force(), 5)
+  ms = event_time(lambda: sp.argmax(Xv, 1).force(), 10)
   out['argmax_axis1_GBps'] = round(4.0 * n / ms / 1e6, 1)
+  out['frac_of_measured_copy'] = {k: round(v / out['stream_copy_GBps'], 3) for k, v in out.items()
+                                  if k.endswith('_GBps') and k != 'stream_copy_GBps'}
   out['hbm_peak_GBps'] = HBM_PEAK_GBPS
   out['tile'] = '%dx%d fp32' % (rows, cols)
   return out

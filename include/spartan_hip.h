@@ -175,6 +175,14 @@ int sp_device_info(int device, int* cu_count, int64_t* hbm_bytes, char* name, si
  */
 int sp_map_fused(const sp_program* prog, const void* const* d_inputs, void* d_out, void* stream);
 
+/* sp_program_static_id: hot fp32 shapes (x+c, a*b, x*x+x, x*(yp-y), plain x ...)
+ * run on kernels specialised at build time on their instruction stream
+ * (spartan_amd/csrc/sp_interp.hpp StaticProg); everything else runs on the
+ * generic interpreter kernels.  Returns the library id the program would use,
+ * or -1.  out_dtype < 0 = "any" (reductions).  SP_NO_STATIC=1 in the
+ * environment disables the specialised kernels (A/B measurements). */
+int sp_program_static_id(const sp_program* prog, int32_t out_dtype);
+
 /* sp_reduce: fused map -> reduce over ONE axis of the program's index space
  * viewed as [outer, axis_len, inner] (prod == prod(prog->shape)); axis=None is
  * outer=1, inner=1.  Replaces `_reduce_mapper`'s local reduction

@@ -12,7 +12,7 @@
 // workgroup is a fully coalesced 4 KiB.  The grid covers the tile exactly (no
 // grid-stride loop: on MI355X a full grid streams ~25% faster than a capped,
 // grid-striding one -- tools/hbm_probe.hip, profiles/).
-template <typename T, int V, int U, bool LINEAR>
+template <typename T, int V, int U, bool LINEAR, typename P = DynProg>
 __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, const sp_inputs in,
                                                           void* __restrict__ out, int64_t start,
                                                           int64_t nvec) {
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
       full = full && (k < nvec);
     }
     T res[U][V];
-    sp_eval_u<T, V, U, LINEAR>(p, in, L, res);
+    sp_eval_u<T, V, U, LINEAR, P>(p, in, L, res);
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (u == 0 || full || i + (int64_t)u * SP_BLOCK < nvec) sp_store_vec<T, V>(out, p.out_dtype, L[u], res[u]);
@@ -91,6 +91,18 @@ static inline unsigned sp_grid_for(int64_t nvec, int U) {
   return (unsigned)blocks;
 }
 
+// SP_NO_STATIC=1 forces the generic interpreter (A/B measurements, tests).
+int sp_static_enabled() {
+  static int v = -1;
+  if (v < 0) v = getenv("SP_NO_STATIC") ? 0 : 1;
+  return v;
+}
+
+// Reports which specialised kernel (if any) a program would run on; -1 = interpreter.
+extern "C" int sp_program_static_id(const sp_program* prog, int32_t out_dtype) {
+  return prog ? sp_find_static(prog, out_dtype) : -1;
+}
+
 // Tuning knob: groups per lane for the vectorised fp32 paths (SP_MAP_UNROLL=1|2|4).
 static int sp_map_unroll() {
   static int u = -1;
@@ -107,6 +119,28 @@ static int sp_map_go(const sp_program* p, const sp_inputs& in, void* out, int64_
                      hipStream_t st) {
   hipLaunchKernelGGL((sp_map_kernel<T, V, U, LINEAR>), dim3(sp_grid_for(nvec, U)), dim3(SP_BLOCK), 0, st, *p, in,
                      out, start, nvec);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+// Specialised (compile-time instruction stream) fp32 kernels: full grid, one
+// 16-B vector per lane -- the structure that reaches the copy bandwidth
+// (tools/hbm_probe.hip: 6.2 TB/s vs 4.7 TB/s for a capped grid-stride loop).
+template <bool LINEAR>
+static int sp_map_go_static(int sid, const sp_program* p, const sp_inputs& in, void* out, int64_t nvec,
+                            hipStream_t st) {
+  int64_t blocks = (nvec + SP_BLOCK - 1) / SP_BLOCK;
+  if (blocks > (1LL << 30)) blocks = 1LL << 30;
+  switch (sid) {
+#define SP_CASE(ID)                                                                                   \
+  case ID:                                                                                            \
+    hipLaunchKernelGGL((sp_map_kernel<float, 4, 1, LINEAR, StaticProg<ID>>), dim3((unsigned)blocks),  \
+                       dim3(SP_BLOCK), 0, st, *p, in, out, (int64_t)0, nvec);                         \
+    break;
+    SP_FOR_EACH_STATIC(SP_CASE)
+#undef SP_CASE
+    default: SP_FAIL("internal: unknown static program %d", sid);
+  }
   SP_CHECK_LAUNCH();
   return 0;
 }
@@ -137,11 +171,25 @@ static int sp_map_launch(const sp_program* p, const sp_inputs& in, const void* c
     for (int j = 0; j < p->n_inputs && vec; ++j)
       if (p->in_stride[j][p->ndim - 1] != 0 && !aligned16(inp[j])) vec = false;
     int64_t nmain = vec ? (n / V) * V : 0;
+    if constexpr (std::is_same<T, float>::value) {
+      const int sid = sp_static_enabled() ? sp_find_static(p, p->out_dtype) : -1;
+      if (nmain && sid >= 0) {
+        if (sp_map_go_static<true>(sid, p, in, out, nmain / V, st)) return 1;
+        if (n - nmain && sp_map_go<T, 1, 1, true>(p, in, out, nmain, n - nmain, st)) return 1;
+        return 0;
+      }
+    }
     if (nmain && sp_map_go_u<T, V, true>(p, in, out, 0, nmain / V, st)) return 1;
     if (n - nmain && sp_map_go<T, 1, 1, true>(p, in, out, nmain, n - nmain, st)) return 1;
     return 0;
   }
-  if (sp_can_vectorize<V>(p, inp, out)) return sp_map_go_u<T, V, false>(p, in, out, 0, n / V, st);
+  if (sp_can_vectorize<V>(p, inp, out)) {
+    if constexpr (std::is_same<T, float>::value) {
+      const int sid = sp_static_enabled() ? sp_find_static(p, p->out_dtype) : -1;
+      if (sid >= 0) return sp_map_go_static<false>(sid, p, in, out, n / V, st);
+    }
+    return sp_map_go_u<T, V, false>(p, in, out, 0, n / V, st);
+  }
   return sp_map_go<T, 1, 1, false>(p, in, out, 0, n, st);
 }
 

@@ -25,6 +25,7 @@
 #include "sp_interp.hpp"
 
 int sp_validate_program(const sp_program* p);
+int sp_static_enabled();
 
 // ------------------------------------------------------------------ policies
 template <typename T>
@@ -103,8 +104,13 @@ struct ArgAcc {
     if (op == 0 ? (bv > av) : (bv < av)) return true;
     return bv == av && bi < ai;
   }
+  // Per-lane accumulation: every caller feeds one accumulator with INCREASING
+  // positions `a`, so "first occurrence" only needs a strict value comparison
+  // (the full (value, index) order is needed only when lanes are merged).
   __device__ __forceinline__ void add(int op, T x, int64_t a) {
-    if (better(op, x, a, v, i)) { v = x; i = a; }
+    const bool xn = sp_math<T>::isnan_(x), vn = sp_math<T>::isnan_(v);
+    const bool take = (i < 0) || (!vn && (xn || (op == 0 ? (x > v) : (x < v))));
+    if (take) { v = x; i = a; }
   }
   __device__ __forceinline__ void merge(int op, const ArgAcc& o) {
     if (better(op, o.v, o.i, v, i)) { v = o.v; i = o.i; }
@@ -171,7 +177,7 @@ __device__ __forceinline__ void sp_load_partial(const RedOut& ro, int64_t slot, 
 
 // --------------------------------------------------------------- row kernels
 // [O, A] with the reduced axis contiguous.  grid = (nsplit, rows).
-template <typename T, int V, bool LINEAR, template <typename> class AccT>
+template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg>
 __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_program p, const sp_inputs in,
                                                                  int op, int64_t O, int64_t A,
                                                                  int64_t chunk, int nsplit, RedOut ro) {
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
     acc.init(op);
     for (int64_t a = a0 + (int64_t)threadIdx.x * V; a < a1; a += (int64_t)SP_BLOCK * V) {
       T x[V];
-      sp_eval<T, V, LINEAR>(p, in, o * A + a, x);
+      sp_eval<T, V, LINEAR, P>(p, in, o * A + a, x);
 #pragma unroll
       for (int v = 0; v < V; ++v) acc.add(op, x[v], a + v);
     }
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
 }
 
 // many short rows: one wave per row
-template <typename T, int V, bool LINEAR, template <typename> class AccT>
+template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg>
 __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_program p,
                                                                       const sp_inputs in, int op,
                                                                       int64_t O, int64_t A, RedOut ro) {
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
     acc.init(op);
     for (int64_t a = (int64_t)lane * V; a < A; a += 64 * V) {
       T x[V];
-      sp_eval<T, V, LINEAR>(p, in, o * A + a, x);
+      sp_eval<T, V, LINEAR, P>(p, in, o * A + a, x);
 #pragma unroll
       for (int v = 0; v < V; ++v) acc.add(op, x[v], a + v);
     }
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_finish_rows_kernel(int op, int64_
 
 // ------------------------------------------------------------ column kernels
 // [O, A, I], lanes along I.  grid = (ceil(I / (64 V)), nsplit, O').
-template <typename T, int V, bool LINEAR, template <typename> class AccT>
+template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg>
 __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_program p, const sp_inputs in,
                                                                  int op, int64_t O, int64_t A, int64_t I,
                                                                  int64_t chunk, int nsplit, RedOut ro) {
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
     if (active) {
       for (int64_t a = a0 + w; a < a1; a += NW) {
         T x[V];
-        sp_eval<T, V, LINEAR>(p, in, (o * A + a) * I + c, x);
+        sp_eval<T, V, LINEAR, P>(p, in, (o * A + a) * I + c, x);
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v].add(op, x[v], a);
       }
@@ -403,14 +409,40 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
     ro.part_idx = kArg ? (int64_t*)((char*)ws + (size_t)pl.partial_slots * sizeof(T)) : nullptr;
   }
   const bool lin = p->linear != 0;
+  // hot fp32 shapes: kernels specialised on a compile-time instruction stream
+  // (sp_interp.hpp StaticProg) -- plain reductions of x, a*b (matrix.vector),
+  // x*x, x*x+x, x*(yp-y); arg-reductions of x.
+  int sid = -1;
+  if constexpr (std::is_same<T, float>::value) {
+    if (vec && sp_static_enabled()) {
+      sid = sp_find_static(p, -1);
+      if (kArg ? (sid != 0) : !(sid == 0 || sid == 7 || sid == 9 || sid == 10 || sid == 11)) sid = -1;
+    }
+  }
+#define SP_LAUNCH_P(KERNEL, GRID, PROG, ...)                                                                 \
+  do {                                                                                                       \
+    if (lin) hipLaunchKernelGGL((KERNEL<T, VV, true, AccT, PROG>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<T, VV, false, AccT, PROG>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);    \
+  } while (0)
 #define SP_LAUNCH(KERNEL, GRID, ...)                                                        \
   do {                                                                                      \
-    if (vec) {                                                                              \
-      if (lin) hipLaunchKernelGGL((KERNEL<T, VV, true, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<T, VV, false, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);    \
-    } else {                                                                                \
-      if (lin) hipLaunchKernelGGL((KERNEL<T, 1, true, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);  \
-      else hipLaunchKernelGGL((KERNEL<T, 1, false, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);     \
+    if constexpr (std::is_same<T, float>::value) {                                          \
+      if (sid == 0) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<0>, __VA_ARGS__); }              \
+      if constexpr (!kArg) {                                                                \
+        if (sid == 7) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<7>, __VA_ARGS__); }            \
+        if (sid == 9) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<9>, __VA_ARGS__); }            \
+        if (sid == 10) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<10>, __VA_ARGS__); }          \
+        if (sid == 11) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<11>, __VA_ARGS__); }          \
+      }                                                                                     \
+    }                                                                                       \
+    if (sid < 0) {                                                                          \
+      if (vec) {                                                                            \
+        if (lin) hipLaunchKernelGGL((KERNEL<T, VV, true, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<T, VV, false, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);    \
+      } else {                                                                              \
+        if (lin) hipLaunchKernelGGL((KERNEL<T, 1, true, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((KERNEL<T, 1, false, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);     \
+      }                                                                                     \
     }                                                                                       \
     SP_CHECK_LAUNCH();                                                                      \
   } while (0)
@@ -441,6 +473,7 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
     }
   }
 #undef SP_LAUNCH
+#undef SP_LAUNCH_P
   return 0;
 }
 

@@ -318,21 +318,153 @@ __device__ __forceinline__ T sp_const(const sp_program& p, int i) {
   }
 }
 
+// ---- program sources ----------------------------------------------------------
+// DynProg: the generic path -- instructions are fetched from the kernel-argument
+// copy of sp_program and dispatched at run time (any tree the host can lower).
+// StaticProg<ID>: hot shapes whose instruction stream is a compile-time constant:
+// the very same evaluator source is then fully unrolled by the compiler (static
+// register indices, no dispatch), which is what lets the HBM-bound kernels stream
+// at the chip's copy bandwidth.  The host-emitted stream is matched against this
+// library (sp_find_static); constants, strides and shapes stay run-time values.
+struct DynProg {
+  static constexpr bool kStatic = false;
+  static constexpr int N = 0;
+  static constexpr int NIN = SP_MAX_INPUTS;
+  static constexpr int RESULT = 0;
+  static __host__ __device__ constexpr sp_instr at(int) { return sp_instr{0, 0, 0, 0, 0, 0, 0, 0}; }
+};
+
+template <int ID>
+struct StaticProg;
+
+#define SP_I(op, dst, a, b) \
+  sp_instr { (uint8_t)(op), (uint8_t)(dst), (uint8_t)(a), (uint8_t)(b), 0, 0, 0, 0 }
+// NB: the stream is exposed through a constexpr FUNCTION, not a static array: a
+// constexpr array becomes a device global whose loads hipcc does not fold, and
+// the "static" kernel would still dispatch at run time (checked in the ISA).
+#define SP_DEF_STATIC(ID, NIN_, RESULT_, N_, I0, I1, I2, I3)                         \
+  template <>                                                                        \
+  struct StaticProg<ID> {                                                            \
+    static constexpr bool kStatic = true;                                            \
+    static constexpr int N = N_;                                                     \
+    static constexpr int NIN = NIN_;                                                 \
+    static constexpr int RESULT = RESULT_;                                           \
+    static __host__ __device__ constexpr sp_instr at(int pc) {                       \
+      return pc == 0 ? I0 : (pc == 1 ? I1 : (pc == 2 ? I2 : I3));                    \
+    }                                                                                \
+  };
+#define SP_NOPI SP_I(SP_OP_NOP, 0, 0, 0)
+
+// The streams below are exactly what spartan_amd/lower.py's Emitter produces for
+// the named expression (tests/test_hip_kernels.py::test_static_program_library
+// asserts that each of them is recognised).
+SP_DEF_STATIC(0, 1, 0, 0, SP_NOPI, SP_NOPI, SP_NOPI, SP_NOPI)                                        // x (reduce / argreduce of a tile)
+SP_DEF_STATIC(1, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_ADD, 1, 0, 1), SP_NOPI, SP_NOPI)    // x + c
+SP_DEF_STATIC(2, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_SUB, 1, 0, 1), SP_NOPI, SP_NOPI)    // x - c
+SP_DEF_STATIC(3, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_MUL, 1, 0, 1), SP_NOPI, SP_NOPI)    // x * c
+SP_DEF_STATIC(4, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_DIV, 1, 0, 1), SP_NOPI, SP_NOPI)    // x / c
+SP_DEF_STATIC(5, 2, 2, 1, SP_I(SP_OP_ADD, 2, 0, 1), SP_NOPI, SP_NOPI, SP_NOPI)                       // a + b
+SP_DEF_STATIC(6, 2, 2, 1, SP_I(SP_OP_SUB, 2, 0, 1), SP_NOPI, SP_NOPI, SP_NOPI)                       // a - b
+SP_DEF_STATIC(7, 2, 2, 1, SP_I(SP_OP_MUL, 2, 0, 1), SP_NOPI, SP_NOPI, SP_NOPI)                       // a * b (also matrix.vector)
+SP_DEF_STATIC(8, 2, 2, 1, SP_I(SP_OP_DIV, 2, 0, 1), SP_NOPI, SP_NOPI, SP_NOPI)                       // a / b
+SP_DEF_STATIC(9, 1, 1, 2, SP_I(SP_OP_MUL, 1, 0, 0), SP_I(SP_OP_ADD, 1, 1, 0), SP_NOPI, SP_NOPI)      // x*x + x
+SP_DEF_STATIC(10, 3, 3, 2, SP_I(SP_OP_SUB, 3, 1, 2), SP_I(SP_OP_MUL, 3, 0, 3), SP_NOPI, SP_NOPI)     // x * (yp - y) (lreg gradient)
+SP_DEF_STATIC(11, 1, 1, 1, SP_I(SP_OP_MUL, 1, 0, 0), SP_NOPI, SP_NOPI, SP_NOPI)                      // x * x
+SP_DEF_STATIC(12, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_MUL, 1, 1, 0), SP_NOPI, SP_NOPI)   // c * x
+#define SP_NUM_STATIC 13
+#define SP_FOR_EACH_STATIC(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+
+// one interpreted / unrolled instruction on U register files
+template <typename T, int V, int U>
+__device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, const int64_t (&L)[U],
+                                        T (&r0)[SP_NREG * V], T (&r1)[SP_NREG * V], T (&r2)[SP_NREG * V],
+                                        T (&r3)[SP_NREG * V]) {
+  using M = sp_math<T>;
+#define SP_U_LIST(X)                 \
+  X(0)                               \
+  if constexpr (U > 1) { X(1) }      \
+  if constexpr (U > 2) { X(2) X(3) }
+  T a[U][V], b[U][V], d[U][V];
+  const int ra = (I.a & (SP_NREG - 1)) * V, rb = (I.b & (SP_NREG - 1)) * V;
+#define SP_RD(u) _Pragma("unroll") for (int v = 0; v < V; ++v) { a[u][v] = r##u[ra + v]; b[u][v] = r##u[rb + v]; }
+  SP_U_LIST(SP_RD)
+#undef SP_RD
+#define SP_EACH(expr)                               \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {   \
+    _Pragma("unroll") for (int v = 0; v < V; ++v) { \
+      const T av = a[u][v], bv = b[u][v];           \
+      (void)av; (void)bv;                           \
+      d[u][v] = (expr);                             \
+    }                                               \
+  }
+  switch (I.op) {
+    case SP_OP_CONST: { T c = sp_const<T>(p, I.a); SP_EACH(c); } break;
+    case SP_OP_IOTA: SP_EACH((T)(L[u] + v)); break;
+    case SP_OP_MOV: SP_EACH(av); break;
+    case SP_OP_ADD: SP_EACH(av + bv); break;
+    case SP_OP_SUB: SP_EACH(av - bv); break;
+    case SP_OP_MUL: SP_EACH(av * bv); break;
+    case SP_OP_DIV: SP_EACH(M::div(av, bv)); break;
+    case SP_OP_FLOORDIV: SP_EACH(M::floordiv(av, bv)); break;
+    case SP_OP_MOD: SP_EACH(M::mod(av, bv)); break;
+    case SP_OP_FMOD: SP_EACH(M::fmod_(av, bv)); break;
+    case SP_OP_POW: SP_EACH(M::pow_(av, bv)); break;
+    case SP_OP_MAX: SP_EACH(sp_nanmax<T>(av, bv)); break;
+    case SP_OP_MIN: SP_EACH(sp_nanmin<T>(av, bv)); break;
+    case SP_OP_EQ: SP_EACH((T)(av == bv)); break;
+    case SP_OP_NE: SP_EACH((T)(av != bv)); break;
+    case SP_OP_LT: SP_EACH((T)(av < bv)); break;
+    case SP_OP_LE: SP_EACH((T)(av <= bv)); break;
+    case SP_OP_GT: SP_EACH((T)(av > bv)); break;
+    case SP_OP_GE: SP_EACH((T)(av >= bv)); break;
+    case SP_OP_LAND: SP_EACH((T)((av != (T)0) && (bv != (T)0))); break;
+    case SP_OP_LOR: SP_EACH((T)((av != (T)0) || (bv != (T)0))); break;
+    case SP_OP_LXOR: SP_EACH((T)((av != (T)0) != (bv != (T)0))); break;
+    case SP_OP_LNOT: SP_EACH((T)(av == (T)0)); break;
+    case SP_OP_NEG: SP_EACH(-av); break;
+    case SP_OP_ABS: SP_EACH(M::abs_(av)); break;
+    case SP_OP_SQRT: SP_EACH(M::sqrt_(av)); break;
+    case SP_OP_SQUARE: SP_EACH(av * av); break;
+    case SP_OP_EXP: SP_EACH(M::exp_(av)); break;
+    case SP_OP_LOG: SP_EACH(M::log_(av)); break;
+    case SP_OP_RECIP: SP_EACH(M::div((T)1, av)); break;
+    case SP_OP_SIGN: SP_EACH((T)((av > (T)0) - (av < (T)0))); break;
+    case SP_OP_FLOOR: SP_EACH(M::floor_(av)); break;
+    case SP_OP_CEIL: SP_EACH(M::ceil_(av)); break;
+    case SP_OP_TANH: SP_EACH(M::tanh_(av)); break;
+    case SP_OP_WHERE: {
+      const int rc = (I.c & (SP_NREG - 1)) * V;
+      T c[U][V];
+#define SP_RC(u) _Pragma("unroll") for (int v = 0; v < V; ++v) c[u][v] = r##u[rc + v];
+      SP_U_LIST(SP_RC)
+#undef SP_RC
+      SP_EACH(av != (T)0 ? bv : c[u][v]);
+    } break;
+    case SP_OP_TO_F32: SP_EACH(M::to_f32(av)); break;
+    case SP_OP_TO_I32: SP_EACH(M::to_i32(av)); break;
+    case SP_OP_TO_I64: SP_EACH(M::to_i64(av)); break;
+    case SP_OP_TO_BOOL: SP_EACH((T)(av != (T)0)); break;
+    case SP_OP_TO_U8: SP_EACH((T)(uint8_t)(int64_t)av); break;
+    default: SP_EACH(av); break;
+  }
+#undef SP_EACH
+  const int rd = (I.dst & (SP_NREG - 1)) * V;
+#define SP_WR(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[rd + v] = d[u][v];
+  SP_U_LIST(SP_WR)
+#undef SP_WR
+#undef SP_U_LIST
+}
+
 // ---- the evaluator ----------------------------------------------------------
 // Evaluates the program for U groups of V consecutive elements; group u starts
 // at row-major linear index L[u] (callers guarantee the V elements of a group
 // share every coordinate but the last when !LINEAR).  Results in out[u][0..V).
-//
-// U > 1 amortises the scalar dispatch of each interpreted instruction (the
-// shared scalar unit is the bottleneck of long programs) over U*V elements and
-// puts U independent 16-B loads per operand in flight per lane.  Each group has
-// its own 8 x V register file so that every dynamically indexed array stays
-// within the 32 dwords the s_set_gpr_idx path handles.
-template <typename T, int V, int U, bool LINEAR>
+// Each group has its own 8 x V register file so that every dynamically indexed
+// array stays within the 32 dwords the s_set_gpr_idx path handles (a [U][32]
+// array would be one 32*U-dword alloca and go to scratch).
+template <typename T, int V, int U, bool LINEAR, typename P = DynProg>
 __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& in, const int64_t (&L)[U],
                                           T (&out)[U][V]) {
-  // one array per group: a [U][32] array would be a single 32*U-dword alloca that
-  // the compiler cannot keep in registers under dynamic indexing (it goes to scratch)
   T r0[SP_NREG * V], r1[SP_NREG * V], r2[SP_NREG * V], r3[SP_NREG * V];
   static_assert(U == 1 || U == 2 || U == 4, "U must be 1, 2 or 4");
 #define SP_U_LIST(X)                 \
@@ -342,6 +474,7 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
 #define SP_ZERO(u) _Pragma("unroll") for (int k = 0; k < SP_NREG * V; ++k) r##u[k] = (T)0;
   SP_U_LIST(SP_ZERO)
 #undef SP_ZERO
+  (void)r1; (void)r2; (void)r3;
 
   // coordinates of L[u] for the strided path
   int64_t idx[U][SP_MAX_DIMS];
@@ -366,19 +499,21 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
     }
   }
 
-  // operand loads: static register slots, so all loads are in flight together
+  // operand loads: static register slots, so all loads are in flight together.
+  // Static programs are only selected for all-fp32 operands: the dtype is a constant.
 #pragma unroll
   for (int j = 0; j < SP_MAX_INPUTS; ++j) {
-    if (j < p.n_inputs) {
+    if (j < (P::kStatic ? P::NIN : p.n_inputs)) {
+      const int32_t dt = P::kStatic ? (int32_t)SP_F32 : p.in_dtype[j];
       if constexpr (LINEAR) {
         // dense operand (stride pattern == output) or scalar (all strides 0)
         if (p.in_stride[j][p.ndim - 1] != 0) {
-#define SP_LD(u) sp_load_vec<T, V>(in.p[j], p.in_dtype[j], L[u], &r##u[j * V]);
+#define SP_LD(u) sp_load_vec<T, V>(in.p[j], dt, L[u], &r##u[j * V]);
           SP_U_LIST(SP_LD)
 #undef SP_LD
         } else {
           T s;
-          sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], 0, &s);
+          sp_load_vec<T, 1>(in.p[j], dt, 0, &s);
 #define SP_BC(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[j * V + v] = s;
           SP_U_LIST(SP_BC)
 #undef SP_BC
@@ -390,14 +525,14 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
     int64_t off = 0;                                                                           \
     _Pragma("unroll") for (int d = 0; d < SP_MAX_DIMS; ++d) if (d < p.ndim) off += idx[u][d] * p.in_stride[j][d]; \
     if (inner == 1 || V == 1) {                                                                \
-      sp_load_vec<T, V>(in.p[j], p.in_dtype[j], off, &r##u[j * V]);                            \
+      sp_load_vec<T, V>(in.p[j], dt, off, &r##u[j * V]);                                       \
     } else if (inner == 0) {                                                                   \
       T s;                                                                                     \
-      sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], off, &s);                                      \
+      sp_load_vec<T, 1>(in.p[j], dt, off, &s);                                                 \
       _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[j * V + v] = s;                       \
     } else {                                                                                   \
       _Pragma("unroll") for (int v = 0; v < V; ++v)                                            \
-          sp_load_vec<T, 1>(in.p[j], p.in_dtype[j], off + v * inner, &r##u[j * V + v]);        \
+          sp_load_vec<T, 1>(in.p[j], dt, off + v * inner, &r##u[j * V + v]);                   \
     }                                                                                          \
   }
         SP_U_LIST(SP_LDS)
@@ -406,91 +541,46 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
     }
   }
 
-  using M = sp_math<T>;
-  for (int pc = 0; pc < p.n_instr; ++pc) {
-    const sp_instr I = p.instr[pc];
-    T a[U][V], b[U][V], d[U][V];
-    const int ra = (I.a & (SP_NREG - 1)) * V, rb = (I.b & (SP_NREG - 1)) * V;
-#define SP_RD(u) _Pragma("unroll") for (int v = 0; v < V; ++v) { a[u][v] = r##u[ra + v]; b[u][v] = r##u[rb + v]; }
-    SP_U_LIST(SP_RD)
-#undef SP_RD
-#define SP_EACH(expr)                               \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {   \
-    _Pragma("unroll") for (int v = 0; v < V; ++v) { \
-      const T av = a[u][v], bv = b[u][v];           \
-      (void)av; (void)bv;                           \
-      d[u][v] = (expr);                             \
-    }                                               \
+  if constexpr (P::kStatic) {
+#pragma unroll
+    for (int pc = 0; pc < P::N; ++pc) sp_step<T, V, U>(p, P::at(pc), L, r0, r1, r2, r3);
+  } else {
+    for (int pc = 0; pc < p.n_instr; ++pc) sp_step<T, V, U>(p, p.instr[pc], L, r0, r1, r2, r3);
   }
-    switch (I.op) {
-      case SP_OP_CONST: { T c = sp_const<T>(p, I.a); SP_EACH(c); } break;
-      case SP_OP_IOTA: SP_EACH((T)(L[u] + v)); break;
-      case SP_OP_MOV: SP_EACH(av); break;
-      case SP_OP_ADD: SP_EACH(av + bv); break;
-      case SP_OP_SUB: SP_EACH(av - bv); break;
-      case SP_OP_MUL: SP_EACH(av * bv); break;
-      case SP_OP_DIV: SP_EACH(M::div(av, bv)); break;
-      case SP_OP_FLOORDIV: SP_EACH(M::floordiv(av, bv)); break;
-      case SP_OP_MOD: SP_EACH(M::mod(av, bv)); break;
-      case SP_OP_FMOD: SP_EACH(M::fmod_(av, bv)); break;
-      case SP_OP_POW: SP_EACH(M::pow_(av, bv)); break;
-      case SP_OP_MAX: SP_EACH(sp_nanmax<T>(av, bv)); break;
-      case SP_OP_MIN: SP_EACH(sp_nanmin<T>(av, bv)); break;
-      case SP_OP_EQ: SP_EACH((T)(av == bv)); break;
-      case SP_OP_NE: SP_EACH((T)(av != bv)); break;
-      case SP_OP_LT: SP_EACH((T)(av < bv)); break;
-      case SP_OP_LE: SP_EACH((T)(av <= bv)); break;
-      case SP_OP_GT: SP_EACH((T)(av > bv)); break;
-      case SP_OP_GE: SP_EACH((T)(av >= bv)); break;
-      case SP_OP_LAND: SP_EACH((T)((av != (T)0) && (bv != (T)0))); break;
-      case SP_OP_LOR: SP_EACH((T)((av != (T)0) || (bv != (T)0))); break;
-      case SP_OP_LXOR: SP_EACH((T)((av != (T)0) != (bv != (T)0))); break;
-      case SP_OP_LNOT: SP_EACH((T)(av == (T)0)); break;
-      case SP_OP_NEG: SP_EACH(-av); break;
-      case SP_OP_ABS: SP_EACH(M::abs_(av)); break;
-      case SP_OP_SQRT: SP_EACH(M::sqrt_(av)); break;
-      case SP_OP_SQUARE: SP_EACH(av * av); break;
-      case SP_OP_EXP: SP_EACH(M::exp_(av)); break;
-      case SP_OP_LOG: SP_EACH(M::log_(av)); break;
-      case SP_OP_RECIP: SP_EACH(M::div((T)1, av)); break;
-      case SP_OP_SIGN: SP_EACH((T)((av > (T)0) - (av < (T)0))); break;
-      case SP_OP_FLOOR: SP_EACH(M::floor_(av)); break;
-      case SP_OP_CEIL: SP_EACH(M::ceil_(av)); break;
-      case SP_OP_TANH: SP_EACH(M::tanh_(av)); break;
-      case SP_OP_WHERE: {
-        const int rc = (I.c & (SP_NREG - 1)) * V;
-        T c[U][V];
-#define SP_RC(u) _Pragma("unroll") for (int v = 0; v < V; ++v) c[u][v] = r##u[rc + v];
-        SP_U_LIST(SP_RC)
-#undef SP_RC
-        SP_EACH(av != (T)0 ? bv : c[u][v]);
-      } break;
-      case SP_OP_TO_F32: SP_EACH(M::to_f32(av)); break;
-      case SP_OP_TO_I32: SP_EACH(M::to_i32(av)); break;
-      case SP_OP_TO_I64: SP_EACH(M::to_i64(av)); break;
-      case SP_OP_TO_BOOL: SP_EACH((T)(av != (T)0)); break;
-      case SP_OP_TO_U8: SP_EACH((T)(uint8_t)(int64_t)av); break;
-      default: SP_EACH(av); break;
-    }
-#undef SP_EACH
-    const int rd = (I.dst & (SP_NREG - 1)) * V;
-#define SP_WR(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[rd + v] = d[u][v];
-    SP_U_LIST(SP_WR)
-#undef SP_WR
-  }
-  const int rr = (p.result_reg & (SP_NREG - 1)) * V;
+  const int rr = ((P::kStatic ? P::RESULT : p.result_reg) & (SP_NREG - 1)) * V;
 #define SP_OUT(u) _Pragma("unroll") for (int v = 0; v < V; ++v) out[u][v] = r##u[rr + v];
   SP_U_LIST(SP_OUT)
 #undef SP_OUT
 #undef SP_U_LIST
-  (void)r1; (void)r2; (void)r3;
 }
 
-template <typename T, int V, bool LINEAR>
+template <typename T, int V, bool LINEAR, typename P = DynProg>
 __device__ __forceinline__ void sp_eval(const sp_program& p, const sp_inputs& in, int64_t L, T (&out)[V]) {
   const int64_t Ls[1] = {L};
   T o[1][V];
-  sp_eval_u<T, V, 1, LINEAR>(p, in, Ls, o);
+  sp_eval_u<T, V, 1, LINEAR, P>(p, in, Ls, o);
 #pragma unroll
   for (int v = 0; v < V; ++v) out[v] = o[0][v];
+}
+
+// Host side: which StaticProg (if any) has exactly this instruction stream?
+// Only all-fp32 programs (class, operands, result) qualify.
+static inline int sp_find_static(const sp_program* p, int32_t out_dtype) {
+  if (p->cls != SP_F32 || (out_dtype >= 0 && out_dtype != SP_F32)) return -1;
+  for (int j = 0; j < p->n_inputs; ++j)
+    if (p->in_dtype[j] != SP_F32) return -1;
+#define SP_MATCH(ID)                                                                          \
+  {                                                                                           \
+    using S = StaticProg<ID>;                                                                 \
+    bool ok = p->n_inputs == S::NIN && p->n_instr == S::N && p->result_reg == S::RESULT;      \
+    for (int i = 0; ok && i < S::N; ++i) {                                                    \
+      const sp_instr& x = p->instr[i];                                                        \
+      const sp_instr y = S::at(i);                                                          \
+      ok = x.op == y.op && x.dst == y.dst && x.a == y.a && (x.op == SP_OP_CONST || x.b == y.b); \
+    }                                                                                         \
+    if (ok) return ID;                                                                        \
+  }
+  SP_FOR_EACH_STATIC(SP_MATCH)
+#undef SP_MATCH
+  return -1;
 }

@@ -397,3 +397,45 @@ def test_gemm_strided_views():
 def test_errors_are_loud():
   with pytest.raises(_hip.HipError):
     kernels.gemm_f32(torch.zeros(4, 4), torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_static_program_library():
+  """The streams the host emits for the hot expressions are the ones the kernel
+  library was specialised for (so they do not silently fall back to the
+  interpreter), and both paths agree bit for bit."""
+  import ctypes as C
+  import spartan_amd as sp
+  from spartan_amd import lower
+  from spartan_amd.backend_hip import HipBackend
+  be = HipBackend()
+  x = dev(RNG.rand(256, 512).astype(np.float32))
+  y = dev(RNG.rand(256, 512).astype(np.float32))
+  yp = dev(RNG.rand(256, 1).astype(np.float32))
+  yy = dev(RNG.rand(256, 1).astype(np.float32))
+  T = lambda t: lower.V('tensor', dtype=np.float32, shape=tuple(t.shape), tensor=t)
+  ap = lower.apply
+  cases = {
+      1: ap('ADD', np.add, [T(x), lower.const(1)]),
+      2: ap('SUB', np.subtract, [T(x), lower.const(1.5)]),
+      3: ap('MUL', np.multiply, [T(x), lower.const(2.0)]),
+      4: ap('DIV', np.divide, [T(x), lower.const(7)]),
+      5: ap('ADD', np.add, [T(x), T(y)]),
+      6: ap('SUB', np.subtract, [T(x), T(y)]),
+      7: ap('MUL', np.multiply, [T(x), T(y)]),
+      8: ap('DIV', np.divide, [T(x), T(y)]),
+      9: ap('ADD', np.add, [ap('MUL', np.multiply, [T(x), T(x)]), T(x)]),
+      10: ap('MUL', np.multiply, [T(x), ap('SUB', np.subtract, [T(yp), T(yy)])]),
+      11: ap('MUL', np.multiply, [T(x), T(x)]),
+      12: ap('MUL', np.multiply, [lower.const(3.0), T(x)]),
+  }
+  for sid, root in cases.items():
+    em = lower.Emitter(_hip.SP_F32, root.shape)
+    prog, tensors = em.finish(root, np.float32)
+    assert _hip.lib().sp_program_static_id(C.byref(prog), _hip.SP_F32) == sid, sid
+  ident = lower.Emitter(_hip.SP_F32, x.shape).finish(T(x), None)[0]
+  assert _hip.lib().sp_program_static_id(C.byref(ident), -1) == 0
+  # a shape outside the library runs on the interpreter and still agrees with NumPy
+  root = ap('ADD', np.add, [ap('MUL', np.multiply, [T(x), T(y)]), ap('SUB', np.subtract, [T(x), lower.const(2)])])
+  prog, _ = lower.Emitter(_hip.SP_F32, root.shape).finish(root, np.float32)
+  assert _hip.lib().sp_program_static_id(C.byref(prog), _hip.SP_F32) == -1
+  np.testing.assert_array_equal(host(be._run_map(root, x.shape)), host(x) * host(y) + (host(x) - 2))

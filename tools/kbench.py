@@ -99,7 +99,7 @@ if __name__ == '__main__':
   if what in ('all', 'copy'):
     bench_copy(2 << 30)
   if what in ('all', 'map'):
-    print('SP_MAP_UNROLL=%s' % os.environ.get('SP_MAP_UNROLL'))
+    print('SP_NO_STATIC=%s SP_MAP_UNROLL=%s' % (os.environ.get('SP_NO_STATIC'), os.environ.get('SP_MAP_UNROLL')))
     bench_map(1 << 29)
   if what in ('all', 'reduce'):
     bench_reduce(8192, 65536)
