@@ -98,6 +98,21 @@ def hbm_section(ctx):
     out['sum_axis%s_GBps' % axis] = round(4.0 * n / ms / 1e6, 1)    # 4*E bytes
   ms = event_time(lambda: sp.argmax(Xv, 1).force(), 10)
   out['argmax_axis1_GBps'] = round(4.0 * n / ms / 1e6, 1)
+  del X, Xv, x
+  torch.cuda.empty_cache()
+  # one linear-regression step on a BASELINE configs[4] per-GPU tile (125000 x 4096 fp32):
+  # yp = dot(X, w); grad = sum(X * (yp - y), axis=0)  (sgd.py:34-39) -- X streamed twice
+  N, D = 125000, 4096
+  Xl = sp.from_tile_fn((N, D), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 11))
+  yl = sp.from_tile_fn((N, 1), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 12))
+  w = np.random.RandomState(SEED).rand(D, 1).astype(np.float32)
+
+  def lreg_step():
+    yp = sp.dot(Xl, w)
+    return sp.sum(Xl * (yp - yl), axis=0).optimized().force()
+  ms = event_time(lreg_step, 10)
+  out['lreg_step_GBps'] = round(2 * 4.0 * N * D / ms / 1e6, 1)     # 2*4*N*D bytes
+  out['lreg_step_ms'] = round(ms, 4)
   out['frac_of_measured_copy'] = {k: round(v / out['stream_copy_GBps'], 3) for k, v in out.items()
                                   if k.endswith('_GBps') and k != 'stream_copy_GBps'}
   out['hbm_peak_GBps'] = HBM_PEAK_GBPS

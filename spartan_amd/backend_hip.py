@@ -270,6 +270,12 @@ class HipBackend(object):
     multiply-reduce launches for everything else."""
     a_dt, b_dt = self.dtype_of(a), self.dtype_of(b)
     res_dt = np.result_type(a_dt, b_dt)
+    if a.dim() == 2 and b.dim() == 2 and b.shape[1] == 1:
+      # (M,K).(K,1), the lreg `X.w` (linear_regression.py:10-16): HBM-bound matrix.vector,
+      # not a GEMM -- one fused multiply-reduce pass over A
+      return self.dot(a, b.reshape(b.shape[0])).reshape(a.shape[0], 1)
+    if a.dim() == 2 and b.dim() == 2 and a.shape[0] == 1:
+      return self.dot(a.reshape(a.shape[1]), b).reshape(1, b.shape[1])
     if a.dim() == 2 and b.dim() == 2 and a_dt == np.float32 and b_dt == np.float32:
       M, K = a.shape
       N = b.shape[1]

@@ -188,9 +188,15 @@ class Expr(object):
 
   def optimized(self):
     """base.py:477-492 (fusion is opt-in, as in the reference)."""
+    # The reference makes the optimised node point at itself (base.py:489), a
+    # reference cycle that only the cyclic GC can free -- which would keep multi-GiB
+    # HBM tiles of dead results alive between collections.  A flag has the same
+    # effect (optimising an optimised node is the identity) without the cycle.
+    if getattr(self, '_is_optimized', False):
+      return self
     if self.optimized_expr is None:
       self.optimized_expr = optimized_dag(self)
-      self.optimized_expr.optimized_expr = self.optimized_expr
+      self.optimized_expr._is_optimized = True
     return self.optimized_expr
 
   def glom(self):
