@@ -26,6 +26,8 @@ extern "C" int sp_argreduce(const sp_program* prog, const void* const* d_inputs,
   ro.index_offset = index_offset;
   ro.nan_index = nan_index;
   hipStream_t st = (hipStream_t)stream;
+  const sp_program prepared = sp_prepare_program(prog);
+  prog = &prepared;
   switch (prog->cls) {
     case SP_F32:
       return sp_reduce_launch<float, ArgAcc>(prog, in, d_inputs, which, outer, axis_len, inner, ro, d_ws,

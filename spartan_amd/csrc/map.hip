@@ -205,6 +205,8 @@ extern "C" int sp_map_fused(const sp_program* prog, const void* const* d_inputs,
     in.p[j] = d_inputs[j];
   }
   hipStream_t st = (hipStream_t)stream;
+  const sp_program prepared = sp_prepare_program(prog);
+  prog = &prepared;
   switch (prog->cls) {
     case SP_F32: return sp_map_launch<float>(prog, in, d_inputs, d_out, st);
     case SP_F64: return sp_map_launch<double>(prog, in, d_inputs, d_out, st);

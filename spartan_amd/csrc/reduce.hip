@@ -23,6 +23,8 @@ extern "C" int sp_reduce(const sp_program* prog, const void* const* d_inputs, in
   ro.out = d_out;
   ro.out_dtype = out_dtype;
   hipStream_t st = (hipStream_t)stream;
+  const sp_program prepared = sp_prepare_program(prog);
+  prog = &prepared;
   switch (prog->cls) {
     case SP_F32:
       return sp_reduce_launch<float, PlainAcc>(prog, in, d_inputs, red_op, outer, axis_len, inner, ro, d_ws,

@@ -177,12 +177,13 @@ __device__ __forceinline__ void sp_load_partial(const RedOut& ro, int64_t slot, 
 
 // --------------------------------------------------------------- row kernels
 // [O, A] with the reduced axis contiguous.  grid = (nsplit, rows).
-template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg>
+template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg, int OP = -1, int MASK = -1>
 __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_program p, const sp_inputs in,
                                                                  int op, int64_t O, int64_t A,
                                                                  int64_t chunk, int nsplit, RedOut ro) {
   using Acc = AccT<T>;
   __shared__ Acc sm[SP_BLOCK / 64];
+  if constexpr (OP >= 0) op = OP;   // specialised kernels: the combine op is a constant too
   const int s = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int64_t o = blockIdx.y; o < O; o += gridDim.y) {
@@ -191,11 +192,29 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
     if (a1 > A) a1 = A;
     Acc acc;
     acc.init(op);
-    for (int64_t a = a0 + (int64_t)threadIdx.x * V; a < a1; a += (int64_t)SP_BLOCK * V) {
-      T x[V];
-      sp_eval<T, V, LINEAR, P>(p, in, o * A + a, x);
+    constexpr int U = 1;   // measured: more groups per lane do not help (profiles/r01_notes.md)
+    for (int64_t a = a0 + (int64_t)threadIdx.x * V; a < a1; a += (int64_t)SP_BLOCK * V * U) {
+      int64_t L[U];
 #pragma unroll
-      for (int v = 0; v < V; ++v) acc.add(op, x[v], a + v);
+      for (int u = 0; u < U; ++u) {
+        const int64_t au = a + (int64_t)u * SP_BLOCK * V;
+        L[u] = o * A + (au < a1 ? au : a);
+      }
+      T x[U][V];
+      if constexpr (MASK >= 0) {
+        sp_eval_2d<T, V, P, MASK>(p, in, (uint32_t)o, (uint32_t)a, L[0], x[0]);
+      } else {
+        const int64_t rc[1][2] = {{o, a}};   // (row, column) when the program space is [O, A]
+        sp_eval_u<T, V, U, LINEAR, P>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t au = a + (int64_t)u * SP_BLOCK * V;
+        if (u == 0 || au < a1) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc.add(op, x[u][v], au + v);
+        }
+      }
     }
     acc = sp_wave_reduce(op, acc);
     if (lane == 0) sm[w] = acc;
@@ -211,21 +230,40 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
 }
 
 // many short rows: one wave per row
-template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg>
+template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg, int OP = -1, int MASK = -1>
 __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_program p,
                                                                       const sp_inputs in, int op,
                                                                       int64_t O, int64_t A, RedOut ro) {
   using Acc = AccT<T>;
+  if constexpr (OP >= 0) op = OP;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wstride = (int64_t)gridDim.x * (SP_BLOCK / 64);
   for (int64_t o = (int64_t)blockIdx.x * (SP_BLOCK / 64) + w; o < O; o += wstride) {
     Acc acc;
     acc.init(op);
-    for (int64_t a = (int64_t)lane * V; a < A; a += 64 * V) {
-      T x[V];
-      sp_eval<T, V, LINEAR, P>(p, in, o * A + a, x);
+    constexpr int U = 1;
+    for (int64_t a = (int64_t)lane * V; a < A; a += 64 * V * U) {
+      int64_t L[U];
 #pragma unroll
-      for (int v = 0; v < V; ++v) acc.add(op, x[v], a + v);
+      for (int u = 0; u < U; ++u) {
+        const int64_t au = a + (int64_t)u * 64 * V;
+        L[u] = o * A + (au < A ? au : a);
+      }
+      T x[U][V];
+      if constexpr (MASK >= 0) {
+        sp_eval_2d<T, V, P, MASK>(p, in, (uint32_t)o, (uint32_t)a, L[0], x[0]);
+      } else {
+        const int64_t rc[1][2] = {{o, a}};
+        sp_eval_u<T, V, U, LINEAR, P>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t au = a + (int64_t)u * 64 * V;
+        if (u == 0 || au < A) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc.add(op, x[u][v], au + v);
+        }
+      }
     }
     acc = sp_wave_reduce(op, acc);
     if (lane == 0) sp_emit<T>(ro, true, o, acc);
@@ -253,13 +291,14 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_finish_rows_kernel(int op, int64_
 
 // ------------------------------------------------------------ column kernels
 // [O, A, I], lanes along I.  grid = (ceil(I / (64 V)), nsplit, O').
-template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg>
+template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg, int OP = -1, int MASK = -1>
 __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_program p, const sp_inputs in,
                                                                  int op, int64_t O, int64_t A, int64_t I,
                                                                  int64_t chunk, int nsplit, RedOut ro) {
   using Acc = AccT<T>;
   constexpr int NW = SP_BLOCK / 64;
   __shared__ Acc sm[NW - 1][64 * V];
+  if constexpr (OP >= 0) op = OP;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int s = blockIdx.y;
   const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * V;
@@ -272,11 +311,29 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v].init(op);
     if (active) {
-      for (int64_t a = a0 + w; a < a1; a += NW) {
-        T x[V];
-        sp_eval<T, V, LINEAR, P>(p, in, (o * A + a) * I + c, x);
+      constexpr int U = 1;
+      for (int64_t a = a0 + w; a < a1; a += NW * U) {
+        int64_t L[U];
 #pragma unroll
-        for (int v = 0; v < V; ++v) acc[v].add(op, x[v], a);
+        for (int u = 0; u < U; ++u) {
+          const int64_t au = a + (int64_t)u * NW;
+          L[u] = (o * A + (au < a1 ? au : a)) * I + c;
+        }
+        T x[U][V];
+        if constexpr (MASK >= 0) {
+          sp_eval_2d<T, V, P, MASK>(p, in, (uint32_t)(o * A + a), (uint32_t)c, L[0], x[0]);
+        } else {
+          const int64_t rc[1][2] = {{o * A + a, c}};   // (row, column) when the program space is [O*A, I]
+          sp_eval_u<T, V, U, LINEAR, P>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t au = a + (int64_t)u * NW;
+          if (u == 0 || au < a1) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v].add(op, x[u][v], au);
+          }
+        }
       }
     }
     if (w > 0) {
@@ -297,20 +354,33 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
   }
 }
 
-// second stage over [nsplit, E] partials (E = O*I): one thread per output
+// second stage over [nsplit, E] partials (E = O*I): lanes along E (coalesced),
+// the 4 waves of a workgroup interleave over the nsplit partials, LDS combine
 template <typename T, template <typename> class AccT>
 __global__ __launch_bounds__(SP_BLOCK) void sp_finish_cols_kernel(int op, int64_t E, int nsplit, RedOut ro) {
   using Acc = AccT<T>;
-  const int64_t stride = (int64_t)gridDim.x * SP_BLOCK;
-  for (int64_t e = (int64_t)blockIdx.x * SP_BLOCK + threadIdx.x; e < E; e += stride) {
+  constexpr int NW = SP_BLOCK / 64;
+  __shared__ Acc sm[NW - 1][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < E; e0 += (int64_t)gridDim.x * 64) {
+    const int64_t e = e0 + lane;
     Acc acc;
     acc.init(op);
-    for (int k = 0; k < nsplit; ++k) {
-      Acc t;
-      sp_load_partial<T>(ro, (int64_t)k * E + e, t);
-      acc.merge(op, t);
+    if (e < E) {
+      for (int k = w; k < nsplit; k += NW) {
+        Acc t;
+        sp_load_partial<T>(ro, (int64_t)k * E + e, t);
+        acc.merge(op, t);
+      }
     }
-    sp_emit<T>(ro, true, e, acc);
+    if (w > 0) sm[w - 1][lane] = acc;
+    __syncthreads();
+    if (w == 0 && e < E) {
+#pragma unroll
+      for (int k = 0; k < NW - 1; ++k) acc.merge(op, sm[k][lane]);
+      sp_emit<T>(ro, true, e, acc);
+    }
+    __syncthreads();
   }
 }
 
@@ -419,23 +489,46 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
       if (kArg ? (sid != 0) : !(sid == 0 || sid == 7 || sid == 9 || sid == 10 || sid == 11)) sid = -1;
     }
   }
-#define SP_LAUNCH_P(KERNEL, GRID, PROG, ...)                                                                 \
-  do {                                                                                                       \
-    if (lin) hipLaunchKernelGGL((KERNEL<T, VV, true, AccT, PROG>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<T, VV, false, AccT, PROG>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);    \
+  // 2-D specialised addressing: program space must be the kernel's own (row, column) space
+  int mask2d = -1;
+  if (sid >= 0 && !lin) {
+    const int64_t cols = (I == 1) ? A : I;
+    if (p->shape[1] == cols) mask2d = sp_mask_2d(p, p->n_inputs);
+  }
+  const int sop = (!kArg && (op == SP_RED_SUM || op == SP_RED_MAX || op == SP_RED_MIN)) ? op : -1;
+#define SP_GO(KERNEL, GRID, LIN, PROG, OPC, MSK, ...) \
+  hipLaunchKernelGGL((KERNEL<T, VV, LIN, AccT, PROG, OPC, MSK>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__)
+#define SP_LAUNCH_OP(KERNEL, GRID, LIN, PROG, MSK, ...)                                   \
+  do {                                                                                    \
+    if constexpr (kArg) { SP_GO(KERNEL, GRID, LIN, PROG, -1, MSK, __VA_ARGS__); }         \
+    else {                                                                                \
+      if (sop == SP_RED_SUM) SP_GO(KERNEL, GRID, LIN, PROG, SP_RED_SUM, MSK, __VA_ARGS__); \
+      else if (sop == SP_RED_MAX) SP_GO(KERNEL, GRID, LIN, PROG, SP_RED_MAX, MSK, __VA_ARGS__); \
+      else if (sop == SP_RED_MIN) SP_GO(KERNEL, GRID, LIN, PROG, SP_RED_MIN, MSK, __VA_ARGS__); \
+      else SP_GO(KERNEL, GRID, LIN, PROG, -1, MSK, __VA_ARGS__);                          \
+    }                                                                                     \
+  } while (0)
+#define SP_LAUNCH_P(KERNEL, GRID, PROG, ...)                                              \
+  do {                                                                                    \
+    if (lin) SP_LAUNCH_OP(KERNEL, GRID, true, PROG, -1, __VA_ARGS__);                     \
+    else SP_LAUNCH_OP(KERNEL, GRID, false, PROG, -1, __VA_ARGS__);                        \
   } while (0)
 #define SP_LAUNCH(KERNEL, GRID, ...)                                                        \
   do {                                                                                      \
+    bool done_ = false;                                                                     \
     if constexpr (std::is_same<T, float>::value) {                                          \
-      if (sid == 0) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<0>, __VA_ARGS__); }              \
+      if (sid == 0) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<0>, __VA_ARGS__); done_ = true; } \
       if constexpr (!kArg) {                                                                \
-        if (sid == 7) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<7>, __VA_ARGS__); }            \
-        if (sid == 9) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<9>, __VA_ARGS__); }            \
-        if (sid == 10) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<10>, __VA_ARGS__); }          \
-        if (sid == 11) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<11>, __VA_ARGS__); }          \
+        if (sid == 7 && mask2d == 0) { SP_LAUNCH_OP(KERNEL, GRID, false, StaticProg<7>, 0, __VA_ARGS__); done_ = true; } \
+        else if (sid == 7 && mask2d == 2) { SP_LAUNCH_OP(KERNEL, GRID, false, StaticProg<7>, 2, __VA_ARGS__); done_ = true; } \
+        else if (sid == 7) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<7>, __VA_ARGS__); done_ = true; } \
+        if (sid == 9) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<9>, __VA_ARGS__); done_ = true; } \
+        if (sid == 10 && mask2d == 6) { SP_LAUNCH_OP(KERNEL, GRID, false, StaticProg<10>, 6, __VA_ARGS__); done_ = true; } \
+        else if (sid == 10) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<10>, __VA_ARGS__); done_ = true; } \
+        if (sid == 11) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<11>, __VA_ARGS__); done_ = true; } \
       }                                                                                     \
     }                                                                                       \
-    if (sid < 0) {                                                                          \
+    if (!done_) {                                                                           \
       if (vec) {                                                                            \
         if (lin) hipLaunchKernelGGL((KERNEL<T, VV, true, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__); \
         else hipLaunchKernelGGL((KERNEL<T, VV, false, AccT>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__);    \
@@ -466,7 +559,7 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
               pl.chunk, pl.nsplit, ro);
     if (pl.nsplit > 1) {
       const int64_t E = O * I;
-      const int64_t blocks = (E + SP_BLOCK - 1) / SP_BLOCK;
+      const int64_t blocks = (E + 63) / 64;
       hipLaunchKernelGGL((sp_finish_cols_kernel<T, AccT>), dim3(cap_dim(blocks, kTargetBlocks)),
                          dim3(SP_BLOCK), 0, st, op, E, pl.nsplit, ro);
       SP_CHECK_LAUNCH();
@@ -474,6 +567,8 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
   }
 #undef SP_LAUNCH
 #undef SP_LAUNCH_P
+#undef SP_LAUNCH_OP
+#undef SP_GO
   return 0;
 }
 

@@ -464,7 +464,7 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
 // array would be one 32*U-dword alloca and go to scratch).
 template <typename T, int V, int U, bool LINEAR, typename P = DynProg>
 __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& in, const int64_t (&L)[U],
-                                          T (&out)[U][V]) {
+                                          T (&out)[U][V], const int64_t (*pre)[2] = nullptr) {
   T r0[SP_NREG * V], r1[SP_NREG * V], r2[SP_NREG * V], r3[SP_NREG * V];
   static_assert(U == 1 || U == 2 || U == 4, "U must be 1, 2 or 4");
 #define SP_U_LIST(X)                 \
@@ -477,22 +477,54 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
   (void)r1; (void)r2; (void)r3;
 
   // coordinates of L[u] for the strided path
+  // Coordinates of L[u] for the strided path.  p.pad != 0 (set by the launcher):
+  // the whole index space -- hence every operand offset -- fits 32 bits, so the
+  // row/column split and the offset arithmetic are 32-bit (the 64-bit versions
+  // made these HBM kernels VALU-bound).  `pre`: the caller already knows the
+  // (row, column) of group 0 of a 2-D program (reduce kernels): no division.
   int64_t idx[U][SP_MAX_DIMS];
+  uint32_t idx32[U][SP_MAX_DIMS];
   if constexpr (!LINEAR) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int64_t rem = L[u];
 #pragma unroll
-      for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
+      for (int d = 0; d < SP_MAX_DIMS; ++d) {
         idx[u][d] = 0;
-        if (d < p.ndim) {
-          int64_t s = p.shape[d];
-          if (d == 0) {
-            idx[u][d] = rem;
-          } else {
-            int64_t q = rem / s;
-            idx[u][d] = rem - q * s;
-            rem = q;
+        idx32[u][d] = 0;
+      }
+      if (U == 1 && pre != nullptr) {
+        idx[u][0] = pre[0][0];
+        idx[u][1] = pre[0][1];
+        idx32[u][0] = (uint32_t)pre[0][0];
+        idx32[u][1] = (uint32_t)pre[0][1];
+      } else if (p.pad) {
+        uint32_t rem = (uint32_t)L[u];
+#pragma unroll
+        for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
+          if (d < p.ndim) {
+            const uint32_t s = (uint32_t)p.shape[d];
+            if (d == 0) {
+              idx32[u][d] = rem;
+            } else {
+              const uint32_t q = rem / s;
+              idx32[u][d] = rem - q * s;
+              rem = q;
+            }
+          }
+        }
+      } else {
+        int64_t rem = L[u];
+#pragma unroll
+        for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
+          if (d < p.ndim) {
+            int64_t s = p.shape[d];
+            if (d == 0) {
+              idx[u][d] = rem;
+            } else {
+              int64_t q = rem / s;
+              idx[u][d] = rem - q * s;
+              rem = q;
+            }
           }
         }
       }
@@ -523,7 +555,15 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
 #define SP_LDS(u)                                                                              \
   {                                                                                            \
     int64_t off = 0;                                                                           \
-    _Pragma("unroll") for (int d = 0; d < SP_MAX_DIMS; ++d) if (d < p.ndim) off += idx[u][d] * p.in_stride[j][d]; \
+    if (p.pad) {                                                                               \
+      uint32_t o32 = 0;                                                                        \
+      _Pragma("unroll") for (int d = 0; d < SP_MAX_DIMS; ++d)                                  \
+          if (d < p.ndim) o32 += idx32[u][d] * (uint32_t)p.in_stride[j][d];                    \
+      off = (int64_t)o32;                                                                      \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int d = 0; d < SP_MAX_DIMS; ++d)                                  \
+          if (d < p.ndim) off += idx[u][d] * p.in_stride[j][d];                                \
+    }                                                                                          \
     if (inner == 1 || V == 1) {                                                                \
       sp_load_vec<T, V>(in.p[j], dt, off, &r##u[j * V]);                                       \
     } else if (inner == 0) {                                                                   \
@@ -561,6 +601,66 @@ __device__ __forceinline__ void sp_eval(const sp_program& p, const sp_inputs& in
   sp_eval_u<T, V, 1, LINEAR, P>(p, in, Ls, o);
 #pragma unroll
   for (int v = 0; v < V; ++v) out[v] = o[0][v];
+}
+
+// ---- 2-D strided evaluator for specialised programs -----------------------------
+// The general strided path decides per operand, per evaluation, how to address
+// it (dense inner run / broadcast inner / arbitrary stride, 32- or 64-bit): a few
+// dozen wave-uniform branches per trip, which is what bounded the fused
+// broadcast kernels (lreg gradient, matrix.vector) at ~45% of the copy bandwidth.
+// Here every such decision is a compile-time constant: the program space is 2-D
+// and fits 32 bits, operand j is read with ONE 16-B load when bit j of MASK is
+// clear (inner stride 1) and with one broadcast dword when it is set (inner
+// stride 0); offsets are row*s0 + col*s1 in 32-bit arithmetic.
+template <typename T, int V, typename P, int MASK>
+__device__ __forceinline__ void sp_eval_2d(const sp_program& p, const sp_inputs& in, uint32_t row, uint32_t col,
+                                           int64_t L, T (&out)[V]) {
+  static_assert(P::kStatic, "sp_eval_2d is for specialised programs");
+  T r0[SP_NREG * V], r1[SP_NREG * V], r2[SP_NREG * V], r3[SP_NREG * V];
+#pragma unroll
+  for (int k = 0; k < SP_NREG * V; ++k) r0[k] = (T)0;
+  (void)r1; (void)r2; (void)r3;
+#pragma unroll
+  for (int j = 0; j < P::NIN; ++j) {
+    const uint32_t off = row * (uint32_t)p.in_stride[j][0] + col * (uint32_t)p.in_stride[j][1];
+    if (((MASK >> j) & 1) != 0) {  // folds once the loop is unrolled
+      T s;
+      sp_load_vec<T, 1>(in.p[j], SP_F32, (int64_t)off, &s);
+#pragma unroll
+      for (int v = 0; v < V; ++v) r0[j * V + v] = s;
+    } else {
+      sp_load_vec<T, V>(in.p[j], SP_F32, (int64_t)off, &r0[j * V]);
+    }
+  }
+  const int64_t Ls[1] = {L};
+#pragma unroll
+  for (int pc = 0; pc < P::N; ++pc) sp_step<T, V, 1>(p, P::at(pc), Ls, r0, r1, r2, r3);
+#pragma unroll
+  for (int v = 0; v < V; ++v) out[v] = r0[(P::RESULT & (SP_NREG - 1)) * V + v];
+}
+
+// Host side: is the 2-D specialised path applicable, and with which MASK?
+// Returns -1 if not (then the general strided evaluator is used).
+static inline int sp_mask_2d(const sp_program* p, int nin) {
+  if (p->ndim != 2 || !p->pad || p->linear) return -1;
+  int mask = 0;
+  for (int j = 0; j < nin; ++j) {
+    const int64_t s1 = p->in_stride[j][1];
+    if (s1 == 0) mask |= 1 << j;
+    else if (s1 != 1) return -1;
+    if (p->in_stride[j][0] < 0 || p->in_stride[j][0] >= (1LL << 32)) return -1;
+  }
+  return mask;
+}
+
+// Host side: the copy of the program handed to a kernel; `pad` carries the
+// "index space fits 32 bits" flag used by the strided evaluator.
+static inline sp_program sp_prepare_program(const sp_program* p) {
+  sp_program q = *p;
+  int64_t n = 1;
+  for (int d = 0; d < p->ndim; ++d) n *= p->shape[d];
+  q.pad = (n > 0 && n < (1LL << 32)) ? 1 : 0;
+  return q;
 }
 
 // Host side: which StaticProg (if any) has exactly this instruction stream?
