@@ -183,7 +183,8 @@ def main():
     A = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED))
     B = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 1))
     hint = None
-    workload = 'spartan.dot %dx%dx%d fp32, one tile (BASELINE configs[1])' % (n, n, n)
+    tag = {8192: 'BASELINE configs[1]', 32768: 'north-star shape'}.get(n, 'custom size')
+    workload = 'spartan.dot %dx%dx%d fp32, one tile (%s)' % (n, n, n, tag)
     parallelism = 'single tile'
   else:
     A = sp.from_tile_fn((M, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED), tile_hint=(n, n))

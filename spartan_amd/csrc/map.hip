@@ -12,7 +12,7 @@
 // workgroup is a fully coalesced 4 KiB.  The grid covers the tile exactly (no
 // grid-stride loop: on MI355X a full grid streams ~25% faster than a capped,
 // grid-striding one -- tools/hbm_probe.hip, profiles/).
-template <typename T, int V, int U, bool LINEAR, typename P = DynProg>
+template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1>
 __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, const sp_inputs in,
                                                           void* __restrict__ out, int64_t start,
                                                           int64_t nvec) {
@@ -27,7 +27,15 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
       full = full && (k < nvec);
     }
     T res[U][V];
-    sp_eval_u<T, V, U, LINEAR, P>(p, in, L, res);
+    if constexpr (MASK >= 0) {
+      // specialised 2-D broadcast addressing (sp_eval_2d): one 32-bit division per lane
+      const uint32_t cols = (uint32_t)p.shape[1];
+      const uint32_t l32 = (uint32_t)L[0];
+      const uint32_t row = l32 / cols;
+      sp_eval_2d<T, V, P, MASK>(p, in, row, l32 - row * cols, L[0], res[0]);
+    } else {
+      sp_eval_u<T, V, U, LINEAR, P>(p, in, L, res);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (u == 0 || full || i + (int64_t)u * SP_BLOCK < nvec) sp_store_vec<T, V>(out, p.out_dtype, L[u], res[u]);
@@ -145,6 +153,30 @@ static int sp_map_go_static(int sid, const sp_program* p, const sp_inputs& in, v
   return 0;
 }
 
+// Specialised programs with NumPy-broadcast operands (x - row_means, x * col_scale,
+// x * (yp - y) ...): addressing mode per operand fixed at compile time (MASK).
+static int sp_map_go_static_2d(int sid, int mask, const sp_program* p, const sp_inputs& in, void* out,
+                               int64_t nvec, hipStream_t st, bool* handled) {
+  int64_t blocks = (nvec + SP_BLOCK - 1) / SP_BLOCK;
+  if (blocks > (1LL << 30)) blocks = 1LL << 30;
+  *handled = true;
+#define SP_CASE2(ID, MSK)                                                                                  \
+  if (sid == ID && mask == MSK) {                                                                          \
+    hipLaunchKernelGGL((sp_map_kernel<float, 4, 1, false, StaticProg<ID>, MSK>), dim3((unsigned)blocks),   \
+                       dim3(SP_BLOCK), 0, st, *p, in, out, (int64_t)0, nvec);                              \
+    SP_CHECK_LAUNCH();                                                                                     \
+    return 0;                                                                                              \
+  }
+  // binary ops: second operand broadcast along columns (mask 2) or along rows (mask 0, strides (0,1));
+  // first operand broadcast (mask 1)
+  SP_CASE2(5, 0) SP_CASE2(5, 1) SP_CASE2(5, 2) SP_CASE2(6, 0) SP_CASE2(6, 1) SP_CASE2(6, 2)
+  SP_CASE2(7, 0) SP_CASE2(7, 1) SP_CASE2(7, 2) SP_CASE2(8, 0) SP_CASE2(8, 1) SP_CASE2(8, 2)
+  SP_CASE2(10, 6) SP_CASE2(10, 0)
+#undef SP_CASE2
+  *handled = false;
+  return 0;
+}
+
 template <typename T, int V, bool LINEAR>
 static int sp_map_go_u(const sp_program* p, const sp_inputs& in, void* out, int64_t start, int64_t nvec,
                        hipStream_t st) {
@@ -186,7 +218,15 @@ static int sp_map_launch(const sp_program* p, const sp_inputs& in, const void* c
   if (sp_can_vectorize<V>(p, inp, out)) {
     if constexpr (std::is_same<T, float>::value) {
       const int sid = sp_static_enabled() ? sp_find_static(p, p->out_dtype) : -1;
-      if (sid >= 0) return sp_map_go_static<false>(sid, p, in, out, n / V, st);
+      if (sid >= 0) {
+        const int mask = sp_mask_2d(p, p->n_inputs);
+        if (mask >= 0) {
+          bool handled = false;
+          if (sp_map_go_static_2d(sid, mask, p, in, out, n / V, st, &handled)) return 1;
+          if (handled) return 0;
+        }
+        return sp_map_go_static<false>(sid, p, in, out, n / V, st);
+      }
     }
     return sp_map_go_u<T, V, false>(p, in, out, 0, n / V, st);
   }

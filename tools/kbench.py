@@ -60,6 +60,23 @@ def bench_map(n):
     print('map %-12s n=%.2e  %8.3f ms  %8.1f GB/s (8 B/elem)' % (name, n, ms, 8.0 * n / ms / 1e6))
 
 
+def bench_map_bcast(rows, cols):
+  from spartan_amd.program import broadcast_strides, collapse
+  x = torch.rand(rows, cols, dtype=torch.float32, device=DEV)
+  out = torch.empty_like(x)
+  for name, bshape in (('x - col(N,1)', (rows, 1)), ('x * row(D,)', (cols,))):
+    b = torch.rand(*bshape, dtype=torch.float32, device=DEV)
+    p = Program()
+    cshape, cst = collapse((rows, cols), [broadcast_strides((rows, cols), (rows, cols)), broadcast_strides(bshape, (rows, cols))])
+    for st in cst:
+      p.add_input(np.float32, st)
+    p.emit('SUB' if 'col' in name else 'MUL', 2, 0, 1)
+    p.result_reg = 2
+    prog = p.finish(_hip.SP_F32, cshape, np.float32, False)
+    ms = timeit(lambda: kernels.map_fused(prog, [x, b], out))
+    print('map %-14s %dx%d  %8.3f ms  %8.1f GB/s (8 B/elem)' % (name, rows, cols, ms, 8.0 * rows * cols / ms / 1e6))
+
+
 def bench_reduce(rows, cols):
   x = torch.rand(rows, cols, dtype=torch.float32, device=DEV)
   n = rows * cols
@@ -101,6 +118,7 @@ if __name__ == '__main__':
   if what in ('all', 'map'):
     print('SP_NO_STATIC=%s SP_MAP_UNROLL=%s' % (os.environ.get('SP_NO_STATIC'), os.environ.get('SP_MAP_UNROLL')))
     bench_map(1 << 29)
+    bench_map_bcast(125000, 4096)
   if what in ('all', 'reduce'):
     bench_reduce(8192, 65536)
     bench_reduce(125000, 4096)
