@@ -54,6 +54,13 @@ class OArr(object):
   def __neg__(self): return self.api.map((self,), np.negative)
   __hash__ = object.__hash__
 
+  # views (slice.py / transpose.py / reshape.py): the oracle materialises them
+  def __getitem__(self, idx):
+    a = self.glom()
+    if isinstance(idx, (int, np.integer)):
+      return self.api.from_numpy(np.ascontiguousarray(a[idx:idx + 1]))     # base.py:437-440 keeps the axis
+    return self.api.from_numpy(np.ascontiguousarray(a[idx]))
+
 
 class Facade(object):
   def __init__(self, num_workers=1):
@@ -103,6 +110,9 @@ class Facade(object):
     return self._w(self.c.map_with_location(fn, self.c.empty((N, M), dtype)))
 
   def from_numpy(self, a, tile_hint=None): return self._w(self.c.from_numpy(a))
+  def transpose(self, x): return self.from_numpy(np.ascontiguousarray(x.glom().T))
+  def reshape(self, x, shape): return self.from_numpy(np.ascontiguousarray(x.glom().reshape(shape)))
+  def ravel(self, x): return self.from_numpy(np.ascontiguousarray(x.glom().ravel()))
 
   # elementwise
   def sqrt(self, v): return self.map((v,), np.sqrt)

@@ -119,6 +119,25 @@ def programs():
   add(('dot_f64', lambda sp: sp.dot(sp.arange((30, 20)), sp.arange((20, 10))), lambda: _ar((30, 20), np.float64).dot(_ar((20, 10), np.float64)), None))
   add(('lreg_step', lambda sp: sp.sum(sm(sp, (256, 16)) * (sp.dot(sm(sp, (256, 16)), small((16, 1))) - sm(sp, (256, 1))), axis=0).optimized(),
        lambda: (small((256, 16)) * (small((256, 16)).dot(small((16, 1))) - small((256, 1)))).sum(0), None))
+  # ---- views: Slice / Transpose / Reshape (tests/test_slice.py, test_transpose.py, test_reshape.py)
+  A = lambda sp: sp.arange((40, 30), dtype=F32)
+  a = lambda: _ar((40, 30))
+  add(('slice_rows', lambda sp: A(sp)[5:30] + 1, lambda: a()[5:30] + 1, None))
+  add(('slice_2d', lambda sp: A(sp)[2:30, 3:17] * 2, lambda: a()[2:30, 3:17] * 2, None))
+  add(('slice_col_sum', lambda sp: sp.sum(A(sp)[:, 4:20], 0), lambda: a()[:, 4:20].sum(0), None))
+  add(('slice_of_slice', lambda sp: A(sp)[4:36][3:20, 1:9] - 3, lambda: a()[4:36][3:20, 1:9] - 3, None))
+  add(('int_index', lambda sp: A(sp)[3] * 1, lambda: a()[3:4] * 1, None))   # reference keeps the axis (base.py:437-440)
+  add(('tuple_int_index', lambda sp: A(sp)[:, 7] + 0, lambda: a()[:, 7] + 0, None))
+  add(('transpose_map', lambda sp: sp.transpose(A(sp)) + 1, lambda: a().T + 1, None))
+  add(('transpose_sum', lambda sp: sp.sum(sp.transpose(A(sp)), 1), lambda: a().T.sum(1), None))
+  small2 = lambda: _ar((40, 30)) % 5 - 2
+  S2 = lambda sp: sp.arange((40, 30), dtype=F32) % 5 - 2
+  add(('dot_a_at', lambda sp: sp.dot(S2(sp), sp.transpose(S2(sp))), lambda: small2().dot(small2().T), None))
+  add(('dot_at_a', lambda sp: sp.dot(sp.transpose(S2(sp)), S2(sp)), lambda: small2().T.dot(small2()), None))
+  add(('reshape_flat', lambda sp: sp.reshape(A(sp), (1200,)) * 2, lambda: a().reshape(1200) * 2, None))
+  add(('reshape_2d', lambda sp: sp.reshape(A(sp), (30, 40)) + 1, lambda: a().reshape(30, 40) + 1, None))
+  add(('reshape_add_dim', lambda sp: sp.reshape(A(sp), (40, 30, 1)) + 1, lambda: a().reshape(40, 30, 1) + 1, None))
+  add(('ravel_sum', lambda sp: sp.sum(sp.ravel(A(sp))), lambda: a().ravel().sum(), None))
   return P
 
 
