@@ -1,0 +1,117 @@
+"""Parity at BASELINE.json's FULL per-GPU sizes through size-independent
+properties (the oracle cannot finish these sizes in seconds):
+  * configs[2] tile: 8192 x 65536 fp32 (2 GiB) -- sum of sums, planted
+    argmax/argmin (incl. duplicates: first occurrence wins), map linearity;
+  * configs[1]: dot 8192^3 fp32 -- closed forms for integer-valued operands
+    (bit-exact) and spot rows against float64 NumPy for uniform[-1,1) operands;
+  * configs[4] tile: 125000 x 4096 fp32 -- one lreg step against float64 NumPy
+    on sampled columns/rows.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+import spartan_amd as sp  # noqa: E402
+
+
+@pytest.fixture
+def ctx():
+  c = sp.initialize('hip')
+  yield c
+  sp.shutdown()
+  torch.cuda.empty_cache()
+
+
+def _uniform(shape, seed, lo=0.0, hi=1.0):
+  def fn(ex):
+    g = torch.Generator(device='cuda')
+    g.manual_seed(seed + ex.ul[0])
+    return torch.rand(ex.shape, dtype=torch.float32, device='cuda', generator=g) * (hi - lo) + lo
+  return sp.from_tile_fn(shape, np.float32, fn)
+
+
+def test_config3_tile_reductions(ctx):
+  R, C = 8192, 65536
+  X = _uniform((R, C), 3).force()
+  x = ctx.tile(list(X.tiles.values())[0]).data
+  # plant extremes (duplicates: the FIRST occurrence must be reported)
+  x[100, 7] = 5.0
+  x[4000, 7] = 5.0
+  x[17, 65000] = 9.0
+  x[8000, 3] = 9.0
+  x[5000, 123] = -4.0
+  x[6000, 123] = -4.0
+  Xv = sp.Val(val=X)
+  total = float(sp.sum(Xv).glom())
+  by_col = sp.sum(Xv, 0).glom().astype(np.float64)
+  by_row = sp.sum(Xv, 1).glom().astype(np.float64)
+  n = R * C
+  # checksum of checksums: three different kernels / summation trees agree to 1e-6 * sum|x|
+  assert abs(by_col.sum() - total) <= 1e-6 * n and abs(by_row.sum() - total) <= 1e-6 * n
+  assert abs(total - 0.5 * n) < 2e-3 * n                        # uniform[0,1) mean
+  assert int(sp.argmax(Xv).glom()) == 17 * C + 65000            # first 9.0 in row-major order
+  am0 = sp.argmax(Xv, 0).glom()
+  assert am0[7] == 100 and am0[65000] == 17 and am0[3] == 8000
+  am1 = sp.argmax(Xv, 1).glom()
+  assert am1[100] == 7 and am1[17] == 65000 and am1[8000] == 3 and am1[4000] == 7
+  assert sp.argmin(Xv, 0).glom()[123] == 5000
+  assert float(sp.max(Xv).glom()) == 9.0 and float(sp.min(Xv).glom()) == -4.0
+  # spot rows/columns against float64 NumPy
+  xs = x[::1024].cpu().numpy().astype(np.float64)
+  np.testing.assert_allclose(by_row[::1024], xs.sum(1), rtol=1e-6)
+
+
+def test_config3_tile_fused_maps(ctx):
+  R, C = 8192, 65536
+  X = _uniform((R, C), 5).force()
+  Xv = sp.Val(val=X)
+  x = ctx.tile(list(X.tiles.values())[0]).data
+  y = (Xv * Xv + Xv).optimized().force()
+  yt = ctx.tile(list(y.tiles.values())[0]).data
+  assert torch.equal(yt, x * x + x)                             # bit-exact vs the same fp32 ops (no FMA contraction)
+  z = ((Xv + 1) - 1 - Xv).optimized().force()                   # exact in fp32 for x in [0,1): (x+1)-1 == x up to 1 ulp of 1
+  zt = ctx.tile(list(z.tiles.values())[0]).data
+  assert float(zt.abs().max()) <= 2 ** -23
+  assert float(sp.sum((Xv > 2.0)).glom()) == 0
+
+
+def test_config2_dot_8192(ctx):
+  n = 8192
+  # closed form, integer-valued: A[i,k] = (i+k)%3-1, B = ones  =>  C[i,j] = sum_k A[i,k]
+  ii = torch.arange(n, device='cuda', dtype=torch.float32)
+  a = ((ii[:, None] + ii[None, :]) % 3) - 1
+  A = sp.from_tile_fn((n, n), np.float32, lambda ex: a)
+  B = sp.ones((n, n))
+  Cd = sp.dot(A, B).force()
+  c = ctx.tile(list(Cd.tiles.values())[0]).data
+  assert torch.equal(c, a.sum(1, keepdim=True).expand(n, n))
+  # uniform[-1,1): spot rows vs float64, |dC| <= 2 K eps
+  U = _uniform((n, n), 11, -1.0, 1.0).force()
+  V = _uniform((n, n), 12, -1.0, 1.0).force()
+  W = sp.dot(sp.Val(val=U), sp.Val(val=V)).force()
+  u = ctx.tile(list(U.tiles.values())[0]).data
+  v = ctx.tile(list(V.tiles.values())[0]).data
+  w = ctx.tile(list(W.tiles.values())[0]).data
+  rows = [0, 1, 4095, 8191]
+  ref = u[rows].double() @ v.double()
+  assert float((w[rows].double() - ref).abs().max()) <= 2 * n * np.finfo(np.float32).eps
+
+
+def test_config5_lreg_step(ctx):
+  N, D = 125000, 4096
+  X = _uniform((N, D), 21).force()
+  y = _uniform((N, 1), 22).force()
+  w = np.random.RandomState(1).rand(D, 1).astype(np.float32)
+  Xv, yv = sp.Val(val=X), sp.Val(val=y)
+  yp = sp.dot(Xv, w)
+  grad = sp.sum(Xv * (yp - yv), axis=0).optimized().glom()
+  x = ctx.tile(list(X.tiles.values())[0]).data
+  yt = ctx.tile(list(y.tiles.values())[0]).data
+  r = x.double() @ torch.from_numpy(w).cuda().double() - yt.double()      # float64 reference on the device
+  cols = [0, 1, 2047, 4095]
+  ref = (x[:, cols].double() * r).sum(0).cpu().numpy()
+  np.testing.assert_allclose(grad[cols], ref, rtol=2e-5)
+  np.testing.assert_allclose(yp.glom()[:5, 0], (x[:5].double() @ torch.from_numpy(w).cuda().double())[:, 0].cpu().numpy(), rtol=2e-6)
