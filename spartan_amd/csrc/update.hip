@@ -154,7 +154,35 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_box_copy_kernel(E* __restrict__ d
   }
 }
 
-struct uint128_t_ { uint32_t a, b, c, d; };
+// 2-D transposing copy through LDS: dst[c][r] = src[r][c].  Both the global read
+// and the global write are coalesced (64 consecutive 4/8-byte elements per wave
+// row); the 64x65 LDS tile (one pad column) makes the column-wise read conflict
+// free.  Used when a Transpose view (transpose.py:64-67 `base_tile.transpose()`)
+// has to be handed to a kernel as a dense operand.
+template <typename E>
+__global__ __launch_bounds__(SP_BLOCK) void sp_transpose_kernel(E* __restrict__ dst, const E* __restrict__ src,
+                                                                int64_t R, int64_t C, int64_t src_ld,
+                                                                int64_t dst_ld) {
+  __shared__ E tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  const int64_t tiles_c = (C + 63) / 64;
+  const int64_t ntiles = ((R + 63) / 64) * tiles_c;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int64_t r = r0 + ty + 4 * k, c = c0 + tx;
+      if (r < R && c < C) tile[ty + 4 * k][tx] = src[r * src_ld + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int64_t c = c0 + ty + 4 * k, r = r0 + tx;
+      if (r < R && c < C) dst[c * dst_ld + r] = tile[tx][ty + 4 * k];
+    }
+    __syncthreads();
+  }
+}
 
 extern "C" int sp_slice_copy(void* d_dst, const int64_t* dst_stride, const void* d_src,
                              const int64_t* src_stride, const int64_t* shape, int32_t ndim,
@@ -181,6 +209,23 @@ extern "C" int sp_slice_copy(void* d_dst, const int64_t* dst_stride, const void*
   }
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  // 2-D transpose pattern (dst dense rows, src walks a column): LDS-tiled kernel
+  if (b.ndim == 2 && (elem_size == 4 || elem_size == 8) && b.dstride[1] == 1 && b.sstride[0] == 1 &&
+      b.sstride[1] >= b.shape[0] && b.dstride[0] >= b.shape[1] && b.shape[0] >= 16 && b.shape[1] >= 16) {
+    // dst[i][j] = src[j][i] with src row-major of leading dimension sstride[1]
+    const int64_t R = b.shape[1], Cc = b.shape[0];   // src is R x Cc
+    int64_t blocks = ((R + 63) / 64) * ((Cc + 63) / 64);
+    const int64_t cap = (int64_t)SP_CUS * SP_BLOCKS_PER_CU * 4;
+    if (blocks > cap) blocks = cap;
+    if (elem_size == 4)
+      hipLaunchKernelGGL((sp_transpose_kernel<uint32_t>), dim3((unsigned)blocks), dim3(SP_BLOCK), 0, st,
+                         (uint32_t*)d_dst, (const uint32_t*)d_src, R, Cc, b.sstride[1], b.dstride[0]);
+    else
+      hipLaunchKernelGGL((sp_transpose_kernel<uint64_t>), dim3((unsigned)blocks), dim3(SP_BLOCK), 0, st,
+                         (uint64_t*)d_dst, (const uint64_t*)d_src, R, Cc, b.sstride[1], b.dstride[0]);
+    SP_CHECK_LAUNCH();
+    return 0;
+  }
   // widen: if the innermost run is contiguous on both sides, move 16-B words
   const int last = b.ndim - 1;
   int64_t es = elem_size;

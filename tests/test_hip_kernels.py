@@ -439,3 +439,15 @@ def test_static_program_library():
   prog, _ = lower.Emitter(_hip.SP_F32, root.shape).finish(root, np.float32)
   assert _hip.lib().sp_program_static_id(C.byref(prog), _hip.SP_F32) == -1
   np.testing.assert_array_equal(host(be._run_map(root, x.shape)), host(x) * host(y) + (host(x) - 2))
+
+
+@pytest.mark.parametrize('shape', [(64, 64), (100, 37), (1000, 513), (17, 4096)])
+def test_transposing_slice_copy(shape):
+  """dst = src.T through sp_slice_copy (the LDS-tiled path) for 4- and 8-byte elements."""
+  for dt in (np.float32, np.int64):
+    a = RNG.randint(-1000, 1000, size=shape).astype(dt)
+    da = dev(a)
+    v = da.t()
+    out = torch.empty((shape[1], shape[0]), dtype=da.dtype, device=DEV)
+    kernels.slice_copy(out, 0, out.stride(), da, 0, v.stride(), v.shape)
+    np.testing.assert_array_equal(host(out), a.T)
