@@ -183,6 +183,22 @@ int sp_map_fused(const sp_program* prog, const void* const* d_inputs, void* d_ou
  * environment disables the specialised kernels (A/B measurements). */
 int sp_program_static_id(const sp_program* prog, int32_t out_dtype);
 
+/* Run-time specialisation: a program OUTSIDE that library, applied to a large
+ * tile (>= min_elems elements, default 2^22), is compiled once per instruction
+ * stream with hipRTC from the same evaluator source (spartan_amd/csrc/sp_jit.hip;
+ * the reference's precedent is its JIT local op, local.py:187-209) and cached for
+ * the life of the process; smaller tiles and any compile failure use the
+ * interpreter kernels.  Results are bit-identical across the three tiers.
+ *   sp_jit_configure      enabled: 0/1, or -1 to leave; min_elems: threshold, or -1 to leave
+ *                         (defaults: SP_NO_JIT / SP_JIT_MIN_ELEMS in the environment).
+ *                         Returns 1 if the tier is usable (libhiprtc present and enabled).
+ *   sp_jit_compiled_count kernels specialised so far.
+ *   sp_jit_compile_check  does `template_expr` (a kernel template-id naming the program
+ *                         type StaticProg<1000>) compile for `prog`?  Needs no device. */
+int sp_jit_configure(int enabled, long long min_elems);
+int sp_jit_compiled_count(void);
+int sp_jit_compile_check(const char* header, const char* template_expr, const sp_program* prog);
+
 /* sp_reduce: fused map -> reduce over ONE axis of the program's index space
  * viewed as [outer, axis_len, inner] (prod == prod(prog->shape)); axis=None is
  * outer=1, inner=1.  Replaces `_reduce_mapper`'s local reduction

@@ -5,42 +5,10 @@
 // HBM roofline kernel: algorithmic bytes = sum(sizeof(in_j) for dense inputs)
 // + sizeof(out) per element; 16 B per lane per operand, grid capped at
 // 8 workgroups per CU with a grid-stride loop.
-#include "sp_interp.hpp"
+#include <type_traits>
 
-// One workgroup handles U x 256 vectors of V elements (16 B each): group u of a
-// thread is 256 vectors after group u-1, so every load/store instruction of the
-// workgroup is a fully coalesced 4 KiB.  The grid covers the tile exactly (no
-// grid-stride loop: on MI355X a full grid streams ~25% faster than a capped,
-// grid-striding one -- tools/hbm_probe.hip, profiles/).
-template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1>
-__global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, const sp_inputs in,
-                                                          void* __restrict__ out, int64_t start,
-                                                          int64_t nvec) {
-  const int64_t stride = (int64_t)gridDim.x * SP_BLOCK * U;
-  for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK * U + threadIdx.x; i < nvec; i += stride) {
-    int64_t L[U];
-    bool full = true;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t k = i + (int64_t)u * SP_BLOCK;
-      L[u] = start + (k < nvec ? k : i) * V;   // tail groups re-evaluate group 0 (never stored)
-      full = full && (k < nvec);
-    }
-    T res[U][V];
-    if constexpr (MASK >= 0) {
-      // specialised 2-D broadcast addressing (sp_eval_2d): one 32-bit division per lane
-      const uint32_t cols = (uint32_t)p.shape[1];
-      const uint32_t l32 = (uint32_t)L[0];
-      const uint32_t row = l32 / cols;
-      sp_eval_2d<T, V, P, MASK>(p, in, row, l32 - row * cols, L[0], res[0]);
-    } else {
-      sp_eval_u<T, V, U, LINEAR, P>(p, in, L, res);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (u == 0 || full || i + (int64_t)u * SP_BLOCK < nvec) sp_store_vec<T, V>(out, p.out_dtype, L[u], res[u]);
-  }
-}
+#include "map_kernel.hpp"
+#include "sp_jit.hpp"
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -177,6 +145,28 @@ static int sp_map_go_static_2d(int sid, int mask, const sp_program* p, const sp_
   return 0;
 }
 
+// Run-time specialised kernel for a program outside the prebuilt library (large tiles only).
+template <typename T, int V, bool LINEAR>
+static int sp_map_go_jit(const sp_program* p, const sp_inputs& in, void* out, int64_t nvec, int mask,
+                         hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!sp_jit_enabled() || p->n_instr == 0 || nvec * V < sp_jit_min_elems()) return 0;
+  char expr[160];
+  snprintf(expr, sizeof(expr), "sp_map_kernel<%s, %d, 1, %s, StaticProg<1000>, %d>", sp_cls<T>::name(), V,
+           LINEAR ? "true" : "false", mask);
+  void* fn = sp_jit_get("map_kernel.hpp", expr, p);
+  if (!fn) return 0;
+  int64_t blocks = (nvec + SP_BLOCK - 1) / SP_BLOCK;
+  if (blocks > (1LL << 30)) blocks = 1LL << 30;
+  sp_program pc = *p;
+  sp_inputs ic = in;
+  int64_t start = 0;
+  void* args[] = {&pc, &ic, &out, &start, &nvec};
+  if (sp_jit_launch(fn, dim3((unsigned)blocks), dim3(SP_BLOCK), args, st)) return 1;
+  *handled = true;
+  return 0;
+}
+
 template <typename T, int V, bool LINEAR>
 static int sp_map_go_u(const sp_program* p, const sp_inputs& in, void* out, int64_t start, int64_t nvec,
                        hipStream_t st) {
@@ -211,6 +201,14 @@ static int sp_map_launch(const sp_program* p, const sp_inputs& in, const void* c
         return 0;
       }
     }
+    if (nmain) {
+      bool handled = false;
+      if (sp_map_go_jit<T, V, true>(p, in, out, nmain / V, -1, st, &handled)) return 1;
+      if (handled) {
+        if (n - nmain && sp_map_go<T, 1, 1, true>(p, in, out, nmain, n - nmain, st)) return 1;
+        return 0;
+      }
+    }
     if (nmain && sp_map_go_u<T, V, true>(p, in, out, 0, nmain / V, st)) return 1;
     if (n - nmain && sp_map_go<T, 1, 1, true>(p, in, out, nmain, n - nmain, st)) return 1;
     return 0;
@@ -227,6 +225,13 @@ static int sp_map_launch(const sp_program* p, const sp_inputs& in, const void* c
         }
         return sp_map_go_static<false>(sid, p, in, out, n / V, st);
       }
+    }
+    {
+      // outside the library: run-time specialisation, with compile-time 2-D addressing when it applies
+      bool handled = false;
+      const int mask = sp_mask_2d(p, p->n_inputs);
+      if (sp_map_go_jit<T, V, false>(p, in, out, n / V, mask, st, &handled)) return 1;
+      if (handled) return 0;
     }
     return sp_map_go_u<T, V, false>(p, in, out, 0, n / V, st);
   }

@@ -24,8 +24,11 @@
 
 #include "sp_interp.hpp"
 
+#ifndef __HIPCC_RTC__
 int sp_validate_program(const sp_program* p);
 int sp_static_enabled();
+#include "sp_jit.hpp"
+#endif
 
 // ------------------------------------------------------------------ policies
 template <typename T>
@@ -34,10 +37,10 @@ __device__ __forceinline__ T sp_red_identity(int op) {
     case SP_RED_SUM: return (T)0;
     case SP_RED_PROD: return (T)1;
     case SP_RED_MAX:
-      if constexpr (std::is_integral<T>::value) return (T)INT64_MIN;
+      if constexpr (sp_is_integral<T>::value) return (T)INT64_MIN;
       else return (T)(-INFINITY);
     case SP_RED_MIN:
-      if constexpr (std::is_integral<T>::value) return (T)INT64_MAX;
+      if constexpr (sp_is_integral<T>::value) return (T)INT64_MAX;
       else return (T)(INFINITY);
     case SP_RED_AND: return (T)1;
     default: return (T)0;
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_finish_cols_kernel(int op, int64_
   }
 }
 
+#ifndef __HIPCC_RTC__
 // ------------------------------------------------------------------- planner
 struct RedPlan {
   int kind;  // 0 rows-split, 1 rows-wave, 2 cols
@@ -447,7 +451,8 @@ template <int V>
 static bool sp_reduce_can_vec(const sp_program* p, const void* const* in, int64_t A, int64_t I) {
   if (V == 1) return true;
   const int nd = p->ndim;
-  if (p->shape[nd - 1] % V != 0) return false;
+  // (a linear program addresses by the flat index alone: its own shape split does not matter)
+  if (!p->linear && p->shape[nd - 1] % V != 0) return false;
   if ((I == 1 ? A : I) % V != 0) return false;
   for (int j = 0; j < p->n_inputs; ++j) {
     const int64_t inner = p->in_stride[j][nd - 1];
@@ -462,6 +467,12 @@ static bool sp_reduce_can_vec(const sp_program* p, const void* const* in, int64_
 }
 
 static inline int cap_dim(int64_t x, int64_t cap) { return (int)(x < cap ? (x < 1 ? 1 : x) : cap); }
+
+template <typename... Args>
+static int sp_jit_go(void* fn, dim3 grid, hipStream_t st, Args... args) {
+  void* ptrs[] = {(void*)&args...};
+  return sp_jit_launch(fn, grid, dim3(SP_BLOCK), ptrs, st);
+}
 
 template <typename T, template <typename> class AccT>
 static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void* const* inp, int op,
@@ -483,7 +494,7 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
   // (sp_interp.hpp StaticProg) -- plain reductions of x, a*b (matrix.vector),
   // x*x, x*x+x, x*(yp-y); arg-reductions of x.
   int sid = -1;
-  if constexpr (std::is_same<T, float>::value) {
+  if constexpr (sp_is_same<T, float>::value) {
     if (vec && sp_static_enabled()) {
       sid = sp_find_static(p, -1);
       if (kArg ? (sid != 0) : !(sid == 0 || sid == 7 || sid == 9 || sid == 10 || sid == 11)) sid = -1;
@@ -495,6 +506,10 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
     const int64_t cols = (I == 1) ? A : I;
     if (p->shape[1] == cols) mask2d = sp_mask_2d(p, p->n_inputs);
   }
+  // programs outside the library: run-time specialisation for large tiles (sp_jit.hip)
+  const bool jit_ok = vec && sid < 0 && sp_jit_enabled() && O * A * I >= sp_jit_min_elems();
+  int jit_mask = -1;
+  if (jit_ok && !lin && p->shape[1] == ((I == 1) ? A : I)) jit_mask = sp_mask_2d(p, p->n_inputs);
   const int sop = (!kArg && (op == SP_RED_SUM || op == SP_RED_MAX || op == SP_RED_MIN)) ? op : -1;
 #define SP_GO(KERNEL, GRID, LIN, PROG, OPC, MSK, ...) \
   hipLaunchKernelGGL((KERNEL<T, VV, LIN, AccT, PROG, OPC, MSK>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__)
@@ -516,7 +531,7 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
 #define SP_LAUNCH(KERNEL, GRID, ...)                                                        \
   do {                                                                                      \
     bool done_ = false;                                                                     \
-    if constexpr (std::is_same<T, float>::value) {                                          \
+    if constexpr (sp_is_same<T, float>::value) {                                          \
       if (sid == 0) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<0>, __VA_ARGS__); done_ = true; } \
       if constexpr (!kArg) {                                                                \
         if (sid == 7 && mask2d == 0) { SP_LAUNCH_OP(KERNEL, GRID, false, StaticProg<7>, 0, __VA_ARGS__); done_ = true; } \
@@ -526,6 +541,16 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
         if (sid == 10 && mask2d == 6) { SP_LAUNCH_OP(KERNEL, GRID, false, StaticProg<10>, 6, __VA_ARGS__); done_ = true; } \
         else if (sid == 10) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<10>, __VA_ARGS__); done_ = true; } \
         if (sid == 11) { SP_LAUNCH_P(KERNEL, GRID, StaticProg<11>, __VA_ARGS__); done_ = true; } \
+      }                                                                                     \
+    }                                                                                       \
+    if (!done_ && vec && jit_ok) {                                                          \
+      char expr_[192];                                                                      \
+      snprintf(expr_, sizeof(expr_), #KERNEL "<%s, %d, %s, %s, StaticProg<1000>, %d, %d>", sp_cls<T>::name(), VV, \
+               lin ? "true" : "false", kArg ? "ArgAcc" : "PlainAcc", sop, jit_mask);        \
+      void* fn_ = sp_jit_get("reduce_impl.hpp", expr_, p);                                  \
+      if (fn_) {                                                                            \
+        if (sp_jit_go(fn_, GRID, st, __VA_ARGS__)) return 1;                                \
+        done_ = true;                                                                       \
       }                                                                                     \
     }                                                                                       \
     if (!done_) {                                                                           \
@@ -596,3 +621,5 @@ static int sp_check_space(const sp_program* p, int64_t O, int64_t A, int64_t I) 
   return 0;
 }
 
+
+#endif  // !__HIPCC_RTC__

@@ -2,8 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifndef __HIPCC_RTC__
 #include <stdio.h>
 #include <string.h>
+#endif
 
 #include "../../include/spartan_hip.h"
 

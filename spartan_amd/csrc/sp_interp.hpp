@@ -8,24 +8,35 @@
 // space per call; V*sizeof(T) == 16 B so the dense operands are read with one
 // global_load_dwordx4 per lane (1 KiB per wave-instruction).
 #pragma once
-#include <type_traits>
 
 #include "sp_common.hpp"
+
+// the two type traits the evaluator needs, spelled here so that these headers also
+// compile under hipRTC (no C++ standard library there; see sp_jit.hip)
+template <typename A, typename B> struct sp_is_same { static constexpr bool value = false; };
+template <typename A> struct sp_is_same<A, A> { static constexpr bool value = true; };
+template <typename T> struct sp_is_integral { static constexpr bool value = false; };
+template <> struct sp_is_integral<int64_t> { static constexpr bool value = true; };
+template <> struct sp_is_integral<int32_t> { static constexpr bool value = true; };
+template <> struct sp_is_integral<uint8_t> { static constexpr bool value = true; };
 
 template <typename T>
 struct sp_cls;
 template <>
 struct sp_cls<float> {
+  static constexpr const char* name() { return "float"; }
   static constexpr int V = 4;
   static constexpr int id = SP_F32;
 };
 template <>
 struct sp_cls<double> {
+  static constexpr const char* name() { return "double"; }
   static constexpr int V = 2;
   static constexpr int id = SP_F64;
 };
 template <>
 struct sp_cls<int64_t> {
+  static constexpr const char* name() { return "int64_t"; }
   static constexpr int V = 2;
   static constexpr int id = SP_I64;
 };
@@ -311,7 +322,7 @@ __device__ __forceinline__ T sp_nanmin(T a, T b) {
 
 template <typename T>
 __device__ __forceinline__ T sp_const(const sp_program& p, int i) {
-  if constexpr (std::is_integral<T>::value) {
+  if constexpr (sp_is_integral<T>::value) {
     return (T)p.iconsts[i];
   } else {
     return (T)p.consts[i];
@@ -332,6 +343,7 @@ struct DynProg {
   static constexpr int NIN = SP_MAX_INPUTS;
   static constexpr int RESULT = 0;
   static __host__ __device__ constexpr sp_instr at(int) { return sp_instr{0, 0, 0, 0, 0, 0, 0, 0}; }
+  static __host__ __device__ constexpr int in_dtype(int) { return SP_F32; }
 };
 
 template <int ID>
@@ -352,6 +364,9 @@ struct StaticProg;
     static __host__ __device__ constexpr sp_instr at(int pc) {                       \
       return pc == 0 ? I0 : (pc == 1 ? I1 : (pc == 2 ? I2 : I3));                    \
     }                                                                                \
+    /* the prebuilt library is all-fp32; run-time specialised programs (sp_jit.hip) \
+       carry their own operand dtypes */                                             \
+    static __host__ __device__ constexpr int in_dtype(int) { return SP_F32; }        \
   };
 #define SP_NOPI SP_I(SP_OP_NOP, 0, 0, 0)
 
@@ -536,7 +551,7 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
 #pragma unroll
   for (int j = 0; j < SP_MAX_INPUTS; ++j) {
     if (j < (P::kStatic ? P::NIN : p.n_inputs)) {
-      const int32_t dt = P::kStatic ? (int32_t)SP_F32 : p.in_dtype[j];
+      const int32_t dt = P::kStatic ? (int32_t)P::in_dtype(j) : p.in_dtype[j];
       if constexpr (LINEAR) {
         // dense operand (stride pattern == output) or scalar (all strides 0)
         if (p.in_stride[j][p.ndim - 1] != 0) {
@@ -625,11 +640,11 @@ __device__ __forceinline__ void sp_eval_2d(const sp_program& p, const sp_inputs&
     const uint32_t off = row * (uint32_t)p.in_stride[j][0] + col * (uint32_t)p.in_stride[j][1];
     if (((MASK >> j) & 1) != 0) {  // folds once the loop is unrolled
       T s;
-      sp_load_vec<T, 1>(in.p[j], SP_F32, (int64_t)off, &s);
+      sp_load_vec<T, 1>(in.p[j], P::in_dtype(j), (int64_t)off, &s);
 #pragma unroll
       for (int v = 0; v < V; ++v) r0[j * V + v] = s;
     } else {
-      sp_load_vec<T, V>(in.p[j], SP_F32, (int64_t)off, &r0[j * V]);
+      sp_load_vec<T, V>(in.p[j], P::in_dtype(j), (int64_t)off, &r0[j * V]);
     }
   }
   const int64_t Ls[1] = {L};

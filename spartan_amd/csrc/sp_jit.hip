@@ -1,0 +1,221 @@
+// Run-time specialisation ("third tier") of the fused-map / reduce kernels.
+//
+// The prebuilt StaticProg library covers the hot shapes; every other fused tree
+// runs on the interpreter kernels, whose wave-uniform dispatch holds them at
+// 25-70 % of the copy bandwidth (profiles/r01_notes.md).  For LARGE tiles this
+// file closes the gap: it hands the very same hand-written evaluator source
+// (sp_interp.hpp, map_kernel.hpp, reduce_impl.hpp) to hipRTC with the program's
+// instruction stream spelled as one more `StaticProg` specialisation, so hipcc
+// unrolls it exactly as it does for the prebuilt library.  Nothing is generated
+// but that one struct; compiled code objects are cached per instruction stream.
+// The reference's precedent is ParakeetExpr: a JIT-compiled local op installed
+// when code generation succeeds, the interpreter otherwise
+// (spartan/expr/operator/local.py:187-209, optimize.py:321-370).
+//
+// Failure of any step (no libhiprtc, compile error) is not an error: the caller
+// falls back to the interpreter kernels, which are always correct.
+#include <dlfcn.h>
+#include <stdlib.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "sp_jit.hpp"
+
+namespace {
+
+typedef struct _hiprtcProgram* rtcProgram;
+struct Rtc {
+  void* lib = nullptr;
+  int (*create)(rtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+  int (*compile)(rtcProgram, int, const char**) = nullptr;
+  int (*addName)(rtcProgram, const char*) = nullptr;
+  int (*lowered)(rtcProgram, const char*, const char**) = nullptr;
+  int (*codeSize)(rtcProgram, size_t*) = nullptr;
+  int (*code)(rtcProgram, char*) = nullptr;
+  int (*logSize)(rtcProgram, size_t*) = nullptr;
+  int (*log)(rtcProgram, char*) = nullptr;
+  int (*destroy)(rtcProgram*) = nullptr;
+  bool ok = false;
+};
+
+Rtc& rtc() {
+  static Rtc r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+    for (const char* n : names) {
+      r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+#define SP_SYM(field, name) *(void**)(&r.field) = dlsym(r.lib, name)
+    SP_SYM(create, "hiprtcCreateProgram");
+    SP_SYM(compile, "hiprtcCompileProgram");
+    SP_SYM(addName, "hiprtcAddNameExpression");
+    SP_SYM(lowered, "hiprtcGetLoweredName");
+    SP_SYM(codeSize, "hiprtcGetCodeSize");
+    SP_SYM(code, "hiprtcGetCode");
+    SP_SYM(logSize, "hiprtcGetProgramLogSize");
+    SP_SYM(log, "hiprtcGetProgramLog");
+    SP_SYM(destroy, "hiprtcDestroyProgram");
+#undef SP_SYM
+    r.ok = r.create && r.compile && r.addName && r.lowered && r.codeSize && r.code && r.destroy;
+  });
+  return r;
+}
+
+bool verbose() {
+  static int v = -1;
+  if (v < 0) v = getenv("SP_JIT_VERBOSE") ? 1 : 0;
+  return v != 0;
+}
+
+// directory of this shared library == spartan_amd/csrc (the headers ship next to it)
+std::string source_dir() {
+  Dl_info info;
+  if (dladdr((const void*)&sp_jit_enabled, &info) && info.dli_fname) {
+    std::string path(info.dli_fname);
+    size_t slash = path.rfind('/');
+    if (slash != std::string::npos) return path.substr(0, slash);
+  }
+  return ".";
+}
+
+std::string program_struct(const sp_program* p) {
+  std::string s = "template <> struct StaticProg<1000> {\n  static constexpr bool kStatic = true;\n";
+  s += "  static constexpr int N = " + std::to_string(p->n_instr) + ";\n";
+  s += "  static constexpr int NIN = " + std::to_string(p->n_inputs) + ";\n";
+  s += "  static constexpr int RESULT = " + std::to_string(p->result_reg) + ";\n";
+  s += "  static __host__ __device__ constexpr sp_instr at(int pc) {\n    switch (pc) {\n";
+  for (int i = 0; i < p->n_instr; ++i) {
+    const sp_instr& I = p->instr[i];
+    s += "      case " + std::to_string(i) + ": return sp_instr{" + std::to_string(I.op) + ", " +
+         std::to_string(I.dst) + ", " + std::to_string(I.a) + ", " + std::to_string(I.b) + ", " +
+         std::to_string(I.c) + ", 0, 0, 0};\n";
+  }
+  s += "      default: return sp_instr{0, 0, 0, 0, 0, 0, 0, 0};\n    }\n  }\n";
+  s += "  static __host__ __device__ constexpr int in_dtype(int j) {\n    switch (j) {\n";
+  for (int j = 0; j < p->n_inputs; ++j)
+    s += "      case " + std::to_string(j) + ": return " + std::to_string(p->in_dtype[j]) + ";\n";
+  s += "      default: return 0;\n    }\n  }\n};\n";
+  return s;
+}
+
+std::string program_key(const char* header, const char* expr, const sp_program* p) {
+  std::string k = std::string(header) + "|" + expr + "|" + std::to_string(p->cls) + "|" +
+                  std::to_string(p->n_inputs) + "|" + std::to_string(p->result_reg) + "|";
+  for (int j = 0; j < p->n_inputs; ++j) k += std::to_string(p->in_dtype[j]) + ",";
+  k += "|";
+  for (int i = 0; i < p->n_instr; ++i) {
+    const sp_instr& I = p->instr[i];
+    char buf[48];
+    snprintf(buf, sizeof(buf), "%u.%u.%u.%u.%u;", I.op, I.dst, I.a, I.b, I.c);
+    k += buf;
+  }
+  return k;
+}
+
+std::mutex g_mu;
+std::unordered_map<std::string, hipFunction_t> g_cache;   // value NULL = tried and failed
+
+hipFunction_t compile(const char* header, const char* expr, const sp_program* p, bool load = true, int* compiled = nullptr) {
+  Rtc& r = rtc();
+  if (!r.ok) return nullptr;
+  const std::string dir = source_dir();
+  std::string src = "#include \"" + std::string(header) + "\"\n" + program_struct(p);
+  rtcProgram prog = nullptr;
+  if (r.create(&prog, src.c_str(), "sp_jit_program.hip", 0, nullptr, nullptr) != 0) return nullptr;
+  r.addName(prog, expr);
+  const std::string inc1 = "-I" + dir + "/rtc_shim", inc2 = "-I" + dir;
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc1.c_str(), inc2.c_str()};
+  const int rc = r.compile(prog, 6, opts);
+  hipFunction_t fn = nullptr;
+  if (rc != 0) {
+    if (verbose() && r.logSize && r.log) {
+      size_t n = 0;
+      r.logSize(prog, &n);
+      std::vector<char> log(n + 1, 0);
+      r.log(prog, log.data());
+      fprintf(stderr, "[spartan_hip jit] compile failed for %s:\n%s\n", expr, log.data());
+    }
+  } else if (!load) {
+    if (compiled) *compiled = 1;
+  } else {
+    const char* lowered = nullptr;
+    size_t n = 0;
+    if (r.lowered(prog, expr, &lowered) == 0 && lowered && r.codeSize(prog, &n) == 0 && n) {
+      std::vector<char> code(n);
+      if (r.code(prog, code.data()) == 0) {
+        hipModule_t mod = nullptr;
+        if (hipModuleLoadData(&mod, code.data()) == hipSuccess) {
+          if (hipModuleGetFunction(&fn, mod, lowered) != hipSuccess) fn = nullptr;
+        }
+        (void)hipGetLastError();
+      }
+    }
+    if (verbose()) fprintf(stderr, "[spartan_hip jit] %s %s (%d instrs)\n", fn ? "compiled" : "load failed", expr, p->n_instr);
+  }
+  r.destroy(&prog);
+  return fn;
+}
+
+}  // namespace
+
+static int g_enabled = -1;
+static long long g_min_elems = -1;
+
+int sp_jit_enabled() {
+  if (g_enabled < 0) g_enabled = getenv("SP_NO_JIT") == nullptr ? 1 : 0;
+  return g_enabled && rtc().ok;
+}
+
+int64_t sp_jit_min_elems() {
+  if (g_min_elems < 0) {
+    const char* e = getenv("SP_JIT_MIN_ELEMS");
+    g_min_elems = e ? atoll(e) : (1LL << 22);
+  }
+  return g_min_elems;
+}
+
+extern "C" int sp_jit_configure(int enabled, long long min_elems) {
+  if (enabled >= 0) g_enabled = enabled ? 1 : 0;
+  if (min_elems >= 0) g_min_elems = min_elems;
+  return sp_jit_enabled();
+}
+
+void* sp_jit_get(const char* header, const char* template_expr, const sp_program* p) {
+  if (!sp_jit_enabled()) return nullptr;
+  const std::string key = program_key(header, template_expr, p);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_cache.find(key);
+  if (it != g_cache.end()) return (void*)it->second;
+  hipFunction_t fn = compile(header, template_expr, p);
+  g_cache.emplace(key, fn);
+  return (void*)fn;
+}
+
+int sp_jit_launch(void* fn, dim3 grid, dim3 block, void** args, hipStream_t st) {
+  SP_HIP(hipModuleLaunchKernel((hipFunction_t)fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, st, args,
+                               nullptr));
+  return 0;
+}
+
+// Test / diagnostics hook: does `template_expr` compile for `p` (no device needed)?
+// Returns 1 when hipRTC produced a code object, 0 otherwise.
+extern "C" int sp_jit_compile_check(const char* header, const char* template_expr, const sp_program* p) {
+  int ok = 0;
+  compile(header, template_expr, p, false, &ok);
+  return ok;
+}
+
+// Test / diagnostics hook: number of run-time specialised kernels compiled so far.
+extern "C" int sp_jit_compiled_count(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  int n = 0;
+  for (auto& kv : g_cache)
+    if (kv.second) ++n;
+  return n;
+}

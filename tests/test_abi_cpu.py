@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: libspartan_hip.so loads without a GPU,
+exports every entry point include/spartan_hip.h declares, the ctypes structs match
+the header's layout, and the product path refuses to run without a device (there is
+no CPU fallback).  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from spartan_amd import _hip
+from spartan_amd.program import Program, dense_strides
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'spartan_hip.h')
+
+
+def _declared_functions():
+  text = open(HEADER).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return sorted(set(re.findall(r'\b(sp_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+  names = _declared_functions()
+  assert len(names) >= 20, names
+  raw = C.CDLL(_hip.LIB_PATH)
+  missing = [n for n in names if not hasattr(raw, n)]
+  assert not missing, 'declared in include/spartan_hip.h but not exported: %s' % missing
+  # and the Python binding declares the same set
+  assert sorted(_hip.EXPORTS) == names
+  assert _hip.lib().sp_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+  assert C.sizeof(_hip.sp_instr) == 8
+  # cls,n_inputs,n_instr,result_reg,ndim,out_dtype,linear,pad (8 x i32) + shape[4] i64
+  # + in_stride[8][4] i64 + in_dtype[8] i32 + consts[16] f64 + iconsts[16] i64 + instr[64]
+  want = 8 * 4 + 4 * 8 + 8 * 4 * 8 + 8 * 4 + 16 * 8 + 16 * 8 + 64 * 8
+  assert C.sizeof(_hip.sp_program) == want
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+  torch = pytest.importorskip('torch')
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  from spartan_amd import kernels
+  p = Program()
+  p.add_input(np.float32, dense_strides((4,)))
+  prog = p.finish(_hip.SP_F32, (4,), np.float32, True)
+  x = torch.zeros(4)
+  with pytest.raises(Exception):
+    kernels.map_fused(prog, [x], torch.empty(4))
+
+
+def _chain_program(cls, dt):
+  shape = (1024, 1024)
+  p = Program()
+  p.add_input(dt, dense_strides(shape))
+  p.add_input(dt, dense_strides(shape))
+  p.emit('MUL', 2, 0, 1)
+  p.emit('ADD', 2, 2, 0)
+  p.emit('NEG', 2, 2)
+  p.result_reg = 2
+  return p.finish(cls, shape, dt, True)
+
+
+@pytest.mark.parametrize('cls,dt,t,v', [(_hip.SP_F32, np.float32, 'float', 4), (_hip.SP_F64, np.float64, 'double', 2),
+                                        (_hip.SP_I64, np.int64, 'int64_t', 2)])
+def test_runtime_specialisation_source_compiles(cls, dt, t, v):
+  """The evaluator headers compile under hipRTC with a generated StaticProg (the
+  run-time specialised tier, sp_jit.hip) -- cross-compiled here, no device needed."""
+  lib = _hip.lib()
+  if lib.sp_jit_configure(-1, -1) != 1:
+    pytest.skip('libhiprtc not loadable')
+  prog = _chain_program(cls, dt)
+  exprs = [
+      ('map_kernel.hpp', 'sp_map_kernel<%s, %d, 1, true, StaticProg<1000>, -1>' % (t, v)),
+      ('map_kernel.hpp', 'sp_map_kernel<%s, %d, 1, false, StaticProg<1000>, 2>' % (t, v)),
+      ('reduce_impl.hpp', 'sp_reduce_rows_kernel<%s, %d, true, PlainAcc, StaticProg<1000>, 0, -1>' % (t, v)),
+      ('reduce_impl.hpp', 'sp_reduce_cols_kernel<%s, %d, false, ArgAcc, StaticProg<1000>, -1, -1>' % (t, v)),
+  ]
+  for header, expr in exprs:
+    assert lib.sp_jit_compile_check(header.encode(), expr.encode(), C.byref(prog)) == 1, expr

@@ -451,3 +451,96 @@ def test_transposing_slice_copy(shape):
     out = torch.empty((shape[1], shape[0]), dtype=da.dtype, device=DEV)
     kernels.slice_copy(out, 0, out.stride(), da, 0, v.stride(), v.shape)
     np.testing.assert_array_equal(host(out), a.T)
+
+
+# ---- run-time specialised tier (sp_jit.hip) --------------------------------------
+def _both_tiers(fn):
+  """fn() evaluated on the interpreter kernels and on run-time specialised ones."""
+  lib = _hip.lib()
+  try:
+    assert lib.sp_jit_configure(0, -1) == 0
+    want = fn()
+    if lib.sp_jit_configure(1, 0) != 1:
+      pytest.skip('libhiprtc not loadable on this box')
+    got = fn()
+    # (the stream may already be cached from another shape: the cache key is the program, not the tile)
+    assert lib.sp_jit_compiled_count() > 0, 'program was not specialised at run time'
+    got2 = fn()   # second call: served from the cache
+  finally:
+    lib.sp_jit_configure(1, 1 << 22)
+  return want, got, got2
+
+
+def _chain(ops):
+  def body(p):
+    c = p.add_const(1.25)
+    p.emit('CONST', 3, c)
+    p.emit(ops[0], 2, 0, 1)
+    for op in ops[1:]:
+      p.emit(op, 2, 2, 3 if op in ('ADD', 'MUL') else 1)
+    return 2
+  return body
+
+
+@pytest.mark.parametrize('cls,dt,ops', [
+    (_hip.SP_F32, np.float32, ['MUL', 'ADD', 'SUB', 'MUL', 'MAX']),
+    (_hip.SP_F64, np.float64, ['ADD', 'MUL', 'DIV', 'SUB']),
+    (_hip.SP_I64, np.int64, ['ADD', 'MUL', 'SUB', 'MIN']),
+])
+@pytest.mark.parametrize('shape,bshape', [((257, 1024), (257, 1024)), ((256, 512), (256, 1)), ((256, 512), (1, 512)),
+                                          ((31, 7, 12), (31, 1, 12)), ((1003,), (1003,))])
+def test_jit_map_bit_identical(cls, dt, ops, shape, bshape):
+  a = (RNG.rand(*shape) * 8 + 1).astype(dt)
+  b = (RNG.rand(*bshape) * 8 + 1).astype(dt)
+  body = _chain(ops)
+  want, got, got2 = _both_tiers(lambda: run_map(cls, shape, [a, b], body, dt))
+  np.testing.assert_array_equal(got, want)
+  np.testing.assert_array_equal(got2, want)
+
+
+@pytest.mark.parametrize('cls,dt', [(_hip.SP_F32, np.float32), (_hip.SP_F64, np.float64), (_hip.SP_I64, np.int64)])
+@pytest.mark.parametrize('shape,bshape', [((512, 1024), (512, 1024)), ((512, 1024), (512, 1)), ((8, 65536), (1, 65536)),
+                                          ((70000, 8), (70000, 1))])
+@pytest.mark.parametrize('op', ['SUM', 'MAX', 'PROD'])
+def test_jit_reduce_bit_identical(cls, dt, shape, bshape, op):
+  a = (RNG.rand(*shape) + 0.5).astype(dt) if op != 'PROD' else np.ones(shape, dt)
+  b = (RNG.rand(*bshape) * 3 + 1).astype(dt)
+
+  def body(p):
+    p.emit('MUL', 2, 0, 1)
+    p.emit('ADD', 2, 2, 0)
+    p.emit('SUB', 2, 2, 1)
+    return 2
+  for axis in (0, 1, None):
+    want, got, got2 = _both_tiers(lambda: run_reduce(a, axis, op, cls, dt, body, extra=[b]))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got2, want)
+
+
+def test_jit_argreduce_bit_identical():
+  x = RNG.rand(300, 4096).astype(np.float32)
+  x[7, 100] = np.nan
+  y = RNG.rand(300, 4096).astype(np.float32)
+
+  def run(axis):
+    O, A, I = (1, x.size, 1) if axis is None else ((1, 300, 4096) if axis == 0 else (300, 4096, 1))
+    p = Program()
+    p.add_input(np.float32, dense_strides((O, A, I)))
+    p.add_input(np.float32, dense_strides((O, A, I)))
+    p.emit('SUB', 2, 0, 1)
+    p.emit('ABS', 2, 2)
+    p.result_reg = 2
+    prog = p.finish(_hip.SP_F32, (O, A, I), None, True)
+    oi = torch.empty(O * I, dtype=torch.int64, device=DEV)
+    ov = torch.empty(O * I, dtype=torch.float32, device=DEV)
+    kernels.argreduce(prog, [dev(x), dev(y)], 0, O, A, I, 0, -7, oi, ov)
+    torch.cuda.synchronize()
+    return np.stack([host(oi).astype(np.float64), host(ov).astype(np.float64)])
+  for axis in (0, 1, None):
+    want, got, got2 = _both_tiers(lambda: run(axis))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got2, want)
+  idx = run(1)[0].astype(np.int64)
+  keep = np.arange(300) != 7
+  np.testing.assert_array_equal(idx[keep], np.argmax(np.abs(x - y)[keep], axis=1))
+  assert idx[7] == -7
