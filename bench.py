@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import spartan_amd as sp  # noqa: E402
-from spartan_amd import kernels  # noqa: E402
+from spartan_amd import _hip, kernels  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
@@ -66,6 +66,10 @@ def time_steps(ctx, step, steps, warmup):
 def event_time(fn, iters, warmup=4):
   for _ in range(warmup):
     fn()
+  # programs outside the prebuilt kernel library are specialised at run time on a
+  # background thread (include/spartan_hip.h sp_jit_*): let the warm-up's requests land
+  _hip.lib().sp_jit_wait()
+  fn()
   torch.cuda.synchronize()
   e0, e1 = kernels.Event(), kernels.Event()
   e0.record()
@@ -93,6 +97,11 @@ def hbm_section(ctx):
   out['map_xx_plus_x_GBps'] = round(8.0 * n / ms / 1e6, 1)          # 4*(n_in+1)*E bytes
   ms = event_time(lambda: (Xv + 1).force(), 10)
   out['map_x_plus_1_GBps'] = round(8.0 * n / ms / 1e6, 1)
+  # fused trees outside the prebuilt library: run-time specialised kernels (csrc/sp_jit.hip)
+  ms = event_time(lambda: (((Xv * Xv + Xv) * 0.5 - Xv) / (Xv + 2.0)).optimized().force(), 10)
+  out['map_5op_chain_jit_GBps'] = round(8.0 * n / ms / 1e6, 1)
+  ms = event_time(lambda: sp.sum((Xv - 0.5) * (Xv - 0.5), axis=0).optimized().force(), 10)
+  out['sum_sq_dev_axis0_jit_GBps'] = round(4.0 * n / ms / 1e6, 1)
   for axis in (None, 0, 1):
     ms = event_time(lambda: sp.sum(Xv, axis).force(), 10)
     out['sum_axis%s_GBps' % axis] = round(4.0 * n / ms / 1e6, 1)    # 4*E bytes

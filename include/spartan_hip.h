@@ -187,15 +187,20 @@ int sp_program_static_id(const sp_program* prog, int32_t out_dtype);
  * tile (>= min_elems elements, default 2^22), is compiled once per instruction
  * stream with hipRTC from the same evaluator source (spartan_amd/csrc/sp_jit.hip;
  * the reference's precedent is its JIT local op, local.py:187-209) and cached for
- * the life of the process; smaller tiles and any compile failure use the
- * interpreter kernels.  Results are bit-identical across the three tiers.
+ * the life of the process.  The compile (~0.4 s) runs on a background thread: the
+ * launch that requests it, and every launch until it is ready, uses the interpreter
+ * kernels, as do smaller tiles and programs whose compile fails.  Results are
+ * bit-identical across the three tiers, so the switch is not observable.
+ * SP_JIT_SYNC=1 in the environment compiles in the calling thread instead.
  *   sp_jit_configure      enabled: 0/1, or -1 to leave; min_elems: threshold, or -1 to leave
  *                         (defaults: SP_NO_JIT / SP_JIT_MIN_ELEMS in the environment).
  *                         Returns 1 if the tier is usable (libhiprtc present and enabled).
+ *   sp_jit_wait           block until every queued specialisation is ready.
  *   sp_jit_compiled_count kernels specialised so far.
  *   sp_jit_compile_check  does `template_expr` (a kernel template-id naming the program
  *                         type StaticProg<1000>) compile for `prog`?  Needs no device. */
 int sp_jit_configure(int enabled, long long min_elems);
+void sp_jit_wait(void);
 int sp_jit_compiled_count(void);
 int sp_jit_compile_check(const char* header, const char* template_expr, const sp_program* prog);
 

@@ -88,6 +88,8 @@ def _declare(lib):
   lib.sp_program_static_id.argtypes = [C.POINTER(sp_program), i32]
   lib.sp_jit_configure.argtypes = [C.c_int, C.c_longlong]
   lib.sp_jit_compiled_count.argtypes = []
+  lib.sp_jit_wait.argtypes = []
+  lib.sp_jit_wait.restype = None
   lib.sp_jit_compile_check.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(sp_program)]
   lib.sp_reduce_workspace_bytes.argtypes = [i32, i64, i64, i64]
   lib.sp_reduce_workspace_bytes.restype = sz
@@ -110,7 +112,7 @@ def _declare(lib):
 # every symbol include/spartan_hip.h declares
 EXPORTS = [
     'sp_abi_version', 'sp_last_error', 'sp_device_count', 'sp_device_info', 'sp_map_fused',
-    'sp_program_static_id', 'sp_jit_configure', 'sp_jit_compiled_count', 'sp_jit_compile_check',
+    'sp_program_static_id', 'sp_jit_configure', 'sp_jit_wait', 'sp_jit_compiled_count', 'sp_jit_compile_check',
     'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
     'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',

@@ -17,8 +17,11 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -119,7 +122,23 @@ std::string program_key(const char* header, const char* expr, const sp_program* 
 }
 
 std::mutex g_mu;
-std::unordered_map<std::string, hipFunction_t> g_cache;   // value NULL = tried and failed
+std::unordered_map<std::string, hipFunction_t> g_cache;   // value NULL = pending, or tried and failed
+
+// Compiles run on ONE background thread: a launch that finds its program not yet
+// specialised enqueues the job and carries on with the interpreter kernel, so the
+// ~0.4 s hipRTC compile is never on the launch path; later launches of the same
+// program pick the specialised kernel up once it is ready.  (Tiers are bit-identical,
+// so the switch is invisible in the results.)  SP_JIT_SYNC=1 compiles in the caller.
+struct Job {
+  std::string key, header, expr;
+  sp_program prog;
+  int device;
+};
+std::deque<Job> g_jobs;
+std::condition_variable g_cv, g_idle_cv;
+std::thread g_worker;
+bool g_worker_started = false, g_stop = false;
+int g_inflight = 0;
 
 hipFunction_t compile(const char* header, const char* expr, const sp_program* p, bool load = true, int* compiled = nullptr) {
   Rtc& r = rtc();
@@ -186,15 +205,73 @@ extern "C" int sp_jit_configure(int enabled, long long min_elems) {
   return sp_jit_enabled();
 }
 
+static void worker_main() {
+  for (;;) {
+    Job job;
+    {
+      std::unique_lock<std::mutex> lock(g_mu);
+      g_cv.wait(lock, [] { return g_stop || !g_jobs.empty(); });
+      if (g_stop) return;
+      job = std::move(g_jobs.front());
+      g_jobs.pop_front();
+    }
+    hipFunction_t fn = nullptr;
+    if (hipSetDevice(job.device) == hipSuccess) fn = compile(job.header.c_str(), job.expr.c_str(), &job.prog);
+    {
+      std::lock_guard<std::mutex> lock(g_mu);
+      if (!g_stop) g_cache[job.key] = fn;
+      --g_inflight;
+    }
+    g_idle_cv.notify_all();
+  }
+}
+
+static void stop_worker() {
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_stop = true;
+  }
+  g_cv.notify_all();
+  if (g_worker.joinable()) g_worker.join();
+}
+
+static int sync_mode() {
+  static int v = -1;
+  if (v < 0) v = getenv("SP_JIT_SYNC") ? 1 : 0;
+  return v;
+}
+
 void* sp_jit_get(const char* header, const char* template_expr, const sp_program* p) {
   if (!sp_jit_enabled()) return nullptr;
-  const std::string key = program_key(header, template_expr, p);
-  std::lock_guard<std::mutex> lock(g_mu);
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return nullptr;
+  const std::string key = std::to_string(device) + "|" + program_key(header, template_expr, p);
+  std::unique_lock<std::mutex> lock(g_mu);
   auto it = g_cache.find(key);
   if (it != g_cache.end()) return (void*)it->second;
-  hipFunction_t fn = compile(header, template_expr, p);
-  g_cache.emplace(key, fn);
-  return (void*)fn;
+  if (sync_mode()) {
+    hipFunction_t fn = compile(header, template_expr, p);
+    g_cache.emplace(key, fn);
+    return (void*)fn;
+  }
+  if (g_stop) return nullptr;
+  g_cache.emplace(key, nullptr);   // pending: callers use the interpreter meanwhile
+  g_jobs.push_back(Job{key, header, template_expr, *p, device});
+  ++g_inflight;
+  if (!g_worker_started) {
+    g_worker_started = true;
+    g_worker = std::thread(worker_main);
+    atexit(stop_worker);   // registered after the HIP runtime came up => runs before its teardown
+  }
+  lock.unlock();
+  g_cv.notify_one();
+  return nullptr;
+}
+
+// Block until every queued specialisation has been compiled (tests, benchmarks).
+extern "C" void sp_jit_wait(void) {
+  std::unique_lock<std::mutex> lock(g_mu);
+  g_idle_cv.wait(lock, [] { return g_inflight == 0 || g_stop; });
 }
 
 int sp_jit_launch(void* fn, dim3 grid, dim3 block, void** args, hipStream_t st) {

@@ -462,7 +462,9 @@ def _both_tiers(fn):
     want = fn()
     if lib.sp_jit_configure(1, 0) != 1:
       pytest.skip('libhiprtc not loadable on this box')
-    got = fn()
+    fn()             # requests the specialisation (compiled on the background thread) ...
+    lib.sp_jit_wait()
+    got = fn()       # ... which this launch uses
     # (the stream may already be cached from another shape: the cache key is the program, not the tile)
     assert lib.sp_jit_compiled_count() > 0, 'program was not specialised at run time'
     got2 = fn()   # second call: served from the cache

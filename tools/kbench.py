@@ -17,6 +17,8 @@ DEV = 'cuda:0'
 def timeit(fn, iters=10, warmup=3):
   for _ in range(warmup):
     fn()
+  _hip.lib().sp_jit_wait()   # run-time specialised kernels requested by the warm-up are ready
+  fn()
   torch.cuda.synchronize()
   e0, e1 = kernels.Event(), kernels.Event()
   e0.record()
