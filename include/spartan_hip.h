@@ -270,6 +270,47 @@ int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, fl
  * a broadcast stride on the vector operand (row kernels for A.x, column
  * kernels for A^T.x). */
 
+/* k-means tile kernels: the bodies of the reference's k-means mappers
+ * (spartan/examples/sklearn/cluster/k_means_.py), BASELINE configs[3].
+ *
+ * sp_nearest_center: d_labels[i] = np.argmin(cdist(points, centers), axis=1)[i]
+ * (kmeans_map2_dist_mapper :61-66, kmeans_outer_dist_mapper :52-58; also
+ * _find_closest :11-28).  points [n, d] (SP_F32 | SP_F64, row stride ldx
+ * elements), centers [k, d] (SP_F32 | SP_F64, row stride ldc).  tier:
+ *   SP_NEAREST_EXACT (1): squared differences accumulated in fp64 in feature
+ *     order, sqrt, first minimum -- cdist's arithmetic, bit for bit;
+ *   SP_NEAREST_FUSED (2): fp32 MFMA GEMM with the argmin fused into the epilogue
+ *     (the n x k distance matrix is never written) + the exact kernel for the
+ *     points whose two best scores are within the fp32 error bound: SAME labels;
+ *   SP_NEAREST_AUTO (0): fused for fp32 points when n*k*d >= 2^24, else exact.
+ *   SP_NEAREST_FUSED_UNCHECKED (3): diagnostics only -- the fused kernel alone; points it
+ *     could not decide are left as -1 - (fp32 best) (used to report the re-check rate).
+ * d_ws: sp_nearest_center_workspace_bytes(n, k, d) bytes of scratch.
+ *
+ * sp_bincount_i64: np.bincount(labels, minlength=k)[:k] (kmeans_count_mapper :69-72);
+ * labels outside [0, k) are ignored.  k <= 16384.
+ *
+ * sp_segment_sum: d_out[c, :] = points[labels == c].sum(axis=0) (kmeans_center_mapper
+ * :75-97, _find_cluster_mapper :35-42).  After a stable counting sort of the row
+ * ids by label, the rows of a label are added per feature column in ascending row
+ * order in chunks of 512 rows, and the chunk sums are added in order: deterministic,
+ * no floating-point atomics, and for a label with <= 512 rows exactly NumPy's axis-0
+ * order (bit-identical); larger labels differ from it by rounding only.
+ * d_out [k, d] of the points' dtype; k <= 16384.
+ */
+#define SP_NEAREST_AUTO 0
+#define SP_NEAREST_EXACT 1
+#define SP_NEAREST_FUSED 2
+#define SP_NEAREST_FUSED_UNCHECKED 3
+size_t sp_nearest_center_workspace_bytes(int64_t n, int64_t k, int64_t d);
+int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ldx, const void* d_centers,
+                      int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d, int64_t* d_labels,
+                      int32_t tier, void* d_ws, size_t ws_bytes, void* stream);
+int sp_bincount_i64(const int64_t* d_labels, int64_t n, int64_t k, int64_t* d_counts, void* stream);
+size_t sp_segment_sum_workspace_bytes(int64_t n, int64_t k, int64_t d);
+int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, const int64_t* d_labels, int64_t n,
+                   int64_t k, int64_t d, void* d_out, void* d_ws, size_t ws_bytes, void* stream);
+
 /* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
  * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
 int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);

@@ -180,5 +180,26 @@ class NumpyBackend(object):
     self.launches += 1
     return self._wrap(_np(a).dot(_np(b)))
 
+  # -- k-means tile bodies: the reference's own NumPy/SciPy statements
+  def nearest_center(self, points, centers, tier=0):
+    """k_means_.py:61-66: np.argmin(cdist(points, centers), axis=1)."""
+    from scipy.spatial.distance import cdist
+    self.launches += 1
+    return self._wrap(np.argmin(cdist(_np(points), _np(centers)), axis=1).astype(np.int64))
+
+  def bincount(self, labels, k):
+    """k_means_.py:69-72."""
+    self.launches += 1
+    return self._wrap(np.bincount(_np(labels).reshape(-1).astype(np.int64), minlength=int(k))[:int(k)].astype(np.int64))
+
+  def segment_sum(self, points, labels, k):
+    """k_means_.py:91-95: per-cluster masked row sums (NumPy axis-0 order)."""
+    self.launches += 1
+    pts, lab = _np(points), _np(labels).reshape(-1)
+    out = np.zeros((int(k), pts.shape[1]), pts.dtype)
+    for i in range(int(k)):
+      out[i] = pts[lab == i].sum(axis=0)
+    return self._wrap(out)
+
   def synchronize(self):
     pass

@@ -48,6 +48,19 @@ distarray.DistArray.evaluate = evaluate
 distarray.DistArray.force = evaluate
 
 
+def _export_expr_namespace():
+  """`from spartan import expr; expr.rand(...)`: the reference's spartan.expr is a flat
+  namespace of builders (spartan/expr/__init__.py:26-93); re-export ours on the package."""
+  import types
+  from . import expr as _expr
+  for name, value in list(globals().items()):
+    if not name.startswith('_') and not isinstance(value, types.ModuleType):
+      setattr(_expr, name, value)
+
+
+_export_expr_namespace()
+
+
 def initialize(backend='hip', num_workers=None, world=None):
   """Create the process-wide worker context (reference spartan.initialize,
   spartan/__init__.py:42-56: start_cluster + blob_ctx).

@@ -27,6 +27,7 @@ OP = dict(
 RED = dict(SUM=0, PROD=1, MAX=2, MIN=3, AND=4, OR=5)
 REDUCER = dict(NONE=0, ADD=1, MUL=2, MAX=3, MIN=4, AND=5, OR=6)
 MASK_ALL_CLEAR, MASK_ALL_SET, MASK_ARRAY = 0, 1, 2
+NEAREST_AUTO, NEAREST_EXACT, NEAREST_FUSED, NEAREST_FUSED_UNCHECKED = 0, 1, 2, 3
 
 _NP2SP = {
     np.dtype(np.float32): SP_F32, np.dtype(np.float64): SP_F64, np.dtype(np.int32): SP_I32,
@@ -100,6 +101,13 @@ def _declare(lib):
   lib.sp_update.argtypes = [vp, i32, p64, i32, p64, p64, vp, i32, i32, i32, vp, vp]
   lib.sp_slice_copy.argtypes = [vp, p64, vp, p64, p64, i32, i32, vp]
   lib.sp_gemm_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]
+  lib.sp_nearest_center_workspace_bytes.argtypes = [i64, i64, i64]
+  lib.sp_nearest_center_workspace_bytes.restype = sz
+  lib.sp_nearest_center.argtypes = [vp, i32, i64, vp, i32, i64, i64, i64, i64, vp, i32, vp, sz, vp]
+  lib.sp_bincount_i64.argtypes = [vp, i64, i64, vp, vp]
+  lib.sp_segment_sum_workspace_bytes.argtypes = [i64, i64, i64]
+  lib.sp_segment_sum_workspace_bytes.restype = sz
+  lib.sp_segment_sum.argtypes = [vp, i32, i64, vp, i64, i64, i64, vp, vp, sz, vp]
   lib.sp_stream_copy.argtypes = [vp, vp, sz, vp]
   lib.sp_event_create.argtypes = [pp]
   lib.sp_event_destroy.argtypes = [vp]
@@ -114,7 +122,8 @@ EXPORTS = [
     'sp_abi_version', 'sp_last_error', 'sp_device_count', 'sp_device_info', 'sp_map_fused',
     'sp_program_static_id', 'sp_jit_configure', 'sp_jit_wait', 'sp_jit_compiled_count', 'sp_jit_compile_check',
     'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
-    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_stream_copy', 'sp_event_create',
+    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
+    'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',
 ]
 

@@ -6,6 +6,8 @@ reference, spartan/expr/operator/local.py:187-209) on top of the C-ABI
 Constructing it without a GPU or without the built library raises: there is no
 CPU fallback in the product path.
 """
+import collections
+
 import numpy as np
 import torch
 
@@ -29,7 +31,7 @@ class HipBackend(object):
       raise _hip.HipError('the HIP tile backend needs an AMD GPU (torch.cuda.is_available() is False); '
                           'there is no CPU fallback')
     self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-    self._np_cache = {}
+    self._np_cache = collections.OrderedDict()   # bounded: iterative drivers pass a new array every step
     self.launches = 0
     self.gemm_events = None   # set to [] to record (start, stop) HIP events around every GEMM launch
 
@@ -86,6 +88,10 @@ class HipBackend(object):
     if hit is None or hit[0] is not arr:
       hit = (arr, self.from_numpy(arr[slices]))
       self._np_cache[key] = hit
+      while len(self._np_cache) > 64:
+        self._np_cache.popitem(last=False)
+    else:
+      self._np_cache.move_to_end(key)
     return hit[1]
 
   def reducer_name(self, fn):
@@ -314,6 +320,47 @@ class HipBackend(object):
       prod = lower.apply('MUL', np.multiply, [va, vb])
       return self._run_reduce(prod, 'SUM', res_dt, (M, K, N), 1)
     raise lower.NotLowerable('dot of %d-d and %d-d operands' % (a.dim(), b.dim()))
+
+  # -- k-means tile bodies (examples/sklearn/cluster/k_means_.py) ---------------------
+  def _as_device(self, t):
+    if isinstance(t, np.ndarray):
+      return self.cached_numpy(t, (slice(None),) * t.ndim)
+    return t
+
+  def _rows(self, t):
+    """2-D view with inner stride 1 (a box copy if the tile is a strided view)."""
+    if t.dim() != 2:
+      raise lower.NotLowerable('expected a 2-D tile, got %d-d' % t.dim())
+    if t.shape[1] > 1 and t.stride(1) != 1:
+      t = self.copy(t)
+    if self.dtype_of(t) not in (np.float32, np.float64):
+      t = self.astype(t, np.float64)
+    return t
+
+  def _labels_i64(self, labels, n):
+    labels = self.astype(labels, np.int64) if self.dtype_of(labels) != np.int64 else labels
+    return self.contiguous(labels).reshape(n)
+
+  def nearest_center(self, points, centers, tier=_hip.NEAREST_AUTO):
+    """np.argmin(cdist(points, centers), axis=1) -> int64 (n,)  (k_means_.py:61-66)."""
+    points, centers = self._rows(self._as_device(points)), self._rows(self._as_device(centers))
+    out = self.empty((points.shape[0],), np.int64)
+    self.launches += 1
+    return kernels.nearest_center(points, centers, out, tier)
+
+  def bincount(self, labels, k):
+    """np.bincount(labels.astype(int), minlength=k) -> int64 (k,)  (k_means_.py:69-72)."""
+    labels = self._labels_i64(labels, int(np.prod(labels.shape)))
+    self.launches += 1
+    return kernels.bincount(labels, int(k), self.empty((int(k),), np.int64))
+
+  def segment_sum(self, points, labels, k):
+    """out[c] = points[labels == c].sum(axis=0), in the points' dtype (k_means_.py:75-97)."""
+    points = self._rows(points)
+    labels = self._labels_i64(labels, points.shape[0])
+    out = self.empty((int(k), points.shape[1]), self.dtype_of(points))
+    self.launches += 1
+    return kernels.segment_sum(points, labels, int(k), out)
 
   def synchronize(self):
     torch.cuda.synchronize(self.device)

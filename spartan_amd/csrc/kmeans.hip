@@ -1,0 +1,568 @@
+// k-means tile kernels: the per-tile bodies of the reference's k-means mappers
+// (spartan/examples/sklearn/cluster/k_means_.py):
+//   kmeans_map2_dist_mapper / kmeans_outer_dist_mapper (:52-66)
+//        labels = np.argmin(cdist(points, centers), axis=1)      -> sp_nearest_center
+//   kmeans_count_mapper (:69-72)   np.bincount(labels, minlength=k) -> sp_bincount_i64
+//   kmeans_center_mapper (:75-97)  new_centers[i] = points[labels == i].sum(axis=0)
+//        (also _find_cluster_mapper :35-42)                       -> sp_segment_sum
+//
+// sp_nearest_center has two tiers (same results, see kmeans_mfma.hpp):
+//   exact : one wavefront per point, squared distances accumulated in fp64 in
+//           feature order exactly like cdist's C loop, sqrt, first-minimum;
+//   fused : fp32 MFMA GEMM  x.c^T  with the argmin fused into the epilogue (the
+//           n x k distance matrix is never written); points whose two best
+//           scores are closer than the fp32 error bound are re-done by the exact
+//           kernel, so the labels are those of the exact tier.
+// sp_segment_sum adds the rows of each cluster sequentially in ascending row
+// order (one lane per feature column), which is the order NumPy's axis-0 sum
+// uses, after a stable counting sort of the row ids by label -- deterministic,
+// no floating-point atomics.
+#include "sp_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ exact tier
+// Ct64[j][c] = (double)C[c][j], zero padded to [d][kp]: lanes (= centers) read it coalesced
+template <typename TC>
+__global__ __launch_bounds__(256) void sp_centers_t64_kernel(const TC* __restrict__ C, int64_t ldc, int k, int d,
+                                                             int kp, double* __restrict__ Ct64) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [d][kp]
+  if (i >= (int64_t)d * kp) return;
+  const int j = (int)(i / kp), c = (int)(i - (int64_t)j * kp);
+  Ct64[i] = c < k ? (double)C[(int64_t)c * ldc + j] : 0.0;
+}
+
+// One wavefront per R points.  Lane l owns centers l, l+64, ... (G at a time); each squared
+// distance is accumulated over the features sequentially in fp64 and sqrt'ed -- cdist
+// 'euclidean' on doubles, bit for bit -- then the wave takes the lexicographic
+// (distance, index) minimum = np.argmin's first minimum.  Every center value loaded from
+// the (L2-resident) Ct64 is used for the R points of the wave: the kernel is bound by
+// L2 -> CU traffic otherwise.
+// rows == NULL: every point 0..n-1; else the *n_rows points listed in rows[] (the ones the
+// fused kernel could not decide).
+template <typename TX>
+__global__ __launch_bounds__(256) void sp_nearest_exact_kernel(const TX* __restrict__ X, int64_t ldx,
+                                                               const double* __restrict__ Ct64, int kp, int64_t n,
+                                                               int k, int d, int64_t* __restrict__ labels,
+                                                               const int* __restrict__ rows,
+                                                               const int* __restrict__ n_rows) {
+  constexpr int G = 2, R = 4, J = 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t count = rows ? (int64_t)*n_rows : n;
+  for (int64_t it = wave * R; it < count; it += nwaves * R) {
+    int64_t row[R];
+    const TX* __restrict__ xr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t e = it + r < count ? it + r : count - 1;   // tail: repeat the last point
+      row[r] = rows ? (int64_t)rows[e] : e;
+      xr[r] = X + row[r] * ldx;
+    }
+    double best[R];
+    int best_k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      best[r] = INFINITY;
+      best_k[r] = 0x7fffffff;
+    }
+    for (int c0 = 0; c0 < k; c0 += 64 * G) {
+      double s[R][G];
+      int col[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int c = c0 + g * 64 + lane;
+        col[g] = c < kp ? c : kp - 1;   // (columns k..kp-1 are zero padding; beyond kp: clamp, result unused)
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r][g] = 0.0;
+      }
+      int j = 0;
+      for (; j + J <= d; j += J) {
+        double xv[R][J], cv[J][G];
+#pragma unroll
+        for (int u = 0; u < J; ++u) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) cv[u][g] = Ct64[(int64_t)(j + u) * kp + col[g]];
+#pragma unroll
+          for (int r = 0; r < R; ++r) xv[r][u] = (double)xr[r][j + u];
+        }
+#pragma unroll
+        for (int u = 0; u < J; ++u)   // feature order preserved within every chain
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const double diff = xv[r][u] - cv[u][g];
+              s[r][g] += diff * diff;
+            }
+      }
+      for (; j < d; ++j) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const double cvv = Ct64[(int64_t)j * kp + col[g]];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const double diff = (double)xr[r][j] - cvv;
+            s[r][g] += diff * diff;
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {   // ascending center index: `<` keeps the first minimum
+        const int c = c0 + g * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double v = sqrt(s[r][g]);
+          if (c < k && v < best[r]) {
+            best[r] = v;
+            best_k[r] = c;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double b = best[r];
+      int bk = best_k[r];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(b, off);
+        const int ok = __shfl_xor(bk, off);
+        if (ob < b || (ob == b && ok < bk)) {
+          b = ob;
+          bk = ok;
+        }
+      }
+      if (lane == 0) labels[row[r]] = bk == 0x7fffffff ? 0 : bk;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ bincount
+__global__ __launch_bounds__(256) void sp_bincount_kernel(const int64_t* __restrict__ labels, int64_t n, int k,
+                                                          unsigned long long* __restrict__ counts) {
+  extern __shared__ int hist[];
+  for (int i = threadIdx.x; i < k; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t l = labels[i];
+    if (l >= 0 && l < k) atomicAdd(&hist[(int)l], 1);   // integer atomics: exact, order-free
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += blockDim.x)
+    if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
+// ------------------------------------------------------------------ stable counting sort of row ids by label
+// hist[c * nblk + b] = number of rows of label c in row block b (row blocks of RB rows)
+__global__ __launch_bounds__(256) void sp_label_hist_kernel(const int64_t* __restrict__ labels, int64_t n, int k,
+                                                            int rb, int nblk, int* __restrict__ hist) {
+  extern __shared__ int lh[];
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < k; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  const int64_t r0 = (int64_t)b * rb;
+  const int64_t r1 = r0 + rb < n ? r0 + rb : n;
+  for (int64_t i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+    const int64_t l = labels[i];
+    if (l >= 0 && l < k) atomicAdd(&lh[(int)l], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += blockDim.x) hist[(int64_t)i * nblk + b] = lh[i];
+}
+
+// exclusive scan of `m` ints in place, three coalesced phases over chunks of 4096:
+//   1. chunk sums   2. one workgroup scans the (<= 4096 per pass) chunk sums   3. local scan + chunk offset
+constexpr int SCAN_CHUNK = 4096;
+
+__global__ __launch_bounds__(1024) void sp_scan_sums_kernel(const int* __restrict__ a, int64_t m,
+                                                            int* __restrict__ sums) {
+  __shared__ int red[16];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+  int s = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = base + u * 1024 + threadIdx.x;
+    if (i < m) s += a[i];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    sums[blockIdx.x] = t;
+  }
+}
+
+// block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, *total = sum
+__device__ __forceinline__ int sp_block_exscan_1024(int v, int* total) {
+  __shared__ int wsum[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int woff = 0, tot = 0;
+  for (int i = 0; i < 16; ++i) {
+    const int t = wsum[i];
+    if (i < w) woff += t;
+    tot += t;
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return woff + inc - v;
+}
+
+// in-place exclusive scan of the n_sums chunk sums by one workgroup (sequential passes of 1024)
+__global__ __launch_bounds__(1024) void sp_scan_top_kernel(int* __restrict__ sums, int n_sums,
+                                                           int* __restrict__ total_out) {
+  int carry = 0;
+  for (int base = 0; base < n_sums; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n_sums ? sums[i] : 0;
+    int tot;
+    const int ex = sp_block_exscan_1024(v, &tot);
+    if (i < n_sums) sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(1024) void sp_scan_apply_kernel(int* __restrict__ a, int64_t m,
+                                                             const int* __restrict__ sums) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * 4;
+  int v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] = base + u < m ? a[base + u] : 0;
+  const int mine = v[0] + v[1] + v[2] + v[3];
+  int run = sums[blockIdx.x] + sp_block_exscan_1024(mine, nullptr);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (base + u < m) a[base + u] = run;
+    run += v[u];
+  }
+}
+
+// perm[pos] = row, rows of one label contiguous and in ascending row order.
+// One wavefront per row block; LDS cursor per label starts at the scanned offset.  Within a
+// 64-row chunk a row's rank among the rows of its label is the number of LOWER lanes holding
+// the same label (64 readlane/compare steps, no divergence); the last lane of each label
+// advances the cursor (distinct addresses, no atomics).
+__global__ __launch_bounds__(64) void sp_label_rank_kernel(const int64_t* __restrict__ labels, int64_t n, int k,
+                                                           int rb, int nblk, const int* __restrict__ offs,
+                                                           int* __restrict__ perm, int* __restrict__ seg_start,
+                                                           const int* __restrict__ total) {
+  extern __shared__ int cur[];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < k; i += 64) {
+    cur[i] = offs[(int64_t)i * nblk + b];
+    if (b == 0) seg_start[i] = offs[(int64_t)i * nblk];
+  }
+  if (b == 0 && lane == 0) seg_start[k] = *total;
+  __syncthreads();
+  const int64_t r0 = (int64_t)b * rb;
+  const int64_t r1 = r0 + rb < n ? r0 + rb : n;
+  for (int64_t base = r0; base < r1; base += 64) {
+    const int64_t row = base + lane;
+    int lab = -1 - lane;                 // invalid rows: a value no other lane holds
+    bool valid = false;
+    if (row < r1) {
+      const int64_t l = labels[row];
+      if (l >= 0 && l < k) {
+        lab = (int)l;
+        valid = true;
+      }
+    }
+    int lower = 0, same = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const int lj = __builtin_amdgcn_readlane(lab, j);
+      const int eq = (lj == lab) ? 1 : 0;
+      same += eq;
+      lower += (j < lane) ? eq : 0;
+    }
+    int start = 0;
+    if (valid) start = cur[lab];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      perm[start + lower] = (int)row;
+      if (lower == same - 1) cur[lab] = start + same;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- balanced, deterministic segment sums --------------------------------------------------
+// The rows of a label are cut into chunks of SEG_CHUNK; chunk slots are numbered label-major.
+constexpr int SEG_CHUNK = 512;
+
+// slot_first[c] = first chunk slot of label c (exclusive scan of ceil(n_c / SEG_CHUNK)); one workgroup
+__global__ __launch_bounds__(1024) void sp_seg_slots_kernel(const int* __restrict__ seg_start, int k,
+                                                            int* __restrict__ slot_first) {
+  int carry = 0;
+  for (int base = 0; base < k; base += 1024) {
+    const int c = base + threadIdx.x;
+    const int v = c < k ? (seg_start[c + 1] - seg_start[c] + SEG_CHUNK - 1) / SEG_CHUNK : 0;
+    int tot;
+    const int ex = sp_block_exscan_1024(v, &tot);
+    if (c < k) slot_first[c] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) slot_first[k] = carry;
+}
+
+// One wavefront per (chunk slot, 64*V-column block): the <= SEG_CHUNK rows of the chunk are added
+// in ascending row order, one lane per V adjacent feature columns.  The row ids are fetched 64
+// at a time with one coalesced load and broadcast from registers, so the row loads (64*V*sizeof(T)
+// contiguous bytes each, U in flight) do not wait on an index load.  A label with at most
+// SEG_CHUNK rows is therefore summed in exactly NumPy's axis-0 order.
+template <typename T, int V>
+__global__ __launch_bounds__(64) void sp_segment_sum_kernel(const T* __restrict__ X, int64_t ldx,
+                                                            const int* __restrict__ perm,
+                                                            const int* __restrict__ seg_start,
+                                                            const int* __restrict__ slot_first, int k, int d,
+                                                            T* __restrict__ partial) {
+  constexpr int U = 8;
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const int slot = blockIdx.x;
+  if (slot >= slot_first[k]) return;
+  // label of this slot: last c with slot_first[c] <= slot (binary search; empty labels own no slot)
+  int lo = 0, hi = k - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (slot_first[mid] <= slot) lo = mid;
+    else hi = mid - 1;
+  }
+  const int c = lo;
+  const int lane = threadIdx.x;
+  const int col = (blockIdx.y * 64 + lane) * V;
+  const bool live = col < d;            // d % V == 0 (host-checked): a live lane owns V valid columns
+  const int s0 = seg_start[c] + (slot - slot_first[c]) * SEG_CHUNK;
+  const int s1 = s0 + SEG_CHUNK < seg_start[c + 1] ? s0 + SEG_CHUNK : seg_start[c + 1];
+  T acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = (T)0;
+  const T* __restrict__ Xc = X + (live ? col : 0);
+  for (int base = s0; base < s1; base += 64) {
+    const int cnt = s1 - base < 64 ? s1 - base : 64;
+    const int pidx = lane < cnt ? perm[base + lane] : 0;
+    int u0 = 0;
+    for (; u0 + U <= cnt; u0 += U) {
+      vec_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = __shfl(pidx, u0 + u);
+        if constexpr (V == 1) v[u][0] = Xc[(int64_t)row * ldx];
+        else v[u] = *(const vec_t*)(Xc + (int64_t)row * ldx);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += v[u][e];
+    }
+    for (; u0 < cnt; ++u0) {
+      const int row = __shfl(pidx, u0);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += Xc[(int64_t)row * ldx + e];
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) partial[(int64_t)slot * d + col + e] = acc[e];
+  }
+}
+
+// out[c][col] = partial[first slot of c][col] + partial[next][col] + ... in slot order (0 for an empty label)
+template <typename T>
+__global__ __launch_bounds__(256) void sp_segment_combine_kernel(const T* __restrict__ partial,
+                                                                 const int* __restrict__ slot_first, int k, int d,
+                                                                 T* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)k * d) return;
+  const int c = (int)(i / d), col = (int)(i - (int64_t)c * d);
+  const int f0 = slot_first[c], f1 = slot_first[c + 1];
+  T acc = (T)0;
+  if (f1 > f0) {
+    acc = partial[(int64_t)f0 * d + col];
+    for (int f = f0 + 1; f < f1; ++f) acc += partial[(int64_t)f * d + col];
+  }
+  out[i] = acc;
+}
+
+static int sort_block_rows(int64_t n, int64_t k) {
+  // row-block size: keep the k x nblk histogram (scanned by one workgroup) under ~4M entries
+  int64_t rb = 1024;
+  while (((n + rb - 1) / rb) * k > (4LL << 20)) rb *= 2;
+  return (int)rb;
+}
+
+}  // namespace
+
+#include "kmeans_mfma.hpp"
+
+extern "C" size_t sp_nearest_center_workspace_bytes(int64_t n, int64_t k, int64_t d) {
+  return sp_nearest_fused_ws_bytes(n, k, d);
+}
+
+extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ldx, const void* d_centers,
+                                 int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
+                                 int64_t* d_labels, int32_t tier, void* d_ws, size_t ws_bytes, void* stream) {
+  if (n < 0 || k < 1 || d < 0) SP_FAIL("sp_nearest_center: bad sizes n=%lld k=%lld d=%lld", (long long)n, (long long)k, (long long)d);
+  if (n == 0) return 0;
+  if (!d_points || !d_centers || !d_labels) SP_FAIL("sp_nearest_center: NULL pointer");
+  if ((dtype != SP_F32 && dtype != SP_F64) || (cdtype != SP_F32 && cdtype != SP_F64)) SP_FAIL("sp_nearest_center: points/centers must be f32 or f64");
+  if (k > 2147483647LL || d > 2147483647LL) SP_FAIL("sp_nearest_center: k or d too large");
+  if (ldx < d || ldc < d) SP_FAIL("sp_nearest_center: leading dimension too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t need = sp_nearest_fused_ws_bytes(n, k, d);
+  if (!d_ws || ws_bytes < need) SP_FAIL("sp_nearest_center: workspace too small (%zu < %zu)", ws_bytes, need);
+  KmWorkspace w = km_carve(d_ws, n, k, d);
+  // fp64 transposed centers for the exact kernel
+  {
+    const int64_t tot = d * w.kp;
+    const unsigned blocks = (unsigned)((tot + 255) / 256);
+    if (tot > 0) {
+      if (cdtype == SP_F32)
+        hipLaunchKernelGGL((sp_centers_t64_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)d_centers, ldc,
+                           (int)k, (int)d, (int)w.kp, w.Ct64);
+      else
+        hipLaunchKernelGGL((sp_centers_t64_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)d_centers,
+                           ldc, (int)k, (int)d, (int)w.kp, w.Ct64);
+      SP_CHECK_LAUNCH();
+    }
+  }
+  const int* rows = nullptr;
+  const int* n_rows = nullptr;
+  if (tier != SP_NEAREST_EXACT && dtype == SP_F32 && sp_nearest_fused_applicable(n, k, d, tier)) {
+    if (sp_nearest_fused_launch((const float*)d_points, ldx, d_centers, cdtype, ldc, n, k, d, d_labels, w, st)) return 1;
+    if (tier == SP_NEAREST_FUSED_UNCHECKED) return 0;   // diagnostics: leave the marks (-1 - best) in place
+    rows = w.amb_rows;       // the exact kernel re-does the points the fused kernel listed as undecided
+    n_rows = w.amb_count;
+  }
+  const int64_t groups = (n + 3) / 4;   // 4 points per wave
+  int64_t waves = rows ? (int64_t)SP_CUS * 16 : (groups < (int64_t)SP_CUS * 32 ? groups : (int64_t)SP_CUS * 32);
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  if (dtype == SP_F32)
+    hipLaunchKernelGGL((sp_nearest_exact_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)d_points, ldx,
+                       w.Ct64, (int)w.kp, n, (int)k, (int)d, d_labels, rows, n_rows);
+  else
+    hipLaunchKernelGGL((sp_nearest_exact_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)d_points, ldx,
+                       w.Ct64, (int)w.kp, n, (int)k, (int)d, d_labels, rows, n_rows);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sp_bincount_i64(const int64_t* d_labels, int64_t n, int64_t k, int64_t* d_counts, void* stream) {
+  if (n < 0 || k < 1) SP_FAIL("sp_bincount_i64: bad sizes");
+  if (k > 16384) SP_FAIL("sp_bincount_i64: k=%lld exceeds the LDS histogram (16384)", (long long)k);
+  if (!d_counts || (n && !d_labels)) SP_FAIL("sp_bincount_i64: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SP_HIP(hipMemsetAsync(d_counts, 0, (size_t)k * 8, st));
+  if (n == 0) return 0;
+  int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > SP_CUS * 4) blocks = SP_CUS * 4;
+  hipLaunchKernelGGL(sp_bincount_kernel, dim3((unsigned)blocks), dim3(256), (size_t)k * 4, st, d_labels, n, (int)k,
+                     (unsigned long long*)d_counts);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+static int64_t seg_max_slots(int64_t n, int64_t k) { return k + n / SEG_CHUNK; }
+
+static size_t seg_int_words(int64_t n, int64_t k) {
+  const int64_t rb = sort_block_rows(n, k);
+  const int64_t nblk = (n + rb - 1) / rb;
+  return (size_t)(k * nblk + n + (k + 1) + 1 + (k * nblk + SCAN_CHUNK - 1) / SCAN_CHUNK + (k + 1));
+}
+
+extern "C" size_t sp_segment_sum_workspace_bytes(int64_t n, int64_t k, int64_t d) {
+  if (n < 1 || k < 1) return 256;
+  return ((seg_int_words(n, k) * 4 + 255) & ~(size_t)255) + (size_t)seg_max_slots(n, k) * (size_t)(d < 1 ? 1 : d) * 8 + 512;
+}
+
+extern "C" int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, const int64_t* d_labels, int64_t n,
+                              int64_t k, int64_t d, void* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+  if (n < 0 || k < 1 || d < 0) SP_FAIL("sp_segment_sum: bad sizes");
+  if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_segment_sum: points must be f32 or f64");
+  if (k > 16384) SP_FAIL("sp_segment_sum: k=%lld exceeds the LDS cursor table (16384)", (long long)k);
+  if (n > 2147483647LL || d > 2147483647LL) SP_FAIL("sp_segment_sum: n or d too large");
+  if (!d_out || (n && (!d_points || !d_labels))) SP_FAIL("sp_segment_sum: NULL pointer");
+  if (ldx < d) SP_FAIL("sp_segment_sum: leading dimension too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = dtype == SP_F32 ? 4 : 8;
+  if (n == 0 || d == 0) {
+    SP_HIP(hipMemsetAsync(d_out, 0, (size_t)k * (size_t)d * esz, st));
+    return 0;
+  }
+  if (!d_ws || ws_bytes < sp_segment_sum_workspace_bytes(n, k, d)) SP_FAIL("sp_segment_sum: workspace too small");
+  const int rb = sort_block_rows(n, k);
+  const int nblk = (int)((n + rb - 1) / rb);
+  int* hist = (int*)d_ws;                    // [k][nblk]
+  int* perm = hist + (int64_t)k * nblk;      // [n]
+  int* seg = perm + n;                       // [k + 1]
+  int* total = seg + k + 1;                  // [1]
+  int* sums = total + 1;                     // [ceil(k * nblk / 4096)] scan chunk sums
+  int* slot_first = sums + ((int64_t)k * nblk + SCAN_CHUNK - 1) / SCAN_CHUNK;   // [k + 1]
+  void* partial = (char*)d_ws + ((seg_int_words(n, k) * 4 + 255) & ~(size_t)255);   // [max slots][d]
+  hipLaunchKernelGGL(sp_label_hist_kernel, dim3(nblk), dim3(256), (size_t)k * 4, st, d_labels, n, (int)k, rb, nblk, hist);
+  SP_CHECK_LAUNCH();
+  const int64_t m = (int64_t)k * nblk;
+  const int n_chunks = (int)((m + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  hipLaunchKernelGGL(sp_scan_sums_kernel, dim3(n_chunks), dim3(1024), 0, st, hist, m, sums);
+  SP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sp_scan_top_kernel, dim3(1), dim3(1024), 0, st, sums, n_chunks, total);
+  SP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sp_scan_apply_kernel, dim3(n_chunks), dim3(1024), 0, st, hist, m, sums);
+  SP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sp_label_rank_kernel, dim3(nblk), dim3(64), (size_t)k * 4, st, d_labels, n, (int)k, rb, nblk,
+                     hist, perm, seg, total);
+  SP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sp_seg_slots_kernel, dim3(1), dim3(1024), 0, st, seg, (int)k, slot_first);
+  SP_CHECK_LAUNCH();
+  const int64_t max_slots = seg_max_slots(n, k);
+  // V columns per lane: as wide as alignment allows while the launch still has >= 2048 waves
+  const size_t vbytes = esz;
+  int V = 1;
+  for (int cand = 4; cand > 1; cand >>= 1) {
+    const bool aligned = (d % cand == 0) && (ldx % cand == 0) && ((((uintptr_t)d_points) % (cand * vbytes)) == 0);
+    if (aligned && max_slots * ((d + 64 * cand - 1) / (64 * cand)) >= 2048) {
+      V = cand;
+      break;
+    }
+  }
+  const dim3 grid((unsigned)max_slots, (unsigned)((d + 64 * V - 1) / (64 * V)));
+#define SP_SEG_GO(T, VV)                                                                                      \
+  hipLaunchKernelGGL((sp_segment_sum_kernel<T, VV>), grid, dim3(64), 0, st, (const T*)d_points, ldx, perm, seg, \
+                     slot_first, (int)k, (int)d, (T*)partial)
+  if (dtype == SP_F32) {
+    if (V == 4) SP_SEG_GO(float, 4);
+    else if (V == 2) SP_SEG_GO(float, 2);
+    else SP_SEG_GO(float, 1);
+  } else {
+    if (V == 4) SP_SEG_GO(double, 4);
+    else if (V == 2) SP_SEG_GO(double, 2);
+    else SP_SEG_GO(double, 1);
+  }
+#undef SP_SEG_GO
+  SP_CHECK_LAUNCH();
+  const unsigned cblocks = (unsigned)((k * d + 255) / 256);
+  if (dtype == SP_F32)
+    hipLaunchKernelGGL((sp_segment_combine_kernel<float>), dim3(cblocks), dim3(256), 0, st, (const float*)partial,
+                       slot_first, (int)k, (int)d, (float*)d_out);
+  else
+    hipLaunchKernelGGL((sp_segment_combine_kernel<double>), dim3(cblocks), dim3(256), 0, st, (const double*)partial,
+                       slot_first, (int)k, (int)d, (double*)d_out);
+  SP_CHECK_LAUNCH();
+  return 0;
+}

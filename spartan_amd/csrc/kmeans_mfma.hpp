@@ -1,0 +1,363 @@
+// Fused tier of sp_nearest_center: fp32 MFMA GEMM  score[i][c] = |c|^2 - 2 x_i.c
+// with the per-point argmin folded into the epilogue, so the n x k distance matrix
+// (40 GB at BASELINE configs[3]) is never materialised.  (|x_i|^2 is constant per
+// row and irrelevant to the argmin.)
+//
+// One workgroup (4 waves, 2x2) owns 128 points and walks ALL centers in blocks
+// of 128, each block a full contraction over the features in BK=16 steps; the
+// (center block, k-step) pairs form ONE software pipeline (global -> VGPR -> LDS
+// double buffer, one barrier per step, as in gemm.hip).  Per accumulator row slot
+// every lane keeps (best, second best, best's column) over the columns it has seen;
+// lanes and the two column waves are merged once at the end.
+//
+// Exactness: a point is final only if its two best scores differ by more than
+// 4E, E = u((2D+4)|x||c|max + 2|c|max^2), u = 2^-24: the fp32 error bound of one
+// score (centers rounded to fp32, fmaf chain of D terms, |c|^2 rounded once, one
+// final rounding).  Otherwise its label is written as -1-best and the exact fp64
+// kernel (kmeans.hip) re-does that point, so the labels equal the exact tier's.
+#pragma once
+
+typedef float km_f32x16 __attribute__((ext_vector_type(16)));
+typedef float km_f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KM_BM = 128, KM_BN = 128, KM_BK = 16;
+constexpr int KM_LDA = KM_BK + 4;
+constexpr int KM_A_FLOATS = KM_BM * KM_LDA, KM_B_FLOATS = KM_BK * KM_BN;
+constexpr int KM_STAGE = KM_A_FLOATS + KM_B_FLOATS;
+
+// Ct[j][c] = (float)C[c][j] (zero padded to [dp][kp]); cn[c] = |C[c]|^2 (fp64 sum, rounded; +inf on padding);
+// *cmax2 = max_c |C[c]|^2 (as float bits; non-negative floats order like unsigned ints)
+template <typename TC>
+__global__ __launch_bounds__(256) void sp_centers_prep_kernel(const TC* __restrict__ C, int64_t ldc, int k, int d,
+                                                              int kp, float* __restrict__ Ct,
+                                                              float* __restrict__ cn, unsigned* __restrict__ cmax2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= kp) return;
+  if (c >= k) {
+    cn[c] = INFINITY;
+    return;
+  }
+  double s = 0.0;
+  for (int j = 0; j < d; ++j) {
+    const double v = (double)C[(int64_t)c * ldc + j];
+    s += v * v;
+    Ct[(int64_t)j * kp + c] = (float)v;
+  }
+  const float sf = (float)s;
+  cn[c] = sf;
+  // round the max up so the bound stays a bound
+  atomicMax(cmax2, __float_as_uint(sf * 1.0000002f));
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                  const float* __restrict__ Ct,
+                                                                  const float* __restrict__ cn,
+                                                                  const unsigned* __restrict__ cmax2_bits, int n,
+                                                                  int d, int kp, int64_t* __restrict__ labels,
+                                                                  int* __restrict__ amb_rows,
+                                                                  int* __restrict__ amb_count) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * KM_STAGE];
+  __shared__ float xn_s[KM_BM];
+  __shared__ float mb_s[KM_BM], ms_s[KM_BM];
+  __shared__ int mi_s[KM_BM];
+  constexpr int THREADS = 256;
+  constexpr int KQ = KM_BK / 4, NQ = KM_BN / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * KM_BM;
+
+  const float* __restrict__ Ablk = X + (int64_t)m0 * ldx;
+  int a_off[2], a_lds[2], b_off[2], b_lds[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * THREADS;
+    int row = e / KQ;
+    const int kq = e % KQ;
+    a_lds[j] = row * KM_LDA + kq * 4;
+    if (m0 + row > n - 1) row = n - 1 - m0;   // clamp: results of rows >= n are discarded
+    a_off[j] = row * (int)ldx + kq * 4;
+    const int brow = e / NQ, nq = e % NQ;
+    b_lds[j] = brow * KM_BN + nq * 4;
+    b_off[j] = brow * kp + nq * 4;
+  }
+  const int nt = (d + KM_BK - 1) / KM_BK;
+  const int tiles_n = kp / KM_BN;
+  const int steps = nt * tiles_n;
+  km_f32x4 ra[2], rb[2];
+
+#define KM_LOAD(step)                                                                    \
+  do {                                                                                   \
+    const int tn_ = (step) / nt, kt_ = (step) - tn_ * nt;                                \
+    const int k0_ = kt_ * KM_BK;                                                         \
+    const float* Bk_ = Ct + (int64_t)k0_ * kp + tn_ * KM_BN;                             \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                      \
+      if constexpr (FAST) {                                                              \
+        ra[j] = *(const km_f32x4*)(Ablk + k0_ + a_off[j]);                               \
+      } else {                                                                           \
+        const int kk = k0_ + ((tid + j * THREADS) % KQ) * 4;                             \
+        const float* p = Ablk + k0_ + a_off[j];                                          \
+        ra[j].x = kk + 0 < d ? p[0] : 0.f;                                               \
+        ra[j].y = kk + 1 < d ? p[1] : 0.f;                                               \
+        ra[j].z = kk + 2 < d ? p[2] : 0.f;                                               \
+        ra[j].w = kk + 3 < d ? p[3] : 0.f;                                               \
+      }                                                                                  \
+      rb[j] = *(const km_f32x4*)(Bk_ + b_off[j]);                                        \
+    }                                                                                    \
+  } while (0)
+#define KM_STORE(buf)                                                                    \
+  do {                                                                                   \
+    float* sA_ = smem + (buf) * KM_STAGE;                                                \
+    float* sB_ = sA_ + KM_A_FLOATS;                                                      \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                      \
+      *(km_f32x4*)(sA_ + a_lds[j]) = ra[j];                                              \
+      *(km_f32x4*)(sB_ + b_lds[j]) = rb[j];                                              \
+    }                                                                                    \
+  } while (0)
+
+  km_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float best[2][16], second[2][16];
+  // column of `best` = 32 * (its 32-column tile id) + l31; tile ids (< 65536) packed two per register
+  unsigned btile[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      best[i][r] = INFINITY;
+      second[i][r] = INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) btile[i][r] = 0u;
+  }
+  float xs[2] = {0.f, 0.f};   // partial |x|^2 of rows wm*64 + i*32 + l31 (this lane's k slots)
+
+  KM_LOAD(0);
+  KM_STORE(0);
+  __syncthreads();
+  const int a_frag = (wm * 64 + l31) * KM_LDA + 4 * lh;
+  const int b_frag = (4 * lh) * KM_BN + wn * 64 + l31;
+
+  int kt = 0, tn = 0;
+  for (int t = 0; t < steps; ++t) {
+    if (t + 1 < steps) KM_LOAD(t + 1);
+    const float* sA = smem + (t & 1) * KM_STAGE;
+    const float* sB = sA + KM_A_FLOATS;
+#pragma unroll
+    for (int c = 0; c < KM_BK / 8; ++c) {
+      km_f32x4 af[2];
+      float bf[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *(const km_f32x4*)(sA + a_frag + i * 32 * KM_LDA + c * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag + (c * 8 + s) * KM_BN + j * 32];
+      if (tn == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) xs[i] += af[i][s] * af[i][s];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kt == nt - 1) {
+      // epilogue of center block tn: columns ascend with j, so `<` keeps the first minimum
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned tile = (unsigned)(tn * 4 + wn * 2 + j);
+        const float cnc = cn[tile * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = cnc - 2.0f * acc[i][j][r];
+            if (v < best[i][r]) {
+              second[i][r] = best[i][r];
+              best[i][r] = v;
+              btile[i][r >> 1] = (r & 1) ? ((btile[i][r >> 1] & 0xffffu) | (tile << 16))
+                                         : ((btile[i][r >> 1] & 0xffff0000u) | tile);
+            } else if (v < second[i][r]) {
+              second[i][r] = v;
+            }
+            acc[i][j][r] = 0.f;
+          }
+      }
+      kt = 0;
+      ++tn;
+    } else {
+      ++kt;
+    }
+    if (t + 1 < steps) KM_STORE((t + 1) & 1);
+    __syncthreads();
+  }
+#undef KM_LOAD
+#undef KM_STORE
+
+  // |x|^2 per row -> LDS (the two lane halves hold complementary k slots)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float tot = xs[i] + __shfl_xor(xs[i], 32);
+    if (wn == 0 && lh == 0) xn_s[wm * 64 + i * 32 + l31] = tot;
+  }
+  // merge the 32 column lanes of each row slot (lanes with the same lh)
+  int bidx[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float b = best[i][r], s = second[i][r];
+      int ix = (int)(((btile[i][r >> 1] >> ((r & 1) * 16)) & 0xffffu) * 32u) + l31;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) {
+        const float ob = __shfl_xor(b, off), os = __shfl_xor(s, off);
+        const int oi = __shfl_xor(ix, off);
+        if (ob < b || (ob == b && oi < ix)) {
+          s = fminf(b, os);
+          b = ob;
+          ix = oi;
+        } else {
+          s = fminf(ob, s);
+        }
+      }
+      best[i][r] = b;
+      second[i][r] = s;
+      bidx[i][r] = ix;
+    }
+  // merge the two column waves through LDS, then decide
+  if (wn == 1 && l31 == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        mb_s[row] = best[i][r];
+        ms_s[row] = second[i][r];
+        mi_s[row] = bidx[i][r];
+      }
+  }
+  __syncthreads();
+  if (wn == 0 && l31 == 0) {
+    const float cmax2 = __uint_as_float(*cmax2_bits);
+    const float cmax = sqrtf(cmax2) * 1.0000002f;
+    const float u = 5.9604645e-8f;   // 2^-24
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float b = best[i][r], s = second[i][r];
+        int ix = bidx[i][r];
+        const float ob = mb_s[row], os = ms_s[row];
+        const int oi = mi_s[row];
+        if (ob < b || (ob == b && oi < ix)) {
+          s = fminf(b, os);
+          b = ob;
+          ix = oi;
+        } else {
+          s = fminf(ob, s);
+        }
+        if (m0 + row < n) {
+          const float xnorm = sqrtf(xn_s[row]) * 1.001f;   // fp32 sum of squares: generous slack
+          const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
+          const bool sure = (s - b) > 4.0f * E;            // false for NaN / inf-inf as well
+          labels[m0 + row] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
+          if (!sure) amb_rows[atomicAdd(amb_count, 1)] = m0 + row;   // (order-free: each listed point is re-done on its own)
+        }
+      }
+  }
+}
+
+static inline int64_t km_round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// scratch layout of sp_nearest_center (all 256-B aligned)
+struct KmWorkspace {
+  int64_t kp, dp;
+  double* Ct64;      // [d][kp]   fp64 transposed centers (exact kernel)
+  float* Ct;         // [dp][kp]  fp32 transposed centers (fused kernel)
+  float* cn;         // [kp]      |c|^2
+  unsigned* cmax2;   // [1]       max |c|^2 (float bits)
+  int* amb_count;    // [1]
+  int* amb_rows;     // [n]       points the fused kernel could not decide
+};
+
+static inline size_t km_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t sp_nearest_fused_ws_bytes(int64_t n, int64_t k, int64_t d) {
+  const int64_t kp = km_round_up(k < 1 ? 1 : k, KM_BN), dp = km_round_up(d < 1 ? 1 : d, KM_BK);
+  return 256 + km_align((size_t)(d < 1 ? 1 : d) * kp * 8) + km_align((size_t)dp * kp * 4) + km_align((size_t)kp * 4) + 256 + 256 +
+         km_align((size_t)(n < 1 ? 1 : n) * 4);
+}
+
+static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
+  KmWorkspace w;
+  w.kp = km_round_up(k, KM_BN);
+  w.dp = km_round_up(d < 1 ? 1 : d, KM_BK);
+  char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  w.Ct64 = (double*)p;
+  p += km_align((size_t)(d < 1 ? 1 : d) * w.kp * 8);
+  w.Ct = (float*)p;
+  p += km_align((size_t)w.dp * w.kp * 4);
+  w.cn = (float*)p;
+  p += km_align((size_t)w.kp * 4);
+  w.cmax2 = (unsigned*)p;
+  p += 256;
+  w.amb_count = (int*)p;
+  p += 256;
+  w.amb_rows = (int*)p;
+  (void)n;
+  return w;
+}
+
+// the fused tier pays once the contraction is big enough to hide its fixed costs
+static bool sp_nearest_fused_applicable(int64_t n, int64_t k, int64_t d, int tier) {
+  if (n > 2147483647LL - KM_BM || d < 1 || k > (1LL << 20)) return false;
+  if (tier == SP_NEAREST_FUSED || tier == SP_NEAREST_FUSED_UNCHECKED) return true;
+  return n >= 1024 && k >= 16 && d >= 8 && n * k * d >= (1LL << 24);
+}
+
+static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, int32_t cdtype, int64_t ldc,
+                                   int64_t n, int64_t k, int64_t d, int64_t* labels, const KmWorkspace& w,
+                                   hipStream_t st) {
+  if (ldx > 2147483647LL / KM_BM) SP_FAIL("sp_nearest_center: leading dimension too large for the fused tier");
+  const int64_t kp = w.kp, dp = w.dp;
+  float* Ct = w.Ct;
+  float* cn = w.cn;
+  unsigned* cmax2 = w.cmax2;
+  SP_HIP(hipMemsetAsync(Ct, 0, (size_t)dp * kp * 4, st));
+  SP_HIP(hipMemsetAsync(cmax2, 0, 512, st));   // cmax2 and amb_count
+  const unsigned pblocks = (unsigned)((kp + 255) / 256);
+  if (cdtype == SP_F32)
+    hipLaunchKernelGGL((sp_centers_prep_kernel<float>), dim3(pblocks), dim3(256), 0, st, (const float*)C, ldc, (int)k,
+                       (int)d, (int)kp, Ct, cn, cmax2);
+  else
+    hipLaunchKernelGGL((sp_centers_prep_kernel<double>), dim3(pblocks), dim3(256), 0, st, (const double*)C, ldc, (int)k,
+                       (int)d, (int)kp, Ct, cn, cmax2);
+  SP_CHECK_LAUNCH();
+  const unsigned blocks = (unsigned)((n + KM_BM - 1) / KM_BM);
+  const bool fast = (d % KM_BK == 0) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+  if (fast)
+    hipLaunchKernelGGL((sp_nearest_fused_kernel<true>), dim3(blocks), dim3(256), 0, st, X, ldx, Ct, cn, cmax2, (int)n,
+                       (int)d, (int)kp, labels, w.amb_rows, w.amb_count);
+  else
+    hipLaunchKernelGGL((sp_nearest_fused_kernel<false>), dim3(blocks), dim3(256), 0, st, X, ldx, Ct, cn, cmax2, (int)n,
+                       (int)d, (int)kp, labels, w.amb_rows, w.amb_count);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace

@@ -330,8 +330,8 @@ def glom(value):
 def optimized_dag(node):
   if not isinstance(node, Expr):
     raise TypeError
-  from . import optimize
-  return optimize.optimize(node)
+  from .optimize import optimize
+  return optimize(node)
 
 
 def evaluate(node):

@@ -125,6 +125,53 @@ def gemm_f32(a, b, c, accumulate=False):
   return c
 
 
+def _ld(t):
+  """Row stride (elements) of a 2-D tensor whose inner stride is 1."""
+  assert t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1), (t.shape, t.stride())
+  return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def nearest_center(points, centers, labels, tier=_hip.NEAREST_AUTO):
+  """labels[i] = argmin_c |points[i] - centers[c]| (cdist + argmin; k_means_.py:61-66)."""
+  _require_device(points, centers, labels)
+  n, d = points.shape
+  k, d2 = centers.shape
+  assert d == d2 and labels.dtype == torch.int64 and labels.numel() == n and labels.is_contiguous()
+  lib = _hip.lib()
+  need = lib.sp_nearest_center_workspace_bytes(n, k, d)
+  ws = _ws.get(need, points.device)
+  check(lib.sp_nearest_center(C.c_void_p(points.data_ptr()), _hip.sp_dtype(np_dtype_of(points)), _ld(points),
+                              C.c_void_p(centers.data_ptr()), _hip.sp_dtype(np_dtype_of(centers)), _ld(centers),
+                              n, k, d, C.c_void_p(labels.data_ptr()), tier, C.c_void_p(ws.data_ptr()),
+                              ws.numel(), _stream()))
+  return labels
+
+
+def bincount(labels, k, counts):
+  """counts[:k] = np.bincount(labels, minlength=k) (k_means_.py:69-72)."""
+  _require_device(labels, counts)
+  assert labels.dtype == torch.int64 and counts.dtype == torch.int64 and counts.numel() == k
+  assert labels.is_contiguous() and counts.is_contiguous()
+  check(_hip.lib().sp_bincount_i64(C.c_void_p(labels.data_ptr()), labels.numel(), k,
+                                   C.c_void_p(counts.data_ptr()), _stream()))
+  return counts
+
+
+def segment_sum(points, labels, k, out):
+  """out[c] = points[labels == c].sum(axis=0) (k_means_.py:75-97)."""
+  _require_device(points, labels, out)
+  n, d = points.shape
+  assert labels.dtype == torch.int64 and labels.numel() == n and labels.is_contiguous()
+  assert out.dtype == points.dtype and tuple(out.shape) == (k, d) and out.is_contiguous()
+  lib = _hip.lib()
+  need = lib.sp_segment_sum_workspace_bytes(n, k, d)
+  ws = _ws.get(need, points.device)
+  check(lib.sp_segment_sum(C.c_void_p(points.data_ptr()), _hip.sp_dtype(np_dtype_of(points)), _ld(points),
+                           C.c_void_p(labels.data_ptr()), n, k, d, C.c_void_p(out.data_ptr()),
+                           C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
+  return out
+
+
 def stream_copy(dst, src):
   _require_device(dst, src)
   n = src.numel() * src.element_size()

@@ -533,9 +533,87 @@ def fusion_goldens(sp):
   out['sum_mul_add_nchildren'] = len(r.children)
   return out
 
+def prepare_examples():
+  """lib2to3 over the reference's example drivers that BASELINE benchmarks (k-means, SGD regressions)."""
+  os.chdir(SCRATCH)
+  files = []
+  for d in ('spartan/examples', 'spartan/examples/sklearn', 'spartan/examples/sklearn/cluster'):
+    files += [os.path.join(d, f) for f in os.listdir(d) if f.endswith('.py')]
+  subprocess.check_call([sys.executable, '-m', 'lib2to3', '-w', '-n', '-x', 'map', '-x', 'filter',
+                         '-x', 'reduce', '-x', 'zip', '-x', 'import'] + files,
+                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+  # `np.int` (removed alias) as a dtype; `new_centers / new_counts` etc. are true divisions already
+  for f in files:
+    t = open(f).read()
+    t2 = t.replace('np.int)', 'np.int64)').replace('dtype=np.int,', 'dtype=np.int64,')
+    if t2 != t:
+      open(f, 'w').write(t2)
+
+
+def example_inputs():
+  """Seeded inputs shared with tests/test_examples.py (kept in the .npz so the tests need no RNG parity)."""
+  rng = np.random.RandomState(20150708)
+  true_centers = rng.rand(5, 6) * 10
+  x = (true_centers[rng.randint(0, 5, size=200)] + rng.randn(200, 6) * 0.1).astype(np.float32)
+  init = true_centers + 0.3
+  init_empty = init.copy()
+  init_empty[4] = 1000.0            # nobody is nearest to it: exercises the empty-cluster re-seed
+  xr = rng.rand(96, 8).astype(np.float32)
+  yr = rng.rand(96, 1).astype(np.float32)
+  return dict(km_x=x, km_init=init, km_init_empty=init_empty, reg_x=xr, reg_y=yr)
+
+
+def example_goldens(sp, workers):
+  from spartan.examples.sklearn.cluster import KMeans
+  from spartan.examples import linear_regression, logistic_regression, ridge_regression
+  inp = example_inputs()
+  out = {}
+
+  def val(v):
+    return np.asarray(v.glom() if hasattr(v, 'glom') else v)
+  for impl in ('map2', 'outer', 'broadcast', 'shuffle'):
+    for tag, init in (('', inp['km_init']), ('_empty', inp['km_init_empty'])):
+      start_cluster(sp, workers)
+      X = sp.from_numpy(inp['km_x'])
+      np.random.seed(4321)
+      c0 = init.copy() if impl in ('map2', 'shuffle') else sp.from_numpy(init.copy())
+      try:
+        centers, labels = KMeans(5, 3).fit(X, c0, implementation=impl)
+        out['kmeans_%s%s_centers' % (impl, tag)] = val(centers)
+        out['kmeans_%s%s_labels' % (impl, tag)] = val(labels)
+      except Exception as e:
+        print('   kmeans', impl, tag, 'w%d' % workers, 'failed in the reference:', type(e).__name__, str(e)[:300])
+  for name, fn in (('lreg', lambda x, y: linear_regression.linear_regression(x, y, 3)),
+                   ('logreg', lambda x, y: logistic_regression.logistic_regression(x, y, 3)),
+                   ('ridge', lambda x, y: ridge_regression.ridge_regression(x, y, 1, 2))):
+    start_cluster(sp, workers)
+    np.random.seed(1234)
+    try:
+      out[name + '_w'] = np.asarray(fn(sp.from_numpy(inp['reg_x']), sp.from_numpy(inp['reg_y'])))
+    except Exception as e:
+      print('  ', name, 'w%d' % workers, 'failed in the reference:', type(e).__name__, str(e)[:300])
+  return out
+
+
 if __name__ == '__main__':
+  if '--examples' in sys.argv:
+    # only the example-driver goldens, re-using an existing scratch build of the reference
+    if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
+      prepare_tree()
+      build_cython()
+    prepare_examples()
+    install_stubs()
+    sp = import_reference()
+    np.savez_compressed(os.path.join(OUT, 'examples_inputs.npz'), **example_inputs())
+    for n in (1, 4):
+      res = example_goldens(sp, n)
+      np.savez_compressed(os.path.join(OUT, 'examples_w%d.npz' % n), **res)
+      print('workers', n, ':', sorted(res))
+    sys.stdout.flush()
+    os._exit(0)
   prepare_tree()
   build_cython()
+  prepare_examples()
   install_stubs()
   sp = import_reference()
   print('imported reference:', sp)

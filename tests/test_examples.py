@@ -1,0 +1,135 @@
+"""The example drivers BASELINE.json benchmarks (k-means configs[3], SGD regressions
+configs[4]) against golden outputs produced by RUNNING THE REFERENCE's own
+spartan/examples on the same inputs (tests/golden/make_golden.py --examples).
+
+CPU leg: the host framework on the NumPy oracle backend (tile mappers, map2 / outer /
+shuffle plumbing, reducers).  GPU leg: the same drivers on the HIP backend, i.e.
+sp_nearest_center / sp_bincount_i64 / sp_segment_sum, the fused map->reduce kernels and
+the GEMM behind the C-ABI.  Labels and dtypes must be identical; centres are bit-exact
+where the kernels keep NumPy's summation order (map2 / outer / shuffle) and within a stated
+fp32 tolerance where the reduction tree differs ('broadcast' variant, SGD gradients)."""
+import os
+
+import numpy as np
+import pytest
+
+import spartan_amd as sp
+from spartan_amd.examples import linear_regression, logistic_regression, ridge_regression
+from spartan_amd.examples.sklearn.cluster import KMeans
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+INPUTS = dict(np.load(os.path.join(G, 'examples_inputs.npz')))
+GOLD = {n: dict(np.load(os.path.join(G, 'examples_w%d.npz' % n))) for n in (1, 4)}
+
+IMPLS = ('map2', 'outer', 'broadcast', 'shuffle')
+
+
+def _val(v):
+  return np.asarray(v.glom() if hasattr(v, 'glom') else v)
+
+
+def _run_kmeans(impl, tag):
+  X = sp.from_numpy(INPUTS['km_x'])
+  init = INPUTS['km_init' + tag].copy()
+  np.random.seed(4321)   # the empty-cluster re-seed draws np.random.randn on the driver, as the reference does
+  c0 = init if impl in ('map2', 'shuffle') else sp.from_numpy(init)
+  centers, labels = KMeans(5, 3).fit(X, c0, implementation=impl)
+  return _val(centers), _val(labels)
+
+
+def _check_kmeans(workers, impl, tag, exact_centers):
+  key = 'kmeans_%s%s' % (impl, tag)
+  gold = GOLD[workers]
+  if key + '_centers' not in gold:
+    pytest.skip('the reference itself cannot run this case (fp32 points + fp64 centres trip its Tile dtype assert)')
+  centers, labels = _run_kmeans(impl, tag)
+  want_c, want_l = gold[key + '_centers'], gold[key + '_labels']
+  assert labels.shape == want_l.shape
+  if impl == 'broadcast':
+    # The reference returns these indices as float32: its fused ReduceExpr takes the output dtype from
+    # the FIRST INPUT of the fused op (reduce.py:102 `dtype_fn(children[0])`, here the fp32 points), and
+    # the cached fused result is what `labels` later resolves to.  Unfused, the reference's own argmin
+    # gives int64 (tests/golden programs argmin_*), which is what we return; the values are identical.
+    assert labels.dtype == np.int64
+  else:
+    assert labels.dtype == want_l.dtype
+  np.testing.assert_array_equal(labels, want_l.astype(labels.dtype))
+  assert centers.shape == want_c.shape
+  if impl == 'broadcast':
+    # same quirk: the reference's fused sums land in fp32 tiles (dtype of the first fused input); NumPy
+    # promotion (fp32 * int64 -> fp64), which we follow, gives fp64.  Compare at the reference's precision.
+    assert centers.dtype == np.float64
+    np.testing.assert_allclose(centers.astype(want_c.dtype), want_c, rtol=2e-6, atol=1e-6)
+    return
+  assert centers.dtype == want_c.dtype
+  if exact_centers:
+    np.testing.assert_array_equal(centers, want_c)
+  else:
+    np.testing.assert_allclose(centers, want_c, rtol=2e-6, atol=1e-6)
+
+
+def _check_regressions(workers, rtol):
+  gold = GOLD[workers]
+  x, y = INPUTS['reg_x'], INPUTS['reg_y']
+  for name, fn in (('lreg', lambda a, b: linear_regression.linear_regression(a, b, 3)),
+                   ('logreg', lambda a, b: logistic_regression.logistic_regression(a, b, 3)),
+                   ('ridge', lambda a, b: ridge_regression.ridge_regression(a, b, 1, 2))):
+    np.random.seed(1234)   # SGDRegressor draws w with np.random.rand (sgd.py:30)
+    w = np.asarray(fn(sp.from_numpy(x), sp.from_numpy(y)))
+    want = gold[name + '_w']
+    assert w.dtype == want.dtype and w.shape == want.shape, name
+    if rtol == 0:
+      np.testing.assert_array_equal(w, want, err_msg=name)
+    else:
+      np.testing.assert_allclose(w, want, rtol=rtol, err_msg=name)
+
+
+# ------------------------------------------------------------------ CPU: host framework on the oracle backend
+@pytest.fixture(params=[1, 4], ids=lambda n: 'workers%d' % n)
+def cpu_ctx(request):
+  from oracle.np_backend import NumpyBackend
+  sp.initialize(backend=NumpyBackend(), num_workers=request.param)
+  yield request.param
+  sp.shutdown()
+
+
+@pytest.mark.parametrize('tag', ['', '_empty'])
+@pytest.mark.parametrize('impl', IMPLS)
+def test_kmeans_host_framework(cpu_ctx, impl, tag):
+  _check_kmeans(cpu_ctx, impl, tag, exact_centers=True)
+
+
+def test_regressions_host_framework(cpu_ctx):
+  _check_regressions(cpu_ctx, rtol=0)
+
+
+def test_kmeans_reducer_combines_tiles(cpu_ctx):
+  """fit(reducer=np.add) is the true k-means update: equal to a NumPy Lloyd iteration for any tiling."""
+  x, init = INPUTS['km_x'], INPUTS['km_init'].copy()
+  centers, labels = KMeans(5, 1).fit(sp.from_numpy(x), init.copy(), implementation='map2', reducer=np.add)
+  from scipy.spatial.distance import cdist
+  lab = np.argmin(cdist(x, init), axis=1)
+  want = np.stack([x[lab == i].sum(axis=0) for i in range(5)]) / np.bincount(lab, minlength=5)[:, None]
+  np.testing.assert_array_equal(_val(labels), lab.astype(np.float32))
+  np.testing.assert_allclose(centers, want, rtol=1e-6)
+
+
+# ------------------------------------------------------------------ GPU: the same drivers on the HIP kernels
+@pytest.fixture(params=[1, 4], ids=lambda n: 'workers%d' % n)
+def gpu_ctx(request):
+  sp.initialize('hip', num_workers=request.param)
+  yield request.param
+  sp.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['', '_empty'])
+@pytest.mark.parametrize('impl', IMPLS)
+def test_kmeans_hip(gpu_ctx, impl, tag):
+  # 'broadcast' sums squares / matches with the LDS reduction tree, not NumPy's order
+  _check_kmeans(gpu_ctx, impl, tag, exact_centers=(impl != 'broadcast'))
+
+
+@pytest.mark.gpu
+def test_regressions_hip(gpu_ctx):
+  _check_regressions(gpu_ctx, rtol=2e-6)

@@ -546,3 +546,95 @@ def test_jit_argreduce_bit_identical():
   keep = np.arange(300) != 7
   np.testing.assert_array_equal(idx[keep], np.argmax(np.abs(x - y)[keep], axis=1))
   assert idx[7] == -7
+
+
+# ---- k-means tile kernels (kmeans.hip) --------------------------------------------
+def _nearest(x, c, tier):
+  labels = torch.empty(x.shape[0], dtype=torch.int64, device=DEV)
+  kernels.nearest_center(dev(x), dev(c), labels, tier)
+  torch.cuda.synchronize()
+  return host(labels)
+
+
+@pytest.mark.parametrize('n,k,d', [(1, 1, 1), (100, 10, 5), (257, 70, 33), (1000, 130, 64), (64, 200, 7)])
+@pytest.mark.parametrize('xdt,cdt', [(np.float32, np.float64), (np.float32, np.float32), (np.float64, np.float64)])
+def test_nearest_center_exact_is_cdist_argmin(n, k, d, xdt, cdt):
+  from scipy.spatial.distance import cdist
+  x = RNG.rand(n, d).astype(xdt)
+  c = RNG.rand(k, d).astype(cdt)
+  want = np.argmin(cdist(x, c), axis=1)
+  np.testing.assert_array_equal(_nearest(x, c, _hip.NEAREST_EXACT), want)
+
+
+@pytest.mark.parametrize('n,k,d', [(5000, 300, 64), (4097, 129, 50), (3000, 1024, 256), (2048, 16, 8), (130, 5, 3)])
+def test_nearest_center_fused_equals_exact(n, k, d):
+  """The MFMA tier + exact re-check of near ties gives the exact tier's labels, bit for bit."""
+  from scipy.spatial.distance import cdist
+  x = RNG.rand(n, d).astype(np.float32)
+  c = RNG.rand(k, d)
+  c[k // 2] = c[0]                       # exact duplicate centre: ties must go to the lower index
+  x[: min(n, k)] = c[: min(n, k)].astype(np.float32)   # points sitting (almost) on centres
+  fused = _nearest(x, c, _hip.NEAREST_FUSED)
+  exact = _nearest(x, c, _hip.NEAREST_EXACT)
+  np.testing.assert_array_equal(fused, exact)
+  np.testing.assert_array_equal(exact, np.argmin(cdist(x, c), axis=1))
+  assert not np.any(fused == k // 2) or not np.array_equal(c[k // 2], c[0])
+
+
+def test_nearest_center_strided_rows_and_auto_tier():
+  from scipy.spatial.distance import cdist
+  big = RNG.rand(6000, 96).astype(np.float32)
+  c = RNG.rand(64, 80).astype(np.float32)
+  xt = dev(big)[:, 8:88]                 # row stride 96, 80 features, 32-B offset
+  labels = torch.empty(6000, dtype=torch.int64, device=DEV)
+  kernels.nearest_center(xt, dev(c), labels)
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(host(labels), np.argmin(cdist(big[:, 8:88], c), axis=1))
+
+
+@pytest.mark.parametrize('n,k', [(0, 4), (1, 1), (1000, 7), (100000, 1024), (5000, 16384)])
+def test_bincount(n, k):
+  lab = RNG.randint(0, k, size=n).astype(np.int64)
+  counts = torch.empty(k, dtype=torch.int64, device=DEV)
+  kernels.bincount(dev(lab) if n else torch.empty(0, dtype=torch.int64, device=DEV), k, counts)
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(host(counts), np.bincount(lab, minlength=k))
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('n,k,d', [(1, 1, 1), (200, 5, 6), (5000, 37, 70), (20000, 1024, 256), (3000, 3, 130)])
+def test_segment_sum_is_numpy_masked_sum(n, k, d, dt):
+  x = (RNG.rand(n, d) * 100).astype(dt)
+  lab = RNG.randint(0, k, size=n).astype(np.int64)
+  if k > 2:
+    lab[lab == 1] = 0                    # an empty cluster
+  out = torch.empty(k, d, dtype=kernels.torch_dtype(dt), device=DEV)
+  kernels.segment_sum(dev(x), dev(lab), k, out)
+  torch.cuda.synchronize()
+  want = np.zeros((k, d), dt)
+  for i in range(k):
+    want[i] = x[lab == i].sum(axis=0)    # k_means_.py:91-95
+  got = host(out)
+  small = np.bincount(lab, minlength=k) <= 512
+  # labels with <= 512 rows are added in NumPy's own (sequential) order: bit-identical
+  np.testing.assert_array_equal(got[small], want[small])
+  # larger ones in 512-row chunks combined in order: rounding-level differences only
+  np.testing.assert_allclose(got[~small], want[~small], rtol=1e-5 if dt == np.float32 else 1e-13)
+
+
+def test_segment_sum_is_deterministic_and_balanced():
+  """One huge label next to tiny ones (the shape k-means produces): same bits on every run."""
+  n, k, d = 60000, 64, 128
+  x = (RNG.rand(n, d) * 10).astype(np.float32)
+  lab = np.zeros(n, np.int64)
+  lab[::7] = RNG.randint(1, k, size=len(lab[::7]))
+  outs = []
+  for _ in range(3):
+    out = torch.empty(k, d, dtype=torch.float32, device=DEV)
+    kernels.segment_sum(dev(x), dev(lab), k, out)
+    torch.cuda.synchronize()
+    outs.append(host(out))
+  np.testing.assert_array_equal(outs[0], outs[1])
+  np.testing.assert_array_equal(outs[0], outs[2])
+  want = np.stack([x[lab == i].astype(np.float64).sum(axis=0) for i in range(k)])
+  np.testing.assert_allclose(outs[0], want, rtol=2e-5)

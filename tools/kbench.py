@@ -113,6 +113,40 @@ def bench_gemm(M, N, K, variants=(0, 1, 2, 3)):
     break
 
 
+def bench_kmeans(n, k, d):
+  """BASELINE configs[3] per-GPU tile: 1 250 000 x 256 fp32 points, k = 1024."""
+  g = torch.Generator(device=DEV)
+  g.manual_seed(20150708)
+  x = torch.rand(n, d, dtype=torch.float32, device=DEV, generator=g)
+  c = torch.rand(k, d, dtype=torch.float64, device=DEV, generator=g)
+  labels = torch.empty(n, dtype=torch.int64, device=DEV)
+  flop = 2.0 * n * k * d
+  ms = timeit(lambda: kernels.nearest_center(x, c, labels, _hip.NEAREST_FUSED_UNCHECKED), iters=5, warmup=2)
+  amb = int((labels < 0).sum().item())
+  print('nearest fused kernel only  %dx%dx%d  %8.3f ms  %7.1f TFLOP/s (%.1f%% of 157.3)  undecided rows %d (%.3f%%)'
+        % (n, k, d, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100, amb, 100.0 * amb / n))
+  ms = timeit(lambda: kernels.nearest_center(x, c, labels, _hip.NEAREST_FUSED), iters=5, warmup=2)
+  print('nearest fused + re-check   %dx%dx%d  %8.3f ms  %7.1f TFLOP/s (%.1f%% of 157.3)'
+        % (n, k, d, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100))
+  ne = min(n, 20000)
+  le = torch.empty(ne, dtype=torch.int64, device=DEV)
+  ms_e = timeit(lambda: kernels.nearest_center(x[:ne], c, le, _hip.NEAREST_EXACT), iters=2, warmup=1)
+  print('nearest exact tier         %dx%dx%d  %8.3f ms  %7.2f TFLOP/s (fp64, 1 wave per point)'
+        % (ne, k, d, ms_e, 2.0 * ne * k * d / ms_e / 1e9))
+  assert bool((le == labels[:ne]).all().item()), 'fused tier disagrees with the exact tier'
+  counts = torch.empty(k, dtype=torch.int64, device=DEV)
+  ms = timeit(lambda: kernels.bincount(labels, k, counts))
+  print('bincount                   n=%d k=%d  %8.3f ms  %8.1f GB/s (8 B/label)' % (n, k, ms, 8.0 * n / ms / 1e6))
+  out = torch.empty(k, d, dtype=torch.float32, device=DEV)
+  ms = timeit(lambda: kernels.segment_sum(x, labels, k, out))
+  print('segment_sum                %dx%d k=%d  %8.3f ms  %8.1f GB/s (4*n*d bytes)' % (n, d, k, ms, 4.0 * n * d / ms / 1e6))
+  bc = torch.bincount(labels, minlength=k)
+  print('   cluster sizes: mean %.0f  max %d  min %d' % (n / k, int(bc.max()), int(bc.min())))
+  ul = torch.randint(0, k, (n,), dtype=torch.int64, device=DEV, generator=g)
+  ms = timeit(lambda: kernels.segment_sum(x, ul, k, out))
+  print('segment_sum (uniform random labels)  %8.3f ms  %8.1f GB/s' % (ms, 4.0 * n * d / ms / 1e6))
+
+
 if __name__ == '__main__':
   what = sys.argv[1] if len(sys.argv) > 1 else 'all'
   if what in ('all', 'copy'):
@@ -124,6 +158,8 @@ if __name__ == '__main__':
   if what in ('all', 'reduce'):
     bench_reduce(8192, 65536)
     bench_reduce(125000, 4096)
+  if what == 'kmeans':
+    bench_kmeans(1250000, 1024, 256)
   if what == 'gemm':
     M, N, K = [int(v) for v in sys.argv[2:5]]
     bench_gemm(M, N, K)
