@@ -129,6 +129,45 @@ def hbm_section(ctx):
   return out
 
 
+def kmeans_section(ctx):
+  """One k-means iteration on a BASELINE configs[3] per-GPU tile (1 250 000 x 256 fp32 points,
+  k = 1024): distance+argmin is MFMA-bound (2*n*k*d flop), the accumulate HBM-bound (4*n*d bytes)."""
+  from spartan_amd.examples.sklearn.cluster import KMeans
+  n, k, d = 1250000, 1024, 256
+  X = sp.from_tile_fn((n, d), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 21)).force()
+  Xv = sp.Val(val=X)
+  x = ctx.tile(list(X.tiles.values())[0]).data
+  centers = np.random.RandomState(SEED).rand(k, d)
+  cdev = ctx.backend.from_numpy(centers)
+  labels = torch.empty(n, dtype=torch.int64, device=x.device)
+  out = {'tile': '%dx%d fp32, k=%d' % (n, d, k)}
+  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels), 5, warmup=2)
+  out['assign_ms'] = round(ms, 3)
+  out['assign_TFLOPs'] = round(2.0 * n * k * d / ms / 1e9, 1)          # SURVEY 8d: 2*N*K*D flop
+  out['assign_frac_of_mfma_peak'] = round(2.0 * n * k * d / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)
+  kernels.nearest_center(x, cdev, labels, _hip.NEAREST_FUSED_UNCHECKED)
+  out['assign_rechecked_points'] = int((labels < 0).sum().item())   # re-done by the exact fp64 kernel
+  kernels.nearest_center(x, cdev, labels)
+  sums = torch.empty(k, d, dtype=torch.float32, device=x.device)
+  counts = torch.empty(k, dtype=torch.int64, device=x.device)
+
+  def accumulate():
+    kernels.bincount(labels, k, counts)
+    kernels.segment_sum(x, labels, k, sums)
+  ms = event_time(accumulate, 10)
+  out['accumulate_ms'] = round(ms, 3)
+  out['accumulate_GBps'] = round(4.0 * n * d / ms / 1e6, 1)             # SURVEY 8d: 4*N*D bytes
+  km = KMeans(k, 1)
+  t = []
+  for _ in range(4):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    km.fit(Xv, centers, implementation='map2', reducer=np.add)   # glom of counts / centres synchronises
+    t.append(time.perf_counter() - t0)
+  out['iteration_ms'] = round(min(t[1:]) * 1e3, 3)                     # driver program end to end
+  return out
+
+
 def cpu_baseline():
   """The NumPy oracle (a port of the reference's NumPy-worker path) on the host:
   one worker == one core (spartan/worker.py:40), BLAS pinned to one thread."""
@@ -244,6 +283,8 @@ def main():
       del keep[:]
       torch.cuda.empty_cache()
       line['hbm'] = hbm_section(ctx)
+      torch.cuda.empty_cache()
+      line['kmeans'] = kmeans_section(ctx)
       line['cpu_baseline'] = cpu_baseline()
   if world.distributed:
     line['comm'] = dict(world.stats)

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libspartan_hip.so')
+# SPARTAN_HIP_LIB: load another build of the same library (kernel A/B experiments, tools/)
+LIB_PATH = os.environ.get('SPARTAN_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libspartan_hip.so')
 
 # ---- enums (mirror include/spartan_hip.h) ---------------------------------
 SP_F32, SP_F64, SP_I32, SP_I64, SP_BOOL, SP_U8 = range(6)

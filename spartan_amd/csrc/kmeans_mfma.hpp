@@ -161,12 +161,14 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag + (c * 8 + s) * KM_BN + j * 32];
+#ifndef KM_EXP_NOXN
       if (tn == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int s = 0; s < 4; ++s) xs[i] += af[i][s] * af[i][s];
       }
+#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -186,6 +188,9 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = cnc - 2.0f * acc[i][j][r];
+#ifdef KM_EXP_NOEPI
+            if (r == 0 && i == 0 && v < best[0][0]) best[0][0] = v;
+#else
             if (v < best[i][r]) {
               second[i][r] = best[i][r];
               best[i][r] = v;
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
             } else if (v < second[i][r]) {
               second[i][r] = v;
             }
+#endif
             acc[i][j][r] = 0.f;
           }
       }

@@ -14,6 +14,28 @@ from oracle.np_backend import NumpyBackend  # noqa: E402
 from tests import programs  # noqa: E402
 
 
+def run_examples(total_workers):
+  from tests import test_examples as T
+  hip = sp.get_context().backend.name == 'hip'
+  count = 0
+  if total_workers in T.GOLD:
+    for impl in ('map2', 'outer', 'shuffle'):
+      for tag in ('', '_empty'):
+        T._check_kmeans(total_workers, impl, tag, exact_centers=True)
+        count += 1
+    T._check_regressions(total_workers, rtol=2e-6 if hip else 0)
+    count += 1
+  # true k-means update (partials combined across ranks by the reducer)
+  x, init = T.INPUTS['km_x'], T.INPUTS['km_init'].copy()
+  centers, labels = T.KMeans(5, 1).fit(sp.from_numpy(x), init.copy(), implementation='map2', reducer=np.add)
+  from scipy.spatial.distance import cdist
+  lab = np.argmin(cdist(x, init), axis=1)
+  want = np.stack([x[lab == i].sum(axis=0) for i in range(5)]) / np.bincount(lab, minlength=5)[:, None]
+  np.testing.assert_array_equal(T._val(labels), lab.astype(np.float32))
+  np.testing.assert_allclose(centers, want, rtol=1e-6)
+  return count + 1
+
+
 def main():
   workers = int(sys.argv[1])
   use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
@@ -44,6 +66,9 @@ def main():
     np.testing.assert_array_equal(d, (np.arange(32 * 64, dtype=np.float32).reshape(32, 64) % 5).dot(
         np.arange(64 * 32, dtype=np.float32).reshape(64, 32) % 7))
     assert world.stats['collectives'] > before['collectives'], world.stats
+  # the example drivers across ranks: identical to the single-process goldens of the reference
+  # (tile->worker round robin puts tiles on both ranks; every rank must see the same result)
+  n += run_examples(workers)
   world.barrier()
   print('RANK %d OK %d' % (world.rank, n))
   sys.stdout.flush()
