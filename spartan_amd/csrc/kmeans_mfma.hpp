@@ -27,7 +27,7 @@ constexpr int KM_LDA = KM_BK + 4;
 constexpr int KM_A_FLOATS = KM_BM * KM_LDA, KM_B_FLOATS = KM_BK * KM_BN;
 constexpr int KM_STAGE = KM_A_FLOATS + KM_B_FLOATS;
 
-// Ct[j][c] = (float)C[c][j] (zero padded to [dp][kp]); cn[c] = |C[c]|^2 (fp64 sum, rounded; +inf on padding);
+// Ct[j][c] = (float)C[c][j] (zero padded to [dp][kp]); cn[c] = |C[c]|^2 / 2 (fp64 sum, rounded; +inf on padding);
 // *cmax2 = max_c |C[c]|^2 (as float bits; non-negative floats order like unsigned ints)
 template <typename TC>
 __global__ __launch_bounds__(256) void sp_centers_prep_kernel(const TC* __restrict__ C, int64_t ldc, int k, int d,
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void sp_centers_prep_kernel(const TC* __restri
     Ct[(int64_t)j * kp + c] = (float)v;
   }
   const float sf = (float)s;
-  cn[c] = sf;
+  cn[c] = 0.5f * sf;   // the kernel compares halved scores |c|^2/2 - x.c (exact scaling)
   // round the max up so the bound stays a bound
   atomicMax(cmax2, __float_as_uint(sf * 1.0000002f));
 }
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void sp_centers_prep_kernel(const TC* __restri
 template <bool FAST>
 __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const float* __restrict__ Ct,
-                                                                  const float* __restrict__ cn,
+                                                                  const float* __restrict__ chalf,
                                                                   const unsigned* __restrict__ cmax2_bits, int n,
                                                                   int d, int kp, int64_t* __restrict__ labels,
                                                                   int* __restrict__ amb_rows,
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float best[2][16], second[2][16];
-  // column of `best` = 32 * (its 32-column tile id) + l31; tile ids (< 65536) packed two per register
-  unsigned btile[2][8];
+  // column of `best` = 32 * (its 32-column tile id) + l31
+  int btile[2][16];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
       second[i][r] = INFINITY;
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) btile[i][r] = 0u;
+    for (int r = 0; r < 16; ++r) btile[i][r] = 0;
   }
   float xs[2] = {0.f, 0.f};   // partial |x|^2 of rows wm*64 + i*32 + l31 (this lane's k slots)
 
@@ -146,70 +146,66 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
   const int a_frag = (wm * 64 + l31) * KM_LDA + 4 * lh;
   const int b_frag = (4 * lh) * KM_BN + wn * 64 + l31;
 
-  int kt = 0, tn = 0;
-  for (int t = 0; t < steps; ++t) {
-    if (t + 1 < steps) KM_LOAD(t + 1);
-    const float* sA = smem + (t & 1) * KM_STAGE;
-    const float* sB = sA + KM_A_FLOATS;
+  float chv[2];   // |c|^2 / 2 of this lane's two columns of the current center block (fetched a block ahead of use)
 #pragma unroll
-    for (int c = 0; c < KM_BK / 8; ++c) {
-      km_f32x4 af[2];
-      float bf[2][4];
+  for (int j = 0; j < 2; ++j) chv[j] = chalf[(wn * 2 + j) * 32 + l31];
+  int t = 0;
+  for (int tn = 0; tn < tiles_n; ++tn) {
+    // ---- contraction over the features for center block tn: one straight-line body per k-step
+    for (int kt = 0; kt < nt; ++kt, ++t) {
+      if (t + 1 < steps) KM_LOAD(t + 1);
+      const float* sA = smem + (t & 1) * KM_STAGE;
+      const float* sB = sA + KM_A_FLOATS;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const km_f32x4*)(sA + a_frag + i * 32 * KM_LDA + c * 8);
+      for (int c = 0; c < KM_BK / 8; ++c) {
+        km_f32x4 af[2];
+        float bf[2][4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i) af[i] = *(const km_f32x4*)(sA + a_frag + i * 32 * KM_LDA + c * 8);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag + (c * 8 + s) * KM_BN + j * 32];
-#ifndef KM_EXP_NOXN
-      if (tn == 0) {
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag + (c * 8 + s) * KM_BN + j * 32];
+        // |x|^2 is accumulated on every pass over the point block (no branch in this loop) and
+        // divided by the number of passes at the end; it only feeds the error bound
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) xs[i] += af[i][s] * af[i][s];
+          for (int s = 0; s < 4; ++s) xs[i] = __builtin_fmaf(af[i][s], af[i][s], xs[i]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
       }
-#endif
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+      if (t + 1 < steps) KM_STORE((t + 1) & 1);
+      __syncthreads();
     }
-    if (kt == nt - 1) {
-      // epilogue of center block tn: columns ascend with j, so `<` keeps the first minimum
+    // ---- epilogue of center block tn, branch-free (the if/else form compiles to one exec-masked
+    // basic block per accumulator).  Scores are kept halved, h = |c|^2/2 - x.c; columns ascend
+    // with j, so `<` keeps the first minimum.  Invariant: best <= second.
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned tile = (unsigned)(tn * 4 + wn * 2 + j);
-        const float cnc = cn[tile * 32 + l31];
+    for (int j = 0; j < 2; ++j) {
+      const int tile = tn * 4 + wn * 2 + j;
+      const float ch = chv[j];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = cnc - 2.0f * acc[i][j][r];
-#ifdef KM_EXP_NOEPI
-            if (r == 0 && i == 0 && v < best[0][0]) best[0][0] = v;
-#else
-            if (v < best[i][r]) {
-              second[i][r] = best[i][r];
-              best[i][r] = v;
-              btile[i][r >> 1] = (r & 1) ? ((btile[i][r >> 1] & 0xffffu) | (tile << 16))
-                                         : ((btile[i][r >> 1] & 0xffff0000u) | tile);
-            } else if (v < second[i][r]) {
-              second[i][r] = v;
-            }
-#endif
-            acc[i][j][r] = 0.f;
-          }
-      }
-      kt = 0;
-      ++tn;
-    } else {
-      ++kt;
+        for (int r = 0; r < 16; ++r) {
+          const float v = ch - acc[i][j][r];
+          const bool better = v < best[i][r];
+          second[i][r] = fminf(second[i][r], fmaxf(v, best[i][r]));
+          btile[i][r] = better ? tile : btile[i][r];
+          best[i][r] = fminf(best[i][r], v);
+          acc[i][j][r] = 0.f;
+        }
     }
-    if (t + 1 < steps) KM_STORE((t + 1) & 1);
-    __syncthreads();
+    if (tn + 1 < tiles_n) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) chv[j] = chalf[((tn + 1) * 4 + wn * 2 + j) * 32 + l31];
+    }
   }
 #undef KM_LOAD
 #undef KM_STORE
@@ -217,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
   // |x|^2 per row -> LDS (the two lane halves hold complementary k slots)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const float tot = xs[i] + __shfl_xor(xs[i], 32);
+    const float tot = (xs[i] + __shfl_xor(xs[i], 32)) / (float)tiles_n;
     if (wn == 0 && lh == 0) xn_s[wm * 64 + i * 32 + l31] = tot;
   }
   // merge the 32 column lanes of each row slot (lanes with the same lh)
@@ -227,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float b = best[i][r], s = second[i][r];
-      int ix = (int)(((btile[i][r >> 1] >> ((r & 1) * 16)) & 0xffffu) * 32u) + l31;
+      int ix = btile[i][r] * 32 + l31;
 #pragma unroll
       for (int off = 1; off < 32; off <<= 1) {
         const float ob = __shfl_xor(b, off), os = __shfl_xor(s, off);
@@ -280,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
         if (m0 + row < n) {
           const float xnorm = sqrtf(xn_s[row]) * 1.001f;   // fp32 sum of squares: generous slack
           const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
-          const bool sure = (s - b) > 4.0f * E;            // false for NaN / inf-inf as well
+          const bool sure = 2.0f * (s - b) > 4.0f * E;     // (scores are halved) false for NaN / inf-inf as well
           labels[m0 + row] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
           if (!sure) amb_rows[atomicAdd(amb_count, 1)] = m0 + row;   // (order-free: each listed point is re-done on its own)
         }

@@ -159,7 +159,10 @@ if __name__ == '__main__':
     bench_reduce(8192, 65536)
     bench_reduce(125000, 4096)
   if what == 'kmeans':
-    bench_kmeans(1250000, 1024, 256)
+    if len(sys.argv) > 4:
+      bench_kmeans(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    else:
+      bench_kmeans(1250000, 1024, 256)
   if what == 'gemm':
     M, N, K = [int(v) for v in sys.argv[2:5]]
     bench_gemm(M, N, K)
