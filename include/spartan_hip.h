@@ -311,6 +311,15 @@ size_t sp_segment_sum_workspace_bytes(int64_t n, int64_t k, int64_t d);
 int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, const int64_t* d_labels, int64_t n,
                    int64_t k, int64_t d, void* d_out, void* d_ws, size_t ws_bytes, void* stream);
 
+/* sp_random_fill: the per-tile bodies of the reference's random builders
+ * (spartan/expr/srandom.py:38-55, np.random.rand / randn / randint per tile) as a
+ * counter-based generator: element i = Philox4x32-10(seed, offset + i), so a tile's
+ * content is independent of the launch geometry.  kind 0: uniform [0,1), 1: standard
+ * normal, 2: integers in [lo, hi).  dtype: SP_F32 | SP_F64 | SP_I32 | SP_I64.
+ * (Not NumPy's stream; the reference re-seeds every worker from the clock.) */
+int sp_random_fill(void* d_out, int32_t dtype, int64_t n, int32_t kind, uint64_t seed, uint64_t offset,
+                   int64_t lo, int64_t hi, void* stream);
+
 /* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
  * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
 int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);

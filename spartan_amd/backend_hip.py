@@ -7,6 +7,8 @@ Constructing it without a GPU or without the built library raises: there is no
 CPU fallback in the product path.
 """
 import collections
+import os
+import time
 
 import numpy as np
 import torch
@@ -34,6 +36,8 @@ class HipBackend(object):
     self._np_cache = collections.OrderedDict()   # bounded: iterative drivers pass a new array every step
     self.launches = 0
     self.gemm_events = None   # set to [] to record (start, stop) HIP events around every GEMM launch
+    self._rng_seed = (int(time.time() * 100000) + os.getpid()) & (2**63 - 1)   # srandom.py:23-35: from the clock
+    self._rng_offset = 0
 
   # -- memory -------------------------------------------------------------------
   def empty(self, shape, dtype):
@@ -154,13 +158,60 @@ class HipBackend(object):
       kernels.map_fused(prog, [self.contiguous(t) for t in tensors], out)
     return out
 
+  def seed_random(self, seed):
+    self._rng_seed = int(seed) & (2**63 - 1)
+    self._rng_offset = 0
+
+  def random_tile(self, kind, shape, dtype, low=0, high=10):
+    """One srandom tile (srandom.py:38-50) from the counter-based generator; consecutive
+    fills consume consecutive counters of this worker's stream."""
+    out = self.empty(shape, dtype)
+    n = out.numel()
+    if n:
+      self.launches += 1
+      kernels.random_fill(out, kind, self._rng_seed, self._rng_offset, low, high)
+      self._rng_offset += n + (n & 1)
+    return out
+
   def evaluate_map(self, op, inputs, ex):
     """tile_mapper body: the fused map as ONE launch (map.py:74, local.py:115-127)."""
+    rnd = getattr(getattr(op, 'fn', None), '_sp_random', None)
+    if rnd is not None:
+      return self.random_tile(rnd[0], ex.shape, rnd[1], **(op.kw or {}))
+    op, inputs = self._materialise_random(op, inputs, ex)
     try:
       root = lower.infer(op, inputs, ex, self.dtype_of)
       return self._run_map(root, root.shape if root.kind != 'const' else ex.shape)
     except ProgramTooLarge:
       return self._evaluate_split(op, inputs, ex)
+
+  def _materialise_random(self, op, inputs, ex):
+    """Random sources fused INTO a tree (the reference's fusion does that despite @not_idempotent,
+    because the marker is keyed by id() and the optimiser clones nodes: `(r - r).optimized()` draws
+    twice there too) become tensor inputs, one fill per occurrence, like the reference's evaluation."""
+    if not isinstance(op, FnCallExpr):
+      return op, inputs
+    new_deps, changed = [], False
+    for i, d in enumerate(op.deps):
+      rnd = getattr(getattr(d, 'fn', None), '_sp_random', None)
+      if rnd is not None:
+        if not changed:
+          inputs = dict(inputs)
+        name = '__random_%d_%d' % (id(op), i)
+        inputs[name] = self.random_tile(rnd[0], ex.shape, rnd[1], **(d.kw or {}))
+        new_deps.append(LocalInput(idx=name))
+        changed = True
+      elif isinstance(d, FnCallExpr):
+        nd, inputs2 = self._materialise_random(d, inputs, ex)
+        if nd is not d:
+          changed = True
+          inputs = inputs2
+        new_deps.append(nd)
+      else:
+        new_deps.append(d)
+    if not changed:
+      return op, inputs
+    return op.__class__(fn=op.fn, kw=op.kw, pretty_fn=op.pretty_fn, deps=new_deps), inputs
 
   def _evaluate_split(self, op, inputs, ex):
     """The tree does not fit one kernel: materialise its sub-expressions first."""

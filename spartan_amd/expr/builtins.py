@@ -158,6 +158,75 @@ def from_tile_fn(shape, dtype, fn, tile_hint=None):
   return base.Val(val=arr)
 
 
+# ---------------------------------------------------------------- srandom.py
+def _make_rand(input):
+  """srandom.py:38-40."""
+  return np.random.rand(*input.shape)
+
+
+def _make_randn(input):
+  """srandom.py:43-45."""
+  return np.random.randn(*input.shape)
+
+
+def _make_randint(input, low=0, high=10):
+  """srandom.py:48-50."""
+  return np.random.randint(low, high, size=input.shape)
+
+
+# (kind, result dtype): the HIP backend fills these tiles with its counter-based generator
+# (sp_random_fill) instead of calling NumPy on the host
+_make_rand._sp_random = ('uniform', np.float64)
+_make_randn._sp_random = ('normal', np.float64)
+_make_randint._sp_random = ('randint', np.int64)
+
+
+def set_random_seed(seed=None):
+  """srandom.py:23-35 re-seeds every worker from the clock; here: seed the backend's
+  generator (None = from the clock), mixed with the rank so workers draw distinct streams."""
+  import os
+  import time
+  ctx = context.get()
+  if seed is None:
+    seed = (int(time.time() * 100000) + os.getpid()) % 4294967295
+  if hasattr(ctx.backend, 'seed_random'):
+    ctx.backend.seed_random(int(seed) * 1000003 + ctx.world.rank)
+  np.random.seed((int(seed) + ctx.world.rank) % 4294967295)
+
+
+def _tile_hint_kw(kw):
+  tile_hint = kw.pop('tile_hint', None)
+  return tile_hint
+
+
+@not_idempotent
+def rand(*shape, **kw):
+  """Uniform [0, 1) array (srandom.py:68-85)."""
+  tile_hint = _tile_hint_kw(kw)
+  assert len(kw) == 0, 'Unknown keywords %s' % kw
+  for s in shape:
+    assert isinstance(s, (int, np.integer))
+  return map(ndarray(shape, dtype=np.float64, tile_hint=tile_hint), fn=_make_rand)
+
+
+@not_idempotent
+def randn(*shape, **kw):
+  """Standard normal array (srandom.py:87-101)."""
+  tile_hint = _tile_hint_kw(kw)
+  for s in shape:
+    assert isinstance(s, (int, np.integer))
+  return map(ndarray(shape, dtype=np.float64, tile_hint=tile_hint), fn=_make_randn)
+
+
+@not_idempotent
+def randint(*shape, **kw):
+  """Integers in [low, high) (srandom.py:103-118)."""
+  tile_hint = _tile_hint_kw(kw)
+  for s in shape:
+    assert isinstance(s, (int, np.integer))
+  return map(ndarray(shape, dtype=np.float64, tile_hint=tile_hint), fn=_make_randint, fn_kw=kw)
+
+
 # ------------------------------------------------------------- mathematics.py
 def add(a, b): return map((a, b), fn=np.add)
 def reciprocal(a): return map(a, fn=np.reciprocal)

@@ -172,6 +172,19 @@ def segment_sum(points, labels, k, out):
   return out
 
 
+RANDOM_KINDS = {'uniform': 0, 'normal': 1, 'randint': 2}
+
+
+def random_fill(out, kind, seed, offset, lo=0, hi=1):
+  """Philox fill of a dense tensor: element i = f(seed, offset + i) (srandom.py:38-55)."""
+  _require_device(out)
+  assert out.is_contiguous()
+  check(_hip.lib().sp_random_fill(C.c_void_p(out.data_ptr()), _hip.sp_dtype(np_dtype_of(out)), out.numel(),
+                                  RANDOM_KINDS[kind], int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
+                                  int(lo), int(hi), _stream()))
+  return out
+
+
 def stream_copy(dst, src):
   _require_device(dst, src)
   n = src.numel() * src.element_size()

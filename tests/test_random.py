@@ -1,0 +1,98 @@
+"""srandom builders (reference spartan/expr/srandom.py): rand / randn / randint.
+Values are random by construction (the reference seeds every worker from the clock), so the
+tests pin what the reference fixes: shape, tiling, dtype, range and the distribution; on the
+GPU additionally that the counter-based generator is a pure function of (seed, position)."""
+import numpy as np
+import pytest
+
+import spartan_amd as sp
+
+
+def _check_builders():
+  a = sp.rand(300, 7)
+  assert a.shape == (300, 7)
+  av = a.glom()
+  assert av.dtype == np.float64 and av.min() >= 0.0 and av.max() < 1.0
+  assert abs(av.mean() - 0.5) < 0.05
+  b = sp.randn(400, 5, tile_hint=(100, 5)).glom()
+  assert b.dtype == np.float64 and b.shape == (400, 5)
+  assert abs(b.mean()) < 0.15 and abs(b.std() - 1.0) < 0.15
+  c = sp.randint(500, 3, low=3, high=9).glom()
+  assert c.dtype == np.int64 and c.min() == 3 and c.max() == 8
+  # evaluated lazily ONCE per expression (EvalCache): r - r is exactly zero ...
+  r = sp.rand(64, 4)
+  np.testing.assert_array_equal((r - r).glom(), np.zeros((64, 4)))
+  # ... but, as in the reference (checked by running it: its MapMapFusion clones nodes, so the id()-keyed
+  # @not_idempotent marker does not survive), the OPTIMISED tree draws once per occurrence
+  r = sp.rand(64, 4)
+  e = (r - r).optimized().glom()
+  assert e.shape == (64, 4) and np.abs(e).max() < 1.0 and np.abs(e).max() > 0.0
+  with pytest.raises(AssertionError):
+    sp.rand(3, 3, bogus=1)
+
+
+@pytest.mark.parametrize('workers', [1, 4])
+def test_random_builders_host_framework(workers):
+  from oracle.np_backend import NumpyBackend
+  sp.initialize(backend=NumpyBackend(), num_workers=workers)
+  sp.set_random_seed(11)
+  try:
+    _check_builders()
+  finally:
+    sp.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workers', [1, 3])
+def test_random_builders_hip(workers):
+  ctx = sp.initialize('hip', num_workers=workers)
+  sp.set_random_seed(11)
+  try:
+    before = ctx.backend.launches
+    _check_builders()
+    assert ctx.backend.launches > before
+    sp.set_random_seed(11)
+    x1 = sp.rand(1000, 9).glom()
+    sp.set_random_seed(11)
+    x2 = sp.rand(1000, 9).glom()
+    np.testing.assert_array_equal(x1, x2)          # same seed, same program -> same bits
+    x3 = sp.rand(1000, 9).glom()
+    assert not np.array_equal(x1, x3)              # the stream advances
+  finally:
+    sp.shutdown()
+
+
+@pytest.mark.gpu
+def test_random_fill_kernel_statistics_and_counter_semantics():
+  import torch
+  from spartan_amd import kernels
+  n = 1 << 20
+  for dt, tol in ((torch.float32, 2e-3), (torch.float64, 2e-3)):
+    u = torch.empty(n, dtype=dt, device='cuda:0')
+    kernels.random_fill(u, 'uniform', 1234, 0)
+    h = u.double().cpu().numpy()
+    assert h.min() >= 0.0 and h.max() < 1.0
+    assert abs(h.mean() - 0.5) < tol and abs(h.var() - 1.0 / 12) < tol
+    hist = np.histogram(h, bins=64, range=(0, 1))[0]
+    assert np.abs(hist / (n / 64.0) - 1).max() < 0.05
+    g = torch.empty(n, dtype=dt, device='cuda:0')
+    kernels.random_fill(g, 'normal', 1234, 0)
+    gh = g.double().cpu().numpy()
+    assert abs(gh.mean()) < 5e-3 and abs(gh.var() - 1) < 1e-2
+    assert abs(((gh - gh.mean()) ** 4).mean() / gh.var() ** 2 - 3.0) < 0.05       # kurtosis of a normal
+    assert abs(np.corrcoef(gh[0::2], gh[1::2])[0, 1]) < 5e-3                       # the Box-Muller pair is uncorrelated
+  # position semantics: one fill of n == two consecutive fills of n/2 (launch geometry is irrelevant)
+  a = torch.empty(n, dtype=torch.float64, device='cuda:0')
+  kernels.random_fill(a, 'uniform', 77, 0)
+  b = torch.empty(n, dtype=torch.float64, device='cuda:0')
+  kernels.random_fill(b[: n // 2], 'uniform', 77, 0)
+  kernels.random_fill(b[n // 2:], 'uniform', 77, n // 2)
+  assert torch.equal(a, b)
+  c = torch.empty(n, dtype=torch.float64, device='cuda:0')
+  kernels.random_fill(c, 'uniform', 78, 0)
+  assert not torch.equal(a, c)
+  k = torch.empty(100001, dtype=torch.int64, device='cuda:0')
+  kernels.random_fill(k, 'randint', 5, 0, -3, 4)
+  kh = k.cpu().numpy()
+  assert kh.min() == -3 and kh.max() == 3
+  assert np.abs(np.bincount(kh + 3, minlength=7) / (len(kh) / 7.0) - 1).max() < 0.05
