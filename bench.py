@@ -240,7 +240,8 @@ def main():
     hint = (n, n)
     workload = ('spartan.dot (%dx%d).(%dx%d) fp32, A and C row-tiled %d x (%dx%d), B all-gathered per step'
                 % (M, n, n, n, p, n, n))
-    parallelism = 'row tiles, 1 worker per GPU, RCCL all-gather of B'
+    parallelism = ('row tiles, 1 worker per GPU; B re-gathered every step as asynchronous RCCL all-gathers of '
+                   'column chunks, one GEMM per chunk behind them')
 
   keep = []
 
@@ -252,8 +253,11 @@ def main():
   ctx.backend.gemm_events = []
   dt = time_steps(ctx, step, args.steps, args.warmup)
   torch.cuda.synchronize()
-  events = ctx.backend.gemm_events[-args.steps:] if world.size == 1 else ctx.backend.gemm_events[-args.steps:]
+  all_events = ctx.backend.gemm_events
   ctx.backend.gemm_events = None
+  # launches per step: 1 on one GPU; one per gathered column chunk of B on several (dot_chunked)
+  per_step = max(1, len(all_events) // (args.steps + args.warmup))
+  events = all_events[-args.steps * per_step:]
   kernel_ms = [e0.elapsed_ms(e1) for (e0, e1, _, _, _) in events]
   flops_launch = 2.0 * events[0][2] * events[0][3] * events[0][4]
   avg_ms = sum(kernel_ms) / len(kernel_ms)
@@ -270,7 +274,8 @@ def main():
       'roofline': {'bound': 'mfma', 'kernel': 'sp_gemm_kernel<256,128,16,2,2> (v_mfma_f32_32x32x2_f32)',
                    'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                   'flop_per_launch': flops_launch, 'avg_launch_ms': round(avg_ms, 4), 'traffic': None},
+                   'flop_per_launch': flops_launch, 'avg_launch_ms': round(avg_ms, 4),
+                   'launches_per_step': per_step, 'traffic': None},
   }
   traffic_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
   if os.path.exists(traffic_file):

@@ -180,6 +180,14 @@ class NumpyBackend(object):
     self.launches += 1
     return self._wrap(_np(a).dot(_np(b)))
 
+  def dot_chunked(self, a, rhs):
+    """Host-framework counterpart of HipBackend.dot_chunked (column chunks of a gathered B)."""
+    parts = [None] * len(rhs.chunks)
+    for i in range(len(rhs.chunks)):
+      c0, c1, t = rhs.ready(i)
+      parts[i] = _np(t)
+    return self.dot(a, self._wrap(np.concatenate(parts, axis=1)))
+
   # -- k-means tile bodies: the reference's own NumPy/SciPy statements
   def nearest_center(self, points, centers, tier=0):
     """k_means_.py:61-66: np.argmin(cdist(points, centers), axis=1)."""

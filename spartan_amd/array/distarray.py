@@ -160,6 +160,24 @@ class DistArray(object):
     return len(self.shape)
 
 
+class ChunkedWhole(object):
+  """A whole 2-D array replicated as column chunks that may still be in flight:
+  chunks = [(col0, col1, tensor (rows, col1-col0), work handle or None, keep-alive)]."""
+
+  def __init__(self, shape, dtype, chunks):
+    self.shape = tuple(shape)
+    self.dtype = np.dtype(dtype)
+    self.chunks = chunks
+
+  def ready(self, i):
+    """Make the current stream wait for chunk i and return (col0, col1, tensor)."""
+    c0, c1, t, work, _ = self.chunks[i]
+    if work is not None:
+      work.wait()
+      self.chunks[i] = (c0, c1, t, None, None)
+    return c0, c1, t
+
+
 class UpdateBatch(object):
   """Updates issued while one kernel (foreach_tile) runs, joined at its end --
   the reference collects `target.update(..., wait=False)` futures and joins them
@@ -479,6 +497,46 @@ class DistArrayImpl(DistArray):
       if extent.all_nonzero_shape(buf.shape):
         be.paste(tgt, extent.offset_slice(region, inter), buf)
     return tgt
+
+  def fetch_whole_chunked(self, chunk_cols):
+    """Replicate a row-tiled 2-D array on every rank as COLUMN chunks gathered by independent,
+    asynchronous all-gathers (one per chunk), so that a consumer can start on chunk 0 while the
+    later chunks are still on the wire (dot's outer path: the gather of B hides behind the GEMM).
+    Returns ChunkedWhole or None when the pattern does not apply (the caller then uses fetch()).
+    Collective: every rank must call it at the same point of the tile walk."""
+    ctx = self.ctx
+    be = ctx.backend
+    world = ctx.world
+    if not world.distributed or ctx.num_workers != world.size or len(self.shape) != 2:
+      return None
+    rows, cols = self.shape
+    if chunk_cols <= 0 or cols % chunk_cols != 0 or cols // chunk_cols < 2:
+      return None
+    tiles = sorted(self.tiles.items(), key=lambda kv: kv[0].ul)
+    if len(tiles) != world.size or rows % world.size != 0:
+      return None
+    step = rows // world.size
+    for r, (ex, tid) in enumerate(tiles):
+      if (ctx.rank_of(tid.worker) != r or ex.ul != (r * step, 0) or ex.lr != ((r + 1) * step, cols)):
+        return None
+    cache = ctx.fetch_cache
+    key = (self.id, 'chunked', chunk_cols)
+    if cache is not None and key in cache:
+      return cache[key]
+    ex, tid = tiles[world.rank]
+    mine = self._tile_piece(tid, ex, ex)
+    if isinstance(mine, tile.EmptyBlob):
+      return None
+    chunks = []
+    for c0 in range(0, cols, chunk_cols):
+      piece = be.copy(mine[:, c0:c0 + chunk_cols])          # contiguous (step, chunk_cols) block of my rows
+      out = be.empty((rows, chunk_cols), self.dtype)         # rank-ordered row blocks == B[:, c0:c1], ld = chunk_cols
+      work = world.all_gather_into_async(out, piece)
+      chunks.append((c0, c0 + chunk_cols, out, work, piece))
+    whole = ChunkedWhole(self.shape, self.dtype, chunks)
+    if cache is not None:
+      cache[key] = whole
+    return whole
 
   def update_slice(self, slc, data):
     return self.update(extent.from_slice(slc, self.shape), data)

@@ -372,6 +372,34 @@ class HipBackend(object):
       return self._run_reduce(prod, 'SUM', res_dt, (M, K, N), 1)
     raise lower.NotLowerable('dot of %d-d and %d-d operands' % (a.dim(), b.dim()))
 
+  def dot_chunked(self, a, rhs):
+    """a . B with B arriving as column chunks (distarray.ChunkedWhole): one GEMM per chunk into the
+    matching columns of C, each launched as soon as its chunk's gather has landed, so the remaining
+    gathers (RCCL stream) overlap with the GEMMs (this stream)."""
+    if not (a.dim() == 2 and self.dtype_of(a) == np.float32 and rhs.dtype == np.float32):
+      whole = self.empty(rhs.shape, rhs.dtype)
+      for i in range(len(rhs.chunks)):
+        c0, c1, t = rhs.ready(i)
+        self.paste(whole, (slice(0, rhs.shape[0]), slice(c0, c1)), t)
+      return self.dot(a, whole)
+    M, K = a.shape
+    N = rhs.shape[1]
+    if a.stride(1) != 1:
+      a = self.copy(a)
+    c = self.empty((M, N), np.float32)
+    for i in range(len(rhs.chunks)):
+      c0, c1, t = rhs.ready(i)
+      self.launches += 1
+      if self.gemm_events is not None:
+        e0, e1 = kernels.Event(), kernels.Event()
+        e0.record()
+        kernels.gemm_f32(a, t, c[:, c0:c1], accumulate=False)
+        e1.record()
+        self.gemm_events.append((e0, e1, M, c1 - c0, K))
+      else:
+        kernels.gemm_f32(a, t, c[:, c0:c1], accumulate=False)
+    return c
+
   # -- k-means tile bodies (examples/sklearn/cluster/k_means_.py) ---------------------
   def _as_device(self, t):
     if isinstance(t, np.ndarray):

@@ -129,6 +129,17 @@ class World(object):
       return
     dist.all_gather_into_tensor(out, tensor, group=self.group)
 
+  def all_gather_into_async(self, out, tensor):
+    """all_gather_into without waiting: returns a handle whose wait() makes the CURRENT STREAM wait
+    for the result (the collective runs on RCCL's own stream, so kernels launched meanwhile overlap
+    with it).  The staged / CPU debug transports complete immediately and return None."""
+    if self.staged or not tensor.is_cuda:
+      self.all_gather_into(out, tensor)
+      return None
+    self.stats['collectives'] += 1
+    self.stats['collective_bytes'] += tensor.numel() * tensor.element_size() * (self.size - 1)
+    return dist.all_gather_into_tensor(out, tensor, group=self.group, async_op=True)
+
   def reduce_scatter(self, out, inp, reducer):
     """out[rank chunk] = reduce over ranks of inp (inp = size equal chunks)."""
     self.stats['collectives'] += 1

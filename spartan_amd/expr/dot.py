@@ -14,6 +14,10 @@ from ..array import distarray, extent
 def _dot(a, b):
   """`a.dot(b)` on backend tensors (Absent on non-executing ranks)."""
   ctx = context.get()
+  if isinstance(b, distarray.ChunkedWhole):
+    if isinstance(a, distarray.Absent):
+      return distarray.Absent((a.shape[0], b.shape[1]), a.dtype)
+    return ctx.backend.dot_chunked(a, b)
   if isinstance(a, distarray.Absent) or isinstance(b, distarray.Absent):
     ash, bsh = tuple(a.shape), tuple(b.shape)
     if len(ash) == 1 and len(bsh) == 1:
@@ -85,6 +89,23 @@ def dot_outer_mapper(ex_a, tile_a, ex_b, tile_b):
     shape = (ex_a.array_shape[0], ex_b.array_shape[1])
   target_ex = extent.create(ul, lr, shape)
   yield target_ex, _dot(tile_a, tile_b)
+
+
+def _fetch_whole_rhs(array, whole_extent):
+  """dot_outer_mapper's B: every worker needs ALL of it (outer.py:21-29).  Across GPUs the
+  gather is issued as a few asynchronous column-chunk all-gathers and the GEMM runs chunk by
+  chunk behind them (SPARTAN_RHS_CHUNK_COLS columns per chunk, 0 = one blocking gather)."""
+  import os
+  chunk_cols = int(os.environ.get('SPARTAN_RHS_CHUNK_COLS', '2048'))
+  if chunk_cols > 0 and len(array.shape) == 2 and hasattr(array, 'fetch_whole_chunked') \
+      and hasattr(context.get().backend, 'dot_chunked'):
+    whole = array.fetch_whole_chunked(chunk_cols)
+    if whole is not None:
+      return whole
+  return array.fetch(whole_extent)
+
+
+dot_outer_mapper.fetch_rhs = _fetch_whole_rhs
 
 
 def dot(a, b, tile_hint=None):

@@ -15,7 +15,10 @@ def outer_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target):
     local_user_fn_kw = {}
   if axes[1] is None:
     outer_extent = extent.from_shape(arrays[1].shape)
-    outer_tile = arrays[1].fetch(outer_extent)
+    # a mapper may bring its own way of fetching the whole right-hand array (dot: column chunks
+    # gathered asynchronously so the gather overlaps the GEMM); default: one replicated fetch
+    fetch_rhs = getattr(local_user_fn, 'fetch_rhs', None)
+    outer_tile = fetch_rhs(arrays[1], outer_extent) if fetch_rhs is not None else arrays[1].fetch(outer_extent)
     result = local_user_fn(first_extent, first_tile, outer_extent, outer_tile, **local_user_fn_kw)
     if result is not None:
       for tex, v in result:

@@ -66,6 +66,20 @@ def main():
     np.testing.assert_array_equal(d, (np.arange(32 * 64, dtype=np.float32).reshape(32, 64) % 5).dot(
         np.arange(64 * 32, dtype=np.float32).reshape(64, 32) % 7))
     assert world.stats['collectives'] > before['collectives'], world.stats
+  # tall dot (outer path): B is gathered as asynchronous column chunks, one GEMM per chunk
+  os.environ['SPARTAN_RHS_CHUNK_COLS'] = '8'
+  ta = np.arange(128 * 32, dtype=np.float32).reshape(128, 32) % 11
+  tb = np.arange(32 * 16, dtype=np.float32).reshape(32, 16) % 3
+  before = dict(world.stats)
+  got = sp.dot(sp.from_numpy(ta), sp.from_numpy(tb), tile_hint=(128 // workers, 16)).glom()
+  np.testing.assert_array_equal(got, ta.dot(tb))
+  if workers == world.size:
+    assert world.stats['collectives'] >= before['collectives'] + 2, (before, world.stats)   # 2 column chunks
+  os.environ['SPARTAN_RHS_CHUNK_COLS'] = '0'
+  got = sp.dot(sp.from_numpy(ta), sp.from_numpy(tb), tile_hint=(128 // workers, 16)).glom()
+  np.testing.assert_array_equal(got, ta.dot(tb))
+  del os.environ['SPARTAN_RHS_CHUNK_COLS']
+  n += 2
   # the example drivers across ranks: identical to the single-process goldens of the reference
   # (tile->worker round robin puts tiles on both ranks; every rank must see the same result)
   n += run_examples(workers)
