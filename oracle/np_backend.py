@@ -157,7 +157,18 @@ class NumpyBackend(object):
 
   def evaluate_map(self, op, inputs, ex):
     self.launches += 1
+    if getattr(getattr(op, 'fn', None), '_sp_tile_fn', False):
+      # a local function written against backend tensors (region_map ...): same call as on the GPU
+      args = [ex.to_tuple() if d.idx == 'extent' else inputs[d.idx] for d in op.deps]
+      return op.fn(*args, **(op.kw or {}))
     return self._wrap(self._eval(op, inputs, ex), ex.shape)
+
+  def assign_box(self, dst, slices, value):
+    view = dst[slices]
+    if isinstance(value, torch.Tensor):
+      view.copy_(value.reshape(view.shape))
+    else:
+      view.copy_(torch.from_numpy(np.broadcast_to(np.asarray(value), tuple(view.shape)).astype(_T2NP[dst.dtype])))
 
   def evaluate_fn(self, fn, args, kw, out_shape):
     self.launches += 1
@@ -208,6 +219,17 @@ class NumpyBackend(object):
     for i in range(int(k)):
       out[i] = pts[lab == i].sum(axis=0)
     return self._wrap(out)
+
+  def weighted_bincount(self, labels, weights, k):
+    """statistics.py:108-111."""
+    self.launches += 1
+    return self._wrap(np.bincount(_np(labels).reshape(-1).astype(np.int64), weights=_np(weights).reshape(-1),
+                                  minlength=int(k))[:int(k)])
+
+  def concat(self, a, b, axis=0):
+    """manipulation.py:51."""
+    self.launches += 1
+    return self._wrap(np.concatenate((_np(a), _np(b)), axis=axis))
 
   def synchronize(self):
     pass

@@ -289,6 +289,8 @@ class UpdateBatch(object):
           if exec_rank == world.rank and owner == world.rank:
             piece = data if whole else data[src_slice]
             merges.append((tile_id, dst_slice, piece, owned and whole))
+          elif worker is None:
+            pass   # driver-level update: the data is replicated, every owner merges its own part
           elif exec_rank == world.rank:
             piece = data if whole else data[src_slice]
             sends.append((owner, be.contiguous(be.astype(piece, array.dtype))))

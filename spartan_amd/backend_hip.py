@@ -178,12 +178,36 @@ class HipBackend(object):
     rnd = getattr(getattr(op, 'fn', None), '_sp_random', None)
     if rnd is not None:
       return self.random_tile(rnd[0], ex.shape, rnd[1], **(op.kw or {}))
+    if getattr(getattr(op, 'fn', None), '_sp_tile_fn', False):
+      return self._call_tile_fn(op, inputs, ex)
     op, inputs = self._materialise_random(op, inputs, ex)
     try:
       root = lower.infer(op, inputs, ex, self.dtype_of)
       return self._run_map(root, root.shape if root.kind != 'const' else ex.shape)
     except ProgramTooLarge:
       return self._evaluate_split(op, inputs, ex)
+
+  def _call_tile_fn(self, op, inputs, ex):
+    """A local function that works on backend tensors itself (region_map, k-means bodies ...)."""
+    args = []
+    for d in op.deps:
+      if not isinstance(d, LocalInput):
+        raise lower.NotLowerable('%s takes whole tiles: it cannot be fused with other local ops' % op.fn_name())
+      args.append(ex.to_tuple() if d.idx == 'extent' else inputs[d.idx])
+    self.launches += 1
+    return op.fn(*args, **(op.kw or {}))
+
+  def assign_box(self, dst, slices, value):
+    """dst[slices] = value; value: Python/NumPy scalar (fill), NumPy array or backend tensor."""
+    view = dst[slices]
+    dt = self.dtype_of(dst)
+    if np.isscalar(value) or (isinstance(value, np.ndarray) and value.ndim == 0):
+      src = self._run_map(lower.const(np.asarray(value).astype(dt)[()], dt), tuple(view.shape), dt)
+    elif isinstance(value, np.ndarray):
+      src = self.from_numpy(np.broadcast_to(value, tuple(view.shape)).astype(dt))
+    else:
+      src = self.astype(value, dt)
+    self.paste(dst, slices, src)
 
   def _materialise_random(self, op, inputs, ex):
     """Random sources fused INTO a tree (the reference's fusion does that despite @not_idempotent,
@@ -440,6 +464,28 @@ class HipBackend(object):
     out = self.empty((int(k), points.shape[1]), self.dtype_of(points))
     self.launches += 1
     return kernels.segment_sum(points, labels, int(k), out)
+
+  def weighted_bincount(self, labels, weights, k):
+    """np.bincount(labels, weights=weights, minlength=k) (statistics.py:108-111): the segment sums
+    of a one-column matrix."""
+    n = int(np.prod(labels.shape))
+    w = self.contiguous(weights).reshape(n, 1)
+    if self.dtype_of(w) not in (np.float32, np.float64):
+      w = self.astype(w, np.float64)
+    return self.segment_sum(w, labels, k).reshape(int(k))
+
+  def concat(self, a, b, axis=0):
+    """np.concatenate((a, b), axis) as two box copies (manipulation.py:51)."""
+    dt = np.result_type(self.dtype_of(a), self.dtype_of(b))
+    shape = list(a.shape)
+    shape[axis] += b.shape[axis]
+    out = self.empty(shape, dt)
+    lo = [slice(0, n) for n in a.shape]
+    self.paste(out, tuple(lo), self.astype(a, dt))
+    hi = [slice(0, n) for n in b.shape]
+    hi[axis] = slice(a.shape[axis], shape[axis])
+    self.paste(out, tuple(hi), self.astype(b, dt))
+    return out
 
   def synchronize(self):
     torch.cuda.synchronize(self.device)

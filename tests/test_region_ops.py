@@ -1,0 +1,92 @@
+"""write / assign / region_map / retile / concatenate / bincount / norm / normalize (the callers next
+to the map-reduce path: reference write_array.py, assign.py, region_map.py, retile.py,
+manipulation.py:45-88, statistics.py:108-228) against NumPy on the same inputs; integer-valued
+data, so results are bit-exact.  CPU leg on the oracle backend, GPU leg on the HIP kernels."""
+import numpy as np
+import pytest
+
+import spartan_amd as sp
+
+
+def _check_all():
+  a = (np.arange(40 * 6, dtype=np.float32).reshape(40, 6) % 17)
+  A = sp.from_numpy(a).evaluate()
+  # assign: scalar / ndarray / distributed value; the source array is NOT modified (region_map copies)
+  want = a.copy()
+  want[5:25, 1:4] = 7.5
+  np.testing.assert_array_equal(sp.assign(A, np.index_exp[5:25, 1:4], 7.5).glom(), want)
+  v = -np.arange(20 * 3, dtype=np.float32).reshape(20, 3)
+  want[5:25, 1:4] = v
+  np.testing.assert_array_equal(sp.assign(A, np.index_exp[5:25, 1:4], v).glom(), want)
+  V = sp.from_numpy(v).evaluate()
+  np.testing.assert_array_equal(sp.assign(A, np.index_exp[5:25, 1:4], V).glom(), want)
+  np.testing.assert_array_equal(sp.assign(A, 3, 1.0).glom()[3], np.ones(6, np.float32))
+  np.testing.assert_array_equal(A.glom(), a)
+  # region_map with a backend-level function
+  def minus_one(view, ex):
+    assert tuple(view.shape)[1] == 6          # a backend tensor view of the intersection
+    return -1.0
+  got = sp.region_map(A, sp.extent.from_slice(np.index_exp[0:10, 0:6], a.shape), minus_one).glom()
+  want2 = a.copy()
+  want2[0:10] = -1
+  np.testing.assert_array_equal(got, want2)
+  # retile keeps the values, changes the tiles
+  R = sp.retile(A, (40, 2)).evaluate()
+  np.testing.assert_array_equal(R.glom(), a)
+  assert all(ex.shape[1] <= 2 for ex in R.tiles)
+  # write mutates in place (write_array.py:1-9), from host data and from another distributed array
+  Bm = sp.from_numpy(a.copy()).evaluate()
+  sp.write(Bm, np.index_exp[0:10, 0:6], np.full((10, 6), 3, np.float32), np.index_exp[0:10, 0:6]).evaluate()
+  w = a.copy()
+  w[0:10] = 3
+  np.testing.assert_array_equal(Bm.glom(), w)
+  sp.write(Bm, np.index_exp[30:40, 0:3], V, np.index_exp[5:15, 0:3]).evaluate()
+  w[30:40, 0:3] = v[5:15]
+  np.testing.assert_array_equal(Bm.glom(), w)
+  # concatenate, both axes and 1-D
+  b = (np.arange(40 * 6, dtype=np.float32).reshape(40, 6) % 5)
+  np.testing.assert_array_equal(sp.concatenate(sp.from_numpy(a), sp.from_numpy(b), axis=1).glom(),
+                                np.concatenate((a, b), axis=1))
+  np.testing.assert_array_equal(sp.concatenate(sp.from_numpy(a), sp.from_numpy(b), axis=0).glom(),
+                                np.concatenate((a, b), axis=0))
+  np.testing.assert_array_equal(sp.concatenate(sp.from_numpy(a[:, 0].copy()), sp.from_numpy(b[:, 1].copy())).glom(),
+                                np.concatenate((a[:, 0], b[:, 1])))
+  with pytest.raises(ValueError):
+    sp.concatenate(sp.from_numpy(a), sp.from_numpy(b[:, :5].copy()), axis=0)
+  # bincount, with and without weights
+  lab = (np.arange(1000) * 7 % 13).astype(np.int64)
+  wts = (np.arange(1000) % 4).astype(np.float64)
+  np.testing.assert_array_equal(sp.bincount(sp.from_numpy(lab)).glom(), np.bincount(lab))
+  np.testing.assert_array_equal(sp.bincount(sp.from_numpy(lab), minlength=20).glom(), np.bincount(lab, minlength=20))
+  np.testing.assert_array_equal(sp.bincount(sp.from_numpy(lab), weights=sp.from_numpy(wts)).glom(),
+                                np.bincount(lab, weights=wts))
+  # norm / normalize
+  assert sp.norm(sp.from_numpy(a), 1) == np.abs(a).sum(axis=0).max()
+  x = a[:, 0].copy()
+  np.testing.assert_allclose(sp.norm(sp.from_numpy(x), 2), np.sqrt((x.astype(np.float64) ** 2).sum()), rtol=1e-6)
+  p = a + 1
+  np.testing.assert_allclose(sp.normalize(sp.from_numpy(p)).glom(), p / p.sum(), rtol=1e-6)
+  np.testing.assert_allclose(sp.normalize(sp.from_numpy(p), axis=0).glom(), p / p.sum(axis=0), rtol=1e-6)
+  np.testing.assert_allclose(sp.normalize(sp.from_numpy(p), axis=1).glom(), p / p.sum(axis=1)[:, None], rtol=1e-6)
+
+
+@pytest.mark.parametrize('workers', [1, 4])
+def test_region_ops_host_framework(workers):
+  from oracle.np_backend import NumpyBackend
+  sp.initialize(backend=NumpyBackend(), num_workers=workers)
+  try:
+    _check_all()
+  finally:
+    sp.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workers', [1, 3])
+def test_region_ops_hip(workers):
+  ctx = sp.initialize('hip', num_workers=workers)
+  try:
+    before = ctx.backend.launches
+    _check_all()
+    assert ctx.backend.launches > before
+  finally:
+    sp.shutdown()
