@@ -1,0 +1,75 @@
+"""save / load / pickle / unpickle in the reference's on-disk layout (spartan/expr/fio.py).
+The reference's writer cannot run here (Python-2 str/bytes file handling), so the layout is pinned by
+(i) a file assembled byte by byte the way fio.py:70-112 assembles it, read back through `load`, and
+(ii) round trips through both backends, zipped and unzipped, for several tilings."""
+import os
+
+import numpy as np
+import pytest
+
+import spartan_amd as sp
+
+
+def _reference_style_tile_file(path, prefix, ul, lr, data):
+  """fio.py:70-112 restated: magic, 2-byte LE dict length, str(dict) space-padded to 16 B, raw bytes."""
+  tile_dict = {'dtype': str(data.dtype), 'shape': data.shape, 'type': "DENSITY", 'lr': lr, 'ul': ul}
+  cnt = b"\x93NUMPY\x01\x00"
+  dict_cnt = str(tile_dict)
+  if (len(cnt) + 2 + len(dict_cnt)) % 16 != 0:
+    dict_cnt += (16 - (len(cnt) + 2 + len(dict_cnt)) % 16) * ' '
+  cnt += bytes([len(dict_cnt) % 256, len(dict_cnt) // 256]) + dict_cnt.encode('latin-1')
+  os.makedirs(os.path.join(path, prefix), exist_ok=True)
+  with open(os.path.join(path, prefix, '%s_%s_%s_spf' % (prefix, str(ul), str(lr))), 'wb') as fp:
+    fp.write(cnt)
+    fp.write(data.tobytes())
+
+
+def _check(tmp):
+  a = (np.arange(48 * 10, dtype=np.float32).reshape(48, 10) % 23) - 7
+  # (i) files laid out by hand exactly as the reference lays them out, two row tiles of 24
+  _reference_style_tile_file(tmp, 'ref', (0, 0), (24, 10), a[:24])
+  _reference_style_tile_file(tmp, 'ref', (24, 0), (48, 10), a[24:])
+  with open(os.path.join(tmp, 'ref', 'ref_dist.spf'), 'w') as fp:
+    fp.write('48 10 \n24 10 \nfloat32\nDENSITY\n')            # fio.py:115-131
+  L = sp.load('ref', path=tmp).evaluate()
+  assert L.dtype == np.float32 and L.shape == (48, 10)
+  assert sorted(ex.ul for ex in L.tiles) == [(0, 0), (24, 0)]
+  np.testing.assert_array_equal(L.glom(), a)
+  # (ii) round trips
+  for dtype in (np.float32, np.float64, np.int64):
+    x = a.astype(dtype)
+    for hint in (None, (12, 10), (48, 5)):
+      X = sp.from_numpy(x, tile_hint=hint).evaluate() if hint else sp.from_numpy(x).evaluate()
+      for z in (False, True):
+        name = 'rt_%s_%s_%d' % (np.dtype(dtype).name, 'x'.join(map(str, hint)) if hint else 'd', z)
+        assert sp.save(X, name, path=tmp, iszip=z) is True
+        Y = sp.load(name, path=tmp, iszip=z).evaluate()
+        assert Y.dtype == np.dtype(dtype) and sorted(Y.tiles) == sorted(X.tiles)
+        np.testing.assert_array_equal(Y.glom(), x)
+        assert sp.pickle(X, name + 'p', path=tmp, iszip=z) is True
+        np.testing.assert_array_equal(sp.unpickle(name + 'p', path=tmp, iszip=z).glom(), x)
+  # an expression can be saved directly; a missing prefix is an IOError as in the reference (fio.py:196-197)
+  assert sp.save(sp.from_numpy(a) + 1, 'expr', path=tmp)
+  np.testing.assert_array_equal(sp.load('expr', path=tmp).glom(), a + 1)
+  with pytest.raises(IOError):
+    sp.load('nothing-here', path=tmp)
+
+
+@pytest.mark.parametrize('workers', [1, 4])
+def test_fio_host_framework(workers, tmp_path):
+  from oracle.np_backend import NumpyBackend
+  sp.initialize(backend=NumpyBackend(), num_workers=workers)
+  try:
+    _check(str(tmp_path))
+  finally:
+    sp.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workers', [1, 3])
+def test_fio_hip(workers, tmp_path):
+  sp.initialize('hip', num_workers=workers)
+  try:
+    _check(str(tmp_path))
+  finally:
+    sp.shutdown()
