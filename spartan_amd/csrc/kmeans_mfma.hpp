@@ -22,10 +22,10 @@ typedef float km_f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int KM_BM = 128, KM_BN = 128, KM_BK = 16;
+constexpr int KM_BM = 128, KM_BK = 16;
+constexpr int KM_BN_MAX = 256;   // centers are padded to a multiple of this (any column-block width divides it)
 constexpr int KM_LDA = KM_BK + 4;
-constexpr int KM_A_FLOATS = KM_BM * KM_LDA, KM_B_FLOATS = KM_BK * KM_BN;
-constexpr int KM_STAGE = KM_A_FLOATS + KM_B_FLOATS;
+constexpr int KM_A_FLOATS = KM_BM * KM_LDA;
 
 // Ct[j][c] = (float)C[c][j] (zero padded to [dp][kp]); cn[c] = |C[c]|^2 / 2 (fp64 sum, rounded; +inf on padding);
 // *cmax2 = max_c |C[c]|^2 (as float bits; non-negative floats order like unsigned ints)
@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void sp_centers_prep_kernel(const TC* __restri
   atomicMax(cmax2, __float_as_uint(sf * 1.0000002f));
 }
 
-template <bool FAST>
+// TN: 32-column MFMA tiles per wave along the centers (column block of the workgroup = 64 * TN)
+template <bool FAST, int TN>
 __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* __restrict__ X, int64_t ldx,
                                                                   const float* __restrict__ Ct,
                                                                   const float* __restrict__ chalf,
@@ -59,6 +60,8 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
                                                                   int d, int kp, int64_t* __restrict__ labels,
                                                                   int* __restrict__ amb_rows,
                                                                   int* __restrict__ amb_count) {
+  constexpr int KM_BN = 64 * TN, KM_B_FLOATS = KM_BK * KM_BN, KM_STAGE = KM_A_FLOATS + KM_B_FLOATS;
+  constexpr int BV = TN;   // float4 of B per thread per k-step
   __shared__ __attribute__((aligned(16))) float smem[2 * KM_STAGE];
   __shared__ float xn_s[KM_BM];
   __shared__ float mb_s[KM_BM], ms_s[KM_BM];
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
   const int m0 = blockIdx.x * KM_BM;
 
   const float* __restrict__ Ablk = X + (int64_t)m0 * ldx;
-  int a_off[2], a_lds[2], b_off[2], b_lds[2];
+  int a_off[2], a_lds[2], b_off[BV], b_lds[BV];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int e = tid + j * THREADS;
@@ -80,6 +83,10 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
     a_lds[j] = row * KM_LDA + kq * 4;
     if (m0 + row > n - 1) row = n - 1 - m0;   // clamp: results of rows >= n are discarded
     a_off[j] = row * (int)ldx + kq * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < BV; ++j) {
+    const int e = tid + j * THREADS;
     const int brow = e / NQ, nq = e % NQ;
     b_lds[j] = brow * KM_BN + nq * 4;
     b_off[j] = brow * kp + nq * 4;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
   const int nt = (d + KM_BK - 1) / KM_BK;
   const int tiles_n = kp / KM_BN;
   const int steps = nt * tiles_n;
-  km_f32x4 ra[2], rb[2];
+  km_f32x4 ra[2], rb[BV];
 
 #define KM_LOAD(step)                                                                    \
   do {                                                                                   \
@@ -105,24 +112,22 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
         ra[j].z = kk + 2 < d ? p[2] : 0.f;                                               \
         ra[j].w = kk + 3 < d ? p[3] : 0.f;                                               \
       }                                                                                  \
-      rb[j] = *(const km_f32x4*)(Bk_ + b_off[j]);                                        \
     }                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < BV; ++j) rb[j] = *(const km_f32x4*)(Bk_ + b_off[j]); \
   } while (0)
 #define KM_STORE(buf)                                                                    \
   do {                                                                                   \
     float* sA_ = smem + (buf) * KM_STAGE;                                                \
     float* sB_ = sA_ + KM_A_FLOATS;                                                      \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                      \
-      *(km_f32x4*)(sA_ + a_lds[j]) = ra[j];                                              \
-      *(km_f32x4*)(sB_ + b_lds[j]) = rb[j];                                              \
-    }                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) *(km_f32x4*)(sA_ + a_lds[j]) = ra[j];  \
+    _Pragma("unroll") for (int j = 0; j < BV; ++j) *(km_f32x4*)(sB_ + b_lds[j]) = rb[j]; \
   } while (0)
 
-  km_f32x16 acc[2][2];
+  km_f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float best[2][16], second[2][16];
@@ -144,11 +149,11 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
   KM_STORE(0);
   __syncthreads();
   const int a_frag = (wm * 64 + l31) * KM_LDA + 4 * lh;
-  const int b_frag = (4 * lh) * KM_BN + wn * 64 + l31;
+  const int b_frag = (4 * lh) * KM_BN + wn * (32 * TN) + l31;
 
-  float chv[2];   // |c|^2 / 2 of this lane's two columns of the current center block (fetched a block ahead of use)
+  float chv[TN];   // |c|^2 / 2 of this lane's two columns of the current center block (fetched a block ahead of use)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) chv[j] = chalf[(wn * 2 + j) * 32 + l31];
+  for (int j = 0; j < TN; ++j) chv[j] = chalf[(wn * TN + j) * 32 + l31];
   int t = 0;
   for (int tn = 0; tn < tiles_n; ++tn) {
     // ---- contraction over the features for center block tn: one straight-line body per k-step
@@ -159,11 +164,11 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
 #pragma unroll
       for (int c = 0; c < KM_BK / 8; ++c) {
         km_f32x4 af[2];
-        float bf[2][4];
+        float bf[TN][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i] = *(const km_f32x4*)(sA + a_frag + i * 32 * KM_LDA + c * 8);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag + (c * 8 + s) * KM_BN + j * 32];
         // |x|^2 is accumulated on every pass over the point block (no branch in this loop) and
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
       }
       if (t + 1 < steps) KM_STORE((t + 1) & 1);
@@ -187,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
     // basic block per accumulator).  Scores are kept halved, h = |c|^2/2 - x.c; columns ascend
     // with j, so `<` keeps the first minimum.  Invariant: best <= second.
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int tile = tn * 4 + wn * 2 + j;
+    for (int j = 0; j < TN; ++j) {
+      const int tile = tn * (2 * TN) + wn * TN + j;
       const float ch = chv[j];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
     }
     if (tn + 1 < tiles_n) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) chv[j] = chalf[((tn + 1) * 4 + wn * 2 + j) * 32 + l31];
+      for (int j = 0; j < TN; ++j) chv[j] = chalf[((tn + 1) * (2 * TN) + wn * TN + j) * 32 + l31];
     }
   }
 #undef KM_LOAD
@@ -300,14 +305,14 @@ struct KmWorkspace {
 static inline size_t km_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t sp_nearest_fused_ws_bytes(int64_t n, int64_t k, int64_t d) {
-  const int64_t kp = km_round_up(k < 1 ? 1 : k, KM_BN), dp = km_round_up(d < 1 ? 1 : d, KM_BK);
+  const int64_t kp = km_round_up(k < 1 ? 1 : k, KM_BN_MAX), dp = km_round_up(d < 1 ? 1 : d, KM_BK);
   return 256 + km_align((size_t)(d < 1 ? 1 : d) * kp * 8) + km_align((size_t)dp * kp * 4) + km_align((size_t)kp * 4) + 256 + 256 +
          km_align((size_t)(n < 1 ? 1 : n) * 4);
 }
 
 static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
   KmWorkspace w;
-  w.kp = km_round_up(k, KM_BN);
+  w.kp = km_round_up(k, KM_BN_MAX);
   w.dp = km_round_up(d < 1 ? 1 : d, KM_BK);
   char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   w.Ct64 = (double*)p;
@@ -352,12 +357,25 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
   SP_CHECK_LAUNCH();
   const unsigned blocks = (unsigned)((n + KM_BM - 1) / KM_BM);
   const bool fast = (d % KM_BK == 0) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
-  if (fast)
-    hipLaunchKernelGGL((sp_nearest_fused_kernel<true>), dim3(blocks), dim3(256), 0, st, X, ldx, Ct, cn, cmax2, (int)n,
-                       (int)d, (int)kp, labels, w.amb_rows, w.amb_count);
-  else
-    hipLaunchKernelGGL((sp_nearest_fused_kernel<false>), dim3(blocks), dim3(256), 0, st, X, ldx, Ct, cn, cmax2, (int)n,
-                       (int)d, (int)kp, labels, w.amb_rows, w.amb_count);
+  // column block of a workgroup: 128 centers (2 MFMA tiles per wave).  256 (SP_KM_TN=4) needs 47 spilled
+  // registers at 2 workgroups/CU and measured 1.7 % slower (profiles/r01_notes.md)
+  static int tn_env = -1;
+  if (tn_env < 0) {
+    const char* e = getenv("SP_KM_TN");
+    tn_env = e ? atoi(e) : 0;
+  }
+  const int tn_sel = tn_env == 4 ? 4 : 2;
+#define KM_GO(F, T)                                                                                              \
+  hipLaunchKernelGGL((sp_nearest_fused_kernel<F, T>), dim3(blocks), dim3(256), 0, st, X, ldx, Ct, cn, cmax2, (int)n, \
+                     (int)d, (int)kp, labels, w.amb_rows, w.amb_count)
+  if (fast) {
+    if (tn_sel == 4) KM_GO(true, 4);
+    else KM_GO(true, 2);
+  } else {
+    if (tn_sel == 4) KM_GO(false, 4);
+    else KM_GO(false, 2);
+  }
+#undef KM_GO
   SP_CHECK_LAUNCH();
   return 0;
 }
