@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void sp_nearest_exact_kernel(const TX* __restr
                                                                int k, int d, int64_t* __restrict__ labels,
                                                                const int* __restrict__ rows,
                                                                const int* __restrict__ n_rows) {
-  constexpr int G = 2, R = 4, J = 4;
+  constexpr int G = 2, R = 8, J = 4;
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -450,7 +450,7 @@ extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ld
     rows = w.amb_rows;       // the exact kernel re-does the points the fused kernel listed as undecided
     n_rows = w.amb_count;
   }
-  const int64_t groups = (n + 3) / 4;   // 4 points per wave
+  const int64_t groups = (n + 7) / 8;   // 8 points per wave
   int64_t waves = rows ? (int64_t)SP_CUS * 16 : (groups < (int64_t)SP_CUS * 32 ? groups : (int64_t)SP_CUS * 32);
   const unsigned blocks = (unsigned)((waves + 3) / 4);
   if (dtype == SP_F32)
