@@ -3,8 +3,10 @@
 // (reference spartan/expr/operator/map.py:48-88, local.py:115-127).
 //
 // HBM roofline kernel: algorithmic bytes = sum(sizeof(in_j) for dense inputs)
-// + sizeof(out) per element; 16 B per lane per operand, grid capped at
-// 8 workgroups per CU with a grid-stride loop.
+// + sizeof(out) per element; 16 B per lane per operand.  Three tiers run the same
+// evaluator (sp_interp.hpp): prebuilt specialised kernels and run-time specialised
+// ones (sp_jit.hip) cover the tile with a full grid, one vector per lane; the
+// interpreter kernels use a grid capped at 8 workgroups per CU that strides.
 #include <type_traits>
 
 #include "map_kernel.hpp"

@@ -5,9 +5,10 @@
 
 // One workgroup handles U x 256 vectors of V elements (16 B each): group u of a
 // thread is 256 vectors after group u-1, so every load/store instruction of the
-// workgroup is a fully coalesced 4 KiB.  The grid covers the tile exactly (no
-// grid-stride loop: on MI355X a full grid streams ~25% faster than a capped,
-// grid-striding one -- tools/hbm_probe.hip, profiles/).
+// workgroup is a fully coalesced 4 KiB.  Specialised programs are launched with a
+// grid that covers the tile exactly (on MI355X a full grid streams ~25% faster than
+// a capped, grid-striding one -- tools/hbm_probe.hip, profiles/); the interpreter
+// launches a capped grid and this loop strides.
 template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1>
 __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, const sp_inputs in,
                                                           void* __restrict__ out, int64_t start,
