@@ -204,10 +204,20 @@ def cpu_baseline():
   t0 = time.perf_counter()
   cl.sum(X, 0).glom()
   t_sum = time.perf_counter() - t0
+  # one k-means iteration of the reference's map2 variant (cdist + argmin, bincount, masked sums) on a
+  # 1/125 sample of the configs[3] per-GPU tile, same k and d
+  kn, kk, kd = 10000, 1024, 256
+  pts = rng.rand(kn, kd).astype(np.float32)
+  cen = rng.rand(kk, kd)
+  t0 = time.perf_counter()
+  O.kmeans_fit_map2(cl, cl.from_numpy(pts), cen, kk, 1, reducer=np.add)
+  t_km = time.perf_counter() - t0
   return {'value': round(2.0 * n ** 3 / dt / 1e12, 4), 'unit': 'TFLOP/s', 'cores': cores, 'kind': 'port',
           'sample': 'oracle (NumPy port) spartan.dot %dx%dx%d fp32, 1 worker, %d BLAS thread(s), best of 2 '
-                    '(%.2f s each); map x*x+x %.1f GB/s, sum axis0 %.1f GB/s on 4096x16384 fp32'
-                    % (n, n, n, cores, dt, 8.0 * x.size / t_map / 1e9, 4.0 * x.size / t_sum / 1e9)}
+                    '(%.2f s each); map x*x+x %.1f GB/s, sum axis0 %.1f GB/s on 4096x16384 fp32; '
+                    'k-means iteration (map2 variant) on %dx%d points, k=%d: %.2f s = %.4f TFLOP/s of 2nkd'
+                    % (n, n, n, cores, dt, 8.0 * x.size / t_map / 1e9, 4.0 * x.size / t_sum / 1e9,
+                       kn, kd, kk, t_km, 2.0 * kn * kk * kd / t_km / 1e12)}
 
 
 def main():

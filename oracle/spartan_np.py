@@ -490,3 +490,67 @@ class Cluster(object):
       else:
         target.update(Extent((0, 0), (first.lr[0], b.shape[1]), (first.shape[0], b.shape[1])), part)
     return target
+
+
+# ----------------------------------------------------------------- example drivers (BASELINE configs[3], [4])
+def kmeans_fit_map2(cl, X, centers, n_clusters, n_iter, reducer=None):
+  """KMeans.fit(implementation='map2') restated eagerly (examples/sklearn/cluster/k_means_.py:130-160):
+  labels = argmin(cdist) per row tile (:61-66); per-tile counts (:69-72) and masked row sums (:75-97)
+  written into ONE whole-array target tile -- with `reducer=None`, as the reference creates those
+  targets (:135-141), every tile REPLACES the previous one (tile.pyx:263-268), so the last tile in
+  tile order wins; empty clusters re-seeded from np.random.randn (:145-155); centers = sums / counts."""
+  from scipy.spatial.distance import cdist
+  num_dim = X.shape[1]
+  labels = None
+  for _ in range(n_iter):
+    labels = cl.empty((X.shape[0],), X.dtype, None)
+    for ex, _, _t in X.tiles:
+      pts = X.fetch(ex)
+      labels.update(Extent((ex.ul[0],), (ex.lr[0],), (X.shape[0],)),
+                    np.argmin(cdist(pts, centers), axis=1))
+    counts = cl.empty((n_clusters,), labels.dtype, reducer)
+    for ex, _, _t in labels.tiles:
+      lab = labels.fetch(ex)
+      counts.update(Extent((0,), (n_clusters,), (n_clusters,)),
+                    np.bincount(lab.astype(np.int64), minlength=n_clusters))
+    sums = cl.empty((n_clusters, num_dim), X.dtype, reducer)
+    for ex, _, _t in X.tiles:
+      pts = X.fetch(ex)
+      lab = labels.fetch(Extent((ex.ul[0],), (ex.lr[0],), (X.shape[0],)))
+      new_centers = np.zeros((n_clusters, num_dim))
+      for i in range(n_clusters):
+        new_centers[i] = pts[lab == i].sum(axis=0)
+      sums.update(Extent((0, 0), (n_clusters, num_dim), (n_clusters, num_dim)), new_centers)
+    counts_h = counts.glom()
+    centers = sums.glom()
+    zero = (counts_h == 0).reshape(n_clusters)
+    if np.any(zero):
+      counts_h[zero] = 1
+      centers[zero, :] = np.random.randn(np.count_nonzero(zero), num_dim)
+    centers = centers / counts_h.reshape(n_clusters, 1)
+  return centers, labels
+
+
+def sgd_train(cl, x, y, iterations, update, alpha=1e-6):
+  """SGDRegressor.train (examples/sgd.py:14-40): w drawn with np.random.rand, then
+  w -= alpha * sum(update(w), axis=0)."""
+  n_dim = x.shape[1]
+  w = np.random.rand(n_dim, 1)
+  for _ in range(iterations):
+    diff = update(cl, x, y, w)
+    grad = cl.sum(diff, 0).glom().reshape((n_dim, 1))
+    w = w - grad * alpha
+  return w
+
+
+def linear_update(cl, x, y, w):
+  """linear_regression.py:10-16: x * (dot(x, w) - y)."""
+  yp = cl.dot(x, w)
+  return cl.map(lambda a, b, c: a * (b - c), x, yp, y)
+
+
+def logistic_update(cl, x, y, w):
+  """logistic_regression.py:10-17: g = exp(dot(x, w)); x * (g / (g + 1) - y)."""
+  g = cl.map(np.exp, cl.dot(x, w))
+  yp = cl.map(lambda t: t / (t + 1), g)
+  return cl.map(lambda a, b, c: a * (b - c), x, yp, y)
