@@ -264,6 +264,11 @@ int sp_slice_copy(void* d_dst, const int64_t* dst_stride, const void* d_src,
 int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C,
                 int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t accumulate, void* stream);
 
+/* sp_gemm_f64: the same contract in float64 on the f64 MFMA (v_mfma_f64_16x16x4_f64); the reference's
+ * builders produce float64 arrays by default, so `spartan.dot` of two such matrices lands here. */
+int sp_gemm_f64(const double* d_A, int64_t lda, const double* d_B, int64_t ldb, double* d_C,
+                int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t accumulate, void* stream);
+
 /* Matrix . vector products (dot.py:180-183, dot_map2_np_mapper with a 1-D rhs;
  * the lreg step X.w and X^T.r) are HBM-bound and have no GEMM entry point:
  * the host lowers them to sp_reduce with the fused program MUL(in0, in1) and

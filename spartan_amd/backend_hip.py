@@ -357,10 +357,11 @@ class HipBackend(object):
       return self.dot(a, b.reshape(b.shape[0])).reshape(a.shape[0], 1)
     if a.dim() == 2 and b.dim() == 2 and a.shape[0] == 1:
       return self.dot(a.reshape(a.shape[1]), b).reshape(1, b.shape[1])
-    if a.dim() == 2 and b.dim() == 2 and a_dt == np.float32 and b_dt == np.float32:
+    if a.dim() == 2 and b.dim() == 2 and a_dt == b_dt and a_dt in (np.float32, np.float64):
+      # fp32 / fp64 MFMA GEMM (sp_gemm_f32 / sp_gemm_f64)
       M, K = a.shape
       N = b.shape[1]
-      c = self.empty((M, N), np.float32)
+      c = self.empty((M, N), a_dt)
       if a.stride(1) != 1:
         a = self.copy(a)
       if b.stride(1) != 1:

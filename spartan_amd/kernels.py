@@ -111,18 +111,22 @@ def slice_copy(dst, dst_offset, dst_strides, src, src_offset, src_strides, shape
 
 
 def gemm_f32(a, b, c, accumulate=False):
-  """c (+)= a . b for 2-D row-major fp32 tensors (inner stride 1)."""
+  """c (+)= a . b for 2-D row-major fp32 (or, all three, fp64) tensors (inner stride 1)."""
   _require_device(a, b, c)
-  assert a.dtype == b.dtype == c.dtype == torch.float32
+  assert a.dtype == b.dtype == c.dtype and a.dtype in (torch.float32, torch.float64)
+  fn = _hip.lib().sp_gemm_f32 if a.dtype == torch.float32 else _hip.lib().sp_gemm_f64
   M, K = a.shape
   K2, N = b.shape
   assert K == K2 and tuple(c.shape) == (M, N), (a.shape, b.shape, c.shape)
   assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1
-  check(_hip.lib().sp_gemm_f32(C.c_void_p(a.data_ptr()), a.stride(0) if M > 1 else max(K, 1),
-                               C.c_void_p(b.data_ptr()), b.stride(0) if K > 1 else max(N, 1),
-                               C.c_void_p(c.data_ptr()), c.stride(0) if M > 1 else max(N, 1),
-                               M, N, K, 1 if accumulate else 0, _stream()))
+  check(fn(C.c_void_p(a.data_ptr()), a.stride(0) if M > 1 else max(K, 1),
+           C.c_void_p(b.data_ptr()), b.stride(0) if K > 1 else max(N, 1),
+           C.c_void_p(c.data_ptr()), c.stride(0) if M > 1 else max(N, 1),
+           M, N, K, 1 if accumulate else 0, _stream()))
   return c
+
+
+gemm = gemm_f32   # dtype-dispatching: fp32 -> sp_gemm_f32, fp64 -> sp_gemm_f64
 
 
 def _ld(t):

@@ -638,3 +638,45 @@ def test_segment_sum_is_deterministic_and_balanced():
   np.testing.assert_array_equal(outs[0], outs[2])
   want = np.stack([x[lab == i].astype(np.float64).sum(axis=0) for i in range(k)])
   np.testing.assert_allclose(outs[0], want, rtol=2e-5)
+
+
+# ---- fp64 GEMM (gemm_f64.hip) ------------------------------------------------------
+@pytest.mark.parametrize('mnk', [(1, 1, 1), (16, 16, 4), (128, 128, 8), (130, 70, 33), (257, 300, 129), (64, 2, 1024),
+                                 (512, 384, 256)])
+def test_gemm_f64_integer_valued_exact(mnk):
+  M, N, K = mnk
+  a = RNG.randint(-4, 5, size=(M, K)).astype(np.float64)
+  b = RNG.randint(-4, 5, size=(K, N)).astype(np.float64)
+  c = torch.empty(M, N, dtype=torch.float64, device=DEV)
+  kernels.gemm_f32(dev(a), dev(b), c)
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(host(c), a.dot(b))
+  kernels.gemm_f32(dev(a), dev(b), c, accumulate=True)     # C += A.B (the np.add merge fused in)
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(host(c), 2 * a.dot(b))
+
+
+def test_gemm_f64_random_tolerance_and_strides():
+  a = RNG.rand(300, 520)
+  b = RNG.rand(520, 260)
+  big_a = dev(np.pad(a, ((0, 0), (0, 8))))[:, :520]        # lda = 528
+  big_c = torch.zeros(300, 264, dtype=torch.float64, device=DEV)
+  kernels.gemm_f32(big_a, dev(b), big_c[:, :260])
+  torch.cuda.synchronize()
+  np.testing.assert_allclose(host(big_c)[:, :260], a.dot(b), rtol=1e-13)
+  assert np.all(host(big_c)[:, 260:] == 0)
+
+
+def test_dot_float64_uses_the_mfma_gemm():
+  import spartan_amd as sp
+  ctx = sp.initialize('hip', num_workers=3)
+  try:
+    a = RNG.randint(-3, 4, size=(200, 96)).astype(np.float64)
+    b = RNG.randint(-3, 4, size=(96, 150)).astype(np.float64)
+    ctx.backend.gemm_events = []
+    got = sp.dot(sp.from_numpy(a), sp.from_numpy(b)).glom()
+    assert got.dtype == np.float64 and len(ctx.backend.gemm_events) > 0
+    ctx.backend.gemm_events = None
+    np.testing.assert_array_equal(got, a.dot(b))
+  finally:
+    sp.shutdown()

@@ -158,6 +158,14 @@ if __name__ == '__main__':
   if what in ('all', 'reduce'):
     bench_reduce(8192, 65536)
     bench_reduce(125000, 4096)
+  if what == 'dgemm':
+    M, N, K = [int(v) for v in sys.argv[2:5]]
+    a = torch.rand(M, K, dtype=torch.float64, device=DEV) * 2 - 1
+    b = torch.rand(K, N, dtype=torch.float64, device=DEV) * 2 - 1
+    c = torch.empty(M, N, dtype=torch.float64, device=DEV)
+    ms = timeit(lambda: kernels.gemm_f32(a, b, c), iters=5, warmup=2)
+    print('dgemm %dx%dx%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 78.6 fp64 MFMA peak)' % (
+        M, N, K, ms, 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9 / 78.6 * 100))
   if what == 'kmeans':
     if len(sys.argv) > 4:
       bench_kmeans(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
