@@ -401,7 +401,7 @@ class HipBackend(object):
     """a . B with B arriving as column chunks (distarray.ChunkedWhole): one GEMM per chunk into the
     matching columns of C, each launched as soon as its chunk's gather has landed, so the remaining
     gathers (RCCL stream) overlap with the GEMMs (this stream)."""
-    if not (a.dim() == 2 and self.dtype_of(a) == np.float32 and rhs.dtype == np.float32):
+    if not (a.dim() == 2 and self.dtype_of(a) == rhs.dtype and rhs.dtype in (np.float32, np.float64)):
       whole = self.empty(rhs.shape, rhs.dtype)
       for i in range(len(rhs.chunks)):
         c0, c1, t = rhs.ready(i)
@@ -411,7 +411,7 @@ class HipBackend(object):
     N = rhs.shape[1]
     if a.stride(1) != 1:
       a = self.copy(a)
-    c = self.empty((M, N), np.float32)
+    c = self.empty((M, N), rhs.dtype)
     for i in range(len(rhs.chunks)):
       c0, c1, t = rhs.ready(i)
       self.launches += 1
