@@ -269,6 +269,17 @@ int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, fl
 int sp_gemm_f64(const double* d_A, int64_t lda, const double* d_B, int64_t ldb, double* d_C,
                 int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t accumulate, void* stream);
 
+/* sp_gemm_ws: sp_gemm_f32 / sp_gemm_f64 (dtype SP_F32 | SP_F64) with scratch for SPLIT-K.  A product
+ * with fewer than 256 output tiles and a long contraction (x^T.x of a tall matrix,
+ * ridge_regression.py:18-19) would leave most CUs idle; with d_ws of at least
+ * sp_gemm_workspace_bytes(...) bytes the contraction is cut into slices computed side by side and the
+ * partial products are added in slice order (deterministic, no atomics).  Without scratch, or when no
+ * split pays, it is exactly sp_gemm_f32 / sp_gemm_f64. */
+size_t sp_gemm_workspace_bytes(int32_t dtype, int64_t M, int64_t N, int64_t K);
+int sp_gemm_ws(int32_t dtype, const void* d_A, int64_t lda, const void* d_B, int64_t ldb, void* d_C,
+               int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t accumulate, void* d_ws,
+               size_t ws_bytes, void* stream);
+
 /* Matrix . vector products (dot.py:180-183, dot_map2_np_mapper with a 1-D rhs;
  * the lreg step X.w and X^T.r) are HBM-bound and have no GEMM entry point:
  * the host lowers them to sp_reduce with the fused program MUL(in0, in1) and

@@ -103,6 +103,9 @@ def _declare(lib):
   lib.sp_slice_copy.argtypes = [vp, p64, vp, p64, p64, i32, i32, vp]
   lib.sp_gemm_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]
   lib.sp_gemm_f64.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp]
+  lib.sp_gemm_workspace_bytes.argtypes = [i32, i64, i64, i64]
+  lib.sp_gemm_workspace_bytes.restype = sz
+  lib.sp_gemm_ws.argtypes = [i32, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp, sz, vp]
   lib.sp_nearest_center_workspace_bytes.argtypes = [i64, i64, i64]
   lib.sp_nearest_center_workspace_bytes.restype = sz
   lib.sp_nearest_center.argtypes = [vp, i32, i64, vp, i32, i64, i64, i64, i64, vp, i32, vp, sz, vp]
@@ -125,7 +128,7 @@ EXPORTS = [
     'sp_abi_version', 'sp_last_error', 'sp_device_count', 'sp_device_info', 'sp_map_fused',
     'sp_program_static_id', 'sp_jit_configure', 'sp_jit_wait', 'sp_jit_compiled_count', 'sp_jit_compile_check',
     'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
-    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
+    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
     'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_random_fill', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',
 ]

@@ -65,14 +65,16 @@ __device__ __forceinline__ void sp_gemm_tile_of_block(int bid, int nblk, int til
   tn = in_group / gsize;
 }
 
-// FAST: K % BK == 0, N % 4 == 0, lda/ldb % 4 == 0, 16-B aligned bases.
+// FAST: N % 4 == 0, lda/ldb % 4 == 0, 16-B aligned bases (a K % BK tail is guarded on its own k-tile).
 // Rows beyond M / columns beyond N are clamped on load and masked on store.
-template <typename Cfg, int BM, int BN, int BK, int WM, int WN, bool FAST>
+// KTAIL: FAST kernel whose last k-tile is partial; SPLIT: split-K slice per blockIdx.y (sp_gemm_ws).
+// The hot instantiation (FAST, no tail, no split) carries none of that code.
+template <typename Cfg, int BM, int BN, int BK, int WM, int WN, bool FAST, bool KTAIL = false, bool SPLIT = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                                const float* __restrict__ B, int64_t ldb,
                                                                float* __restrict__ C, int64_t ldc, int M,
                                                                int N, int K, int accumulate, int tiles_m,
-                                                               int tiles_n) {
+                                                               int tiles_n, int ksplit_len, int64_t c_split_stride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int THREADS = Cfg::THREADS;
   constexpr int TM = Cfg::TM, TN = Cfg::TN;
@@ -84,6 +86,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
   int tm, tn;
   sp_gemm_tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
+  if constexpr (SPLIT) {
+    // split-K: slice blockIdx.y of the contraction goes to its own partial output (sp_gemm_ws)
+    const int kb = blockIdx.y * ksplit_len;
+    A += kb;
+    B += (int64_t)kb * ldb;
+    C += (int64_t)blockIdx.y * c_split_stride;
+    K = (K - kb) < ksplit_len ? (K - kb) : ksplit_len;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -152,6 +162,28 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
     }                                                                                 \
   } while (0)
 
+// FAST kernels, last k-tile when K % BK != 0: rows / columns are clamped as usual, elements with
+// k >= K are zero and are not read
+#define SP_GEMM_LOAD_KTAIL(kt)                                                        \
+  do {                                                                                \
+    const int k0_ = (kt) * BK;                                                        \
+    const float* Ak_ = Ablk + k0_;                                                    \
+    const float* Bk_ = Bblk + (int64_t)k0_ * ldb;                                     \
+    _Pragma("unroll") for (int j = 0; j < A_VEC; ++j) {                               \
+      const int kk = k0_ + ((tid + j * THREADS) % KQ) * 4;                            \
+      const float* p = Ak_ + a_off[j];                                                \
+      ra[j].x = kk + 0 < K ? p[0] : 0.f;                                              \
+      ra[j].y = kk + 1 < K ? p[1] : 0.f;                                              \
+      ra[j].z = kk + 2 < K ? p[2] : 0.f;                                              \
+      ra[j].w = kk + 3 < K ? p[3] : 0.f;                                              \
+    }                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < B_VEC; ++j) {                               \
+      const bool kok = (k0_ + (tid + j * THREADS) / NQ) < K;                          \
+      if (kok) rb[j] = *(const f32x4*)(Bk_ + b_off[j]);                               \
+      else rb[j] = f32x4{0.f, 0.f, 0.f, 0.f};                                         \
+    }                                                                                 \
+  } while (0)
+
 #define SP_GEMM_STORE_TILE(buf)                                                       \
   do {                                                                                \
     float* sA_ = smem + (buf) * Cfg::STAGE_FLOATS;                                    \
@@ -169,7 +201,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nt = (K + BK - 1) / BK;
-  SP_GEMM_LOAD_TILE(0);
+  constexpr bool ktail = FAST && KTAIL;   // (the general path guards every element anyway)
+  if (ktail && nt == 1) SP_GEMM_LOAD_KTAIL(0);
+  else SP_GEMM_LOAD_TILE(0);
   SP_GEMM_STORE_TILE(0);
   __syncthreads();
 
@@ -177,7 +211,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
   const int b_frag_off = (4 * lh) * LDB_S + wn * Cfg::WTN + l31;
 
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) SP_GEMM_LOAD_TILE(t + 1);
+    if (t + 1 < nt) {
+      if (ktail && t + 2 == nt) SP_GEMM_LOAD_KTAIL(t + 1);
+      else SP_GEMM_LOAD_TILE(t + 1);
+    }
     const float* sA = smem + (t & 1) * Cfg::STAGE_FLOATS;
     const float* sB = sA + Cfg::A_FLOATS;
 #pragma unroll
@@ -225,33 +262,38 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <typename Cfg, typename KernelT>
+static int sp_gemm_go(KernelT k, bool* attr_set, unsigned nblk, unsigned splits, hipStream_t st, const float* A,
+                      int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int acc,
+                      int tiles_m, int tiles_n, int ksplit_len, int64_t c_split_stride) {
+  if (!*attr_set) {
+    SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    *attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(nblk, splits), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, A, lda, B, ldb, C, ldc, M, N, K,
+                     acc, tiles_m, tiles_n, ksplit_len, c_split_stride);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+// SPLIT launches one slice of the contraction per blockIdx.y (only instantiated for the 128x128 tile).
+template <int BM, int BN, int BK, int WM, int WN, bool SPLIT = false>
 static int sp_gemm_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
-                          int64_t M, int64_t N, int64_t K, int acc, bool fast, hipStream_t st) {
+                          int64_t M, int64_t N, int64_t K, int acc, bool fast, hipStream_t st, int splits = 1,
+                          int ksplit_len = 0, int64_t c_split_stride = 0) {
   using Cfg = GemmCfg<BM, BN, BK, WM, WN>;
   const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int64_t nblk = tiles_m * tiles_n;
   if (nblk > 2147483647LL) SP_FAIL("sp_gemm_f32: too many tiles");
-  static bool attr_set_fast = false, attr_set_gen = false;
-  if (fast) {
-    auto k = sp_gemm_kernel<Cfg, BM, BN, BK, WM, WN, true>;
-    if (!attr_set_fast) {
-      SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-      attr_set_fast = true;
-    }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, A, lda, B, ldb, C, ldc,
-                       (int)M, (int)N, (int)K, acc, (int)tiles_m, (int)tiles_n);
-  } else {
-    auto k = sp_gemm_kernel<Cfg, BM, BN, BK, WM, WN, false>;
-    if (!attr_set_gen) {
-      SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-      attr_set_gen = true;
-    }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, A, lda, B, ldb, C, ldc,
-                       (int)M, (int)N, (int)K, acc, (int)tiles_m, (int)tiles_n);
-  }
-  SP_CHECK_LAUNCH();
-  return 0;
+  static bool set_fast = false, set_tail = false, set_gen = false;
+  // a slice of a split may end in a partial k-tile even when K itself does not: always the tail kernel there
+  const bool tail = SPLIT ? true : (K % BK != 0);
+#define SP_GEMM_ARGS (unsigned)nblk, (unsigned)splits, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, acc, \
+                     (int)tiles_m, (int)tiles_n, ksplit_len, c_split_stride
+  if (fast && !tail) return sp_gemm_go<Cfg>(sp_gemm_kernel<Cfg, BM, BN, BK, WM, WN, true, false, SPLIT>, &set_fast, SP_GEMM_ARGS);
+  if (fast) return sp_gemm_go<Cfg>(sp_gemm_kernel<Cfg, BM, BN, BK, WM, WN, true, true, SPLIT>, &set_tail, SP_GEMM_ARGS);
+  return sp_gemm_go<Cfg>(sp_gemm_kernel<Cfg, BM, BN, BK, WM, WN, false, false, SPLIT>, &set_gen, SP_GEMM_ARGS);
+#undef SP_GEMM_ARGS
 }
 
 // Tuning knob (not part of the ABI contract): SP_GEMM_VARIANT=0..3 picks the
@@ -281,7 +323,7 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
     }
     return 0;
   }
-  const bool fast = (K % 16 == 0) && (N % 4 == 0) && (N >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+  const bool fast = (N % 4 == 0) && (N >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                     ((((uintptr_t)d_A) | ((uintptr_t)d_B)) & 15) == 0;
   int v = sp_gemm_variant();
   if (v < 0) {
@@ -296,4 +338,91 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
     case 3: return sp_gemm_launch<128, 256, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     default: SP_FAIL("sp_gemm_f32: unknown SP_GEMM_VARIANT=%d", v);
   }
+}
+
+
+// ---- split-K (small M x N, long contraction: x^T x of a tall matrix, ridge_regression.py:18-19) ----------
+// With fewer than 256 output tiles most CUs would idle while a few walk the whole K; the contraction is
+// cut into `splits` slices, each slice writes its own partial product, and the partials are added in slice
+// order (deterministic, no atomics).
+template <typename T>
+__global__ __launch_bounds__(256) void sp_splitk_reduce_kernel(const T* __restrict__ part, int splits, int64_t mn, int N,
+                                                               T* __restrict__ C, int64_t ldc, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < mn; e += stride) {
+    const int64_t i = e / N, j = e - i * N;
+    T* p = C + i * ldc + j;
+    T acc = accumulate ? *p : (T)0;
+    for (int s = 0; s < splits; ++s) acc += part[(int64_t)s * mn + e];
+    *p = acc;
+  }
+}
+
+struct SplitPlan {
+  int splits, klen;
+};
+
+static SplitPlan sp_split_plan(int64_t M, int64_t N, int64_t K, int bk) {
+  SplitPlan pl = {1, 0};
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles >= 256 || K < 2048) return pl;
+  int64_t s = (512 + tiles - 1) / tiles;
+  if (s > K / 512) s = K / 512;
+  if (s > 512) s = 512;
+  if (s < 2) return pl;
+  int64_t klen = (K + s - 1) / s;
+  klen = (klen + bk - 1) / bk * bk;
+  s = (K + klen - 1) / klen;
+  if (s < 2) return pl;
+  pl.splits = (int)s;
+  pl.klen = (int)klen;
+  return pl;
+}
+
+int sp_dgemm_split_launch(const double* A, int64_t lda, const double* B, int64_t ldb, double* part, int64_t M,
+                          int64_t N, int64_t K, int splits, int klen, hipStream_t st);
+
+extern "C" size_t sp_gemm_workspace_bytes(int32_t dtype, int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || N < 1 || (dtype != SP_F32 && dtype != SP_F64)) return 0;
+  const SplitPlan pl = sp_split_plan(M, N, K, dtype == SP_F32 ? 16 : 8);
+  return pl.splits > 1 ? (size_t)pl.splits * M * N * (dtype == SP_F32 ? 4 : 8) + 256 : 0;
+}
+
+extern "C" int sp_gemm_f64(const double*, int64_t, const double*, int64_t, double*, int64_t, int64_t, int64_t, int64_t,
+                           int32_t, void*);
+
+extern "C" int sp_gemm_ws(int32_t dtype, const void* d_A, int64_t lda, const void* d_B, int64_t ldb, void* d_C,
+                          int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t accumulate, void* d_ws,
+                          size_t ws_bytes, void* stream) {
+  if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_gemm_ws: dtype must be f32 or f64");
+  const SplitPlan pl = (M > 0 && N > 0) ? sp_split_plan(M, N, K, dtype == SP_F32 ? 16 : 8) : SplitPlan{1, 0};
+  const size_t need = sp_gemm_workspace_bytes(dtype, M, N, K);
+  if (pl.splits <= 1 || !d_ws || ws_bytes < need) {
+    return dtype == SP_F32 ? sp_gemm_f32((const float*)d_A, lda, (const float*)d_B, ldb, (float*)d_C, ldc, M, N, K, accumulate, stream)
+                           : sp_gemm_f64((const double*)d_A, lda, (const double*)d_B, ldb, (double*)d_C, ldc, M, N, K, accumulate, stream);
+  }
+  if (!d_A || !d_B || !d_C) SP_FAIL("sp_gemm_ws: NULL pointer");
+  if (lda < K || ldb < N || ldc < N) SP_FAIL("sp_gemm_ws: leading dimension too small");
+  hipStream_t st = (hipStream_t)stream;
+  char* part = (char*)(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
+  const int64_t mn = M * N;
+  if (dtype == SP_F32) {
+    const float* A = (const float*)d_A;
+    const float* B = (const float*)d_B;
+    // every slice but the last is a multiple of BK long; the general (guarded) loads cover the last one
+    const bool fast = (N % 4 == 0) && (N >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                      ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
+    if (sp_gemm_launch<128, 128, 16, 2, 2, true>(A, lda, B, ldb, (float*)part, N, M, N, K, 0, fast, st, pl.splits, pl.klen, mn))
+      return 1;
+    hipLaunchKernelGGL((sp_splitk_reduce_kernel<float>), dim3((unsigned)((mn + 255) / 256 > 4096 ? 4096 : (mn + 255) / 256)),
+                       dim3(256), 0, st, (const float*)part, pl.splits, mn, (int)N, (float*)d_C, ldc, accumulate);
+  } else {
+    if (sp_dgemm_split_launch((const double*)d_A, lda, (const double*)d_B, ldb, (double*)part, M, N, K, pl.splits,
+                              pl.klen, st))
+      return 1;
+    hipLaunchKernelGGL((sp_splitk_reduce_kernel<double>), dim3((unsigned)((mn + 255) / 256 > 4096 ? 4096 : (mn + 255) / 256)),
+                       dim3(256), 0, st, (const double*)part, pl.splits, mn, (int)N, (double*)d_C, ldc, accumulate);
+  }
+  SP_CHECK_LAUNCH();
+  return 0;
 }

@@ -35,11 +35,12 @@ __device__ __forceinline__ void dgemm_tile_of_block(int bid, int nblk, int tiles
 }
 
 // FAST: K % 8 == 0, N % 2 == 0, lda/ldb % 2 == 0, 16-B aligned bases.
-template <bool FAST>
+template <bool FAST, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void sp_dgemm_kernel(const double* __restrict__ A, int64_t lda,
                                                           const double* __restrict__ B, int64_t ldb,
                                                           double* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                          int accumulate, int tiles_m, int tiles_n) {
+                                                          int accumulate, int tiles_m, int tiles_n, int ksplit_len,
+                                                          int64_t c_split_stride) {
   __shared__ __attribute__((aligned(16))) double smem[2 * DSTAGE];
   constexpr int THREADS = 256;
   constexpr int KQ = DBK / 2;   // 16-B pieces per A row
@@ -47,6 +48,13 @@ __global__ __launch_bounds__(256, 2) void sp_dgemm_kernel(const double* __restri
   int tm, tn;
   dgemm_tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * DBM, n0 = tn * DBN;
+  if constexpr (SPLIT) {   // split-K slice (sp_gemm_ws)
+    const int kb = blockIdx.y * ksplit_len;
+    A += kb;
+    B += (int64_t)kb * ldb;
+    C += (int64_t)blockIdx.y * c_split_stride;
+    K = (K - kb) < ksplit_len ? (K - kb) : ksplit_len;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l15 = lane & 15, lq = lane >> 4;   // MFMA: row/col index and k (or row-group) index
@@ -185,10 +193,28 @@ extern "C" int sp_gemm_f64(const double* d_A, int64_t lda, const double* d_B, in
                     ((((uintptr_t)d_A) | ((uintptr_t)d_B)) & 15) == 0;
   if (fast)
     hipLaunchKernelGGL((sp_dgemm_kernel<true>), dim3((unsigned)nblk), dim3(256), 0, st, d_A, lda, d_B, ldb, d_C, ldc,
-                       (int)M, (int)N, (int)K, accumulate, (int)tiles_m, (int)tiles_n);
+                       (int)M, (int)N, (int)K, accumulate, (int)tiles_m, (int)tiles_n, 0, (int64_t)0);
   else
     hipLaunchKernelGGL((sp_dgemm_kernel<false>), dim3((unsigned)nblk), dim3(256), 0, st, d_A, lda, d_B, ldb, d_C, ldc,
-                       (int)M, (int)N, (int)K, accumulate, (int)tiles_m, (int)tiles_n);
+                       (int)M, (int)N, (int)K, accumulate, (int)tiles_m, (int)tiles_n, 0, (int64_t)0);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// split-K launch used by sp_gemm_ws (gemm.hip): slice s of the contraction -> part[s][M][N]
+int sp_dgemm_split_launch(const double* A, int64_t lda, const double* B, int64_t ldb, double* part, int64_t M,
+                          int64_t N, int64_t K, int splits, int klen, hipStream_t st) {
+  const int64_t tiles_m = (M + DBM - 1) / DBM, tiles_n = (N + DBN - 1) / DBN;
+  const int64_t nblk = tiles_m * tiles_n;
+  const bool fast = (K % DBK == 0) && (N % 2 == 0) && (N >= 2) && (lda % 2 == 0) && (ldb % 2 == 0) &&
+                    ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
+  if (fast)
+    hipLaunchKernelGGL((sp_dgemm_kernel<true, true>), dim3((unsigned)nblk, (unsigned)splits), dim3(256), 0, st, A, lda, B, ldb,
+                       part, N, (int)M, (int)N, (int)K, 0, (int)tiles_m, (int)tiles_n, klen, M * N);
+  else
+    hipLaunchKernelGGL((sp_dgemm_kernel<false, true>), dim3((unsigned)nblk, (unsigned)splits), dim3(256), 0, st, A, lda, B, ldb,
+                       part, N, (int)M, (int)N, (int)K, 0, (int)tiles_m, (int)tiles_n, klen, M * N);
   SP_CHECK_LAUNCH();
   return 0;
 }

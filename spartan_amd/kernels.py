@@ -114,15 +114,19 @@ def gemm_f32(a, b, c, accumulate=False):
   """c (+)= a . b for 2-D row-major fp32 (or, all three, fp64) tensors (inner stride 1)."""
   _require_device(a, b, c)
   assert a.dtype == b.dtype == c.dtype and a.dtype in (torch.float32, torch.float64)
-  fn = _hip.lib().sp_gemm_f32 if a.dtype == torch.float32 else _hip.lib().sp_gemm_f64
+  lib = _hip.lib()
+  dt = _hip.SP_F32 if a.dtype == torch.float32 else _hip.SP_F64
   M, K = a.shape
   K2, N = b.shape
   assert K == K2 and tuple(c.shape) == (M, N), (a.shape, b.shape, c.shape)
   assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1
-  check(fn(C.c_void_p(a.data_ptr()), a.stride(0) if M > 1 else max(K, 1),
-           C.c_void_p(b.data_ptr()), b.stride(0) if K > 1 else max(N, 1),
-           C.c_void_p(c.data_ptr()), c.stride(0) if M > 1 else max(N, 1),
-           M, N, K, 1 if accumulate else 0, _stream()))
+  need = lib.sp_gemm_workspace_bytes(dt, M, N, K)     # > 0: few output tiles, long contraction -> split-K
+  ws = _ws.get(need, a.device) if need else None
+  check(lib.sp_gemm_ws(dt, C.c_void_p(a.data_ptr()), a.stride(0) if M > 1 else max(K, 1),
+                       C.c_void_p(b.data_ptr()), b.stride(0) if K > 1 else max(N, 1),
+                       C.c_void_p(c.data_ptr()), c.stride(0) if M > 1 else max(N, 1),
+                       M, N, K, 1 if accumulate else 0, C.c_void_p(ws.data_ptr() if need else 0),
+                       ws.numel() if need else 0, _stream()))
   return c
 
 

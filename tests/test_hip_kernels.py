@@ -680,3 +680,32 @@ def test_dot_float64_uses_the_mfma_gemm():
     np.testing.assert_array_equal(got, a.dot(b))
   finally:
     sp.shutdown()
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('mnk', [(64, 64, 100000), (10, 10, 65536), (512, 384, 20000), (130, 70, 4099), (1, 1, 5000)])
+def test_gemm_split_k(mnk, dt):
+  """Small output, long contraction (x^T x): the split-K path -- exact for integer-valued operands,
+  same tolerance as the plain kernel otherwise, identical bits on every run, `accumulate` honoured."""
+  M, N, K = mnk
+  assert _hip.lib().sp_gemm_workspace_bytes(_hip.sp_dtype(dt), M, N, K) > 0
+  a = RNG.randint(-3, 4, size=(M, K)).astype(dt)
+  b = RNG.randint(-3, 4, size=(K, N)).astype(dt)
+  c = torch.full((M, N), 5, dtype=kernels.torch_dtype(dt), device=DEV)
+  kernels.gemm_f32(dev(a), dev(b), c)
+  torch.cuda.synchronize()
+  want = a.astype(np.float64).dot(b.astype(np.float64))
+  np.testing.assert_array_equal(host(c), want.astype(dt))
+  kernels.gemm_f32(dev(a), dev(b), c, accumulate=True)
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(host(c), (2 * want).astype(dt))
+  x = (RNG.rand(M, K) - 0.5).astype(dt)
+  y = (RNG.rand(K, N) - 0.5).astype(dt)
+  outs = []
+  for _ in range(2):
+    kernels.gemm_f32(dev(x), dev(y), c)
+    torch.cuda.synchronize()
+    outs.append(host(c).copy())
+  np.testing.assert_array_equal(outs[0], outs[1])
+  ref = x.astype(np.float64).dot(y.astype(np.float64))
+  np.testing.assert_allclose(outs[0], ref, rtol=0, atol=(2e-4 if dt == np.float32 else 1e-10) * np.sqrt(K))

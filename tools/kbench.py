@@ -158,6 +158,18 @@ if __name__ == '__main__':
   if what in ('all', 'reduce'):
     bench_reduce(8192, 65536)
     bench_reduce(125000, 4096)
+  if what == 'splitk':
+    for dt, peak in ((torch.float32, 157.3), (torch.float64, 78.6)):
+      for (M, N, K) in ((512, 512, 1000000), (64, 64, 4000000), (4096, 4096, 125000)):
+        a = torch.rand(M, K, dtype=dt, device=DEV) * 2 - 1
+        b = torch.rand(K, N, dtype=dt, device=DEV) * 2 - 1
+        c = torch.empty(M, N, dtype=dt, device=DEV)
+        ms = timeit(lambda: kernels.gemm_f32(a, b, c), iters=5, warmup=2)
+        nbytes = (M * K + K * N) * a.element_size()
+        print('gemm %s %dx%dx%d  %8.3f ms  %7.1f TFLOP/s (%.0f%% of MFMA peak)  operands streamed at %6.1f GB/s  ws=%d'
+              % (str(dt).split('.')[1], M, N, K, ms, 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms / 1e9 / peak * 100,
+                 nbytes / ms / 1e6, _hip.lib().sp_gemm_workspace_bytes(_hip.SP_F32 if dt == torch.float32 else _hip.SP_F64, M, N, K)))
+        del a, b, c
   if what == 'dgemm':
     M, N, K = [int(v) for v in sys.argv[2:5]]
     a = torch.rand(M, K, dtype=torch.float64, device=DEV) * 2 - 1
