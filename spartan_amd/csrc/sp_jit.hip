@@ -148,9 +148,15 @@ hipFunction_t compile(const char* header, const char* expr, const sp_program* p,
   rtcProgram prog = nullptr;
   if (r.create(&prog, src.c_str(), "sp_jit_program.hip", 0, nullptr, nullptr) != 0) return nullptr;
   r.addName(prog, expr);
-  const std::string inc1 = "-I" + dir + "/rtc_shim", inc2 = "-I" + dir;
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc1.c_str(), inc2.c_str()};
-  const int rc = r.compile(prog, 6, opts);
+  // (hipRTC normally serves <hip/hip_runtime.h> from its built-in copy; under rocprofv3 it does not:
+  //  the ROCm include directory -- after the shims, which must win for the C headers -- is the retry)
+  const char* rocm = getenv("ROCM_PATH");
+  const std::string inc1 = "-I" + dir + "/rtc_shim", inc2 = "-I" + dir,
+                    inc3 = std::string("-I") + (rocm && *rocm ? rocm : "/opt/rocm") + "/include";
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc1.c_str(), inc2.c_str(),
+                        inc3.c_str()};
+  int rc = r.compile(prog, 6, opts);            // built-in HIP headers: the fast, usual case
+  if (rc != 0) rc = r.compile(prog, 7, opts);   // retry with the installed ROCm headers
   hipFunction_t fn = nullptr;
   if (rc != 0) {
     if (verbose() && r.logSize && r.log) {
