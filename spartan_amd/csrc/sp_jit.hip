@@ -156,7 +156,17 @@ hipFunction_t compile(const char* header, const char* expr, const sp_program* p,
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc1.c_str(), inc2.c_str(),
                         inc3.c_str()};
   int rc = r.compile(prog, 6, opts);            // built-in HIP headers: the fast, usual case
-  if (rc != 0) rc = r.compile(prog, 7, opts);   // retry with the installed ROCm headers
+  if (rc != 0) {
+    // retry with the installed ROCm headers, on a fresh program object (a failed compile leaves its
+    // partial outputs in the old one: "duplicate symbol" at link)
+    rtcProgram again = nullptr;
+    if (r.create(&again, src.c_str(), "sp_jit_program.hip", 0, nullptr, nullptr) == 0) {
+      r.destroy(&prog);
+      prog = again;
+      r.addName(prog, expr);
+      rc = r.compile(prog, 7, opts);
+    }
+  }
   hipFunction_t fn = nullptr;
   if (rc != 0) {
     if (verbose() && r.logSize && r.log) {
