@@ -289,6 +289,213 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
   }
 }
 
+// ---- point block RESIDENT in LDS (d <= 256) ------------------------------------------------------
+// The streaming kernel above re-reads its 128-point block from L2/HBM once per center block (PMC:
+// 8.9 GB fetched per call at configs[3] for 1.28 GB of points).  MI355X has 160 KB of LDS per CU: the
+// whole block [128][d] (133 KB at d = 256) is loaded ONCE and stays; only the center tiles stream
+// (L2-resident, 1 MB in all).  One workgroup per CU, 8 waves (4 x 2), wave tile 32 x 64 -- two waves per
+// SIMD, so one wave's LDS reads / epilogue hide behind the other's MFMAs.
+// MEASURED (profiles/r01_notes.md): HBM fetch drops from 8.9 GB to 1.56 GB per call (1.28 GB algorithmic), but the
+// kernel is SLOWER (95 vs 107 TFLOP/s at d = 256, 82 vs 94 at d = 128): the re-reads were not the limiter,
+// one workgroup per CU with 32 x 64 wave tiles is.  Kept selectable (SP_KM_ARES=1), not the default.
+constexpr int KA_THREADS = 512, KA_BN = 128;
+constexpr int KA_B_FLOATS = KM_BK * KA_BN;
+
+template <bool FAST>
+__global__ __launch_bounds__(KA_THREADS, 1) void sp_nearest_ares_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                        const float* __restrict__ Ct,
+                                                                        const float* __restrict__ chalf,
+                                                                        const unsigned* __restrict__ cmax2_bits,
+                                                                        int n, int d, int dp, int kp,
+                                                                        int64_t* __restrict__ labels,
+                                                                        int* __restrict__ amb_rows,
+                                                                        int* __restrict__ amb_count) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  __shared__ float xn_s[KM_BM];
+  __shared__ float mb_s[KM_BM], ms_s[KM_BM];
+  __shared__ int mi_s[KM_BM];
+  const int lda = dp + 4;                       // row pad: 8 consecutive rows cover the 32 LDS banks in 16-B units
+  float* sAres = dsm;                           // [128][lda]
+  float* sBst = dsm + KM_BM * lda;              // 2 x [16][128]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;        // 4 x 2 waves
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * KM_BM;
+
+  // ---- the point block, once: coalesced 16-B loads along the features
+  {
+    const int q4 = dp / 4;                      // float4 per row
+    for (int e = tid; e < KM_BM * q4; e += KA_THREADS) {
+      const int row = e / q4, kq = e - row * q4;
+      int grow = m0 + row;
+      if (grow > n - 1) grow = n - 1;           // clamp: results of rows >= n are discarded
+      const float* p = X + (int64_t)grow * ldx + kq * 4;
+      km_f32x4 v;
+      if constexpr (FAST) {
+        v = *(const km_f32x4*)p;
+      } else {
+        const int kk = kq * 4;
+        v.x = kk + 0 < d ? p[0] : 0.f;
+        v.y = kk + 1 < d ? p[1] : 0.f;
+        v.z = kk + 2 < d ? p[2] : 0.f;
+        v.w = kk + 3 < d ? p[3] : 0.f;
+      }
+      *(km_f32x4*)(sAres + row * lda + kq * 4) = v;
+    }
+  }
+  // B tile loads: 16 x 128 floats = 512 float4, one per thread
+  const int b_row = tid / (KA_BN / 4), b_nq = tid % (KA_BN / 4);
+  const int b_lds = b_row * KA_BN + b_nq * 4;
+  const int b_off = b_row * kp + b_nq * 4;
+  const int nt = dp / KM_BK;
+  const int tiles_n = kp / KA_BN;
+  const int steps = nt * tiles_n;
+  km_f32x4 rb;
+#define KA_LOAD(step)                                                              \
+  do {                                                                             \
+    const int tn_ = (step) / nt, kt_ = (step) - tn_ * nt;                          \
+    rb = *(const km_f32x4*)(Ct + (int64_t)(kt_ * KM_BK) * kp + tn_ * KA_BN + b_off); \
+  } while (0)
+#define KA_STORE(buf) *(km_f32x4*)(sBst + (buf) * KA_B_FLOATS + b_lds) = rb
+
+  KA_LOAD(0);
+  KA_STORE(0);
+  __syncthreads();
+  // |x|^2 per row from the resident block (feeds the error bound only)
+  for (int r = wid; r < KM_BM; r += KA_THREADS / 64) {
+    float s = 0.f;
+    for (int k = lane; k < dp; k += 64) {
+      const float v = sAres[r * lda + k];
+      s = __builtin_fmaf(v, v, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) xn_s[r] = s;
+  }
+
+  km_f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float best[16], second[16];
+  int btile[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    best[r] = INFINITY;
+    second[r] = INFINITY;
+    btile[r] = 0;
+  }
+  const int a_frag = (wm * 32 + l31) * lda + 4 * lh;
+  const int b_frag = (4 * lh) * KA_BN + wn * 64 + l31;
+  float chv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) chv[j] = chalf[(wn * 2 + j) * 32 + l31];
+  int t = 0;
+  for (int tn = 0; tn < tiles_n; ++tn) {
+    for (int kt = 0; kt < nt; ++kt, ++t) {
+      if (t + 1 < steps) KA_LOAD(t + 1);
+      const float* sB = sBst + (t & 1) * KA_B_FLOATS;
+      const float* sA = sAres + a_frag + kt * KM_BK;
+#pragma unroll
+      for (int c = 0; c < KM_BK / 8; ++c) {
+        const km_f32x4 af = *(const km_f32x4*)(sA + c * 8);
+        float bf[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag + (c * 8 + s) * KA_BN + j * 32];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[j][s], acc[j], 0, 0, 0);
+      }
+      if (t + 1 < steps) KA_STORE((t + 1) & 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tile = tn * 4 + wn * 2 + j;
+      const float ch = chv[j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = ch - acc[j][r];
+        const bool better = v < best[r];
+        second[r] = fminf(second[r], fmaxf(v, best[r]));
+        btile[r] = better ? tile : btile[r];
+        best[r] = fminf(best[r], v);
+        acc[j][r] = 0.f;
+      }
+    }
+    if (tn + 1 < tiles_n) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) chv[j] = chalf[((tn + 1) * 4 + wn * 2 + j) * 32 + l31];
+    }
+  }
+#undef KA_LOAD
+#undef KA_STORE
+
+  int bidx[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float b = best[r], s = second[r];
+    int ix = btile[r] * 32 + l31;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const float ob = __shfl_xor(b, off), os = __shfl_xor(s, off);
+      const int oi = __shfl_xor(ix, off);
+      if (ob < b || (ob == b && oi < ix)) {
+        s = fminf(b, os);
+        b = ob;
+        ix = oi;
+      } else {
+        s = fminf(ob, s);
+      }
+    }
+    best[r] = b;
+    second[r] = s;
+    bidx[r] = ix;
+  }
+  if (wn == 1 && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      mb_s[row] = best[r];
+      ms_s[row] = second[r];
+      mi_s[row] = bidx[r];
+    }
+  }
+  __syncthreads();
+  if (wn == 0 && l31 == 0) {
+    const float cmax2 = __uint_as_float(*cmax2_bits);
+    const float cmax = sqrtf(cmax2) * 1.0000002f;
+    const float u = 5.9604645e-8f;   // 2^-24
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float b = best[r], s = second[r];
+      int ix = bidx[r];
+      const float ob = mb_s[row], os = ms_s[row];
+      const int oi = mi_s[row];
+      if (ob < b || (ob == b && oi < ix)) {
+        s = fminf(b, os);
+        b = ob;
+        ix = oi;
+      } else {
+        s = fminf(ob, s);
+      }
+      if (m0 + row < n) {
+        const float xnorm = sqrtf(xn_s[row]) * 1.001f;
+        const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
+        const bool sure = 2.0f * (s - b) > 4.0f * E;
+        labels[m0 + row] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
+        if (!sure) amb_rows[atomicAdd(amb_count, 1)] = m0 + row;
+      }
+    }
+  }
+}
+
 static inline int64_t km_round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // scratch layout of sp_nearest_center (all 256-B aligned)
@@ -357,6 +564,35 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
   SP_CHECK_LAUNCH();
   const unsigned blocks = (unsigned)((n + KM_BM - 1) / KM_BM);
   const bool fast = (d % KM_BK == 0) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+  // d <= 256: the point block fits the CU's LDS next to the streaming center tiles -> resident variant
+  static int ares_env = -1;
+  if (ares_env < 0) {
+    const char* e = getenv("SP_KM_ARES");
+    ares_env = e ? atoi(e) : 0;   // measured slower than the streaming kernel (see the kernel's comment): opt-in
+  }
+  if (ares_env && dp <= 256) {
+    const size_t lds = (size_t)(KM_BM * (dp + 4) + 2 * KA_B_FLOATS) * 4;
+    static bool attr_set[2] = {false, false};
+    if (fast) {
+      auto kfn = sp_nearest_ares_kernel<true>;
+      if (!attr_set[0]) {
+        SP_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        attr_set[0] = true;
+      }
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(KA_THREADS), lds, st, X, ldx, Ct, cn, cmax2, (int)n, (int)d, (int)dp,
+                         (int)kp, labels, w.amb_rows, w.amb_count);
+    } else {
+      auto kfn = sp_nearest_ares_kernel<false>;
+      if (!attr_set[1]) {
+        SP_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        attr_set[1] = true;
+      }
+      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(KA_THREADS), lds, st, X, ldx, Ct, cn, cmax2, (int)n, (int)d, (int)dp,
+                         (int)kp, labels, w.amb_rows, w.amb_count);
+    }
+    SP_CHECK_LAUNCH();
+    return 0;
+  }
   // column block of a workgroup: 128 centers (2 MFMA tiles per wave).  256 (SP_KM_TN=4) needs 47 spilled
   // registers at 2 workgroups/CU and measured 1.7 % slower (profiles/r01_notes.md)
   static int tn_env = -1;
