@@ -118,7 +118,8 @@ def _program(seed, api):
 @pytest.mark.parametrize('workers', [1, 3])
 def test_fuzz_hip_vs_oracle_backend(workers):
   from oracle.np_backend import NumpyBackend
-  seeds = range(1000 * workers, 1000 * workers + 500)
+  import os
+  seeds = range(1000 * workers, 1000 * workers + int(os.environ.get('SPARTAN_FUZZ_N', '500')))
   want = {}
   sp.initialize(backend=NumpyBackend(), num_workers=workers)
   try:
