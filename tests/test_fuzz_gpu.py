@@ -162,3 +162,50 @@ def test_fuzz_hip_vs_oracle_backend(workers):
   finally:
     sp.shutdown()
   assert not bad, '%d of %d programs disagree: %s' % (len(bad), len(seeds), bad[:12])
+
+
+def _dot_case(seed, api):
+  rng = np.random.RandomState(seed)
+  M, K, N = [int(v) for v in rng.randint(1, 260, size=3)]
+  if rng.rand() < 0.25:
+    M, K, N = M * 8, K * 8, N * 8          # big enough for several GEMM macro-tiles / split-K
+  dt = [np.float32, np.float64, np.int64, np.float32][rng.randint(4)]
+  kind = rng.randint(5)
+  a = rng.randint(-3, 4, size=(M, K)).astype(dt)
+  b = rng.randint(-3, 4, size=(K, N)).astype(dt)
+  if kind == 1:
+    b = b[:, 0].copy()                     # matrix . vector
+  elif kind == 2:
+    a, b = a[0].copy(), b[:, 0].copy()     # vector . vector
+  elif kind == 3:
+    b = np.ascontiguousarray(b)            # driver-side NumPy rhs (dot_map2_np_mapper)
+    return np.asarray(api.dot(api.from_numpy(a), b).glom())
+  hint = None
+  if kind == 4 and M > 4:
+    hint = (max(1, M // 3), N)
+  A, B = api.from_numpy(a), api.from_numpy(b)
+  return np.asarray((api.dot(A, B, tile_hint=hint) if hint else api.dot(A, B)).glom())
+
+
+@pytest.mark.parametrize('workers', [1, 4])
+def test_fuzz_dot_dispatch(workers):
+  """Random dot shapes / ranks / dtypes / tilings: every dispatch branch of dot.py:243-299 and the GEMM,
+  split-K, matrix.vector and generic-dtype kernels, integer-valued operands so the results are exact."""
+  from oracle.np_backend import NumpyBackend
+  seeds = range(7000 * workers, 7000 * workers + 120)
+  sp.initialize(backend=NumpyBackend(), num_workers=workers)
+  try:
+    want = {s: _dot_case(s, sp) for s in seeds}
+  finally:
+    sp.shutdown()
+  sp.initialize('hip', num_workers=workers)
+  bad = []
+  try:
+    for s in seeds:
+      got = _dot_case(s, sp)
+      w = want[s]
+      if got.dtype != w.dtype or got.shape != w.shape or not np.array_equal(got, w):
+        bad.append((s, got.dtype, got.shape, w.dtype, w.shape))
+  finally:
+    sp.shutdown()
+  assert not bad, bad[:10]
