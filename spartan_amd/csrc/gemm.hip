@@ -17,15 +17,21 @@
 //     and B), which is legal because the contraction index order only has to
 //     agree between A and B;
 //   - B is kept [k][n]; fragments are 4 x ds_read_b32 (lanes along n);
-//   - XCD-aware block -> tile mapping: each XCD walks a contiguous range of a
-//     GROUP_M-grouped tile order so that the 64 workgroups resident on one XCD
-//     share A and B panels in that XCD's private L2.
+//   - XCD-aware block -> tile mapping: each XCD walks a contiguous range of the
+//     tile order, so the 64 workgroups resident on one XCD are neighbours and share
+//     their A panel in that XCD's private L2 (see SP_GEMM_GROUP_M).
 #include "sp_common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define SP_GEMM_GROUP_M 8
+// Tiles are walked m-fastest inside groups of SP_GEMM_GROUP_M tile rows.  Measured on 8192^3 (PMC, 2 x
+// FETCH_SIZE): group 32 / 16 / 8 / 4 / 2 / 1 -> 23.7 / 22.3 / 18.6 / 12.9 / 10.6 / 10.1 GB of L2 misses and
+// 137.5 -> 139.5 TFLOP/s: only the A panel shared by the WGs of one tile ROW is reliably served from the
+// XCD's L2, so the plain row-major walk (group 1: 64 resident WGs = one 256-row A panel x 64 B panels) wins.
+#ifndef SP_GEMM_GROUP_M
+#define SP_GEMM_GROUP_M 1
+#endif
 
 template <int BM, int BN, int BK, int WM, int WN>
 struct GemmCfg {

@@ -19,7 +19,7 @@ namespace {
 constexpr int DBM = 128, DBN = 128, DBK = 8;
 constexpr int DLDA = DBK + 1;
 constexpr int DA_DOUBLES = DBM * DLDA, DB_DOUBLES = DBK * DBN, DSTAGE = DA_DOUBLES + DB_DOUBLES;
-constexpr int DGROUP_M = 8;
+constexpr int DGROUP_M = 1;   // row-major walk inside an XCD's range (see SP_GEMM_GROUP_M in gemm.hip)
 
 __device__ __forceinline__ void dgemm_tile_of_block(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
   const int xcd = bid & 7, local = bid >> 3;
