@@ -398,6 +398,16 @@ struct RedPlan {
 
 static const int64_t kTargetBlocks = (int64_t)SP_CUS * SP_BLOCKS_PER_CU;
 
+// workgroups the planner aims for when it splits the reduced axis (SP_RED_TARGET: tuning knob)
+static int64_t sp_plan_target() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* e = getenv("SP_RED_TARGET");
+    v = e ? atoll(e) : kTargetBlocks;
+  }
+  return v;
+}
+
 static RedPlan sp_plan(int V, int64_t O, int64_t A, int64_t I) {
   RedPlan pl;
   memset(&pl, 0, sizeof(pl));
@@ -411,7 +421,7 @@ static RedPlan sp_plan(int V, int64_t O, int64_t A, int64_t I) {
     pl.kind = 0;
     const int64_t unit = (int64_t)SP_BLOCK * V;  // one pass of the workgroup
     const int64_t min_chunk = unit * 8;
-    int64_t want = (kTargetBlocks + O - 1) / O;       // splits needed to fill the chip
+    int64_t want = (sp_plan_target() + O - 1) / O;       // splits needed to fill the chip
     int64_t maxs = (A + min_chunk - 1) / min_chunk;   // splits the row can afford
     int64_t ns = want < maxs ? want : maxs;
     if (ns < 1) ns = 1;
@@ -428,7 +438,7 @@ static RedPlan sp_plan(int V, int64_t O, int64_t A, int64_t I) {
   pl.kind = 2;
   const int64_t bx = (I + 64 * V - 1) / (64 * V);
   const int64_t min_chunk = (SP_BLOCK / 64) * 16;
-  int64_t want = (kTargetBlocks + bx * O - 1) / (bx * O);
+  int64_t want = (sp_plan_target() + bx * O - 1) / (bx * O);
   int64_t maxs = (A + min_chunk - 1) / min_chunk;
   int64_t ns = want < maxs ? want : maxs;
   if (ns < 1) ns = 1;

@@ -147,8 +147,19 @@ def bench_kmeans(n, k, d):
   print('segment_sum (uniform random labels)  %8.3f ms  %8.1f GB/s' % (ms, 4.0 * n * d / ms / 1e6))
 
 
+def prewarm():
+  """~150 ms of streaming load before anything is timed: these boxes stall dispatch once (~30 ms) about
+  50 ms into the first sustained load of a process and ramp clocks afterwards (profiles/r01_notes.md)."""
+  a = torch.empty(1 << 30, dtype=torch.uint8, device=DEV)
+  b = torch.empty(1 << 30, dtype=torch.uint8, device=DEV)
+  for _ in range(400):
+    kernels.stream_copy(b, a)
+  torch.cuda.synchronize()
+
+
 if __name__ == '__main__':
   what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+  prewarm()
   if what in ('all', 'copy'):
     bench_copy(2 << 30)
   if what in ('all', 'map'):
