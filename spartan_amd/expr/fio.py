@@ -154,3 +154,31 @@ def unpickle(prefix, path='.', iszip=False):
                  kw={'path': path, 'prefix': prefix, 'sparse': info['sparse'], 'dtype': info['dtype'],
                      'iszip': iszip, 'ispickle': True},
                  shape_hint=info['shape'])
+
+
+def from_file(fn, file_type='numpy', sparse=True, tile_hint=None):
+  """Make an array from a file read on the driver (write_array.py:380-421): `numpy` (.npy / one-array
+  .npz) or `mm` (Matrix Market).  Sparse inputs would become sparse tiles in the reference; those are
+  outside the GPU tile path, so `sparse=True` (the reference's default) is refused loudly
+  unless the Matrix Market file holds a dense array."""
+  from .builtins import from_numpy
+  if file_type == 'numpy':
+    if sparse:
+      raise NotImplementedError('from_file(sparse=True): sparse tiles are outside the GPU tile path; '
+                                'pass sparse=False for a dense .npy / .npz file')
+    npa = np.load(fn)
+    if fn.endswith("npz"):
+      data = None
+      for _k, v in npa.items():      # "we expect only one npy in npz" (write_array.py:409-413)
+        data = v
+      npa.close()
+      npa = data
+  elif file_type == 'mm':
+    import scipy.io
+    import scipy.sparse
+    npa = scipy.io.mmread(fn)
+    if scipy.sparse.issparse(npa):
+      raise NotImplementedError('from_file: %s holds a sparse matrix; sparse tiles are outside the GPU tile path' % fn)
+  else:
+    raise NotImplementedError("Only support npy and mm now. Got %s" % file_type)
+  return from_numpy(np.asarray(npa), tile_hint)

@@ -53,6 +53,16 @@ def _check(tmp):
   np.testing.assert_array_equal(sp.load('expr', path=tmp).glom(), a + 1)
   with pytest.raises(IOError):
     sp.load('nothing-here', path=tmp)
+  # from_file: dense .npy / .npz / Matrix Market read on the driver (write_array.py:380-421)
+  import scipy.io
+  np.save(os.path.join(tmp, 'dense.npy'), a)
+  np.savez(os.path.join(tmp, 'dense.npz'), only=a)
+  scipy.io.mmwrite(os.path.join(tmp, 'dense.mtx'), a.astype(np.float64))
+  np.testing.assert_array_equal(sp.from_file(os.path.join(tmp, 'dense.npy'), sparse=False).glom(), a)
+  np.testing.assert_array_equal(sp.from_file(os.path.join(tmp, 'dense.npz'), sparse=False, tile_hint=(12, 10)).glom(), a)
+  np.testing.assert_array_equal(sp.from_file(os.path.join(tmp, 'dense.mtx'), file_type='mm').glom(), a.astype(np.float64))
+  with pytest.raises(NotImplementedError):
+    sp.from_file(os.path.join(tmp, 'dense.npy'))          # sparse=True is the reference's default
 
 
 @pytest.mark.parametrize('workers', [1, 4])
