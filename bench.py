@@ -110,6 +110,17 @@ def hbm_section(ctx):
   out['argmax_axis1_GBps'] = round(4.0 * n / ms / 1e6, 1)
   del X, Xv, x
   torch.cuda.empty_cache()
+  # the reference's DEFAULT dtype is float64 (its builders make np.float arrays): same tile shape halved
+  Xd = sp.astype(sp.from_tile_fn((rows, cols // 2), np.float32,
+                                 lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 9)), np.float64).force()
+  Xdv = sp.Val(val=Xd)
+  nd = rows * (cols // 2)
+  ms = event_time(lambda: (Xdv * Xdv + Xdv).optimized().force(), 10)
+  out['map_xx_plus_x_f64_jit_GBps'] = round(16.0 * nd / ms / 1e6, 1)      # 8*(n_in+1)*E bytes
+  ms = event_time(lambda: sp.sum(Xdv, 0).force(), 10)
+  out['sum_axis0_f64_jit_GBps'] = round(8.0 * nd / ms / 1e6, 1)
+  del Xd, Xdv
+  torch.cuda.empty_cache()
   # one linear-regression step on a BASELINE configs[4] per-GPU tile (125000 x 4096 fp32):
   # yp = dot(X, w); grad = sum(X * (yp - y), axis=0)  (sgd.py:34-39) -- X streamed twice
   N, D = 125000, 4096
