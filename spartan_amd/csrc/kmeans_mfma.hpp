@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
                                                                   const unsigned* __restrict__ cmax2_bits, int n,
                                                                   int d, int kp, int64_t* __restrict__ labels,
                                                                   int* __restrict__ amb_rows,
+                                                                  float* __restrict__ amb_best,
                                                                   int* __restrict__ amb_count) {
   constexpr int KM_BN = 64 * TN, KM_B_FLOATS = KM_BK * KM_BN, KM_STAGE = KM_A_FLOATS + KM_B_FLOATS;
   constexpr int BV = TN;   // float4 of B per thread per k-step
@@ -283,7 +284,11 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
           const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
           const bool sure = 2.0f * (s - b) > 4.0f * E;     // (scores are halved) false for NaN / inf-inf as well
           labels[m0 + row] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
-          if (!sure) amb_rows[atomicAdd(amb_count, 1)] = m0 + row;   // (order-free: each listed point is re-done on its own)
+          if (!sure) {   // (order-free: each listed point is re-done on its own)
+            const int pos = atomicAdd(amb_count, 1);
+            amb_rows[pos] = m0 + row;
+            amb_best[pos] = b;   // its best (halved) fp32 score: the re-check's candidate window starts here
+          }
         }
       }
   }
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(KA_THREADS, 1) void sp_nearest_ares_kernel(const fl
                                                                         int n, int d, int dp, int kp,
                                                                         int64_t* __restrict__ labels,
                                                                         int* __restrict__ amb_rows,
+                                                                        float* __restrict__ amb_best,
                                                                         int* __restrict__ amb_count) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   __shared__ float xn_s[KM_BM];
@@ -490,7 +496,11 @@ __global__ __launch_bounds__(KA_THREADS, 1) void sp_nearest_ares_kernel(const fl
         const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
         const bool sure = 2.0f * (s - b) > 4.0f * E;
         labels[m0 + row] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
-        if (!sure) amb_rows[atomicAdd(amb_count, 1)] = m0 + row;
+        if (!sure) {
+          const int pos = atomicAdd(amb_count, 1);
+          amb_rows[pos] = m0 + row;
+          amb_best[pos] = b;
+        }
       }
     }
   }
@@ -507,6 +517,7 @@ struct KmWorkspace {
   unsigned* cmax2;   // [1]       max |c|^2 (float bits)
   int* amb_count;    // [1]
   int* amb_rows;     // [n]       points the fused kernel could not decide
+  float* amb_best;   // [n]       their best (halved) fp32 score
 };
 
 static inline size_t km_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -514,7 +525,7 @@ static inline size_t km_align(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t sp_nearest_fused_ws_bytes(int64_t n, int64_t k, int64_t d) {
   const int64_t kp = km_round_up(k < 1 ? 1 : k, KM_BN_MAX), dp = km_round_up(d < 1 ? 1 : d, KM_BK);
   return 256 + km_align((size_t)(d < 1 ? 1 : d) * kp * 8) + km_align((size_t)dp * kp * 4) + km_align((size_t)kp * 4) + 256 + 256 +
-         km_align((size_t)(n < 1 ? 1 : n) * 4);
+         2 * km_align((size_t)(n < 1 ? 1 : n) * 4);
 }
 
 static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
@@ -533,7 +544,8 @@ static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
   w.amb_count = (int*)p;
   p += 256;
   w.amb_rows = (int*)p;
-  (void)n;
+  p += km_align((size_t)(n < 1 ? 1 : n) * 4);
+  w.amb_best = (float*)p;
   return w;
 }
 
@@ -580,7 +592,7 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
         attr_set[0] = true;
       }
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(KA_THREADS), lds, st, X, ldx, Ct, cn, cmax2, (int)n, (int)d, (int)dp,
-                         (int)kp, labels, w.amb_rows, w.amb_count);
+                         (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count);
     } else {
       auto kfn = sp_nearest_ares_kernel<false>;
       if (!attr_set[1]) {
@@ -588,7 +600,7 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
         attr_set[1] = true;
       }
       hipLaunchKernelGGL(kfn, dim3(blocks), dim3(KA_THREADS), lds, st, X, ldx, Ct, cn, cmax2, (int)n, (int)d, (int)dp,
-                         (int)kp, labels, w.amb_rows, w.amb_count);
+                         (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count);
     }
     SP_CHECK_LAUNCH();
     return 0;
@@ -603,7 +615,7 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
   const int tn_sel = tn_env == 4 ? 4 : 2;
 #define KM_GO(F, T)                                                                                              \
   hipLaunchKernelGGL((sp_nearest_fused_kernel<F, T>), dim3(blocks), dim3(256), 0, st, X, ldx, Ct, cn, cmax2, (int)n, \
-                     (int)d, (int)kp, labels, w.amb_rows, w.amb_count)
+                     (int)d, (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count)
   if (fast) {
     if (tn_sel == 4) KM_GO(true, 4);
     else KM_GO(true, 2);
