@@ -101,6 +101,7 @@ enum sp_opcode {
   SP_OP_FLOOR = 38,
   SP_OP_CEIL = 39,
   SP_OP_TANH = 40,
+  SP_OP_NORM_CDF = 41, /* standard normal CDF, 0.5 * erfc(-x / sqrt(2)) (statistics.py:224-225) */
   /* ternary: dst = a ? b : c */
   SP_OP_WHERE = 45,
   /* dtype normalisation inside a wider class */

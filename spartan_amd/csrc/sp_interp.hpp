@@ -217,6 +217,7 @@ struct sp_math<float> {
   static __device__ __forceinline__ T exp_(T a) { return expf(a); }
   static __device__ __forceinline__ T log_(T a) { return logf(a); }
   static __device__ __forceinline__ T tanh_(T a) { return tanhf(a); }
+  static __device__ __forceinline__ T normcdf_(T a) { return 0.5f * erfcf(-a * 0.70710678118654752440f); }
   static __device__ __forceinline__ T floor_(T a) { return floorf(a); }
   static __device__ __forceinline__ T ceil_(T a) { return ceilf(a); }
   static __device__ __forceinline__ T abs_(T a) { return fabsf(a); }
@@ -258,6 +259,7 @@ struct sp_math<double> {
   static __device__ __forceinline__ T exp_(T a) { return exp(a); }
   static __device__ __forceinline__ T log_(T a) { return log(a); }
   static __device__ __forceinline__ T tanh_(T a) { return tanh(a); }
+  static __device__ __forceinline__ T normcdf_(T a) { return 0.5 * erfc(-a * 0.70710678118654752440); }
   static __device__ __forceinline__ T floor_(T a) { return floor(a); }
   static __device__ __forceinline__ T ceil_(T a) { return ceil(a); }
   static __device__ __forceinline__ T abs_(T a) { return fabs(a); }
@@ -298,6 +300,7 @@ struct sp_math<int64_t> {
   static __device__ __forceinline__ T exp_(T a) { return (T)exp((double)a); }
   static __device__ __forceinline__ T log_(T a) { return (T)log((double)a); }
   static __device__ __forceinline__ T tanh_(T a) { return (T)tanh((double)a); }
+  static __device__ __forceinline__ T normcdf_(T a) { return (T)(0.5 * erfc(-(double)a * 0.70710678118654752440)); }
   static __device__ __forceinline__ T floor_(T a) { return a; }
   static __device__ __forceinline__ T ceil_(T a) { return a; }
   static __device__ __forceinline__ T abs_(T a) { return a < 0 ? -a : a; }
@@ -447,6 +450,7 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
     case SP_OP_FLOOR: SP_EACH(M::floor_(av)); break;
     case SP_OP_CEIL: SP_EACH(M::ceil_(av)); break;
     case SP_OP_TANH: SP_EACH(M::tanh_(av)); break;
+    case SP_OP_NORM_CDF: SP_EACH(M::normcdf_(av)); break;
     case SP_OP_WHERE: {
       const int rc = (I.c & (SP_NREG - 1)) * V;
       T c[U][V];

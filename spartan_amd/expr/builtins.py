@@ -250,6 +250,12 @@ def sqrt(v): return map(v, fn=np.sqrt)
 def abs(v): return map(v, fn=np.abs)
 
 
+def norm_cdf(v):
+  """Standard normal CDF (statistics.py:224-225)."""
+  import scipy.stats
+  return map(v, fn=scipy.stats.norm.cdf)
+
+
 def _sum_local(ex, data, axis):
   """mathematics.py:126-127."""
   return data.sum(axis)

@@ -126,6 +126,11 @@ for _name, _fn in [
     ('TANH', np.tanh)]:
   _ufunc(_name, _fn)
 # np.true_divide is np.divide, np.remainder is np.mod, np.absolute is np.abs in NumPy 2
+try:   # statistics.py:224-225: norm_cdf maps scipy.stats.norm.cdf over the tiles
+  import scipy.stats as _scipy_stats
+  _ufunc('NORM_CDF', _scipy_stats.norm.cdf)
+except ImportError:   # pragma: no cover
+  _scipy_stats = None
 
 
 def _where(args, kw, ex):

@@ -60,6 +60,14 @@ def _check_all():
   np.testing.assert_array_equal(sp.bincount(sp.from_numpy(lab), minlength=20).glom(), np.bincount(lab, minlength=20))
   np.testing.assert_array_equal(sp.bincount(sp.from_numpy(lab), weights=sp.from_numpy(wts)).glom(),
                                 np.bincount(lab, weights=wts))
+  # norm_cdf (statistics.py:224-225): scipy.stats.norm.cdf per tile; float64 in, float64 out
+  import scipy.stats
+  z = (np.arange(41 * 7, dtype=np.float64).reshape(41, 7) - 140) / 23.0
+  got = sp.norm_cdf(sp.from_numpy(z)).glom()
+  assert got.dtype == np.float64
+  np.testing.assert_allclose(got, scipy.stats.norm.cdf(z), rtol=1e-13, atol=1e-300)
+  got32 = sp.norm_cdf(sp.from_numpy(z.astype(np.float32)) * 2).optimized().glom()
+  np.testing.assert_allclose(got32, scipy.stats.norm.cdf(z.astype(np.float32) * 2), rtol=1e-6)
   # norm / normalize
   assert sp.norm(sp.from_numpy(a), 1) == np.abs(a).sum(axis=0).max()
   x = a[:, 0].copy()
