@@ -231,5 +231,18 @@ class NumpyBackend(object):
     self.launches += 1
     return self._wrap(np.concatenate((_np(a), _np(b)), axis=axis))
 
+  def diag_extract(self, t, slices):
+    """creation.py:275."""
+    self.launches += 1
+    return self._wrap(_np(t)[slices].diagonal().copy())
+
+  def diag_embed(self, t, width, col0):
+    """creation.py:236-241 (np.diagflat + zero blocks left / right)."""
+    self.launches += 1
+    flat = _np(t).ravel()
+    out = np.zeros((flat.shape[0], int(width)), flat.dtype)
+    out[np.arange(flat.shape[0]), int(col0) + np.arange(flat.shape[0])] = flat
+    return self._wrap(out)
+
   def synchronize(self):
     pass

@@ -488,5 +488,26 @@ class HipBackend(object):
     self.paste(out, tuple(hi), self.astype(b, dt))
     return out
 
+  def diag_extract(self, t, slices):
+    """t[slices].diagonal() of a 2-D tile: one strided copy (element i at i * (ld + 1))."""
+    view = t[slices]
+    n = min(view.shape)
+    out = self.empty((n,), self.dtype_of(t))
+    if n:
+      self.launches += 1
+      kernels.slice_copy(out, 0, (1,), t, view.storage_offset() - t.storage_offset(),
+                         (view.stride(0) + view.stride(1),), (n,))
+    return out
+
+  def diag_embed(self, t, width, col0):
+    """zeros((t.size, width)) with t.ravel() on the diagonal that starts at column col0 (np.diagflat + hstack)."""
+    flat = self.contiguous(t).reshape(-1)
+    m = flat.shape[0]
+    out = self.zeros((m, int(width)), self.dtype_of(t))
+    if m:
+      self.launches += 1
+      kernels.slice_copy(out, int(col0), (int(width) + 1,), flat, 0, (1,), (m,))
+    return out
+
   def synchronize(self):
     torch.cuda.synchronize(self.device)

@@ -111,3 +111,61 @@ def concatenate(a, b, axis=0):
     partition_axis = 0
   return map2((a, b), (partition_axis, partition_axis), fn=_concatenate_mapper,
               fn_kw={'axis': axis, 'shape': new_shape}, shape=new_shape)
+
+
+# ------------------------------------------------------------------ diagonal / diag / diagflat (creation.py:222-330)
+def _diagflat_mapper(extents, tiles, shape=None):
+  """creation.py:222-246: this tile's elements, ravelled, on the diagonal of rows head..tail."""
+  ex = extents[0]
+  head = extent.ravelled_pos(ex.ul, ex.array_shape)
+  tail = extent.ravelled_pos([l - 1 for l in ex.lr], ex.array_shape)
+  rows = tail - head + 1
+  dt = tiles[0].dtype if isinstance(tiles[0], distarray.Absent) else context.get().backend.dtype_of(tiles[0])
+  target_ex = extent.create((head, 0), (tail + 1, shape[1]), shape)
+  yield target_ex, _tile_op('diag_embed', (rows, shape[1]), dt, tiles[0], width=shape[1], col0=head)
+
+
+def diagflat(array):
+  """A 2-D array with the flattened input on its diagonal (creation.py:249-261)."""
+  n = int(np.prod(array.shape))
+  shape = (n, n)
+  return map2(array, 0, fn=_diagflat_mapper, fn_kw={'shape': shape}, shape=shape)
+
+
+def _diagonal_mapper(ex, tiles, shape=None):
+  """creation.py:264-279: the part of the main diagonal that crosses this tile."""
+  ex = ex[0] if isinstance(ex, (list, tuple)) else ex
+  tile = tiles[0]
+  max_dim = builtins.max(*ex.ul)
+  first_point = [max_dim for _ in range(len(ex.ul))]
+  slices = []
+  for i in range(len(ex.ul)):
+    if first_point[i] >= ex.lr[i]:
+      return
+    slices.append(slice(first_point[i] - ex.ul[i], ex.shape[i]))
+  if len(slices) != 2:
+    raise NotImplementedError('diagonal of a %d-d array' % len(slices))
+  n = builtins.min(s.stop - s.start for s in slices)
+  dt = tile.dtype if isinstance(tile, distarray.Absent) else context.get().backend.dtype_of(tile)
+  result = _tile_op('diag_extract', (n,), dt, tile, slices=tuple(slices))
+  target_ex = extent.create((first_point[0],), (first_point[0] + n,), shape)
+  yield target_ex, result
+
+
+def diagonal(a):
+  """Main diagonal (creation.py:282-299)."""
+  if len(a.shape) < 2:
+    raise ValueError("diag requires an array of at least two dimensions")
+  shape = (builtins.min(a.shape),)
+  return map2(a, fn=_diagonal_mapper, fn_kw={'shape': shape}, shape=shape)
+
+
+def diag(array, offset=0):
+  """Extract a diagonal or construct a diagonal array (creation.py:302-330)."""
+  if offset != 0:
+    raise NotImplementedError
+  if len(array.shape) == 1:
+    return diagflat(array)
+  elif len(array.shape) == 2:
+    return diagonal(array)
+  raise ValueError("Input must be 1- or 2-d.")

@@ -1,0 +1,202 @@
+"""What the reference's own dense test files check (tests/test_*.py of spartan-array/spartan), restated
+against this framework: same builders, same expectations, NumPy as the yardstick exactly as there.
+Each test names the reference test it follows.  CPU leg: host framework on the oracle backend;
+GPU leg: HIP backend.  (Sparse cases of those files are outside the GPU tile path.)"""
+import numpy as np
+import pytest
+
+import spartan_amd as spartan
+from spartan_amd import expr
+from spartan_amd.array import extent
+
+RNG = np.random.RandomState(20150708)
+
+
+def check_numpy_interface():
+  """tests/test_numpy_interface.py:24-35, test_logic.py:9-22, test_mathematics.py:9-14."""
+  A = spartan.arange(40000, dtype=np.int32).reshape(100, 400).evaluate()
+  nA = np.arange(40000).reshape(100, 400)
+  B = A.transpose().evaluate()
+  C = B.T.evaluate()
+  D = (C / 100).evaluate()
+  assert D.all().glom() == (nA.T.T / 100).all()
+  At = spartan.arange(40000, dtype=np.int32).reshape(100, 400).T / 1000
+  assert spartan.all(At).glom() == np.all(nA.T / 1000)
+  assert spartan.any(At).glom() == np.any(nA.T / 1000)
+  np.testing.assert_array_equal(spartan.arange(40000, dtype=np.int32).reshape(100, 400).prod().glom(), nA.prod())
+
+
+def check_elementwise_broadcast():
+  """tests/test_elementwise.py:10-24, test_broadcast.py:10-21."""
+  a, b = RNG.randn(10, 10), RNG.randn(10, 10)
+  np.testing.assert_array_equal(spartan.maximum(spartan.from_numpy(a), spartan.from_numpy(b)).glom(), np.maximum(a, b))
+  np.testing.assert_array_equal(spartan.maximum(spartan.from_numpy(a), 0).glom(), np.maximum(a, 0))
+  x = expr.ones((20, 1, 30, 10)).evaluate()
+  y = expr.ones((10, 30, 1)).evaluate()
+  xb, yb = expr.broadcast((x, y))
+  n = np.ones((20, 10, 30, 10), np.float32)
+  np.testing.assert_array_equal(expr.add(xb, yb).glom(), n + n)
+  np.testing.assert_array_equal(expr.sub(xb, yb).glom(), n - n)
+
+
+def check_creation():
+  """tests/test_creation.py:9-91."""
+  np.testing.assert_array_equal(spartan.eye(100, 10).glom(), np.eye(100, 10))
+  np.testing.assert_array_equal(spartan.identity(100).glom(), np.identity(100))
+  with pytest.raises(ValueError):
+    spartan.arange()
+  cases = [(((10,),), {}, np.arange(10)), (((3, 5),), {}, np.arange(15).reshape(3, 5)),
+           (((10,), -1), {}, np.arange(-1, 9)), (((10,), 1), {}, np.arange(1, 11)),
+           (((3, 5), -1), {}, np.arange(-1, 14).reshape(3, 5)), (((10,),), {'step': 2}, np.arange(0, 20, 2)),
+           (((3, 5),), {'step': 2}, np.arange(0, 30, 2).reshape(3, 5)), (((10,), -1), {'step': 2}, np.arange(-1, 19, 2)),
+           (((10,), 1), {'step': 2}, np.arange(1, 21, 2)), (((3, 5), 1), {'step': 2}, np.arange(1, 31, 2).reshape(3, 5)),
+           ((), {'stop': 10}, np.arange(10)), ((-1, 10), {}, np.arange(-1, 10)), ((1, 10), {}, np.arange(1, 10)),
+           ((-1, 19, 2), {}, np.arange(-1, 19, 2)), ((1, 21, 2), {}, np.arange(1, 21, 2))]
+  for args, kw, want in cases:
+    np.testing.assert_array_equal(spartan.arange(*args, **kw).glom(), want, err_msg=str((args, kw)))
+  for shape in ((2, 2), (15, 10), (16, 16)):
+    m = RNG.randn(*shape)
+    np.testing.assert_array_equal(spartan.diagonal(spartan.from_numpy(m)).glom(), np.diagonal(m))
+  m = RNG.randn(37, 37)
+  np.testing.assert_array_equal(spartan.diag(spartan.from_numpy(m)).glom(), np.diag(m))
+  np.testing.assert_array_equal(spartan.diag(spartan.diag(spartan.from_numpy(m))).glom(), np.diag(np.diag(m)))
+
+
+def check_newaxis_and_int_indices():
+  """tests/test_newaxis.py:9-62."""
+  na = np.arange(100).reshape(10, 10)
+  a = expr.from_numpy(na)
+  nx, N = expr.newaxis, np.newaxis
+  for idx, nidx in [((nx, slice(2, 7), slice(4, 8)), (N, slice(2, 7), slice(4, 8))),
+                    ((nx, slice(2, 7), nx, slice(4, 8), nx), (N, slice(2, 7), N, slice(4, 8), N)),
+                    ((nx, nx, nx, nx, slice(2, 7), nx, nx, nx, slice(4, 8), nx, nx, nx),
+                     (N, N, N, N, slice(2, 7), N, N, N, slice(4, 8), N, N, N))]:
+    assert a[idx].shape == na[nidx].shape
+  for idx in [(slice(2, 7), 8), (slice(2, 7), -1)]:
+    np.testing.assert_array_equal(a[idx].glom(), na[idx])
+  assert a[3:9, 4].shape == na[3:9, 4].shape and a[-1, 3:9].shape == na[-1, 3:9].shape
+  for idx, nidx in [((nx, slice(2, 7), 4), (N, slice(2, 7), 4)), ((slice(2, 7), nx, -1), (slice(2, 7), N, -1)),
+                    ((-1, nx, slice(2, 7)), (-1, N, slice(2, 7))),
+                    ((nx, slice(2, 7), nx, nx, 4, nx, nx), (N, slice(2, 7), N, N, 4, N, N))]:
+    np.testing.assert_array_equal(a[idx].glom(), na[nidx])
+
+
+def check_statistics():
+  """tests/test_statistics.py:9-69."""
+  src = np.asarray([1, 1, 1, 2, 2, 5, 5, 10])
+  np.testing.assert_array_equal(spartan.bincount(spartan.from_numpy(src)).glom(), np.bincount(src))
+  assert spartan.max(spartan.from_numpy(src)).glom() == 10 and spartan.min(spartan.from_numpy(src)).glom() == 1
+  g = np.arange(100).reshape(10, 10)
+  np.testing.assert_array_equal(spartan.min(spartan.from_numpy(g), axis=1).glom(), np.min(g, axis=1))
+  for shape in ((10,), (10, 10), (17, 17)):
+    v = RNG.randn(*shape)
+    np.testing.assert_allclose(spartan.std(spartan.from_numpy(v)).glom(), np.std(v), rtol=1e-9)
+  for shape in ((10, 10), (15, 13), (13, 15), (17, 17)):
+    v = RNG.randn(*shape)
+    for ax in (0, 1):
+      np.testing.assert_allclose(spartan.std(spartan.from_numpy(v), ax).glom(), np.std(v, ax), rtol=1e-9)
+
+
+def check_manipulation():
+  """tests/test_manipulation.py:12-36."""
+  x = spartan.arange((100, 100))
+  np.testing.assert_array_equal(x.ravel().glom(), np.arange(100 * 100).astype(x.glom().dtype))
+  v = RNG.randn(10)
+  np.testing.assert_array_equal(spartan.concatenate(spartan.from_numpy(v), spartan.from_numpy(v)).glom(), np.concatenate((v, v)))
+  m = np.arange(1024).reshape(32, 32)
+  for ax in (0, 1):
+    np.testing.assert_array_equal(spartan.concatenate(spartan.from_numpy(m), spartan.from_numpy(m), ax).glom(),
+                                  np.concatenate((m, m), ax))
+  p, q = RNG.randn(15, 5), RNG.randn(15, 7)
+  np.testing.assert_array_equal(spartan.concatenate(spartan.from_numpy(p), spartan.from_numpy(q), 1).glom(),
+                                np.concatenate((p, q), 1))
+
+
+def check_assign():
+  """tests/test_assign.py:10-83."""
+  a, b = np.zeros((20, 10)), np.ones((10,))
+  got = expr.assign(expr.from_numpy(a), np.s_[10, ], b).glom()
+  a[np.s_[10, ]] = b
+  np.testing.assert_array_equal(got, a)
+  b = RNG.randn(100)
+  sp_b = expr.from_numpy(b)
+  for ra, rb in [(np.s_[0:100], np.s_[0:100]), (np.s_[0], np.s_[1]), (np.s_[0:10], np.s_[20:30]), (np.s_[30:60], np.s_[0:30])]:
+    a = RNG.randn(100)
+    got = expr.assign(expr.from_numpy(a), ra, sp_b[rb]).glom()
+    a[ra] = b[rb]
+    np.testing.assert_array_equal(got, a)
+  for shape, region, vshape in [((20, 10), np.s_[10, ], (10,)), ((200, 100), np.s_[50, ], (100,)),
+                                ((200, 100), np.s_[99:102, 25:75], (3, 50))]:
+    a, v = RNG.randn(*shape), RNG.randn(*vshape)
+    got = expr.assign(expr.from_numpy(a), region, expr.from_numpy(v)).glom()
+    a[region] = v
+    np.testing.assert_array_equal(got, a)
+
+
+def check_write():
+  """tests/test_write.py:30-70 (the from_file cases :9-28 live in test_fio.py)."""
+  npa = RNG.rand(100, 100)
+  q = [(slice(0, 50), slice(0, 50)), (slice(0, 50), slice(50, 100)), (slice(50, 100), slice(0, 50)),
+       (slice(50, 100), slice(50, 100))]
+  t = expr.randn(100, 100)
+  for s in q:
+    t = expr.write(t, s, npa, s)
+  np.testing.assert_array_equal(t.glom(), npa)
+  t1, t2 = expr.randn(100, 100), expr.randn(100, 100)
+  t = t2
+  for s in q:
+    t = expr.write(t, s, t1, s)
+  np.testing.assert_array_equal(t.glom(), t1.glom())
+  dst = np.arange(0, 2500, dtype=np.float64).reshape(50, 50)
+  ta = t1
+  for s in q:
+    ta = expr.write(ta, s, dst, q[0])
+  tmp = expr.write(expr.randn(100, 100), q[3], dst, q[0])
+  tb = t2
+  for s in q:
+    tb = expr.write(tb, s, tmp, q[3])
+  np.testing.assert_array_equal(ta.glom(), tb.glom())
+
+
+def check_transpose_and_region_map(workers):
+  """tests/test_transpose.py:9-38 (dense cases), test_tile_sharing.py:8-19."""
+  t1 = expr.arange((372, 134))
+  np.testing.assert_array_equal(expr.transpose(t1).glom(), np.arange(372 * 134, dtype=np.float64).reshape(372, 134).T)
+  t3 = expr.arange((11, 12, 13))
+  np.testing.assert_array_equal(expr.transpose(t3).glom(), np.transpose(np.arange(11 * 12 * 13, dtype=np.float64).reshape(11, 12, 13)))
+  m1, m2 = RNG.rand(401, 97), RNG.rand(401, 97)
+  got = expr.dot(expr.from_numpy(m1), expr.transpose(expr.from_numpy(m2))).glom()
+  assert np.all(np.isclose(got, np.dot(m1, m2.T)))
+  n = 5 * workers
+  x = expr.ones((n, 1), tile_hint=(n // workers, 1))
+  y = expr.region_map(x, extent.create((0, 0), (3, 1), (n, 1)), fn=lambda data, ex, a: data + a, fn_kw={'a': 1})
+  want = np.ones((n, 1), np.float32)
+  np.testing.assert_array_equal(x.glom(), want)
+  want[0:3, 0] += 1
+  np.testing.assert_array_equal(y.glom(), want)
+
+
+CHECKS = [check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
+          check_statistics, check_manipulation, check_assign, check_write]
+
+
+@pytest.mark.parametrize('workers', [1, 4])
+@pytest.mark.parametrize('check', CHECKS + [check_transpose_and_region_map], ids=lambda f: f.__name__)
+def test_reference_suite_host_framework(check, workers):
+  from oracle.np_backend import NumpyBackend
+  spartan.initialize(backend=NumpyBackend(), num_workers=workers)
+  try:
+    check(workers) if check is check_transpose_and_region_map else check()
+  finally:
+    spartan.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workers', [1, 3])
+@pytest.mark.parametrize('check', CHECKS + [check_transpose_and_region_map], ids=lambda f: f.__name__)
+def test_reference_suite_hip(check, workers):
+  spartan.initialize('hip', num_workers=workers)
+  try:
+    check(workers) if check is check_transpose_and_region_map else check()
+  finally:
+    spartan.shutdown()
