@@ -5,7 +5,10 @@ the ParakeetGeneration pass (spartan/expr/operator/local.py:187-209,
 optimize.py:321-370): a MapExpr's `op` tree is turned into one compiled
 function when every node is understood, and code generation failure is a soft
 error there.  Here the set of understood callables is a registry
-(`register_map_rule` / `register_reduce_rule`); an unregistered Python callable
+(`register_map_rule` / `register_reduce_rule`); any OTHER Python callable handed to
+`map` is run once on `Traced` stand-ins for its tiles, so a user function made of
+operators and NumPy ufuncs (`lambda t: np.sqrt(t * 2 + 1)`) becomes part of the fused
+kernel as well; what cannot be traced (indexing, reductions, data-dependent `if`)
 raises `NotLowerable` -- loudly, there is no CPU fallback.
 
 NumPy typing is reproduced exactly: every node's dtype is obtained by applying
@@ -278,14 +281,113 @@ def infer(op, inputs, ex, dtype_of):
   if not isinstance(op, FnCallExpr):
     raise NotLowerable('cannot lower local expression %r' % (op,))
   rule = MAP_RULES.get(op.fn)
-  if rule is None:
-    raise NotLowerable(
-        'no GPU lowering registered for local function %s; the HIP backend evaluates a closed '
-        'registry of ops (see spartan_amd/lower.py: register_map_rule) and has no CPU fallback'
-        % op.fn_name())
   args = [infer(d, inputs, ex, dtype_of) for d in op.deps]
+  if rule is None:
+    return trace(op, args, ex)
   args = [a for a in args if a.kind != 'extent']
   return rule(args, dict(op.kw), ex)
+
+
+# ----------------------------------------------------------- tracing of user functions
+class Traced(object):
+  """Stand-in for a tile handed to a user's element-wise Python function (`map(x, lambda t: t * 2 + 1)`,
+  tests/test_slice.py:23-24,41-56 of the reference).  Operators and NumPy ufuncs applied to it extend the
+  tree being lowered, so the function becomes part of the fused HIP kernel; anything that is not
+  element-wise (indexing, reductions, data-dependent `if`) is refused loudly."""
+  __array_priority__ = 1000.0
+  __slots__ = ('v',)
+
+  def __init__(self, v):
+    self.v = v
+
+  shape = property(lambda self: self.v.shape)
+  dtype = property(lambda self: self.v.dtype)
+  ndim = property(lambda self: len(self.v.shape))
+  size = property(lambda self: int(np.prod(self.v.shape, dtype=np.int64)))
+
+  def astype(self, dtype):
+    return Traced(cast(self.v, dtype))
+
+  def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+    if method != '__call__' or kwargs.get('out') is not None:
+      raise NotLowerable('only plain element-wise ufunc calls can be traced into a kernel (%s.%s)' % (ufunc.__name__, method))
+    rule = MAP_RULES.get(ufunc)
+    if rule is None:
+      raise NotLowerable('no GPU lowering registered for %s' % ufunc.__name__)
+    return Traced(rule([_as_value(i) for i in inputs], dict(kwargs), None))
+
+  def __array_function__(self, func, types, args, kwargs):
+    """Non-ufunc NumPy functions with a registered lowering (np.where ...)."""
+    rule = MAP_RULES.get(func)
+    if rule is None:
+      raise NotLowerable('numpy.%s of a tile cannot be traced into an element-wise kernel' % getattr(func, '__name__', func))
+    return Traced(rule([_as_value(i) for i in args], dict(kwargs), None))
+
+  def _refuse(self, what):
+    raise NotLowerable('%s inside a mapped function cannot be traced into an element-wise kernel' % what)
+
+  def __getitem__(self, idx): self._refuse('indexing a tile')
+  def __bool__(self): self._refuse('a data-dependent Python condition')
+  def __iter__(self): self._refuse('iterating over a tile')
+  def __len__(self): self._refuse('len() of a tile')
+  def sum(self, *a, **k): self._refuse('a reduction (.sum)')
+  def max(self, *a, **k): self._refuse('a reduction (.max)')
+  def min(self, *a, **k): self._refuse('a reduction (.min)')
+  def mean(self, *a, **k): self._refuse('a reduction (.mean)')
+  def dot(self, *a, **k): self._refuse('a contraction (.dot)')
+  def reshape(self, *a, **k): self._refuse('reshaping a tile')
+  __hash__ = None
+
+
+def _as_value(x):
+  return x.v if isinstance(x, Traced) else value_of_input(x)
+
+
+def _traced_op(ufunc, reflected=False):
+  def method(self, other=None):
+    ins = (self,) if other is None else ((other, self) if reflected else (self, other))
+    return self.__array_ufunc__(ufunc, '__call__', *ins)
+  return method
+
+
+for _dunder, _uf in dict(add=np.add, sub=np.subtract, mul=np.multiply, truediv=np.divide, floordiv=np.floor_divide,
+                         mod=np.mod, pow=np.power, lt=np.less, le=np.less_equal, gt=np.greater, ge=np.greater_equal,
+                         eq=np.equal, ne=np.not_equal, and_=np.logical_and, or_=np.logical_or,
+                         xor=np.logical_xor).items():
+  _n = _dunder.rstrip('_')
+  setattr(Traced, '__%s__' % _n, _traced_op(_uf))
+  if _n in ('add', 'sub', 'mul', 'truediv', 'floordiv', 'mod', 'pow', 'and', 'or', 'xor'):
+    setattr(Traced, '__r%s__' % _n, _traced_op(_uf, reflected=True))
+Traced.__neg__ = _traced_op(np.negative)
+Traced.__abs__ = _traced_op(np.abs)
+Traced.__invert__ = _traced_op(np.logical_not)
+
+
+def trace(op, args, ex):
+  """Run the user's function once on Traced stand-ins to obtain its element-wise tree."""
+  call = []
+  for a in args:
+    if a.kind == 'extent':
+      call.append(ex.to_tuple())          # map_with_location hands the tile's position over (local.py:137-149)
+    elif a.kind == 'const':
+      call.append(a.value)
+    else:
+      call.append(Traced(a))
+  try:
+    res = op.fn(*call, **dict(op.kw or {}))
+  except NotLowerable:
+    raise
+  except Exception as e:   # noqa: BLE001
+    raise NotLowerable('local function %s could not be traced into an element-wise kernel (%s: %s); the HIP '
+                       'backend has no CPU fallback -- use ufuncs / operators on the tile, or register a rule '
+                       '(spartan_amd/lower.py: register_map_rule)' % (op.fn_name(), type(e).__name__, e))
+  if isinstance(res, Traced):
+    return res.v
+  try:
+    return value_of_input(res)
+  except Exception:   # noqa: BLE001
+    raise NotLowerable('local function %s returned %r, not an element-wise expression of its tiles'
+                       % (op.fn_name(), type(res)))
 
 
 # -------------------------------------------------------------------- emission

@@ -176,7 +176,37 @@ def check_transpose_and_region_map(workers):
   np.testing.assert_array_equal(y.glom(), want)
 
 
-CHECKS = [check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
+def check_slices_and_user_functions():
+  """tests/test_slice.py:27-76: slices feeding map / shuffle / reduce; the mapped functions are plain
+  Python (`tile + 1`, a lambda) -- traced into the fused kernel on the HIP backend."""
+  def add_one_tile(tile):
+    return tile + 1
+
+  def add_one_extent(v, ex):
+    yield (ex, v.fetch(ex) + 1)
+  nx = np.arange(100, dtype=np.float64).reshape(10, 10)
+  x = expr.arange((10, 10))
+  np.testing.assert_array_equal(x[5:8, 5:8].evaluate().glom(), nx[5:8, 5:8])
+  np.testing.assert_array_equal(expr.map(x[5:8, 5:8], add_one_tile).glom(), nx[5:8, 5:8] + 1)
+  np.testing.assert_array_equal(expr.shuffle(x[5:8, 5:8], add_one_extent).evaluate().glom(), nx[5:8, 5:8] + 1)
+  c = expr.arange((10, 10, 10), dtype=np.int64)
+  nc = np.arange(1000, dtype=np.int64).reshape(10, 10, 10)
+  np.testing.assert_array_equal(expr.map(c[:, :, 0], lambda tile: tile + 13).glom().reshape(10, 10), nc[:, :, 0] + 13)
+  assert c[:, :, 0].sum().glom() == nc[:, :, 0].sum()
+  a = expr.arange((10,), dtype=np.int64)
+  np.testing.assert_array_equal((a[1:] - a[:-1]).glom(), np.ones(9, np.int64))
+  # richer traced functions: ufuncs, np.where, astype, several inputs, a keyword, fusion with builders
+  p, q = RNG.rand(40, 12).astype(np.float32), RNG.randint(1, 9, size=(40, 12)).astype(np.int64)
+
+  def f(u, v, scale=1.0):
+    return np.where(u > 0.5, np.sqrt(u * scale) / v, -np.abs(u)).astype(np.float32) + (v % 3)
+  got = expr.map((expr.from_numpy(p), expr.from_numpy(q)), f, fn_kw={'scale': 2.0})
+  np.testing.assert_allclose((got * 2).optimized().glom(), f(p, q, scale=2.0) * 2, rtol=1e-6)
+  with pytest.raises(Exception):
+    expr.map(expr.from_numpy(p), lambda t: t[0:2]).glom()      # not element-wise: refused, never silently wrong
+
+
+CHECKS = [check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
           check_statistics, check_manipulation, check_assign, check_write]
 
 
