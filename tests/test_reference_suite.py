@@ -206,7 +206,49 @@ def check_slices_and_user_functions():
     expr.map(expr.from_numpy(p), lambda t: t[0:2]).glom()      # not element-wise: refused, never silently wrong
 
 
-CHECKS = [check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
+def check_reshape():
+  """tests/test_reshape.py:9-120 (dense cases)."""
+  ar = lambda shape, **kw: expr.arange(shape, **kw)   # noqa: E731
+  np.testing.assert_array_equal(expr.reshape(ar((10, 10)), (100,)).glom(), ar((100,)).glom())
+  b = expr.reshape(ar((1000,), tile_hint=[100]), (10, 100)).evaluate()
+  np.testing.assert_array_equal(expr.reshape(b, (1000,)).evaluate().glom(), np.arange(1000.0))
+  chains = [((100, 100), [(10000,), (10000, 1), (1, 10000)]),
+            ((10000,), [(10, 1000), (1000, 10), (20, 500), (500, 20), (1, 10000)]),
+            ((35511,), [(133, 267), (267, 133), (1, 35511)]), ((12319,), [(127, 97), (97, 127), (1, 12319)])]
+  for start, steps in chains:
+    e = ar(start)
+    for shp in steps:
+      e = expr.reshape(e, shp)
+    np.testing.assert_array_equal(e.glom(), ar(steps[-1]).glom())
+  n = 23 * 12 * 10
+  targets = [(23, 12, 10), (12, 23, 10), (n, 1), (1, n)]
+  for src in [(10, 23, 12), (12, 23, 10), (1, n), (n, 1), (n,)]:
+    for tgt in targets:
+      np.testing.assert_array_equal(expr.reshape(ar(src), tgt).glom(), ar(tgt).glom(), err_msg=str((src, tgt)))
+  a, b2 = RNG.rand(357, 93), RNG.rand(31, 357)
+  np.testing.assert_allclose(expr.dot(expr.reshape(expr.from_numpy(a), (1071, 31)), expr.from_numpy(b2)).glom(),
+                             np.dot(a.reshape(1071, 31), b2), rtol=1e-8)
+  a, v = RNG.rand(357, 718), RNG.rand(718)
+  np.testing.assert_allclose(expr.dot(expr.from_numpy(a), expr.reshape(expr.from_numpy(v), (718, 1))).glom(),
+                             np.dot(a, v.reshape(718, 1)), rtol=1e-8)
+  u, w = RNG.rand(718), RNG.rand(1, 357)
+  np.testing.assert_allclose(expr.dot(expr.reshape(expr.from_numpy(u), (718, 1)), expr.from_numpy(w)).glom(),
+                             np.dot(u.reshape(718, 1), w), rtol=1e-8)
+
+
+def check_example_runs():
+  """tests/test_lreg.py:12-16, test_logreg.py:12-16, test_ridgereg.py, test_kmeans.py:18-23: the example
+  drivers run end to end on random data (values are random there too; shapes / finiteness are checked)."""
+  from spartan_amd.examples import linear_regression, logistic_regression, ridge_regression
+  from spartan_amd.examples.sklearn.cluster import KMeans
+  for mod, it in ((linear_regression, 3), (logistic_regression, 2), (ridge_regression, 2)):
+    w = mod.run(100, 3, it)
+    assert w.shape == (3, 1) and np.all(np.isfinite(w))
+  centers, labels = KMeans(10, 5).fit(expr.rand(100, 5))
+  assert centers.shape == (10, 5) and np.all(np.isfinite(centers)) and labels.glom().shape == (100,)
+
+
+CHECKS = [check_reshape, check_example_runs, check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
           check_statistics, check_manipulation, check_assign, check_write]
 
 
