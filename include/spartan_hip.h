@@ -337,6 +337,12 @@ int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, const int64
 int sp_random_fill(void* d_out, int32_t dtype, int64_t n, int32_t kind, uint64_t seed, uint64_t offset,
                    int64_t lo, int64_t hi, void* stream);
 
+/* sp_cumscan: np.cumsum (product == 0) / np.cumprod (product != 0) along one axis of a dense tile viewed
+ * as [outer, axis_len, inner] -- the per-tile `scan_fn(tile, axis)` of the scan operator
+ * (spartan/expr/operator/scan.py:42-63).  dtype: SP_F32 | SP_F64 | SP_I32 | SP_I64, in and out alike. */
+int sp_cumscan(const void* d_in, void* d_out, int32_t dtype, int64_t outer, int64_t axis_len, int64_t inner,
+               int32_t product, void* stream);
+
 /* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
  * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
 int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);

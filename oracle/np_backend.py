@@ -231,6 +231,17 @@ class NumpyBackend(object):
     self.launches += 1
     return self._wrap(np.concatenate((_np(a), _np(b)), axis=axis))
 
+  def reduce_axis(self, t, red_op, axis):
+    """scan.py:25."""
+    self.launches += 1
+    return self._wrap({'SUM': np.sum, 'PROD': np.prod}[red_op](_np(t), axis=axis))
+
+  def cumscan(self, t, axis, product=False):
+    """scan.py:63."""
+    self.launches += 1
+    x = _np(t)
+    return self._wrap((np.cumprod if product else np.cumsum)(x, axis=axis).astype(x.dtype).reshape(x.shape))
+
   def diag_extract(self, t, slices):
     """creation.py:275."""
     self.launches += 1

@@ -488,6 +488,23 @@ class HipBackend(object):
     self.paste(out, tuple(hi), self.astype(b, dt))
     return out
 
+  def reduce_axis(self, t, red_op, axis):
+    """np.sum / np.prod of a tile along one axis (the scan operator's per-tile totals, scan.py:25)."""
+    t = self.contiguous(t)
+    v = lower.V('tensor', dtype=self.dtype_of(t), shape=tuple(t.shape), tensor=t)
+    return self._run_reduce(v, red_op, self.dtype_of(t), tuple(t.shape), axis)
+
+  def cumscan(self, t, axis, product=False):
+    """np.cumsum / np.cumprod along `axis` (sp_cumscan)."""
+    t = self.contiguous(t)
+    if self.dtype_of(t) == np.bool_:
+      t = self.astype(t, np.int64)
+    out = self.empty(tuple(t.shape), self.dtype_of(t))
+    if out.numel():
+      self.launches += 1
+      kernels.cumscan(t, out, axis, product)
+    return out
+
   def diag_extract(self, t, slices):
     """t[slices].diagonal() of a 2-D tile: one strided copy (element i at i * (ld + 1))."""
     view = t[slices]

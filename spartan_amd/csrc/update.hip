@@ -403,3 +403,81 @@ extern "C" int sp_update(void* d_dst, int32_t dst_dtype, const int64_t* dst_shap
     default: return sp_update_launch<int64_t>(d_dst, d_src, d_mask, u, n, st);
   }
 }
+
+// ---- cumulative sum / product along one axis of a dense tile viewed as [outer, axis_len, inner] ----
+// (the per-tile `scan_fn(tile, axis)` of the reference's scan operator, spartan/expr/operator/scan.py:42-63;
+// np.cumsum / np.cumprod).  inner > 1: one thread per (outer, inner) line walks the axis in order --
+// coalesced across `inner`, NumPy's own sequential order.  inner == 1: one wavefront per line, 64
+// elements at a time (shuffle scan inside the chunk, running carry between chunks).
+template <typename T, bool PROD>
+__device__ __forceinline__ T sp_scan_op(T a, T b) { return PROD ? a * b : a + b; }
+
+template <typename T, bool PROD>
+__global__ __launch_bounds__(256) void sp_cumscan_cols_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t O,
+                                                              int64_t A, int64_t I) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= O * I) return;
+  const int64_t o = e / I, i = e - o * I;
+  const T* p = in + o * A * I + i;
+  T* q = out + o * A * I + i;
+  T acc = PROD ? (T)1 : (T)0;
+  for (int64_t a = 0; a < A; ++a) {
+    acc = sp_scan_op<T, PROD>(acc, p[a * I]);
+    q[a * I] = acc;
+  }
+}
+
+template <typename T, bool PROD>
+__global__ __launch_bounds__(256) void sp_cumscan_rows_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t O,
+                                                              int64_t A) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t o = wave; o < O; o += nwaves) {
+    T carry = PROD ? (T)1 : (T)0;
+    for (int64_t a0 = 0; a0 < A; a0 += 64) {
+      const int64_t a = a0 + lane;
+      T v = a < A ? in[o * A + a] : (PROD ? (T)1 : (T)0);
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const T u = __shfl_up(v, off);
+        if (lane >= off) v = sp_scan_op<T, PROD>(u, v);
+      }
+      v = sp_scan_op<T, PROD>(carry, v);
+      if (a < A) out[o * A + a] = v;
+      carry = __shfl(v, 63);
+    }
+  }
+}
+
+extern "C" int sp_cumscan(const void* d_in, void* d_out, int32_t dtype, int64_t outer, int64_t axis_len, int64_t inner,
+                          int32_t product, void* stream) {
+  if (outer < 0 || axis_len < 0 || inner < 0) SP_FAIL("sp_cumscan: negative size");
+  if (outer == 0 || axis_len == 0 || inner == 0) return 0;
+  if (!d_in || !d_out) SP_FAIL("sp_cumscan: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+#define SP_SCAN_GO(T)                                                                                             \
+  do {                                                                                                            \
+    if (inner > 1) {                                                                                              \
+      const int64_t n = outer * inner;                                                                            \
+      const unsigned blocks = (unsigned)((n + 255) / 256);                                                        \
+      if (product) hipLaunchKernelGGL((sp_cumscan_cols_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)d_in, (T*)d_out, outer, axis_len, inner); \
+      else hipLaunchKernelGGL((sp_cumscan_cols_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)d_in, (T*)d_out, outer, axis_len, inner); \
+    } else {                                                                                                      \
+      int64_t blocks = (outer + 3) / 4;                                                                           \
+      if (blocks > SP_CUS * 16) blocks = SP_CUS * 16;                                                             \
+      if (product) hipLaunchKernelGGL((sp_cumscan_rows_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)d_in, (T*)d_out, outer, axis_len); \
+      else hipLaunchKernelGGL((sp_cumscan_rows_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)d_in, (T*)d_out, outer, axis_len); \
+    }                                                                                                             \
+  } while (0)
+  switch (dtype) {
+    case SP_F32: SP_SCAN_GO(float); break;
+    case SP_F64: SP_SCAN_GO(double); break;
+    case SP_I64: SP_SCAN_GO(int64_t); break;
+    case SP_I32: SP_SCAN_GO(int32_t); break;
+    default: SP_FAIL("sp_cumscan: unsupported dtype %d", dtype);
+  }
+#undef SP_SCAN_GO
+  SP_CHECK_LAUNCH();
+  return 0;
+}

@@ -193,6 +193,18 @@ def random_fill(out, kind, seed, offset, lo=0, hi=1):
   return out
 
 
+def cumscan(src, out, axis, product=False):
+  """out = np.cumsum / np.cumprod(src, axis) for dense tensors of one dtype (scan.py:42-63)."""
+  _require_device(src, out)
+  assert src.is_contiguous() and out.is_contiguous() and src.dtype == out.dtype and src.shape == out.shape
+  shape = tuple(src.shape)
+  outer = int(np.prod(shape[:axis], dtype=np.int64))
+  inner = int(np.prod(shape[axis + 1:], dtype=np.int64))
+  check(_hip.lib().sp_cumscan(C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()), _hip.sp_dtype(np_dtype_of(src)),
+                              outer, shape[axis], inner, 1 if product else 0, _stream()))
+  return out
+
+
 def stream_copy(dst, src):
   _require_device(dst, src)
   n = src.numel() * src.element_size()

@@ -248,7 +248,26 @@ def check_example_runs():
   assert centers.shape == (10, 5) and np.all(np.isfinite(centers)) and labels.glom().shape == (100,)
 
 
-CHECKS = [check_reshape, check_example_runs, check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
+def check_scan():
+  """tests/test_scan.py:18-27 (np.cumsum flattens, scan keeps the shape: hence the reshape there too)."""
+  src = np.ones((10, 10), np.float32)
+  S = spartan.from_numpy(src, [5, 5])
+  np.testing.assert_array_equal(spartan.scan(S).glom(), np.cumsum(src).reshape(10, 10))
+  for ax in (0, 1):
+    np.testing.assert_array_equal(spartan.scan(S, axis=ax).glom(), np.cumsum(src, ax))
+  v = (np.arange(48 * 20).reshape(48, 20) % 7).astype(np.int64)
+  V = spartan.from_numpy(v, [12, 5])
+  np.testing.assert_array_equal(spartan.scan(V).glom(), np.cumsum(v).reshape(v.shape))
+  np.testing.assert_array_equal(spartan.scan(V, axis=0).glom(), np.cumsum(v, 0))
+  np.testing.assert_array_equal(spartan.scan(V, axis=1).glom(), np.cumsum(v, 1))
+  f = RNG.rand(300, 70)
+  np.testing.assert_allclose(spartan.scan(spartan.from_numpy(f), axis=1).glom(), np.cumsum(f, 1), rtol=1e-12)
+  np.testing.assert_allclose(spartan.scan(spartan.from_numpy(f), axis=0).glom(), np.cumsum(f, 0), rtol=1e-12)
+  w = 1 + (np.arange(24).reshape(6, 4) % 2).astype(np.float64)
+  np.testing.assert_array_equal(spartan.scan(spartan.from_numpy(w), np.prod, np.cumprod, axis=1).glom(), np.cumprod(w, 1))
+
+
+CHECKS = [check_scan, check_reshape, check_example_runs, check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
           check_statistics, check_manipulation, check_assign, check_write]
 
 
