@@ -12,26 +12,16 @@
 #include "map_kernel.hpp"
 #include "sp_jit.hpp"
 
-static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// Can the program be evaluated V elements at a time?
+// Can the program be evaluated V elements at a time?  Groups of V consecutive output elements must
+// not cross the end of the innermost dimension (broadcast / strided operands change address mode
+// there); alignment is not required (element-aligned vector accesses, sp_interp.hpp).
 template <int V>
 static bool sp_can_vectorize(const sp_program* p, const void* const* in, const void* out) {
+  (void)in;
+  (void)out;
   if (V == 1) return true;
-  const int nd = p->ndim;
-  if (p->shape[nd - 1] % V != 0) return false;
-  if (out && !aligned16(out)) return false;
-  for (int j = 0; j < p->n_inputs; ++j) {
-    const int64_t inner = p->in_stride[j][nd - 1];
-    if (inner == 1) {
-      if (!aligned16(in[j])) return false;
-      for (int d = 0; d < nd - 1; ++d)
-        if (p->in_stride[j][d] % V != 0) return false;
-    } else if (inner != 0 && !p->linear) {
-      // strided inner dimension: handled element-wise inside the vector path
-    }
-  }
-  return true;
+  return p->shape[p->ndim - 1] % V == 0;
 }
 
 int sp_validate_program(const sp_program* p) {
@@ -190,11 +180,9 @@ static int sp_map_launch(const sp_program* p, const sp_inputs& in, const void* c
   if (n == 0) return 0;
   const bool lin = p->linear != 0;
   if (lin) {
-    // dense: vector body + scalar tail
-    bool vec = aligned16(out);
-    for (int j = 0; j < p->n_inputs && vec; ++j)
-      if (p->in_stride[j][p->ndim - 1] != 0 && !aligned16(inp[j])) vec = false;
-    int64_t nmain = vec ? (n / V) * V : 0;
+    // dense: vector body + scalar tail (element-aligned vector accesses: any base address will do)
+    (void)inp;
+    int64_t nmain = (n / V) * V;
     if constexpr (std::is_same<T, float>::value) {
       const int sid = sp_static_enabled() ? sp_find_static(p, p->out_dtype) : -1;
       if (nmain && sid >= 0) {

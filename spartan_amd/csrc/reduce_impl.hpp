@@ -180,6 +180,21 @@ __device__ __forceinline__ void sp_load_partial(const RedOut& ro, int64_t slot, 
 
 // --------------------------------------------------------------- row kernels
 // [O, A] with the reduced axis contiguous.  grid = (nsplit, rows).
+// one element of the program at (row, col) / flat index L -- the scalar tails of the vector kernels
+template <typename T, bool LINEAR, typename P, int MASK>
+__device__ __forceinline__ T sp_eval_one(const sp_program& p, const sp_inputs& in, int64_t row, int64_t col, int64_t L,
+                                         bool have_rc) {
+  T x[1][1];
+  if constexpr (MASK >= 0) {
+    sp_eval_2d<T, 1, P, MASK>(p, in, (uint32_t)row, (uint32_t)col, L, x[0]);
+  } else {
+    const int64_t Ls[1] = {L};
+    const int64_t rc[1][2] = {{row, col}};
+    sp_eval_u<T, 1, 1, LINEAR, P>(p, in, Ls, x, have_rc ? rc : nullptr);
+  }
+  return x[0][0];
+}
+
 template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg, int OP = -1, int MASK = -1>
 __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_program p, const sp_inputs in,
                                                                  int op, int64_t O, int64_t A,
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
     Acc acc;
     acc.init(op);
     constexpr int U = 1;   // measured: more groups per lane do not help (profiles/r01_notes.md)
-    for (int64_t a = a0 + (int64_t)threadIdx.x * V; a < a1; a += (int64_t)SP_BLOCK * V * U) {
+    for (int64_t a = a0 + (int64_t)threadIdx.x * V; a + V <= a1; a += (int64_t)SP_BLOCK * V * U) {
       int64_t L[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -217,6 +232,14 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
 #pragma unroll
           for (int v = 0; v < V; ++v) acc.add(op, x[u][v], au + v);
         }
+      }
+    }
+    if constexpr (V > 1) {
+      // the row's last (a1 - a0) % V elements (only when the row length is not a multiple of V)
+      const int rem = (int)((a1 - a0) % V);
+      if ((int)threadIdx.x < rem) {
+        const int64_t a = a1 - rem + threadIdx.x;
+        acc.add(op, sp_eval_one<T, LINEAR, P, MASK>(p, in, o, a, o * A + a, p.ndim == 2 && p.shape[1] == A), a);
       }
     }
     acc = sp_wave_reduce(op, acc);
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
     Acc acc;
     acc.init(op);
     constexpr int U = 1;
-    for (int64_t a = (int64_t)lane * V; a < A; a += 64 * V * U) {
+    for (int64_t a = (int64_t)lane * V; a + V <= A; a += 64 * V * U) {
       int64_t L[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -266,6 +289,13 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
 #pragma unroll
           for (int v = 0; v < V; ++v) acc.add(op, x[u][v], au + v);
         }
+      }
+    }
+    if constexpr (V > 1) {
+      const int rem = (int)(A % V);
+      if (lane < rem) {
+        const int64_t a = A - rem + lane;
+        acc.add(op, sp_eval_one<T, LINEAR, P, MASK>(p, in, o, a, o * A + a, p.ndim == 2 && p.shape[1] == A), a);
       }
     }
     acc = sp_wave_reduce(op, acc);
@@ -313,7 +343,16 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
     Acc acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v].init(op);
-    if (active) {
+    const int nvalid = active ? (int)((I - c) < V ? (I - c) : V) : 0;   // < V only in the last column group
+    if (active && nvalid < V) {
+      for (int64_t a = a0 + w; a < a1; a += NW) {
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (v < nvalid)
+            acc[v].add(op, sp_eval_one<T, LINEAR, P, MASK>(p, in, o * A + a, c + v, (o * A + a) * I + c + v,
+                                                           p.ndim == 2 && p.shape[1] == I), a);
+      }
+    } else if (active) {
       constexpr int U = 1;
       for (int64_t a = a0 + w; a < a1; a += NW * U) {
         int64_t L[U];
@@ -347,6 +386,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
     if (w == 0 && active) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
+        if (v >= nvalid) break;
 #pragma unroll
         for (int k = 0; k < NW - 1; ++k) acc[v].merge(op, sm[k][lane * V + v]);
         const int64_t slot = nsplit == 1 ? o * I + c + v : ((int64_t)s * O + o) * I + c + v;
@@ -453,27 +493,18 @@ static RedPlan sp_plan(int V, int64_t O, int64_t A, int64_t I) {
   return pl;
 }
 
-static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-
-// V-wide evaluation needs every V-group of the [O,A,I] space to be contiguous
-// and 16-B aligned in each dense operand.
+// V-wide evaluation: a group of V consecutive elements along the kernel's fastest axis (A for the row
+// kernels, I for the column kernels) must stay inside one row of the PROGRAM's index space, where
+// broadcast / strided operands keep one address mode.  Linear programs address by the flat index alone.
+// Row ends that are not a multiple of V are handled by the kernels' scalar tails; alignment is not
+// required (element-aligned vector accesses, sp_interp.hpp).
 template <int V>
 static bool sp_reduce_can_vec(const sp_program* p, const void* const* in, int64_t A, int64_t I) {
-  if (V == 1) return true;
-  const int nd = p->ndim;
-  // (a linear program addresses by the flat index alone: its own shape split does not matter)
-  if (!p->linear && p->shape[nd - 1] % V != 0) return false;
-  if ((I == 1 ? A : I) % V != 0) return false;
-  for (int j = 0; j < p->n_inputs; ++j) {
-    const int64_t inner = p->in_stride[j][nd - 1];
-    if (inner == 1 || (p->linear && inner != 0)) {
-      if (!aligned16(in[j])) return false;
-      if (!p->linear)
-        for (int d = 0; d < nd - 1; ++d)
-          if (p->in_stride[j][d] % V != 0) return false;
-    }
-  }
-  return true;
+  (void)in;
+  if (V == 1 || p->linear) return true;
+  const int64_t fast = (I == 1) ? A : I;
+  const int64_t last = p->shape[p->ndim - 1];
+  return last % V == 0 || last == fast;
 }
 
 static inline int cap_dim(int64_t x, int64_t cap) { return (int)(x < cap ? (x < 1 ? 1 : x) : cap); }

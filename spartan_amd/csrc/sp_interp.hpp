@@ -41,6 +41,26 @@ struct sp_cls<int64_t> {
   static constexpr int id = SP_I64;
 };
 
+// Vector memory types with ELEMENT alignment: global_load/store_dwordx2/x4 do not need 16-B aligned
+// addresses on gfx950 (the compiler still emits one wide instruction), so rows of odd length and
+// views that start anywhere keep the 16-B-per-lane access pattern.
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+typedef double sp_f64x2 __attribute__((ext_vector_type(2)));
+typedef int32_t sp_i32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t sp_i32x2 __attribute__((ext_vector_type(2)));
+typedef int64_t sp_i64x2 __attribute__((ext_vector_type(2)));
+typedef uint8_t sp_u8x4 __attribute__((ext_vector_type(4)));
+typedef uint8_t sp_u8x2 __attribute__((ext_vector_type(2)));
+typedef sp_f32x4 sp_f32x4u __attribute__((aligned(4)));
+typedef sp_f32x2 sp_f32x2u __attribute__((aligned(4)));
+typedef sp_f64x2 sp_f64x2u __attribute__((aligned(8)));
+typedef sp_i32x4 sp_i32x4u __attribute__((aligned(4)));
+typedef sp_i32x2 sp_i32x2u __attribute__((aligned(4)));
+typedef sp_i64x2 sp_i64x2u __attribute__((aligned(8)));
+typedef sp_u8x4 sp_u8x4u __attribute__((aligned(1)));
+typedef sp_u8x2 sp_u8x2u __attribute__((aligned(1)));
+
 // ---- typed loads: `n` consecutive elements (n == V, or 1) converted to T ----
 template <typename T, int N>
 __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_t off, T* dst) {
@@ -48,10 +68,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     case SP_F32: {
       const float* p = (const float*)base + off;
       if constexpr (N == 4) {
-        float4 v = *(const float4*)p;
+        sp_f32x4u v = *(const sp_f32x4u*)p;
         dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
       } else if constexpr (N == 2) {
-        float2 v = *(const float2*)p;
+        sp_f32x2u v = *(const sp_f32x2u*)p;
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -60,10 +80,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     case SP_F64: {
       const double* p = (const double*)base + off;
       if constexpr (N == 4) {
-        double2 v0 = *(const double2*)p, v1 = *(const double2*)(p + 2);
+        sp_f64x2u v0 = *(const sp_f64x2u*)p, v1 = *(const sp_f64x2u*)(p + 2);
         dst[0] = (T)v0.x; dst[1] = (T)v0.y; dst[2] = (T)v1.x; dst[3] = (T)v1.y;
       } else if constexpr (N == 2) {
-        double2 v = *(const double2*)p;
+        sp_f64x2u v = *(const sp_f64x2u*)p;
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -72,10 +92,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     case SP_I32: {
       const int32_t* p = (const int32_t*)base + off;
       if constexpr (N == 4) {
-        int4 v = *(const int4*)p;
+        sp_i32x4u v = *(const sp_i32x4u*)p;
         dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
       } else if constexpr (N == 2) {
-        int2 v = *(const int2*)p;
+        sp_i32x2u v = *(const sp_i32x2u*)p;
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -84,10 +104,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     case SP_I64: {
       const int64_t* p = (const int64_t*)base + off;
       if constexpr (N == 4) {
-        longlong2 v0 = *(const longlong2*)p, v1 = *(const longlong2*)(p + 2);
+        sp_i64x2u v0 = *(const sp_i64x2u*)p, v1 = *(const sp_i64x2u*)(p + 2);
         dst[0] = (T)v0.x; dst[1] = (T)v0.y; dst[2] = (T)v1.x; dst[3] = (T)v1.y;
       } else if constexpr (N == 2) {
-        longlong2 v = *(const longlong2*)p;
+        sp_i64x2u v = *(const sp_i64x2u*)p;
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -96,10 +116,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     default: {  // SP_BOOL / SP_U8
       const uint8_t* p = (const uint8_t*)base + off;
       if constexpr (N == 4) {
-        uchar4 v = *(const uchar4*)p;
+        sp_u8x4u v = *(const sp_u8x4u*)p;
         dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
       } else if constexpr (N == 2) {
-        uchar2 v = *(const uchar2*)p;
+        sp_u8x2u v = *(const sp_u8x2u*)p;
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -120,9 +140,9 @@ __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off
     case SP_F32: {
       float* p = (float*)base + off;
       if constexpr (N == 4) {
-        *(float4*)p = make_float4((float)src[0], (float)src[1], (float)src[2], (float)src[3]);
+        *(sp_f32x4u*)p = sp_f32x4{(float)src[0], (float)src[1], (float)src[2], (float)src[3]};
       } else if constexpr (N == 2) {
-        *(float2*)p = make_float2((float)src[0], (float)src[1]);
+        *(sp_f32x2u*)p = sp_f32x2{(float)src[0], (float)src[1]};
       } else {
         p[0] = (float)src[0];
       }
@@ -132,7 +152,7 @@ __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off
 #pragma unroll
       for (int j = 0; j < N; j += 2) {
         if constexpr (N >= 2) {
-          *(double2*)(p + j) = make_double2((double)src[j], (double)src[j + 1]);
+          *(sp_f64x2u*)(p + j) = sp_f64x2{(double)src[j], (double)src[j + 1]};
         } else {
           p[0] = (double)src[0];
         }
@@ -141,9 +161,9 @@ __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off
     case SP_I32: {
       int32_t* p = (int32_t*)base + off;
       if constexpr (N == 4) {
-        *(int4*)p = make_int4((int32_t)src[0], (int32_t)src[1], (int32_t)src[2], (int32_t)src[3]);
+        *(sp_i32x4u*)p = sp_i32x4{(int32_t)src[0], (int32_t)src[1], (int32_t)src[2], (int32_t)src[3]};
       } else if constexpr (N == 2) {
-        *(int2*)p = make_int2((int32_t)src[0], (int32_t)src[1]);
+        *(sp_i32x2u*)p = sp_i32x2{(int32_t)src[0], (int32_t)src[1]};
       } else {
         p[0] = (int32_t)src[0];
       }
@@ -153,10 +173,7 @@ __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off
 #pragma unroll
       for (int j = 0; j < N; j += 2) {
         if constexpr (N >= 2) {
-          longlong2 v;
-          v.x = (int64_t)src[j];
-          v.y = (int64_t)src[j + 1];
-          *(longlong2*)(p + j) = v;
+          *(sp_i64x2u*)(p + j) = sp_i64x2{(int64_t)src[j], (int64_t)src[j + 1]};
         } else {
           p[0] = (int64_t)src[0];
         }
@@ -165,9 +182,9 @@ __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off
     case SP_BOOL: {
       uint8_t* p = (uint8_t*)base + off;
       if constexpr (N == 4) {
-        *(uchar4*)p = make_uchar4(src[0] != (T)0, src[1] != (T)0, src[2] != (T)0, src[3] != (T)0);
+        *(sp_u8x4u*)p = sp_u8x4{(uint8_t)(src[0] != (T)0), (uint8_t)(src[1] != (T)0), (uint8_t)(src[2] != (T)0), (uint8_t)(src[3] != (T)0)};
       } else if constexpr (N == 2) {
-        *(uchar2*)p = make_uchar2(src[0] != (T)0, src[1] != (T)0);
+        *(sp_u8x2u*)p = sp_u8x2{(uint8_t)(src[0] != (T)0), (uint8_t)(src[1] != (T)0)};
       } else {
         p[0] = src[0] != (T)0;
       }

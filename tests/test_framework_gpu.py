@@ -40,10 +40,14 @@ def test_hip_backend_is_the_one_running(ctx):
   assert _hip.lib().sp_abi_version() == 1
 
 
-def test_unregistered_callable_is_loud(ctx):
+def test_user_callables_are_traced_or_refused_loudly(ctx):
+  """An element-wise Python function becomes part of the kernel (traced); anything else is refused --
+  there is no CPU fallback to run it on."""
   from spartan_amd.lower import NotLowerable
-  with pytest.raises(NotLowerable):
-    sp.map(sp.ones((8, 8)), fn=lambda x: x + 1).force()
+  np.testing.assert_array_equal(sp.map(sp.ones((8, 8)), fn=lambda x: x * 3 + 1).glom(), np.full((8, 8), 4, np.float32))
+  for bad in (lambda x: np.cumsum(x), lambda x: x[::2], lambda x: x.sum(), lambda x: x + 1 if x > 0 else x):
+    with pytest.raises(NotLowerable):
+      sp.map(sp.ones((8, 8)), fn=bad).force()
 
 
 def test_fused_map_is_one_launch_per_tile(ctx):
