@@ -150,12 +150,12 @@ class HipBackend(object):
       root = lower.V('op', dtype=root.dtype, shape=(), op='FILL', args=[root])
     out_dtype = np.dtype(out_dtype or root.dtype)
     cls = lower.choose_class(root, [class_of(out_dtype)] if out_dtype != np.bool_ else [])
-    em = lower.Emitter(cls, out_shape)
+    em = lower.Emitter(cls, out_shape, self.contiguous)
     prog, tensors = em.finish(root, out_dtype)
     out = self.empty(out_shape, out_dtype)
     if out.numel():
       self.launches += 1
-      kernels.map_fused(prog, [self.contiguous(t) for t in tensors], out)
+      kernels.map_fused(prog, tensors, out)
     return out
 
   def seed_random(self, seed):
@@ -286,14 +286,14 @@ class HipBackend(object):
     extra = [class_of(nat_dtype)] if nat_dtype != np.bool_ else []
     cls = lower.choose_class(data, extra)
     full_shape = tuple(np.broadcast_shapes(data.shape, shape))
-    em = lower.Emitter(cls, full_shape)
+    em = lower.Emitter(cls, full_shape, self.contiguous)
     prog, tensors = em.finish(data, None)
     O, A, I = self._axis_split(full_shape, axis)
     out = self.empty((O * I,), nat_dtype)
     if A == 0 or O * I == 0:
       raise _hip.HipError('reduction over an empty axis')
     self.launches += 1
-    kernels.reduce(prog, [self.contiguous(t) for t in tensors], red_op, O, A, I, out)
+    kernels.reduce(prog, tensors, red_op, O, A, I, out)
     if axis is None:
       return out.reshape(())
     ax = axis if axis >= 0 else axis + len(full_shape)
@@ -332,14 +332,14 @@ class HipBackend(object):
       raise lower.NotLowerable('argmax/argmin of an uninitialised array')
     v = lower.V('tensor', dtype=self.dtype_of(data), shape=tuple(data.shape), tensor=data)
     cls = lower.choose_class(v)
-    em = lower.Emitter(cls, v.shape)
+    em = lower.Emitter(cls, v.shape, self.contiguous)
     prog, tensors = em.finish(v, None)
     O, A, I = self._axis_split(v.shape, axis)
     out_idx = self.empty((O * I,), np.int64)
     val_dtype = {_hip.SP_F32: np.float32, _hip.SP_F64: np.float64, _hip.SP_I64: np.int64}[cls]
     out_val = self.empty((O * I,), val_dtype)
     self.launches += 1
-    kernels.argreduce(prog, [self.contiguous(t) for t in tensors], which, O, A, I, index_offset,
+    kernels.argreduce(prog, tensors, which, O, A, I, index_offset,
                       nan_index, out_idx, out_val)
     if np.dtype(val_dtype) != v.dtype:
       out_val = self.astype(out_val, v.dtype)

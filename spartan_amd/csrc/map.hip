@@ -140,12 +140,12 @@ static int sp_map_go_static_2d(int sid, int mask, const sp_program* p, const sp_
 // Run-time specialised kernel for a program outside the prebuilt library (large tiles only).
 template <typename T, int V, bool LINEAR>
 static int sp_map_go_jit(const sp_program* p, const sp_inputs& in, void* out, int64_t nvec, int mask,
-                         hipStream_t st, bool* handled) {
+                         hipStream_t st, bool* handled, bool ragged = false) {
   *handled = false;
   if (!sp_jit_enabled() || p->n_instr == 0 || nvec * V < sp_jit_min_elems()) return 0;
-  char expr[160];
-  snprintf(expr, sizeof(expr), "sp_map_kernel<%s, %d, 1, %s, StaticProg<1000>, %d>", sp_cls<T>::name(), V,
-           LINEAR ? "true" : "false", mask);
+  char expr[176];
+  snprintf(expr, sizeof(expr), "sp_map_kernel<%s, %d, 1, %s, StaticProg<1000>, %d, %s>", sp_cls<T>::name(), V,
+           LINEAR ? "true" : "false", mask, ragged ? "true" : "false");
   void* fn = sp_jit_get("map_kernel.hpp", expr, p);
   if (!fn) return 0;
   int64_t blocks = (nvec + SP_BLOCK - 1) / SP_BLOCK;
@@ -224,6 +224,19 @@ static int sp_map_launch(const sp_program* p, const sp_inputs& in, const void* c
       if (handled) return 0;
     }
     return sp_map_go_u<T, V, false>(p, in, out, 0, n / V, st);
+  }
+  if constexpr (V > 1) {
+    // innermost dimension not a multiple of V: rows x ceil(inner / V) groups, scalar last group
+    const int64_t inner = p->shape[p->ndim - 1];
+    const int64_t nvec = (n / inner) * ((inner + V - 1) / V);
+    bool handled = false;
+    const int mask = sp_mask_2d(p, p->n_inputs);
+    if (sp_map_go_jit<T, V, false>(p, in, out, nvec, mask, st, &handled, true)) return 1;
+    if (handled) return 0;
+    hipLaunchKernelGGL((sp_map_kernel<T, V, 1, false, DynProg, -1, true>), dim3(sp_grid_for(nvec, 1)), dim3(SP_BLOCK), 0,
+                       st, *p, in, out, (int64_t)0, nvec);
+    SP_CHECK_LAUNCH();
+    return 0;
   }
   return sp_map_go<T, 1, 1, false>(p, in, out, 0, n, st);
 }

@@ -9,11 +9,55 @@
 // grid that covers the tile exactly (on MI355X a full grid streams ~25% faster than
 // a capped, grid-striding one -- tools/hbm_probe.hip, profiles/); the interpreter
 // launches a capped grid and this loop strides.
-template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1>
+//
+// RAGGED (strided programs whose innermost dimension is not a multiple of V, e.g. a map over the
+// slice x[1:, 1:]): the index space is walked as rows x ceil(inner / V) groups, so a group never
+// crosses a row end; the last group of a row is evaluated element by element.  (U == 1 only.)
+template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1, bool RAGGED = false>
 __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, const sp_inputs in,
                                                           void* __restrict__ out, int64_t start,
                                                           int64_t nvec) {
   const int64_t stride = (int64_t)gridDim.x * SP_BLOCK * U;
+  if constexpr (RAGGED) {
+    static_assert(U == 1 && !LINEAR, "ragged rows: strided programs, one group per lane");
+    const int64_t inner = p.shape[p.ndim - 1];
+    const int64_t gpr = (inner + V - 1) / V;   // groups per row
+    for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK + threadIdx.x; i < nvec; i += stride) {
+      int64_t row, g;
+      if (p.pad) {   // index space fits 32 bits
+        const uint32_t r32 = (uint32_t)i / (uint32_t)gpr;
+        row = r32;
+        g = (uint32_t)i - r32 * (uint32_t)gpr;
+      } else {
+        row = i / gpr;
+        g = i - row * gpr;
+      }
+      const int64_t col = g * V;
+      const int64_t L0 = row * inner + col;
+      if (col + V <= inner) {
+        T res[1][V];
+        if constexpr (MASK >= 0) {
+          sp_eval_2d<T, V, P, MASK>(p, in, (uint32_t)row, (uint32_t)col, L0, res[0]);
+        } else {
+          const int64_t Ls[1] = {L0};
+          sp_eval_u<T, V, 1, false, P>(p, in, Ls, res);
+        }
+        sp_store_vec<T, V>(out, p.out_dtype, L0, res[0]);
+      } else {
+        for (int64_t c = col; c < inner; ++c) {
+          T one[1][1];
+          if constexpr (MASK >= 0) {
+            sp_eval_2d<T, 1, P, MASK>(p, in, (uint32_t)row, (uint32_t)c, row * inner + c, one[0]);
+          } else {
+            const int64_t Ls[1] = {row * inner + c};
+            sp_eval_u<T, 1, 1, false, P>(p, in, Ls, one);
+          }
+          sp_store_vec<T, 1>(out, p.out_dtype, row * inner + c, one[0]);
+        }
+      }
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK * U + threadIdx.x; i < nvec; i += stride) {
     int64_t L[U];
     bool full = true;

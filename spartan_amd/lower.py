@@ -430,8 +430,10 @@ def _same_storage(a, b):
 
 
 class Emitter(object):
-  def __init__(self, cls, out_shape):
+  def __init__(self, cls, out_shape, contiguous=None):
+    """contiguous: backend callable making a dense copy of a tensor the kernels cannot address in place."""
     self.cls = cls
+    self.contiguous = contiguous
     self.out_shape = tuple(out_shape)
     self.prog = Program()
     self.tensors = []      # backend tensors, in input order
@@ -443,8 +445,20 @@ class Emitter(object):
     for i, t in enumerate(self.tensors):
       if self.in_vals[i][0].shape == v.shape and _same_storage(t, v.tensor):
         return i
-    self.tensors.append(v.tensor)
-    self.in_vals.append((v, broadcast_strides(v.shape, self.out_shape)))
+    t, elem_strides = v.tensor, None
+    if hasattr(t, 'is_contiguous') and not t.is_contiguous():
+      # a strided view (slice / transpose of a tile): read in place through its own strides when the
+      # program can express them, otherwise through one dense copy
+      st = tuple(int(x) for x in t.stride())
+      # (inner stride 1 only: a transposed view is better served by the LDS-tiled transposing copy)
+      if tuple(t.shape) == v.shape and all(x >= 0 for x in st) and (not st or st[-1] in (0, 1)) \
+          and self.contiguous is not None:
+        elem_strides = st
+      elif self.contiguous is not None:
+        t = self.contiguous(t)
+        v.tensor = t
+    self.tensors.append(t)
+    self.in_vals.append((v, broadcast_strides(v.shape, self.out_shape, elem_strides)))
     if len(self.tensors) > min(_hip.SP_MAX_INPUTS, _hip.SP_NREG - 1):
       raise ProgramTooLarge('too many tensor operands')
     return len(self.tensors) - 1

@@ -112,15 +112,16 @@ def dense_strides(shape):
   return tuple(reversed(out))
 
 
-def broadcast_strides(in_shape, out_shape):
-  """Element strides of a dense array of `in_shape` viewed (NumPy broadcasting,
+def broadcast_strides(in_shape, out_shape, elem_strides=None):
+  """Element strides of an array of `in_shape` viewed (NumPy broadcasting,
   right-aligned: reference spartan/expr/operator/broadcast.py:111-158) in
-  `out_shape`; broadcast dimensions get stride 0."""
+  `out_shape`; broadcast dimensions get stride 0.  `elem_strides`: the array's own
+  element strides when it is a strided view (default: dense row-major)."""
   in_shape = tuple(in_shape)
   out_shape = tuple(out_shape)
   pad = len(out_shape) - len(in_shape)
   assert pad >= 0, (in_shape, out_shape)
-  ds = dense_strides(in_shape)
+  ds = dense_strides(in_shape) if elem_strides is None else tuple(int(s) for s in elem_strides)
   strides = [0] * pad
   for d, n in enumerate(in_shape):
     if n == out_shape[pad + d]:

@@ -78,6 +78,8 @@ def test_runtime_specialisation_source_compiles(cls, dt, t, v):
   exprs = [
       ('map_kernel.hpp', 'sp_map_kernel<%s, %d, 1, true, StaticProg<1000>, -1>' % (t, v)),
       ('map_kernel.hpp', 'sp_map_kernel<%s, %d, 1, false, StaticProg<1000>, 2>' % (t, v)),
+      ('map_kernel.hpp', 'sp_map_kernel<%s, %d, 1, false, StaticProg<1000>, -1, true>' % (t, v)),
+      ('map_kernel.hpp', 'sp_map_kernel<%s, %d, 1, false, StaticProg<1000>, 1, true>' % (t, v)),
       ('reduce_impl.hpp', 'sp_reduce_rows_kernel<%s, %d, true, PlainAcc, StaticProg<1000>, 0, -1>' % (t, v)),
       ('reduce_impl.hpp', 'sp_reduce_cols_kernel<%s, %d, false, ArgAcc, StaticProg<1000>, -1, -1>' % (t, v)),
   ]
