@@ -99,7 +99,10 @@ def _fetch_whole_rhs(array, whole_extent):
   chunk_cols = int(os.environ.get('SPARTAN_RHS_CHUNK_COLS', '2048'))
   if chunk_cols > 0 and len(array.shape) == 2 and hasattr(array, 'fetch_whole_chunked') \
       and hasattr(context.get().backend, 'dot_chunked'):
-    whole = array.fetch_whole_chunked(chunk_cols)
+    try:
+      whole = array.fetch_whole_chunked(chunk_cols)
+    except NotImplementedError:   # a transport without the asynchronous collective: same on every rank
+      whole = None
     if whole is not None:
       return whole
   return array.fetch(whole_extent)
