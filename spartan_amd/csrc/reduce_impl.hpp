@@ -327,15 +327,16 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_finish_rows_kernel(int op, int64_
 template <typename T, int V, bool LINEAR, template <typename> class AccT, typename P = DynProg, int OP = -1, int MASK = -1>
 __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_program p, const sp_inputs in,
                                                                  int op, int64_t O, int64_t A, int64_t I,
-                                                                 int64_t chunk, int nsplit, RedOut ro) {
+                                                                 int64_t chunk, int nsplit, RedOut ro, int64_t c0) {
   using Acc = AccT<T>;
   constexpr int NW = SP_BLOCK / 64;
   __shared__ Acc sm[NW - 1][64 * V];
   if constexpr (OP >= 0) op = OP;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int s = blockIdx.y;
-  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * V;
-  const bool active = c < I;
+  // columns c0 + ...: only whole groups of V (the I % V columns left over go to sp_reduce_cols_tail_kernel)
+  const int64_t c = c0 + ((int64_t)blockIdx.x * 64 + lane) * V;
+  const bool active = c + V <= I;
   for (int64_t o = blockIdx.z; o < O; o += gridDim.z) {
     const int64_t a0 = (int64_t)s * chunk;
     int64_t a1 = a0 + chunk;
@@ -343,16 +344,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
     Acc acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v].init(op);
-    const int nvalid = active ? (int)((I - c) < V ? (I - c) : V) : 0;   // < V only in the last column group
-    if (active && nvalid < V) {
-      for (int64_t a = a0 + w; a < a1; a += NW) {
-#pragma unroll
-        for (int v = 0; v < V; ++v)
-          if (v < nvalid)
-            acc[v].add(op, sp_eval_one<T, LINEAR, P, MASK>(p, in, o * A + a, c + v, (o * A + a) * I + c + v,
-                                                           p.ndim == 2 && p.shape[1] == I), a);
-      }
-    } else if (active) {
+    if (active) {
       constexpr int U = 1;
       for (int64_t a = a0 + w; a < a1; a += NW * U) {
         int64_t L[U];
@@ -386,12 +378,51 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
     if (w == 0 && active) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        if (v >= nvalid) break;
 #pragma unroll
         for (int k = 0; k < NW - 1; ++k) acc[v].merge(op, sm[k][lane * V + v]);
         const int64_t slot = nsplit == 1 ? o * I + c + v : ((int64_t)s * O + o) * I + c + v;
         sp_emit<T>(ro, nsplit == 1, slot, acc[v]);
       }
+    }
+    __syncthreads();
+  }
+}
+
+// the I % V (< 4) columns the vector launch leaves over: the workgroup's threads go down the ROWS of the
+// chunk (thread t: column c0 + t % 4, rows t / 4, t / 4 + 64, ...), LDS combine in row order.
+// grid = (1, nsplit, O'), same partial layout as sp_reduce_cols_kernel.
+template <typename T, bool LINEAR, template <typename> class AccT>
+__global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_tail_kernel(const sp_program p, const sp_inputs in,
+                                                                      int op, int64_t O, int64_t A, int64_t I,
+                                                                      int64_t chunk, int nsplit, RedOut ro, int64_t c0) {
+  using Acc = AccT<T>;
+  constexpr int NR = SP_BLOCK / 4;
+  __shared__ Acc sm[SP_BLOCK];
+  const int col = threadIdx.x & 3, r = threadIdx.x >> 2;
+  const int s = blockIdx.y;
+  const int64_t c = c0 + col;
+  const bool active = c < I;
+  for (int64_t o = blockIdx.z; o < O; o += gridDim.z) {
+    const int64_t a0 = (int64_t)s * chunk;
+    int64_t a1 = a0 + chunk;
+    if (a1 > A) a1 = A;
+    Acc acc;
+    acc.init(op);
+    if (active) {
+      for (int64_t a = a0 + r; a < a1; a += NR) {
+        const int64_t L[1] = {(o * A + a) * I + c};
+        const int64_t rc[1][2] = {{o * A + a, c}};
+        T x[1][1];
+        sp_eval_u<T, 1, 1, LINEAR, DynProg>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr);
+        acc.add(op, x[0][0], a);
+      }
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 4 && active) {
+      for (int k = 1; k < NR; ++k) acc.merge(op, sm[k * 4 + col]);
+      const int64_t slot = nsplit == 1 ? o * I + c : ((int64_t)s * O + o) * I + c;
+      sp_emit<T>(ro, nsplit == 1, slot, acc);
     }
     __syncthreads();
   }
@@ -621,8 +652,17 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
   } else {
     const int64_t bx = (I + 64 * V - 1) / (64 * V);
     if (bx > 2147483647LL) SP_FAIL("sp_reduce: inner dimension too large");
-    SP_LAUNCH(sp_reduce_cols_kernel, dim3((unsigned)bx, pl.nsplit, cap_dim(O, 65535)), *p, in, op, O, A, I,
-              pl.chunk, pl.nsplit, ro);
+    const int64_t i_tail = V > 1 ? I % V : 0;   // columns that do not fill a group of V
+    if (I - i_tail > 0)
+      SP_LAUNCH(sp_reduce_cols_kernel, dim3((unsigned)bx, pl.nsplit, cap_dim(O, 65535)), *p, in, op, O, A, I,
+                pl.chunk, pl.nsplit, ro, (int64_t)0);
+    if (i_tail) {
+      // the left-over columns: the tail kernel on the same split plan, so its outputs / partials land in
+      // the slots the finish kernel reads
+      if (lin) hipLaunchKernelGGL((sp_reduce_cols_tail_kernel<T, true, AccT>), dim3(1, pl.nsplit, cap_dim(O, 65535)), dim3(SP_BLOCK), 0, st, *p, in, op, O, A, I, pl.chunk, pl.nsplit, ro, I - i_tail);
+      else hipLaunchKernelGGL((sp_reduce_cols_tail_kernel<T, false, AccT>), dim3(1, pl.nsplit, cap_dim(O, 65535)), dim3(SP_BLOCK), 0, st, *p, in, op, O, A, I, pl.chunk, pl.nsplit, ro, I - i_tail);
+      SP_CHECK_LAUNCH();
+    }
     if (pl.nsplit > 1) {
       const int64_t E = O * I;
       const int64_t blocks = (E + 63) / 64;
