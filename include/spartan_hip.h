@@ -343,6 +343,56 @@ int sp_random_fill(void* d_out, int32_t dtype, int64_t n, int32_t kind, uint64_t
 int sp_cumscan(const void* d_in, void* d_out, int32_t dtype, int64_t outer, int64_t axis_len, int64_t inner,
                int32_t product, void* stream);
 
+/* ---- sparse tiles ---------------------------------------------------------------
+ * Device format of a sparse tile: canonical CSR -- int64 indptr[nrows + 1], int32 column indices ascending
+ * inside a row, no duplicate coordinates, values SP_F32 | SP_F64.  Replaces the scipy.sparse objects the
+ * reference keeps in Tile.data (spartan/array/tile.pyx:149-156) and the conversions done on every use
+ * (sparse.pyx:232-242 convert_sparse_array, dot.py:212-216 tocsr()).
+ *
+ * sp_coo_to_csr: (row, col, value) list in any order -> canonical CSR.  Entries with row < 0 are dropped;
+ * entries with equal coordinates are added in list order (stable LSD radix sort of the row*ncols+col keys,
+ * no atomics).  One primitive carries: upload of a mapper's scipy matrix, transpose (rows <-> cols),
+ * slicing (sp_coo_box then this; sparse.pyx:198-230 slice / slice_coo, :289-341 multiple_slice[_coo]),
+ * region updates (sparse.pyx:246-286 compute_sparse_update), A + B (concatenated lists; scipy's `+` behind
+ * np.add on two sparse tiles) and the reduction of the sparse x sparse expansion.
+ * d_indices / d_vals_out need room for nnz entries; the number kept is indptr[nrows] (read it back). */
+size_t sp_coo_to_csr_workspace_bytes(int64_t nnz);
+int sp_coo_to_csr(int32_t dtype, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t* d_rows,
+                  const int32_t* d_cols, const void* d_vals, int64_t* d_indptr, int32_t* d_indices,
+                  void* d_vals_out, void* d_ws, size_t ws_bytes, void* stream);
+/* row index of every stored entry (CSR -> COO). */
+int sp_csr_rows(int64_t nrows, int64_t nnz, const int64_t* d_indptr, int32_t* d_rows, void* stream);
+/* In-place edit of a COO list against the box [r0, r1) x [c0, c1): drop_inside == 0 keeps the entries inside
+ * (the others get row = -1) and shifts them by (dr, dc); drop_inside != 0 drops the entries inside and shifts
+ * the others. */
+int sp_coo_box(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+               int64_t dr, int64_t dc, int32_t drop_inside, void* stream);
+/* sp_csr_spmm: C[m, n] (+)= A[m, k] (CSR) x B[k, n] (dense, row-major, ldb) -- the tile body of
+ * dot_map2_mapper / dot_outer_mapper when tile_a is sparse (spartan/expr/dot.py:193-240, scipy's csr .dot)
+ * and of dot_coo_dense_unordered_map (sparse.pyx:103-158, n == 1; the result is written dense).
+ * d_b == NULL with n == 1 multiplies by a vector of ones (row sums).  n == 1: 2..64 lanes per row by mean row
+ * length, shuffle reduction; n > 1: entries of a row in storage order (scipy's csr_matvecs order). */
+int sp_csr_spmm(int32_t dtype, int64_t m, int64_t k, int64_t n, int64_t nnz, const int64_t* d_indptr,
+                const int32_t* d_indices, const void* d_vals, const void* d_b, int64_t ldb, void* d_c, int64_t ldc,
+                int32_t accumulate, void* stream);
+/* sp_csr_scatter: write a CSR tile into the box of a dense tile whose upper-left corner is (row0, col0).
+ * mode 0: assign, 1: add, 2: sparse_to_dense_update with REDUCE_ADD (sparse.pyx:21-38; tile.pyx:229-233):
+ * where mask == 0 assign and set the mask, else add. */
+int sp_csr_scatter(int32_t dtype, int64_t m, int64_t nnz, const int64_t* d_indptr, const int32_t* d_indices,
+                   const void* d_vals, void* d_out, int64_t ld, int64_t row0, int64_t col0, uint8_t* d_mask,
+                   int64_t ldmask, int32_t mode, void* stream);
+/* sparse x sparse (scipy's csr_matmat behind tile_a.dot(tile_b), dot.py:216,237), as expand -> sort ->
+ * compress: sp_spgemm_count gives every stored entry of A the offset of its products (d_offs[nnz_a + 1], int32)
+ * and the exact number of products (*d_total, device int64); sp_spgemm_expand writes the (row, col, a*b) list
+ * in A's storage order; sp_coo_to_csr adds the products of a cell in that (k ascending) order. */
+size_t sp_spgemm_count_workspace_bytes(int64_t nnz_a);
+int sp_spgemm_count(int64_t nnz_a, const int32_t* d_indices_a, const int64_t* d_indptr_b, int32_t* d_offs,
+                    int64_t* d_total, void* d_ws, size_t ws_bytes, void* stream);
+int sp_spgemm_expand(int32_t dtype, int64_t m_a, int64_t nnz_a, const int64_t* d_indptr_a,
+                     const int32_t* d_indices_a, const void* d_vals_a, const int64_t* d_indptr_b,
+                     const int32_t* d_indices_b, const void* d_vals_b, const int32_t* d_offs, int32_t* d_rows,
+                     int32_t* d_cols, void* d_vals, void* stream);
+
 /* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
  * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
 int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);

@@ -16,6 +16,7 @@ Tile payloads are torch CPU tensors (so torch.distributed/gloo can move them);
 all arithmetic is NumPy on views of them.
 """
 import numpy as np
+import scipy.sparse as sps
 import torch
 
 from spartan_amd.array import distarray, tile
@@ -67,6 +68,8 @@ class NumpyBackend(object):
     return t.numpy().copy()
 
   def dtype_of(self, t):
+    if sps.issparse(t):
+      return np.dtype(t.dtype)
     if isinstance(t, torch.Tensor):
       return _T2NP[t.dtype]
     if isinstance(t, (tile.EmptyBlob, distarray.Absent, np.ndarray, np.generic)):
@@ -146,10 +149,15 @@ class NumpyBackend(object):
           deps.append(self._eval(d, inputs, ex))
     else:
       deps = [self._eval(d, inputs, ex) for d in op.deps]
+    # local.py:120-126: a ufunc over one sparse and one dense operand sees the sparse one densified
+    if isinstance(op.fn, np.ufunc) and len(deps) == 2 and (sps.issparse(deps[0]) ^ sps.issparse(deps[1])):
+      deps = [np.asarray(d.todense()) if sps.issparse(d) else d for d in deps]
     with np.errstate(all='ignore'):
       return op.fn(*deps, **op.kw)
 
   def _wrap(self, result, shape=None):
+    if sps.issparse(result):
+      return result          # a sparse local result stays a scipy matrix (tile.pyx:145-152 from_data)
     result = np.asarray(result)
     if shape is not None and result.shape != tuple(shape):
       result = np.broadcast_to(result, shape)
@@ -189,7 +197,12 @@ class NumpyBackend(object):
 
   def dot(self, a, b):
     self.launches += 1
-    return self._wrap(_np(a).dot(_np(b)))
+    a, b = _np(a), _np(b)
+    if sps.issparse(a):
+      a = a.tocsr()          # dot.py:212-216
+    if sps.issparse(b):
+      b = b.tocsr()
+    return self._wrap(a.dot(b))
 
   def dot_chunked(self, a, rhs):
     """Host-framework counterpart of HipBackend.dot_chunked (column chunks of a gathered B)."""
@@ -254,6 +267,66 @@ class NumpyBackend(object):
     out = np.zeros((flat.shape[0], int(width)), flat.dtype)
     out[np.arange(flat.shape[0]), int(col0) + np.arange(flat.shape[0])] = flat
     return self._wrap(out)
+
+  # -- sparse tiles: scipy.sparse, the library the reference's sparse tile bodies are written in
+  # (spartan/array/sparse.pyx, tile.pyx:226-252, dot.py:212-240)
+  def is_sparse(self, x):
+    return sps.issparse(x)
+
+  def sparse_blob(self, mat, dtype=None):
+    if dtype is not None and mat.dtype != np.dtype(dtype):
+      mat = mat.astype(dtype)
+    return mat
+
+  def sparse_to_host(self, b):
+    return b
+
+  def sparse_empty(self, shape, dtype):
+    return sps.coo_matrix(tuple(shape), dtype=dtype)     # tile.pyx:74-77
+
+  def sparse_slice(self, b, slices):
+    return b.tocsr()[slices]                              # tile.pyx:98 / sparse.pyx:198-213
+
+  def sparse_paste(self, shape, dtype, pieces):
+    """distarray.py:338-353: the pieces are written into a lil matrix of the region."""
+    tgt = sps.lil_matrix(tuple(shape), dtype=dtype)
+    for ul, p in pieces:
+      if p.shape[0] and p.shape[1]:
+        tgt[ul[0]:ul[0] + p.shape[0], ul[1]:ul[1] + p.shape[1]] = p
+    return tgt.tocsr()
+
+  def sparse_reduce(self, old, upd, reducer):
+    return reducer(old, upd)                              # tile.pyx:246-247
+
+  def sparse_update(self, old, ul, lr, upd, reducer):
+    """sparse.pyx:246-286 compute_sparse_update (out of place: the box is replaced / reduced)."""
+    data = old.tolil(copy=True)
+    box = (slice(ul[0], lr[0]), slice(ul[1], lr[1]))
+    data[box] = reducer(data[box].tocsr(), upd.tocsr()) if reducer is not None else upd
+    return data.tocsr()
+
+  def sparse_scatter(self, dst, ul, blob, mode, mask):
+    """sparse.pyx:21-38 sparse_to_dense_update with REDUCE_ADD, entry by entry in COO order."""
+    self.launches += 1
+    d = dst.numpy()
+    m = mask.numpy() if mask is not None else None
+    coo = blob.tocoo()
+    for r, c, v in zip(coo.row + ul[0], coo.col + ul[1], coo.data):
+      if mode == 0 or (mode == 2 and not m[r, c]):
+        d[r, c] = v
+        if m is not None:
+          m[r, c] = 1
+      else:
+        d[r, c] = d[r, c] + v
+
+  def sparse_to_dense(self, b):
+    return self.from_numpy(np.asarray(b.todense()))
+
+  def sparse_transpose(self, b):
+    return b.transpose()
+
+  def sparse_random(self, shape, density, dtype):
+    return sps.rand(shape[0], shape[1], density=density, format='csr', dtype=dtype)
 
   def synchronize(self):
     pass

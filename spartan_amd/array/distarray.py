@@ -141,7 +141,10 @@ class DistArray(object):
   def glom(self):
     """distarray.py:198-200: the whole array as a NumPy array (on every rank)."""
     ctx = context.get()
-    return ctx.backend.to_numpy(self.select(np.index_exp[:]))
+    whole = self.select(np.index_exp[:])
+    if tile.is_sparse_blob(whole):
+      return ctx.backend.sparse_to_host(whole)   # a scipy.sparse matrix, like the reference's glom
+    return ctx.backend.to_numpy(whole)
 
   def map_to_array(self, mapper_fn, kw=None):
     """distarray.py:202-208."""
@@ -278,6 +281,9 @@ class UpdateBatch(object):
           world.reduce_scatter(out, be.contiguous(data), red)
           t.update(be, None, out, array.reducer_fn, owned=True)
         continue
+      if array.sparse:
+        self._flush_sparse(array, items)
+        continue
       # generic path: explicit transfers, merged in issue order
       array._touched = True
       sends, recvs, merges = [], [], []
@@ -304,6 +310,56 @@ class UpdateBatch(object):
         t = ctx.tile(tile_id)
         full = tuple(piece.shape) == t.shape
         t.update(be, None if full else dst_slice, piece, array.reducer_fn, owned=owned and full)
+
+
+def _flush_sparse(self, array, items):
+  """Updates of a SPARSE target: blocks whose tile lives on the executing rank merge on the device;
+  blocks for other ranks travel as host (scipy) objects in one object all-gather per kernel -- building a
+  sparse array is the only place this happens (pagerank_sparse-style shuffles), not the iteration loop."""
+  ctx = self.ctx
+  be = ctx.backend
+  world = ctx.world
+  array._touched = True
+  plan = []       # (seq, tile_id, dst_slice, exec_rank, owner, src_slice, whole)
+  for seq, (_, worker, region, data, owned) in enumerate(items):
+    exec_rank = world.rank if worker is None else ctx.rank_of(worker)
+    for tile_id, src_slice, dst_slice in array._update_splits(region):
+      owner = ctx.rank_of(tile_id.worker)
+      whole = _slices_shape(src_slice, region.shape) == tuple(region.shape)
+      plan.append((seq, tile_id, dst_slice, exec_rank, owner, src_slice, whole, worker is None))
+  crossing = world.distributed and any((not drv) and ex_r != ow for (_, _, _, ex_r, ow, _, _, drv) in plan)
+  outbox = {}
+  local = {}
+  for k, (seq, tile_id, dst_slice, exec_rank, owner, src_slice, whole, drv) in enumerate(plan):
+    if exec_rank != world.rank:
+      continue
+    data = items[seq][3]
+    if drv and owner != world.rank:
+      continue      # driver-level update: the data is replicated, every owner merges its own part
+    piece = data if whole else be.sparse_slice(data, src_slice)
+    if owner == world.rank:
+      local[k] = piece
+    else:
+      outbox[k] = be.sparse_to_host(piece)
+  inbox = {}
+  if crossing:
+    for part in world.all_gather_object(outbox):
+      inbox.update(part)
+  for k, (seq, tile_id, dst_slice, exec_rank, owner, src_slice, whole, drv) in enumerate(plan):
+    if owner != world.rank:
+      continue
+    if k in local:
+      piece = local[k]
+    elif k in inbox:
+      piece = be.sparse_blob(inbox[k], array.dtype)
+    else:
+      continue
+    t = ctx.tile(tile_id)
+    full = tuple(piece.shape) == t.shape
+    t.update(be, None if full else dst_slice, piece, array.reducer_fn)
+
+
+UpdateBatch._flush_sparse = _flush_sparse
 
 
 class DistArrayImpl(DistArray):
@@ -383,6 +439,9 @@ class DistArrayImpl(DistArray):
     else:
       splits = list(extent.find_overlapping(self.tiles.keys(), region))
 
+    if self.sparse:
+      return self._fetch_sparse(region, splits, replicated, dst_rank, want)
+
     if not world.distributed:
       pieces = [self._tile_piece(self.tiles[ex], ex, inter) for ex, inter in splits]
       if len(splits) == 1:
@@ -451,6 +510,42 @@ class DistArrayImpl(DistArray):
     if not want:
       return Absent(region.shape, self.dtype)
     return self._stitch(region, splits, pieces)
+
+  def _fetch_sparse(self, region, splits, replicated, dst_rank, want):
+    """Sparse counterpart of fetch (distarray.py:338-353: the pieces are placed into one sparse matrix).
+    Pieces owned by the destination stay on the device; pieces that have to cross ranks travel as host
+    (scipy) objects in ONE object all-gather -- a slow path kept off the dot / reduce hot loops, where
+    every sparse tile is used by the rank that owns it."""
+    ctx = self.ctx
+    be = ctx.backend
+    world = ctx.world
+    owners = [ctx.rank_of(self.tiles[ex].worker) for ex, _ in splits]
+
+    def local_piece(i):
+      ex, inter = splits[i]
+      return self._tile_piece(self.tiles[ex], ex, inter)
+
+    remote = {}
+    if world.distributed:
+      crossing = [i for i in range(len(splits)) if replicated or owners[i] != dst_rank]
+      if crossing:   # known identically on every rank
+        mine = {i: be.sparse_to_host(local_piece(i)) for i in crossing if owners[i] == world.rank}
+        for part in world.all_gather_object(mine):
+          remote.update(part)
+    if not want:
+      return Absent(region.shape, self.dtype)
+    pieces = []
+    for i, (ex, inter) in enumerate(splits):
+      if owners[i] == world.rank or not world.distributed:
+        p = local_piece(i)
+      else:
+        p = be.sparse_blob(remote[i], self.dtype)
+      pieces.append(p)
+    if len(splits) == 1:
+      return pieces[0]
+    return be.sparse_paste(region.shape, self.dtype,
+                           [(tuple(a - b for a, b in zip(inter.ul, region.ul)), p)
+                            for (ex, inter), p in zip(splits, pieces)])
 
   def _stitch(self, region, splits, pieces):
     """distarray.py:355-365: allocate the region and paste the pieces."""
@@ -571,6 +666,19 @@ class DistArrayImpl(DistArray):
     Assert.isinstance(region, extent.TileExtent)
     Assert.eq(region.shape, tuple(data.shape), 'Size of extent does not match size of data')
     ctx = self.ctx
+    if tile.is_sparse_blob(data) and not ctx.executing:
+      data = Absent(region.shape, self.dtype)    # a mapper that builds its block on every rank: only the executing rank's counts
+    if tile.is_sparse_blob(data):
+      if self.sparse:
+        data = ctx.backend.sparse_blob(data, self.dtype)     # upload what a mapper yielded
+      else:
+        # A sparse block for a dense target travels and merges as a dense block.  (The reference adds
+        # it cell by cell with REDUCE_ADD whatever the target's reducer is, tile.pyx:229-233; the two
+        # agree for the add reducer and for non-overlapping blocks.)
+        data = ctx.backend.sparse_to_dense(ctx.backend.sparse_blob(data, self.dtype))
+        owned = True
+    elif self.sparse and not isinstance(data, Absent):
+      raise NotImplementedError('a dense update of a sparse array is not supported; yield a sparse block')
     if ctx.pending is not None:
       ctx.pending.add(self, region, data, owned)
       return None
@@ -620,18 +728,19 @@ DistArrayImpl._invoke_mapper = _invoke_default
 
 def create(shape, dtype=float, sharder=None, reducer=None, tile_hint=None, sparse=False):
   """distarray.py:425-487 (round_robin tile assignment, the default)."""
-  if sparse:
-    raise NotImplementedError('sparse arrays are outside the GPU tile path (SURVEY 8f.2)')
   ctx = context.get()
   dtype = np.dtype(dtype)
   shape = tuple(int(s) for s in shape)
+  if sparse:
+    Assert.eq(len(shape), 2, 'sparse arrays are two-dimensional')
+  ttype = tile.TYPE_SPARSE if sparse else tile.TYPE_DENSE
   extents = compute_extents(shape, tile_hint, ctx.num_workers)
   tiles = collections.OrderedDict()
   for ex, i in extents.items():
     worker = i % ctx.num_workers
-    t = tile.from_shape(ex.shape, dtype, tile.TYPE_DENSE) if ctx.is_local_worker(worker) else None
+    t = tile.from_shape(ex.shape, dtype, ttype) if ctx.is_local_worker(worker) else None
     tiles[ex] = ctx.create(t, hint=worker)
-  return DistArrayImpl(shape=shape, dtype=dtype, tiles=tiles, reducer_fn=reducer, sparse=False)
+  return DistArrayImpl(shape=shape, dtype=dtype, tiles=tiles, reducer_fn=reducer, sparse=bool(sparse))
 
 
 def from_table(extents):

@@ -1,11 +1,15 @@
 """Tile: the unit of storage (an HBM blob) and of the combine step.
 
-Mirror of the reference's spartan/array/tile.pyx for DENSE tiles.  `data` is a
-backend tensor (torch tensor in HBM for the HIP backend) instead of a NumPy
-array; the mask is kept as a *state* (all-clear / all-set) and only
-materialised as a byte array in HBM when a sub-slice update makes it
-non-uniform -- the reference allocates a 1 B/element bool array for every tile
-(tile.pyx:145-159), which would cost 25 % extra HBM traffic on fp32 tiles.
+Mirror of the reference's spartan/array/tile.pyx.  `data` is a backend tensor
+(torch tensor in HBM for the HIP backend) instead of a NumPy array; the mask is
+kept as a *state* (all-clear / all-set) and only materialised as a byte array in
+HBM when a sub-slice update makes it non-uniform -- the reference allocates a
+1 B/element bool array for every tile (tile.pyx:145-159), which would cost 25 %
+extra HBM traffic on fp32 tiles.
+
+Sparse tiles (TYPE_SPARSE) hold a backend sparse blob: canonical CSR in HBM for
+the HIP backend (spartan_amd/sparse.py) where the reference holds a scipy.sparse
+matrix; they have no mask (tile.pyx:129-132).
 """
 import itertools
 
@@ -35,6 +39,13 @@ class EmptyBlob(object):
     self.dtype = np.dtype(dtype)
 
 
+def is_sparse_blob(x):
+  """A backend sparse blob (device CSR) or a scipy.sparse matrix (what user mappers yield)."""
+  if getattr(x, 'is_sparse_tile', False):
+    return True
+  return type(x).__module__.startswith('scipy.sparse')
+
+
 class Tile(object):
   """tile.pyx:24-62."""
 
@@ -57,6 +68,22 @@ class Tile(object):
     """tile.pyx:64-113.  Returns a backend tensor (a view when possible)."""
     if subslice is not None and not isinstance(subslice, tuple):
       subslice = (subslice,)
+    if self.type == TYPE_SPARSE:
+      # tile.pyx:74-77, :91-99 (the reference warns that slicing a sparse tile "will likely fail";
+      # here a box of a CSR tile is a well-defined device operation)
+      if subslice is None:
+        shp = self.shape
+      else:
+        shp = tuple(len(range(*slc.indices(n))) for slc, n in zip(subslice, self.shape)) + self.shape[len(subslice):]
+      if self.data is None:
+        # tile.pyx:77 `coo_matrix(shape, self.dtype)`: the dtype lands in coo_matrix's `shape` parameter, so
+        # the blob of a never-written sparse tile is float64 whatever the array's dtype -- and so is
+        # everything a creation mapper derives from it (sparse_diagonal is float64 in the reference's
+        # outputs, tests/golden/sparse_meta.json).  Kept.
+        return backend.sparse_empty(shp, np.float64)
+      if tuple(shp) == self.shape:
+        return self.data
+      return backend.sparse_slice(self.data, subslice)
     if self.data is None:
       if subslice is None or len(self.shape) == 0:
         return EmptyBlob(self.shape, self.dtype)
@@ -87,14 +114,18 @@ class Tile(object):
 
 def from_data(data, dtype=None, shape=None):
   """tile.pyx:145-159 (mask = all set, kept as a state)."""
+  if is_sparse_blob(data):
+    return Tile(shape=tuple(data.shape), data=data, dtype=data.dtype if dtype is None else dtype,
+                mask=MASK_ALL_SET, tile_type=TYPE_SPARSE)
   return Tile(shape=tuple(data.shape) if shape is None else shape,
               data=data, dtype=dtype, mask=MASK_ALL_SET, tile_type=TYPE_DENSE)
 
 
 def from_shape(shape, dtype, tile_type=TYPE_DENSE):
   """tile.pyx:162-176: an empty tile carries no data."""
-  if tile_type != TYPE_DENSE:
-    raise NotImplementedError('sparse tiles are outside the GPU tile path (SURVEY 8f.2)')
+  if tile_type == TYPE_SPARSE:
+    return Tile(shape=shape, data=None, dtype=dtype, tile_type=TYPE_SPARSE, mask=None)
+  assert tile_type == TYPE_DENSE, 'Unknown tile type %s' % tile_type
   return Tile(shape=shape, data=None, dtype=dtype, tile_type=tile_type, mask=MASK_ALL_CLEAR)
 
 
@@ -105,6 +136,9 @@ def merge(backend, old_tile, subslice, update, reducer, owned=False):
   full-tile write can adopt it instead of copying."""
   Assert.isinstance(old_tile, Tile)
   nd = len(old_tile.shape)
+
+  if is_sparse_blob(update) or old_tile.type == TYPE_SPARSE:
+    return _merge_sparse(backend, old_tile, subslice, update, reducer)
 
   if nd == 0:
     # tile.pyx:212-217: data None acts as the mask
@@ -167,3 +201,60 @@ def merge(backend, old_tile, subslice, update, reducer, owned=False):
     return old_tile
   backend.update_box(old_tile.data, ul, lr, update, reducer, 2, old_tile.mask)
   return old_tile
+
+
+def _box_of(subslice, shape):
+  if subslice is None:
+    return tuple(0 for _ in shape), tuple(shape)
+  ul, lr = [], []
+  for slc, n in zip(subslice, shape):
+    start, stop, _ = slc.indices(n)
+    ul.append(start)
+    lr.append(stop)
+  for d in range(len(subslice), len(shape)):
+    ul.append(0)
+    lr.append(shape[d])
+  return tuple(ul), tuple(lr)
+
+
+def _merge_sparse(backend, old_tile, subslice, update, reducer):
+  """tile.pyx:226-252 (sparse update) and :283-295 (dense update of a sparse tile)."""
+  Assert.eq(len(old_tile.shape), 2, 'sparse tiles are two-dimensional')
+  ul, lr = _box_of(subslice, old_tile.shape)
+  if is_sparse_blob(update):
+    update = backend.sparse_blob(update, old_tile.dtype)
+    if old_tile.type == TYPE_DENSE:
+      # tile.pyx:229-243: sparse_to_dense_update(..., REDUCE_ADD) -- first write where the mask is clear,
+      # add where it is set -- then mask[subslice] = True.  (The reference passes the update's own
+      # coordinates without adding the box origin; the box origin is honoured here.)
+      if old_tile.data is None:
+        old_tile.data = backend.zeros(old_tile.shape, old_tile.dtype)
+        old_tile.mask = MASK_ALL_CLEAR
+      full = (ul == (0, 0) and lr == old_tile.shape)
+      if old_tile.mask_is_uniform():
+        if old_tile.mask == MASK_ALL_SET:
+          backend.sparse_scatter(old_tile.data, ul, update, 1, None)
+          return old_tile
+        if full:
+          backend.sparse_scatter(old_tile.data, ul, update, 0, None)
+          old_tile.mask = MASK_ALL_SET
+          return old_tile
+        old_tile.mask = backend.zeros(old_tile.shape, np.uint8)
+      backend.sparse_scatter(old_tile.data, ul, update, 2, old_tile.mask)
+      backend.assign_box(old_tile.mask, tuple(slice(u, l) for u, l in zip(ul, lr)), 1)
+      return old_tile
+    # sparse update of a sparse tile (tile.pyx:244-252)
+    if tuple(update.shape) == old_tile.shape:
+      if reducer is not None and old_tile.data is not None:
+        old_tile.data = backend.sparse_reduce(old_tile.data, update, reducer)
+      else:
+        old_tile.data = update
+      return old_tile
+    if old_tile.data is None:
+      old_tile.data = backend.sparse_empty(old_tile.shape, old_tile.dtype)
+    old_tile.data = backend.sparse_update(old_tile.data, ul, lr, update, reducer)
+    return old_tile
+  # dense update of a sparse tile: the reference converts the tile to lil and assigns the slice
+  # (tile.pyx:283-295, marked "this is SLOW")
+  raise NotImplementedError('a dense update of a sparse tile is not supported; make the target dense '
+                            'or yield a sparse block')

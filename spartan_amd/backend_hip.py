@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import _hip, kernels, lower
+from . import sparse as sparse_mod
 from .array import distarray, tile
 from .expr.local import FnCallExpr, LocalInput
 from .program import ProgramTooLarge, class_of, join_class
@@ -59,6 +60,8 @@ class HipBackend(object):
     return t.detach().cpu().numpy()
 
   def dtype_of(self, t):
+    if isinstance(t, sparse_mod.CsrTile):
+      return t.dtype
     if isinstance(t, (tile.EmptyBlob, distarray.Absent, np.ndarray, np.generic)):
       return np.dtype(t.dtype)
     if isinstance(t, torch.Tensor):
@@ -180,6 +183,8 @@ class HipBackend(object):
       return self.random_tile(rnd[0], ex.shape, rnd[1], **(op.kw or {}))
     if getattr(getattr(op, 'fn', None), '_sp_tile_fn', False):
       return self._call_tile_fn(op, inputs, ex)
+    if any(tile.is_sparse_blob(v) for v in inputs.values()):
+      return self._evaluate_sparse_map(op, inputs, ex)
     op, inputs = self._materialise_random(op, inputs, ex)
     try:
       root = lower.infer(op, inputs, ex, self.dtype_of)
@@ -307,6 +312,8 @@ class HipBackend(object):
     data_deps = [d for d in op.deps if not (isinstance(d, LocalInput) and d.idx in ('extent', 'axis'))]
     if len(data_deps) != 1:
       raise lower.NotLowerable('reduce over %d operands' % len(data_deps))
+    if any(tile.is_sparse_blob(v) for v in inputs.values()):
+      return self._evaluate_sparse_reduce(op, data_deps[0], inputs, ex, axis)
     try:
       data = lower.infer(data_deps[0], inputs, ex, self.dtype_of)
     except ProgramTooLarge:
@@ -349,6 +356,8 @@ class HipBackend(object):
   def dot(self, a, b):
     """ndarray.dot for backend tensors: MFMA GEMM for fp32 matrix.matrix, fused
     multiply-reduce launches for everything else."""
+    if tile.is_sparse_blob(a) or tile.is_sparse_blob(b):
+      return self._sparse_dot(a, b)
     a_dt, b_dt = self.dtype_of(a), self.dtype_of(b)
     res_dt = np.result_type(a_dt, b_dt)
     if a.dim() == 2 and b.dim() == 2 and b.shape[1] == 1:
@@ -525,6 +534,140 @@ class HipBackend(object):
       self.launches += 1
       kernels.slice_copy(out, int(col0), (int(width) + 1,), flat, 0, (1,), (m,))
     return out
+
+  # -- sparse tiles: canonical CSR in HBM, spartan_amd/sparse.py over csrc/sparse.hip -----------
+  def is_sparse(self, x):
+    return isinstance(x, sparse_mod.CsrTile)
+
+  def sparse_blob(self, mat, dtype=None):
+    """What a mapper yielded (scipy.sparse, any format) or a device tile -> device tile of `dtype`."""
+    if isinstance(mat, sparse_mod.CsrTile):
+      if dtype is None or mat.dtype == np.dtype(dtype):
+        return mat
+      return sparse_mod.CsrTile(mat.shape, dtype, mat.indptr, mat.indices, self.astype(mat.data, dtype))
+    self.launches += 1
+    return sparse_mod.from_scipy(mat, self.device, dtype)
+
+  def sparse_to_host(self, b):
+    return sparse_mod.to_scipy(b)
+
+  def sparse_empty(self, shape, dtype):
+    return sparse_mod.empty(shape, dtype, self.device)
+
+  def sparse_slice(self, b, slices):
+    r0, r1, _ = slices[0].indices(b.shape[0])
+    c0, c1 = slices[1].indices(b.shape[1])[:2] if len(slices) > 1 else (0, b.shape[1])
+    self.launches += 1
+    return sparse_mod.slice_box(b, r0, r1, c0, c1)
+
+  def sparse_paste(self, shape, dtype, pieces):
+    self.launches += 1
+    return sparse_mod.paste(shape, dtype, [(ul[0], ul[1], p) for ul, p in pieces])
+
+  def sparse_reduce(self, old, upd, reducer):
+    if reducer is not np.add:
+      raise NotImplementedError('sparse tiles combine with np.add only (got %r)' % (reducer,))
+    self.launches += 1
+    return sparse_mod.add(old, upd)
+
+  def sparse_update(self, old, ul, lr, upd, reducer):
+    if reducer is not None and reducer is not np.add:
+      raise NotImplementedError('sparse tiles combine with np.add only (got %r)' % (reducer,))
+    self.launches += 1
+    return sparse_mod.update_box(old, ul[0], lr[0], ul[1], lr[1], upd, add_to_old=reducer is not None)
+
+  def sparse_scatter(self, dst, ul, blob, mode, mask):
+    self.launches += 1
+    blob = self.sparse_blob(blob, self.dtype_of(dst))
+    sparse_mod.scatter(blob, dst, ul[0], ul[1], mode, mask)
+
+  def sparse_to_dense(self, b):
+    self.launches += 1
+    return sparse_mod.to_dense(b)
+
+  def sparse_transpose(self, b):
+    self.launches += 1
+    return sparse_mod.transpose(b)
+
+  def sparse_random(self, shape, density, dtype):
+    """scipy.sparse.rand's role (srandom.py:57-65) from the counter-based generator: int(density * size)
+    uniformly drawn positions (colliding ones merge, their values add), uniform [0, 1) values."""
+    m, n = int(shape[0]), int(shape[1])
+    k = int(density * m * n)
+    if k <= 0 or m == 0 or n == 0:
+      return self.sparse_empty((m, n), dtype)
+    rows = self.random_tile('randint', (k,), np.int32, 0, m)
+    cols = self.random_tile('randint', (k,), np.int32, 0, n)
+    vals = self.random_tile('uniform', (k,), dtype)
+    return sparse_mod.from_coo((m, n), dtype, rows, cols, vals)
+
+  def _sparse_dot(self, a, b):
+    """tile_a.dot(tile_b) with a sparse operand (dot.py:212-240)."""
+    self.launches += 1
+    if isinstance(a, sparse_mod.CsrTile):
+      if isinstance(b, sparse_mod.CsrTile):
+        return sparse_mod.spgemm(a, b)
+      return sparse_mod.spmm(a, self._as_device(b))
+    # dense x sparse = (sparse^T x dense^T)^T
+    a = self._as_device(a)
+    vec = a.dim() == 1
+    at = a.reshape(1, -1) if vec else a
+    out = sparse_mod.spmm(sparse_mod.transpose(b), self.copy(at.t()))
+    out = self.copy(out.t())
+    return out.reshape(-1) if vec else out
+
+  def _evaluate_sparse_map(self, op, inputs, ex):
+    """A local map tree with sparse operands, node by node (the reference hands the scipy matrices to the
+    NumPy function, local.py:115-127): sparse (+|-) sparse and scalings stay sparse; a ufunc over one sparse
+    and one dense operand sees the sparse one densified (local.py:120-126); dense sub-trees are fused maps."""
+    from .expr import builtins as B
+
+    def ev(node):
+      if isinstance(node, LocalInput):
+        return ex.to_tuple() if node.idx == 'extent' else inputs[node.idx]
+      if not isinstance(node, FnCallExpr):
+        raise lower.NotLowerable('cannot evaluate local expression %r' % (node,))
+      args = [ev(d) for d in node.deps]
+      flags = [tile.is_sparse_blob(a) for a in args]
+      fn = node.fn
+      if isinstance(fn, np.ufunc) and len(args) == 2 and (flags[0] ^ flags[1]):
+        args = [self.sparse_to_dense(a) if f else a for a, f in zip(args, flags)]
+        flags = [False, False]
+      if not any(flags):
+        if fn not in lower.MAP_RULES:
+          raise lower.NotLowerable('%s next to sparse operands has no GPU lowering' % node.fn_name())
+        return self.evaluate_fn(fn, args, dict(node.kw or {}), ex.shape)
+      self.launches += 1
+      if fn is np.add and all(flags) and len(args) == 2:
+        return sparse_mod.add(args[0], args[1])
+      if fn is np.subtract and all(flags) and len(args) == 2:
+        return sparse_mod.add(args[0], args[1], -1)
+      if fn is np.negative:
+        return sparse_mod.scaled(args[0], -1.0)
+      if fn is np.multiply and len(args) == 2 and sum(flags) == 1:
+        other = args[1] if flags[0] else args[0]
+        if isinstance(other, (int, float, np.generic)):
+          return sparse_mod.scaled(args[0] if flags[0] else args[1], float(other))
+      raise NotImplementedError('%s on sparse tiles is not supported on the GPU backend' % node.fn_name())
+
+    return ev(op)
+
+  def _evaluate_sparse_reduce(self, op, data_dep, inputs, ex, axis):
+    """Local reduction of a sparse tile: sums only (scipy's .sum(axis), dense result; reduce.py:57-66)."""
+    from .expr import builtins as B
+    if op.fn is not B._sum_local:
+      raise NotImplementedError('%s of a sparse tile is not supported on the GPU backend' % op.fn_name())
+    t = inputs[data_dep.idx] if isinstance(data_dep, LocalInput) else self._evaluate_sparse_map(data_dep, inputs, ex)
+    if not tile.is_sparse_blob(t):
+      return self.evaluate_reduce_tensor(t, 'SUM') if axis is None else self.reduce_axis(t, 'SUM', axis)
+    self.launches += 1
+    if axis is None:
+      if t.nnz == 0:
+        return self.zeros((), t.dtype)
+      return self.evaluate_reduce_tensor(t.data, 'SUM')
+    if axis in (1, -1):
+      return sparse_mod.row_sums(t)
+    return sparse_mod.row_sums(sparse_mod.transpose(t))
 
   def synchronize(self):
     torch.cuda.synchronize(self.device)

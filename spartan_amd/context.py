@@ -137,9 +137,10 @@ class Context(object):
     src = self.rank_of(tile_id.worker)
     meta = None
     if self.world.rank == src:
-      meta = self._blobs[tile_id].dtype.str
+      t = self._blobs[tile_id]
+      meta = (t.dtype.str, t.type == tile_mod.TYPE_SPARSE)
     meta = self.world.broadcast_object(meta, src)
-    return np.dtype(meta), False
+    return np.dtype(meta[0]), bool(meta[1])
 
 
 _ctx = None

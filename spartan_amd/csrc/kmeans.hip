@@ -18,6 +18,7 @@
 // uses, after a stable counting sort of the row ids by label -- deterministic,
 // no floating-point atomics.
 #include "sp_common.hpp"
+#include "sp_scan.hpp"
 
 namespace {
 
@@ -300,84 +301,6 @@ __global__ __launch_bounds__(256) void sp_label_hist_kernel(const int64_t* __res
   }
   __syncthreads();
   for (int i = threadIdx.x; i < k; i += blockDim.x) hist[(int64_t)i * nblk + b] = lh[i];
-}
-
-// exclusive scan of `m` ints in place, three coalesced phases over chunks of 4096:
-//   1. chunk sums   2. one workgroup scans the (<= 4096 per pass) chunk sums   3. local scan + chunk offset
-constexpr int SCAN_CHUNK = 4096;
-
-__global__ __launch_bounds__(1024) void sp_scan_sums_kernel(const int* __restrict__ a, int64_t m,
-                                                            int* __restrict__ sums) {
-  __shared__ int red[16];
-  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
-  int s = 0;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int64_t i = base + u * 1024 + threadIdx.x;
-    if (i < m) s += a[i];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int w = 0; w < 16; ++w) t += red[w];
-    sums[blockIdx.x] = t;
-  }
-}
-
-// block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, *total = sum
-__device__ __forceinline__ int sp_block_exscan_1024(int v, int* total) {
-  __shared__ int wsum[16];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(inc, off);
-    if (lane >= off) inc += o;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  int woff = 0, tot = 0;
-  for (int i = 0; i < 16; ++i) {
-    const int t = wsum[i];
-    if (i < w) woff += t;
-    tot += t;
-  }
-  __syncthreads();
-  if (total) *total = tot;
-  return woff + inc - v;
-}
-
-// in-place exclusive scan of the n_sums chunk sums by one workgroup (sequential passes of 1024)
-__global__ __launch_bounds__(1024) void sp_scan_top_kernel(int* __restrict__ sums, int n_sums,
-                                                           int* __restrict__ total_out) {
-  int carry = 0;
-  for (int base = 0; base < n_sums; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < n_sums ? sums[i] : 0;
-    int tot;
-    const int ex = sp_block_exscan_1024(v, &tot);
-    if (i < n_sums) sums[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
-__global__ __launch_bounds__(1024) void sp_scan_apply_kernel(int* __restrict__ a, int64_t m,
-                                                             const int* __restrict__ sums) {
-  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * 4;
-  int v[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] = base + u < m ? a[base + u] : 0;
-  const int mine = v[0] + v[1] + v[2] + v[3];
-  int run = sums[blockIdx.x] + sp_block_exscan_1024(mine, nullptr);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (base + u < m) a[base + u] = run;
-    run += v[u];
-  }
 }
 
 // perm[pos] = row, rows of one label contiguous and in ascending row order.

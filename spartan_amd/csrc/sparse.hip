@@ -1,0 +1,573 @@
+// Sparse tiles in HBM: the per-tile bodies of the reference's sparse path
+//   spartan/array/sparse.pyx   sparse_to_dense_update (:21-38), dot_coo_dense_unordered_map (:103-158),
+//                              slice / multiple_slice / compute_sparse_update (:198-341)
+//   spartan/array/tile.pyx     merge, sparse branches (:226-252, :283-295)
+//   spartan/expr/dot.py        dot_map2_mapper / dot_outer_mapper on scipy.sparse tiles (:193-240)
+// The reference keeps a tile as whatever scipy.sparse format the producing mapper chose (lil, coo, csr ...)
+// and converts on every use.  Here a sparse tile has ONE device format -- canonical CSR: int64 indptr,
+// int32 column indices ascending inside a row, no duplicate coordinates -- and every structural operation
+// (upload of COO/CSR data, transpose, slicing by a box, region updates, A + B, the expansion step of
+// sparse x sparse) is "edit a COO list, then sp_coo_to_csr": an LSD radix sort of (row, col) keys that is
+// stable, so duplicate coordinates are added in list order, without floating-point atomics.
+//   sp_csr_spmm     CSR x dense (the dot of the pagerank / netflix-style programs): HBM-bound,
+//                   12 B per stored entry + 12 B per row for N = 1.
+//   sp_csr_scatter  sparse -> dense update (assign / add / the reference's masked first-write rule).
+#include <stdlib.h>
+
+#include "sp_common.hpp"
+#include "sp_scan.hpp"
+
+namespace {
+
+constexpr int RDX_BITS = 8;
+constexpr int RDX = 1 << RDX_BITS;
+constexpr int SORT_RB = 4096;            // keys per workgroup / wavefront of one radix pass
+constexpr uint64_t KEY_DROPPED = ~0ull;  // entries with row < 0 are dropped: they sort to the end
+
+// ---------------------------------------------------------------- COO -> keys
+__global__ __launch_bounds__(256) void sp_coo_keys_kernel(const int32_t* __restrict__ rows,
+                                                          const int32_t* __restrict__ cols, int64_t n,
+                                                          int64_t ncols, uint64_t* __restrict__ keys,
+                                                          int32_t* __restrict__ idx) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int32_t r = rows[i];
+    keys[i] = r < 0 ? KEY_DROPPED : (uint64_t)r * (uint64_t)ncols + (uint64_t)cols[i];
+    idx[i] = (int32_t)i;
+  }
+}
+
+// ---------------------------------------------------------------- one stable radix pass
+// hist[d * nblk + b] = number of keys with digit d in key block b
+__global__ __launch_bounds__(256) void sp_radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                            int nblk, int* __restrict__ hist) {
+  __shared__ int lh[RDX];
+  const int b = blockIdx.x;
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t r0 = (int64_t)b * SORT_RB;
+  const int64_t r1 = r0 + SORT_RB < n ? r0 + SORT_RB : n;
+  for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) atomicAdd(&lh[(int)((keys[i] >> shift) & (RDX - 1))], 1);
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * nblk + b] = lh[threadIdx.x];
+}
+
+// One wavefront per key block walks it in order; the rank of a key among the keys of the same digit in its
+// 64-key chunk is the number of LOWER lanes with that digit (64 readlane steps, no divergence), the last
+// lane of each digit advances the LDS cursor -- the scheme of sp_label_rank_kernel (kmeans.hip).
+__global__ __launch_bounds__(64) void sp_radix_rank_kernel(const uint64_t* __restrict__ keys,
+                                                           const int32_t* __restrict__ idx, int64_t n, int shift,
+                                                           int nblk, const int* __restrict__ offs,
+                                                           uint64_t* __restrict__ keys_out,
+                                                           int32_t* __restrict__ idx_out) {
+  __shared__ int cur[RDX];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < RDX; i += 64) cur[i] = offs[(int64_t)i * nblk + b];
+  __syncthreads();
+  const int64_t r0 = (int64_t)b * SORT_RB;
+  const int64_t r1 = r0 + SORT_RB < n ? r0 + SORT_RB : n;
+  for (int64_t base = r0; base < r1; base += 64) {
+    const int64_t i = base + lane;
+    const bool valid = i < r1;
+    uint64_t key = 0;
+    int32_t id = 0;
+    int dg = -1 - lane;  // invalid lanes: a value no other lane holds
+    if (valid) {
+      key = keys[i];
+      id = idx[i];
+      dg = (int)((key >> shift) & (RDX - 1));
+    }
+    int lower = 0, same = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const int dj = __builtin_amdgcn_readlane(dg, j);
+      const int eq = (dj == dg) ? 1 : 0;
+      same += eq;
+      lower += (j < lane) ? eq : 0;
+    }
+    int start = 0;
+    if (valid) start = cur[dg];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      keys_out[start + lower] = key;
+      idx_out[start + lower] = id;
+      if (lower == same - 1) cur[dg] = start + same;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------- compress sorted keys to CSR
+__device__ __forceinline__ bool sp_is_head(const uint64_t* keys, int64_t i) {
+  const uint64_t k = keys[i];
+  return k != KEY_DROPPED && (i == 0 || keys[i - 1] != k);
+}
+
+__global__ __launch_bounds__(256) void sp_coo_heads_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                           int* __restrict__ flags) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    flags[i] = sp_is_head(keys, i) ? 1 : 0;
+}
+
+// entries with equal coordinates are added in list order (the sort is stable)
+template <typename T>
+__global__ __launch_bounds__(256) void sp_coo_compress_kernel(const uint64_t* __restrict__ keys,
+                                                              const int32_t* __restrict__ idx,
+                                                              const T* __restrict__ vals, int64_t n,
+                                                              const int* __restrict__ pos, int64_t ncols,
+                                                              int32_t* __restrict__ indices, T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (!sp_is_head(keys, i)) continue;
+    const uint64_t k = keys[i];
+    T s = vals[idx[i]];
+    for (int64_t j = i + 1; j < n && keys[j] == k; ++j) s += vals[idx[j]];
+    const int o = pos[i];
+    indices[o] = (int32_t)(k % (uint64_t)ncols);
+    out[o] = s;
+  }
+}
+
+// indptr[r] = number of output entries whose key is below r * ncols
+__global__ __launch_bounds__(256) void sp_csr_indptr_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                            const int* __restrict__ pos,
+                                                            const int* __restrict__ total, int64_t nrows,
+                                                            int64_t ncols, int64_t* __restrict__ indptr) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= nrows; r += (int64_t)gridDim.x * 256) {
+    const uint64_t target = (uint64_t)r * (uint64_t)ncols;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < target) lo = mid + 1;
+      else hi = mid;
+    }
+    // the first key >= target is a head unless it is a dropped entry (then every later key is dropped too)
+    indptr[r] = (lo < n && keys[lo] != KEY_DROPPED) ? pos[lo] : *total;
+  }
+}
+
+// ---------------------------------------------------------------- CSR -> COO rows, box edits
+__device__ __forceinline__ int64_t sp_row_of(const int64_t* __restrict__ indptr, int64_t nrows, int64_t t) {
+  int64_t lo = 0, hi = nrows;  // largest r with indptr[r] <= t
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (indptr[mid] <= t) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void sp_csr_rows_kernel(const int64_t* __restrict__ indptr, int64_t nrows,
+                                                          int64_t nnz, int32_t* __restrict__ rows) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * 256)
+    rows[t] = (int32_t)sp_row_of(indptr, nrows, t);
+}
+
+__global__ __launch_bounds__(256) void sp_coo_box_kernel(int32_t* __restrict__ rows, int32_t* __restrict__ cols,
+                                                         int64_t n, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+                                                         int64_t dr, int64_t dc, int drop_inside) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = rows[i], c = cols[i];
+    if (r < 0) continue;
+    const bool inside = r >= r0 && r < r1 && c >= c0 && c < c1;
+    if (inside == (drop_inside != 0)) {
+      rows[i] = -1;
+    } else {
+      rows[i] = (int32_t)(r + dr);
+      cols[i] = (int32_t)(c + dc);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- CSR x dense
+// N == 1: G lanes per row, strided over the row's entries, shuffle reduction (fixed order per G).
+template <typename T, int G>
+__global__ __launch_bounds__(256) void sp_csr_spmv_kernel(const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices,
+                                                          const T* __restrict__ vals, const T* __restrict__ x,
+                                                          int64_t ldx, T* __restrict__ y, int64_t ldy, int64_t m,
+                                                          int accumulate) {
+  const int g = threadIdx.x % G;
+  const int64_t groups = (int64_t)gridDim.x * (256 / G);
+  for (int64_t r = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; r < m; r += groups) {
+    const int64_t a = indptr[r], b = indptr[r + 1];
+    T acc = 0;
+    if (x) {
+      for (int64_t j = a + g; j < b; j += G) acc += vals[j] * x[(int64_t)indices[j] * ldx];
+    } else {
+      for (int64_t j = a + g; j < b; j += G) acc += vals[j];
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (g == 0) y[r * ldy] = accumulate ? y[r * ldy] + acc : acc;
+  }
+}
+
+// N > 1: NL lanes along the columns of C (V columns each), 64 / NL rows per wavefront; a row's entries are
+// walked in storage order, y += a * B[k, :] (the order of scipy's csr_matvecs).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void sp_csr_spmm_kernel(const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices,
+                                                          const T* __restrict__ vals, const T* __restrict__ B,
+                                                          int64_t ldb, T* __restrict__ C, int64_t ldc, int64_t m,
+                                                          int64_t n, int nl, int accumulate) {
+  const int lr = threadIdx.x % nl;            // lane inside the row group
+  const int rows_per_block = 256 / nl;
+  const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / nl; r < m; r += stride) {
+    const int64_t a = indptr[r], b = indptr[r + 1];
+    for (int64_t c0 = (int64_t)lr * V; c0 < n; c0 += (int64_t)nl * V) {
+      T acc[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = (accumulate && c0 + v < n) ? C[r * ldc + c0 + v] : (T)0;
+      for (int64_t j = a; j < b; ++j) {
+        const T av = vals[j];
+        const T* brow = B + (int64_t)indices[j] * ldb + c0;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (c0 + v < n) acc[v] += av * brow[v];
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v)
+        if (c0 + v < n) C[r * ldc + c0 + v] = acc[v];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- sparse -> dense
+// mode 0: out = v   1: out += v   2: sparse.pyx:21-38 with REDUCE_ADD -- first write where the mask is clear
+// (and set it), add where it is set.  Canonical CSR has no duplicate coordinates: no two threads share a cell.
+template <typename T>
+__global__ __launch_bounds__(256) void sp_csr_scatter_kernel(const int64_t* __restrict__ indptr,
+                                                             const int32_t* __restrict__ indices,
+                                                             const T* __restrict__ vals, int64_t m, int64_t nnz,
+                                                             T* __restrict__ out, int64_t ld, int64_t row0,
+                                                             int64_t col0, uint8_t* __restrict__ mask,
+                                                             int64_t ldmask, int mode) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = sp_row_of(indptr, m, t) + row0;
+    const int64_t c = (int64_t)indices[t] + col0;
+    T* o = out + r * ld + c;
+    if (mode == 0) {
+      *o = vals[t];
+    } else if (mode == 1) {
+      *o += vals[t];
+    } else {
+      uint8_t* mk = mask + r * ldmask + c;
+      if (*mk) {
+        *o += vals[t];
+      } else {
+        *o = vals[t];
+        *mk = 1;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- sparse x sparse, expansion step
+// counts[t] = entries of B's row indicesA[t]
+__global__ __launch_bounds__(256) void sp_spgemm_count_kernel(const int32_t* __restrict__ ia, int64_t nnza,
+                                                              const int64_t* __restrict__ pb,
+                                                              int* __restrict__ counts,
+                                                              unsigned long long* __restrict__ total) {
+  unsigned long long mine = 0;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nnza; t += (int64_t)gridDim.x * 256) {
+    const int64_t k = ia[t];
+    const int64_t c = pb[k + 1] - pb[k];
+    counts[t] = (int)c;
+    mine += (unsigned long long)c;
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);   // integer: order does not matter
+}
+
+// products of A's entry t = (i, k, a) with B's row k, written at offs[t] in A's storage order, so that the
+// stable sort adds the products of one output cell in the order scipy's csr_matmat does (k ascending)
+template <typename T>
+__global__ __launch_bounds__(256) void sp_spgemm_expand_kernel(const int64_t* __restrict__ pa, int64_t ma,
+                                                               const int32_t* __restrict__ ia,
+                                                               const T* __restrict__ va, int64_t nnza,
+                                                               const int64_t* __restrict__ pb,
+                                                               const int32_t* __restrict__ ib,
+                                                               const T* __restrict__ vb,
+                                                               const int* __restrict__ offs,
+                                                               int32_t* __restrict__ rows,
+                                                               int32_t* __restrict__ cols, T* __restrict__ out) {
+  constexpr int G = 8;
+  const int g = threadIdx.x % G;
+  const int64_t stride = (int64_t)gridDim.x * (256 / G);
+  for (int64_t t = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; t < nnza; t += stride) {
+    const int32_t i = (int32_t)sp_row_of(pa, ma, t);
+    const int64_t k = ia[t];
+    const T a = va[t];
+    const int64_t b0 = pb[k], len = pb[k + 1] - b0;
+    const int64_t o = offs[t];
+    for (int64_t j = g; j < len; j += G) {
+      rows[o + j] = i;
+      cols[o + j] = ib[b0 + j];
+      out[o + j] = a * vb[b0 + j];
+    }
+  }
+}
+
+inline unsigned grid_for(int64_t n, int per_block) {
+  int64_t b = (n + per_block - 1) / per_block;
+  const int64_t cap = (int64_t)SP_CUS * SP_BLOCKS_PER_CU * 4;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+inline int key_bits(int64_t nrows, int64_t ncols) {
+  // keys are < nrows * ncols; one more value keeps the all-ones pattern of dropped entries above every key
+  const unsigned __int128 span = (unsigned __int128)nrows * (unsigned __int128)ncols + 1;
+  int bits = 1;
+  while (bits < 64 && ((unsigned __int128)1 << bits) < span) ++bits;
+  return bits;
+}
+
+struct SortWs {
+  uint64_t* keys[2];
+  int32_t* idx[2];
+  int* hist;   // [RDX][nblk]; reused as the head flags / positions [nnz]
+  int* sums;   // scan chunk sums
+  int* total;
+};
+
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+inline size_t sort_ws_bytes(int64_t nnz, SortWs* ws, char* base) {
+  const int64_t nblk = (nnz + SORT_RB - 1) / SORT_RB;
+  const int64_t hist_words = (int64_t)RDX * nblk > nnz ? (int64_t)RDX * nblk : nnz;
+  const int64_t sums_words = (hist_words + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += al256(bytes);
+    return p;
+  };
+  char* k0 = take((size_t)nnz * 8);
+  char* k1 = take((size_t)nnz * 8);
+  char* i0 = take((size_t)nnz * 4);
+  char* i1 = take((size_t)nnz * 4);
+  char* h = take((size_t)hist_words * 4);
+  char* s = take((size_t)sums_words * 4);
+  char* t = take(256);
+  if (ws) {
+    ws->keys[0] = (uint64_t*)k0;
+    ws->keys[1] = (uint64_t*)k1;
+    ws->idx[0] = (int32_t*)i0;
+    ws->idx[1] = (int32_t*)i1;
+    ws->hist = (int*)h;
+    ws->sums = (int*)s;
+    ws->total = (int*)t;
+  }
+  return off;
+}
+
+}  // namespace
+
+extern "C" size_t sp_coo_to_csr_workspace_bytes(int64_t nnz) {
+  if (nnz < 1) return 256;
+  return sort_ws_bytes(nnz, nullptr, nullptr);
+}
+
+extern "C" int sp_coo_to_csr(int32_t dtype, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t* d_rows,
+                             const int32_t* d_cols, const void* d_vals, int64_t* d_indptr, int32_t* d_indices,
+                             void* d_vals_out, void* d_ws, size_t ws_bytes, void* stream) {
+  if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_coo_to_csr: values must be f32 or f64");
+  if (nrows < 0 || ncols < 0 || nnz < 0) SP_FAIL("sp_coo_to_csr: bad sizes");
+  if (nrows > 2147483647LL || ncols > 2147483647LL) SP_FAIL("sp_coo_to_csr: a dimension exceeds the int32 index range");
+  if (nnz > 2147483647LL - SCAN_CHUNK) SP_FAIL("sp_coo_to_csr: more than 2^31 entries in one tile");
+  if (!d_indptr) SP_FAIL("sp_coo_to_csr: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (nnz == 0 || ncols == 0 || nrows == 0) {
+    SP_HIP(hipMemsetAsync(d_indptr, 0, (size_t)(nrows + 1) * 8, st));
+    return 0;
+  }
+  if (!d_rows || !d_cols || !d_vals || !d_indices || !d_vals_out) SP_FAIL("sp_coo_to_csr: NULL pointer");
+  if (!d_ws || ws_bytes < sp_coo_to_csr_workspace_bytes(nnz)) SP_FAIL("sp_coo_to_csr: workspace too small");
+  SortWs ws;
+  sort_ws_bytes(nnz, &ws, (char*)d_ws);
+  const int nblk = (int)((nnz + SORT_RB - 1) / SORT_RB);
+  hipLaunchKernelGGL(sp_coo_keys_kernel, dim3(grid_for(nnz, 256)), dim3(256), 0, st, d_rows, d_cols, nnz, ncols,
+                     ws.keys[0], ws.idx[0]);
+  SP_CHECK_LAUNCH();
+  const int bits = key_bits(nrows, ncols);
+  int cur = 0;
+  for (int shift = 0; shift < bits; shift += RDX_BITS) {
+    hipLaunchKernelGGL(sp_radix_hist_kernel, dim3(nblk), dim3(256), 0, st, ws.keys[cur], nnz, shift, nblk, ws.hist);
+    SP_CHECK_LAUNCH();
+    if (sp_exscan_int(ws.hist, (int64_t)RDX * nblk, ws.sums, nullptr, st)) return 1;
+    hipLaunchKernelGGL(sp_radix_rank_kernel, dim3(nblk), dim3(64), 0, st, ws.keys[cur], ws.idx[cur], nnz, shift, nblk,
+                       ws.hist, ws.keys[1 - cur], ws.idx[1 - cur]);
+    SP_CHECK_LAUNCH();
+    cur = 1 - cur;
+  }
+  int* pos = ws.hist;
+  hipLaunchKernelGGL(sp_coo_heads_kernel, dim3(grid_for(nnz, 256)), dim3(256), 0, st, ws.keys[cur], nnz, pos);
+  SP_CHECK_LAUNCH();
+  if (sp_exscan_int(pos, nnz, ws.sums, ws.total, st)) return 1;
+  if (dtype == SP_F32)
+    hipLaunchKernelGGL((sp_coo_compress_kernel<float>), dim3(grid_for(nnz, 256)), dim3(256), 0, st, ws.keys[cur],
+                       ws.idx[cur], (const float*)d_vals, nnz, pos, ncols, d_indices, (float*)d_vals_out);
+  else
+    hipLaunchKernelGGL((sp_coo_compress_kernel<double>), dim3(grid_for(nnz, 256)), dim3(256), 0, st, ws.keys[cur],
+                       ws.idx[cur], (const double*)d_vals, nnz, pos, ncols, d_indices, (double*)d_vals_out);
+  SP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sp_csr_indptr_kernel, dim3(grid_for(nrows + 1, 256)), dim3(256), 0, st, ws.keys[cur], nnz, pos,
+                     ws.total, nrows, ncols, d_indptr);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sp_csr_rows(int64_t nrows, int64_t nnz, const int64_t* d_indptr, int32_t* d_rows, void* stream) {
+  if (nrows < 0 || nnz < 0) SP_FAIL("sp_csr_rows: bad sizes");
+  if (nnz == 0) return 0;
+  if (!d_indptr || !d_rows) SP_FAIL("sp_csr_rows: NULL pointer");
+  hipLaunchKernelGGL(sp_csr_rows_kernel, dim3(grid_for(nnz, 256)), dim3(256), 0, (hipStream_t)stream, d_indptr, nrows,
+                     nnz, d_rows);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sp_coo_box(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+                          int64_t dr, int64_t dc, int32_t drop_inside, void* stream) {
+  if (nnz < 0) SP_FAIL("sp_coo_box: bad size");
+  if (nnz == 0) return 0;
+  if (!d_rows || !d_cols) SP_FAIL("sp_coo_box: NULL pointer");
+  hipLaunchKernelGGL(sp_coo_box_kernel, dim3(grid_for(nnz, 256)), dim3(256), 0, (hipStream_t)stream, d_rows, d_cols,
+                     nnz, r0, r1, c0, c1, dr, dc, (int)drop_inside);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+namespace {
+
+template <typename T>
+int spmm_go(int64_t m, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices, const T* vals, const T* B,
+            int64_t ldb, T* C, int64_t ldc, int accumulate, hipStream_t st) {
+  if (n == 1 || !B) {
+    // lanes per row: the power of two nearest above the mean row length, 2 .. 64
+    const double mean = m > 0 ? (double)nnz / (double)m : 0.0;
+    int G = 2;
+    while (G < 64 && G < mean) G <<= 1;
+    const char* e = getenv("SP_SPMV_G");
+    if (e && atoi(e) > 0) G = atoi(e);
+    const unsigned grid = grid_for(m, 256 / G);
+#define SP_SPMV_GO(GG)                                                                                           \
+  hipLaunchKernelGGL((sp_csr_spmv_kernel<T, GG>), dim3(grid), dim3(256), 0, st, indptr, indices, vals, B, ldb, C, ldc, \
+                     m, accumulate)
+    switch (G) {
+      case 2: SP_SPMV_GO(2); break;
+      case 4: SP_SPMV_GO(4); break;
+      case 8: SP_SPMV_GO(8); break;
+      case 16: SP_SPMV_GO(16); break;
+      case 32: SP_SPMV_GO(32); break;
+      default: SP_SPMV_GO(64); break;
+    }
+#undef SP_SPMV_GO
+    SP_CHECK_LAUNCH();
+    return 0;
+  }
+  int V = n >= 256 ? 4 : (n >= 128 ? 2 : 1);
+  int nl = 1;
+  while (nl < 64 && (int64_t)nl * V < n) nl <<= 1;
+  const unsigned grid = grid_for(m, 256 / nl);
+  if (V == 4)
+    hipLaunchKernelGGL((sp_csr_spmm_kernel<T, 4>), dim3(grid), dim3(256), 0, st, indptr, indices, vals, B, ldb, C, ldc, m,
+                       n, nl, accumulate);
+  else if (V == 2)
+    hipLaunchKernelGGL((sp_csr_spmm_kernel<T, 2>), dim3(grid), dim3(256), 0, st, indptr, indices, vals, B, ldb, C, ldc, m,
+                       n, nl, accumulate);
+  else
+    hipLaunchKernelGGL((sp_csr_spmm_kernel<T, 1>), dim3(grid), dim3(256), 0, st, indptr, indices, vals, B, ldb, C, ldc, m,
+                       n, nl, accumulate);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sp_csr_spmm(int32_t dtype, int64_t m, int64_t k, int64_t n, int64_t nnz, const int64_t* d_indptr,
+                           const int32_t* d_indices, const void* d_vals, const void* d_b, int64_t ldb, void* d_c,
+                           int64_t ldc, int32_t accumulate, void* stream) {
+  if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_csr_spmm: values must be f32 or f64");
+  if (m < 0 || k < 0 || n < 0 || nnz < 0) SP_FAIL("sp_csr_spmm: bad sizes");
+  if (m == 0 || n == 0) return 0;
+  if (!d_indptr || !d_c || (nnz && (!d_indices || !d_vals))) SP_FAIL("sp_csr_spmm: NULL pointer");
+  if (!d_b && n != 1) SP_FAIL("sp_csr_spmm: a NULL right-hand side (row sums) needs n == 1");
+  if (ldc < n || (d_b && ldb < n)) SP_FAIL("sp_csr_spmm: leading dimension too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SP_F32)
+    return spmm_go<float>(m, n, nnz, d_indptr, d_indices, (const float*)d_vals, (const float*)d_b, ldb, (float*)d_c, ldc,
+                          accumulate, st);
+  return spmm_go<double>(m, n, nnz, d_indptr, d_indices, (const double*)d_vals, (const double*)d_b, ldb, (double*)d_c,
+                         ldc, accumulate, st);
+}
+
+extern "C" int sp_csr_scatter(int32_t dtype, int64_t m, int64_t nnz, const int64_t* d_indptr, const int32_t* d_indices,
+                              const void* d_vals, void* d_out, int64_t ld, int64_t row0, int64_t col0, uint8_t* d_mask,
+                              int64_t ldmask, int32_t mode, void* stream) {
+  if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_csr_scatter: values must be f32 or f64");
+  if (m < 0 || nnz < 0 || mode < 0 || mode > 2) SP_FAIL("sp_csr_scatter: bad arguments");
+  if (nnz == 0) return 0;
+  if (!d_indptr || !d_indices || !d_vals || !d_out) SP_FAIL("sp_csr_scatter: NULL pointer");
+  if (mode == 2 && !d_mask) SP_FAIL("sp_csr_scatter: masked mode needs a mask");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SP_F32)
+    hipLaunchKernelGGL((sp_csr_scatter_kernel<float>), dim3(grid_for(nnz, 256)), dim3(256), 0, st, d_indptr, d_indices,
+                       (const float*)d_vals, m, nnz, (float*)d_out, ld, row0, col0, d_mask, ldmask, (int)mode);
+  else
+    hipLaunchKernelGGL((sp_csr_scatter_kernel<double>), dim3(grid_for(nnz, 256)), dim3(256), 0, st, d_indptr, d_indices,
+                       (const double*)d_vals, m, nnz, (double*)d_out, ld, row0, col0, d_mask, ldmask, (int)mode);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t sp_spgemm_count_workspace_bytes(int64_t nnz_a) {
+  return al256((size_t)((nnz_a + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4) + 256;
+}
+
+extern "C" int sp_spgemm_count(int64_t nnz_a, const int32_t* d_indices_a, const int64_t* d_indptr_b, int32_t* d_offs,
+                               int64_t* d_total, void* d_ws, size_t ws_bytes, void* stream) {
+  if (nnz_a < 0 || nnz_a > 2147483647LL - SCAN_CHUNK) SP_FAIL("sp_spgemm_count: bad size");
+  if (!d_offs || !d_total) SP_FAIL("sp_spgemm_count: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SP_HIP(hipMemsetAsync(d_total, 0, 8, st));
+  if (nnz_a == 0) {
+    SP_HIP(hipMemsetAsync(d_offs, 0, 4, st));
+    return 0;
+  }
+  if (!d_indices_a || !d_indptr_b) SP_FAIL("sp_spgemm_count: NULL pointer");
+  if (!d_ws || ws_bytes < sp_spgemm_count_workspace_bytes(nnz_a)) SP_FAIL("sp_spgemm_count: workspace too small");
+  hipLaunchKernelGGL(sp_spgemm_count_kernel, dim3(grid_for(nnz_a, 256)), dim3(256), 0, st, d_indices_a, nnz_a,
+                     d_indptr_b, (int*)d_offs, (unsigned long long*)d_total);
+  SP_CHECK_LAUNCH();
+  // offs[t] = exclusive prefix (int); *d_total = the exact 64-bit number of products -- the caller refuses an
+  // expansion that does not fit the int offsets before calling sp_spgemm_expand
+  return sp_exscan_int((int*)d_offs, nnz_a, (int*)d_ws, (int*)d_offs + nnz_a, st);
+}
+
+extern "C" int sp_spgemm_expand(int32_t dtype, int64_t m_a, int64_t nnz_a, const int64_t* d_indptr_a,
+                                const int32_t* d_indices_a, const void* d_vals_a, const int64_t* d_indptr_b,
+                                const int32_t* d_indices_b, const void* d_vals_b, const int32_t* d_offs,
+                                int32_t* d_rows, int32_t* d_cols, void* d_vals, void* stream) {
+  if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_spgemm_expand: values must be f32 or f64");
+  if (m_a < 0 || nnz_a < 0) SP_FAIL("sp_spgemm_expand: bad sizes");
+  if (nnz_a == 0) return 0;
+  if (!d_indptr_a || !d_indices_a || !d_vals_a || !d_indptr_b || !d_offs) SP_FAIL("sp_spgemm_expand: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(nnz_a, 256 / 8);
+  if (dtype == SP_F32)
+    hipLaunchKernelGGL((sp_spgemm_expand_kernel<float>), dim3(grid), dim3(256), 0, st, d_indptr_a, m_a, d_indices_a,
+                       (const float*)d_vals_a, nnz_a, d_indptr_b, d_indices_b, (const float*)d_vals_b,
+                       (const int*)d_offs, d_rows, d_cols, (float*)d_vals);
+  else
+    hipLaunchKernelGGL((sp_spgemm_expand_kernel<double>), dim3(grid), dim3(256), 0, st, d_indptr_a, m_a, d_indices_a,
+                       (const double*)d_vals_a, nnz_a, d_indptr_b, d_indices_b, (const double*)d_vals_b,
+                       (const int*)d_offs, d_rows, d_cols, (double*)d_vals);
+  SP_CHECK_LAUNCH();
+  return 0;
+}

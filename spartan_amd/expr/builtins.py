@@ -27,7 +27,53 @@ def empty(shape, dtype=np.float32, tile_hint=None):
 def empty_like(array, dtype=None, tile_hint=None):
   if dtype is None:
     dtype = array.dtype
-  return ndarray(array.shape, dtype=dtype, tile_hint=tile_hint)
+  return ndarray(array.shape, dtype=dtype, tile_hint=tile_hint, sparse=getattr(array, 'sparse', False))
+
+
+def sparse_empty(shape, dtype=np.float32, tile_hint=None):
+  """creation.py:25-32."""
+  return ndarray(shape, dtype=dtype, tile_hint=tile_hint, sparse=True)
+
+
+def _make_sparse_diagonal(tile, ex):
+  """creation.py:209-220: the part of the unit diagonal that crosses this tile, as a sparse block
+  (built as index arrays on the host -- min(rows, cols) entries -- and handed to the backend)."""
+  import scipy.sparse
+  ul, lr = ex[0], ex[1]
+  lo = ul[0] if ul[0] > ul[1] else ul[1]      # (max / min are the array reductions in this module)
+  hi = lr[0] if lr[0] < lr[1] else lr[1]
+  n = hi - lo if hi > lo else 0
+  idx = np.arange(lo, lo + n)
+  dtype = np.dtype(tile.dtype)
+  mat = scipy.sparse.coo_matrix((np.ones(n, dtype=dtype), (idx - ul[0], idx - ul[1])),
+                                shape=(lr[0] - ul[0], lr[1] - ul[1]), dtype=dtype)
+  return context.get().backend.sparse_blob(mat, dtype)
+
+
+_make_sparse_diagonal._sp_tile_fn = True
+
+
+def sparse_diagonal(shape, dtype=np.float32, tile_hint=None):
+  """creation.py:223-225."""
+  return map_with_location(ndarray(shape, dtype, tile_hint, sparse=True), _make_sparse_diagonal)
+
+
+def _make_sparse_rand(tile, density=None, dtype=None, format=None):
+  """srandom.py:57-65 (scipy.sparse.rand per tile): density * size entries at uniform random positions with
+  uniform [0, 1) values, drawn by the backend's generator (positions that collide are merged)."""
+  return context.get().backend.sparse_random(tuple(tile.shape), density, dtype)
+
+
+_make_sparse_rand._sp_tile_fn = True
+
+
+@not_idempotent
+def sparse_rand(shape, density=0.001, format='lil', dtype=np.float32, tile_hint=None):
+  """srandom.py:121-146.  `format` is accepted and ignored: a device tile has one format (CSR)."""
+  for s in shape:
+    assert isinstance(s, (int, np.integer))
+  return map(ndarray(shape, dtype=dtype, tile_hint=tile_hint, sparse=True), fn=_make_sparse_rand,
+             fn_kw={'dtype': dtype, 'density': density, 'format': format})
 
 
 def _make_zeros(input):

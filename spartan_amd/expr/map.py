@@ -179,8 +179,9 @@ class Map2Expr(Expr):
       dtype = arrays[0].dtype
     if self.update_region is not None:
       raise NotImplementedError('map2(update_region=...) (region_join_mapper) is not on the tile path')
+    sparse = len(arrays) > 1 and bool(getattr(arrays[0], 'sparse', False) and getattr(arrays[1], 'sparse', False))   # map.py:323
     target = distarray.create(self.shape_, dtype, sharder=None, reducer=self.reducer,
-                              tile_hint=self.tile_hint)
+                              tile_hint=self.tile_hint, sparse=sparse)
     arrays[0].foreach_tile(mapper_fn=join_mapper,
                            kw=dict(arrays=arrays, axes=self.axes, local_user_fn=self.fn,
                                    local_user_fn_kw=self.fn_kw, target=target))

@@ -62,8 +62,9 @@ class OuterProductExpr(Expr):
     dtype = self.dtype
     if dtype is None:
       dtype = arrays[0].dtype
+    sparse = len(arrays) > 1 and bool(getattr(arrays[0], 'sparse', False) and getattr(arrays[1], 'sparse', False))   # outer.py:94
     target = distarray.create(self.shape_, dtype, sharder=None, reducer=self.reducer,
-                              tile_hint=self.tile_hint)
+                              tile_hint=self.tile_hint, sparse=sparse)
     arrays[0].foreach_tile(mapper_fn=outer_mapper,
                            kw=dict(arrays=arrays, axes=self.axes, local_user_fn=self.fn,
                                    local_user_fn_kw=self.fn_kw, target=target))

@@ -12,7 +12,7 @@ from . import base as base_mod
 from .base import Expr, lazify
 from .broadcast import Broadcast
 from .. import context
-from ..array import distarray, extent
+from ..array import distarray, extent, tile
 from ..context import LocalKernelResult
 from ..util import Assert
 
@@ -21,6 +21,8 @@ def _permute_all(t):
   """ndarray.transpose() (reverse all axes) for a backend tensor / placeholder."""
   if isinstance(t, distarray.Absent):
     return distarray.Absent(t.shape[::-1], t.dtype)
+  if tile.is_sparse_blob(t):
+    return context.get().backend.sparse_transpose(t)
   if hasattr(t, 'permute'):
     return t.permute(*reversed(range(t.dim())))
   if isinstance(t, np.ndarray):

@@ -595,7 +595,44 @@ def example_goldens(sp, workers):
   return out
 
 
+def sparse_goldens(sp, workers):
+  """Sparse-tile programs (tests/sparse_programs.py) through the reference; values recorded dense."""
+  sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+  from tests import sparse_programs
+  arrays, meta = {}, {}
+  for name, build, tol in sparse_programs.programs():
+    start_cluster(sp, workers)
+    try:
+      expr = build(sp)
+      res = expr.evaluate() if hasattr(expr, 'evaluate') else expr
+      val, was_sparse = sparse_programs.to_dense(res.glom())
+    except Exception as e:  # programs the reference itself cannot run
+      meta[name] = {'skipped': '%s: %s' % (type(e).__name__, str(e)[:200])}
+      continue
+    arrays[name] = val
+    meta[name] = {'sparse': bool(was_sparse), 'dtype': val.dtype.str, 'shape': list(val.shape)}
+  return arrays, meta
+
+
 if __name__ == '__main__':
+  if '--sparse' in sys.argv:
+    if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
+      prepare_tree()
+      build_cython()
+    install_stubs()
+    sp = import_reference()
+    allmeta = {}
+    for n in (1, 4):
+      arrays, meta = sparse_goldens(sp, n)
+      np.savez_compressed(os.path.join(OUT, 'sparse_w%d.npz' % n), **arrays)
+      allmeta[str(n)] = meta
+      print('workers', n, ':', len(arrays), 'arrays')
+      for k, m in meta.items():
+        if 'skipped' in m:
+          print('   skipped', k, m['skipped'][:200])
+    json.dump(allmeta, open(os.path.join(OUT, 'sparse_meta.json'), 'w'), indent=0, sort_keys=True)
+    sys.stdout.flush()
+    os._exit(0)
   if '--examples' in sys.argv:
     # only the example-driver goldens, re-using an existing scratch build of the reference
     if not os.path.exists(os.path.join(SCRATCH, 'spartan')):

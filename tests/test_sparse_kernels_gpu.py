@@ -1,0 +1,217 @@
+"""Sparse tile kernels (spartan_amd/csrc/sparse.hip) through the C-ABI against scipy.sparse -- the library
+the reference's sparse tile bodies are written in (spartan/array/sparse.pyx, tile.pyx:226-252, dot.py:212-240).
+Structure (indptr / indices) must be identical to scipy's canonical CSR; values are bit-exact wherever no
+floating-point re-association is involved (no duplicates / integer-valued data), otherwise within the stated
+tolerance."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from spartan_amd import sparse as S  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _rand_coo(rng, m, n, nnz, dtype, dup=False, integer=False):
+  rows = rng.randint(0, m, size=nnz).astype(np.int32)
+  cols = rng.randint(0, n, size=nnz).astype(np.int32)
+  if dup and nnz > 4:
+    rows[nnz // 2:] = rows[:nnz - nnz // 2]
+    cols[nnz // 2:] = cols[:nnz - nnz // 2]
+  vals = rng.randint(-4, 5, size=nnz).astype(dtype) if integer else rng.standard_normal(nnz).astype(dtype)
+  return sps.coo_matrix((vals, (rows, cols)), shape=(m, n))
+
+
+def _canon(mat):
+  c = mat.tocsr().copy()
+  c.sum_duplicates()
+  c.sort_indices()
+  return c
+
+
+def _same_structure(t, ref):
+  got = S.to_scipy(t)
+  assert got.shape == ref.shape
+  np.testing.assert_array_equal(got.indptr, ref.indptr)
+  np.testing.assert_array_equal(got.indices, ref.indices)
+  return got
+
+
+@pytest.mark.parametrize('shape,nnz', [((1, 1), 1), ((7, 5), 0), ((13, 1), 9), ((1, 17), 9), ((300, 200), 5000),
+                                      ((5000, 70000), 200000), ((2 ** 16, 2 ** 16), 300000)])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_upload_canonical_csr(shape, nnz, dtype):
+  rng = np.random.RandomState(nnz + shape[0])
+  coo = _rand_coo(rng, shape[0], shape[1], nnz, dtype)
+  ref = _canon(coo)
+  got = _same_structure(S.from_scipy(coo, DEV), ref)
+  # random coordinates collide: colliding values are added in list order, scipy adds them in its own order
+  np.testing.assert_allclose(got.data, ref.data, rtol=1e-5 if dtype == np.float32 else 1e-13, atol=1e-6)
+
+
+def test_upload_duplicates_are_summed_exactly_for_integer_values():
+  rng = np.random.RandomState(3)
+  coo = _rand_coo(rng, 200, 300, 20000, np.float32, dup=True, integer=True)
+  ref = _canon(coo)
+  got = _same_structure(S.from_scipy(coo, DEV), ref)
+  np.testing.assert_array_equal(got.data, ref.data)
+
+
+def test_upload_keeps_explicit_zeros_and_any_input_format():
+  m = sps.lil_matrix((6, 9), dtype=np.float32)
+  m[0, 8] = 2
+  m[5, 0] = 0.5
+  m[3, 3] = -1
+  for fmt in ('lil', 'csr', 'csc', 'coo', 'dok'):
+    got = _same_structure(S.from_scipy(m.asformat(fmt), DEV), _canon(m))
+    np.testing.assert_array_equal(got.data, _canon(m).data)
+  z = sps.coo_matrix((np.array([0.0, 1.0], np.float32), ([1, 2], [1, 2])), shape=(4, 4))
+  assert S.from_scipy(z, DEV).nnz == 2     # scipy keeps an explicitly stored zero, so do we
+
+
+def test_transpose_slice_add_sub():
+  rng = np.random.RandomState(5)
+  a = _rand_coo(rng, 257, 1031, 9000, np.float32, integer=True)
+  b = _rand_coo(rng, 257, 1031, 7000, np.float32, integer=True)
+  A, B = S.from_scipy(a, DEV), S.from_scipy(b, DEV)
+  ca, cb = _canon(a), _canon(b)
+  got = _same_structure(S.transpose(A), _canon(ca.T))
+  np.testing.assert_array_equal(got.data, _canon(ca.T).data)
+  for (r0, r1, c0, c1) in [(0, 257, 0, 1031), (10, 200, 0, 1031), (0, 257, 100, 101), (250, 257, 1000, 1031),
+                           (5, 5, 0, 10)]:
+    ref = _canon(ca[r0:r1, c0:c1])
+    got = _same_structure(S.slice_box(A, r0, r1, c0, c1), ref)
+    np.testing.assert_array_equal(got.data, ref.data)
+  # a + b / a - b: scipy drops nothing either (cancelled cells stay stored as 0 only in ours -> compare dense)
+  for sign, ref in ((1, ca + cb), (-1, ca - cb)):
+    got = S.to_scipy(S.add(A, B, sign))
+    np.testing.assert_array_equal(got.toarray(), ref.toarray())
+    assert got.has_canonical_format
+
+
+def test_region_update_matches_compute_sparse_update():
+  rng = np.random.RandomState(6)
+  old = _canon(_rand_coo(rng, 64, 96, 1500, np.float32, integer=True))
+  upd = _canon(_rand_coo(rng, 16, 32, 200, np.float32, integer=True))
+  O, U = S.from_scipy(old, DEV), S.from_scipy(upd, DEV)
+  box = (8, 24, 40, 72)
+  ref = old.tolil()
+  ref[box[0]:box[1], box[2]:box[3]] = upd.toarray()
+  got = S.to_scipy(S.update_box(O, *box, U, add_to_old=False))
+  np.testing.assert_array_equal(got.toarray(), ref.toarray())
+  ref2 = old.toarray()
+  ref2[box[0]:box[1], box[2]:box[3]] += upd.toarray()
+  got2 = S.to_scipy(S.update_box(O, *box, U, add_to_old=True))
+  np.testing.assert_array_equal(got2.toarray(), ref2)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('n', [1, 3, 64, 129, 300])
+@pytest.mark.parametrize('shape,nnz', [((1000, 777), 20000), ((33, 5000), 40000), ((4096, 64), 900)])
+def test_csr_times_dense(shape, nnz, n, dtype):
+  rng = np.random.RandomState(n + nnz)
+  a = _canon(_rand_coo(rng, shape[0], shape[1], nnz, dtype))
+  A = S.from_scipy(a, DEV)
+  b = rng.standard_normal((shape[1], n)).astype(dtype)
+  got = S.spmm(A, torch.from_numpy(b).to(DEV)).cpu().numpy()
+  ref = a.astype(np.float64) @ b.astype(np.float64)
+  scale = (abs(a).astype(np.float64) @ np.abs(b).astype(np.float64))
+  eps = np.finfo(dtype).eps
+  k = max(1, int(a.getnnz(axis=1).max()))
+  assert np.all(np.abs(got - ref) <= 2 * k * eps * scale + 1e-30)   # |dy| <= nnz_row * eps * sum|a||x|
+  if n > 1:
+    # n > 1 walks a row's entries in storage order like scipy's csr_matvecs: bit-exact
+    np.testing.assert_array_equal(got, a @ b)
+  # vectors ([k]) give vectors ([m])
+  v = torch.from_numpy(b[:, 0].copy()).to(DEV)
+  assert tuple(S.spmm(A, v).shape) == (shape[0],)
+
+
+def test_spmv_integer_valued_is_exact_for_every_group_width(monkeypatch):
+  rng = np.random.RandomState(9)
+  a = _canon(_rand_coo(rng, 3000, 2000, 60000, np.float32, integer=True))
+  A = S.from_scipy(a, DEV)
+  x = rng.randint(-3, 4, size=(2000, 1)).astype(np.float32)
+  ref = a @ x
+  for g in (2, 4, 8, 16, 32, 64):
+    monkeypatch.setenv('SP_SPMV_G', str(g))
+    np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV)).cpu().numpy(), ref)
+  monkeypatch.delenv('SP_SPMV_G')
+  np.testing.assert_array_equal(S.row_sums(A).cpu().numpy(), np.asarray(a.sum(axis=1)).ravel())
+  # accumulate
+  y = torch.ones((3000, 1), dtype=torch.float32, device=DEV)
+  S.spmm(A, torch.from_numpy(x).to(DEV), out=y, accumulate=True)
+  np.testing.assert_array_equal(y.cpu().numpy(), ref + 1)
+
+
+def test_scatter_modes():
+  rng = np.random.RandomState(10)
+  a = _canon(_rand_coo(rng, 40, 50, 300, np.float32, integer=True))
+  A = S.from_scipy(a, DEV)
+  np.testing.assert_array_equal(S.to_dense(A).cpu().numpy(), a.toarray())
+  base = rng.randint(0, 5, size=(64, 80)).astype(np.float32)
+  out = torch.from_numpy(base.copy()).to(DEV)
+  S.scatter(A, out, 7, 11, mode=1)
+  ref = base.copy()
+  ref[7:47, 11:61] += a.toarray()
+  np.testing.assert_array_equal(out.cpu().numpy(), ref)
+  # sparse.pyx:21-38 with REDUCE_ADD: first write where the mask is clear, add where it is set
+  mask = (rng.rand(64, 80) < 0.5)
+  out = torch.from_numpy(base.copy()).to(DEV)
+  mk = torch.from_numpy(mask.astype(np.uint8)).to(DEV)
+  S.scatter(A, out, 7, 11, mode=2, mask=mk)
+  ref, rmask = base.copy(), mask.copy()
+  coo = a.tocoo()
+  for r, c, v in zip(coo.row + 7, coo.col + 11, coo.data):
+    if rmask[r, c]:
+      ref[r, c] += v
+    else:
+      ref[r, c] = v
+      rmask[r, c] = True
+  np.testing.assert_array_equal(out.cpu().numpy(), ref)
+  np.testing.assert_array_equal(mk.cpu().numpy().astype(bool), rmask)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_sparse_times_sparse(dtype):
+  rng = np.random.RandomState(12)
+  a = _canon(_rand_coo(rng, 300, 500, 4000, dtype))
+  b = _canon(_rand_coo(rng, 500, 400, 5000, dtype))
+  ref = _canon(a @ b)
+  got = _same_structure(S.spgemm(S.from_scipy(a, DEV), S.from_scipy(b, DEV)), ref)
+  # products of a cell are added in k-ascending order, the order of scipy's csr_matmat
+  np.testing.assert_allclose(got.data, ref.data, rtol=4 * np.finfo(dtype).eps * 16, atol=1e-6)
+  eye = sps.identity(500, dtype=dtype, format='csr')
+  got = _same_structure(S.spgemm(S.from_scipy(a, DEV), S.from_scipy(eye, DEV)), a)
+  np.testing.assert_array_equal(got.data, a.data)
+
+
+def test_pagerank_sized_tile_properties():
+  """configs-style full size: 900 000 pages x 10 out-links (tests/benchmark_pagerank.py:124-127).  Size-independent
+  checks: W x ones == in-degree histogram (integer-valued: exact), transpose twice == identity, structure sorted."""
+  n, deg = 900000, 10
+  g = torch.Generator(device=DEV)
+  g.manual_seed(1)
+  rows = torch.randint(0, n, (n * deg,), device=DEV, generator=g, dtype=torch.int32)
+  cols = torch.arange(n, device=DEV, dtype=torch.int32).repeat_interleave(deg)
+  vals = torch.ones(n * deg, device=DEV, dtype=torch.float32)
+  W = S.from_coo((n, n), np.float32, rows, cols, vals)
+  assert int(W.indptr[-1]) == W.nnz and W.nnz <= n * deg
+  assert float(W.data.sum()) == n * deg                       # duplicates were added, nothing lost
+  indeg = torch.bincount(rows.long(), minlength=n).float()
+  ones = torch.ones((n, 1), device=DEV, dtype=torch.float32)
+  assert torch.equal(S.spmm(W, ones).reshape(-1), indeg)
+  assert torch.equal(S.row_sums(W), indeg)
+  Wt = S.transpose(W)
+  assert torch.equal(S.spmm(Wt, ones).reshape(-1), torch.full((n,), float(deg), device=DEV))
+  Wtt = S.transpose(Wt)
+  assert torch.equal(Wtt.indptr, W.indptr) and torch.equal(Wtt.indices, W.indices) and torch.equal(Wtt.data, W.data)
+  # column indices ascend strictly inside every row
+  d = W.indices[1:].long() - W.indices[:-1].long()
+  row_start = torch.zeros(W.nnz, dtype=torch.bool, device=DEV)
+  row_start[W.indptr[1:-1][W.indptr[1:-1] < W.nnz]] = True
+  assert bool(torch.all((d > 0) | row_start[1:]))
