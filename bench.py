@@ -180,6 +180,49 @@ def kmeans_section(ctx):
   return out
 
 
+def sparse_section(ctx):
+  """the sparse multiply of tests/benchmark_pagerank.py on one worker's tile -- 900 000 pages,
+  10 out-links per page, 90 % of them inside one of 8 sites -- p <- W . p with W a device CSR tile.
+  HBM-bound: 8 B per stored entry (value + column index) + 16 B per row (indptr, y, x read once)."""
+  from spartan_amd import sparse as S
+  n, deg, sites = 900000, 10, 8
+  g = torch.Generator(device='cuda')
+  g.manual_seed(SEED + 31)
+  cols = torch.arange(n, device='cuda', dtype=torch.int64).repeat_interleave(deg)
+  local = (cols // (n // sites)) * (n // sites) + torch.randint(0, n // sites, (n * deg,), device='cuda', generator=g)
+  far = torch.randint(0, n, (n * deg,), device='cuda', generator=g)
+  rows = torch.where(torch.rand(n * deg, device='cuda', generator=g) <= 0.9, local, far).int()
+  cols = cols.int()
+  vals = torch.ones(n * deg, device='cuda', dtype=torch.float32)
+  out = {'tile': '%dx%d fp32 CSR, %d links per page' % (n, n, deg)}
+  ms = event_time(lambda: S.from_coo((n, n), np.float32, rows, cols, vals), 3, warmup=1)
+  out['coo_to_csr_ms'] = round(ms, 3)
+  W = S.from_coo((n, n), np.float32, rows, cols, vals)
+  del rows, cols, vals, local, far
+  x = torch.rand((n, 1), device='cuda', dtype=torch.float32, generator=g)
+  y = torch.empty((n, 1), device='cuda', dtype=torch.float32)
+  alg = W.nnz * 8 + n * 16
+  ms = event_time(lambda: S.spmm(W, x, out=y), 20, warmup=3)
+  out.update({'nnz': W.nnz, 'spmv_ms': round(ms, 4), 'spmv_GBps': round(alg / ms / 1e6, 1),
+              'spmv_bytes_per_launch': alg})
+  # the driver program: 5 iterations of p = dot(wts, p) through the expression API on the same tile
+  if True:
+    wts = sp.from_tile_fn((n, n), np.float32, lambda ex: W, sparse=True).force()
+    p = sp.from_tile_fn((n, 1), np.float32, lambda ex: x).force()
+    t = []
+    for _ in range(3):
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      q = sp.Val(val=p)
+      for _ in range(5):
+        q = sp.dot(sp.Val(val=wts), q).optimized()
+      q.force()
+      torch.cuda.synchronize()
+      t.append(time.perf_counter() - t0)
+    out['five_iterations_ms'] = round(min(t[1:]) * 1e3, 3)
+  return out
+
+
 def cpu_baseline():
   """The NumPy oracle (a port of the reference's NumPy-worker path) on the host:
   one worker == one core (spartan/worker.py:40), BLAS pinned to one thread."""
@@ -224,12 +267,27 @@ def cpu_baseline():
   t0 = time.perf_counter()
   O.kmeans_fit_map2(cl, cl.from_numpy(pts), cen, kk, 1, reducer=np.add)
   t_km = time.perf_counter() - t0
+  # the sparse multiply of benchmark_pagerank.py on the same tile shape as the `sparse` section (scipy's CSR
+  # matvec, which is what the reference's dot mapper calls for a sparse tile, dot.py:212-216)
+  import scipy.sparse as sps
+  sn, sdeg = 900000, 10
+  srows = rng.randint(0, sn, size=sn * sdeg).astype(np.int32)
+  scols = np.repeat(np.arange(sn, dtype=np.int32), sdeg)
+  Wc = sps.coo_matrix((np.ones(sn * sdeg, np.float32), (srows, scols)), shape=(sn, sn)).tocsr()
+  xv = rng.rand(sn, 1).astype(np.float32)
+  Wc.dot(xv)
+  t0 = time.perf_counter()
+  for _ in range(5):
+    Wc.dot(xv)
+  t_spmv = (time.perf_counter() - t0) / 5
   return {'value': round(2.0 * n ** 3 / dt / 1e12, 4), 'unit': 'TFLOP/s', 'cores': cores, 'kind': 'port',
           'sample': 'oracle (NumPy port) spartan.dot %dx%dx%d fp32, 1 worker, %d BLAS thread(s), best of 2 '
                     '(%.2f s each); map x*x+x %.1f GB/s, sum axis0 %.1f GB/s on 4096x16384 fp32; '
-                    'k-means iteration (map2 variant) on %dx%d points, k=%d: %.2f s = %.4f TFLOP/s of 2nkd'
+                    'k-means iteration (map2 variant) on %dx%d points, k=%d: %.2f s = %.4f TFLOP/s of 2nkd; '
+                    'sparse multiply %dx%d, %d links per page (scipy CSR matvec): %.2f ms = %.2f GB/s'
                     % (n, n, n, cores, dt, 8.0 * x.size / t_map / 1e9, 4.0 * x.size / t_sum / 1e9,
-                       kn, kd, kk, t_km, 2.0 * kn * kk * kd / t_km / 1e12)}
+                       kn, kd, kk, t_km, 2.0 * kn * kk * kd / t_km / 1e12,
+                       sn, sn, sdeg, t_spmv * 1e3, (Wc.nnz * 8 + sn * 16) / t_spmv / 1e9)}
 
 
 def main():
@@ -316,6 +374,8 @@ def main():
       line['hbm'] = hbm_section(ctx)
       torch.cuda.empty_cache()
       line['kmeans'] = kmeans_section(ctx)
+      torch.cuda.empty_cache()
+      line['sparse'] = sparse_section(ctx)
       line['cpu_baseline'] = cpu_baseline()
   if world.distributed:
     line['comm'] = dict(world.stats)

@@ -370,11 +370,20 @@ int sp_coo_box(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t r0, int64_
 /* sp_csr_spmm: C[m, n] (+)= A[m, k] (CSR) x B[k, n] (dense, row-major, ldb) -- the tile body of
  * dot_map2_mapper / dot_outer_mapper when tile_a is sparse (spartan/expr/dot.py:193-240, scipy's csr .dot)
  * and of dot_coo_dense_unordered_map (sparse.pyx:103-158, n == 1; the result is written dense).
- * d_b == NULL with n == 1 multiplies by a vector of ones (row sums).  n == 1: 2..64 lanes per row by mean row
- * length, shuffle reduction; n > 1: entries of a row in storage order (scipy's csr_matvecs order). */
+ * d_b == NULL with n == 1 multiplies by a vector of ones (row sums).  n == 1, short rows: workgroups own
+ * 2048 consecutive stored entries (coalesced loads, products in LDS, one thread per row, carries of rows that
+ * span chunks added by a fix-up pass in chunk order -- no floating-point atomics; needs the workspace);
+ * n == 1, long rows: 2..64 lanes per row, shuffle reduction; n > 1: entries of a row in storage order
+ * (scipy's csr_matvecs order).  Without a workspace the lanes-per-row kernel is used for every n == 1.
+ * d_plan (may be NULL): the output of sp_csr_spmv_plan for this matrix -- the first row that starts in each
+ * 2048-entry chunk, sp_csr_spmv_plan_entries(nnz) int64 values -- computed once per matrix and reused by every
+ * multiply (an iteration like p <- W.p keeps W); without it every workgroup searches indptr itself. */
+size_t sp_csr_spmm_workspace_bytes(int64_t nnz, int64_t n);
+int64_t sp_csr_spmv_plan_entries(int64_t nnz);
+int sp_csr_spmv_plan(int64_t m, int64_t nnz, const int64_t* d_indptr, int64_t* d_plan, void* stream);
 int sp_csr_spmm(int32_t dtype, int64_t m, int64_t k, int64_t n, int64_t nnz, const int64_t* d_indptr,
                 const int32_t* d_indices, const void* d_vals, const void* d_b, int64_t ldb, void* d_c, int64_t ldc,
-                int32_t accumulate, void* stream);
+                int32_t accumulate, const int64_t* d_plan, void* d_ws, size_t ws_bytes, void* stream);
 /* sp_csr_scatter: write a CSR tile into the box of a dense tile whose upper-left corner is (row0, col0).
  * mode 0: assign, 1: add, 2: sparse_to_dense_update with REDUCE_ADD (sparse.pyx:21-38; tile.pyx:229-233):
  * where mask == 0 assign and set the mask, else add. */

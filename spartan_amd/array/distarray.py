@@ -261,6 +261,9 @@ class UpdateBatch(object):
     self.items = []
     for items in by_array.values():
       array = items[0][0]
+      if array.sparse:
+        self._flush_sparse(array, items)
+        continue
       plan = self._collective_plan(array, items)
       if plan is not None:
         mine = [it for it in items if ctx.is_local_worker(it[1])][0]
@@ -280,9 +283,6 @@ class UpdateBatch(object):
           out = be.empty(t.shape, t.dtype)
           world.reduce_scatter(out, be.contiguous(data), red)
           t.update(be, None, out, array.reducer_fn, owned=True)
-        continue
-      if array.sparse:
-        self._flush_sparse(array, items)
         continue
       # generic path: explicit transfers, merged in issue order
       array._touched = True

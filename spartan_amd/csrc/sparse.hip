@@ -204,6 +204,120 @@ __global__ __launch_bounds__(256) void sp_csr_spmv_kernel(const int64_t* __restr
   }
 }
 
+// N == 1, short rows: "stream" formulation.  A workgroup owns SPMV_CH consecutive STORED ENTRIES (not rows):
+// it loads their (column, value) pairs fully coalesced -- 8 independent loads per thread in flight, no
+// indptr -> entries -> x dependency chain per row -- gathers x, leaves the products in LDS, and then one
+// thread per row adds the row's products in storage order.  Rows are assigned by where they START
+// (indptr[r] in [e0, e1)), so empty rows are written too; the head of the chunk that belongs to a row
+// started earlier goes to carry[b] and a fix-up pass adds the carries of a row in chunk order
+// (deterministic, no floating-point atomics).  Chunks are dealt to the 8 XCDs in contiguous ranges so a
+// site-local link structure keeps its slice of x in that XCD's L2.
+constexpr int SPMV_CH = 2048;
+
+__device__ __forceinline__ int64_t sp_lower_bound(const int64_t* __restrict__ a, int64_t n, int64_t v) {
+  int64_t lo = 0, hi = n;   // first i in [0, n) with a[i] >= v, else n
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sp_csr_spmv_stream_kernel(const int64_t* __restrict__ indptr,
+                                                                 const int32_t* __restrict__ indices,
+                                                                 const T* __restrict__ vals,
+                                                                 const T* __restrict__ x, int64_t ldx,
+                                                                 T* __restrict__ y, int64_t ldy, int64_t m,
+                                                                 int64_t nnz, int nchunk, int accumulate,
+                                                                 T* __restrict__ carry,
+                                                                 int64_t* __restrict__ carry_row,
+                                                                 const int64_t* __restrict__ plan) {
+  __shared__ T prod[SPMV_CH];
+  __shared__ int64_t rng[2];
+  const int per = (nchunk + 7) >> 3;
+  const int c = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);   // XCD k walks chunks [k*per, (k+1)*per)
+  if (c >= nchunk) return;
+  const int64_t e0 = (int64_t)c * SPMV_CH;
+  const int64_t e1 = e0 + SPMV_CH < nnz ? e0 + SPMV_CH : nnz;
+  const int tid = threadIdx.x;
+  // Without a plan (sp_csr_spmv_plan: first row starting in each chunk, computed once per matrix) two lanes
+  // search the row range here: ~20 dependent loads on the critical path of every workgroup.
+  // (A workgroup-wide 256-ary search was slower still: 256 cache lines per step.)
+  if (plan) {
+    if (tid == 0) rng[0] = plan[c];
+    if (tid == 64) rng[1] = plan[c + 1];
+  } else {
+    if (tid == 0) rng[0] = sp_lower_bound(indptr, m, e0);
+    if (tid == 64) rng[1] = (c == nchunk - 1) ? m : sp_lower_bound(indptr, m, e1);
+  }
+#pragma unroll
+  for (int u = 0; u < SPMV_CH / 256; ++u) {
+    const int64_t e = e0 + u * 256 + tid;
+    T p = 0;
+    if (e < e1) {
+      const T v = vals[e];
+      p = x ? v * x[(int64_t)indices[e] * ldx] : v;
+    }
+    prod[u * 256 + tid] = p;
+  }
+  __syncthreads();
+  const int64_t r_lo = rng[0], r_hi = rng[1];
+  // head of the chunk: tail of a row that started in an earlier chunk
+  int64_t c_end = r_lo < m ? indptr[r_lo] : nnz;
+  if (c_end > e1) c_end = e1;
+  if (tid < 64) {
+    const int len = (int)(c_end - e0);
+    if (len > 0) {
+      // one wavefront, lane-strided partial sums then a fixed shuffle tree
+      T s = 0;
+      for (int i = tid; i < len; i += 64) s += prod[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (tid == 0) {
+        carry[c] = s;
+        carry_row[c] = r_lo - 1;
+      }
+    } else if (tid == 0) {
+      carry_row[c] = -1;
+    }
+  }
+  for (int64_t r = r_lo + tid; r < r_hi; r += 256) {
+    const int64_t a = indptr[r] - e0;
+    int64_t b = indptr[r + 1];
+    b = (b < e1 ? b : e1) - e0;
+    T s = 0;
+    for (int64_t i = a; i < b; ++i) s += prod[i];
+    y[r * ldy] = accumulate ? y[r * ldy] + s : s;
+  }
+}
+
+// plan[c] = first row starting at or after entry c * SPMV_CH (c < nchunk), plan[nchunk] = m
+__global__ __launch_bounds__(256) void sp_csr_spmv_plan_kernel(const int64_t* __restrict__ indptr, int64_t m,
+                                                               int nchunk, int64_t* __restrict__ plan) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c > nchunk) return;
+  plan[c] = c == nchunk ? m : sp_lower_bound(indptr, m, (int64_t)c * SPMV_CH);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sp_csr_spmv_fixup_kernel(const int64_t* __restrict__ indptr, T* __restrict__ y,
+                                                                int64_t ldy, int nchunk,
+                                                                const T* __restrict__ carry,
+                                                                const int64_t* __restrict__ carry_row) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunk) return;
+  const int64_t row = carry_row[c];
+  if (row < 0) return;
+  // only the FIRST chunk carrying into `row` adds (in chunk order) every carry of that row
+  if (c > 0 && carry_row[c - 1] == row) return;
+  const int64_t row_end = indptr[row + 1];
+  T s = y[row * ldy];
+  for (int cc = c; cc < nchunk && (int64_t)cc * SPMV_CH < row_end && carry_row[cc] == row; ++cc) s += carry[cc];
+  y[row * ldy] = s;
+}
+
 // N > 1: NL lanes along the columns of C (V columns each), 64 / NL rows per wavefront; a row's entries are
 // walked in storage order, y += a * B[k, :] (the order of scipy's csr_matvecs).
 template <typename T, int V>
@@ -445,9 +559,34 @@ extern "C" int sp_coo_box(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t
 
 namespace {
 
+inline int spmv_chunks(int64_t nnz) { return (int)((nnz + SPMV_CH - 1) / SPMV_CH); }
+
 template <typename T>
 int spmm_go(int64_t m, int64_t n, int64_t nnz, const int64_t* indptr, const int32_t* indices, const T* vals, const T* B,
-            int64_t ldb, T* C, int64_t ldc, int accumulate, hipStream_t st) {
+            int64_t ldb, T* C, int64_t ldc, int accumulate, const int64_t* plan, void* ws, size_t ws_bytes,
+            hipStream_t st) {
+  if ((n == 1 || !B) && nnz > 0) {
+    // short rows: entry-split stream kernel; long rows: lanes-per-row kernel below
+    const double mean_len = m > 0 ? (double)nnz / (double)m : 0.0;
+    const char* ea = getenv("SP_SPMV_ALGO");      // "stream" | "vector": tuning / test knob
+    bool stream = mean_len < 24.0;
+    if (ea && ea[0] == 's') stream = true;
+    if (ea && ea[0] == 'v') stream = false;
+    const int nchunk = spmv_chunks(nnz);
+    const size_t need = al256((size_t)nchunk * sizeof(T)) + al256((size_t)nchunk * 8);
+    if (stream && ws && ws_bytes >= need) {
+      T* carry = (T*)ws;
+      int64_t* carry_row = (int64_t*)((char*)ws + al256((size_t)nchunk * sizeof(T)));
+      const int per = (nchunk + 7) / 8;
+      hipLaunchKernelGGL((sp_csr_spmv_stream_kernel<T>), dim3(per * 8), dim3(256), 0, st, indptr, indices, vals, B, ldb,
+                         C, ldc, m, nnz, nchunk, accumulate, carry, carry_row, plan);
+      SP_CHECK_LAUNCH();
+      hipLaunchKernelGGL((sp_csr_spmv_fixup_kernel<T>), dim3((nchunk + 255) / 256), dim3(256), 0, st, indptr, C, ldc,
+                         nchunk, carry, carry_row);
+      SP_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (n == 1 || !B) {
     // lanes per row: the power of two nearest above the mean row length, 2 .. 64
     const double mean = m > 0 ? (double)nnz / (double)m : 0.0;
@@ -490,9 +629,28 @@ int spmm_go(int64_t m, int64_t n, int64_t nnz, const int64_t* indptr, const int3
 
 }  // namespace
 
+extern "C" size_t sp_csr_spmm_workspace_bytes(int64_t nnz, int64_t n) {
+  if (n != 1 || nnz < 1) return 256;
+  const size_t nchunk = (size_t)spmv_chunks(nnz);
+  return al256(nchunk * 8) + al256(nchunk * 8) + 256;
+}
+
+extern "C" int64_t sp_csr_spmv_plan_entries(int64_t nnz) { return nnz < 1 ? 1 : (int64_t)spmv_chunks(nnz) + 1; }
+
+extern "C" int sp_csr_spmv_plan(int64_t m, int64_t nnz, const int64_t* d_indptr, int64_t* d_plan, void* stream) {
+  if (m < 0 || nnz < 0) SP_FAIL("sp_csr_spmv_plan: bad sizes");
+  if (!d_indptr || !d_plan) SP_FAIL("sp_csr_spmv_plan: NULL pointer");
+  const int nchunk = nnz < 1 ? 0 : spmv_chunks(nnz);
+  hipLaunchKernelGGL(sp_csr_spmv_plan_kernel, dim3((nchunk + 256) / 256), dim3(256), 0, (hipStream_t)stream, d_indptr,
+                     m, nchunk, d_plan);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int sp_csr_spmm(int32_t dtype, int64_t m, int64_t k, int64_t n, int64_t nnz, const int64_t* d_indptr,
                            const int32_t* d_indices, const void* d_vals, const void* d_b, int64_t ldb, void* d_c,
-                           int64_t ldc, int32_t accumulate, void* stream) {
+                           int64_t ldc, int32_t accumulate, const int64_t* d_plan, void* d_ws, size_t ws_bytes,
+                           void* stream) {
   if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_csr_spmm: values must be f32 or f64");
   if (m < 0 || k < 0 || n < 0 || nnz < 0) SP_FAIL("sp_csr_spmm: bad sizes");
   if (m == 0 || n == 0) return 0;
@@ -502,9 +660,9 @@ extern "C" int sp_csr_spmm(int32_t dtype, int64_t m, int64_t k, int64_t n, int64
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SP_F32)
     return spmm_go<float>(m, n, nnz, d_indptr, d_indices, (const float*)d_vals, (const float*)d_b, ldb, (float*)d_c, ldc,
-                          accumulate, st);
+                          accumulate, d_plan, d_ws, ws_bytes, st);
   return spmm_go<double>(m, n, nnz, d_indptr, d_indices, (const double*)d_vals, (const double*)d_b, ldb, (double*)d_c,
-                         ldc, accumulate, st);
+                         ldc, accumulate, d_plan, d_ws, ws_bytes, st);
 }
 
 extern "C" int sp_csr_scatter(int32_t dtype, int64_t m, int64_t nnz, const int64_t* d_indptr, const int32_t* d_indices,

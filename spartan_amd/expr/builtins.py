@@ -190,16 +190,18 @@ def from_numpy(npa, tile_hint=None):
   return base.Val(val=arr)
 
 
-def from_tile_fn(shape, dtype, fn, tile_hint=None):
+def from_tile_fn(shape, dtype, fn, tile_hint=None, sparse=False):
   """Build a DistArray whose tiles are produced IN PLACE on their owning worker:
-  fn(extent) -> backend tensor of extent.shape (e.g. device-side RNG).  The
-  loader analogue of from_numpy for data that never exists on the host."""
+  fn(extent) -> backend tensor (or, with sparse=True, sparse blob) of extent.shape (e.g. device-side
+  RNG).  The loader analogue of from_numpy for data that never exists on the host."""
   ctx = context.get()
-  arr = distarray.create(shape, dtype, tile_hint=tile_hint)
+  arr = distarray.create(shape, dtype, tile_hint=tile_hint, sparse=sparse)
   for ex, tid in arr.tiles.items():
     if ctx.is_local(tid):
       data = fn(ex)
-      ctx.tile(tid).update(ctx.backend, None, data.reshape(ex.shape), None, owned=True)
+      if not sparse:
+        data = data.reshape(ex.shape)
+      ctx.tile(tid).update(ctx.backend, None, data, None, owned=True)
   arr._touched = True
   return base.Val(val=arr)
 

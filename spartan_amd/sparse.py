@@ -44,7 +44,7 @@ def _p(t):
 
 class CsrTile(object):
   """Device blob of a sparse tile."""
-  __slots__ = ('shape', 'dtype', 'indptr', 'indices', 'data')
+  __slots__ = ('shape', 'dtype', 'indptr', 'indices', 'data', '_plan')
   is_sparse_tile = True
 
   def __init__(self, shape, dtype, indptr, indices, data):
@@ -53,6 +53,7 @@ class CsrTile(object):
     self.indptr = indptr
     self.indices = indices
     self.data = data
+    self._plan = None      # sp_csr_spmv_plan output, made on the first matrix x vector product and kept
 
   @property
   def nnz(self):
@@ -68,6 +69,17 @@ class CsrTile(object):
 
   def __repr__(self):
     return 'CsrTile(%s, %s, nnz=%d)' % (self.shape, self.dtype, self.nnz)
+
+
+def spmv_plan(t):
+  """First row starting in each 2048-entry chunk (csrc/sparse.hip): an analysis of the STRUCTURE, computed once
+  per tile -- tiles are immutable -- and reused by every product with a vector."""
+  if t._plan is None:
+    lib = _hip.lib()
+    plan = torch.empty(int(lib.sp_csr_spmv_plan_entries(t.nnz)), dtype=torch.int64, device=t.device)
+    check(lib.sp_csr_spmv_plan(t.shape[0], t.nnz, _p(t.indptr), _p(plan), _stream()))
+    t._plan = plan
+  return t._plan
 
 
 def _check_dtype(dtype):
@@ -208,7 +220,7 @@ def update_box(old, r0, r1, c0, c1, upd, add_to_old):
                   torch.cat([old.data, _cast(upd.data, dtype)]))
 
 
-def spmm(a, b, out=None, accumulate=False):
+def spmm(a, b, out=None, accumulate=False, plan=True):
   """a (CsrTile [m, k]) x b (dense [k] / [k, n]) -> dense [m] / [m, n]."""
   vec = b.dim() == 1
   b2 = b.reshape(-1, 1) if vec else b
@@ -224,18 +236,23 @@ def spmm(a, b, out=None, accumulate=False):
   if out is None:
     out = torch.empty((m, n), dtype=td, device=a.device)
   if m and n:
-    check(_hip.lib().sp_csr_spmm(_hip.sp_dtype(dtype), m, a.shape[1], n, a.nnz, _p(a.indptr), _p(a.indices), _p(av),
-                                 C.c_void_p(b2.data_ptr()), _ld(b2) if b2.shape[0] > 1 else max(n, 1),
-                                 C.c_void_p(out.data_ptr()), n, 1 if accumulate else 0, _stream()))
+    lib = _hip.lib()
+    ws = _ws.get(lib.sp_csr_spmm_workspace_bytes(a.nnz, n), a.device)
+    check(lib.sp_csr_spmm(_hip.sp_dtype(dtype), m, a.shape[1], n, a.nnz, _p(a.indptr), _p(a.indices), _p(av),
+                          C.c_void_p(b2.data_ptr()), _ld(b2) if b2.shape[0] > 1 else max(n, 1),
+                          C.c_void_p(out.data_ptr()), n, 1 if accumulate else 0,
+                          _p(spmv_plan(a)) if plan and n == 1 and a.nnz else C.c_void_p(0), _p(ws), ws.numel(), _stream()))
   return out.reshape(m) if vec else out
 
 
 def row_sums(t):
   out = torch.empty((t.shape[0], 1), dtype=t.data.dtype, device=t.device)
   if t.shape[0]:
-    check(_hip.lib().sp_csr_spmm(_hip.sp_dtype(t.dtype), t.shape[0], t.shape[1], 1, t.nnz, _p(t.indptr),
-                                 _p(t.indices), _p(t.data), C.c_void_p(0), 1, C.c_void_p(out.data_ptr()), 1, 0,
-                                 _stream()))
+    lib = _hip.lib()
+    ws = _ws.get(lib.sp_csr_spmm_workspace_bytes(t.nnz, 1), t.device)
+    check(lib.sp_csr_spmm(_hip.sp_dtype(t.dtype), t.shape[0], t.shape[1], 1, t.nnz, _p(t.indptr), _p(t.indices),
+                          _p(t.data), C.c_void_p(0), 1, C.c_void_p(out.data_ptr()), 1, 0,
+                          _p(spmv_plan(t)) if t.nnz else C.c_void_p(0), _p(ws), ws.numel(), _stream()))
   return out.reshape(-1)
 
 

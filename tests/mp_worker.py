@@ -36,6 +36,29 @@ def run_examples(total_workers):
   return count + 1
 
 
+def run_sparse(total_workers):
+  """Sparse arrays across two ranks: tiles are built and used by the rank that owns them (device path);
+  blocks that cross ranks (glom, sparse x sparse joins, row-tiled shuffles) travel as host objects."""
+  import json
+  from tests import sparse_programs as SP
+  here = os.path.join(ROOT, 'tests', 'golden')
+  meta = json.load(open(os.path.join(here, 'sparse_meta.json')))
+  gold1 = np.load(os.path.join(here, 'sparse_w1.npz'))
+  count = 0
+  for name, build, tol in SP.programs():
+    res = build(sp)
+    res = res.force() if hasattr(res, 'force') else res
+    got, was_sparse = SP.to_dense(res.glom())
+    want, m = gold1[name], meta['1'][name]           # the programs' values do not depend on the tiling
+    assert was_sparse == m['sparse'] and got.dtype.str == m['dtype'], (name, was_sparse, got.dtype)
+    if tol is None:
+      np.testing.assert_array_equal(got, want, err_msg=name)
+    else:
+      np.testing.assert_allclose(got, want, rtol=tol[0], atol=tol[1], err_msg=name)
+    count += 1
+  return count
+
+
 def main():
   workers = int(sys.argv[1])
   use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
@@ -83,6 +106,7 @@ def main():
   # the example drivers across ranks: identical to the single-process goldens of the reference
   # (tile->worker round robin puts tiles on both ranks; every rank must see the same result)
   n += run_examples(workers)
+  n += run_sparse(workers)
   world.barrier()
   print('RANK %d OK %d' % (world.rank, n))
   sys.stdout.flush()

@@ -137,15 +137,51 @@ def test_spmv_integer_valued_is_exact_for_every_group_width(monkeypatch):
   A = S.from_scipy(a, DEV)
   x = rng.randint(-3, 4, size=(2000, 1)).astype(np.float32)
   ref = a @ x
+  monkeypatch.setenv('SP_SPMV_ALGO', 'vector')
   for g in (2, 4, 8, 16, 32, 64):
     monkeypatch.setenv('SP_SPMV_G', str(g))
     np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV)).cpu().numpy(), ref)
   monkeypatch.delenv('SP_SPMV_G')
+  monkeypatch.delenv('SP_SPMV_ALGO')
   np.testing.assert_array_equal(S.row_sums(A).cpu().numpy(), np.asarray(a.sum(axis=1)).ravel())
   # accumulate
   y = torch.ones((3000, 1), dtype=torch.float32, device=DEV)
   S.spmm(A, torch.from_numpy(x).to(DEV), out=y, accumulate=True)
   np.testing.assert_array_equal(y.cpu().numpy(), ref + 1)
+
+
+@pytest.mark.parametrize('algo', ['stream', 'vector'])
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_spmv_rows_spanning_entry_chunks(monkeypatch, algo, seed):
+  """The stream kernel splits the STORED ENTRIES in chunks of 2048: rows that span several chunks, rows that end
+  exactly on a chunk boundary, empty rows at the start / end / on a boundary.  Integer values: exact."""
+  monkeypatch.setenv('SP_SPMV_ALGO', algo)
+  rng = np.random.RandomState(seed)
+  ncols = 9000
+  pool = [0, 0, 0, 1, 2, 3, 7, 40, 300, 2048, 2047, 2049, 5000, 4096, 8999]
+  lens = [0, 0] + [pool[i] for i in rng.randint(0, len(pool), size=40)] + [0, 0, 0]
+  if seed == 0:
+    lens = [2048, 0, 0, 2048, 4096, 0, 1, 2047, 0]      # boundaries hit exactly
+  rows, cols = [], []
+  for r, n in enumerate(lens):
+    rows.append(np.full(n, r, np.int32))
+    cols.append(np.sort(rng.choice(ncols, size=n, replace=False)).astype(np.int32))
+  rows, cols = np.concatenate(rows), np.concatenate(cols)
+  vals = rng.randint(-3, 4, size=rows.size).astype(np.float32)
+  a = sps.csr_matrix((vals, (rows, cols)), shape=(len(lens), ncols))
+  A = S.from_scipy(a, DEV)
+  x = rng.randint(-2, 3, size=(ncols, 1)).astype(np.float32)
+  np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV)).cpu().numpy(), a @ x)
+  # without the per-matrix plan every workgroup searches its own row range
+  np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV), plan=False).cpu().numpy(), a @ x)
+  np.testing.assert_array_equal(S.row_sums(A).cpu().numpy(), np.asarray(a.sum(axis=1)).ravel())
+  y = torch.full((len(lens), 1), 2.0, dtype=torch.float32, device=DEV)
+  S.spmm(A, torch.from_numpy(x).to(DEV), out=y, accumulate=True)
+  np.testing.assert_array_equal(y.cpu().numpy(), a @ x + 2)
+  # float64 too
+  a64 = a.astype(np.float64)
+  np.testing.assert_array_equal(S.spmm(S.from_scipy(a64, DEV), torch.from_numpy(x.astype(np.float64)).to(DEV)).cpu().numpy(),
+                                a64 @ x.astype(np.float64))
 
 
 def test_scatter_modes():
