@@ -249,6 +249,12 @@ class NumpyBackend(object):
     self.launches += 1
     return self._wrap({'SUM': np.sum, 'PROD': np.prod}[red_op](_np(t), axis=axis))
 
+  def sort_axis(self, t, axis, indices=False):
+    """np.sort / np.argsort of a tile (sort.py:68-69, :137-138), kind='stable' (the documented tie order)."""
+    self.launches += 1
+    x = _np(t)
+    return self._wrap(np.argsort(x, axis, kind='stable') if indices else np.sort(x, axis, kind='stable'))
+
   def cumscan(self, t, axis, product=False):
     """scan.py:63."""
     self.launches += 1

@@ -119,11 +119,18 @@ class HipBackend(object):
     if view.dtype != src.dtype:
       raise _hip.HipError('paste: dtype mismatch %s vs %s' % (view.dtype, src.dtype))
     nd = view.dim()
+    base = view.storage_offset() - dst.storage_offset()
     if nd > _hip.SP_MAX_DIMS:
-      raise _hip.HipError('paste: more than %d dimensions' % _hip.SP_MAX_DIMS)
+      # the copy kernel walks SP_MAX_DIMS dimensions: one launch per index of the leading ones
+      lead = nd - _hip.SP_MAX_DIMS
+      for index in np.ndindex(*view.shape[:lead]):
+        self.launches += 1
+        kernels.slice_copy(dst, base + sum(i * st for i, st in zip(index, view.stride()[:lead])), view.stride()[lead:],
+                           src, sum(i * st for i, st in zip(index, src.stride()[:lead])), src.stride()[lead:],
+                           view.shape[lead:])
+      return
     self.launches += 1
-    kernels.slice_copy(dst, view.storage_offset() - dst.storage_offset(), view.stride(),
-                       src, 0, src.stride(), view.shape)
+    kernels.slice_copy(dst, base, view.stride(), src, 0, src.stride(), view.shape)
 
   # -- combine --------------------------------------------------------------------
   def update_box(self, dst, ul, lr, src, reducer, mask_mode, mask):
@@ -502,6 +509,26 @@ class HipBackend(object):
     t = self.contiguous(t)
     v = lower.V('tensor', dtype=self.dtype_of(t), shape=tuple(t.shape), tensor=t)
     return self._run_reduce(v, red_op, self.dtype_of(t), tuple(t.shape), axis)
+
+  def sort_axis(self, t, axis, indices=False):
+    """np.sort(t, axis) / np.argsort(t, axis, kind='stable') of a tile (sort.py:68-69, :137-138): the axis is
+    brought last by a strided copy, sp_sort_rows sorts every line, and the result is copied back."""
+    t = self.contiguous(self._as_device(t))
+    shape = tuple(t.shape)
+    nd = len(shape)
+    axis = axis if axis >= 0 else axis + nd
+    n = shape[axis]
+    outer = int(np.prod(shape[:axis], dtype=np.int64))
+    inner = int(np.prod(shape[axis + 1:], dtype=np.int64))
+    self.launches += 1
+    if inner == 1:
+      vals, idx = kernels.sort_rows(t.reshape(outer, n), values=not indices, indices=indices)
+      return (idx if indices else vals).reshape(shape)
+    # [outer, n, inner] -> [outer, inner, n] (a 3-d strided copy whatever the rank of the tile), sort, and back
+    lines = self.contiguous(t.reshape(outer, n, inner).movedim(1, 2))
+    vals, idx = kernels.sort_rows(lines.reshape(outer * inner, n), values=not indices, indices=indices)
+    out = (idx if indices else vals).reshape(outer, inner, n)
+    return self.contiguous(out.movedim(2, 1)).reshape(shape)
 
   def cumscan(self, t, axis, product=False):
     """np.cumsum / np.cumprod along `axis` (sp_cumscan)."""

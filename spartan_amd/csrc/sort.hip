@@ -1,0 +1,209 @@
+// sort / argsort along the last axis of a dense tile: the tile bodies of the reference's sort operators
+//   spartan/expr/operator/sort.py   _sort_mapper (:68-69)  np.sort(tile, axis)
+//                                   _argsort_mapper (:137-138) np.argsort(tile, axis)
+//                                   _sample_sort_mapper (:11-25) / _fetch_sort_mapper (:43-65) np.sort(data, axis=None)
+// The sort is STABLE (equal keys keep their order, np.argsort(kind='stable')); NaNs go last like NumPy's,
+// -0.0 and +0.0 compare equal.  Values are gathered from the input by the sorted positions, so the output holds
+// the input's bit patterns.
+//   rows of <= 4096 32-bit elements : bitonic network on (key, column) pairs in LDS, one HBM pass
+//   anything else                   : LSD radix sort of the whole tile -- sizeof(T) passes over the key bytes, then
+//                                     ceil(log2(rows) / 8) passes over the ROW of each element's flat position
+//                                     (sp_radix.hpp), which brings every row together in order without ever
+//                                     sorting rows one at a time.
+#include <stdlib.h>
+
+#include "sp_common.hpp"
+#include "sp_radix.hpp"
+
+namespace {
+
+__device__ __forceinline__ uint32_t key32(float v) {
+  if (v != v) return 0xFFFFFFFFu;
+  uint32_t u = __float_as_uint(v);
+  if (u == 0x80000000u) u = 0;   // -0.0 == +0.0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint32_t key32(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+
+// value back from its key; false when the key does not determine the bit pattern (NaN payloads, the sign of zero)
+__device__ __forceinline__ bool unkey32(uint32_t k, float* v) {
+  if (k == 0xFFFFFFFFu || k == 0x80000000u) return false;
+  *v = __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+  return true;
+}
+__device__ __forceinline__ bool unkey32(uint32_t k, int32_t* v) {
+  *v = (int32_t)(k ^ 0x80000000u);
+  return true;
+}
+
+template <typename T>
+__device__ __forceinline__ uint64_t key64(T v);
+template <>
+__device__ __forceinline__ uint64_t key64<float>(float v) { return key32(v); }
+template <>
+__device__ __forceinline__ uint64_t key64<int32_t>(int32_t v) { return key32(v); }
+template <>
+__device__ __forceinline__ uint64_t key64<double>(double v) {
+  if (v != v) return ~0ull;
+  uint64_t u = (uint64_t)__double_as_longlong(v);
+  if (u == 0x8000000000000000ull) u = 0;
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+template <>
+__device__ __forceinline__ uint64_t key64<int64_t>(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void sp_sort_keys_kernel(const T* __restrict__ in, int64_t n,
+                                                           uint64_t* __restrict__ keys, int32_t* __restrict__ idx) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    keys[i] = key64<T>(in[i]);
+    idx[i] = (int32_t)i;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sp_sort_emit_kernel(const T* __restrict__ in, const int32_t* __restrict__ idx,
+                                                           int64_t n, uint32_t cols, T* __restrict__ out_vals,
+                                                           int64_t* __restrict__ out_idx) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t p = (uint32_t)idx[i];
+    if (out_vals) out_vals[i] = in[p];
+    if (out_idx) out_idx[i] = (int64_t)(p % cols);
+  }
+}
+
+constexpr int LDS_SORT_E = 4096;   // (key, column) pairs per workgroup: 32 KB
+
+// `npad` = cols rounded up to a power of two; a workgroup sorts LDS_SORT_E / npad rows at once.  The compare
+// direction of the bitonic network is taken from the index INSIDE the row, so every row ends ascending.
+template <typename T>
+__global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restrict__ in, int64_t rows, int cols, int npad,
+                                                               int log_npad, T* __restrict__ out_vals,
+                                                               int64_t* __restrict__ out_idx) {
+  __shared__ uint64_t sm[LDS_SORT_E];
+  const int tid = threadIdx.x;
+  const int rpw = LDS_SORT_E >> log_npad;
+  const int64_t nblocks = (rows + rpw - 1) / rpw;
+  for (int64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    for (int e = tid; e < LDS_SORT_E; e += 256) {
+      const int c = e & (npad - 1);
+      const int64_t r = rb * rpw + (e >> log_npad);
+      uint64_t v = ~0ull;
+      if (r < rows && c < cols) v = ((uint64_t)key32(in[r * cols + c]) << 32) | (uint32_t)c;
+      sm[e] = v;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < LDS_SORT_E / 2; t += 256) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int p = i | j;
+          const bool asc = ((i & (npad - 1)) & k) == 0;
+          const uint64_t a = sm[i], b = sm[p];
+          if ((a > b) == asc) {
+            sm[i] = b;
+            sm[p] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int e = tid; e < LDS_SORT_E; e += 256) {
+      const int c = e & (npad - 1);
+      const int64_t r = rb * rpw + (e >> log_npad);
+      if (r < rows && c < cols) {
+        const uint64_t kv = sm[e];
+        const uint32_t src = (uint32_t)(kv & 0xFFFFFFFFull);
+        if (out_vals) {
+          T v;
+          if (!unkey32((uint32_t)(kv >> 32), &v)) v = in[r * cols + src];   // NaN / zero: the input's own bits
+          out_vals[r * cols + c] = v;
+        }
+        if (out_idx) out_idx[r * cols + c] = (int64_t)src;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+inline unsigned sort_grid(int64_t n, int per_block) {
+  int64_t b = (n + per_block - 1) / per_block;
+  const int64_t cap = (int64_t)SP_CUS * SP_BLOCKS_PER_CU * 4;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+inline bool lds_path(int32_t dtype, int64_t cols) {
+  const char* e = getenv("SP_SORT_ALGO");   // "radix" | "lds": test / tuning knob
+  if (e && e[0] == 'r') return false;
+  return (dtype == SP_F32 || dtype == SP_I32) && cols <= LDS_SORT_E;
+}
+
+template <typename T>
+int sort_radix(const T* in, int64_t rows, int64_t cols, T* out_vals, int64_t* out_idx, void* d_ws, hipStream_t st) {
+  const int64_t n = rows * cols;
+  SortWs ws;
+  sp_sort_ws_bytes(n, &ws, (char*)d_ws);
+  hipLaunchKernelGGL((sp_sort_keys_kernel<T>), dim3(sort_grid(n, 256)), dim3(256), 0, st, in, n, ws.keys[0], ws.idx[0]);
+  SP_CHECK_LAUNCH();
+  int cur = 0;
+  for (int shift = 0; shift < (int)sizeof(T) * 8; shift += RDX_BITS) {
+    if (sp_radix_pass(ws, cur, n, DigitOfKey{shift}, st)) return 1;
+    cur = 1 - cur;
+  }
+  int row_bits = 0;
+  while (row_bits < 32 && ((int64_t)1 << row_bits) < rows) ++row_bits;
+  for (int shift = 0; shift < row_bits; shift += RDX_BITS) {
+    if (sp_radix_pass(ws, cur, n, DigitOfRow{shift, (uint32_t)cols}, st)) return 1;
+    cur = 1 - cur;
+  }
+  hipLaunchKernelGGL((sp_sort_emit_kernel<T>), dim3(sort_grid(n, 256)), dim3(256), 0, st, in, ws.idx[cur], n,
+                     (uint32_t)cols, out_vals, out_idx);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+int sort_lds(const T* in, int64_t rows, int64_t cols, T* out_vals, int64_t* out_idx, hipStream_t st) {
+  int npad = 1, lg = 0;
+  while (npad < cols) {
+    npad <<= 1;
+    ++lg;
+  }
+  const int rpw = LDS_SORT_E / npad;
+  hipLaunchKernelGGL((sp_sort_rows_lds_kernel<T>), dim3(sort_grid(rows, rpw)), dim3(256), 0, st, in, rows, (int)cols, npad,
+                     lg, out_vals, out_idx);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t sp_sort_rows_workspace_bytes(int32_t dtype, int64_t rows, int64_t cols) {
+  if (rows < 1 || cols < 1 || lds_path(dtype, cols)) return 256;
+  return sp_sort_ws_bytes(rows * cols, nullptr, nullptr);
+}
+
+extern "C" int sp_sort_rows(const void* d_in, int32_t dtype, int64_t rows, int64_t cols, void* d_out_vals,
+                            int64_t* d_out_idx, void* d_ws, size_t ws_bytes, void* stream) {
+  if (dtype != SP_F32 && dtype != SP_F64 && dtype != SP_I32 && dtype != SP_I64)
+    SP_FAIL("sp_sort_rows: dtype must be f32, f64, i32 or i64");
+  if (rows < 0 || cols < 0) SP_FAIL("sp_sort_rows: bad sizes");
+  if (rows == 0 || cols == 0) return 0;
+  if (!d_in || (!d_out_vals && !d_out_idx)) SP_FAIL("sp_sort_rows: NULL pointer");
+  if (d_out_vals == d_in) SP_FAIL("sp_sort_rows: the sort is out of place");
+  if (rows * cols > 2147483647LL - SCAN_CHUNK) SP_FAIL("sp_sort_rows: more than 2^31 elements in one tile");
+  hipStream_t st = (hipStream_t)stream;
+  if (lds_path(dtype, cols)) {
+    if (dtype == SP_F32) return sort_lds<float>((const float*)d_in, rows, cols, (float*)d_out_vals, d_out_idx, st);
+    return sort_lds<int32_t>((const int32_t*)d_in, rows, cols, (int32_t*)d_out_vals, d_out_idx, st);
+  }
+  if (!d_ws || ws_bytes < sp_sort_rows_workspace_bytes(dtype, rows, cols)) SP_FAIL("sp_sort_rows: workspace too small");
+  switch (dtype) {
+    case SP_F32: return sort_radix<float>((const float*)d_in, rows, cols, (float*)d_out_vals, d_out_idx, d_ws, st);
+    case SP_F64: return sort_radix<double>((const double*)d_in, rows, cols, (double*)d_out_vals, d_out_idx, d_ws, st);
+    case SP_I32: return sort_radix<int32_t>((const int32_t*)d_in, rows, cols, (int32_t*)d_out_vals, d_out_idx, d_ws, st);
+    default: return sort_radix<int64_t>((const int64_t*)d_in, rows, cols, (int64_t*)d_out_vals, d_out_idx, d_ws, st);
+  }
+}

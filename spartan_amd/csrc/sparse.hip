@@ -16,12 +16,10 @@
 
 #include "sp_common.hpp"
 #include "sp_scan.hpp"
+#include "sp_radix.hpp"
 
 namespace {
 
-constexpr int RDX_BITS = 8;
-constexpr int RDX = 1 << RDX_BITS;
-constexpr int SORT_RB = 4096;            // keys per workgroup / wavefront of one radix pass
 constexpr uint64_t KEY_DROPPED = ~0ull;  // entries with row < 0 are dropped: they sort to the end
 
 // ---------------------------------------------------------------- COO -> keys
@@ -33,69 +31,6 @@ __global__ __launch_bounds__(256) void sp_coo_keys_kernel(const int32_t* __restr
     const int32_t r = rows[i];
     keys[i] = r < 0 ? KEY_DROPPED : (uint64_t)r * (uint64_t)ncols + (uint64_t)cols[i];
     idx[i] = (int32_t)i;
-  }
-}
-
-// ---------------------------------------------------------------- one stable radix pass
-// hist[d * nblk + b] = number of keys with digit d in key block b
-__global__ __launch_bounds__(256) void sp_radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
-                                                            int nblk, int* __restrict__ hist) {
-  __shared__ int lh[RDX];
-  const int b = blockIdx.x;
-  lh[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t r0 = (int64_t)b * SORT_RB;
-  const int64_t r1 = r0 + SORT_RB < n ? r0 + SORT_RB : n;
-  for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) atomicAdd(&lh[(int)((keys[i] >> shift) & (RDX - 1))], 1);
-  __syncthreads();
-  hist[(int64_t)threadIdx.x * nblk + b] = lh[threadIdx.x];
-}
-
-// One wavefront per key block walks it in order; the rank of a key among the keys of the same digit in its
-// 64-key chunk is the number of LOWER lanes with that digit (64 readlane steps, no divergence), the last
-// lane of each digit advances the LDS cursor -- the scheme of sp_label_rank_kernel (kmeans.hip).
-__global__ __launch_bounds__(64) void sp_radix_rank_kernel(const uint64_t* __restrict__ keys,
-                                                           const int32_t* __restrict__ idx, int64_t n, int shift,
-                                                           int nblk, const int* __restrict__ offs,
-                                                           uint64_t* __restrict__ keys_out,
-                                                           int32_t* __restrict__ idx_out) {
-  __shared__ int cur[RDX];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x;
-  for (int i = lane; i < RDX; i += 64) cur[i] = offs[(int64_t)i * nblk + b];
-  __syncthreads();
-  const int64_t r0 = (int64_t)b * SORT_RB;
-  const int64_t r1 = r0 + SORT_RB < n ? r0 + SORT_RB : n;
-  for (int64_t base = r0; base < r1; base += 64) {
-    const int64_t i = base + lane;
-    const bool valid = i < r1;
-    uint64_t key = 0;
-    int32_t id = 0;
-    int dg = -1 - lane;  // invalid lanes: a value no other lane holds
-    if (valid) {
-      key = keys[i];
-      id = idx[i];
-      dg = (int)((key >> shift) & (RDX - 1));
-    }
-    int lower = 0, same = 0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const int dj = __builtin_amdgcn_readlane(dg, j);
-      const int eq = (dj == dg) ? 1 : 0;
-      same += eq;
-      lower += (j < lane) ? eq : 0;
-    }
-    int start = 0;
-    if (valid) start = cur[dg];
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    if (valid) {
-      keys_out[start + lower] = key;
-      idx_out[start + lower] = id;
-      if (lower == same - 1) cur[dg] = start + same;
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -441,50 +376,11 @@ inline int key_bits(int64_t nrows, int64_t ncols) {
   return bits;
 }
 
-struct SortWs {
-  uint64_t* keys[2];
-  int32_t* idx[2];
-  int* hist;   // [RDX][nblk]; reused as the head flags / positions [nnz]
-  int* sums;   // scan chunk sums
-  int* total;
-};
-
-inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-inline size_t sort_ws_bytes(int64_t nnz, SortWs* ws, char* base) {
-  const int64_t nblk = (nnz + SORT_RB - 1) / SORT_RB;
-  const int64_t hist_words = (int64_t)RDX * nblk > nnz ? (int64_t)RDX * nblk : nnz;
-  const int64_t sums_words = (hist_words + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    char* p = base ? base + off : nullptr;
-    off += al256(bytes);
-    return p;
-  };
-  char* k0 = take((size_t)nnz * 8);
-  char* k1 = take((size_t)nnz * 8);
-  char* i0 = take((size_t)nnz * 4);
-  char* i1 = take((size_t)nnz * 4);
-  char* h = take((size_t)hist_words * 4);
-  char* s = take((size_t)sums_words * 4);
-  char* t = take(256);
-  if (ws) {
-    ws->keys[0] = (uint64_t*)k0;
-    ws->keys[1] = (uint64_t*)k1;
-    ws->idx[0] = (int32_t*)i0;
-    ws->idx[1] = (int32_t*)i1;
-    ws->hist = (int*)h;
-    ws->sums = (int*)s;
-    ws->total = (int*)t;
-  }
-  return off;
-}
-
 }  // namespace
 
 extern "C" size_t sp_coo_to_csr_workspace_bytes(int64_t nnz) {
   if (nnz < 1) return 256;
-  return sort_ws_bytes(nnz, nullptr, nullptr);
+  return sp_sort_ws_bytes(nnz, nullptr, nullptr);
 }
 
 extern "C" int sp_coo_to_csr(int32_t dtype, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t* d_rows,
@@ -503,20 +399,14 @@ extern "C" int sp_coo_to_csr(int32_t dtype, int64_t nrows, int64_t ncols, int64_
   if (!d_rows || !d_cols || !d_vals || !d_indices || !d_vals_out) SP_FAIL("sp_coo_to_csr: NULL pointer");
   if (!d_ws || ws_bytes < sp_coo_to_csr_workspace_bytes(nnz)) SP_FAIL("sp_coo_to_csr: workspace too small");
   SortWs ws;
-  sort_ws_bytes(nnz, &ws, (char*)d_ws);
-  const int nblk = (int)((nnz + SORT_RB - 1) / SORT_RB);
+  sp_sort_ws_bytes(nnz, &ws, (char*)d_ws);
   hipLaunchKernelGGL(sp_coo_keys_kernel, dim3(grid_for(nnz, 256)), dim3(256), 0, st, d_rows, d_cols, nnz, ncols,
                      ws.keys[0], ws.idx[0]);
   SP_CHECK_LAUNCH();
   const int bits = key_bits(nrows, ncols);
   int cur = 0;
   for (int shift = 0; shift < bits; shift += RDX_BITS) {
-    hipLaunchKernelGGL(sp_radix_hist_kernel, dim3(nblk), dim3(256), 0, st, ws.keys[cur], nnz, shift, nblk, ws.hist);
-    SP_CHECK_LAUNCH();
-    if (sp_exscan_int(ws.hist, (int64_t)RDX * nblk, ws.sums, nullptr, st)) return 1;
-    hipLaunchKernelGGL(sp_radix_rank_kernel, dim3(nblk), dim3(64), 0, st, ws.keys[cur], ws.idx[cur], nnz, shift, nblk,
-                       ws.hist, ws.keys[1 - cur], ws.idx[1 - cur]);
-    SP_CHECK_LAUNCH();
+    if (sp_radix_pass(ws, cur, nnz, DigitOfKey{shift}, st)) return 1;
     cur = 1 - cur;
   }
   int* pos = ws.hist;
@@ -573,10 +463,10 @@ int spmm_go(int64_t m, int64_t n, int64_t nnz, const int64_t* indptr, const int3
     if (ea && ea[0] == 's') stream = true;
     if (ea && ea[0] == 'v') stream = false;
     const int nchunk = spmv_chunks(nnz);
-    const size_t need = al256((size_t)nchunk * sizeof(T)) + al256((size_t)nchunk * 8);
+    const size_t need = sp_al256((size_t)nchunk * sizeof(T)) + sp_al256((size_t)nchunk * 8);
     if (stream && ws && ws_bytes >= need) {
       T* carry = (T*)ws;
-      int64_t* carry_row = (int64_t*)((char*)ws + al256((size_t)nchunk * sizeof(T)));
+      int64_t* carry_row = (int64_t*)((char*)ws + sp_al256((size_t)nchunk * sizeof(T)));
       const int per = (nchunk + 7) / 8;
       hipLaunchKernelGGL((sp_csr_spmv_stream_kernel<T>), dim3(per * 8), dim3(256), 0, st, indptr, indices, vals, B, ldb,
                          C, ldc, m, nnz, nchunk, accumulate, carry, carry_row, plan);
@@ -632,7 +522,7 @@ int spmm_go(int64_t m, int64_t n, int64_t nnz, const int64_t* indptr, const int3
 extern "C" size_t sp_csr_spmm_workspace_bytes(int64_t nnz, int64_t n) {
   if (n != 1 || nnz < 1) return 256;
   const size_t nchunk = (size_t)spmv_chunks(nnz);
-  return al256(nchunk * 8) + al256(nchunk * 8) + 256;
+  return sp_al256(nchunk * 8) + sp_al256(nchunk * 8) + 256;
 }
 
 extern "C" int64_t sp_csr_spmv_plan_entries(int64_t nnz) { return nnz < 1 ? 1 : (int64_t)spmv_chunks(nnz) + 1; }
@@ -685,7 +575,7 @@ extern "C" int sp_csr_scatter(int32_t dtype, int64_t m, int64_t nnz, const int64
 }
 
 extern "C" size_t sp_spgemm_count_workspace_bytes(int64_t nnz_a) {
-  return al256((size_t)((nnz_a + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4) + 256;
+  return sp_al256((size_t)((nnz_a + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 4) + 256;
 }
 
 extern "C" int sp_spgemm_count(int64_t nnz_a, const int32_t* d_indices_a, const int64_t* d_indptr_b, int32_t* d_offs,

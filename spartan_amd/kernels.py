@@ -205,6 +205,24 @@ def cumscan(src, out, axis, product=False):
   return out
 
 
+def sort_rows(src, values=True, indices=False):
+  """Stable sort of every row of a contiguous [rows, cols] tensor along its last axis (sort.py:68-69, :137-138):
+  returns (sorted values or None, int64 argsort or None)."""
+  _require_device(src)
+  assert src.dim() == 2 and src.is_contiguous()
+  rows, cols = src.shape
+  vals = torch.empty_like(src) if values else None
+  idx = torch.empty((rows, cols), dtype=torch.int64, device=src.device) if indices else None
+  if rows and cols:
+    lib = _hip.lib()
+    dt = _hip.sp_dtype(np_dtype_of(src))
+    ws = _ws.get(lib.sp_sort_rows_workspace_bytes(dt, rows, cols), src.device)
+    check(lib.sp_sort_rows(C.c_void_p(src.data_ptr()), dt, rows, cols, C.c_void_p(vals.data_ptr() if values else 0),
+                           C.c_void_p(idx.data_ptr() if indices else 0), C.c_void_p(ws.data_ptr()), ws.numel(),
+                           _stream()))
+  return vals, idx
+
+
 def stream_copy(dst, src):
   _require_device(dst, src)
   n = src.numel() * src.element_size()
