@@ -74,6 +74,35 @@ __global__ __launch_bounds__(256) void sp_sort_emit_kernel(const T* __restrict__
 
 constexpr int LDS_SORT_E = 4096;   // (key, column) pairs per workgroup: 32 KB
 
+// NB consecutive sub-stages (compare distances 2^(lowbit+NB-1) ... 2^lowbit) of bitonic level k on the 2^NB
+// elements base + (m << lowbit), held in registers.
+template <int NB>
+__device__ __forceinline__ void sp_bitonic_round(uint64_t* sm, int tid, int lowbit, int k, int npad) {
+  constexpr int G = 1 << NB;
+  for (int gid = tid; gid < LDS_SORT_E / G; gid += 256) {
+    const int base = ((gid >> lowbit) << (lowbit + NB)) | (gid & ((1 << lowbit) - 1));
+    // every element of the group lies in the same run of length k (k > the largest compare distance): one direction
+    const bool asc = ((base & (npad - 1)) & k) == 0;
+    uint64_t r[G];
+#pragma unroll
+    for (int m = 0; m < G; ++m) r[m] = sm[base + (m << lowbit)];
+#pragma unroll
+    for (int b = NB - 1; b >= 0; --b) {
+#pragma unroll
+      for (int m = 0; m < G; ++m) {
+        if ((m & (1 << b)) == 0) {
+          const uint64_t x = r[m], y = r[m | (1 << b)];
+          const bool sw = (x > y) == asc;
+          r[m] = sw ? y : x;
+          r[m | (1 << b)] = sw ? x : y;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < G; ++m) sm[base + (m << lowbit)] = r[m];
+  }
+}
+
 // `npad` = cols rounded up to a power of two; a workgroup sorts LDS_SORT_E / npad rows at once.  The compare
 // direction of the bitonic network is taken from the index INSIDE the row, so every row ends ascending.
 template <typename T>
@@ -93,33 +122,50 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
       sm[e] = v;
     }
     __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < LDS_SORT_E / 2; t += 256) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int p = i | j;
-          const bool asc = ((i & (npad - 1)) & k) == 0;
-          const uint64_t a = sm[i], b = sm[p];
-          if ((a > b) == asc) {
-            sm[i] = b;
-            sm[p] = a;
-          }
+    // level l merges runs of 2^(l-1) into runs of 2^l: sub-stages j = 2^(l-1) ... 1.  A thread takes 2^NB elements
+    // whose indices differ in NB consecutive bits and runs NB sub-stages on them in registers, so a level costs
+    // ceil(l / 4) trips through LDS instead of l.
+    for (int l = 1; l <= log_npad; ++l) {
+      const int k = 1 << l;
+      int jbit = l - 1;
+      while (jbit >= 0) {
+        const int nb = jbit + 1 < 4 ? jbit + 1 : 4;
+        const int lowbit = jbit - nb + 1;
+        switch (nb) {
+          case 4: sp_bitonic_round<4>(sm, tid, lowbit, k, npad); break;
+          case 3: sp_bitonic_round<3>(sm, tid, lowbit, k, npad); break;
+          case 2: sp_bitonic_round<2>(sm, tid, lowbit, k, npad); break;
+          default: sp_bitonic_round<1>(sm, tid, lowbit, k, npad); break;
         }
         __syncthreads();
+        jbit -= nb;
       }
     }
+    int special = 0;
     for (int e = tid; e < LDS_SORT_E; e += 256) {
       const int c = e & (npad - 1);
       const int64_t r = rb * rpw + (e >> log_npad);
       if (r < rows && c < cols) {
         const uint64_t kv = sm[e];
-        const uint32_t src = (uint32_t)(kv & 0xFFFFFFFFull);
         if (out_vals) {
-          T v;
-          if (!unkey32((uint32_t)(kv >> 32), &v)) v = in[r * cols + src];   // NaN / zero: the input's own bits
+          T v = 0;
+          if (!unkey32((uint32_t)(kv >> 32), &v)) special = 1;
           out_vals[r * cols + c] = v;
         }
-        if (out_idx) out_idx[r * cols + c] = (int64_t)src;
+        if (out_idx) out_idx[r * cols + c] = (int64_t)(kv & 0xFFFFFFFFull);
+      }
+    }
+    // NaNs and zeros: the key does not hold their bits (payload, sign) -- a second, rarely taken pass gathers them
+    // from the input (kept out of the loop above so that the common case does no gather at all)
+    if (__syncthreads_or(special) && out_vals) {
+      for (int e = tid; e < LDS_SORT_E; e += 256) {
+        const int c = e & (npad - 1);
+        const int64_t r = rb * rpw + (e >> log_npad);
+        if (r < rows && c < cols) {
+          const uint64_t kv = sm[e];
+          T v;
+          if (!unkey32((uint32_t)(kv >> 32), &v)) out_vals[r * cols + c] = in[r * cols + (uint32_t)(kv & 0xFFFFFFFFull)];
+        }
       }
     }
     __syncthreads();
