@@ -30,6 +30,19 @@ def empty_like(array, dtype=None, tile_hint=None):
   return ndarray(array.shape, dtype=dtype, tile_hint=tile_hint, sparse=getattr(array, 'sparse', False))
 
 
+def _tocoo(data):
+  """arrays.py:44-45 `data.tocoo()`: a device tile has one format (CSR), so this is the identity on it."""
+  return data.tocoo() if hasattr(data, 'tocoo') else data
+
+
+_tocoo._sp_tile_fn = True
+
+
+def tocoo(array):
+  """arrays.py:48-55."""
+  return map(array, fn=_tocoo)
+
+
 def sparse_empty(shape, dtype=np.float32, tile_hint=None):
   """creation.py:25-32."""
   return ndarray(shape, dtype=dtype, tile_hint=tile_hint, sparse=True)
@@ -178,8 +191,18 @@ def identity(n, dtype=np.float32, tile_hint=None):
 
 
 def from_numpy(npa, tile_hint=None):
-  """write_array.py:424-445 (`from_numpy`): load a host array into tiles."""
+  """write_array.py:424-445 (`from_numpy`): load a host array -- or a scipy.sparse matrix, which becomes a
+  sparse array (:435-441) -- into tiles."""
   ctx = context.get()
+  from ..array import tile as tile_mod
+  if tile_mod.is_sparse_blob(npa):
+    csr = npa.tocsr()
+    arr = distarray.create(csr.shape, csr.dtype, tile_hint=tile_hint, sparse=True)
+    for ex, tid in arr.tiles.items():
+      if ctx.is_local(tid):
+        ctx.tile(tid).update(ctx.backend, None, ctx.backend.sparse_blob(csr[ex.to_slice()], csr.dtype), None)
+    arr._touched = True
+    return base.Val(val=arr)
   npa = np.asarray(npa)
   arr = distarray.create(npa.shape, npa.dtype, tile_hint=tile_hint)
   for ex, tid in arr.tiles.items():

@@ -61,8 +61,65 @@ def _check(tmp):
   np.testing.assert_array_equal(sp.from_file(os.path.join(tmp, 'dense.npy'), sparse=False).glom(), a)
   np.testing.assert_array_equal(sp.from_file(os.path.join(tmp, 'dense.npz'), sparse=False, tile_hint=(12, 10)).glom(), a)
   np.testing.assert_array_equal(sp.from_file(os.path.join(tmp, 'dense.mtx'), file_type='mm').glom(), a.astype(np.float64))
-  with pytest.raises(NotImplementedError):
-    sp.from_file(os.path.join(tmp, 'dense.npy'))          # sparse=True is the reference's default
+  # ---- sparse arrays (tests/test_fio.py:test_fio_sparse / test_fio_partial_sparse in the reference)
+  import scipy.sparse as sps
+  rng = np.random.RandomState(3)
+  m = sps.random(60, 44, density=0.1, format='coo', dtype=np.float32, random_state=rng)
+  S = sp.from_numpy(m, tile_hint=(20, 44)).evaluate()
+  assert S.sparse and sps.issparse(S.glom())
+  np.testing.assert_array_equal(S.glom().toarray(), m.toarray())
+  for z in (False, True):
+    assert sp.save(S, 'sps%d' % z, path=tmp, iszip=z) is True
+    T = sp.load('sps%d' % z, path=tmp, iszip=z).evaluate()
+    assert T.sparse and sorted(T.tiles) == sorted(S.tiles) and T.dtype == np.float32
+    np.testing.assert_array_equal(T.glom().toarray(), m.toarray())
+    assert sp.pickle(S, 'spp%d' % z, path=tmp, iszip=z) is True
+    np.testing.assert_array_equal(sp.unpickle('spp%d' % z, path=tmp, iszip=z).glom().toarray(), m.toarray())
+  # the file layout of a sparse tile (fio.py:98-104): header file + <name>.npz with row / col / data / shape
+  first = sorted(S.tiles)[0]
+  z = np.load(os.path.join(tmp, 'sps0', 'sps0_%s_%s.npz' % (str(first.ul), str(first.lr))))
+  assert sorted(z.files) == ['col', 'data', 'row', 'shape'] and tuple(z['shape']) == first.shape
+  assert open(os.path.join(tmp, 'sps0', 'sps0_dist.spf')).read().split('\n')[3] == 'SPARSE'
+  # partial_load / partial_unpickle: some tiles onto chosen workers
+  some = {ex: 0 for ex in sorted(S.tiles)[:2]}
+  for loader, name in ((sp.partial_load, 'sps0'), (sp.partial_unpickle, 'spp0')):
+    got = loader(some, name, path=tmp)
+    assert sorted(got) == sorted(some)
+    ctx = sp.get_context()
+    for ex, tid in got.items():
+      assert tid.worker == 0
+      blob = ctx.tile(tid).data
+      np.testing.assert_array_equal(ctx.backend.sparse_to_host(blob).toarray(), m.toarray()[ex.to_slice()])
+  dense_some = {ex: 0 for ex in sorted(sp.load('rt_float32_12x10_0', path=tmp).evaluate().tiles)[:2]}
+  for ex, tid in sp.partial_load(dense_some, 'rt_float32_12x10_0', path=tmp).items():
+    np.testing.assert_array_equal(sp.get_context().backend.to_numpy(sp.get_context().tile(tid).data), a[ex.to_slice()])
+  # from_file, sparse: the four .npy files of a COO matrix, and a sparse Matrix Market file
+  base = os.path.join(tmp, 'coo')
+  np.save(base + '_shape.npy', np.array(m.shape))
+  np.save(base + '_row.npy', m.row)
+  np.save(base + '_col.npy', m.col)
+  np.save(base + '_data.npy', m.data)
+  F = sp.from_file(base).evaluate()
+  assert F.sparse
+  np.testing.assert_array_equal(F.glom().toarray(), m.toarray())
+  scipy.io.mmwrite(os.path.join(tmp, 'sparse.mtx'), m.astype(np.float64))
+  G = sp.from_file(os.path.join(tmp, 'sparse.mtx'), file_type='mm').evaluate()
+  assert G.sparse and G.dtype == np.float32                      # narrowed like write_array.py:416-417
+  np.testing.assert_allclose(G.glom().toarray(), m.toarray(), rtol=1e-6)
+  # tocoo / tile_operation / checkpoint
+  np.testing.assert_array_equal(sp.tocoo(sp.Val(val=S)).glom().toarray(), m.toarray())
+  counts = sp.tile_operation(sp.Val(val=S), lambda arr, ex: [(ex, ex.shape[0])]).evaluate()
+  assert sorted(v[0] for v in counts.values()) == [20, 20, 20]
+  ck = sp.checkpoint(sp.from_numpy(a) * 2)
+  np.testing.assert_array_equal(ck.evaluate().glom(), a * 2)
+  assert ck.ready
+  np.testing.assert_array_equal(ck.load_data(None).glom(), a * 2)
+  res = ck.evaluate()
+  lost = sorted(res.tiles)[0]
+  res.bad_tiles.append(lost)
+  res = ck.load_data(res)
+  assert res.bad_tiles == []
+  np.testing.assert_array_equal(res.glom(), a * 2)
 
 
 @pytest.mark.parametrize('workers', [1, 4])
