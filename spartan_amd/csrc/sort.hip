@@ -52,6 +52,25 @@ __device__ __forceinline__ uint64_t key64<double>(double v) {
 template <>
 __device__ __forceinline__ uint64_t key64<int64_t>(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
 
+// the value back from its 64-bit key (false: NaN payload / sign of zero are not in the key)
+template <typename T>
+__device__ __forceinline__ bool unkey64(uint64_t k, T* v);
+template <>
+__device__ __forceinline__ bool unkey64<float>(uint64_t k, float* v) { return unkey32((uint32_t)k, v); }
+template <>
+__device__ __forceinline__ bool unkey64<int32_t>(uint64_t k, int32_t* v) { return unkey32((uint32_t)k, v); }
+template <>
+__device__ __forceinline__ bool unkey64<double>(uint64_t k, double* v) {
+  if (k == ~0ull || k == 0x8000000000000000ull) return false;
+  *v = __longlong_as_double((long long)((k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+  return true;
+}
+template <>
+__device__ __forceinline__ bool unkey64<int64_t>(uint64_t k, int64_t* v) {
+  *v = (int64_t)(k ^ 0x8000000000000000ull);
+  return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sp_sort_keys_kernel(const T* __restrict__ in, int64_t n,
                                                            uint64_t* __restrict__ keys, int32_t* __restrict__ idx) {
@@ -62,12 +81,20 @@ __global__ __launch_bounds__(256) void sp_sort_keys_kernel(const T* __restrict__
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sp_sort_emit_kernel(const T* __restrict__ in, const int32_t* __restrict__ idx,
-                                                           int64_t n, uint32_t cols, T* __restrict__ out_vals,
-                                                           int64_t* __restrict__ out_idx) {
+__global__ __launch_bounds__(256) void sp_sort_emit_kernel(const T* __restrict__ in, const uint64_t* __restrict__ keys,
+                                                           const int32_t* __restrict__ idx, int64_t n, uint32_t cols,
+                                                           T* __restrict__ out_vals, int64_t* __restrict__ out_idx) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint32_t p = (uint32_t)idx[i];
-    if (out_vals) out_vals[i] = in[p];
+    if (out_vals) {
+      // the sorted key gives the value back without a random read of the input, except for NaNs and zeros
+      T v = 0;
+      const bool ok = unkey64<T>(keys[i], &v);
+      if (__ballot(!ok) != 0) {        // wave-uniform: the gather stays off the common path
+        if (!ok) v = in[p];
+      }
+      out_vals[i] = v;
+    }
     if (out_idx) out_idx[i] = (int64_t)(p % cols);
   }
 }
@@ -204,8 +231,8 @@ int sort_radix(const T* in, int64_t rows, int64_t cols, T* out_vals, int64_t* ou
     if (sp_radix_pass(ws, cur, n, DigitOfRow{shift, (uint32_t)cols}, st)) return 1;
     cur = 1 - cur;
   }
-  hipLaunchKernelGGL((sp_sort_emit_kernel<T>), dim3(sort_grid(n, 256)), dim3(256), 0, st, in, ws.idx[cur], n,
-                     (uint32_t)cols, out_vals, out_idx);
+  hipLaunchKernelGGL((sp_sort_emit_kernel<T>), dim3(sort_grid(n, 256)), dim3(256), 0, st, in, ws.keys[cur], ws.idx[cur],
+                     n, (uint32_t)cols, out_vals, out_idx);
   SP_CHECK_LAUNCH();
   return 0;
 }
