@@ -202,6 +202,9 @@ class NumpyBackend(object):
       a = a.tocsr()          # dot.py:212-216
     if sps.issparse(b):
       b = b.tocsr()
+      if not sps.issparse(a):
+        # ndarray.dot(scipy matrix) builds an object array; the product is (B^T A^T)^T
+        return self._wrap(np.ascontiguousarray(np.asarray(b.T.dot(np.asarray(a).T)).T))
     return self._wrap(a.dot(b))
 
   def dot_chunked(self, a, rhs):

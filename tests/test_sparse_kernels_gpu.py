@@ -251,3 +251,36 @@ def test_pagerank_sized_tile_properties():
   row_start = torch.zeros(W.nnz, dtype=torch.bool, device=DEV)
   row_start[W.indptr[1:-1][W.indptr[1:-1] < W.nnz]] = True
   assert bool(torch.all((d > 0) | row_start[1:]))
+
+
+def test_sparse_fuzz_against_scipy():
+  """Random shapes (incl. empty rows / columns, single rows, no entries) through every structural and numeric entry
+  point; integer values, so scipy's results must be reproduced exactly."""
+  import os
+  rng = np.random.RandomState(2024)
+  n_cases = int(os.environ.get('SPARTAN_FUZZ_N', '60'))
+  for case in range(n_cases):
+    dtype = [np.float32, np.float64][rng.randint(2)]
+    m, k, n = [int(rng.choice([1, 2, 7, 33, 200, 1025, 3000])) for _ in range(3)]
+    dens = float(rng.choice([0.0, 0.002, 0.05, 0.4]))
+    a = _canon(_rand_coo(rng, m, k, int(dens * m * k), dtype, dup=bool(rng.randint(2)), integer=True))
+    b = _canon(_rand_coo(rng, k, n, int(float(rng.choice([0.0, 0.01, 0.2])) * k * n), dtype, integer=True))
+    A, B = S.from_scipy(a, DEV), S.from_scipy(b, DEV)
+    tag = 'case %d: %s [%d x %d] nnz %d, [%d x %d] nnz %d' % (case, np.dtype(dtype).name, m, k, a.nnz, k, n, b.nnz)
+    got = _same_structure(S.transpose(A), _canon(a.T))
+    np.testing.assert_array_equal(got.data, _canon(a.T).data, err_msg=tag)
+    r0, r1 = sorted(rng.randint(0, m + 1, size=2))
+    c0, c1 = sorted(rng.randint(0, k + 1, size=2))
+    ref = _canon(a[r0:r1, c0:c1])
+    got = _same_structure(S.slice_box(A, int(r0), int(r1), int(c0), int(c1)), ref)
+    np.testing.assert_array_equal(got.data, ref.data, err_msg=tag)
+    np.testing.assert_array_equal(S.to_scipy(S.add(A, S.transpose(S.transpose(A)), -1)).toarray(), np.zeros((m, k), dtype), err_msg=tag)
+    x = rng.randint(-2, 3, size=(k, 1)).astype(dtype)
+    np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV)).cpu().numpy(), a @ x, err_msg=tag)
+    xm = rng.randint(-2, 3, size=(k, int(rng.choice([2, 5, 70])))).astype(dtype)
+    np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(xm).to(DEV)).cpu().numpy(), a @ xm, err_msg=tag)
+    np.testing.assert_array_equal(S.row_sums(A).cpu().numpy(), np.asarray(a.sum(axis=1)).ravel(), err_msg=tag)
+    np.testing.assert_array_equal(S.to_dense(A).cpu().numpy(), a.toarray(), err_msg=tag)
+    prod = S.to_scipy(S.spgemm(A, B))
+    np.testing.assert_array_equal(prod.toarray(), (a @ b).toarray(), err_msg=tag)
+    assert prod.has_canonical_format

@@ -90,6 +90,28 @@ def test_sparse_dot_numpy_rhs_gpu():
   _numpy_rhs(HipBackend)
 
 
+def _dense_times_sparse(backend_factory):
+  """dense x sparse (rows <= cols: the map2 join; rows > cols: the outer path), against the dense product."""
+  for shape_a, shape_w in (((24, 64), (64, 48)), ((96, 32), (32, 20))):
+    a = (np.arange(shape_a[0] * shape_a[1], dtype=np.float32).reshape(shape_a) % 5) - 2
+    got, was_sparse = _run(backend_factory, 1, 'dense_dot_links',
+                           lambda s: s.dot(s.from_numpy(a), sparse_programs.links(s, shape_w, 6)))
+    w, _ = _run(backend_factory, 1, 'links', lambda s: sparse_programs.links(s, shape_w, 6))
+    np.testing.assert_array_equal(got, a @ w)
+    assert not was_sparse
+
+
+def test_dense_times_sparse_cpu():
+  from oracle.np_backend import NumpyBackend
+  _dense_times_sparse(NumpyBackend)
+
+
+@pytest.mark.gpu
+def test_dense_times_sparse_gpu():
+  from spartan_amd.backend_hip import HipBackend
+  _dense_times_sparse(HipBackend)
+
+
 def _sparse_rand(backend_factory):
   sp.initialize(backend=backend_factory(), num_workers=4)
   try:
