@@ -270,7 +270,33 @@ __global__ __launch_bounds__(256) void sp_csr_spmm_kernel(const int64_t* __restr
       T acc[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[v] = (accumulate && c0 + v < n) ? C[r * ldc + c0 + v] : (T)0;
-      for (int64_t j = a; j < b; ++j) {
+      // U entries at a time: their (column, value) loads and then their U rows of B are all in flight before the
+      // first multiply-add (one entry at a time is a chain of two dependent loads per entry); the additions
+      // keep the storage order
+      constexpr int U = 4;
+      int64_t j = a;
+      for (; j + U <= b; j += U) {
+        T av[U];
+        int32_t kk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          av[u] = vals[j + u];
+          kk[u] = indices[j + u];
+        }
+        T bv[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const T* brow = B + (int64_t)kk[u] * ldb + c0;
+#pragma unroll
+          for (int v = 0; v < V; ++v) bv[u][v] = (c0 + v < n) ? brow[v] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[v] += av[u] * bv[u][v];
+        }
+      }
+      for (; j < b; ++j) {
         const T av = vals[j];
         const T* brow = B + (int64_t)indices[j] * ldb + c0;
 #pragma unroll
