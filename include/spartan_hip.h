@@ -367,6 +367,11 @@ int sp_csr_rows(int64_t nrows, int64_t nnz, const int64_t* d_indptr, int32_t* d_
  * the others. */
 int sp_coo_box(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
                int64_t dr, int64_t dc, int32_t drop_inside, void* stream);
+/* In-place reshape of a COO list (the sparse branch of Reshape.fetch, spartan/expr/operator/reshape.py:181-193):
+ * entry (r, c) of a matrix with old_cols columns sits at linear position r * old_cols + c - offset of the target
+ * [new_rows, new_cols]; entries outside the target get row = -1. */
+int sp_coo_reshape(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t old_cols, int64_t offset, int64_t new_rows,
+                   int64_t new_cols, void* stream);
 /* sp_csr_spmm: C[m, n] (+)= A[m, k] (CSR) x B[k, n] (dense, row-major, ldb) -- the tile body of
  * dot_map2_mapper / dot_outer_mapper when tile_a is sparse (spartan/expr/dot.py:193-240, scipy's csr .dot)
  * and of dot_coo_dense_unordered_map (sparse.pyx:103-158, n == 1; the result is written dense).

@@ -334,6 +334,13 @@ class NumpyBackend(object):
   def sparse_transpose(self, b):
     return b.transpose()
 
+  def sparse_reshape(self, b, offset, shape):
+    """reshape.py:181-193 on the COO triplets (linear position - offset, re-split by the new row length)."""
+    coo = b.tocoo()
+    lin = coo.row.astype(np.int64) * b.shape[1] + coo.col - offset
+    keep = (lin >= 0) & (lin < shape[0] * shape[1])
+    return sps.coo_matrix((coo.data[keep], (lin[keep] // shape[1], lin[keep] % shape[1])), shape=tuple(shape)).tocsr()
+
   def sparse_random(self, shape, density, dtype):
     return sps.rand(shape[0], shape[1], density=density, format='csr', dtype=dtype)
 

@@ -616,6 +616,10 @@ class HipBackend(object):
     self.launches += 1
     return sparse_mod.transpose(b)
 
+  def sparse_reshape(self, b, offset, shape):
+    self.launches += 1
+    return sparse_mod.reshape_rect(b, offset, shape)
+
   def sparse_random(self, shape, density, dtype):
     """scipy.sparse.rand's role (srandom.py:57-65) from the counter-based generator: int(density * size)
     uniformly drawn positions (colliding ones merge, their values add), uniform [0, 1) values."""

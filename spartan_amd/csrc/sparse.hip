@@ -115,6 +115,24 @@ __global__ __launch_bounds__(256) void sp_coo_box_kernel(int32_t* __restrict__ r
   }
 }
 
+// reshape of a COO list: linear position row * old_cols + col, minus `offset`, re-split by new_cols; entries that
+// fall outside [0, new_rows * new_cols) are dropped (the Reshape view fetches a covering rectangle of its base)
+__global__ __launch_bounds__(256) void sp_coo_reshape_kernel(int32_t* __restrict__ rows, int32_t* __restrict__ cols,
+                                                             int64_t n, int64_t old_cols, int64_t offset,
+                                                             int64_t new_rows, int64_t new_cols) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = rows[i];
+    if (r < 0) continue;
+    const int64_t lin = r * old_cols + cols[i] - offset;
+    if (lin < 0 || lin >= new_rows * new_cols) {
+      rows[i] = -1;
+    } else {
+      rows[i] = (int32_t)(lin / new_cols);
+      cols[i] = (int32_t)(lin % new_cols);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- CSR x dense
 // N == 1: G lanes per row, strided over the row's entries, shuffle reduction (fixed order per G).
 template <typename T, int G>
@@ -458,6 +476,19 @@ extern "C" int sp_csr_rows(int64_t nrows, int64_t nnz, const int64_t* d_indptr, 
   if (!d_indptr || !d_rows) SP_FAIL("sp_csr_rows: NULL pointer");
   hipLaunchKernelGGL(sp_csr_rows_kernel, dim3(grid_for(nnz, 256)), dim3(256), 0, (hipStream_t)stream, d_indptr, nrows,
                      nnz, d_rows);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sp_coo_reshape(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t old_cols, int64_t offset,
+                              int64_t new_rows, int64_t new_cols, void* stream) {
+  if (nnz < 0 || old_cols < 0 || new_rows < 0 || new_cols < 0) SP_FAIL("sp_coo_reshape: bad sizes");
+  if (new_rows > 2147483647LL || new_cols > 2147483647LL) SP_FAIL("sp_coo_reshape: a dimension exceeds the int32 index range");
+  if (nnz == 0) return 0;
+  if (!d_rows || !d_cols) SP_FAIL("sp_coo_reshape: NULL pointer");
+  if (new_cols == 0) SP_FAIL("sp_coo_reshape: empty target with entries");
+  hipLaunchKernelGGL(sp_coo_reshape_kernel, dim3(grid_for(nnz, 256)), dim3(256), 0, (hipStream_t)stream, d_rows, d_cols,
+                     nnz, old_cols, offset, new_rows, new_cols);
   SP_CHECK_LAUNCH();
   return 0;
 }

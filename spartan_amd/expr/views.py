@@ -293,6 +293,9 @@ class Reshape(distarray.DistArray):
     t = self.base.fetch(base_ex)
     if isinstance(t, distarray.Absent):
       return distarray.Absent(ex.shape, self.dtype)
+    if tile.is_sparse_blob(t):
+      Assert.eq(len(ex.shape), 2, 'sparse arrays are two-dimensional')
+      return context.get().backend.sparse_reshape(t, ravelled_ul - b_ul, ex.shape)
     flat = context.get().backend.contiguous(t).reshape(-1)
     flat = flat[(ravelled_ul - b_ul):(ravelled_lr - b_ul) + 1]
     assert int(np.prod(flat.shape)) == int(np.prod(ex.shape)), (flat.shape, ex.shape)

@@ -161,6 +161,16 @@ def slice_box(t, r0, r1, c0, c1):
   return from_coo((r1 - r0, c1 - c0), t.dtype, rows, cols, t.data)
 
 
+def reshape_rect(t, offset, shape):
+  """The entries of `t` at linear positions [offset, offset + prod(shape)) as a tile of `shape`
+  (reshape.py:181-193)."""
+  rows, cols = rows_of(t), t.indices.clone()
+  if t.nnz:
+    check(_hip.lib().sp_coo_reshape(t.nnz, _p(rows), _p(cols), t.shape[1], int(offset), int(shape[0]), int(shape[1]),
+                                    _stream()))
+  return from_coo(shape, t.dtype, rows, cols, t.data)
+
+
 def transpose(t):
   return from_coo((t.shape[1], t.shape[0]), t.dtype, t.indices.clone(), rows_of(t), t.data)
 

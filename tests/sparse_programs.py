@@ -74,6 +74,9 @@ def programs():
   # ---- tests/test_transpose.py:test_transpose3
   add(('diag_transpose', lambda sp: sp.transpose(sp.sparse_diagonal((107, 401))), None))
   add(('links_transpose', lambda sp: sp.transpose(links(sp, (60, 50), 3)), None))
+  # ---- tests/test_reshape.py:test_reshape8
+  add(('diag_reshape', lambda sp: sp.reshape(sp.sparse_diagonal((137, 113)), (113, 137)), None))
+  add(('links_reshape', lambda sp: sp.reshape(links(sp, (60, 50), 3), (100, 30)), None))
   return P
 
 
