@@ -223,6 +223,53 @@ def sparse_section(ctx):
   return out
 
 
+def dist_section(ctx):
+  """N > 1: BASELINE configs[2] -- an array of N row tiles of 8192 x 65536 fp32 (2 GiB per GPU), reduced along
+  every axis through the expression API: the per-tile kernels plus the RCCL combine (reduce to the owner for
+  axis=None, reduce-scatter for axis=0, nothing for axis=1 / argmax axis=1 / the fused map).  GB/s = whole-job
+  algorithmic bytes / wall-clock, barrier + synchronize on both sides, max over ranks."""
+  p = ctx.world.size
+  R = int(os.environ.get('SPARTAN_BENCH_DIST_ROWS', '8192'))
+  C = 65536
+  X = sp.from_tile_fn((R * p, C), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 41), tile_hint=(R, C)).force()
+  Xv = sp.Val(val=X)
+  E = float(R) * p * C
+  out = {'array': '%d x %d fp32, %d row tiles of %d x %d' % (R * p, C, p, R, C)}
+  keep = []
+  progs = (('sum_axisNone', lambda: sp.sum(Xv), 4.0), ('sum_axis0', lambda: sp.sum(Xv, 0), 4.0),
+           ('sum_axis1', lambda: sp.sum(Xv, 1), 4.0), ('argmax_axis1', lambda: sp.argmax(Xv, 1), 4.0),
+           ('map_xx_plus_x', lambda: (Xv * Xv + Xv).optimized(), 8.0))
+  for name, build, bpe in progs:
+    def step():
+      keep[:] = [build().force()]
+    dt = time_steps(ctx, step, 5, 2)
+    out[name + '_GBps'] = round(bpe * E * 5 / dt / 1e9, 1)
+    del keep[:]
+  return out
+
+
+def guarded(fn, timeout_s, rank, fallback_line):
+  """Run an informational section; if it does not come back (a collective that never completes), rank 0 prints the
+  line it already has and every rank leaves -- the headline measurement is never lost to an extra."""
+  import threading
+  done = threading.Event()
+
+  def watchdog():
+    if not done.wait(timeout_s):
+      if rank == 0:
+        fallback_line['extras_error'] = 'section timed out after %d s' % timeout_s
+        print(json.dumps(fallback_line))
+        sys.stdout.flush()
+      os._exit(0)
+  threading.Thread(target=watchdog, daemon=True).start()
+  try:
+    res = fn()
+  except Exception as e:   # informational: report, do not fail the run
+    res = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+  done.set()
+  return res
+
+
 def cpu_baseline():
   """The NumPy oracle (a port of the reference's NumPy-worker path) on the host:
   one worker == one core (spartan/worker.py:40), BLAS pinned to one thread."""
@@ -379,6 +426,10 @@ def main():
       line['cpu_baseline'] = cpu_baseline()
   if world.distributed:
     line['comm'] = dict(world.stats)
+    if not args.no_extras:
+      del keep[:]
+      torch.cuda.empty_cache()
+      line['hbm_dist'] = guarded(lambda: dist_section(ctx), 240, world.rank, dict(line))
   world.barrier()
   if world.rank == 0:
     print(json.dumps(line))
