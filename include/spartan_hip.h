@@ -418,6 +418,17 @@ size_t sp_sort_rows_workspace_bytes(int32_t dtype, int64_t rows, int64_t cols);
 int sp_sort_rows(const void* d_in, int32_t dtype, int64_t rows, int64_t cols, void* d_out_vals, int64_t* d_out_idx,
                  void* d_ws, size_t ws_bytes, void* stream);
 
+/* sp_tiling_solve: the solver behind the auto-tiling pass (reference: the CPython-2 extension
+ * spartan/expr/operator/tiling.cc called from AutomaticTiling.calc_tiling, optimize.py:937-975).  HOST code, no GPU
+ * work.  Nodes 0..n_nodes-1 are (expression, tiling) alternatives; group g owns the nodes
+ * group_nodes[group_ptr[g] .. group_ptr[g+1]) and exactly one of them is chosen; nodes in no group are always chosen;
+ * an edge's cost (>= 0; here bytes over xGMI links) is paid when both its ends are chosen.  choice[g] receives the
+ * index (inside its group) of the chosen alternative, *total the cost.  Exact for small problems, greedy + local
+ * moves beyond that. */
+int sp_tiling_solve(int32_t n_nodes, int64_t n_edges, const int32_t* edge_u, const int32_t* edge_v,
+                    const double* edge_cost, int32_t n_groups, const int32_t* group_ptr, const int32_t* group_nodes,
+                    int32_t* choice, double* total);
+
 /* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
  * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
 int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);

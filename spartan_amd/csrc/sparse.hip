@@ -9,8 +9,8 @@
 // (upload of COO/CSR data, transpose, slicing by a box, region updates, A + B, the expansion step of
 // sparse x sparse) is "edit a COO list, then sp_coo_to_csr": an LSD radix sort of (row, col) keys that is
 // stable, so duplicate coordinates are added in list order, without floating-point atomics.
-//   sp_csr_spmm     CSR x dense (the dot of the pagerank / netflix-style programs): HBM-bound,
-//                   12 B per stored entry + 12 B per row for N = 1.
+//   sp_csr_spmm     CSR x dense (the dot of the pagerank / netflix-style programs).  N = 1: 8 B per stored entry
+//                   (value + column) + 16 B per row (indptr, y, x once) of algorithmic HBM traffic.
 //   sp_csr_scatter  sparse -> dense update (assign / add / the reference's masked first-write rule).
 #include <stdlib.h>
 

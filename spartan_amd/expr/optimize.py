@@ -3,8 +3,9 @@ over maps) into ONE LocalExpr tree = one HIP kernel per tile.
 
 Mirror of the reference's spartan/expr/operator/optimize.py:107-247
 (`fusable`, `merge_var`, MapMapFusion, ReduceMapFusion,
-CollapsedCachedExpressions) and `optimize` (:1072-1081).  Auto-tiling, Parakeet
-generation and slice rotation are outside the tile-kernel path.
+CollapsedCachedExpressions) and `optimize` (:1072-1081); the auto-tiling pass
+(:459-1054) lives in expr/tiling.py.  Parakeet generation and slice rotation are
+outside the tile-kernel path.
 """
 from . import base
 from .base import AsArray, Expr, ListExpr, Val, expr_like, lazify
@@ -18,7 +19,10 @@ from ..util import Assert
 _not_idempotent_list = set()
 
 FLAGS = {'optimization': True, 'opt_map_fusion': True, 'opt_reduce_fusion': True,
-         'opt_collapse_cached': True}
+         'opt_collapse_cached': True,
+         # the reference's default is True; the golden vectors were recorded with it off (its solver is a
+         # CPython-2 extension), so it is opt-in here
+         'opt_auto_tiling': False}
 
 
 def not_idempotent(fn):
@@ -152,6 +156,9 @@ def optimize(dag):
     return dag
   if FLAGS['opt_collapse_cached']:
     dag = CollapsedCachedExpressions().visit(dag)
+  if FLAGS['opt_auto_tiling']:            # optimize.py:1094: after the cached-value collapse, before the fusions
+    from .tiling import AutomaticTiling
+    dag = AutomaticTiling().visit(dag)
   if FLAGS['opt_map_fusion']:
     dag = MapMapFusion().visit(dag)
   if FLAGS['opt_reduce_fusion']:

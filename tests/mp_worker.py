@@ -59,6 +59,32 @@ def run_sparse(total_workers):
   return count
 
 
+def run_auto_tiling(world):
+  """Auto-tiling across ranks: same values, and the bytes that actually cross ranks do not go up (here they go to
+  what the model predicts: a column-tiled operand summed over axis 0 needs no exchange when the new array is created
+  column-tiled too)."""
+  import importlib
+  opt = importlib.import_module('spartan_amd.expr.optimize')
+  a = (np.arange(64 * 64, dtype=np.float32).reshape(64, 64) % 7)
+
+  def moved(flag):
+    opt.FLAGS['opt_auto_tiling'] = flag
+    try:
+      A = sp.from_numpy(a, tile_hint=(64, 64 // sp.get_context().num_workers))     # column tiles
+      before = dict(world.stats)
+      got = sp.sum(sp.ones((64, 64)) * 2 + A, axis=1).optimized().glom()
+      np.testing.assert_array_equal(got, (a + 2).sum(1))
+      got0 = sp.sum(sp.ones((64, 64)) * 2 + A, axis=0).optimized().force()
+      after = dict(world.stats)
+      np.testing.assert_array_equal(got0.glom(), (a + 2).sum(0))
+      return (after['collective_bytes'] + after['p2p_bytes']) - (before['collective_bytes'] + before['p2p_bytes'])
+    finally:
+      opt.FLAGS['opt_auto_tiling'] = False
+  plain, tiled = moved(False), moved(True)
+  assert tiled <= plain, (plain, tiled)
+  return 1
+
+
 def main():
   workers = int(sys.argv[1])
   use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
@@ -107,6 +133,7 @@ def main():
   # (tile->worker round robin puts tiles on both ranks; every rank must see the same result)
   n += run_examples(workers)
   n += run_sparse(workers)
+  n += run_auto_tiling(world)
   world.barrier()
   print('RANK %d OK %d' % (world.rank, n))
   sys.stdout.flush()

@@ -1,0 +1,166 @@
+"""Auto-tiling: the C++ solver behind sp_tiling_solve against brute force, and the pass
+(spartan_amd/expr/tiling.py, reference optimize.py:459-1054) on expression DAGs: values unchanged, tilings chosen so
+that reductions / joins need no redistribution, modelled xGMI bytes never above those of the default tiling."""
+import itertools
+
+import numpy as np
+import pytest
+
+import spartan_amd as sp
+import importlib
+
+opt = importlib.import_module('spartan_amd.expr.optimize')   # (`spartan_amd.expr.optimize` the ATTRIBUTE is the function)
+tiling = importlib.import_module('spartan_amd.expr.tiling')
+
+
+def _brute(n_nodes, edges, groups):
+  best = None
+  grouped = {n for g in groups for n in g}
+  for pick in itertools.product(*[range(len(g)) for g in groups]):
+    chosen = set(range(n_nodes)) - grouped
+    chosen |= {g[s] for g, s in zip(groups, pick)}
+    cost = sum(c for u, v, c in edges if u in chosen and v in chosen)
+    if best is None or cost < best[0] - 1e-9:
+      best = (cost, pick)
+  return best
+
+
+def test_solver_matches_brute_force():
+  rng = np.random.RandomState(0)
+  for case in range(60):
+    n_groups = rng.randint(0, 6)
+    groups, n = [], 0
+    for _ in range(n_groups):
+      k = rng.randint(1, 5)
+      groups.append(list(range(n, n + k)))
+      n += k
+    n += rng.randint(0, 4)                       # ungrouped nodes
+    if n == 0:
+      continue
+    edges = []
+    for _ in range(rng.randint(0, 40)):
+      u, v = rng.randint(0, n, size=2)
+      edges.append((int(u), int(v), float(rng.randint(0, 100))))
+    choice, total = tiling.solve(n, edges, groups)
+    want = _brute(n, edges, groups)
+    assert abs(total - want[0]) < 1e-6, (case, total, want)
+    chosen = (set(range(n)) - {m for g in groups for m in g}) | {g[s] for g, s in zip(groups, choice)}
+    assert abs(sum(c for u, v, c in edges if u in chosen and v in chosen) - total) < 1e-6
+
+
+def test_solver_large_problem_is_a_local_optimum():
+  rng = np.random.RandomState(1)
+  groups = [list(range(4 * i, 4 * i + 4)) for i in range(60)]
+  edges = [(int(u), int(v), float(c)) for u, v, c in
+           zip(rng.randint(0, 240, 2000), rng.randint(0, 240, 2000), rng.randint(1, 1000, 2000))]
+  choice, total = tiling.solve(240, edges, groups)
+
+  def cost(ch):
+    chosen = {g[s] for g, s in zip(groups, ch)}
+    return sum(c for u, v, c in edges if u in chosen and v in chosen)
+  assert abs(cost(choice) - total) < 1e-6
+  for g in range(len(groups)):                   # no single-group move improves it
+    for s in range(4):
+      alt = list(choice)
+      alt[g] = s
+      assert cost(alt) >= total - 1e-6
+
+
+@pytest.fixture
+def ctx4():
+  from oracle.np_backend import NumpyBackend
+  c = sp.initialize(backend=NumpyBackend(), num_workers=4)
+  opt.FLAGS['opt_auto_tiling'] = True
+  yield c
+  opt.FLAGS['opt_auto_tiling'] = False
+  sp.shutdown()
+
+
+def _tiles(arr):
+  return sorted((ex.ul, ex.lr) for ex in arr.tiles)
+
+
+def test_reduction_axis_decides_the_tiling_of_a_new_array(ctx4):
+  # sum over axis 0 is free when the array is split by COLUMNS, sum over axis 1 when split by ROWS
+  # (optimize.py:620-629); the creation node is free in every tiling, so the reduce decides.
+  at = tiling.AutomaticTiling()
+  e = sp.sum(sp.ones((64, 48)) * 2, axis=0)
+  at.visit(e)
+  nd = [x for x in _walk(e) if x.typename() == 'NdArrayExpr'][0]
+  assert nd.tile_hint == (64, 12) and at.report['link_bytes'] == 0
+  np.testing.assert_array_equal(e.optimized().glom(), np.full(48, 128, np.float32))
+  at = tiling.AutomaticTiling()
+  e = sp.sum(sp.ones((64, 48)) * 2, axis=1)
+  at.visit(e)
+  nd = [x for x in _walk(e) if x.typename() == 'NdArrayExpr'][0]
+  assert nd.tile_hint == (16, 48) and at.report['link_bytes'] == 0
+  np.testing.assert_array_equal(e.optimized().glom(), np.full(64, 96, np.float32))
+
+
+def _walk(e, seen=None):
+  seen = seen if seen is not None else set()
+  if not isinstance(e, sp.Expr) or id(e) in seen:
+    return
+  seen.add(id(e))
+  yield e
+  for v in e.dependencies().values():
+    if isinstance(v, sp.Expr):
+      for x in _walk(v, seen):
+        yield x
+    elif isinstance(v, (list, tuple)):
+      for w in v:
+        for x in _walk(w, seen):
+          yield x
+  vals = getattr(e, 'vals', None)
+  if isinstance(vals, (list, tuple)):
+    for w in vals:
+      for x in _walk(w, seen):
+        yield x
+
+
+def test_existing_arrays_keep_their_tiling_and_values_do_not_change(ctx4):
+  rng = np.random.RandomState(2)
+  a = rng.randint(-3, 4, size=(40, 24)).astype(np.float32)
+  b = rng.randint(-3, 4, size=(24, 32)).astype(np.float32)
+  A, B = sp.from_numpy(a), sp.from_numpy(b)
+  progs = {
+      'dot': lambda: sp.dot(A, B),
+      'dot_then_sum': lambda: sp.sum(sp.dot(A, B) + 1, axis=0),
+      'map_two_inputs': lambda: A * 2 + sp.ones((40, 24)),
+      'transpose_dot': lambda: sp.dot(sp.transpose(A), sp.from_numpy(a)),
+      'tall_dot': lambda: sp.dot(sp.from_numpy(np.tile(a, (4, 1))), B),
+  }
+  want = {'dot': a @ b, 'dot_then_sum': (a @ b + 1).sum(0), 'map_two_inputs': a * 2 + 1,
+          'transpose_dot': a.T @ a, 'tall_dot': np.tile(a, (4, 1)) @ b}
+  for name, build in progs.items():
+    got = build().optimized().glom()
+    np.testing.assert_array_equal(got, want[name], err_msg=name)
+  assert _tiles(A.val) == _tiles(sp.from_numpy(a).val)          # inputs are not re-tiled
+
+
+def test_modelled_bytes_never_exceed_the_default_tiling(ctx4):
+  """The chosen assignment costs at most what "every new array by rows" costs in the same model."""
+  a = sp.from_numpy(np.ones((64, 64), np.float32), tile_hint=(64, 16))        # a COLUMN-tiled input
+  e = sp.sum(sp.ones((64, 64)) + a, axis=0)
+  at = tiling.AutomaticTiling()
+  at.visit(e)
+  edges = [(u, v, c) for (u, v), c in at.edges.items()]
+  rows_only = set(range(len(at.nodes))) - {n for g in at.groups for n in g} | {g[0] for g in at.groups}
+  default_cost = sum(c for u, v, c in edges if u in rows_only and v in rows_only)
+  assert at.report['link_bytes'] <= default_cost
+  assert at.report['link_bytes'] == 0 and default_cost > 0      # columns everywhere: nothing moves
+  nd = [x for x in _walk(e) if x.typename() == 'NdArrayExpr'][0]
+  assert nd.tile_hint == (64, 16)
+  np.testing.assert_array_equal(e.optimized().glom(), np.full(64, 128, np.float32))
+
+
+def test_pass_is_off_by_default_and_a_no_op_on_one_worker():
+  from oracle.np_backend import NumpyBackend
+  assert opt.FLAGS['opt_auto_tiling'] is False
+  sp.initialize(backend=NumpyBackend(), num_workers=1)
+  try:
+    e = sp.sum(sp.ones((8, 8)), axis=0)
+    at = tiling.AutomaticTiling()
+    assert at.visit(e) is e and at.report == {}
+  finally:
+    sp.shutdown()
