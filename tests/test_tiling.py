@@ -164,3 +164,29 @@ def test_pass_is_off_by_default_and_a_no_op_on_one_worker():
     assert at.visit(e) is e and at.report == {}
   finally:
     sp.shutdown()
+
+
+@pytest.mark.gpu
+def test_auto_tiled_programs_on_the_hip_backend():
+  """The pass only changes tile hints; the HIP tile path must give the same values under the tilings it picks
+  (column tiles, blocks) as under the default row tiles."""
+  sp.initialize('hip', num_workers=4)
+  opt.FLAGS['opt_auto_tiling'] = True
+  try:
+    rng = np.random.RandomState(3)
+    a = rng.randint(-3, 4, size=(96, 64)).astype(np.float32)
+    b = rng.randint(-3, 4, size=(64, 80)).astype(np.float32)
+    A, B = sp.from_numpy(a), sp.from_numpy(b)
+    Ac = sp.from_numpy(a, tile_hint=(96, 16))
+    np.testing.assert_array_equal(sp.dot(A, B).optimized().glom(), a @ b)
+    np.testing.assert_array_equal(sp.sum(sp.dot(A, B) + 1, axis=0).optimized().glom(), (a @ b + 1).sum(0))
+    np.testing.assert_array_equal(sp.sum(sp.ones((96, 64)) * 2 + Ac, axis=0).optimized().glom(), (a + 2).sum(0))
+    np.testing.assert_array_equal(sp.sum(sp.ones((96, 64)) * 2 + Ac, axis=1).optimized().glom(), (a + 2).sum(1))
+    np.testing.assert_array_equal(sp.dot(sp.transpose(A), sp.from_numpy(a)).optimized().glom(), a.T @ a)
+    e = sp.sum(sp.ones((96, 64)) + Ac, axis=0)
+    at = tiling.AutomaticTiling()
+    at.visit(e)
+    assert at.report['link_bytes'] == 0
+  finally:
+    opt.FLAGS['opt_auto_tiling'] = False
+    sp.shutdown()
