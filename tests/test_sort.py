@@ -162,3 +162,42 @@ def test_sort_full_size_tile_properties():
     assert torch.equal(ref.values, vals[r]) and torch.equal(ref.indices, idx[r])
   del vals, idx, x
   torch.cuda.empty_cache()
+
+
+def _sort_fuzz(backend_factory, n_cases=25):
+  """Random ranks (1..4), shapes, dtypes, axes and worker counts through the expression API."""
+  rng = np.random.RandomState(77)
+  for case in range(n_cases):
+    nd = int(rng.randint(1, 5))
+    workers = int(rng.choice([1, 2, 4])) if nd > 1 else 1        # (1-d arrays are split along the sort axis itself)
+    shape = tuple(int(v) for v in rng.choice([4, 5, 8, 17, 64, 300], size=nd))
+    if workers > 1:
+      shape = tuple(max(s, workers) for s in shape)              # change_partition_axis needs >= workers slabs
+    dtype = [np.float32, np.float64, np.int32, np.int64][rng.randint(4)]
+    x = (rng.randn(*shape) * 20).astype(dtype) if np.dtype(dtype).kind == 'f' else rng.randint(-9, 10, size=shape).astype(dtype)
+    if np.dtype(dtype).kind == 'f' and x.size > 10:
+      x.flat[3] = np.nan
+      x.flat[7] = x.flat[2]
+    axis = int(rng.randint(-nd, nd))
+    sp.initialize(backend=backend_factory(), num_workers=workers)
+    try:
+      a = sp.from_numpy(x)
+      tag = 'case %d: %s %s axis %d, %d workers' % (case, shape, np.dtype(dtype).name, axis, workers)
+      got = sp.sort(a, axis).glom()
+      iview = {4: np.int32, 8: np.int64}[np.dtype(dtype).itemsize]
+      np.testing.assert_array_equal(got.view(iview), np.sort(x, axis, kind='stable').view(iview), err_msg=tag)
+      gi = sp.argsort(a, axis).glom()
+      np.testing.assert_array_equal(gi, np.argsort(x, axis, kind='stable').astype(dtype), err_msg=tag)
+    finally:
+      sp.shutdown()
+
+
+def test_sort_fuzz_cpu():
+  from oracle.np_backend import NumpyBackend
+  _sort_fuzz(NumpyBackend)
+
+
+@pytest.mark.gpu
+def test_sort_fuzz_gpu():
+  from spartan_amd.backend_hip import HipBackend
+  _sort_fuzz(HipBackend, 40)
