@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256) void sp_label_hist_kernel(const int64_t* __res
 // perm[pos] = row, rows of one label contiguous and in ascending row order.
 // One wavefront per row block; LDS cursor per label starts at the scanned offset.  Within a
 // 64-row chunk a row's rank among the rows of its label is the number of LOWER lanes holding
-// the same label (64 readlane/compare steps, no divergence); the last lane of each label
-// advances the cursor (distinct addresses, no atomics).
+// the same label (found with one ballot per label bit, no divergence); the last lane of each
+// label advances the cursor (distinct addresses, no atomics).
 __global__ __launch_bounds__(64) void sp_label_rank_kernel(const int64_t* __restrict__ labels, int64_t n, int k,
                                                            int rb, int nblk, const int* __restrict__ offs,
                                                            int* __restrict__ perm, int* __restrict__ seg_start,
@@ -315,6 +315,8 @@ __global__ __launch_bounds__(64) void sp_label_rank_kernel(const int64_t* __rest
   extern __shared__ int cur[];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
+  int label_bits = 1;
+  while ((1 << label_bits) < k) ++label_bits;
   for (int i = lane; i < k; i += 64) {
     cur[i] = offs[(int64_t)i * nblk + b];
     if (b == 0) seg_start[i] = offs[(int64_t)i * nblk];
@@ -334,14 +336,16 @@ __global__ __launch_bounds__(64) void sp_label_rank_kernel(const int64_t* __rest
         valid = true;
       }
     }
-    int lower = 0, same = 0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const int lj = __builtin_amdgcn_readlane(lab, j);
-      const int eq = (lj == lab) ? 1 : 0;
-      same += eq;
-      lower += (j < lane) ? eq : 0;
+    // lanes holding the same label: the ballots of "my bit value", intersected bit by bit (label_bits <= 14
+    // ballots instead of 64 readlane / compare steps)
+    uint64_t peers = __ballot(valid);
+    for (int bit = 0; bit < label_bits; ++bit) {
+      const bool one = (lab >> bit) & 1;
+      const uint64_t bal = __ballot(one);
+      peers &= one ? bal : ~bal;
     }
+    const int lower = __popcll(peers & ((1ull << lane) - 1ull));
+    const int same = __popcll(peers);
     int start = 0;
     if (valid) start = cur[lab];
     __builtin_amdgcn_s_waitcnt(0);
