@@ -6,10 +6,11 @@
 // -0.0 and +0.0 compare equal.  Values are gathered from the input by the sorted positions, so the output holds
 // the input's bit patterns.
 //   rows of <= 4096 32-bit elements : bitonic network on (key, column) pairs in LDS, one HBM pass
-//   anything else                   : LSD radix sort of the whole tile -- sizeof(T) passes over the key bytes, then
-//                                     ceil(log2(rows) / 8) passes over the ROW of each element's flat position
-//                                     (sp_radix.hpp), which brings every row together in order without ever
-//                                     sorting rows one at a time.
+//   anything else                   : LSD radix sort, sizeof(T) passes over the key bytes, every line a SEGMENT of
+//                                     the same launches (sp_radix.hpp: histogram [line][digit][block], one scan).
+//                                     Lines too short for per-line histograms (64-bit types, < 256 elements) are
+//                                     sorted as one array and then by the bytes of each element's ROW, which brings
+//                                     the lines back together.
 #include <stdlib.h>
 
 #include "sp_common.hpp"
@@ -71,17 +72,33 @@ __device__ __forceinline__ bool unkey64<int64_t>(uint64_t k, int64_t* v) {
   return true;
 }
 
+// 32-bit element types sort 32-bit keys: 8-byte (key, position) pairs instead of 12
+template <typename T>
+struct KeyOf {
+  typedef uint64_t type;
+};
+template <>
+struct KeyOf<float> {
+  typedef uint32_t type;
+};
+template <>
+struct KeyOf<int32_t> {
+  typedef uint32_t type;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void sp_sort_keys_kernel(const T* __restrict__ in, int64_t n,
-                                                           uint64_t* __restrict__ keys, int32_t* __restrict__ idx) {
+                                                           typename KeyOf<T>::type* __restrict__ keys,
+                                                           int32_t* __restrict__ idx) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    keys[i] = key64<T>(in[i]);
+    keys[i] = (typename KeyOf<T>::type)key64<T>(in[i]);
     idx[i] = (int32_t)i;
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sp_sort_emit_kernel(const T* __restrict__ in, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void sp_sort_emit_kernel(const T* __restrict__ in,
+                                                           const typename KeyOf<T>::type* __restrict__ keys,
                                                            const int32_t* __restrict__ idx, int64_t n, uint32_t cols,
                                                            T* __restrict__ out_vals, int64_t* __restrict__ out_idx) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -213,20 +230,31 @@ inline bool lds_path(int32_t dtype, int64_t cols) {
   return (dtype == SP_F32 || dtype == SP_I32) && cols <= LDS_SORT_E;
 }
 
+// segmented passes keep one histogram per (line, digit, key block of the line): affordable while that is at most the
+// size of the data (lines of >= 256 elements)
+inline bool seg_ok(int64_t rows, int64_t cols) {
+  const char* e = getenv("SP_SORT_SEGMENTED");     // "0": force the row passes (test knob)
+  if (e && e[0] == '0') return false;
+  return sp_sort_blocks(rows * cols, cols) * RDX <= rows * cols;
+}
+
 template <typename T>
 int sort_radix(const T* in, int64_t rows, int64_t cols, T* out_vals, int64_t* out_idx, void* d_ws, hipStream_t st) {
   const int64_t n = rows * cols;
-  SortWs ws;
-  sp_sort_ws_bytes(n, &ws, (char*)d_ws);
+  // lines long enough that per-line histograms stay small next to the data are sorted as SEGMENTS by the key passes
+  // alone; otherwise the whole tile is sorted by key and two more passes over the row bytes bring the lines together
+  const bool segmented = rows > 1 && seg_ok(rows, cols);
+  SortWsT<typename KeyOf<T>::type> ws;
+  sp_sort_ws_bytes(n, &ws, (char*)d_ws, segmented ? cols : 0);
   hipLaunchKernelGGL((sp_sort_keys_kernel<T>), dim3(sort_grid(n, 256)), dim3(256), 0, st, in, n, ws.keys[0], ws.idx[0]);
   SP_CHECK_LAUNCH();
   int cur = 0;
   for (int shift = 0; shift < (int)sizeof(T) * 8; shift += RDX_BITS) {
-    if (sp_radix_pass(ws, cur, n, DigitOfKey{shift}, st)) return 1;
+    if (sp_radix_pass(ws, cur, n, DigitOfKey{shift}, st, segmented ? cols : 0)) return 1;
     cur = 1 - cur;
   }
   int row_bits = 0;
-  while (row_bits < 32 && ((int64_t)1 << row_bits) < rows) ++row_bits;
+  while (!segmented && row_bits < 32 && ((int64_t)1 << row_bits) < rows) ++row_bits;
   for (int shift = 0; shift < row_bits; shift += RDX_BITS) {
     if (sp_radix_pass(ws, cur, n, DigitOfRow{shift, (uint32_t)cols}, st)) return 1;
     cur = 1 - cur;
@@ -255,7 +283,10 @@ int sort_lds(const T* in, int64_t rows, int64_t cols, T* out_vals, int64_t* out_
 
 extern "C" size_t sp_sort_rows_workspace_bytes(int32_t dtype, int64_t rows, int64_t cols) {
   if (rows < 1 || cols < 1 || lds_path(dtype, cols)) return 256;
-  return sp_sort_ws_bytes(rows * cols, nullptr, nullptr);
+  // (sized for the wider key type; segmented and plain layouts differ only in the histogram, take the larger)
+  const size_t a = sp_sort_ws_bytes<uint64_t>(rows * cols, nullptr, nullptr, 0);
+  const size_t b = (rows > 1 && seg_ok(rows, cols)) ? sp_sort_ws_bytes<uint64_t>(rows * cols, nullptr, nullptr, cols) : 0;
+  return a > b ? a : b;
 }
 
 extern "C" int sp_sort_rows(const void* d_in, int32_t dtype, int64_t rows, int64_t cols, void* d_out_vals,

@@ -13,31 +13,47 @@ constexpr int SORT_RB = 4096;            // keys per workgroup / wavefront of on
 
 struct DigitOfKey {                      // byte `shift / 8` of the key
   int shift;
-  __device__ __forceinline__ int operator()(uint64_t key, int32_t) const { return (int)((key >> shift) & (RDX - 1)); }
+  template <typename K>
+  __device__ __forceinline__ int operator()(K key, int32_t) const { return (int)((key >> shift) & (RDX - 1)); }
 };
 
 struct DigitOfRow {                      // byte `shift / 8` of the row (payload / cols) of a flat position
   int shift;
   uint32_t cols;
-  __device__ __forceinline__ int operator()(uint64_t, int32_t idx) const {
+  template <typename K>
+  __device__ __forceinline__ int operator()(K, int32_t idx) const {
     return (int)((((uint32_t)idx / cols) >> shift) & (RDX - 1));
   }
 };
 
-// hist[d * nblk + b] = number of keys with digit d in key block b
-template <typename D>
-__global__ __launch_bounds__(256) void sp_radix_hist_kernel(const uint64_t* __restrict__ keys,
+// The keys form segments of seg_len (one segment = the whole array for a plain sort; one LINE of a tile for a
+// segmented sort), each cut into bpr key blocks of SORT_RB.  hist[(seg * RDX + d) * bpr + bi] = number of keys with
+// digit d in block bi of segment seg: ONE exclusive scan over that layout yields destinations ordered by segment,
+// then digit, then block -- every segment is sorted in place, independently, by the same launches.
+__device__ __forceinline__ void sp_radix_block_range(int b, int64_t n, int64_t seg_len, int bpr, int64_t* r0,
+                                                     int64_t* r1, int64_t* hbase) {
+  const int64_t seg = b / bpr;
+  const int bi = b - (int)(seg * bpr);
+  const int64_t s0 = seg * seg_len;
+  int64_t s1 = s0 + seg_len;
+  if (s1 > n) s1 = n;
+  *r0 = s0 + (int64_t)bi * SORT_RB;
+  *r1 = *r0 + SORT_RB < s1 ? *r0 + SORT_RB : s1;
+  *hbase = seg * RDX * (int64_t)bpr + bi;      // + d * bpr
+}
+
+template <typename K, typename D>
+__global__ __launch_bounds__(256) void sp_radix_hist_kernel(const K* __restrict__ keys,
                                                             const int32_t* __restrict__ idx, int64_t n, D dig,
-                                                            int nblk, int* __restrict__ hist) {
+                                                            int64_t seg_len, int bpr, int* __restrict__ hist) {
   __shared__ int lh[RDX];
-  const int b = blockIdx.x;
   lh[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t r0 = (int64_t)b * SORT_RB;
-  const int64_t r1 = r0 + SORT_RB < n ? r0 + SORT_RB : n;
+  int64_t r0, r1, hbase;
+  sp_radix_block_range(blockIdx.x, n, seg_len, bpr, &r0, &r1, &hbase);
   for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) atomicAdd(&lh[dig(keys[i], idx[i])], 1);
   __syncthreads();
-  hist[(int64_t)threadIdx.x * nblk + b] = lh[threadIdx.x];
+  hist[hbase + (int64_t)threadIdx.x * bpr] = lh[threadIdx.x];
 }
 
 // One workgroup (4 wavefronts) per key block.  Wavefront w walks its quarter of the block in order, 64 keys at a
@@ -49,25 +65,24 @@ constexpr int RANK_WAVES = 4;
 constexpr int RANK_PER_WAVE = SORT_RB / RANK_WAVES;     // 1024 keys
 constexpr int RANK_CHUNKS = RANK_PER_WAVE / 64;         // 16 chunks per wavefront
 
-template <typename D>
-__global__ __launch_bounds__(256) void sp_radix_rank_kernel(const uint64_t* __restrict__ keys,
+template <typename K, typename D>
+__global__ __launch_bounds__(256) void sp_radix_rank_kernel(const K* __restrict__ keys,
                                                            const int32_t* __restrict__ idx, int64_t n, D dig,
-                                                           int nblk, const int* __restrict__ offs,
-                                                           uint64_t* __restrict__ keys_out,
+                                                           int64_t seg_len, int bpr, const int* __restrict__ offs,
+                                                           K* __restrict__ keys_out,
                                                            int32_t* __restrict__ idx_out) {
-  __shared__ uint64_t sk[SORT_RB];
+  __shared__ K sk[SORT_RB];
   __shared__ int32_t si[SORT_RB];
   __shared__ uint16_t wcnt[RANK_WAVES][RDX];   // keys of digit d seen so far by wavefront w; then its base
   __shared__ int lstart[RDX];                  // first LDS slot of digit d
   __shared__ int goff[RDX];                    // global position of this block's first key of digit d
-  const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int64_t r0, r1, hbase;
+  sp_radix_block_range(blockIdx.x, n, seg_len, bpr, &r0, &r1, &hbase);
   for (int i = tid; i < RANK_WAVES * RDX; i += 256) (&wcnt[0][0])[i] = 0;
-  goff[tid] = offs[(int64_t)tid * nblk + b];
+  goff[tid] = offs[hbase + (int64_t)tid * bpr];
   __syncthreads();
-  const int64_t r0 = (int64_t)b * SORT_RB;
-  const int64_t r1 = r0 + SORT_RB < n ? r0 + SORT_RB : n;
-  uint64_t key[RANK_CHUNKS];
+  K key[RANK_CHUNKS];
   int32_t id[RANK_CHUNKS];
   int32_t pos[RANK_CHUNKS];                    // digit << 16 | rank inside this wavefront's quarter
 #pragma unroll
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(256) void sp_radix_rank_kernel(const uint64_t* __re
   __syncthreads();
   const int cnt = (int)(r1 - r0);
   for (int p = tid; p < cnt; p += 256) {
-    const uint64_t k = sk[p];
+    const K k = sk[p];
     const int32_t v = si[p];
     const int d = dig(k, v);
     const int64_t dst = (int64_t)goff[d] + (p - lstart[d]);
@@ -154,16 +169,28 @@ __global__ __launch_bounds__(256) void sp_radix_rank_kernel(const uint64_t* __re
 inline size_t sp_al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // scratch of a sort of n pairs: two key arrays, two payload arrays, the histogram (reusable as n ints), scan sums
-struct SortWs {
-  uint64_t* keys[2];
+template <typename K>
+struct SortWsT {
+  K* keys[2];
   int32_t* idx[2];
   int* hist;   // [RDX][nblk] or n ints, whichever is larger
   int* sums;   // scan chunk sums
   int* total;
 };
 
-inline size_t sp_sort_ws_bytes(int64_t n, SortWs* ws, char* base) {
-  const int64_t nblk = (n + SORT_RB - 1) / SORT_RB;
+using SortWs = SortWsT<uint64_t>;
+
+// key blocks of a sort of n keys in segments of seg_len
+inline int64_t sp_sort_blocks(int64_t n, int64_t seg_len) {
+  if (n < 1) return 0;
+  if (seg_len < 1 || seg_len > n) seg_len = n;
+  const int64_t nseg = (n + seg_len - 1) / seg_len;
+  return nseg * ((seg_len + SORT_RB - 1) / SORT_RB);
+}
+
+template <typename K>
+inline size_t sp_sort_ws_bytes(int64_t n, SortWsT<K>* ws, char* base, int64_t seg_len = 0) {
+  const int64_t nblk = sp_sort_blocks(n, seg_len);
   const int64_t hist_words = (int64_t)RDX * nblk > n ? (int64_t)RDX * nblk : n;
   const int64_t sums_words = (hist_words + SCAN_CHUNK - 1) / SCAN_CHUNK + 1;
   size_t off = 0;
@@ -172,16 +199,16 @@ inline size_t sp_sort_ws_bytes(int64_t n, SortWs* ws, char* base) {
     off += sp_al256(bytes);
     return p;
   };
-  char* k0 = take((size_t)n * 8);
-  char* k1 = take((size_t)n * 8);
+  char* k0 = take((size_t)n * sizeof(K));
+  char* k1 = take((size_t)n * sizeof(K));
   char* i0 = take((size_t)n * 4);
   char* i1 = take((size_t)n * 4);
   char* h = take((size_t)hist_words * 4);
   char* s = take((size_t)sums_words * 4);
   char* t = take(256);
   if (ws) {
-    ws->keys[0] = (uint64_t*)k0;
-    ws->keys[1] = (uint64_t*)k1;
+    ws->keys[0] = (K*)k0;
+    ws->keys[1] = (K*)k1;
     ws->idx[0] = (int32_t*)i0;
     ws->idx[1] = (int32_t*)i1;
     ws->hist = (int*)h;
@@ -191,16 +218,20 @@ inline size_t sp_sort_ws_bytes(int64_t n, SortWs* ws, char* base) {
   return off;
 }
 
-// keys[cur] / idx[cur] -> keys[1 - cur] / idx[1 - cur], stable by the digit `dig`
-template <typename D>
-static inline int sp_radix_pass(SortWs& ws, int cur, int64_t n, D dig, hipStream_t st) {
-  const int nblk = (int)((n + SORT_RB - 1) / SORT_RB);
-  hipLaunchKernelGGL((sp_radix_hist_kernel<D>), dim3(nblk), dim3(256), 0, st, ws.keys[cur], ws.idx[cur], n, dig, nblk,
-                     ws.hist);
+// keys[cur] / idx[cur] -> keys[1 - cur] / idx[1 - cur], stable by the digit `dig`; with seg_len > 0 every segment of
+// seg_len keys is sorted on its own (the workspace must have been sized with the same seg_len)
+template <typename K, typename D>
+static inline int sp_radix_pass(SortWsT<K>& ws, int cur, int64_t n, D dig, hipStream_t st, int64_t seg_len = 0) {
+  if (seg_len < 1 || seg_len > n) seg_len = n;
+  const int bpr = (int)((seg_len + SORT_RB - 1) / SORT_RB);
+  const int64_t nblk = sp_sort_blocks(n, seg_len);
+  if (nblk > 2147483647LL / 2) SP_FAIL("radix sort: too many key blocks");
+  hipLaunchKernelGGL((sp_radix_hist_kernel<K, D>), dim3((unsigned)nblk), dim3(256), 0, st, ws.keys[cur], ws.idx[cur], n, dig,
+                     seg_len, bpr, ws.hist);
   SP_CHECK_LAUNCH();
   if (sp_exscan_int(ws.hist, (int64_t)RDX * nblk, ws.sums, nullptr, st)) return 1;
-  hipLaunchKernelGGL((sp_radix_rank_kernel<D>), dim3(nblk), dim3(256), 0, st, ws.keys[cur], ws.idx[cur], n, dig, nblk,
-                     ws.hist, ws.keys[1 - cur], ws.idx[1 - cur]);
+  hipLaunchKernelGGL((sp_radix_rank_kernel<K, D>), dim3((unsigned)nblk), dim3(256), 0, st, ws.keys[cur], ws.idx[cur], n, dig,
+                     seg_len, bpr, ws.hist, ws.keys[1 - cur], ws.idx[1 - cur]);
   SP_CHECK_LAUNCH();
   return 0;
 }

@@ -424,7 +424,7 @@ inline int key_bits(int64_t nrows, int64_t ncols) {
 
 extern "C" size_t sp_coo_to_csr_workspace_bytes(int64_t nnz) {
   if (nnz < 1) return 256;
-  return sp_sort_ws_bytes(nnz, nullptr, nullptr);
+  return sp_sort_ws_bytes<uint64_t>(nnz, nullptr, nullptr);
 }
 
 extern "C" int sp_coo_to_csr(int32_t dtype, int64_t nrows, int64_t ncols, int64_t nnz, const int32_t* d_rows,
