@@ -7,7 +7,6 @@ CollapsedCachedExpressions) and `optimize` (:1072-1081); the auto-tiling pass
 (:459-1054) lives in expr/tiling.py.  Parakeet generation and slice rotation are
 outside the tile-kernel path.
 """
-from . import base
 from .base import AsArray, Expr, ListExpr, Val, expr_like, lazify
 from .local import LocalInput, LocalMapLocationExpr, LocalReduceExpr, make_var
 from .map import MapExpr

@@ -20,13 +20,11 @@ import math
 
 import numpy as np
 
-from . import base
 from .base import AsArray, CollectionExpr, DictExpr, Expr, Val
-from .map import Map2Expr, MapExpr
+from .map import Map2Expr
 from .ndarray import NdArrayExpr
 from .outer import OuterProductExpr
 from .reduce import ReduceExpr
-from .shuffle import ShuffleExpr
 from .. import context
 from ..array import distarray
 
@@ -137,9 +135,6 @@ class AutomaticTiling(object):
     for i in ids:
       self.nodes[i].exprs.append(expr)
     return ids
-
-  def _is_split(self, ids):
-    return len(ids) > 1
 
   def _children(self, children, skip=None):
     out = []
