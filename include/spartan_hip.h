@@ -375,10 +375,10 @@ int sp_coo_reshape(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t old_co
 /* sp_csr_spmm: C[m, n] (+)= A[m, k] (CSR) x B[k, n] (dense, row-major, ldb) -- the tile body of
  * dot_map2_mapper / dot_outer_mapper when tile_a is sparse (spartan/expr/dot.py:193-240, scipy's csr .dot)
  * and of dot_coo_dense_unordered_map (sparse.pyx:103-158, n == 1; the result is written dense).
- * d_b == NULL with n == 1 multiplies by a vector of ones (row sums).  n == 1, short rows: workgroups own
+ * d_b == NULL with n == 1 multiplies by a vector of ones (row sums).  n == 1: workgroups own
  * 2048 consecutive stored entries (coalesced loads, products in LDS, one thread per row, carries of rows that
  * span chunks added by a fix-up pass in chunk order -- no floating-point atomics; needs the workspace);
- * n == 1, long rows: 2..64 lanes per row, shuffle reduction; n > 1: entries of a row in storage order
+ * n == 1, rows of >= 1024 entries on average (or no workspace): 2..64 lanes per row, shuffle reduction; n > 1: entries of a row in storage order
  * (scipy's csr_matvecs order).  Without a workspace the lanes-per-row kernel is used for every n == 1.
  * d_plan (may be NULL): the output of sp_csr_spmv_plan for this matrix -- the first row that starts in each
  * 2048-entry chunk, sp_csr_spmv_plan_entries(nnz) int64 values -- computed once per matrix and reused by every
