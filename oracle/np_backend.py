@@ -258,6 +258,30 @@ class NumpyBackend(object):
     x = _np(t)
     return self._wrap(np.argsort(x, axis, kind='stable') if indices else np.sort(x, axis, kind='stable'))
 
+  def convolve(self, image, filters):
+    """stencil.py:29-45, the loops as written (vectorised over images / filters / positions)."""
+    self.launches += 1
+    img, flt = _np(image), _np(filters)
+    n, c, w, h = img.shape
+    f, fc, fw, fh = flt.shape
+    out = np.zeros((n, f, w, h), dtype=np.result_type(img.dtype, flt.dtype))
+    for ci in range(c):
+      for i in range(min(fw, w)):
+        for j in range(min(fh, h)):
+          out[:, :, :w - i, :h - j] += img[:, ci, i:, j:][:, None] * flt[:, ci, i, j][None, :, None, None]
+    return self._wrap(out)
+
+  def maxpool(self, region, pool_size, stride, out_shape):
+    self.launches += 1
+    x = _np(region)
+    out = np.full(tuple(out_shape), -1e12, dtype=x.dtype)
+    span = pool_size if pool_size < stride else stride      # pixel a belongs to window a // stride (stencil.py:68-70)
+    for i in range(span):
+      for j in range(span):
+        part = x[:, :, i::stride, j::stride]
+        out[:, :, :part.shape[2], :part.shape[3]] = np.maximum(out[:, :, :part.shape[2], :part.shape[3]], part)
+    return self._wrap(out)
+
   def cumscan(self, t, axis, product=False):
     """scan.py:63."""
     self.launches += 1
@@ -343,6 +367,9 @@ class NumpyBackend(object):
 
   def sparse_random(self, shape, density, dtype):
     return sps.rand(shape[0], shape[1], density=density, format='csr', dtype=dtype)
+
+  def _as_device(self, t):
+    return t if isinstance(t, torch.Tensor) else self.from_numpy(np.asarray(t))
 
   def synchronize(self):
     pass

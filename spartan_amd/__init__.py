@@ -34,9 +34,10 @@ from .expr.assign import assign, region_map, retile, write  # noqa: F401
 from .expr.extras import bincount, concatenate, diag, diagflat, diagonal, norm, normalize  # noqa: F401
 from .expr.scan import scan  # noqa: F401
 from .expr.sort import argpartition, argsort, partition, sort  # noqa: F401
-from .expr.fio import from_file, load, partial_load, partial_unpickle, pickle, save, unpickle  # noqa: F401
+from .expr.fio import from_file, from_file_parallel, load, partial_load, partial_unpickle, pickle, save, unpickle  # noqa: F401
 from .expr.tile_operation import tile_operation  # noqa: F401
 from .expr.checkpoint import checkpoint  # noqa: F401
+from .expr.stencil import _convolve, maxpool, stencil  # noqa: F401
 
 # ndarray-style methods on expressions (spartan/expr/__init__.py:66-92)
 Expr.all = all

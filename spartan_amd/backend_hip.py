@@ -530,6 +530,46 @@ class HipBackend(object):
     out = (idx if indices else vals).reshape(outer, inner, n)
     return self.contiguous(out.movedim(2, 1)).reshape(shape)
 
+  def convolve(self, image, filters):
+    """stencil.py:29-45 as a GEMM: P[(n, x, y), (c, i, j)] = image[n, c, x+i, y+j] (0 beyond the edge) by one strided
+    box copy per (c, i, j); P . filters[(c, i, j), f] on the MFMA GEMM; back to [n, f, x, y]."""
+    image = self.contiguous(self._as_device(image))
+    filters = self.contiguous(self._as_device(filters))
+    n, c, w, h = image.shape
+    f, fc, fw, fh = filters.shape
+    assert c == fc
+    dt = np.result_type(self.dtype_of(image), self.dtype_of(filters))
+    image, filters = self.astype(image, dt), self.astype(filters, dt)
+    k = c * fw * fh
+    patches = self.zeros((n, w, h, k), dt)
+    for ci in range(c):
+      for i in range(min(fw, w)):
+        for j in range(min(fh, h)):
+          col = (ci * fw + i) * fh + j
+          self.paste(patches, (slice(0, n), slice(0, w - i), slice(0, h - j), slice(col, col + 1)),
+                     image[:, ci, i:, j:].reshape(n, w - i, h - j, 1))
+    fm = self.copy(filters.reshape(f, k).t())                     # [(c, i, j), f]
+    out = self.dot(patches.reshape(n * w * h, k), fm)             # [(n, x, y), f]
+    return self.copy(out.reshape(n, w, h, f).permute(0, 3, 1, 2))
+
+  def maxpool(self, region, pool_size, stride, out_shape):
+    """out[n, c, X, Y] = max of the pixels (a, b) with a // stride == X, b // stride == Y whose offset inside the
+    window is below pool_size -- the indexing of the reference's (disabled) loop, stencil.py:61-70: one strided copy +
+    one max-merge per window offset, starting from its -1e12 (stencil.py:57-59)."""
+    region = self.contiguous(self._as_device(region))
+    n, c, w, h = region.shape
+    dt = self.dtype_of(region)
+    out = self.evaluate_fn(np.add, [self.zeros(out_shape, dt), dt.type(-1e12)], {}, tuple(out_shape))
+    span = pool_size if pool_size < stride else stride      # pixel a belongs to window a // stride (stencil.py:68-70)
+    for i in range(span):
+      for j in range(span):
+        part = region[:, :, i::stride, j::stride]
+        if part.numel() == 0:
+          continue
+        part = self.copy(part)
+        self.update_box(out, (0, 0, 0, 0), tuple(part.shape), part, np.maximum, tile.MASK_ALL_SET, None)
+    return out
+
   def cumscan(self, t, axis, product=False):
     """np.cumsum / np.cumprod along `axis` (sp_cumscan)."""
     t = self.contiguous(t)

@@ -232,3 +232,10 @@ def from_file(fn, file_type='numpy', sparse=True, tile_hint=None):
   if scipy.sparse.issparse(npa):
     return from_numpy(npa, tile_hint)
   return from_numpy(np.asarray(npa), tile_hint)
+
+
+def from_file_parallel(fn, file_format='mm', sparse=True, tile_hint=None):
+  """write_array.py:315-377: every worker reads its own part of the file.  Every rank of this SPMD program already
+  reads the file itself in `from_file` and keeps only the tiles it owns (nothing passes through a driver), so the two
+  entry points share one implementation; `file_format` is 'mm' or 'numpy'."""
+  return from_file(fn, file_type=file_format, sparse=sparse, tile_hint=tile_hint)

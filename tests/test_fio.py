@@ -105,6 +105,8 @@ def _check(tmp):
   scipy.io.mmwrite(os.path.join(tmp, 'sparse.mtx'), m.astype(np.float64))
   G = sp.from_file(os.path.join(tmp, 'sparse.mtx'), file_type='mm').evaluate()
   assert G.sparse and G.dtype == np.float32                      # narrowed like write_array.py:416-417
+  H = sp.from_file_parallel(os.path.join(tmp, 'sparse.mtx'), file_format='mm', tile_hint=(20, 44)).evaluate()
+  np.testing.assert_allclose(H.glom().toarray(), m.toarray(), rtol=1e-6)
   np.testing.assert_allclose(G.glom().toarray(), m.toarray(), rtol=1e-6)
   # tocoo / tile_operation / checkpoint
   np.testing.assert_array_equal(sp.tocoo(sp.Val(val=S)).glom().toarray(), m.toarray())

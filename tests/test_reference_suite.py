@@ -291,3 +291,21 @@ def test_reference_suite_hip(check, workers):
     check(workers) if check is check_transpose_and_region_map else check()
   finally:
     spartan.shutdown()
+
+
+def test_every_name_the_reference_exports_exists():
+  """spartan/expr/__init__.py:26-65 (the flat builder namespace), listed here so the check needs no reference tree."""
+  names = '''astype tocoo size empty sparse_empty empty_like zeros zeros_like ones ones_like eye identity full full_like
+  arange diagonal diag diagflat sparse_diagonal all any equal not_equal greater greater_equal less less_equal
+  logical_and logical_or logical_xor ravel concatenate add sub multiply divide true_divide floor_divide reciprocal
+  negative fmod mod remainder power ln log square sqrt exp abs maximum minimum sum prod set_random_seed rand randn
+  randint sparse_rand max min mean std bincount normalize norm norm_cdf argmin argmax count_nonzero count_zero assign
+  retile dot save load pickle unpickle partial_load partial_unpickle Expr evaluate optimized_dag eager lazify as_array
+  glom NotShapeable newaxis broadcast checkpoint map map2 map_with_location ndarray outer optimize region_map reshape
+  reduce sort argsort argpartition partition shuffle scan stencil maxpool _convolve tile_operation transpose write
+  from_numpy from_file from_file_parallel'''.split()
+  import spartan_amd
+  missing = [n for n in names if not hasattr(spartan_amd, n)]
+  assert not missing, missing
+  from spartan_amd import expr
+  assert not [n for n in names if not n.startswith('_') and not hasattr(expr, n)]
