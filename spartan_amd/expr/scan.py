@@ -13,7 +13,39 @@ from ..util import divup
 _PAIRS = {np.sum: ('SUM', np.cumsum, False), np.prod: ('PROD', np.cumprod, True)}
 
 
+class _Probe(object):
+  """Stands in for a tile to find out which array method a user function calls (the reference's own test passes
+  `lambda x, **kw: x.sum(axis=kw['axis'])` / `x.cumsum(...)`, tests/test_scan.py:38-39)."""
+
+  def __init__(self):
+    self.called = None
+
+  def _record(self, name):
+    def method(*a, **k):
+      self.called = name
+      return self
+    return method
+
+  def __getattr__(self, name):
+    if name in ('sum', 'prod', 'cumsum', 'cumprod'):
+      return self._record(name)
+    raise AttributeError(name)
+
+
+def _canonical(fn):
+  """np.sum / np.prod / np.cumsum / np.cumprod, or a user function that only calls the method of that name."""
+  if fn in (np.sum, np.prod, np.cumsum, np.cumprod):
+    return fn
+  probe = _Probe()
+  try:
+    fn(probe, axis=0)
+  except Exception:
+    return fn
+  return {'sum': np.sum, 'prod': np.prod, 'cumsum': np.cumsum, 'cumprod': np.cumprod}.get(probe.called, fn)
+
+
 def _kind(reduce_fn, scan_fn):
+  reduce_fn, scan_fn = _canonical(reduce_fn), _canonical(scan_fn)
   try:
     red, want_scan, product = _PAIRS[reduce_fn]
   except (KeyError, TypeError):
@@ -23,10 +55,17 @@ def _kind(reduce_fn, scan_fn):
   return red, product
 
 
+def _dense(data):
+  """A sparse tile is scanned as a dense one (np.cumsum has no sparse form; the reference's test densifies the
+  expected value the same way, tests/test_scan.py:33-35)."""
+  from ..array import tile as tile_mod
+  return context.get().backend.sparse_to_dense(data) if tile_mod.is_sparse_blob(data) else data
+
+
 def _scan_reduce_mapper(array, ex, reduce_fn, axis):
   """scan.py:24-39: this tile's total along `axis`, filed under the tile's index along that axis."""
   ctx = context.get()
-  red, _ = _kind(reduce_fn, _PAIRS[reduce_fn][1])
+  red, _ = _kind(reduce_fn, _PAIRS[_canonical(reduce_fn)][1])
   data = array.fetch(ex)
   axis_shape = array.tile_shape()[axis]
   tid = (ex.lr[axis] - 1) // axis_shape
@@ -37,7 +76,7 @@ def _scan_reduce_mapper(array, ex, reduce_fn, axis):
   if isinstance(data, distarray.Absent) or not ctx.executing:
     yield (dst_ex, distarray.Absent(dst_ex.shape, array.dtype))
     return
-  local = ctx.backend.reduce_axis(data, red, axis)
+  local = ctx.backend.reduce_axis(_dense(data), red, axis)
   yield (dst_ex, local.reshape(dst_ex.shape))
 
 
@@ -56,7 +95,7 @@ def _scan_mapper(tile, ex, scan_fn=None, axis=None, scan_base=None, tile_shape=N
     if tile_id > 0:
       base_slice[axis] = slice(tile_id - 1, tile_id)
       base = scan_base[tuple(base_slice)]
-  out = be.cumscan(tile, axis, product)
+  out = be.cumscan(_dense(tile), axis, product)
   if base is not None:
     base = np.ascontiguousarray(base).astype(be.dtype_of(out))
     out = be.evaluate_fn(np.multiply if product else np.add, [out, base], {}, tuple(out.shape))

@@ -174,3 +174,29 @@ def test_pagerank_example_cpu(workers, tile_hint):
 def test_pagerank_example_gpu(workers, tile_hint):
   from spartan_amd.backend_hip import HipBackend
   _pagerank_example(HipBackend, workers, tile_hint)
+
+
+def _sparse_scan(backend_factory):
+  """tests/test_scan.py:test_sparse_scan, with its own lambdas as reduce / scan functions."""
+  sp.initialize(backend=backend_factory(), num_workers=4)
+  try:
+    eye = np.eye(10)
+    s = sp.sparse_diagonal((10, 10), np.float32, (5, 5))
+    red = lambda x, **kw: x.sum(axis=kw['axis'])          # noqa: E731
+    scn = lambda x, **kw: x.cumsum(axis=kw['axis'])       # noqa: E731
+    np.testing.assert_array_equal(sp.scan(s, reduce_fn=red, scan_fn=scn, axis=None).glom(), np.cumsum(eye).reshape(10, 10))
+    for axis in (0, 1):
+      np.testing.assert_array_equal(sp.scan(s, reduce_fn=red, scan_fn=scn, axis=axis).glom(), np.cumsum(eye, axis))
+  finally:
+    sp.shutdown()
+
+
+def test_sparse_scan_cpu():
+  from oracle.np_backend import NumpyBackend
+  _sparse_scan(NumpyBackend)
+
+
+@pytest.mark.gpu
+def test_sparse_scan_gpu():
+  from spartan_amd.backend_hip import HipBackend
+  _sparse_scan(HipBackend)
