@@ -381,6 +381,7 @@ class DistArrayImpl(DistArray):
       self.blob_to_ex[v] = k
     self.tiles = tiles
     self.id = next(DistArrayImpl._ids)
+    self.ctx.register_array(self)
     pend = self.ctx.pending_destructors
     if pend:
       self.ctx.destroy_all(pend)

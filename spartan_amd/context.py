@@ -19,6 +19,7 @@ spartan/worker.py) for a static world of one process per GPU:
 """
 import collections
 import contextlib
+import weakref
 
 import numpy as np
 
@@ -69,6 +70,7 @@ class Context(object):
     self.pending = None                               # UpdateBatch while a kernel runs
     self.fetch_cache = None                           # whole-array fetches shared inside one kernel
     self.pending_destructors = []                     # tiles of dead arrays (distarray.py:219-268)
+    self._arrays = weakref.WeakSet()                  # live DistArrays (master.py:103-104 register_array)
 
   # -- placement --------------------------------------------------------------
   def rank_of(self, worker):
@@ -130,6 +132,32 @@ class Context(object):
     t = self._blobs.get(tile_id)
     if t is not None:
       t.refcnt += 1
+
+  # -- failures ---------------------------------------------------------
+  def register_array(self, array):
+    self._arrays.add(array)
+
+  def mark_failed_worker(self, worker_id):
+    """master.py:134-140: every tile the worker held is recorded as bad in the array that owns it.  The GPU
+    counterpart of a dead worker is a device that was reset: the rank is still there, its HBM contents are not --
+    so the blobs are dropped here as well and the worker stays available for the reload / recompute that follows
+    (Expr.cache() -> load_data, base.py:193-203: a checkpointed expression reloads the bad tiles from disk, any
+    other is evaluated again from its dependencies)."""
+    for array in list(self._arrays):
+      for ex, tile_id in array.tiles.items():
+        if tile_id.worker == worker_id:
+          if ex not in array.bad_tiles:
+            array.bad_tiles.append(ex)
+          self._blobs.pop(tile_id, None)
+
+  def get_workers_for_reload(self, array):
+    """master.py:110-121: spread an array's bad tiles over the workers, least loaded first."""
+    load = [[w, 0] for w in range(self.num_workers)]
+    for ex, tile_id in array.tiles.items():
+      if ex not in array.bad_tiles:
+        load[tile_id.worker][1] += 1
+    load.sort(key=lambda x: x[1])
+    return {ex: load[i % len(load)][0] for i, ex in enumerate(array.bad_tiles)}
 
   def tile_meta(self, tile_id):
     """(dtype, is_sparse) of a tile, learnt from its owner (the reference issues a

@@ -91,6 +91,11 @@ class Expr(object):
     result = eval_cache.get(self.expr_id)
     if result is not None and len(getattr(result, 'bad_tiles', ())) == 0:
       return result
+    return self.load_data(result)
+
+  def load_data(self, cached_result):
+    """base.py:189-191: nothing to reload -- an expression whose cached value lost tiles is evaluated again from
+    its dependencies (CheckpointExpr overrides this with a reload from disk)."""
     return None
 
   def dependencies(self):

@@ -1,7 +1,8 @@
 """checkpoint: evaluate an expression and keep a copy of its tiles on disk (reference
 spartan/expr/operator/checkpoint.py).  Mode 'disk' saves through fio.save under `<path>/<expr_id>/`; `load_data`
-reads it back whole, or only the tiles listed as bad.  (The reference's 'replica' mode and the master's
-failure detector that triggers a reload are control plane, SURVEY 8f.4: not built.)"""
+reads it back whole, or only the tiles listed as bad (`Context.mark_failed_worker`, the GPU-reset model of a lost
+worker).  The reference's 'replica' mode and the heartbeat that DETECTS a dead worker (master.py:142-146) are control
+plane and not built: a dead rank is detected by torch.distributed's watchdog and restarted by the launcher."""
 import tempfile
 
 from . import base
@@ -33,7 +34,8 @@ class CheckpointExpr(Expr):
     if not self.ready or self.mode != 'disk':
       return None
     if cached_result is not None:
-      extents = workers_for_reload or {ex: cached_result.tiles[ex].worker for ex in list(cached_result.bad_tiles)}
+      from .. import context
+      extents = workers_for_reload or context.get().get_workers_for_reload(cached_result)
       for ex, tile_id in partial_load(extents, "%s" % self.expr_id, path=self.path, iszip=False).items():
         cached_result.tiles[ex] = tile_id
         cached_result.blob_to_ex[tile_id] = ex

@@ -142,3 +142,36 @@ def test_fio_hip(workers, tmp_path):
     _check(str(tmp_path))
   finally:
     sp.shutdown()
+
+
+def _failed_worker(backend_factory):
+  """tests/test_checkpoint.py:test1: a checkpointed value survives the loss of a worker (its bad tiles are reloaded
+  from disk when the value is used again); a value without a checkpoint is recomputed from its dependencies."""
+  ctx = sp.initialize(backend=backend_factory(), num_workers=4)
+  try:
+    a, b, c = sp.ones((10, 10)), sp.ones((10, 10)), sp.ones((10, 10))
+    x = a + b + c
+    y = x + x
+    z = sp.checkpoint(y + y, mode='disk')
+    zv = z.evaluate()
+    plain = (x * 2)
+    pv = plain.evaluate()
+    ctx.mark_failed_worker(0)
+    assert len(zv.bad_tiles) > 0 and len(pv.bad_tiles) > 0
+    res = z + z
+    np.testing.assert_array_equal(res.glom(), np.ones((10, 10)) * 24)
+    assert zv.bad_tiles == []                                   # reloaded in place (checkpoint.py:27-37)
+    np.testing.assert_array_equal((plain + 1).glom(), np.ones((10, 10)) * 7)     # recomputed
+  finally:
+    sp.shutdown()
+
+
+def test_failed_worker_reload_and_recompute_cpu():
+  from oracle.np_backend import NumpyBackend
+  _failed_worker(NumpyBackend)
+
+
+@pytest.mark.gpu
+def test_failed_worker_reload_and_recompute_gpu():
+  from spartan_amd.backend_hip import HipBackend
+  _failed_worker(HipBackend)
