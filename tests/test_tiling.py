@@ -190,3 +190,50 @@ def test_auto_tiled_programs_on_the_hip_backend():
   finally:
     opt.FLAGS['opt_auto_tiling'] = False
     sp.shutdown()
+
+
+def test_random_programs_do_not_change_under_auto_tiling():
+  """tests/test_random_autotiling.py in spirit: the random expression DAGs of tests/test_fuzz_gpu.py (maps, views,
+  reductions, argmax, means) and of its dot generator evaluate to the same values with the pass on and off
+  (reductions to a summation-order tolerance: another tiling is another summation tree)."""
+  from oracle.np_backend import NumpyBackend
+  from tests import test_fuzz_gpu as F
+  seeds = range(4000, 4120)
+
+  def run(flag):
+    out = {}
+    sp.initialize(backend=NumpyBackend(), num_workers=4)
+    opt.FLAGS['opt_auto_tiling'] = flag
+    try:
+      for s in seeds:
+        try:
+          with np.errstate(all='ignore'):
+            out[s] = F._program(s, sp)
+        except Exception as e:   # noqa: BLE001
+          out[s] = type(e).__name__
+      for s in range(20):
+        try:
+          out['dot%d' % s] = F._dot_case(s, sp)
+        except Exception as e:   # noqa: BLE001
+          out['dot%d' % s] = type(e).__name__
+    finally:
+      opt.FLAGS['opt_auto_tiling'] = False
+      sp.shutdown()
+    return out
+  off, on = run(False), run(True)
+  bad = []
+  for k in off:
+    a, b = off[k], on[k]
+    if isinstance(a, str) or isinstance(b, str):
+      if a != b and not isinstance(a, str):
+        bad.append((k, 'raised %s only with the pass on' % b))
+      continue
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+      bad.append((k, 'shape/dtype'))
+    elif a.dtype.kind in 'iub':
+      if not np.array_equal(a, b):
+        bad.append((k, 'integer result differs'))
+    elif not np.allclose(a, b, rtol=1e-5, atol=1e-6, equal_nan=True):
+      bad.append((k, 'float result differs'))
+  assert not bad, bad[:10]
