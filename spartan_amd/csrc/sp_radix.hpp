@@ -42,18 +42,35 @@ __device__ __forceinline__ void sp_radix_block_range(int b, int64_t n, int64_t s
   *hbase = seg * RDX * (int64_t)bpr + bi;      // + d * bpr
 }
 
+// One workgroup counts HIST_GROUP consecutive key blocks (one LDS histogram each) and then stores, for every digit,
+// the counters of its blocks side by side: with one block per workgroup the table was written as 4-byte stores
+// strided by the block count -- 1 GB of HBM writes for a 134 MB table (rocprofv3 WRITE_SIZE).
+constexpr int HIST_GROUP = 16;
+
 template <typename K, typename D>
 __global__ __launch_bounds__(256) void sp_radix_hist_kernel(const K* __restrict__ keys,
                                                             const int32_t* __restrict__ idx, int64_t n, D dig,
-                                                            int64_t seg_len, int bpr, int* __restrict__ hist) {
-  __shared__ int lh[RDX];
-  lh[threadIdx.x] = 0;
+                                                            int64_t seg_len, int bpr, int64_t nblk, int group,
+                                                            int* __restrict__ hist) {
+  __shared__ int lh[HIST_GROUP][RDX];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < group * RDX; i += 256) (&lh[0][0])[i] = 0;
   __syncthreads();
-  int64_t r0, r1, hbase;
-  sp_radix_block_range(blockIdx.x, n, seg_len, bpr, &r0, &r1, &hbase);
-  for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) atomicAdd(&lh[dig(keys[i], idx[i])], 1);
+  const int64_t b0 = (int64_t)blockIdx.x * group;
+  for (int k = 0; k < group && b0 + k < nblk; ++k) {
+    int64_t r0, r1, hbase;
+    sp_radix_block_range((int)(b0 + k), n, seg_len, bpr, &r0, &r1, &hbase);
+    for (int64_t i = r0 + tid; i < r1; i += 256) atomicAdd(&lh[k][dig(keys[i], idx[i])], 1);
+  }
   __syncthreads();
-  hist[hbase + (int64_t)threadIdx.x * bpr] = lh[threadIdx.x];
+  // lane (d % 16, k): 16 digits x 16 blocks per store instruction, a digit's 16 counters contiguous in memory when the
+  // blocks belong to one segment
+  const int k = tid & (group - 1);
+  if (b0 + k < nblk) {
+    int64_t r0, r1, hbase;
+    sp_radix_block_range((int)(b0 + k), n, seg_len, bpr, &r0, &r1, &hbase);
+    for (int d = tid / group; d < RDX; d += 256 / group) hist[hbase + (int64_t)d * bpr] = lh[k][d];
+  }
 }
 
 // One workgroup (4 wavefronts) per key block.  Wavefront w walks its quarter of the block in order, 64 keys at a
@@ -226,8 +243,10 @@ static inline int sp_radix_pass(SortWsT<K>& ws, int cur, int64_t n, D dig, hipSt
   const int bpr = (int)((seg_len + SORT_RB - 1) / SORT_RB);
   const int64_t nblk = sp_sort_blocks(n, seg_len);
   if (nblk > 2147483647LL / 2) SP_FAIL("radix sort: too many key blocks");
-  hipLaunchKernelGGL((sp_radix_hist_kernel<K, D>), dim3((unsigned)nblk), dim3(256), 0, st, ws.keys[cur], ws.idx[cur], n, dig,
-                     seg_len, bpr, ws.hist);
+  // (grouping only once there are enough key blocks to fill the chip with groups)
+  const int group = nblk >= (int64_t)HIST_GROUP * SP_CUS * SP_BLOCKS_PER_CU ? HIST_GROUP : 1;
+  hipLaunchKernelGGL((sp_radix_hist_kernel<K, D>), dim3((unsigned)((nblk + group - 1) / group)), dim3(256), 0, st,
+                     ws.keys[cur], ws.idx[cur], n, dig, seg_len, bpr, nblk, group, ws.hist);
   SP_CHECK_LAUNCH();
   if (sp_exscan_int(ws.hist, (int64_t)RDX * nblk, ws.sums, nullptr, st)) return 1;
   hipLaunchKernelGGL((sp_radix_rank_kernel<K, D>), dim3((unsigned)nblk), dim3(256), 0, st, ws.keys[cur], ws.idx[cur], n, dig,
