@@ -270,6 +270,20 @@ def guarded(fn, timeout_s, rank, fallback_line):
   return res
 
 
+def sort_section(ctx):
+  """np.sort / np.argsort of a BASELINE configs[2] tile (8192 x 65536 fp32) along its rows -- the tile body of
+  spartan.sort -- and of 4096-wide lines (the LDS path).  8 B per element read + written once is the HBM floor."""
+  out = {}
+  for rows, cols, tag in ((8192, 65536, 'radix_8192x65536'), (131072, 4096, 'lds_131072x4096')):
+    x = torch.rand((rows, cols), device='cuda', dtype=torch.float32)
+    ms = event_time(lambda: kernels.sort_rows(x, values=True, indices=False), 3, warmup=1)
+    out[tag + '_ms'] = round(ms, 3)
+    out[tag + '_Gkeys_per_s'] = round(rows * cols / ms / 1e6, 2)
+    del x
+    torch.cuda.empty_cache()
+  return out
+
+
 def cpu_baseline():
   """The NumPy oracle (a port of the reference's NumPy-worker path) on the host:
   one worker == one core (spartan/worker.py:40), BLAS pinned to one thread."""
@@ -327,14 +341,21 @@ def cpu_baseline():
   for _ in range(5):
     Wc.dot(xv)
   t_spmv = (time.perf_counter() - t0) / 5
+  # np.sort along the rows of a 1/16 sample of the `sort` section's tile
+  xs = rng.rand(512, 65536).astype(np.float32)
+  t0 = time.perf_counter()
+  np.sort(xs, axis=1)
+  t_sort = time.perf_counter() - t0
   return {'value': round(2.0 * n ** 3 / dt / 1e12, 4), 'unit': 'TFLOP/s', 'cores': cores, 'kind': 'port',
           'sample': 'oracle (NumPy port) spartan.dot %dx%dx%d fp32, 1 worker, %d BLAS thread(s), best of 2 '
                     '(%.2f s each); map x*x+x %.1f GB/s, sum axis0 %.1f GB/s on 4096x16384 fp32; '
                     'k-means iteration (map2 variant) on %dx%d points, k=%d: %.2f s = %.4f TFLOP/s of 2nkd; '
-                    'sparse multiply %dx%d, %d links per page (scipy CSR matvec): %.2f ms = %.2f GB/s'
+                    'sparse multiply %dx%d, %d links per page (scipy CSR matvec): %.2f ms = %.2f GB/s; '
+                    'np.sort of 512x65536 fp32 along rows: %.2f s = %.3f Gkeys/s'
                     % (n, n, n, cores, dt, 8.0 * x.size / t_map / 1e9, 4.0 * x.size / t_sum / 1e9,
                        kn, kd, kk, t_km, 2.0 * kn * kk * kd / t_km / 1e12,
-                       sn, sn, sdeg, t_spmv * 1e3, (Wc.nnz * 8 + sn * 16) / t_spmv / 1e9)}
+                       sn, sn, sdeg, t_spmv * 1e3, (Wc.nnz * 8 + sn * 16) / t_spmv / 1e9,
+                       t_sort, xs.size / t_sort / 1e9)}
 
 
 def main():
@@ -423,6 +444,8 @@ def main():
       line['kmeans'] = kmeans_section(ctx)
       torch.cuda.empty_cache()
       line['sparse'] = sparse_section(ctx)
+      torch.cuda.empty_cache()
+      line['sort'] = sort_section(ctx)
       line['cpu_baseline'] = cpu_baseline()
   if world.distributed:
     line['comm'] = dict(world.stats)
