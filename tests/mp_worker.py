@@ -85,6 +85,32 @@ def run_auto_tiling(world):
   return 1
 
 
+def run_sort(workers):
+  """sort / argsort along an axis and the sample sort (axis=None) with tiles on both ranks."""
+  rng = np.random.RandomState(5)
+  x = (rng.randn(64, 40) * 30).astype(np.float32)
+  x.flat[::9] = x.flat[0]
+  a = sp.from_numpy(x)
+  for axis in (0, 1):
+    np.testing.assert_array_equal(sp.sort(a, axis).glom(), np.sort(x, axis, kind='stable'))
+    np.testing.assert_array_equal(sp.argsort(a, axis).glom(), np.argsort(x, axis, kind='stable').astype(np.float32))
+  flat = sp.sort(a, axis=None).force()
+  np.testing.assert_array_equal(flat.glom(), np.sort(x, axis=None))
+  # stencil: every rank convolves its own image tiles
+  img = rng.randint(-3, 4, size=(4, 2, 8, 8)).astype(np.float32)
+  flt = rng.randint(-2, 3, size=(3, 2, 3, 3)).astype(np.float32)
+  res = sp.stencil(sp.from_numpy(img, tile_hint=(max(1, 4 // workers), 2, 8, 8)), sp.from_numpy(flt, tile_hint=(3, 2, 3, 3)), 1).glom()
+  want = np.zeros((4, 3, 8, 8), np.float32)
+  for xx in range(8):
+    for yy in range(8):
+      for i in range(3):
+        for j in range(3):
+          if xx + i < 8 and yy + j < 8:
+            want[:, :, xx, yy] += np.einsum('nc,fc->nf', img[:, :, xx + i, yy + j], flt[:, :, i, j])
+  np.testing.assert_array_equal(res, want)
+  return 2
+
+
 def main():
   workers = int(sys.argv[1])
   use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
@@ -134,6 +160,7 @@ def main():
   n += run_examples(workers)
   n += run_sparse(workers)
   n += run_auto_tiling(world)
+  n += run_sort(workers)
   world.barrier()
   print('RANK %d OK %d' % (world.rank, n))
   sys.stdout.flush()
