@@ -44,7 +44,7 @@ def _p(t):
 
 class CsrTile(object):
   """Device blob of a sparse tile."""
-  __slots__ = ('shape', 'dtype', 'indptr', 'indices', 'data', '_plan')
+  __slots__ = ('shape', 'dtype', 'indptr', 'indices', 'data', '_plan', '_transposed')
   is_sparse_tile = True
 
   def __init__(self, shape, dtype, indptr, indices, data):
@@ -54,6 +54,7 @@ class CsrTile(object):
     self.indices = indices
     self.data = data
     self._plan = None      # sp_csr_spmv_plan output, made on the first matrix x vector product and kept
+    self._transposed = None   # the transposed tile, made on first use and kept (tiles are immutable)
 
   @property
   def nnz(self):
@@ -172,7 +173,11 @@ def reshape_rect(t, offset, shape):
 
 
 def transpose(t):
-  return from_coo((t.shape[1], t.shape[0]), t.dtype, t.indices.clone(), rows_of(t), t.data)
+  """The transposed tile (column sums, dense x sparse and Transpose views ask for it repeatedly: kept on the tile)."""
+  if t._transposed is None:
+    tt = from_coo((t.shape[1], t.shape[0]), t.dtype, t.indices.clone(), rows_of(t), t.data)
+    t._transposed = tt        # (one direction only: a cycle would keep both alive until the cyclic GC runs)
+  return t._transposed
 
 
 def add(a, b, sign=1):
