@@ -7,6 +7,8 @@ CollapsedCachedExpressions) and `optimize` (:1072-1081); the auto-tiling pass
 (:459-1054) lives in expr/tiling.py.  Parakeet generation and slice rotation are
 outside the tile-kernel path.
 """
+import weakref
+
 from .base import AsArray, Expr, ListExpr, Val, expr_like, lazify
 from .local import LocalInput, LocalMapLocationExpr, LocalReduceExpr, make_var
 from .map import MapExpr
@@ -31,6 +33,9 @@ def not_idempotent(fn):
     if isinstance(result, Expr):
       result.needs_cache = True
       _not_idempotent_list.add(id(result))
+      # the reference keys this set by id() and never removes entries (optimize.py:60-68): once the expression is
+      # gone its id can be handed to an unrelated one, which would then silently stop fusing -- forget the id with it
+      weakref.finalize(result, _not_idempotent_list.discard, id(result))
     return result
   return wrapped
 
