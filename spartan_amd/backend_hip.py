@@ -662,15 +662,16 @@ class HipBackend(object):
 
   def sparse_random(self, shape, density, dtype):
     """scipy.sparse.rand's role (srandom.py:57-65) from the counter-based generator: int(density * size)
-    uniformly drawn positions (colliding ones merge, their values add), uniform [0, 1) values."""
+    uniformly drawn positions (colliding ones merge), uniform [0, 1) values."""
     m, n = int(shape[0]), int(shape[1])
     k = int(density * m * n)
     if k <= 0 or m == 0 or n == 0:
       return self.sparse_empty((m, n), dtype)
     rows = self.random_tile('randint', (k,), np.int32, 0, m)
     cols = self.random_tile('randint', (k,), np.int32, 0, n)
-    vals = self.random_tile('uniform', (k,), dtype)
-    return sparse_mod.from_coo((m, n), dtype, rows, cols, vals)
+    t = sparse_mod.from_coo((m, n), dtype, rows, cols, self.zeros((k,), dtype))
+    # one uniform value per KEPT position (positions drawn twice were merged), so every value is in [0, 1)
+    return sparse_mod.CsrTile(t.shape, t.dtype, t.indptr, t.indices, self.random_tile('uniform', (t.nnz,), dtype))
 
   def _sparse_dot(self, a, b):
     """tile_a.dot(tile_b) with a sparse operand (dot.py:212-240)."""

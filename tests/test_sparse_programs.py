@@ -119,7 +119,7 @@ def _sparse_rand(backend_factory):
     g = x.glom()
     assert sps.issparse(g) and g.shape == (400, 300) and g.dtype == np.float32
     assert 0.03 * 120000 < g.nnz <= 0.05 * 120000 + 4          # colliding positions are merged
-    assert g.data.min() >= 0 and g.data.max() < 4.0             # (values of merged positions add)
+    assert g.data.min() >= 0 and g.data.max() < 1.0
     e = sp.sparse_empty((30, 20)).force().glom()
     assert sps.issparse(e) and e.nnz == 0 and e.shape == (30, 20)   # (float64: tile.pyx:77, see Tile.get)
     total = float(sp.sum(sp.Val(val=x)).glom())
