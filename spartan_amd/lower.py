@@ -76,8 +76,9 @@ def apply(opname, np_fn, args):
   if all(a.kind == 'const' for a in args):
     with np.errstate(all='ignore'):
       r = np_fn(*[a.value if a.weak else np.dtype(a.dtype).type(a.value) for a in args])
-    if all(a.weak for a in args):
-      return const(r.item() if isinstance(r, np.generic) else r)
+    # a ufunc applied to Python scalars returns a NumPy scalar, which is STRONGLY typed from then on
+    # (np.abs(2) + 1 is np.int64(3); fp32 % np.int64(3) is float64) -- the same value the unfused evaluation of
+    # this sub-tree produces as a 0-d tile
     return const(np.asarray(r)[()])
   with np.errstate(all='ignore'):
     res = np_fn(*[_dummy(a) for a in args])
