@@ -200,3 +200,54 @@ def test_sparse_scan_cpu():
 def test_sparse_scan_gpu():
   from spartan_amd.backend_hip import HipBackend
   _sparse_scan(HipBackend)
+
+
+def _framework_fuzz(backend_factory, n_cases):
+  """Random shapes, tilings and worker counts through the expression API; integer values, expectations from the
+  dense NumPy evaluation of the same program."""
+  rng = np.random.RandomState(99)
+  for case in range(n_cases):
+    workers = int(rng.choice([1, 2, 4]))
+    m, k, n = [int(v) for v in rng.choice([8, 12, 20, 36, 64], size=3)]
+
+    def hint(shape):
+      kind = rng.randint(3)
+      if kind == 0:
+        return None
+      if kind == 1:
+        return (max(1, shape[0] // workers), shape[1])
+      return (shape[0], max(1, shape[1] // workers))
+    ha, hb = hint((m, k)), hint((k, n))
+    da = np.asarray(sparse_programs.link_block((0, 0), (m, k), 100 + case).todense())
+    db = np.asarray(sparse_programs.link_block((0, 0), (k, n), 200 + case).todense())
+    x = (np.arange(k * 3, dtype=np.float32).reshape(k, 3) % 5) - 2
+    sp.initialize(backend=backend_factory(), num_workers=workers)
+    try:
+      A = sparse_programs.links(sp, (m, k), 100 + case, ha)
+      B = sparse_programs.links(sp, (k, n), 200 + case, hb)
+      tag = 'case %d: %s x %s, %d workers, hints %s %s' % (case, (m, k), (k, n), workers, ha, hb)
+      checks = [
+          (lambda: sp.dot(A, sp.from_numpy(x)), da @ x),
+          (lambda: sp.sum(A, axis=0), da.sum(0)),
+          (lambda: sp.sum(A, axis=1), da.sum(1)),
+          (lambda: sp.add(A, A), da + da),
+          (lambda: sp.transpose(A), da.T),
+          (lambda: sp.add(A, sp.ones((m, k))), da + 1),
+      ]
+      checks.append((lambda: sp.dot(A, B), da @ db))       # (any tiling: sparse tiles are sliceable here)
+      for build, want in checks:
+        got, _ = sparse_programs.to_dense(build().force().glom() if hasattr(build(), 'force') else build().glom())
+        np.testing.assert_array_equal(got, want, err_msg=tag)
+    finally:
+      sp.shutdown()
+
+
+def test_sparse_framework_fuzz_cpu():
+  from oracle.np_backend import NumpyBackend
+  _framework_fuzz(NumpyBackend, 30)
+
+
+@pytest.mark.gpu
+def test_sparse_framework_fuzz_gpu():
+  from spartan_amd.backend_hip import HipBackend
+  _framework_fuzz(HipBackend, 30)
