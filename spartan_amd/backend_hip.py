@@ -702,6 +702,9 @@ class HipBackend(object):
       args = [ev(d) for d in node.deps]
       flags = [tile.is_sparse_blob(a) for a in args]
       fn = node.fn
+      if getattr(fn, '_sp_tile_fn', False):      # a builder that works on blobs itself (sparse_diagonal ...), fused in
+        self.launches += 1
+        return fn(*args, **(node.kw or {}))
       if isinstance(fn, np.ufunc) and len(args) == 2 and (flags[0] ^ flags[1]):
         args = [self.sparse_to_dense(a) if f else a for a, f in zip(args, flags)]
         flags = [False, False]
@@ -718,6 +721,8 @@ class HipBackend(object):
         return sparse_mod.scaled(args[0], -1.0)
       if fn is np.multiply and len(args) == 2 and sum(flags) == 1:
         other = args[1] if flags[0] else args[0]
+        if isinstance(other, np.ndarray) and other.ndim == 0:
+          other = other[()]
         if isinstance(other, (int, float, np.generic)):
           return sparse_mod.scaled(args[0] if flags[0] else args[1], float(other))
       raise NotImplementedError('%s on sparse tiles is not supported on the GPU backend' % node.fn_name())
