@@ -429,6 +429,12 @@ int sp_tiling_solve(int32_t n_nodes, int64_t n_edges, const int32_t* edge_u, con
                     const double* edge_cost, int32_t n_groups, const int32_t* group_ptr, const int32_t* group_nodes,
                     int32_t* choice, double* total);
 
+/* sp_gather_rows: dst[i, :] = src[idx[i], :] -- integer-array indexing `x[idx]`, the tile body of _int_index_mapper
+ * (spartan/expr/operator/filter.py:50-75).  Rows of row_bytes bytes (a multiple of 4), source rows
+ * src_row_stride_bytes apart; idx int64 on the device, negative values count from the end. */
+int sp_gather_rows(const void* d_src, int64_t src_row_stride_bytes, int64_t n_src_rows, const int64_t* d_idx,
+                   int64_t n_idx, int64_t row_bytes, void* d_dst, void* stream);
+
 /* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
  * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
 int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);

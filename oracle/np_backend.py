@@ -282,6 +282,10 @@ class NumpyBackend(object):
         out[:, :, :part.shape[2], :part.shape[3]] = np.maximum(out[:, :, :part.shape[2], :part.shape[3]], part)
     return self._wrap(out)
 
+  def gather_rows(self, block, rows):
+    self.launches += 1
+    return self._wrap(_np(block)[np.asarray(rows, dtype=np.int64)])
+
   def cumscan(self, t, axis, product=False):
     """scan.py:63."""
     self.launches += 1

@@ -136,6 +136,7 @@ def _declare(lib):
   lib.sp_sort_rows_workspace_bytes.restype = sz
   lib.sp_sort_rows.argtypes = [vp, i32, i64, i64, vp, vp, vp, sz, vp]
   lib.sp_tiling_solve.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
+  lib.sp_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp]
   lib.sp_stream_copy.argtypes = [vp, vp, sz, vp]
   lib.sp_event_create.argtypes = [pp]
   lib.sp_event_destroy.argtypes = [vp]
@@ -153,7 +154,7 @@ EXPORTS = [
     'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
     'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_random_fill', 'sp_cumscan',
     'sp_coo_to_csr_workspace_bytes', 'sp_coo_to_csr', 'sp_csr_rows', 'sp_coo_box', 'sp_coo_reshape', 'sp_csr_spmm_workspace_bytes', 'sp_csr_spmv_plan_entries', 'sp_csr_spmv_plan', 'sp_csr_spmm', 'sp_csr_scatter',
-    'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_sort_rows_workspace_bytes', 'sp_sort_rows', 'sp_tiling_solve', 'sp_stream_copy', 'sp_event_create',
+    'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_sort_rows_workspace_bytes', 'sp_sort_rows', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',
 ]
 

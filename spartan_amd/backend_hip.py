@@ -570,6 +570,11 @@ class HipBackend(object):
         self.update_box(out, (0, 0, 0, 0), tuple(part.shape), part, np.maximum, tile.MASK_ALL_SET, None)
     return out
 
+  def gather_rows(self, block, rows):
+    """block[rows] along axis 0 (filter.py:50-75); `rows` is a host int64 vector relative to the block."""
+    self.launches += 1
+    return kernels.gather_rows(self.contiguous(self._as_device(block)), self.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)))
+
   def cumscan(self, t, axis, product=False):
     """np.cumsum / np.cumprod along `axis` (sp_cumscan)."""
     t = self.contiguous(t)

@@ -481,3 +481,45 @@ extern "C" int sp_cumscan(const void* d_in, void* d_out, int32_t dtype, int64_t 
   SP_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ------------------------------------------------------------------ row gather (integer-array indexing)
+// dst[i, :] = src[idx[i], :] for rows of `row_bytes` bytes: the tile body of the reference's _int_index_mapper
+// (spartan/expr/operator/filter.py:50-75, one src.select(row) per index there).  One thread per 4-byte word
+// (16-byte words when the row length and both bases allow); negative indices count from the end like NumPy's.
+template <typename W>
+__global__ __launch_bounds__(256) void sp_gather_rows_kernel(const W* __restrict__ src, int64_t src_row_words,
+                                                             const int64_t* __restrict__ idx, int64_t n_idx,
+                                                             int64_t n_src_rows, int64_t row_words,
+                                                             W* __restrict__ dst) {
+  const int64_t total = n_idx * row_words;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / row_words, w = e - i * row_words;
+    int64_t r = idx[i];
+    if (r < 0) r += n_src_rows;
+    dst[e] = src[r * src_row_words + w];
+  }
+}
+
+extern "C" int sp_gather_rows(const void* d_src, int64_t src_row_stride_bytes, int64_t n_src_rows, const int64_t* d_idx,
+                              int64_t n_idx, int64_t row_bytes, void* d_dst, void* stream) {
+  if (n_idx < 0 || row_bytes < 0 || n_src_rows < 0 || src_row_stride_bytes < row_bytes) SP_FAIL("sp_gather_rows: bad sizes");
+  if (n_idx == 0 || row_bytes == 0) return 0;
+  if (!d_src || !d_idx || !d_dst) SP_FAIL("sp_gather_rows: NULL pointer");
+  if (row_bytes % 4 || src_row_stride_bytes % 4) SP_FAIL("sp_gather_rows: rows must be a multiple of 4 bytes");
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = row_bytes % 16 == 0 && src_row_stride_bytes % 16 == 0 && ((uintptr_t)d_src % 16) == 0 &&
+                    ((uintptr_t)d_dst % 16) == 0;
+  const int64_t words = wide ? row_bytes / 16 : row_bytes / 4;
+  int64_t blocks = (n_idx * words + 255) / 256;
+  const int64_t cap = (int64_t)SP_CUS * SP_BLOCKS_PER_CU * 4;
+  if (blocks > cap) blocks = cap;
+  if (wide)
+    hipLaunchKernelGGL((sp_gather_rows_kernel<float4>), dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)d_src,
+                       src_row_stride_bytes / 16, d_idx, n_idx, n_src_rows, words, (float4*)d_dst);
+  else
+    hipLaunchKernelGGL((sp_gather_rows_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)d_src,
+                       src_row_stride_bytes / 4, d_idx, n_idx, n_src_rows, words, (uint32_t*)d_dst);
+  SP_CHECK_LAUNCH();
+  return 0;
+}

@@ -378,7 +378,8 @@ def _getitem(self, idx):
           new_shape.pop(i)
       return ReshapeExpr(array=ret, new_shape=tuple(new_shape), tile_hint=None)
     return SliceExpr(src=self, idx=idx, broadcast_to=None)
-  raise NotImplementedError('boolean / integer-array indexing (FilterExpr) is outside the tile path')
+  from .filter import filter_expr      # base.py:445-447: anything else is an index ARRAY
+  return filter_expr(self, idx)
 
 
 Expr.__getitem__ = _getitem

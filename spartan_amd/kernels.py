@@ -223,6 +223,20 @@ def sort_rows(src, values=True, indices=False):
   return vals, idx
 
 
+def gather_rows(src, idx):
+  """src[idx] along axis 0 for a contiguous tensor and a device int64 index vector (filter.py:50-75)."""
+  _require_device(src, idx)
+  assert src.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+  n = int(idx.numel())
+  row = int(np.prod(src.shape[1:], dtype=np.int64)) * src.element_size()
+  out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+  if row % 4:
+    raise _hip.HipError('gather_rows: rows of %d bytes (need a multiple of 4)' % row)
+  check(_hip.lib().sp_gather_rows(C.c_void_p(src.data_ptr()), row, int(src.shape[0]), C.c_void_p(idx.data_ptr()), n, row,
+                                  C.c_void_p(out.data_ptr()), _stream()))
+  return out
+
+
 def stream_copy(dst, src):
   _require_device(dst, src)
   n = src.numel() * src.element_size()

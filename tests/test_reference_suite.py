@@ -1,7 +1,7 @@
 """What the reference's own dense test files check (tests/test_*.py of spartan-array/spartan), restated
 against this framework: same builders, same expectations, NumPy as the yardstick exactly as there.
 Each test names the reference test it follows.  CPU leg: host framework on the oracle backend;
-GPU leg: HIP backend.  (Sparse cases of those files are outside the GPU tile path.)"""
+GPU leg: HIP backend.  (The sparse cases of those files live in tests/test_sparse_programs.py.)"""
 import numpy as np
 import pytest
 
@@ -267,7 +267,24 @@ def check_scan():
   np.testing.assert_array_equal(spartan.scan(spartan.from_numpy(w), np.prod, np.cumprod, axis=1).glom(), np.cumprod(w, 1))
 
 
-CHECKS = [check_scan, check_reshape, check_example_runs, check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
+def check_array_indexing():
+  """x[idx] with an integer ARRAY (spartan/expr/operator/filter.py): rows gathered in index order, negative and
+  repeated indices like NumPy; a boolean index is refused (the reference returns MaskedArray tiles)."""
+  rng = np.random.RandomState(4)
+  for shape, dtype in (((40, 6), np.float32), ((33,), np.float64), ((20, 3, 5), np.int64), ((64, 8), np.int32)):
+    x = (rng.randn(*shape) * 10).astype(dtype)
+    idx = rng.randint(-shape[0], shape[0], size=27)
+    X = spartan.from_numpy(x)
+    np.testing.assert_array_equal(X[idx].glom(), x[idx])
+    pos = np.abs(idx) % shape[0]
+    np.testing.assert_array_equal((X * 2)[spartan.from_numpy(pos)].glom(), (x * 2)[pos])
+    np.testing.assert_array_equal(spartan.sum(X[np.array([0, 0, shape[0] - 1])], axis=0).glom(), x[[0, 0, shape[0] - 1]].sum(0))
+  with pytest.raises(NotImplementedError):
+    (spartan.from_numpy(x)[np.array([True, False] * (x.shape[0] // 2))]).glom()
+
+
+
+CHECKS = [check_array_indexing, check_scan, check_reshape, check_example_runs, check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
           check_statistics, check_manipulation, check_assign, check_write]
 
 
