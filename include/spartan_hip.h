@@ -200,6 +200,8 @@ int sp_program_static_id(const sp_program* prog, int32_t out_dtype);
  *   sp_jit_compiled_count kernels specialised so far.
  *   sp_jit_compile_check  does `template_expr` (a kernel template-id naming the program
  *                         type StaticProg<1000>) compile for `prog`?  Needs no device. */
+/* Environment: SPARTAN_JIT_CACHE=<directory> keeps the code objects hipRTC produced there (one file per library
+ * build x header x kernel x program) and later processes load them instead of compiling. */
 int sp_jit_configure(int enabled, long long min_elems);
 void sp_jit_wait(void);
 int sp_jit_compiled_count(void);

@@ -25,6 +25,9 @@
 #include <unordered_map>
 #include <vector>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "sp_jit.hpp"
 
 namespace {
@@ -121,6 +124,63 @@ std::string program_key(const char* header, const char* expr, const sp_program* 
   return k;
 }
 
+// ---- code objects kept across processes (opt-in: SPARTAN_JIT_CACHE=<directory>) -------------------------------
+// One file per (library build, header, template expression, program): the lowered kernel name and the code object
+// hipRTC produced.  The build id is the size and modification time of this shared library and of the header the
+// kernel is instantiated from, so a rebuilt library never loads code compiled from older sources.
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+std::string cache_dir() {
+  const char* e = getenv("SPARTAN_JIT_CACHE");
+  return e && *e ? std::string(e) : std::string();
+}
+
+std::string stat_id(const std::string& path) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) return "?";
+  return std::to_string((long long)st.st_size) + "." + std::to_string((long long)st.st_mtime);
+}
+
+std::string cache_path(const char* header, const char* expr, const sp_program* p);
+
+hipFunction_t cache_load(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return nullptr;
+  hipFunction_t fn = nullptr;
+  uint32_t name_len = 0;
+  uint64_t code_len = 0;
+  if (fread(&name_len, 4, 1, f) == 1 && name_len < 4096 && fread(&code_len, 8, 1, f) == 1 && code_len < (1ull << 30)) {
+    std::string name(name_len, 0);
+    std::vector<char> code(code_len);
+    if (fread(&name[0], 1, name_len, f) == name_len && fread(code.data(), 1, code_len, f) == code_len) {
+      hipModule_t mod = nullptr;
+      if (hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(&fn, mod, name.c_str()) != hipSuccess)
+        fn = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  fclose(f);
+  return fn;
+}
+
+void cache_store(const std::string& path, const char* lowered, const std::vector<char>& code) {
+  const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const uint32_t name_len = (uint32_t)strlen(lowered);
+  const uint64_t code_len = code.size();
+  const bool ok = fwrite(&name_len, 4, 1, f) == 1 && fwrite(&code_len, 8, 1, f) == 1 &&
+                  fwrite(lowered, 1, name_len, f) == name_len && fwrite(code.data(), 1, code_len, f) == code_len;
+  fclose(f);
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());   // (rename: readers never see half a file)
+}
+
 std::mutex g_mu;
 std::unordered_map<std::string, hipFunction_t> g_cache;   // value NULL = pending, or tried and failed
 
@@ -144,6 +204,14 @@ hipFunction_t compile(const char* header, const char* expr, const sp_program* p,
   Rtc& r = rtc();
   if (!r.ok) return nullptr;
   const std::string dir = source_dir();
+  const std::string disk = load && !cache_dir().empty() ? cache_path(header, expr, p) : std::string();
+  if (!disk.empty()) {
+    hipFunction_t cached = cache_load(disk);
+    if (cached) {
+      if (verbose()) fprintf(stderr, "[spartan_hip jit] loaded %s from %s\n", expr, disk.c_str());
+      return cached;
+    }
+  }
   std::string src = "#include \"" + std::string(header) + "\"\n" + program_struct(p);
   rtcProgram prog = nullptr;
   if (r.create(&prog, src.c_str(), "sp_jit_program.hip", 0, nullptr, nullptr) != 0) return nullptr;
@@ -189,12 +257,21 @@ hipFunction_t compile(const char* header, const char* expr, const sp_program* p,
           if (hipModuleGetFunction(&fn, mod, lowered) != hipSuccess) fn = nullptr;
         }
         (void)hipGetLastError();
+        if (fn && !disk.empty()) cache_store(disk, lowered, code);
       }
     }
     if (verbose()) fprintf(stderr, "[spartan_hip jit] %s %s (%d instrs)\n", fn ? "compiled" : "load failed", expr, p->n_instr);
   }
   r.destroy(&prog);
   return fn;
+}
+
+std::string cache_path(const char* header, const char* expr, const sp_program* p) {
+  const std::string dir = source_dir();
+  const std::string id = stat_id(dir + "/libspartan_hip.so") + "|" + stat_id(dir + "/" + header) + "|" + stat_id(dir + "/sp_interp.hpp");
+  char name[64];
+  snprintf(name, sizeof(name), "/%016llx.spco", (unsigned long long)fnv1a(program_key(header, expr, p), fnv1a(id)));
+  return cache_dir() + name;
 }
 
 }  // namespace

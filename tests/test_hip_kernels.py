@@ -709,3 +709,29 @@ def test_gemm_split_k(mnk, dt):
   np.testing.assert_array_equal(outs[0], outs[1])
   ref = x.astype(np.float64).dot(y.astype(np.float64))
   np.testing.assert_allclose(outs[0], ref, rtol=0, atol=(2e-4 if dt == np.float32 else 1e-10) * np.sqrt(K))
+
+
+def test_jit_code_objects_persist_across_processes(tmp_path):
+  """SPARTAN_JIT_CACHE=<dir>: the first process compiles a run-time specialised kernel and leaves its code object in
+  the directory, the second loads it instead of compiling (same result; `loaded ... from` in the verbose log)."""
+  import subprocess
+  import sys
+  import os
+  prog = (
+      "import numpy as np, torch, spartan_amd as sp\n"
+      "sp.initialize('hip')\n"
+      "x = sp.from_numpy(np.arange(1 << 16, dtype=np.float32).reshape(256, 256) / 7)\n"
+      "r = (sp.sqrt(sp.abs(x * 3 - 2)) * x + x / 5 - 1).optimized().glom()\n"
+      "print('SUM %.6f' % float(r.astype(np.float64).sum()))\n")
+  env = dict(os.environ, SPARTAN_JIT_CACHE=str(tmp_path), SP_JIT_SYNC='1', SP_JIT_MIN_ELEMS='0', SP_JIT_VERBOSE='1')
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  outs = []
+  for _ in range(2):
+    p = subprocess.run([sys.executable, '-c', prog], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    outs.append(p)
+  files = [f for f in os.listdir(str(tmp_path)) if f.endswith('.spco')]
+  assert files, 'no code object was written'
+  assert 'compiled' in outs[0].stderr and 'loaded' not in outs[0].stderr
+  assert 'loaded' in outs[1].stderr and ' compiled ' not in outs[1].stderr
+  assert outs[0].stdout.strip().splitlines()[-1] == outs[1].stdout.strip().splitlines()[-1]
