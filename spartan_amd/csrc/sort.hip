@@ -5,7 +5,8 @@
 // The sort is STABLE (equal keys keep their order, np.argsort(kind='stable')); NaNs go last like NumPy's,
 // -0.0 and +0.0 compare equal.  Values are gathered from the input by the sorted positions, so the output holds
 // the input's bit patterns.
-//   rows of <= 4096 32-bit elements : bitonic network on (key, column) pairs in LDS, one HBM pass
+//   rows of <= 4096 32-bit elements : bitonic network on (key, column) pairs in LDS (packed as doubles: a
+//                                     compare-exchange is v_min_f64 + v_max_f64), one HBM pass
 //   anything else                   : LSD radix sort, sizeof(T) passes over the key bytes, every line a SEGMENT of
 //                                     the same launches (sp_radix.hpp: histogram [line][digit][block], one scan).
 //                                     Lines too short for per-line histograms (64-bit types, < 256 elements) are
@@ -118,42 +119,62 @@ __global__ __launch_bounds__(256) void sp_sort_emit_kernel(const T* __restrict__
 
 constexpr int LDS_SORT_E = 4096;   // (key, column) pairs per workgroup: 32 KB
 
-// NB consecutive sub-stages (compare distances 2^(lowbit+NB-1) ... 2^lowbit) of bitonic level k on the 2^NB
-// elements base + (m << lowbit), held in registers.
+// The (key, column) pair of an element as a DOUBLE in [1, 2): exponent 0x3FF, the 32-bit key in mantissa bits 51..20,
+// the column in bits 19..7.  Doubles of one exponent order like their mantissas, so a compare-exchange is
+// v_min_f64 + v_max_f64 -- two instructions instead of a 64-bit integer compare and four selects.  Padding slots hold
+// the largest such value (column field 0x1FFF, above every real column).
+__device__ __forceinline__ double sp_pack_pair(uint32_t key, uint32_t col) {
+  return __longlong_as_double((long long)((0x3FFull << 52) | ((uint64_t)key << 20) | ((uint64_t)col << 7)));
+}
+__device__ __forceinline__ void sp_ce(double& lo, double& hi) {
+  const double a = __builtin_fmin(lo, hi), b = __builtin_fmax(lo, hi);
+  lo = a;
+  hi = b;
+}
+
+// NB consecutive half-cleaner sub-stages (compare distances 2^(lowbit+NB-1) ... 2^lowbit, partner = i ^ distance, all
+// ascending) on the 2^NB elements base + (m << lowbit), held in registers: one trip through LDS for NB sub-stages.
 template <int NB>
-__device__ __forceinline__ void sp_bitonic_round(uint64_t* sm, int tid, int lowbit, int k, int npad) {
+__device__ __forceinline__ void sp_bitonic_round(double* sm, int tid, int lowbit) {
   constexpr int G = 1 << NB;
   for (int gid = tid; gid < LDS_SORT_E / G; gid += 256) {
     const int base = ((gid >> lowbit) << (lowbit + NB)) | (gid & ((1 << lowbit) - 1));
-    // every element of the group lies in the same run of length k (k > the largest compare distance): one direction
-    const bool asc = ((base & (npad - 1)) & k) == 0;
-    uint64_t r[G];
+    double r[G];
 #pragma unroll
     for (int m = 0; m < G; ++m) r[m] = sm[base + (m << lowbit)];
 #pragma unroll
     for (int b = NB - 1; b >= 0; --b) {
 #pragma unroll
-      for (int m = 0; m < G; ++m) {
-        if ((m & (1 << b)) == 0) {
-          const uint64_t x = r[m], y = r[m | (1 << b)];
-          const bool sw = (x > y) == asc;
-          r[m] = sw ? y : x;
-          r[m | (1 << b)] = sw ? x : y;
-        }
-      }
+      for (int m = 0; m < G; ++m)
+        if ((m & (1 << b)) == 0) sp_ce(r[m], r[m | (1 << b)]);
     }
 #pragma unroll
     for (int m = 0; m < G; ++m) sm[base + (m << lowbit)] = r[m];
   }
 }
 
-// `npad` = cols rounded up to a power of two; a workgroup sorts LDS_SORT_E / npad rows at once.  The compare
-// direction of the bitonic network is taken from the index INSIDE the row, so every row ends ascending.
+// first sub-stage of level l (runs of 2^(l-1), both ascending, merged into runs of 2^l): element i against its MIRROR
+// inside the run of 2^l, i ^ (2^l - 1).  With the mirror first, every later compare-exchange of the level is ascending
+// (no direction flags).
+__device__ __forceinline__ void sp_bitonic_mirror(double* sm, int tid, int l) {
+  const int half = 1 << (l - 1), k = 1 << l;
+  for (int t = tid; t < LDS_SORT_E / 2; t += 256) {
+    const int i = ((t >> (l - 1)) << l) | (t & (half - 1));
+    const int p = i ^ (k - 1);
+    double a = sm[i], b = sm[p];
+    sp_ce(a, b);
+    sm[i] = a;
+    sm[p] = b;
+  }
+}
+
+// `npad` = cols rounded up to a power of two; a workgroup sorts LDS_SORT_E / npad rows at once (every compare distance
+// is below npad, so rows never mix).
 template <typename T>
 __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restrict__ in, int64_t rows, int cols, int npad,
                                                                int log_npad, T* __restrict__ out_vals,
                                                                int64_t* __restrict__ out_idx) {
-  __shared__ uint64_t sm[LDS_SORT_E];
+  __shared__ double sm[LDS_SORT_E];
   const int tid = threadIdx.x;
   const int rpw = LDS_SORT_E >> log_npad;
   const int64_t nblocks = (rows + rpw - 1) / rpw;
@@ -161,25 +182,23 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
     for (int e = tid; e < LDS_SORT_E; e += 256) {
       const int c = e & (npad - 1);
       const int64_t r = rb * rpw + (e >> log_npad);
-      uint64_t v = ~0ull;
-      if (r < rows && c < cols) v = ((uint64_t)key32(in[r * cols + c]) << 32) | (uint32_t)c;
+      double v = sp_pack_pair(0xFFFFFFFFu, 0x1FFFu);
+      if (r < rows && c < cols) v = sp_pack_pair(key32(in[r * cols + c]), (uint32_t)c);
       sm[e] = v;
     }
     __syncthreads();
-    // level l merges runs of 2^(l-1) into runs of 2^l: sub-stages j = 2^(l-1) ... 1.  A thread takes 2^NB elements
-    // whose indices differ in NB consecutive bits and runs NB sub-stages on them in registers, so a level costs
-    // ceil(l / 4) trips through LDS instead of l.
     for (int l = 1; l <= log_npad; ++l) {
-      const int k = 1 << l;
-      int jbit = l - 1;
+      sp_bitonic_mirror(sm, tid, l);
+      __syncthreads();
+      int jbit = l - 2;                    // remaining sub-stages: distances 2^(l-2) ... 1
       while (jbit >= 0) {
         const int nb = jbit + 1 < 4 ? jbit + 1 : 4;
         const int lowbit = jbit - nb + 1;
         switch (nb) {
-          case 4: sp_bitonic_round<4>(sm, tid, lowbit, k, npad); break;
-          case 3: sp_bitonic_round<3>(sm, tid, lowbit, k, npad); break;
-          case 2: sp_bitonic_round<2>(sm, tid, lowbit, k, npad); break;
-          default: sp_bitonic_round<1>(sm, tid, lowbit, k, npad); break;
+          case 4: sp_bitonic_round<4>(sm, tid, lowbit); break;
+          case 3: sp_bitonic_round<3>(sm, tid, lowbit); break;
+          case 2: sp_bitonic_round<2>(sm, tid, lowbit); break;
+          default: sp_bitonic_round<1>(sm, tid, lowbit); break;
         }
         __syncthreads();
         jbit -= nb;
@@ -190,13 +209,13 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
       const int c = e & (npad - 1);
       const int64_t r = rb * rpw + (e >> log_npad);
       if (r < rows && c < cols) {
-        const uint64_t kv = sm[e];
+        const uint64_t bits = (uint64_t)__double_as_longlong(sm[e]);
         if (out_vals) {
           T v = 0;
-          if (!unkey32((uint32_t)(kv >> 32), &v)) special = 1;
+          if (!unkey32((uint32_t)(bits >> 20), &v)) special = 1;
           out_vals[r * cols + c] = v;
         }
-        if (out_idx) out_idx[r * cols + c] = (int64_t)(kv & 0xFFFFFFFFull);
+        if (out_idx) out_idx[r * cols + c] = (int64_t)((bits >> 7) & 0x1FFFu);
       }
     }
     // NaNs and zeros: the key does not hold their bits (payload, sign) -- a second, rarely taken pass gathers them
@@ -206,9 +225,9 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
         const int c = e & (npad - 1);
         const int64_t r = rb * rpw + (e >> log_npad);
         if (r < rows && c < cols) {
-          const uint64_t kv = sm[e];
+          const uint64_t bits = (uint64_t)__double_as_longlong(sm[e]);
           T v;
-          if (!unkey32((uint32_t)(kv >> 32), &v)) out_vals[r * cols + c] = in[r * cols + (uint32_t)(kv & 0xFFFFFFFFull)];
+          if (!unkey32((uint32_t)(bits >> 20), &v)) out_vals[r * cols + c] = in[r * cols + ((bits >> 7) & 0x1FFFu)];
         }
       }
     }
