@@ -134,10 +134,10 @@ __device__ __forceinline__ void sp_ce(double& lo, double& hi) {
 
 // NB consecutive half-cleaner sub-stages (compare distances 2^(lowbit+NB-1) ... 2^lowbit, partner = i ^ distance, all
 // ascending) on the 2^NB elements base + (m << lowbit), held in registers: one trip through LDS for NB sub-stages.
-template <int NB>
+template <int NB, int E>
 __device__ __forceinline__ void sp_bitonic_round(double* sm, int tid, int lowbit) {
   constexpr int G = 1 << NB;
-  for (int gid = tid; gid < LDS_SORT_E / G; gid += 256) {
+  for (int gid = tid; gid < E / G; gid += 256) {
     const int base = ((gid >> lowbit) << (lowbit + NB)) | (gid & ((1 << lowbit) - 1));
     double r[G];
 #pragma unroll
@@ -156,9 +156,10 @@ __device__ __forceinline__ void sp_bitonic_round(double* sm, int tid, int lowbit
 // first sub-stage of level l (runs of 2^(l-1), both ascending, merged into runs of 2^l): element i against its MIRROR
 // inside the run of 2^l, i ^ (2^l - 1).  With the mirror first, every later compare-exchange of the level is ascending
 // (no direction flags).
+template <int E>
 __device__ __forceinline__ void sp_bitonic_mirror(double* sm, int tid, int l) {
   const int half = 1 << (l - 1), k = 1 << l;
-  for (int t = tid; t < LDS_SORT_E / 2; t += 256) {
+  for (int t = tid; t < E / 2; t += 256) {
     const int i = ((t >> (l - 1)) << l) | (t & (half - 1));
     const int p = i ^ (k - 1);
     double a = sm[i], b = sm[p];
@@ -168,18 +169,19 @@ __device__ __forceinline__ void sp_bitonic_mirror(double* sm, int tid, int l) {
   }
 }
 
-// `npad` = cols rounded up to a power of two; a workgroup sorts LDS_SORT_E / npad rows at once (every compare distance
-// is below npad, so rows never mix).
-template <typename T>
+// `npad` = cols rounded up to a power of two; a workgroup sorts E / npad rows at once (every compare distance is below
+// npad, so rows never mix).  E = 4096 pairs (32 KB of LDS) for lines above 2048 elements, 2048 (16 KB: twice the
+// workgroups per CU to hide the barriers) below.
+template <typename T, int E>
 __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restrict__ in, int64_t rows, int cols, int npad,
                                                                int log_npad, T* __restrict__ out_vals,
                                                                int64_t* __restrict__ out_idx) {
-  __shared__ double sm[LDS_SORT_E];
+  __shared__ double sm[E];
   const int tid = threadIdx.x;
-  const int rpw = LDS_SORT_E >> log_npad;
+  const int rpw = E >> log_npad;
   const int64_t nblocks = (rows + rpw - 1) / rpw;
   for (int64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-    for (int e = tid; e < LDS_SORT_E; e += 256) {
+    for (int e = tid; e < E; e += 256) {
       const int c = e & (npad - 1);
       const int64_t r = rb * rpw + (e >> log_npad);
       double v = sp_pack_pair(0xFFFFFFFFu, 0x1FFFu);
@@ -188,24 +190,24 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
     }
     __syncthreads();
     for (int l = 1; l <= log_npad; ++l) {
-      sp_bitonic_mirror(sm, tid, l);
+      sp_bitonic_mirror<E>(sm, tid, l);
       __syncthreads();
       int jbit = l - 2;                    // remaining sub-stages: distances 2^(l-2) ... 1
       while (jbit >= 0) {
         const int nb = jbit + 1 < 4 ? jbit + 1 : 4;
         const int lowbit = jbit - nb + 1;
         switch (nb) {
-          case 4: sp_bitonic_round<4>(sm, tid, lowbit); break;
-          case 3: sp_bitonic_round<3>(sm, tid, lowbit); break;
-          case 2: sp_bitonic_round<2>(sm, tid, lowbit); break;
-          default: sp_bitonic_round<1>(sm, tid, lowbit); break;
+          case 4: sp_bitonic_round<4, E>(sm, tid, lowbit); break;
+          case 3: sp_bitonic_round<3, E>(sm, tid, lowbit); break;
+          case 2: sp_bitonic_round<2, E>(sm, tid, lowbit); break;
+          default: sp_bitonic_round<1, E>(sm, tid, lowbit); break;
         }
         __syncthreads();
         jbit -= nb;
       }
     }
     int special = 0;
-    for (int e = tid; e < LDS_SORT_E; e += 256) {
+    for (int e = tid; e < E; e += 256) {
       const int c = e & (npad - 1);
       const int64_t r = rb * rpw + (e >> log_npad);
       if (r < rows && c < cols) {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
     // NaNs and zeros: the key does not hold their bits (payload, sign) -- a second, rarely taken pass gathers them
     // from the input (kept out of the loop above so that the common case does no gather at all)
     if (__syncthreads_or(special) && out_vals) {
-      for (int e = tid; e < LDS_SORT_E; e += 256) {
+      for (int e = tid; e < E; e += 256) {
         const int c = e & (npad - 1);
         const int64_t r = rb * rpw + (e >> log_npad);
         if (r < rows && c < cols) {
@@ -291,9 +293,13 @@ int sort_lds(const T* in, int64_t rows, int64_t cols, T* out_vals, int64_t* out_
     npad <<= 1;
     ++lg;
   }
-  const int rpw = LDS_SORT_E / npad;
-  hipLaunchKernelGGL((sp_sort_rows_lds_kernel<T>), dim3(sort_grid(rows, rpw)), dim3(256), 0, st, in, rows, (int)cols, npad,
-                     lg, out_vals, out_idx);
+  if (npad <= LDS_SORT_E / 2) {
+    hipLaunchKernelGGL((sp_sort_rows_lds_kernel<T, LDS_SORT_E / 2>), dim3(sort_grid(rows, LDS_SORT_E / 2 / npad)), dim3(256), 0,
+                       st, in, rows, (int)cols, npad, lg, out_vals, out_idx);
+  } else {
+    hipLaunchKernelGGL((sp_sort_rows_lds_kernel<T, LDS_SORT_E>), dim3(sort_grid(rows, LDS_SORT_E / npad)), dim3(256), 0, st,
+                       in, rows, (int)cols, npad, lg, out_vals, out_idx);
+  }
   SP_CHECK_LAUNCH();
   return 0;
 }
