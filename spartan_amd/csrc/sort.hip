@@ -237,6 +237,111 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
   }
 }
 
+// ---- 64-bit element types, very short lines (<= 64): the same mirror-first network on (64-bit key, column) held in two LDS
+// arrays (24 KB per workgroup); a pair is ordered by key, then column (stable).
+constexpr int LDS_SORT_E64 = 2048;
+
+struct Pair64 {
+  uint64_t k;
+  uint32_t c;
+};
+
+__device__ __forceinline__ void sp_ce64(Pair64& lo, Pair64& hi) {
+  const bool sw = lo.k > hi.k || (lo.k == hi.k && lo.c > hi.c);
+  const Pair64 a = sw ? hi : lo, b = sw ? lo : hi;
+  lo = a;
+  hi = b;
+}
+
+template <int NB>
+__device__ __forceinline__ void sp_bitonic_round64(uint64_t* sk, uint32_t* sc, int tid, int lowbit) {
+  constexpr int G = 1 << NB;
+  for (int gid = tid; gid < LDS_SORT_E64 / G; gid += 256) {
+    const int base = ((gid >> lowbit) << (lowbit + NB)) | (gid & ((1 << lowbit) - 1));
+    Pair64 r[G];
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+      r[m].k = sk[base + (m << lowbit)];
+      r[m].c = sc[base + (m << lowbit)];
+    }
+#pragma unroll
+    for (int b = NB - 1; b >= 0; --b) {
+#pragma unroll
+      for (int m = 0; m < G; ++m)
+        if ((m & (1 << b)) == 0) sp_ce64(r[m], r[m | (1 << b)]);
+    }
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+      sk[base + (m << lowbit)] = r[m].k;
+      sc[base + (m << lowbit)] = r[m].c;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sp_sort_rows_lds64_kernel(const T* __restrict__ in, int64_t rows, int cols, int npad,
+                                                                 int log_npad, T* __restrict__ out_vals,
+                                                                 int64_t* __restrict__ out_idx) {
+  __shared__ uint64_t sk[LDS_SORT_E64];
+  __shared__ uint32_t sc[LDS_SORT_E64];
+  const int tid = threadIdx.x;
+  const int rpw = LDS_SORT_E64 >> log_npad;
+  const int64_t nblocks = (rows + rpw - 1) / rpw;
+  for (int64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+    for (int e = tid; e < LDS_SORT_E64; e += 256) {
+      const int c = e & (npad - 1);
+      const int64_t r = rb * rpw + (e >> log_npad);
+      const bool real = r < rows && c < cols;
+      sk[e] = real ? key64<T>(in[r * cols + c]) : ~0ull;
+      sc[e] = real ? (uint32_t)c : 0xFFFFFFFFu;          // padding: above every real (key, column)
+    }
+    __syncthreads();
+    for (int l = 1; l <= log_npad; ++l) {
+      const int half = 1 << (l - 1), k = 1 << l;
+      for (int t = tid; t < LDS_SORT_E64 / 2; t += 256) {   // mirror sub-stage
+        const int i = ((t >> (l - 1)) << l) | (t & (half - 1));
+        const int p = i ^ (k - 1);
+        Pair64 a{sk[i], sc[i]}, b{sk[p], sc[p]};
+        sp_ce64(a, b);
+        sk[i] = a.k;
+        sc[i] = a.c;
+        sk[p] = b.k;
+        sc[p] = b.c;
+      }
+      __syncthreads();
+      int jbit = l - 2;
+      while (jbit >= 0) {
+        const int nb = jbit + 1 < 3 ? jbit + 1 : 3;
+        const int lowbit = jbit - nb + 1;
+        switch (nb) {
+          case 3: sp_bitonic_round64<3>(sk, sc, tid, lowbit); break;
+          case 2: sp_bitonic_round64<2>(sk, sc, tid, lowbit); break;
+          default: sp_bitonic_round64<1>(sk, sc, tid, lowbit); break;
+        }
+        __syncthreads();
+        jbit -= nb;
+      }
+    }
+    for (int e = tid; e < LDS_SORT_E64; e += 256) {
+      const int c = e & (npad - 1);
+      const int64_t r = rb * rpw + (e >> log_npad);
+      if (r < rows && c < cols) {
+        const uint32_t src = sc[e];
+        if (out_vals) {
+          T v = 0;
+          const bool ok = unkey64<T>(sk[e], &v);
+          if (__ballot(!ok) != 0) {
+            if (!ok) v = in[r * cols + src];
+          }
+          out_vals[r * cols + c] = v;
+        }
+        if (out_idx) out_idx[r * cols + c] = (int64_t)src;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 inline unsigned sort_grid(int64_t n, int per_block) {
   int64_t b = (n + per_block - 1) / per_block;
   const int64_t cap = (int64_t)SP_CUS * SP_BLOCKS_PER_CU * 4;
@@ -248,15 +353,33 @@ inline unsigned sort_grid(int64_t n, int per_block) {
 inline bool lds_path(int32_t dtype, int64_t cols) {
   const char* e = getenv("SP_SORT_ALGO");   // "radix" | "lds": test / tuning knob
   if (e && e[0] == 'r') return false;
+  // (64-bit pairs are much slower in this network than packed 32-bit ones: 17 Gkeys/s on 16-wide lines, 5 on 256-wide,
+  //  3 on 2048-wide -- measured against ~7 for the whole-tile radix sort with row passes and 9-11 for the segmented
+  //  one; so they take it only for very short lines)
+  if (dtype == SP_F64 || dtype == SP_I64) return cols <= 64;
   return (dtype == SP_F32 || dtype == SP_I32) && cols <= LDS_SORT_E;
 }
 
-// segmented passes keep one histogram per (line, digit, key block of the line): affordable while that is at most the
-// size of the data (lines of >= 256 elements)
+template <typename T>
+int sort_lds64(const T* in, int64_t rows, int64_t cols, T* out_vals, int64_t* out_idx, hipStream_t st) {
+  int npad = 1, lg = 0;
+  while (npad < cols) {
+    npad <<= 1;
+    ++lg;
+  }
+  hipLaunchKernelGGL((sp_sort_rows_lds64_kernel<T>), dim3(sort_grid(rows, LDS_SORT_E64 / npad)), dim3(256), 0, st, in, rows,
+                     (int)cols, npad, lg, out_vals, out_idx);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+// segmented passes keep one histogram per (line, digit, key block of the line)
 inline bool seg_ok(int64_t rows, int64_t cols) {
   const char* e = getenv("SP_SORT_SEGMENTED");     // "0": force the row passes (test knob)
   if (e && e[0] == '0') return false;
-  return sp_sort_blocks(rows * cols, cols) * RDX <= rows * cols;
+  // a segment occupies whole key blocks of 4096: lines below 2048 would leave most of every block empty (256-wide
+  // fp64 lines: 120 ms segmented against ~36 ms with the row passes)
+  return cols >= 2048 && sp_sort_blocks(rows * cols, cols) * RDX <= rows * cols;
 }
 
 template <typename T>
@@ -326,7 +449,9 @@ extern "C" int sp_sort_rows(const void* d_in, int32_t dtype, int64_t rows, int64
   hipStream_t st = (hipStream_t)stream;
   if (lds_path(dtype, cols)) {
     if (dtype == SP_F32) return sort_lds<float>((const float*)d_in, rows, cols, (float*)d_out_vals, d_out_idx, st);
-    return sort_lds<int32_t>((const int32_t*)d_in, rows, cols, (int32_t*)d_out_vals, d_out_idx, st);
+    if (dtype == SP_I32) return sort_lds<int32_t>((const int32_t*)d_in, rows, cols, (int32_t*)d_out_vals, d_out_idx, st);
+    if (dtype == SP_F64) return sort_lds64<double>((const double*)d_in, rows, cols, (double*)d_out_vals, d_out_idx, st);
+    return sort_lds64<int64_t>((const int64_t*)d_in, rows, cols, (int64_t*)d_out_vals, d_out_idx, st);
   }
   if (!d_ws || ws_bytes < sp_sort_rows_workspace_bytes(dtype, rows, cols)) SP_FAIL("sp_sort_rows: workspace too small");
   switch (dtype) {

@@ -10,6 +10,7 @@ from tools.kbench import prewarm, timeit  # noqa: E402
 
 prewarm()
 for rows, cols, dt in ((131072, 4096, torch.float32), (2097152, 256, torch.float32), (33554432, 16, torch.float32),
+                       (1048576, 256, torch.float64), (16777216, 16, torch.int64), (131072, 2048, torch.float64),
                        (8192, 65536, torch.float32), (1, 268435456, torch.float32), (8192, 16384, torch.float64),
                        (8192, 32768, torch.int32)):
   n = rows * cols
@@ -17,6 +18,8 @@ for rows, cols, dt in ((131072, 4096, torch.float32), (2097152, 256, torch.float
     x = torch.rand((rows, cols), device='cuda', dtype=dt)
   else:
     x = torch.randint(-2**31, 2**31 - 1, (rows, cols), device='cuda', dtype=dt)
+  if dt == torch.int64:
+    x = torch.randint(-2**62, 2**62, (rows, cols), device='cuda', dtype=dt)
   for what, kw in (('sort', dict(values=True, indices=False)), ('argsort', dict(values=False, indices=True))):
     ms = timeit(lambda: kernels.sort_rows(x, **kw), iters=3, warmup=1)
     es = x.element_size()
