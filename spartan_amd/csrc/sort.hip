@@ -5,13 +5,14 @@
 // The sort is STABLE (equal keys keep their order, np.argsort(kind='stable')); NaNs go last like NumPy's,
 // -0.0 and +0.0 compare equal.  Values are gathered from the input by the sorted positions, so the output holds
 // the input's bit patterns.
-//   rows of <= 4096 32-bit elements : bitonic network on (key, column) pairs in LDS (packed as doubles: a
-//                                     compare-exchange is v_min_f64 + v_max_f64), one HBM pass
-//   anything else                   : LSD radix sort, sizeof(T) passes over the key bytes, every line a SEGMENT of
-//                                     the same launches (sp_radix.hpp: histogram [line][digit][block], one scan).
-//                                     Lines too short for per-line histograms (64-bit types, < 256 elements) are
-//                                     sorted as one array and then by the bytes of each element's ROW, which brings
-//                                     the lines back together.
+//   lines of <= 4096 32-bit elements : bitonic network on (key, column) pairs in LDS (packed as doubles: a
+//                                      compare-exchange is v_min_f64 + v_max_f64), one HBM pass
+//   lines of <= 64 64-bit elements   : the same network on (key64, column) pairs in two LDS arrays
+//   lines of >= 2048 elements        : LSD radix sort, sizeof(T) passes over the key bytes, every line a SEGMENT of the
+//                                      same launches (sp_radix.hpp: histogram [line][digit][block], one scan)
+//   64-bit lines in between          : the tile sorted as ONE array by key, then by the bytes of each element's ROW,
+//                                      which brings the lines back together (a segment would leave its 4096-key
+//                                      blocks mostly empty)
 #include <stdlib.h>
 
 #include "sp_common.hpp"
