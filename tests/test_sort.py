@@ -116,7 +116,7 @@ def _special(x, rng):
 @pytest.mark.gpu
 @pytest.mark.parametrize('algo', ['default', 'radix'])
 @pytest.mark.parametrize('dtype', [np.float32, np.float64, np.int32, np.int64])
-@pytest.mark.parametrize('shape', [(1, 1), (5, 7), (1, 4096), (3, 4097), (1000, 33), (64, 64), (2, 100000), (70000, 3)])
+@pytest.mark.parametrize('shape', [(1, 1), (5, 7), (1, 4096), (3, 4097), (1000, 33), (64, 64), (2, 100000), (70000, 3), (500, 300), (40, 2048)])
 def test_sort_rows_kernel(monkeypatch, shape, dtype, algo):
   torch = pytest.importorskip('torch')
   from spartan_amd import kernels
