@@ -7,12 +7,11 @@
 // the input's bit patterns.
 //   lines of <= 4096 32-bit elements : bitonic network on (key, column) pairs in LDS (packed as doubles: a
 //                                      compare-exchange is v_min_f64 + v_max_f64), one HBM pass
-//   lines of <= 64 64-bit elements   : the same network on (key64, column) pairs in two LDS arrays
+//   lines of <= 2048 64-bit elements : the same network on (key64, column) pairs in two LDS arrays
 //   lines of >= 2048 elements        : LSD radix sort, sizeof(T) passes over the key bytes, every line a SEGMENT of the
 //                                      same launches (sp_radix.hpp: histogram [line][digit][block], one scan)
-//   64-bit lines in between          : the tile sorted as ONE array by key, then by the bytes of each element's ROW,
-//                                      which brings the lines back together (a segment would leave its 4096-key
-//                                      blocks mostly empty)
+//   (SP_SORT_ALGO=radix, lines < 2048: the tile sorted as ONE array by key, then by the bytes of each element's ROW,
+//    which brings the lines back together -- the fallback the LDS paths replaced, kept as a test knob)
 #include <stdlib.h>
 
 #include "sp_common.hpp"
@@ -238,20 +237,19 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
   }
 }
 
-// ---- 64-bit element types, very short lines (<= 64): the same mirror-first network on (64-bit key, column) held in two LDS
+// ---- 64-bit element types, lines of <= 2048: the same mirror-first network on (64-bit key, column) held in two LDS
 // arrays (24 KB per workgroup); a pair is ordered by key, then column (stable).
 constexpr int LDS_SORT_E64 = 2048;
 
-struct Pair64 {
-  uint64_t k;
-  uint32_t c;
-};
-
-__device__ __forceinline__ void sp_ce64(Pair64& lo, Pair64& hi) {
-  const bool sw = lo.k > hi.k || (lo.k == hi.k && lo.c > hi.c);
-  const Pair64 a = sw ? hi : lo, b = sw ? lo : hi;
-  lo = a;
-  hi = b;
+// compare-exchange of two (key, column) pairs kept in separate scalars (arrays of structs spill)
+__device__ __forceinline__ void sp_ce64(uint64_t& ka, uint32_t& ca, uint64_t& kb, uint32_t& cb) {
+  const bool sw = ka > kb || (ka == kb && ca > cb);
+  const uint64_t k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+  const uint32_t c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+  ka = k0;
+  kb = k1;
+  ca = c0;
+  cb = c1;
 }
 
 template <int NB>
@@ -259,22 +257,23 @@ __device__ __forceinline__ void sp_bitonic_round64(uint64_t* sk, uint32_t* sc, i
   constexpr int G = 1 << NB;
   for (int gid = tid; gid < LDS_SORT_E64 / G; gid += 256) {
     const int base = ((gid >> lowbit) << (lowbit + NB)) | (gid & ((1 << lowbit) - 1));
-    Pair64 r[G];
+    uint64_t rk[G];
+    uint32_t rc[G];
 #pragma unroll
     for (int m = 0; m < G; ++m) {
-      r[m].k = sk[base + (m << lowbit)];
-      r[m].c = sc[base + (m << lowbit)];
+      rk[m] = sk[base + (m << lowbit)];
+      rc[m] = sc[base + (m << lowbit)];
     }
 #pragma unroll
     for (int b = NB - 1; b >= 0; --b) {
 #pragma unroll
       for (int m = 0; m < G; ++m)
-        if ((m & (1 << b)) == 0) sp_ce64(r[m], r[m | (1 << b)]);
+        if ((m & (1 << b)) == 0) sp_ce64(rk[m], rc[m], rk[m | (1 << b)], rc[m | (1 << b)]);
     }
 #pragma unroll
     for (int m = 0; m < G; ++m) {
-      sk[base + (m << lowbit)] = r[m].k;
-      sc[base + (m << lowbit)] = r[m].c;
+      sk[base + (m << lowbit)] = rk[m];
+      sc[base + (m << lowbit)] = rc[m];
     }
   }
 }
@@ -302,12 +301,13 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds64_kernel(const T* __rest
       for (int t = tid; t < LDS_SORT_E64 / 2; t += 256) {   // mirror sub-stage
         const int i = ((t >> (l - 1)) << l) | (t & (half - 1));
         const int p = i ^ (k - 1);
-        Pair64 a{sk[i], sc[i]}, b{sk[p], sc[p]};
-        sp_ce64(a, b);
-        sk[i] = a.k;
-        sc[i] = a.c;
-        sk[p] = b.k;
-        sc[p] = b.c;
+        uint64_t ka = sk[i], kb = sk[p];
+        uint32_t ca = sc[i], cb = sc[p];
+        sp_ce64(ka, ca, kb, cb);
+        sk[i] = ka;
+        sc[i] = ca;
+        sk[p] = kb;
+        sc[p] = cb;
       }
       __syncthreads();
       int jbit = l - 2;
@@ -354,10 +354,9 @@ inline unsigned sort_grid(int64_t n, int per_block) {
 inline bool lds_path(int32_t dtype, int64_t cols) {
   const char* e = getenv("SP_SORT_ALGO");   // "radix" | "lds": test / tuning knob
   if (e && e[0] == 'r') return false;
-  // (64-bit pairs are much slower in this network than packed 32-bit ones: 17 Gkeys/s on 16-wide lines, 5 on 256-wide,
-  //  3 on 2048-wide -- measured against ~7 for the whole-tile radix sort with row passes and 9-11 for the segmented
-  //  one; so they take it only for very short lines)
-  if (dtype == SP_F64 || dtype == SP_I64) return cols <= 64;
+  // (64-bit lines up to 2048: 50 Gkeys/s at 256-wide, 31 at 2048-wide -- against 8 for the radix paths.  The first
+  //  version kept its pairs in an array of structs, which spilled to scratch: 10x slower.)
+  if (dtype == SP_F64 || dtype == SP_I64) return cols <= LDS_SORT_E64;
   return (dtype == SP_F32 || dtype == SP_I32) && cols <= LDS_SORT_E;
 }
 
