@@ -7,7 +7,7 @@
 // the input's bit patterns.
 //   lines of <= 4096 32-bit elements : bitonic network on (key, column) pairs in LDS (packed as doubles: a
 //                                      compare-exchange is v_min_f64 + v_max_f64), one HBM pass
-//   lines of <= 2048 64-bit elements : the same network on (key64, column) pairs in two LDS arrays
+//   lines of <= 4096 64-bit elements : the same network on (key64, column) pairs in two LDS arrays
 //   lines of >= 2048 elements        : LSD radix sort, sizeof(T) passes over the key bytes, every line a SEGMENT of the
 //                                      same launches (sp_radix.hpp: histogram [line][digit][block], one scan)
 //   (SP_SORT_ALGO=radix, lines < 2048: the tile sorted as ONE array by key, then by the bytes of each element's ROW,
@@ -237,9 +237,9 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds_kernel(const T* __restri
   }
 }
 
-// ---- 64-bit element types, lines of <= 2048: the same mirror-first network on (64-bit key, column) held in two LDS
-// arrays (24 KB per workgroup); a pair is ordered by key, then column (stable).
-constexpr int LDS_SORT_E64 = 2048;
+// ---- 64-bit element types, lines of <= 4096: the same mirror-first network on (64-bit key, column) held in two LDS
+// arrays (24 or 48 KB per workgroup); a pair is ordered by key, then column (stable).
+constexpr int LDS_SORT_E64 = 4096;   // 2048 pairs (24 KB) for lines up to 2048, 4096 (48 KB) above
 
 // compare-exchange of two (key, column) pairs kept in separate scalars (arrays of structs spill)
 __device__ __forceinline__ void sp_ce64(uint64_t& ka, uint32_t& ca, uint64_t& kb, uint32_t& cb) {
@@ -252,10 +252,10 @@ __device__ __forceinline__ void sp_ce64(uint64_t& ka, uint32_t& ca, uint64_t& kb
   cb = c1;
 }
 
-template <int NB>
+template <int NB, int E>
 __device__ __forceinline__ void sp_bitonic_round64(uint64_t* sk, uint32_t* sc, int tid, int lowbit) {
   constexpr int G = 1 << NB;
-  for (int gid = tid; gid < LDS_SORT_E64 / G; gid += 256) {
+  for (int gid = tid; gid < E / G; gid += 256) {
     const int base = ((gid >> lowbit) << (lowbit + NB)) | (gid & ((1 << lowbit) - 1));
     uint64_t rk[G];
     uint32_t rc[G];
@@ -278,17 +278,17 @@ __device__ __forceinline__ void sp_bitonic_round64(uint64_t* sk, uint32_t* sc, i
   }
 }
 
-template <typename T>
+template <typename T, int E>
 __global__ __launch_bounds__(256) void sp_sort_rows_lds64_kernel(const T* __restrict__ in, int64_t rows, int cols, int npad,
                                                                  int log_npad, T* __restrict__ out_vals,
                                                                  int64_t* __restrict__ out_idx) {
-  __shared__ uint64_t sk[LDS_SORT_E64];
-  __shared__ uint32_t sc[LDS_SORT_E64];
+  __shared__ uint64_t sk[E];
+  __shared__ uint32_t sc[E];
   const int tid = threadIdx.x;
-  const int rpw = LDS_SORT_E64 >> log_npad;
+  const int rpw = E >> log_npad;
   const int64_t nblocks = (rows + rpw - 1) / rpw;
   for (int64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-    for (int e = tid; e < LDS_SORT_E64; e += 256) {
+    for (int e = tid; e < E; e += 256) {
       const int c = e & (npad - 1);
       const int64_t r = rb * rpw + (e >> log_npad);
       const bool real = r < rows && c < cols;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds64_kernel(const T* __rest
     __syncthreads();
     for (int l = 1; l <= log_npad; ++l) {
       const int half = 1 << (l - 1), k = 1 << l;
-      for (int t = tid; t < LDS_SORT_E64 / 2; t += 256) {   // mirror sub-stage
+      for (int t = tid; t < E / 2; t += 256) {   // mirror sub-stage
         const int i = ((t >> (l - 1)) << l) | (t & (half - 1));
         const int p = i ^ (k - 1);
         uint64_t ka = sk[i], kb = sk[p];
@@ -315,15 +315,15 @@ __global__ __launch_bounds__(256) void sp_sort_rows_lds64_kernel(const T* __rest
         const int nb = jbit + 1 < 3 ? jbit + 1 : 3;
         const int lowbit = jbit - nb + 1;
         switch (nb) {
-          case 3: sp_bitonic_round64<3>(sk, sc, tid, lowbit); break;
-          case 2: sp_bitonic_round64<2>(sk, sc, tid, lowbit); break;
-          default: sp_bitonic_round64<1>(sk, sc, tid, lowbit); break;
+          case 3: sp_bitonic_round64<3, E>(sk, sc, tid, lowbit); break;
+          case 2: sp_bitonic_round64<2, E>(sk, sc, tid, lowbit); break;
+          default: sp_bitonic_round64<1, E>(sk, sc, tid, lowbit); break;
         }
         __syncthreads();
         jbit -= nb;
       }
     }
-    for (int e = tid; e < LDS_SORT_E64; e += 256) {
+    for (int e = tid; e < E; e += 256) {
       const int c = e & (npad - 1);
       const int64_t r = rb * rpw + (e >> log_npad);
       if (r < rows && c < cols) {
@@ -354,7 +354,7 @@ inline unsigned sort_grid(int64_t n, int per_block) {
 inline bool lds_path(int32_t dtype, int64_t cols) {
   const char* e = getenv("SP_SORT_ALGO");   // "radix" | "lds": test / tuning knob
   if (e && e[0] == 'r') return false;
-  // (64-bit lines up to 2048: 50 Gkeys/s at 256-wide, 31 at 2048-wide -- against 8 for the radix paths.  The first
+  // (64-bit lines up to 4096: 50 Gkeys/s at 256-wide, 31 at 2048-wide -- against 8 for the radix paths.  The first
   //  version kept its pairs in an array of structs, which spilled to scratch: 10x slower.)
   if (dtype == SP_F64 || dtype == SP_I64) return cols <= LDS_SORT_E64;
   return (dtype == SP_F32 || dtype == SP_I32) && cols <= LDS_SORT_E;
@@ -367,8 +367,12 @@ int sort_lds64(const T* in, int64_t rows, int64_t cols, T* out_vals, int64_t* ou
     npad <<= 1;
     ++lg;
   }
-  hipLaunchKernelGGL((sp_sort_rows_lds64_kernel<T>), dim3(sort_grid(rows, LDS_SORT_E64 / npad)), dim3(256), 0, st, in, rows,
-                     (int)cols, npad, lg, out_vals, out_idx);
+  if (npad <= LDS_SORT_E64 / 2)
+    hipLaunchKernelGGL((sp_sort_rows_lds64_kernel<T, LDS_SORT_E64 / 2>), dim3(sort_grid(rows, LDS_SORT_E64 / 2 / npad)), dim3(256),
+                       0, st, in, rows, (int)cols, npad, lg, out_vals, out_idx);
+  else
+    hipLaunchKernelGGL((sp_sort_rows_lds64_kernel<T, LDS_SORT_E64>), dim3(sort_grid(rows, 1)), dim3(256), 0, st, in, rows,
+                       (int)cols, npad, lg, out_vals, out_idx);
   SP_CHECK_LAUNCH();
   return 0;
 }

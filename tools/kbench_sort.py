@@ -10,7 +10,7 @@ from tools.kbench import prewarm, timeit  # noqa: E402
 
 prewarm()
 for rows, cols, dt in ((131072, 4096, torch.float32), (2097152, 256, torch.float32), (33554432, 16, torch.float32),
-                       (1048576, 256, torch.float64), (16777216, 16, torch.int64), (131072, 2048, torch.float64),
+                       (1048576, 256, torch.float64), (16777216, 16, torch.int64), (131072, 2048, torch.float64), (65536, 4096, torch.float64),
                        (8192, 65536, torch.float32), (1, 268435456, torch.float32), (8192, 16384, torch.float64),
                        (8192, 32768, torch.int32)):
   n = rows * cols
