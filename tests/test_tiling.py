@@ -192,17 +192,15 @@ def test_auto_tiled_programs_on_the_hip_backend():
     sp.shutdown()
 
 
-def test_random_programs_do_not_change_under_auto_tiling():
+def _random_programs(backend_factory, seeds, n_dots):
   """tests/test_random_autotiling.py in spirit: the random expression DAGs of tests/test_fuzz_gpu.py (maps, views,
   reductions, argmax, means) and of its dot generator evaluate to the same values with the pass on and off
   (reductions to a summation-order tolerance: another tiling is another summation tree)."""
-  from oracle.np_backend import NumpyBackend
   from tests import test_fuzz_gpu as F
-  seeds = range(4000, 4120)
 
   def run(flag):
     out = {}
-    sp.initialize(backend=NumpyBackend(), num_workers=4)
+    sp.initialize(backend=backend_factory(), num_workers=4)
     opt.FLAGS['opt_auto_tiling'] = flag
     try:
       for s in seeds:
@@ -211,7 +209,7 @@ def test_random_programs_do_not_change_under_auto_tiling():
             out[s] = F._program(s, sp)
         except Exception as e:   # noqa: BLE001
           out[s] = type(e).__name__
-      for s in range(20):
+      for s in range(n_dots):
         try:
           out['dot%d' % s] = F._dot_case(s, sp)
         except Exception as e:   # noqa: BLE001
@@ -237,3 +235,15 @@ def test_random_programs_do_not_change_under_auto_tiling():
     elif not np.allclose(a, b, rtol=1e-5, atol=1e-6, equal_nan=True):
       bad.append((k, 'float result differs'))
   assert not bad, bad[:10]
+
+
+def test_random_programs_do_not_change_under_auto_tiling():
+  from oracle.np_backend import NumpyBackend
+  _random_programs(NumpyBackend, range(4000, 4120), 20)
+
+
+@pytest.mark.gpu
+def test_random_programs_do_not_change_under_auto_tiling_gpu():
+  """The same on the HIP backend: column- and block-tiled arrays chosen by the pass go through the strided kernels."""
+  from spartan_amd.backend_hip import HipBackend
+  _random_programs(HipBackend, range(4000, 4200), 40)
