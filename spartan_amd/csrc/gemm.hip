@@ -342,6 +342,9 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
     case 1: return sp_gemm_launch<128, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 2: return sp_gemm_launch<256, 256, 16, 2, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 3: return sp_gemm_launch<128, 256, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+    // experimental (SP_GEMM_VARIANT only): k-tiles of 32 halve the barriers per contraction
+    case 4: return sp_gemm_launch<128, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+    case 5: return sp_gemm_launch<256, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     default: SP_FAIL("sp_gemm_f32: unknown SP_GEMM_VARIANT=%d", v);
   }
 }
