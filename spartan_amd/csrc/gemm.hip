@@ -29,6 +29,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FETCH_SIZE): group 32 / 16 / 8 / 4 / 2 / 1 -> 23.7 / 22.3 / 18.6 / 12.9 / 10.6 / 10.1 GB of L2 misses and
 // 137.5 -> 139.5 TFLOP/s: only the A panel shared by the WGs of one tile ROW is reliably served from the
 // XCD's L2, so the plain row-major walk (group 1: 64 resident WGs = one 256-row A panel x 64 B panels) wins.
+#ifndef SP_GEMM_SETPRIO
+#define SP_GEMM_SETPRIO 0
+#endif
+#ifndef SP_GEMM_MID_STORE
+#define SP_GEMM_MID_STORE 0
+#endif
 #ifndef SP_GEMM_GROUP_M
 #define SP_GEMM_GROUP_M 1
 #endif
@@ -233,6 +239,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag_off + (c * 8 + s) * LDB_S + j * 32];
+      if (SP_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);   // (experiment) MFMA issue ahead of the other wave's memory ops
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -243,8 +250,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[j][s], acc[i][j], 0, 0, 0);
         }
       }
+      if (SP_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
+      // SP_GEMM_MID_STORE: the next k-tile goes to its (free) LDS stage after the first half of this tile's
+      // MFMAs instead of after all of them, so the wait for the global loads is off the barrier's path
+      if (SP_GEMM_MID_STORE && BK / 8 > 1 && c == 0) {
+        if (t + 1 < nt) SP_GEMM_STORE_TILE((t + 1) & 1);
+      }
     }
-    if (t + 1 < nt) SP_GEMM_STORE_TILE((t + 1) & 1);
+    if (!(SP_GEMM_MID_STORE && BK / 8 > 1)) {
+      if (t + 1 < nt) SP_GEMM_STORE_TILE((t + 1) & 1);
+    }
     __syncthreads();
   }
 
