@@ -29,6 +29,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FETCH_SIZE): group 32 / 16 / 8 / 4 / 2 / 1 -> 23.7 / 22.3 / 18.6 / 12.9 / 10.6 / 10.1 GB of L2 misses and
 // 137.5 -> 139.5 TFLOP/s: only the A panel shared by the WGs of one tile ROW is reliably served from the
 // XCD's L2, so the plain row-major walk (group 1: 64 resident WGs = one 256-row A panel x 64 B panels) wins.
+#ifndef SP_GEMM_LDB_PAD
+#define SP_GEMM_LDB_PAD 0
+#endif
 #ifndef SP_GEMM_SETPRIO
 #define SP_GEMM_SETPRIO 0
 #endif
@@ -46,7 +49,9 @@ struct GemmCfg {
   static constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
   static constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
   static constexpr int LDA_S = BK + 4;                // padded LDS row (floats)
-  static constexpr int LDB_S = BN;
+  // B fragment reads: lanes 0-31 read 32 consecutive floats of row k, lanes 32-63 of row k + 4; with rows of BN
+  // floats both halves fall on banks 0-31 (2-way conflict); SP_GEMM_LDB_PAD = 8 moves the second half to banks 32-63
+  static constexpr int LDB_S = BN + SP_GEMM_LDB_PAD;
   static constexpr int A_FLOATS = BM * LDA_S;
   static constexpr int B_FLOATS = BK * LDB_S;
   static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
