@@ -29,6 +29,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FETCH_SIZE): group 32 / 16 / 8 / 4 / 2 / 1 -> 23.7 / 22.3 / 18.6 / 12.9 / 10.6 / 10.1 GB of L2 misses and
 // 137.5 -> 139.5 TFLOP/s: only the A panel shared by the WGs of one tile ROW is reliably served from the
 // XCD's L2, so the plain row-major walk (group 1: 64 resident WGs = one 256-row A panel x 64 B panels) wins.
+#ifndef SP_GEMM_STAGES3
+#define SP_GEMM_STAGES3 0
+#endif
 #ifndef SP_GEMM_LDB_PAD
 #define SP_GEMM_LDB_PAD 0
 #endif
@@ -55,7 +58,7 @@ struct GemmCfg {
   static constexpr int A_FLOATS = BM * LDA_S;
   static constexpr int B_FLOATS = BK * LDB_S;
   static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
-  static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+  static constexpr int LDS_BYTES = (SP_GEMM_STAGES3 ? 3 : 2) * STAGE_FLOATS * 4;
   static constexpr int A_VEC = (BM * BK / 4) / THREADS;  // float4 per thread per k-tile
   static constexpr int B_VEC = (BK * BN / 4) / THREADS;
   // 2 workgroups per CU when the wave tile needs 128 accumulator registers:
@@ -219,6 +222,61 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
 
   const int nt = (K + BK - 1) / BK;
   constexpr bool ktail = FAST && KTAIL;   // (the general path guards every element anyway)
+#if SP_GEMM_STAGES3
+  // (experiment) three LDS stages, tiles stored two k-steps ahead: the one barrier of a k-step sits between its two
+  // MFMA halves, with the fragments of the second half already in registers, so neither the wait for the global
+  // loads nor the LDS read latency follows it.
+  const int a_frag_off = (wm * Cfg::WTM + l31) * LDA_S + 4 * lh;
+  const int b_frag_off = (4 * lh) * LDB_S + wn * Cfg::WTN + l31;
+  static_assert(BK == 16, "SP_GEMM_STAGES3 is written for two fragment halves per k-tile");
+  if (ktail && nt == 1) SP_GEMM_LOAD_KTAIL(0);
+  else SP_GEMM_LOAD_TILE(0);
+  SP_GEMM_STORE_TILE(0);
+  if (nt > 1) {
+    if (ktail && nt == 2) SP_GEMM_LOAD_KTAIL(1);
+    else SP_GEMM_LOAD_TILE(1);
+    SP_GEMM_STORE_TILE(1);
+  }
+  __syncthreads();
+  int st_cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 2 < nt) {
+      if (ktail && t + 3 == nt) SP_GEMM_LOAD_KTAIL(t + 2);
+      else SP_GEMM_LOAD_TILE(t + 2);
+    }
+    const float* sA = smem + st_cur * Cfg::STAGE_FLOATS;
+    const float* sB = sA + Cfg::A_FLOATS;
+    f32x4 af[2][TM];
+    float bf[2][TN][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[c][i] = *(const f32x4*)(sA + a_frag_off + i * 32 * LDA_S + c * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[c][j][s] = sB[b_frag_off + (c * 8 + s) * LDB_S + j * 32];
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float av = af[c][i][s];
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[c][j][s], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (c == 0) __syncthreads();
+    }
+    const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;   // (t + 2) % 3
+    if (t + 2 < nt) SP_GEMM_STORE_TILE(st_next2);
+    st_cur = st_cur == 2 ? 0 : st_cur + 1;
+  }
+
+#else
   if (ktail && nt == 1) SP_GEMM_LOAD_KTAIL(0);
   else SP_GEMM_LOAD_TILE(0);
   SP_GEMM_STORE_TILE(0);
@@ -268,6 +326,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
     __syncthreads();
   }
 
+#endif
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -362,9 +421,11 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
     case 1: return sp_gemm_launch<128, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 2: return sp_gemm_launch<256, 256, 16, 2, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 3: return sp_gemm_launch<128, 256, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+#if !SP_GEMM_STAGES3
     // experimental (SP_GEMM_VARIANT only): k-tiles of 32 halve the barriers per contraction
     case 4: return sp_gemm_launch<128, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 5: return sp_gemm_launch<256, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+#endif
     default: SP_FAIL("sp_gemm_f32: unknown SP_GEMM_VARIANT=%d", v);
   }
 }
