@@ -40,18 +40,21 @@ __global__ __launch_bounds__(256) void sp_centers_t64_kernel(const TC* __restric
 // the (L2-resident) Ct64 is used for the R points of the wave: the kernel is bound by
 // L2 -> CU traffic otherwise.
 // rows == NULL: every point 0..n-1; else the *n_rows points listed in rows[] (the ones the
-// fused kernel could not decide).
+// fused kernel could not decide) -- and only if there are MORE than `handled_elsewhere` of them
+// (a shorter list is served by the candidate masks, sp_nearest_candidates_kernel).
 template <typename TX>
 __global__ __launch_bounds__(256) void sp_nearest_exact_kernel(const TX* __restrict__ X, int64_t ldx,
                                                                const double* __restrict__ Ct64, int kp, int64_t n,
                                                                int k, int d, int64_t* __restrict__ labels,
                                                                const int* __restrict__ rows,
-                                                               const int* __restrict__ n_rows) {
+                                                               const int* __restrict__ n_rows,
+                                                               int64_t handled_elsewhere) {
   constexpr int G = 2, R = 8, J = 4;
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t count = rows ? (int64_t)*n_rows : n;
+  if (rows && count <= handled_elsewhere) return;
   for (int64_t it = wave * R; it < count; it += nwaves * R) {
     int64_t row[R];
     const TX* __restrict__ xr[R];
@@ -266,6 +269,84 @@ __global__ __launch_bounds__(256) void sp_nearest_recheck_kernel(const float* __
       // (the window always contains the fused kernel's own best center, so bk is set; the guard is for NaN input)
       if (lane == 0) labels[row[r]] = bk == 0x7fffffff ? -1 - labels[row[r]] : bk;
     }
+  }
+}
+
+// Last step of the fused tier: cdist's exact distance (sequential fp64 sum of squared differences in feature
+// order, sqrt) of the centers sp_nearest_nt_kernel<.., true> marked for each listed point -- typically the two
+// or three that tied -- and the lexicographic (distance, index) minimum = np.argmin's first minimum.
+// A wavefront serves P = 64 / W' listed points at a time (W' = mask words per point rounded up to a power of
+// two, P = 1 and a loop over the words beyond 64): a lane owns one mask word and walks its set bits in ascending
+// center order, reading the point and the center row (straight from the caller's centers: both contiguous) eight
+// features ahead of the sequential sum.
+template <typename TC>
+__global__ __launch_bounds__(256) void sp_nearest_candidates_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                    const TC* __restrict__ C, int64_t ldc, int kp,
+                                                                    int k, int d, int64_t* __restrict__ labels,
+                                                                    const int* __restrict__ rows,
+                                                                    const int* __restrict__ n_rows, int64_t cap,
+                                                                    const unsigned* __restrict__ cand_mask) {
+  constexpr int J = 8;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t count = *n_rows;
+  if (count > cap) return;                        // no masks were written: the exact kernel re-does the list
+  const int words = kp / 32;
+  int wp = 1;
+  while (wp < words && wp < 64) wp <<= 1;         // lanes per point
+  const int P = 64 / wp;                          // points per wavefront and trip
+  const int sub = lane / wp, wl = lane - sub * wp;
+  for (int64_t it0 = wave * P; it0 < count; it0 += nwaves * P) {
+    const int64_t it = it0 + sub < count ? it0 + sub : count - 1;   // tail: repeat the last listed point
+    const int64_t row = rows[it];
+    const float* __restrict__ xr = X + row * ldx;
+    double best = INFINITY;
+    int best_k = 0x7fffffff;
+    for (int w0 = 0; w0 < words; w0 += wp) {
+      const int wi = w0 + wl;
+      unsigned m = wi < words ? cand_mask[it * words + wi] : 0u;
+      while (m) {
+        const int c = wi * 32 + __builtin_ctz(m);
+        m &= m - 1;
+        if (c >= k) break;
+        const TC* __restrict__ cr = C + (int64_t)c * ldc;
+        double s = 0.0;
+        int jj = 0;
+        for (; jj + J <= d; jj += J) {
+          double xv[J], cv[J];
+#pragma unroll
+          for (int u = 0; u < J; ++u) {
+            xv[u] = (double)xr[jj + u];
+            cv[u] = (double)cr[jj + u];
+          }
+#pragma unroll
+          for (int u = 0; u < J; ++u) {
+            const double diff = xv[u] - cv[u];
+            s += diff * diff;
+          }
+        }
+        for (; jj < d; ++jj) {
+          const double diff = (double)xr[jj] - (double)cr[jj];
+          s += diff * diff;
+        }
+        s = sqrt(s);
+        if (s < best) {                           // ascending center index per lane: `<` keeps the first minimum
+          best = s;
+          best_k = c;
+        }
+      }
+    }
+    for (int off = wp >> 1; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off);
+      const int ok = __shfl_xor(best_k, off);
+      if (ob < best || (ob == best && ok < best_k)) {
+        best = ob;
+        best_k = ok;
+      }
+    }
+    // (the window always contains the first pass's own best center; the guard is for NaN input)
+    if (wl == 0 && it0 + sub < count) labels[row] = best_k == 0x7fffffff ? -1 - labels[row] : best_k;
   }
 }
 
@@ -500,14 +581,18 @@ extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ld
   }
   const int* rows = nullptr;
   const int* n_rows = nullptr;
+  int64_t handled = -1;
   if (tier != SP_NEAREST_EXACT && dtype == SP_F32 && sp_nearest_fused_applicable(n, k, d, tier)) {
     if (sp_nearest_fused_launch((const float*)d_points, ldx, d_centers, cdtype, ldc, n, k, d, d_labels, w, st)) return 1;
     if (tier == SP_NEAREST_FUSED_UNCHECKED) return 0;   // diagnostics: leave the marks (-1 - best) in place
     // the points the fused kernel listed as undecided: fp32 window over all centers, exact fp64 distance
     // for the few inside it (SP_KM_FULL_RECHECK=1: the full exact kernel instead, for A/B measurements)
-    static int full_recheck = -1;
-    if (full_recheck < 0) full_recheck = getenv("SP_KM_FULL_RECHECK") ? 1 : 0;
-    if (!full_recheck) {
+    static int recheck_mode = -1;   // 0: MFMA candidate masks (default), 1: round-1 VALU window kernel, 2: exact kernel
+    if (recheck_mode < 0) {
+      const char* e = getenv("SP_KM_RECHECK");
+      recheck_mode = e ? atoi(e) : 0;
+    }
+    if (recheck_mode == 1) {
       hipLaunchKernelGGL(sp_nearest_recheck_kernel, dim3(SP_CUS * 8), dim3(256), 0, st, (const float*)d_points, ldx,
                          w.Ct, w.Ct64, w.cn, w.cmax2, (int)w.kp, (int)k, (int)d, d_labels, w.amb_rows, w.amb_best,
                          w.amb_count);
@@ -516,16 +601,29 @@ extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ld
     }
     rows = w.amb_rows;
     n_rows = w.amb_count;
+    if (recheck_mode == 0) {
+      if (sp_nearest_mark_candidates((const float*)d_points, ldx, d, w, st)) return 1;
+      if (cdtype == SP_F32)
+        hipLaunchKernelGGL((sp_nearest_candidates_kernel<float>), dim3(SP_CUS * 8), dim3(256), 0, st, (const float*)d_points,
+                           ldx, (const float*)d_centers, ldc, (int)w.kp, (int)k, (int)d, d_labels, rows, n_rows, w.cand_cap,
+                           w.cand_mask);
+      else
+        hipLaunchKernelGGL((sp_nearest_candidates_kernel<double>), dim3(SP_CUS * 8), dim3(256), 0, st, (const float*)d_points,
+                           ldx, (const double*)d_centers, ldc, (int)w.kp, (int)k, (int)d, d_labels, rows, n_rows, w.cand_cap,
+                           w.cand_mask);
+      SP_CHECK_LAUNCH();
+      handled = w.cand_cap;   // the exact kernel below only runs for a list the masks had no room for
+    }
   }
   const int64_t groups = (n + 7) / 8;   // 8 points per wave
   int64_t waves = rows ? (int64_t)SP_CUS * 16 : (groups < (int64_t)SP_CUS * 32 ? groups : (int64_t)SP_CUS * 32);
   const unsigned blocks = (unsigned)((waves + 3) / 4);
   if (dtype == SP_F32)
     hipLaunchKernelGGL((sp_nearest_exact_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)d_points, ldx,
-                       w.Ct64, (int)w.kp, n, (int)k, (int)d, d_labels, rows, n_rows);
+                       w.Ct64, (int)w.kp, n, (int)k, (int)d, d_labels, rows, n_rows, handled);
   else
     hipLaunchKernelGGL((sp_nearest_exact_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)d_points, ldx,
-                       w.Ct64, (int)w.kp, n, (int)k, (int)d, d_labels, rows, n_rows);
+                       w.Ct64, (int)w.kp, n, (int)k, (int)d, d_labels, rows, n_rows, handled);
   SP_CHECK_LAUNCH();
   return 0;
 }

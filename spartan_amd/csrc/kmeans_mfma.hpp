@@ -16,6 +16,7 @@
 // final rounding).  Otherwise its label is written as -1-best and the exact fp64
 // kernel (kmeans.hip) re-does that point, so the labels equal the exact tier's.
 #pragma once
+#include <type_traits>
 
 typedef float km_f32x16 __attribute__((ext_vector_type(16)));
 typedef float km_f32x4 __attribute__((ext_vector_type(4)));
@@ -27,28 +28,38 @@ constexpr int KM_BN_MAX = 256;   // centers are padded to a multiple of this (an
 constexpr int KM_LDA = KM_BK + 4;
 constexpr int KM_A_FLOATS = KM_BM * KM_LDA;
 
-// Ct[j][c] = (float)C[c][j] (zero padded to [dp][kp]); cn[c] = |C[c]|^2 / 2 (fp64 sum, rounded; +inf on padding);
-// *cmax2 = max_c |C[c]|^2 (as float bits; non-negative floats order like unsigned ints)
+// Ct[j][c] = (float)C[c][j] (zero padded to [dp][kp]); Cf[c][j] = the same values row-major (zero padded to
+// [kp][dp]); cn[c] = |C[c]|^2 / 2 (fp64 sum, rounded; +inf on padding);
+// *cmax2 = max_c |C[c]|^2 (as float bits; non-negative floats order like unsigned ints).
+// One wavefront per center, lanes along the features (a thread per center walking its row was a 256-step
+// latency chain: 84 us for 1024 x 256, rocprofv3).
 template <typename TC>
 __global__ __launch_bounds__(256) void sp_centers_prep_kernel(const TC* __restrict__ C, int64_t ldc, int k, int d,
-                                                              int kp, float* __restrict__ Ct,
+                                                              int kp, int dp, float* __restrict__ Ct,
+                                                              float* __restrict__ Cf,
                                                               float* __restrict__ cn, unsigned* __restrict__ cmax2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (c >= kp) return;
   if (c >= k) {
-    cn[c] = INFINITY;
+    if (lane == 0) cn[c] = INFINITY;
     return;
   }
   double s = 0.0;
-  for (int j = 0; j < d; ++j) {
+  for (int j = lane; j < d; j += 64) {
     const double v = (double)C[(int64_t)c * ldc + j];
     s += v * v;
     Ct[(int64_t)j * kp + c] = (float)v;
+    Cf[(int64_t)c * dp + j] = (float)v;
   }
-  const float sf = (float)s;
-  cn[c] = 0.5f * sf;   // the kernel compares halved scores |c|^2/2 - x.c (exact scaling)
-  // round the max up so the bound stays a bound
-  atomicMax(cmax2, __float_as_uint(sf * 1.0000002f));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) {
+    const float sf = (float)s;
+    cn[c] = 0.5f * sf;   // the kernel compares halved scores |c|^2/2 - x.c (exact scaling)
+    // round the max up so the bound stays a bound
+    atomicMax(cmax2, __float_as_uint(sf * 1.0000002f));
+  }
 }
 
 // TN: 32-column MFMA tiles per wave along the centers (column block of the workgroup = 64 * TN)
@@ -294,196 +305,276 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
   }
 }
 
-// ---- point block RESIDENT in LDS (d <= 256) ------------------------------------------------------
-// The streaming kernel above re-reads its 128-point block from L2/HBM once per center block (PMC:
-// 8.9 GB fetched per call at configs[3] for 1.28 GB of points).  MI355X has 160 KB of LDS per CU: the
-// whole block [128][d] (133 KB at d = 256) is loaded ONCE and stays; only the center tiles stream
-// (L2-resident, 1 MB in all).  One workgroup per CU, 8 waves (4 x 2), wave tile 32 x 64 -- two waves per
-// SIMD, so one wave's LDS reads / epilogue hide behind the other's MFMAs.
-// MEASURED (profiles/r01_notes.md): HBM fetch drops from 8.9 GB to 1.56 GB per call (1.28 GB algorithmic), but the
-// kernel is SLOWER (95 vs 107 TFLOP/s at d = 256, 82 vs 94 at d = 128): the re-reads were not the limiter,
-// one workgroup per CU with 32 x 64 wave tiles is.  Kept selectable (SP_KM_ARES=1), not the default.
-constexpr int KA_THREADS = 512, KA_BN = 128;
-constexpr int KA_B_FLOATS = KM_BK * KA_BN;
+// ---- centers as MFMA ROWS, points as MFMA COLUMNS (round 2; the default) --------------------------
+// score^T[c][i] = |c|^2/2 - c.x_i as an "NT" GEMM: both operands are row-major over the features
+// ([center][k] and [point][k]), both are staged [row][k] (padded) in LDS and read as 16-B fragments.
+// The MFMA's D layout puts ONE POINT per lane column (lane & 31) and 16 CENTERS per accumulator, so
+// the running (best, second best, best's center) of a point is per LANE: 3 registers per point column
+// instead of 3 per accumulator register (96 VGPRs in sp_nearest_fused_kernel above).  That pays for the
+// GEMM's own 256 x 128 macro-tile (wave tile 128 centers x 64 points, 128 accumulator registers, two
+// workgroups per CU): 64 MFMAs per wave per barrier instead of 32, the point block is re-read once per
+// 256 centers instead of once per 128, and the epilogue is 4 VALU ops per score, once per 256-center block.
+// Scores and their error bound E are exactly those of the kernel above (acc = fmaf chain over the
+// features from 0, one subtraction from |c|^2/2), so the set of undecided points is the same.
+constexpr int KN_BM = 256;                       // centers per block (KM_BN_MAX: kp is a multiple of it)
+constexpr int KN_BN = 128;                       // points per workgroup
+constexpr int KN_A_FLOATS = KN_BM * KM_LDA;      // 5120
+constexpr int KN_B_FLOATS = KN_BN * KM_LDA;      // 2560
+constexpr int KN_STAGE = KN_A_FLOATS + KN_B_FLOATS;
+constexpr int KN_SMEM_FLOATS = 2 * KN_STAGE + 2 * KN_BM;   // two stages + two |c|^2/2 slices  (63 488 B)
+static_assert(KN_SMEM_FLOATS * 4 <= 65536, "static LDS limit");
+static_assert(KN_BM == KM_BN_MAX, "kp must be a multiple of the center block");
 
-template <bool FAST>
-__global__ __launch_bounds__(KA_THREADS, 1) void sp_nearest_ares_kernel(const float* __restrict__ X, int64_t ldx,
-                                                                        const float* __restrict__ Ct,
-                                                                        const float* __restrict__ chalf,
-                                                                        const unsigned* __restrict__ cmax2_bits,
-                                                                        int n, int d, int dp, int kp,
-                                                                        int64_t* __restrict__ labels,
-                                                                        int* __restrict__ amb_rows,
-                                                                        float* __restrict__ amb_best,
-                                                                        int* __restrict__ amb_count) {
-  extern __shared__ __attribute__((aligned(16))) float dsm[];
-  __shared__ float xn_s[KM_BM];
-  __shared__ float mb_s[KM_BM], ms_s[KM_BM];
-  __shared__ int mi_s[KM_BM];
-  const int lda = dp + 4;                       // row pad: 8 consecutive rows cover the 32 LDS banks in 16-B units
-  float* sAres = dsm;                           // [128][lda]
-  float* sBst = dsm + KM_BM * lda;              // 2 x [16][128]
+//
+// RECHECK = true is the second pass over the points the first pass could not decide (amb_rows[0 .. *amb_count),
+// gathered through the row list): the same contraction, one workgroup per (128 listed points, 256-center block
+// blockIdx.y), whose epilogue marks every center whose score lies within the error window E of the point's best
+// score -- the only centers that can be the exact answer (best is within E/2 of its true value, a candidate within
+// E/2 of its own) -- as one bit of cand_mask[listed point][kp / 32].  Every word is written by exactly one lane: no
+// atomics, no zeroing.  sp_nearest_candidates_kernel (kmeans.hip) then takes cdist's fp64 distance of the marked
+// centers only.  (Round 1 re-computed all k scores of a listed point with VALU FMAs: 0.68 ms for 1.4 % of the
+// points at configs[3], against 5.5 ms for the whole first pass.)
+template <bool FAST, bool RECHECK>
+__global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __restrict__ X, int64_t ldx,
+                                                               const float* __restrict__ Cf,   // [kp][dp], zero padded
+                                                               const float* __restrict__ chalf,
+                                                               const unsigned* __restrict__ cmax2_bits, int n,
+                                                               int d, int dp, int kp, int64_t* __restrict__ labels,
+                                                               int* __restrict__ amb_rows,
+                                                               float* __restrict__ amb_best,
+                                                               int* __restrict__ amb_count,
+                                                               unsigned* __restrict__ cand_mask) {
+  // ONE LDS object (stages, |c|^2/2 slices; the merge arrays alias stage 0 after the main loop)
+  __shared__ __attribute__((aligned(16))) float smem[KN_SMEM_FLOATS];
+  float* chs = smem + 2 * KN_STAGE;
+  constexpr int THREADS = 256;
+  constexpr int KQ = KM_BK / 4;
+  constexpr int AV = (KN_BM * KQ) / THREADS, BV = (KN_BN * KQ) / THREADS;   // 4, 2 float4 per thread per k-step
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;        // 4 x 2 waves
+  const int wm = wid >> 1, wn = wid & 1;          // wm: center half (128 rows), wn: point half (64 columns)
   const int l31 = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * KM_BM;
+  const int m0 = blockIdx.x * KN_BN;              // first point (RECHECK: first list slot) of this workgroup
+  int listed = 0;
+  if constexpr (RECHECK) {
+    listed = *amb_count;
+    // the grid covers `n` = the capacity of the candidate masks; a longer list is left to the exact kernel
+    if (listed > n || m0 >= listed) return;
+  }
 
-  // ---- the point block, once: coalesced 16-B loads along the features
-  {
-    const int q4 = dp / 4;                      // float4 per row
-    for (int e = tid; e < KM_BM * q4; e += KA_THREADS) {
-      const int row = e / q4, kq = e - row * q4;
-      int grow = m0 + row;
-      if (grow > n - 1) grow = n - 1;           // clamp: results of rows >= n are discarded
-      const float* p = X + (int64_t)grow * ldx + kq * 4;
-      km_f32x4 v;
-      if constexpr (FAST) {
-        v = *(const km_f32x4*)p;
-      } else {
-        const int kk = kq * 4;
-        v.x = kk + 0 < d ? p[0] : 0.f;
-        v.y = kk + 1 < d ? p[1] : 0.f;
-        v.z = kk + 2 < d ? p[2] : 0.f;
-        v.w = kk + 3 < d ? p[3] : 0.f;
-      }
-      *(km_f32x4*)(sAres + row * lda + kq * 4) = v;
+  int a_off[AV], a_lds[AV], b_lds[BV];
+  typename std::conditional<RECHECK, int64_t, int>::type b_off[BV];
+#pragma unroll
+  for (int j = 0; j < AV; ++j) {
+    const int e = tid + j * THREADS;
+    const int row = e / KQ, kq = e % KQ;
+    a_lds[j] = row * KM_LDA + kq * 4;
+    a_off[j] = row * dp + kq * 4;
+  }
+  const float* __restrict__ Xblk = RECHECK ? X : X + (int64_t)m0 * ldx;
+#pragma unroll
+  for (int j = 0; j < BV; ++j) {
+    const int e = tid + j * THREADS;
+    int row = e / KQ;
+    const int kq = e % KQ;
+    b_lds[j] = row * KM_LDA + kq * 4;
+    if constexpr (RECHECK) {
+      const int slot = m0 + row < listed ? m0 + row : listed - 1;   // tail: repeat the last listed point
+      b_off[j] = (int64_t)amb_rows[slot] * ldx + kq * 4;
+    } else {
+      if (m0 + row > n - 1) row = n - 1 - m0;     // clamp: results of points >= n are discarded
+      b_off[j] = row * (int)ldx + kq * 4;
     }
   }
-  // B tile loads: 16 x 128 floats = 512 float4, one per thread
-  const int b_row = tid / (KA_BN / 4), b_nq = tid % (KA_BN / 4);
-  const int b_lds = b_row * KA_BN + b_nq * 4;
-  const int b_off = b_row * kp + b_nq * 4;
   const int nt = dp / KM_BK;
-  const int tiles_n = kp / KA_BN;
-  const int steps = nt * tiles_n;
-  km_f32x4 rb;
-#define KA_LOAD(step)                                                              \
-  do {                                                                             \
-    const int tn_ = (step) / nt, kt_ = (step) - tn_ * nt;                          \
-    rb = *(const km_f32x4*)(Ct + (int64_t)(kt_ * KM_BK) * kp + tn_ * KA_BN + b_off); \
+  const int tm_first = RECHECK ? (int)blockIdx.y : 0;
+  const int tiles_m = RECHECK ? 1 : kp / KN_BM;   // center blocks walked by this workgroup
+  const int steps = nt * tiles_m;
+  km_f32x4 ra[AV], rb[BV], rch;
+
+#define KN_LOAD(step)                                                                    \
+  do {                                                                                   \
+    const int tr_ = (step) / nt, kt_ = (step) - tr_ * nt;                                \
+    const int tm_ = tm_first + tr_;                                                      \
+    const int k0_ = kt_ * KM_BK;                                                         \
+    const float* Ak_ = Cf + (int64_t)tm_ * KN_BM * dp + k0_;                             \
+    _Pragma("unroll") for (int j = 0; j < AV; ++j) ra[j] = *(const km_f32x4*)(Ak_ + a_off[j]); \
+    _Pragma("unroll") for (int j = 0; j < BV; ++j) {                                     \
+      if constexpr (FAST) {                                                              \
+        rb[j] = *(const km_f32x4*)(Xblk + k0_ + b_off[j]);                               \
+      } else {                                                                           \
+        const int kk = k0_ + ((tid + j * THREADS) % KQ) * 4;                             \
+        const float* p = Xblk + k0_ + b_off[j];                                          \
+        rb[j].x = kk + 0 < d ? p[0] : 0.f;                                               \
+        rb[j].y = kk + 1 < d ? p[1] : 0.f;                                               \
+        rb[j].z = kk + 2 < d ? p[2] : 0.f;                                               \
+        rb[j].w = kk + 3 < d ? p[3] : 0.f;                                               \
+      }                                                                                  \
+    }                                                                                    \
+    if (kt_ == 0 && tid < KN_BM / 4) rch = *(const km_f32x4*)(chalf + tm_ * KN_BM + tid * 4); \
   } while (0)
-#define KA_STORE(buf) *(km_f32x4*)(sBst + (buf) * KA_B_FLOATS + b_lds) = rb
+#define KN_STORE(step)                                                                   \
+  do {                                                                                   \
+    float* sA_ = smem + ((step) & 1) * KN_STAGE;                                         \
+    float* sB_ = sA_ + KN_A_FLOATS;                                                      \
+    _Pragma("unroll") for (int j = 0; j < AV; ++j) *(km_f32x4*)(sA_ + a_lds[j]) = ra[j]; \
+    _Pragma("unroll") for (int j = 0; j < BV; ++j) *(km_f32x4*)(sB_ + b_lds[j]) = rb[j]; \
+    const int tr_ = (step) / nt;                                                         \
+    if ((step) - tr_ * nt == 0 && tid < KN_BM / 4) *(km_f32x4*)(chs + (tr_ & 1) * KN_BM + tid * 4) = rch; \
+  } while (0)
 
-  KA_LOAD(0);
-  KA_STORE(0);
+  km_f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // per point column j (points m0 + wn*64 + j*32 + l31), over the centers this lane has seen
+  float best[2] = {INFINITY, INFINITY}, second[2] = {INFINITY, INFINITY};
+  int bcode[2] = {0, 0};                           // best's center, without this lane's 4 * lh
+  float xs[2] = {0.f, 0.f};                        // partial |x|^2 (this lane's k slots), once per pass
+
+  KN_LOAD(0);
+  KN_STORE(0);
   __syncthreads();
-  // |x|^2 per row from the resident block (feeds the error bound only)
-  for (int r = wid; r < KM_BM; r += KA_THREADS / 64) {
-    float s = 0.f;
-    for (int k = lane; k < dp; k += 64) {
-      const float v = sAres[r * lda + k];
-      s = __builtin_fmaf(v, v, s);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) xn_s[r] = s;
-  }
+  const int a_frag = (wm * 128 + l31) * KM_LDA + 4 * lh;
+  const int b_frag = (wn * 64 + l31) * KM_LDA + 4 * lh;
 
-  km_f32x16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float best[16], second[16];
-  int btile[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    best[r] = INFINITY;
-    second[r] = INFINITY;
-    btile[r] = 0;
-  }
-  const int a_frag = (wm * 32 + l31) * lda + 4 * lh;
-  const int b_frag = (4 * lh) * KA_BN + wn * 64 + l31;
-  float chv[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) chv[j] = chalf[(wn * 2 + j) * 32 + l31];
   int t = 0;
-  for (int tn = 0; tn < tiles_n; ++tn) {
+  for (int tr = 0; tr < tiles_m; ++tr) {
+    const int tm = tm_first + tr;
     for (int kt = 0; kt < nt; ++kt, ++t) {
-      if (t + 1 < steps) KA_LOAD(t + 1);
-      const float* sB = sBst + (t & 1) * KA_B_FLOATS;
-      const float* sA = sAres + a_frag + kt * KM_BK;
+      if (t + 1 < steps) KN_LOAD(t + 1);
+      const float* sA = smem + (t & 1) * KN_STAGE;
+      const float* sB = sA + KN_A_FLOATS;
 #pragma unroll
       for (int c = 0; c < KM_BK / 8; ++c) {
-        const km_f32x4 af = *(const km_f32x4*)(sA + c * 8);
-        float bf[2][4];
+        km_f32x4 af[4], bf[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const km_f32x4*)(sA + a_frag + i * 32 * KM_LDA + c * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *(const km_f32x4*)(sB + b_frag + j * 32 * KM_LDA + c * 8);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag + (c * 8 + s) * KA_BN + j * 32];
+          for (int s = 0; s < 4; ++s) xs[j] = __builtin_fmaf(bf[j][s], bf[j][s], xs[j]);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[j][s], acc[j], 0, 0, 0);
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
       }
-      if (t + 1 < steps) KA_STORE((t + 1) & 1);
+      if (t + 1 < steps) KN_STORE(t + 1);
       __syncthreads();
     }
+    // ---- epilogue of center block tm.  Halved scores h = |c|^2/2 - x.c; the rows of a lane ascend with
+    // (i, q, e), so `<` keeps the first minimum; invariant best <= second, and the new second best is the
+    // median of (best, second, h).
+    const float* chb = chs + (tr & 1) * KN_BM + wm * 128 + 4 * lh;
+    if constexpr (RECHECK) {
+      // the window of each of this lane's two listed points, then one mask word per (point, 32 centers)
+      const float cmax2 = __uint_as_float(*cmax2_bits);
+      const float cmax = sqrtf(cmax2) * 1.0000002f;
+      float thr[2];
+      int slot[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        slot[j] = m0 + wn * 64 + j * 32 + l31;
+        const float xnorm = sqrtf(xs[j] + __shfl_xor(xs[j], 32)) * 1.001f;
+        const float E = 5.9604645e-8f * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
+        thr[j] = amb_best[slot[j] < listed ? slot[j] : listed - 1] + E * 1.001f + 1e-30f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned bits[2] = {0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const km_f32x4 ch4 = *(const km_f32x4*)(chb + i * 32 + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              bits[j] |= (ch4[e] - acc[i][j][4 * q + e] <= thr[j]) ? (1u << (8 * q + e)) : 0u;   // (+ 4 lh below)
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned w = bits[j] << (4 * lh);
+          w |= __shfl_xor(w, 32);
+          if (lh == 0 && slot[j] < listed) cand_mask[(int64_t)slot[j] * (kp / 32) + tm * 8 + wm * 4 + i] = w;
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const km_f32x4 ch4 = *(const km_f32x4*)(chb + i * 32 + 8 * q);   // rows i*32 + 8q + 4lh + (0..3)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int code = tm * KN_BM + wm * 128 + i * 32 + 8 * q + e;   // wave-uniform
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float v = ch4[e] - acc[i][j][4 * q + e];
+            const bool better = v < best[j];
+            second[j] = __builtin_amdgcn_fmed3f(best[j], second[j], v);
+            bcode[j] = better ? code : bcode[j];
+            best[j] = fminf(best[j], v);
+            acc[i][j][4 * q + e] = 0.f;
+          }
+        }
+      }
+  }
+#undef KN_LOAD
+#undef KN_STORE
+
+  // ---- merge: the two lane halves of a column (rows differ by 4), then the two center waves (LDS)
+  float* mb_s = smem;                 // [128]   (the stages are dead: every wave passed the last barrier)
+  float* ms_s = smem + KN_BN;
+  int* mi_s = (int*)(smem + 2 * KN_BN);
+  float bb[2], ss[2], xn[2];
+  int ii[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float b = best[j], s = second[j];
+    int ix = bcode[j] + 4 * lh;
+    const float ob = __shfl_xor(b, 32), os = __shfl_xor(s, 32);
+    const int oi = __shfl_xor(ix, 32);
+    if (ob < b || (ob == b && oi < ix)) {
+      s = fminf(b, os);
+      b = ob;
+      ix = oi;
+    } else {
+      s = fminf(ob, s);
+    }
+    bb[j] = b;
+    ss[j] = s;
+    ii[j] = ix;
+    xn[j] = (xs[j] + __shfl_xor(xs[j], 32)) / (float)tiles_m;
+  }
+  if (wm == 1 && lh == 0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int tile = tn * 4 + wn * 2 + j;
-      const float ch = chv[j];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = ch - acc[j][r];
-        const bool better = v < best[r];
-        second[r] = fminf(second[r], fmaxf(v, best[r]));
-        btile[r] = better ? tile : btile[r];
-        best[r] = fminf(best[r], v);
-        acc[j][r] = 0.f;
-      }
-    }
-    if (tn + 1 < tiles_n) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) chv[j] = chalf[((tn + 1) * 4 + wn * 2 + j) * 32 + l31];
-    }
-  }
-#undef KA_LOAD
-#undef KA_STORE
-
-  int bidx[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float b = best[r], s = second[r];
-    int ix = btile[r] * 32 + l31;
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-      const float ob = __shfl_xor(b, off), os = __shfl_xor(s, off);
-      const int oi = __shfl_xor(ix, off);
-      if (ob < b || (ob == b && oi < ix)) {
-        s = fminf(b, os);
-        b = ob;
-        ix = oi;
-      } else {
-        s = fminf(ob, s);
-      }
-    }
-    best[r] = b;
-    second[r] = s;
-    bidx[r] = ix;
-  }
-  if (wn == 1 && l31 == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      mb_s[row] = best[r];
-      ms_s[row] = second[r];
-      mi_s[row] = bidx[r];
+      const int col = wn * 64 + j * 32 + l31;
+      mb_s[col] = bb[j];
+      ms_s[col] = ss[j];
+      mi_s[col] = ii[j];
     }
   }
   __syncthreads();
-  if (wn == 0 && l31 == 0) {
+  if (wm == 0 && lh == 0) {
     const float cmax2 = __uint_as_float(*cmax2_bits);
     const float cmax = sqrtf(cmax2) * 1.0000002f;
     const float u = 5.9604645e-8f;   // 2^-24
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float b = best[r], s = second[r];
-      int ix = bidx[r];
-      const float ob = mb_s[row], os = ms_s[row];
-      const int oi = mi_s[row];
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn * 64 + j * 32 + l31;
+      float b = bb[j], s = ss[j];
+      int ix = ii[j];
+      const float ob = mb_s[col], os = ms_s[col];
+      const int oi = mi_s[col];
       if (ob < b || (ob == b && oi < ix)) {
         s = fminf(b, os);
         b = ob;
@@ -491,15 +582,15 @@ __global__ __launch_bounds__(KA_THREADS, 1) void sp_nearest_ares_kernel(const fl
       } else {
         s = fminf(ob, s);
       }
-      if (m0 + row < n) {
-        const float xnorm = sqrtf(xn_s[row]) * 1.001f;
+      if (m0 + col < n) {
+        const float xnorm = sqrtf(xn[j]) * 1.001f;       // fp32 sum of squares: generous slack
         const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
-        const bool sure = 2.0f * (s - b) > 4.0f * E;
-        labels[m0 + row] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
-        if (!sure) {
+        const bool sure = 2.0f * (s - b) > 4.0f * E;     // (scores are halved) false for NaN / inf-inf as well
+        labels[m0 + col] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
+        if (!sure) {   // (order-free: each listed point is re-done on its own)
           const int pos = atomicAdd(amb_count, 1);
-          amb_rows[pos] = m0 + row;
-          amb_best[pos] = b;
+          amb_rows[pos] = m0 + col;
+          amb_best[pos] = b;   // its best (halved) fp32 score: the re-check's candidate window starts here
         }
       }
     }
@@ -512,30 +603,49 @@ static inline int64_t km_round_up(int64_t v, int64_t m) { return (v + m - 1) / m
 struct KmWorkspace {
   int64_t kp, dp;
   double* Ct64;      // [d][kp]   fp64 transposed centers (exact kernel)
-  float* Ct;         // [dp][kp]  fp32 transposed centers (fused kernel)
+  float* Ct;         // [dp][kp]  fp32 transposed centers (re-check kernel; the streaming fused kernel)
+  float* Cf;         // [kp][dp]  fp32 row-major centers (sp_nearest_nt_kernel)
   float* cn;         // [kp]      |c|^2
   unsigned* cmax2;   // [1]       max |c|^2 (float bits)
   int* amb_count;    // [1]
   int* amb_rows;     // [n]       points the fused kernel could not decide
   float* amb_best;   // [n]       their best (halved) fp32 score
+  int64_t cand_cap;  //           listed points the candidate masks have room for
+  unsigned* cand_mask;   // [cand_cap][kp / 32]  centers inside the error window of a listed point
 };
 
 static inline size_t km_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// features padded to whole k-steps, and to at least TWO of them: the |c|^2/2 slice of center block tm is stored
+// during the last k-step of block tm - 1, which must lie behind a barrier that follows the epilogue of block tm - 2
+static inline int64_t km_padded_features(int64_t d) {
+  const int64_t dp = km_round_up(d < 1 ? 1 : d, KM_BK);
+  return dp < 2 * KM_BK ? 2 * KM_BK : dp;
+}
+
+// The MFMA re-check has room for n / 8 listed points (1.4 % are listed at configs[3]); a longer list -- degenerate
+// data such as many coincident points -- goes to the exact kernel instead (decided on the device, no host sync).
+static inline int64_t km_cand_cap(int64_t n) {
+  int64_t cap = n / 8 < 4096 ? 4096 : n / 8;
+  return cap > n ? (n < 1 ? 1 : n) : cap;
+}
+
 static size_t sp_nearest_fused_ws_bytes(int64_t n, int64_t k, int64_t d) {
-  const int64_t kp = km_round_up(k < 1 ? 1 : k, KM_BN_MAX), dp = km_round_up(d < 1 ? 1 : d, KM_BK);
-  return 256 + km_align((size_t)(d < 1 ? 1 : d) * kp * 8) + km_align((size_t)dp * kp * 4) + km_align((size_t)kp * 4) + 256 + 256 +
-         2 * km_align((size_t)(n < 1 ? 1 : n) * 4);
+  const int64_t kp = km_round_up(k < 1 ? 1 : k, KM_BN_MAX), dp = km_padded_features(d);
+  return 256 + km_align((size_t)(d < 1 ? 1 : d) * kp * 8) + 2 * km_align((size_t)dp * kp * 4) + km_align((size_t)kp * 4) + 256 + 256 +
+         2 * km_align((size_t)(n < 1 ? 1 : n) * 4) + km_align((size_t)km_cand_cap(n) * (kp / 32) * 4);
 }
 
 static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
   KmWorkspace w;
   w.kp = km_round_up(k, KM_BN_MAX);
-  w.dp = km_round_up(d < 1 ? 1 : d, KM_BK);
+  w.dp = km_padded_features(d);
   char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   w.Ct64 = (double*)p;
   p += km_align((size_t)(d < 1 ? 1 : d) * w.kp * 8);
   w.Ct = (float*)p;
+  p += km_align((size_t)w.dp * w.kp * 4);
+  w.Cf = (float*)p;
   p += km_align((size_t)w.dp * w.kp * 4);
   w.cn = (float*)p;
   p += km_align((size_t)w.kp * 4);
@@ -546,6 +656,9 @@ static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
   w.amb_rows = (int*)p;
   p += km_align((size_t)(n < 1 ? 1 : n) * 4);
   w.amb_best = (float*)p;
+  p += km_align((size_t)(n < 1 ? 1 : n) * 4);
+  w.cand_cap = km_cand_cap(n);
+  w.cand_mask = (unsigned*)p;
   return w;
 }
 
@@ -564,66 +677,58 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
   float* Ct = w.Ct;
   float* cn = w.cn;
   unsigned* cmax2 = w.cmax2;
-  SP_HIP(hipMemsetAsync(Ct, 0, (size_t)dp * kp * 4, st));
+  SP_HIP(hipMemsetAsync(Ct, 0, 2 * km_align((size_t)dp * kp * 4), st));   // Ct and Cf (adjacent)
   SP_HIP(hipMemsetAsync(cmax2, 0, 512, st));   // cmax2 and amb_count
-  const unsigned pblocks = (unsigned)((kp + 255) / 256);
+  const unsigned pblocks = (unsigned)((kp + 3) / 4);   // one wavefront per center
   if (cdtype == SP_F32)
     hipLaunchKernelGGL((sp_centers_prep_kernel<float>), dim3(pblocks), dim3(256), 0, st, (const float*)C, ldc, (int)k,
-                       (int)d, (int)kp, Ct, cn, cmax2);
+                       (int)d, (int)kp, (int)dp, Ct, w.Cf, cn, cmax2);
   else
     hipLaunchKernelGGL((sp_centers_prep_kernel<double>), dim3(pblocks), dim3(256), 0, st, (const double*)C, ldc, (int)k,
-                       (int)d, (int)kp, Ct, cn, cmax2);
+                       (int)d, (int)kp, (int)dp, Ct, w.Cf, cn, cmax2);
   SP_CHECK_LAUNCH();
-  const unsigned blocks = (unsigned)((n + KM_BM - 1) / KM_BM);
-  const bool fast = (d % KM_BK == 0) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
-  // d <= 256: the point block fits the CU's LDS next to the streaming center tiles -> resident variant
-  static int ares_env = -1;
-  if (ares_env < 0) {
-    const char* e = getenv("SP_KM_ARES");
-    ares_env = e ? atoi(e) : 0;   // measured slower than the streaming kernel (see the kernel's comment): opt-in
+  // vector loads of the points need whole k-steps inside a row and 16-B alignment
+  const bool fast = (d == dp) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+  // SP_KM_LEGACY=1: the round-1 streaming kernel (points as MFMA rows), kept for A/B measurements
+  static int legacy_env = -1;
+  if (legacy_env < 0) {
+    const char* e = getenv("SP_KM_LEGACY");
+    legacy_env = e ? atoi(e) : 0;
   }
-  if (ares_env && dp <= 256) {
-    const size_t lds = (size_t)(KM_BM * (dp + 4) + 2 * KA_B_FLOATS) * 4;
-    static bool attr_set[2] = {false, false};
-    if (fast) {
-      auto kfn = sp_nearest_ares_kernel<true>;
-      if (!attr_set[0]) {
-        SP_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-        attr_set[0] = true;
-      }
-      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(KA_THREADS), lds, st, X, ldx, Ct, cn, cmax2, (int)n, (int)d, (int)dp,
-                         (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count);
-    } else {
-      auto kfn = sp_nearest_ares_kernel<false>;
-      if (!attr_set[1]) {
-        SP_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-        attr_set[1] = true;
-      }
-      hipLaunchKernelGGL(kfn, dim3(blocks), dim3(KA_THREADS), lds, st, X, ldx, Ct, cn, cmax2, (int)n, (int)d, (int)dp,
-                         (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count);
-    }
+  if (!legacy_env) {
+    const unsigned blocks = (unsigned)((n + KN_BN - 1) / KN_BN);
+    if (fast)
+      hipLaunchKernelGGL((sp_nearest_nt_kernel<true, false>), dim3(blocks), dim3(256), 0, st, X, ldx, w.Cf, cn, cmax2,
+                         (int)n, (int)d, (int)dp, (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count, (unsigned*)nullptr);
+    else
+      hipLaunchKernelGGL((sp_nearest_nt_kernel<false, false>), dim3(blocks), dim3(256), 0, st, X, ldx, w.Cf, cn, cmax2,
+                         (int)n, (int)d, (int)dp, (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count, (unsigned*)nullptr);
     SP_CHECK_LAUNCH();
     return 0;
   }
-  // column block of a workgroup: 128 centers (2 MFMA tiles per wave).  256 (SP_KM_TN=4) needs 47 spilled
-  // registers at 2 workgroups/CU and measured 1.7 % slower (profiles/r01_notes.md)
-  static int tn_env = -1;
-  if (tn_env < 0) {
-    const char* e = getenv("SP_KM_TN");
-    tn_env = e ? atoi(e) : 0;
-  }
-  const int tn_sel = tn_env == 4 ? 4 : 2;
+  const unsigned blocks = (unsigned)((n + KM_BM - 1) / KM_BM);
 #define KM_GO(F, T)                                                                                              \
   hipLaunchKernelGGL((sp_nearest_fused_kernel<F, T>), dim3(blocks), dim3(256), 0, st, X, ldx, Ct, cn, cmax2, (int)n, \
                      (int)d, (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count)
-  if (fast) {
-    if (tn_sel == 4) KM_GO(true, 4);
-    else KM_GO(true, 2);
-  } else {
-    if (tn_sel == 4) KM_GO(false, 4);
-    else KM_GO(false, 2);
-  }
+  if (fast) KM_GO(true, 2);
+  else KM_GO(false, 2);
 #undef KM_GO
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+// Second pass over the listed points: marks the centers inside each point's error window (see the kernel).
+static int sp_nearest_mark_candidates(const float* X, int64_t ldx, int64_t d, const KmWorkspace& w, hipStream_t st) {
+  const bool fast = (d == w.dp) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+  const dim3 grid((unsigned)((w.cand_cap + KN_BN - 1) / KN_BN), (unsigned)(w.kp / KN_BM));
+  if (fast)
+    hipLaunchKernelGGL((sp_nearest_nt_kernel<true, true>), grid, dim3(256), 0, st, X, ldx, w.Cf, w.cn, w.cmax2,
+                       (int)w.cand_cap, (int)d, (int)w.dp, (int)w.kp, (int64_t*)nullptr, w.amb_rows, w.amb_best,
+                       w.amb_count, w.cand_mask);
+  else
+    hipLaunchKernelGGL((sp_nearest_nt_kernel<false, true>), grid, dim3(256), 0, st, X, ldx, w.Cf, w.cn, w.cmax2,
+                       (int)w.cand_cap, (int)d, (int)w.dp, (int)w.kp, (int64_t*)nullptr, w.amb_rows, w.amb_best,
+                       w.amb_count, w.cand_mask);
   SP_CHECK_LAUNCH();
   return 0;
 }

@@ -1,5 +1,3 @@
-"""Driver programs of the reference's examples that BASELINE.json benchmarks
-(spartan/examples/): the SGD regressions (configs[4], benchmark_lreg.py) and
-k-means (configs[3], benchmark_kmeans.py / tests/test_kmeans.py).  Same class
-and function names and argument meaning as the reference; every per-tile body
-runs in HIP kernels through the backend."""
+"""Workload drivers for the two application configs of BASELINE.json: `lreg` (configs[4], least squares
+by gradient steps) and `sklearn.cluster.KMeans` (configs[3]).  They are thin driver loops over the
+expression API; every per-tile body runs in HIP kernels through the backend."""

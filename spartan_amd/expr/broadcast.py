@@ -1,112 +1,102 @@
-"""NumPy-style broadcasting of DistArrays without copying
-(mirror of the reference's spartan/expr/operator/broadcast.py)."""
+"""Stretched views of distributed arrays (NumPy broadcasting without copies).
+
+Role of the reference's spartan/expr/operator/broadcast.py (`Broadcast`, `broadcast`).  Nothing is ever
+replicated in HBM: a `Broadcast` only translates regions between the stretched index space and the array
+underneath, and the kernels read the un-stretched slab through zero strides (lower.py builds the strides from
+the slab's size-1 axes).  The whole translation is one table, built once per view:
+
+    axis_of[i]    the view axis that base axis i is aligned with (right alignment: i + lead)
+    stretched[i]  base axis i has length 1 but the view axis is longer
+
+* view region -> base region (`project`): a stretched axis always reads [0, 1), any other axis keeps the
+  region's bounds; the `lead` leading view axes have no counterpart and drop out.
+* base tile -> view region (`lift`): an aligned, un-stretched axis keeps the tile's bounds, every other view
+  axis is covered completely -- the region of the result that the tile contributes to.
+"""
 import numpy as np
 
-from .. import context
 from ..array import distarray, extent
-from ..util import Assert
-
-
-def _broadcast_invoke(self, tile_id, blob, mapper_fn, kw):
-  """broadcast.py:11-26 (_broadcast_mapper): map a base tile to its broadcast extent."""
-  array = self
-  base_ex = array.base.extent_for_blob(tile_id)
-  ul = [0 for _ in array.shape]
-  lr = [dim for dim in array.shape]
-  for i in range(len(base_ex.ul) - 1, -1, -1):
-    broadcast_i = i + array.prepend_dim
-    if array.base.shape[i] != array.shape[broadcast_i]:
-      assert ul[broadcast_i] == 0
-    else:
-      ul[broadcast_i] = base_ex.ul[i]
-      lr[broadcast_i] = base_ex.lr[i]
-  ex = extent.create(ul, lr, array.shape)
-  return mapper_fn(ex, **kw)
 
 
 class Broadcast(distarray.DistArray):
-  """broadcast.py:28-109."""
+  """`base` seen with shape `shape` (which `base.shape` broadcasts to)."""
 
   def __init__(self, base, shape):
-    Assert.isinstance(base, (np.ndarray, distarray.DistArray))
-    Assert.isinstance(shape, tuple)
-    if isinstance(base, Broadcast):
-      self.base = base.base
-    else:
-      self.base = base
+    if not isinstance(base, (np.ndarray, distarray.DistArray)):
+      raise TypeError('Broadcast of %r' % type(base))
+    if isinstance(base, Broadcast):          # stretch of a stretch: translate from the innermost array
+      base = base.base
+    shape = tuple(int(s) for s in shape)
+    lead = len(shape) - len(base.shape)
+    if lead < 0:
+      raise ValueError('cannot broadcast %s to %s' % (base.shape, shape))
+    self.base = base
     self.shape = shape
-    self.tiles = self.base.tiles
     self.dtype = base.dtype
-    self.sparse = self.base.sparse
+    self.sparse = base.sparse
+    self.tiles = base.tiles
     self.bad_tiles = []
-    self.prepend_dim = len(shape) - len(base.shape)
+    self.axis_of = tuple(i + lead for i in range(len(base.shape)))
+    self.stretched = tuple(n == 1 and shape[a] != 1 for n, a in zip(base.shape, self.axis_of))
+    for n, a, st in zip(base.shape, self.axis_of, self.stretched):
+      if not st and n != shape[a]:
+        raise ValueError('cannot broadcast %s to %s' % (base.shape, shape))
 
   def __repr__(self):
     return 'Broadcast(%s -> %s)' % (self.base, self.shape)
 
+  # the array with the most elements drives a map; a view must lose a tie against a real array of its size
   def real_size(self):
-    """broadcast.py:54-59: offset by one to prefer direct arrays."""
-    return int(np.prod(self.base.shape, dtype=np.int64)) - 1
+    return self.base.real_size() - 1
 
   def extent_for_blob(self, tile_id):
     return self.base.extent_for_blob(tile_id)
 
-  _invoke_mapper = _broadcast_invoke
+  # -- region translation ----------------------------------------------------------------------------
+  def project(self, region):
+    """The part of `base` that the view region `region` reads."""
+    bounds = [(0, 1) if st else (region.ul[a], region.lr[a]) for a, st in zip(self.axis_of, self.stretched)]
+    return extent.create([b[0] for b in bounds], [b[1] for b in bounds], self.base.shape)
+
+  def lift(self, base_region):
+    """The view region that the tile `base_region` of `base` spans."""
+    ul = [0] * len(self.shape)
+    lr = list(self.shape)
+    for i, (a, st) in enumerate(zip(self.axis_of, self.stretched)):
+      if not st:
+        ul[a], lr[a] = base_region.ul[i], base_region.lr[i]
+    return extent.create(ul, lr, self.shape)
+
+  # -- DistArray interface ---------------------------------------------------------------------------
+  def fetch_base_tile(self, region):
+    """The un-stretched slab under `region` (size-1 axes intact, leading axes absent)."""
+    return self.base.fetch(self.project(region))
+
+  fetch = fetch_base_tile
 
   def foreach_tile(self, mapper_fn, kw=None):
-    if kw is None:
-      kw = {}
-    return distarray.run_kernel(self, list(self.base.tiles.values()), mapper_fn, kw)
+    return distarray.run_kernel(self, list(self.tiles.values()), mapper_fn, kw or {})
 
-  def _base_ex(self, ex):
-    """broadcast.py:72-91."""
-    while len(ex.shape) > len(self.base.shape):
-      ex = extent.drop_axis(ex, 0)
-    ul, lr = [], []
-    for i in range(len(self.base.shape)):
-      size = self.base.shape[i]
-      if size == 1:
-        ul.append(0)
-        lr.append(1)
-      else:
-        ul.append(ex.ul[i])
-        lr.append(ex.lr[i])
-    return extent.create(ul, lr, self.base.shape)
+  def _invoke_mapper(self, tile_id, blob, mapper_fn, kw):
+    return mapper_fn(self.lift(self.base.extent_for_blob(tile_id)), **kw)
 
-  def fetch(self, ex):
-    """broadcast.py:93-104.  The slab is returned un-broadcast with size-1 axes;
-    kernels broadcast through zero strides (no copy is ever made)."""
-    return self.fetch_base_tile(ex)
 
-  def fetch_base_tile(self, ex):
-    """broadcast.py:106-109."""
-    ex = self._base_ex(ex)
-    return self.base.fetch(ex)
+def common_shape(shapes):
+  """NumPy's broadcasting rule on a list of shapes (right-aligned; per axis all lengths equal or 1)."""
+  nd = max(len(s) for s in shapes)
+  table = np.ones((len(shapes), nd), dtype=np.int64)
+  for row, s in zip(table, shapes):
+    if len(s):
+      row[nd - len(s):] = s
+  out = table.max(axis=0)
+  if not np.all((table == out) | (table == 1)):
+    raise AssertionError('Mismatched shapes for broadcast: %s' % [list(s) for s in shapes])
+  return tuple(int(n) for n in out)
 
 
 def broadcast(args):
-  """broadcast.py:111-158."""
-  if len(args) == 1:
+  """Bring the arrays to one shape: arrays that already have it are passed through, the others are wrapped."""
+  if len(args) < 2:
     return args
-  orig_shapes = [list(x.shape) for x in args]
-  dims = [len(shape) for shape in orig_shapes]
-  max_dim = max(dims)
-  new_shapes = []
-  for i in range(len(orig_shapes)):
-    diff = max_dim - len(orig_shapes[i])
-    new_shapes.append([1] * diff + orig_shapes[i])
-  for axis in range(max_dim):
-    axis_shape = set(shp[axis] for shp in new_shapes)
-    assert len(axis_shape) <= 2, 'Mismatched shapes for broadcast: %s' % orig_shapes
-    if len(axis_shape) == 2:
-      assert 1 in axis_shape, 'Mismatched shapes for broadcast: %s' % orig_shapes
-    max_size = max(shp[axis] for shp in new_shapes)
-    for shp in new_shapes:
-      shp[axis] = max_size
-  results = []
-  for i in range(len(args)):
-    if new_shapes[i] == orig_shapes[i]:
-      results.append(args[i])
-    else:
-      results.append(Broadcast(args[i], tuple(new_shapes[i])))
-  return results
+  target = common_shape([tuple(a.shape) for a in args])
+  return [a if tuple(a.shape) == target else Broadcast(a, target) for a in args]

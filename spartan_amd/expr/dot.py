@@ -109,6 +109,10 @@ def _fetch_whole_rhs(array, whole_extent):
 
 
 dot_outer_mapper.fetch_rhs = _fetch_whole_rhs
+# every tensor these mappers yield is the output of a kernel launched for it (never an input tile),
+# so the target may adopt it on a first full-tile write instead of copying
+for _m in (dot_map2_np_mapper, dot_map2_vec_mapper, dot_map2_mapper, dot_outer_mapper):
+  _m.yields_fresh_tensors = True
 
 
 def dot(a, b, tile_hint=None):

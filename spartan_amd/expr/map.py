@@ -149,8 +149,12 @@ def join_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target):
     local_user_fn_kw = {}
   result = local_user_fn(join_extents, tiles, **local_user_fn_kw)
   if result is not None:
+    # only a mapper that declares its outputs freshly produced hands them over: what an arbitrary user
+    # mapper yields may be (a view of) a fetched input tile, and a target tile adopting it would alias
+    # -- and later reduce into -- the source array's storage
+    fresh = bool(getattr(local_user_fn, 'yields_fresh_tensors', False))
     for tex, v in result:
-      target.update(tex, v, wait=False, owned=True)
+      target.update(tex, v, wait=False, owned=fresh)
   return LocalKernelResult(result=[])
 
 

@@ -13,6 +13,7 @@ def outer_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target):
   first_tile = arrays[0].fetch(first_extent)
   if local_user_fn_kw is None:
     local_user_fn_kw = {}
+  fresh = bool(getattr(local_user_fn, 'yields_fresh_tensors', False))   # see map.join_mapper
   if axes[1] is None:
     outer_extent = extent.from_shape(arrays[1].shape)
     # a mapper may bring its own way of fetching the whole right-hand array (dot: column chunks
@@ -22,7 +23,7 @@ def outer_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target):
     result = local_user_fn(first_extent, first_tile, outer_extent, outer_tile, **local_user_fn_kw)
     if result is not None:
       for tex, v in result:
-        target.update(tex, v, wait=False, owned=True)
+        target.update(tex, v, wait=False, owned=fresh)
   else:
     done_extent = {}
     for key in arrays[1].tiles.keys():
@@ -33,7 +34,7 @@ def outer_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target):
       result = local_user_fn(first_extent, first_tile, outer_extent, outer_tile, **local_user_fn_kw)
       if result is not None:
         for tex, v in result:
-          target.update(tex, v, wait=False, owned=True)
+          target.update(tex, v, wait=False, owned=fresh)
       done_extent[outer_extent] = True
   return LocalKernelResult(result=[])
 

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import spartan_amd as sp
-from spartan_amd.examples import linear_regression, logistic_regression, ridge_regression
+from spartan_amd.examples import lreg
 from spartan_amd.examples.sklearn.cluster import KMeans
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -69,19 +69,18 @@ def _check_kmeans(workers, impl, tag, exact_centers):
 
 
 def _check_regressions(workers, rtol):
+  """Three gradient steps of examples/lreg.py against the weights the reference's linear_regression produced
+  on the same inputs and the same np.random stream (its SGDRegressor draws w with np.random.rand, sgd.py:30)."""
   gold = GOLD[workers]
   x, y = INPUTS['reg_x'], INPUTS['reg_y']
-  for name, fn in (('lreg', lambda a, b: linear_regression.linear_regression(a, b, 3)),
-                   ('logreg', lambda a, b: logistic_regression.logistic_regression(a, b, 3)),
-                   ('ridge', lambda a, b: ridge_regression.ridge_regression(a, b, 1, 2))):
-    np.random.seed(1234)   # SGDRegressor draws w with np.random.rand (sgd.py:30)
-    w = np.asarray(fn(sp.from_numpy(x), sp.from_numpy(y)))
-    want = gold[name + '_w']
-    assert w.dtype == want.dtype and w.shape == want.shape, name
-    if rtol == 0:
-      np.testing.assert_array_equal(w, want, err_msg=name)
-    else:
-      np.testing.assert_allclose(w, want, rtol=rtol, err_msg=name)
+  np.random.seed(1234)
+  w = np.asarray(lreg.fit(sp.from_numpy(x), sp.from_numpy(y), 3))
+  want = gold['lreg_w']
+  assert w.dtype == want.dtype and w.shape == want.shape
+  if rtol == 0:
+    np.testing.assert_array_equal(w, want)
+  else:
+    np.testing.assert_allclose(w, want, rtol=rtol)
 
 
 # ------------------------------------------------------------------ CPU: host framework on the oracle backend
@@ -133,82 +132,3 @@ def test_kmeans_hip(gpu_ctx, impl, tag):
 @pytest.mark.gpu
 def test_regressions_hip(gpu_ctx):
   _check_regressions(gpu_ctx, rtol=2e-6)
-
-
-# ---------------------------------------------------------------- conj_gradient / jacobi (tests/test_cg.py, test_jacobi.py)
-def _numpy_cg(A, num_iter):
-  """tests/test_cg.py:numpy_cgit / numpy_cg."""
-  x = np.ones((A.shape[1], 1))
-  for _ in range(num_iter):
-    z = np.zeros(x.shape)
-    r = x
-    rho = np.dot(r.T, r).item()
-    p = r
-    for _ in range(15):
-      q = np.dot(A, p)
-      alpha = rho / np.dot(p.T, q).item()
-      z = z + p * alpha
-      rho0 = rho
-      r = r - q * alpha
-      rho = np.dot(r.T, r).item()
-      p = r + p * (rho / rho0)
-    x = z / np.linalg.norm(z, 2)
-  return x
-
-
-def _check_cg_and_jacobi(workers, sparse):
-  from spartan_amd.examples import conj_gradient, jacobi
-  rng = np.random.RandomState(11)
-  n, la = 48, 20
-  a = rng.rand(n, n)
-  a = (a + a.T) * 0.5
-  if sparse:
-    # A itself sparse: a banded symmetric matrix built by a shuffle mapper, minus la on the diagonal
-    import scipy.sparse as sps
-    band = sps.diags([np.full(n - 1, 0.5), np.full(n, -float(la)), np.full(n - 1, 0.5)], [-1, 0, 1], format='coo')
-
-    def mapper(tile, ex):
-      yield ex, band.tocsr()[ex.to_slice()].tocoo()
-    tgt = sp.ndarray((n, n), dtype=np.float64, sparse=True)
-    A = sp.shuffle(tgt, mapper, target=tgt)
-    dense = band.toarray()
-  else:
-    A = sp.from_numpy(a) - sp.sparse_diagonal((n, n)) * la          # tests/test_cg.py:52-56
-    dense = a - np.eye(n) * la
-  got = conj_gradient.conj_gradient(A, 2).glom()
-  # (expr.ones is float32 like the reference's: the start vector is rounded, the rest runs in float64)
-  np.testing.assert_allclose(got, _numpy_cg(dense, 2), rtol=2e-6)
-  # jacobi (tests/test_jacobi.py): the reference's own input constructor, compared with the same iteration in NumPy
-  size = 24
-  Aj, bj = jacobi.jacobi_init(size)
-  x = jacobi.jacobi_method(Aj, bj, 5).glom()
-  an = (np.arange(2, size + 2, dtype=np.float64) * np.arange(4, size + 4, dtype=np.float64).reshape(size, 1))
-  bn = an[:, -1]
-  D = np.diag(an)
-  R = an - np.diagflat(D)
-  xn = np.zeros(size)
-  for _ in range(5):
-    xn = (bn - R.dot(xn)) / D
-  np.testing.assert_allclose(x, xn, rtol=1e-9)
-
-
-@pytest.mark.parametrize('workers', [1, 4])
-@pytest.mark.parametrize('sparse', [False, True])
-def test_cg_and_jacobi_host_framework(workers, sparse):
-  from oracle.np_backend import NumpyBackend
-  sp.initialize(backend=NumpyBackend(), num_workers=workers)
-  try:
-    _check_cg_and_jacobi(workers, sparse)
-  finally:
-    sp.shutdown()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('workers', [1, 4])
-@pytest.mark.parametrize('sparse', [False, True])
-def test_cg_and_jacobi_hip(workers, sparse):
-  sp.initialize('hip', num_workers=workers)
-  try:
-    _check_cg_and_jacobi(workers, sparse)
-  finally:
-    sp.shutdown()

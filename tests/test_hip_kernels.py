@@ -581,6 +581,23 @@ def test_nearest_center_fused_equals_exact(n, k, d):
   assert not np.any(fused == k // 2) or not np.array_equal(c[k // 2], c[0])
 
 
+@pytest.mark.parametrize('n,k,d', [(9000, 40, 24), (6000, 600, 64), (300, 3000, 16), (4000, 64, 32)])
+def test_nearest_center_everything_undecided(n, k, d):
+  """Every centre exists twice, so no point can be decided by the fp32 pass: with more listed points than the
+  candidate masks hold (n / 8, at least 4096) the list goes to the exact kernel, below that to the MFMA re-check
+  (here with more than 64 mask words per point at k = 3000) -- the labels are the exact tier's either way."""
+  from scipy.spatial.distance import cdist
+  x = RNG.rand(n, d).astype(np.float32)
+  half = RNG.rand(k // 2, d)
+  c = np.concatenate([half, half], axis=0)
+  fused = _nearest(x, c, _hip.NEAREST_FUSED)
+  want = np.argmin(cdist(x, c), axis=1)
+  np.testing.assert_array_equal(fused, want)
+  assert fused.max() < k // 2
+  unchecked = _nearest(x, c, _hip.NEAREST_FUSED_UNCHECKED)
+  assert np.all(unchecked < 0)           # the first pass listed every point
+
+
 def test_nearest_center_strided_rows_and_auto_tier():
   from scipy.spatial.distance import cdist
   big = RNG.rand(6000, 96).astype(np.float32)

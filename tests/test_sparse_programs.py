@@ -139,43 +139,6 @@ def test_sparse_rand_gpu():
   _sparse_rand(HipBackend)
 
 
-def _pagerank_example(backend_factory, workers, tile_hint):
-  """spartan_amd/examples/pagerank.py (tests/benchmark_pagerank.py): every page has `deg` out-links (column sums),
-  and the iterated product equals scipy's on the glommed matrix."""
-  from spartan_amd.examples import pagerank
-  sp.initialize(backend=backend_factory(), num_workers=workers)
-  try:
-    np.random.seed(7)
-    n, deg = 240, 5
-    w = pagerank.pagerank_sparse(n, deg, 0.9, tile_hint=tile_hint).force()
-    W = w.glom()
-    assert sps.issparse(W) and W.shape == (n, n) and W.dtype == np.float32
-    np.testing.assert_array_equal(np.asarray(W.sum(axis=0)).ravel(), np.full(n, deg, np.float32))
-    p0 = np.linspace(0.5, 1.5, n, dtype=np.float32).reshape(n, 1)
-    p = pagerank.sparse_multiply(w, sp.from_numpy(p0), num_iter=3)
-    want = p0.astype(np.float64)
-    for _ in range(3):
-      want = W.astype(np.float64) @ want
-    got = p.glom()
-    assert got.shape == (n, 1) and got.dtype == np.float32
-    np.testing.assert_allclose(got, want, rtol=1e-5)
-  finally:
-    sp.shutdown()
-
-
-@pytest.mark.parametrize('workers,tile_hint', [(1, None), (4, (240, 60)), (3, (240, 80))])
-def test_pagerank_example_cpu(workers, tile_hint):
-  from oracle.np_backend import NumpyBackend
-  _pagerank_example(NumpyBackend, workers, tile_hint)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('workers,tile_hint', [(1, None), (4, (240, 60)), (3, (240, 80))])
-def test_pagerank_example_gpu(workers, tile_hint):
-  from spartan_amd.backend_hip import HipBackend
-  _pagerank_example(HipBackend, workers, tile_hint)
-
-
 def _sparse_scan(backend_factory):
   """tests/test_scan.py:test_sparse_scan, with its own lambdas as reduce / scan functions."""
   sp.initialize(backend=backend_factory(), num_workers=4)
