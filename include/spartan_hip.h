@@ -31,6 +31,8 @@ extern "C" {
 #endif
 
 #define SP_ABI_VERSION 1
+#define SP_BLOB_MAX_DIMS 8     /* rank of a library-owned blob (boxes of one: up to 4-d) */
+#define SP_COMM_UID_BYTES 128  /* size of the rendezvous token of sp_comm_unique_id / sp_comm_init */
 
 /* ---- element types of tile blobs (spartan/array/tile.pyx:34-46: a Tile is
  *      shape + dtype + dense data) ---- */
@@ -440,6 +442,79 @@ int sp_gather_rows(const void* d_src, int64_t src_row_stride_bytes, int64_t n_sr
 /* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
  * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
 int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);
+
+/* ---- the tile store: HBM blobs owned by the library ------------------------------------------------------
+ * What a worker's `_blobs: TileId -> Tile` dictionary stores (spartan/worker.py:70) and BlobCtx creates, reads,
+ * updates and destroys (spartan/blob_ctx.py:103-254; worker.py:126-185).  A handle is an opaque non-zero uint64;
+ * the blob is dense, row-major, on the device that was current at creation, and lives until sp_blob_destroy
+ * (the reference's refcnt / destroy_all, worker.py:152-170).  Destroyed allocations are kept for re-use (tile
+ * sizes repeat every iteration and hipFree synchronises the device); sp_blob_trim returns them to the driver.
+ * Re-use is stream-ordered: keep to one compute stream per device, or synchronise before destroying a blob that
+ * another stream still uses.  The entry points above take plain device pointers: sp_blob_info gives a blob's.
+ *   sp_blob_h2d / sp_blob_d2h   `create(Tile.from_data(ndarray))` / `get(tile_id, subslice)` towards a host
+ *                               array: the box [ul, lr) of the blob (NULL, NULL = all of it) <-> a contiguous
+ *                               host buffer of the box's shape; asynchronous on `stream`.
+ *   sp_blob_slice_copy          `get` + `update(reducer=None)` between two tiles of one worker: the fetch stitch
+ *                               of spartan/array/distarray.py:355-365 on handles. */
+int sp_blob_create(const int64_t* shape, int32_t ndim, int32_t dtype, uint64_t* handle);
+int sp_blob_destroy(uint64_t handle);
+int sp_blob_trim(void);
+int sp_blob_info(uint64_t handle, void** d_ptr, int64_t* shape, int32_t* ndim, int32_t* dtype);
+int sp_blob_stats(int64_t* live_blobs, int64_t* pooled_bytes);
+int sp_blob_h2d(uint64_t handle, const void* host, const int64_t* ul, const int64_t* lr, void* stream);
+int sp_blob_d2h(uint64_t handle, void* host, const int64_t* ul, const int64_t* lr, void* stream);
+int sp_blob_slice_copy(uint64_t dst, const int64_t* dst_ul, uint64_t src, const int64_t* src_ul,
+                       const int64_t* extent, void* stream);
+
+/* ---- the data plane between workers: collectives over RCCL / xGMI ------------------------------------------
+ * One process per GPU.  These replace the reference's tile traffic between workers -- `BlobCtx.update(tile_id,
+ * region, data, reducer)` pushed to the owner and merged there, `BlobCtx.get(tile_id, subslice)` pulled from it
+ * (spartan/blob_ctx.py:143-179, worker.py:172-230, carried by ZeroMQ in spartan/rpc/zeromq.py) -- for the regular
+ * patterns of the tile path:
+ *   sp_comm_reduce_scatter   every worker holds a partial of the WHOLE target, the target is tiled one equal
+ *                            contiguous piece per worker: `update(np.add)` of sum(axis=0) / dot(tile_hint=(M/p,N))
+ *                            (distarray.py:372-422).  d_src: world * recv_count elements, d_dst: recv_count.
+ *   sp_comm_reduce           the same into a one-tile target (dot's default tile_hint, dot.py:277-278; scalars)
+ *   sp_comm_all_reduce       replicated results (k-means counts and sums)
+ *   sp_comm_all_gather       `glom` / fetch of a whole one-tile-per-worker array (distarray.py:294-367)
+ *   sp_comm_bcast            replicated fetch of one tile; small driver-side operands
+ *   sp_comm_all_to_all_blocks  `fetch` of slabs that lie in other workers' tiles (the A column slabs of dot's
+ *                            map2 join, map.py:243-286) and irregular updates: any set of point-to-point
+ *                            blocks (bytes), issued as ONE group.  Blocks between the same two ranks are matched
+ *                            in list order.
+ * Rendezvous: rank 0 calls sp_comm_unique_id and hands the SP_COMM_UID_BYTES token to every rank by whatever
+ * channel the host has (the reference's workers register with the master over TCP, worker.py:98-124); every
+ * rank then calls sp_comm_init with the device it computes on current.  reducer: enum sp_reducer (ADD MUL MAX
+ * MIN; AND / OR for SP_BOOL).  All calls are asynchronous on `stream`; RCCL is bound at run time
+ * (sp_comm_available() == 0 when the host has none). */
+int sp_comm_available(void);
+int sp_comm_version(int* version);
+int sp_comm_unique_id(void* uid, size_t uid_bytes);
+int sp_comm_init(int32_t world, int32_t rank, const void* uid, void** comm);
+int sp_comm_destroy(void* comm);
+int sp_comm_abort(void* comm);
+int sp_comm_async_error(void* comm);
+int sp_comm_all_reduce(void* comm, const void* d_src, void* d_dst, int64_t count, int32_t dtype, int32_t reducer,
+                       void* stream);
+int sp_comm_reduce_scatter(void* comm, const void* d_src, void* d_dst, int64_t recv_count, int32_t dtype,
+                           int32_t reducer, void* stream);
+int sp_comm_reduce(void* comm, const void* d_src, void* d_dst, int64_t count, int32_t dtype, int32_t reducer,
+                   int32_t root, void* stream);
+int sp_comm_all_gather(void* comm, const void* d_src, void* d_dst, int64_t send_count, int32_t dtype, void* stream);
+int sp_comm_bcast(void* comm, void* d_buf, int64_t count, int32_t dtype, int32_t root, void* stream);
+int sp_comm_all_to_all_blocks(void* comm, int32_t n_sends, const int32_t* send_peers, const void* const* d_send,
+                              const int64_t* send_bytes, int32_t n_recvs, const int32_t* recv_peers,
+                              void* const* d_recv, const int64_t* recv_bytes, void* stream);
+
+/* Streams for a host that has none of its own (compute + communication), and ordering between streams through
+ * the events below (the reference's worker serialises tile mutation with a lock, worker.py:134,160,181; here it
+ * is stream order). */
+int sp_set_device(int32_t device);
+int sp_stream_create(void** stream);
+int sp_stream_destroy(void* stream);
+int sp_stream_synchronize(void* stream);
+int sp_stream_query(void* stream, int32_t* done);
+int sp_stream_wait_event(void* stream, void* ev);
 
 /* HIP-event timing of work already enqueued on `stream`; used by bench.py so
  * kernel durations are measured on the stream the kernels were launched on. */

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get('SPARTAN_HIP_LIB') or os.path.join(_HERE, 'csrc', 'lib
 # ---- enums (mirror include/spartan_hip.h) ---------------------------------
 SP_F32, SP_F64, SP_I32, SP_I64, SP_BOOL, SP_U8 = range(6)
 SP_MAX_INPUTS, SP_MAX_INSTR, SP_MAX_CONSTS, SP_MAX_DIMS, SP_NREG = 8, 64, 16, 4, 8
+SP_BLOB_MAX_DIMS, SP_COMM_UID_BYTES = 8, 128
 
 OP = dict(
     NOP=0, CONST=1, IOTA=2, MOV=3,
@@ -138,6 +139,34 @@ def _declare(lib):
   lib.sp_tiling_solve.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
   lib.sp_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp]
   lib.sp_stream_copy.argtypes = [vp, vp, sz, vp]
+  u64 = C.c_uint64
+  lib.sp_blob_create.argtypes = [p64, i32, i32, C.POINTER(u64)]
+  lib.sp_blob_destroy.argtypes = [u64]
+  lib.sp_blob_trim.argtypes = []
+  lib.sp_blob_info.argtypes = [u64, pp, p64, C.POINTER(i32), C.POINTER(i32)]
+  lib.sp_blob_stats.argtypes = [p64, p64]
+  lib.sp_blob_h2d.argtypes = [u64, vp, p64, p64, vp]
+  lib.sp_blob_d2h.argtypes = [u64, vp, p64, p64, vp]
+  lib.sp_blob_slice_copy.argtypes = [u64, p64, u64, p64, p64, vp]
+  lib.sp_comm_available.argtypes = []
+  lib.sp_comm_version.argtypes = [C.POINTER(C.c_int)]
+  lib.sp_comm_unique_id.argtypes = [vp, sz]
+  lib.sp_comm_init.argtypes = [i32, i32, vp, pp]
+  lib.sp_comm_destroy.argtypes = [vp]
+  lib.sp_comm_abort.argtypes = [vp]
+  lib.sp_comm_async_error.argtypes = [vp]
+  lib.sp_comm_all_reduce.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+  lib.sp_comm_reduce_scatter.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+  lib.sp_comm_reduce.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp]
+  lib.sp_comm_all_gather.argtypes = [vp, vp, vp, i64, i32, vp]
+  lib.sp_comm_bcast.argtypes = [vp, vp, i64, i32, i32, vp]
+  lib.sp_comm_all_to_all_blocks.argtypes = [vp, i32, C.POINTER(i32), pp, p64, i32, C.POINTER(i32), pp, p64, vp]
+  lib.sp_set_device.argtypes = [i32]
+  lib.sp_stream_create.argtypes = [pp]
+  lib.sp_stream_destroy.argtypes = [vp]
+  lib.sp_stream_synchronize.argtypes = [vp]
+  lib.sp_stream_query.argtypes = [vp, C.POINTER(i32)]
+  lib.sp_stream_wait_event.argtypes = [vp, vp]
   lib.sp_event_create.argtypes = [pp]
   lib.sp_event_destroy.argtypes = [vp]
   lib.sp_event_record.argtypes = [vp, vp]
@@ -156,6 +185,11 @@ EXPORTS = [
     'sp_coo_to_csr_workspace_bytes', 'sp_coo_to_csr', 'sp_csr_rows', 'sp_coo_box', 'sp_coo_reshape', 'sp_csr_spmm_workspace_bytes', 'sp_csr_spmv_plan_entries', 'sp_csr_spmv_plan', 'sp_csr_spmm', 'sp_csr_scatter',
     'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_sort_rows_workspace_bytes', 'sp_sort_rows', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',
+    'sp_blob_create', 'sp_blob_destroy', 'sp_blob_trim', 'sp_blob_info', 'sp_blob_stats', 'sp_blob_h2d', 'sp_blob_d2h',
+    'sp_blob_slice_copy', 'sp_comm_available', 'sp_comm_version', 'sp_comm_unique_id', 'sp_comm_init',
+    'sp_comm_destroy', 'sp_comm_abort', 'sp_comm_async_error', 'sp_comm_all_reduce', 'sp_comm_reduce_scatter',
+    'sp_comm_reduce', 'sp_comm_all_gather', 'sp_comm_bcast', 'sp_comm_all_to_all_blocks', 'sp_set_device',
+    'sp_stream_create', 'sp_stream_destroy', 'sp_stream_synchronize', 'sp_stream_query', 'sp_stream_wait_event',
 ]
 
 

@@ -1,19 +1,26 @@
-"""K-Means (reference spartan/examples/sklearn/cluster/k_means_.py), BASELINE configs[3].
+"""Lloyd's k-means over a row-tiled point array: the workload of BASELINE configs[3].
 
-The per-tile bodies of the reference's mappers are HIP kernels behind the backend:
+Interface of the reference's spartan/examples/sklearn/cluster/k_means_.py (`KMeans(n_clusters, n_iter)
+.fit(X, centers, implementation)` -> (centers, labels)), including its four ways of phrasing one iteration,
+because each of them exercises a different part of the tile path:
 
-  np.argmin(cdist(points, centers), axis=1)   -> backend.nearest_center  (sp_nearest_center:
-        fp32 MFMA GEMM with the argmin fused into the epilogue, exact fp64 re-check of near ties)
-  np.bincount(labels, minlength=k)            -> backend.bincount        (sp_bincount_i64)
-  new_centers[i] = points[labels == i].sum(0) -> backend.segment_sum     (sp_segment_sum)
+  'map2'       assign = map2 join of every point tile with driver-side centers; accumulate = two more map2
+               joins (counts, per-cluster sums) merged into k-row targets
+  'outer'      the same with the centers as a distributed array fetched whole by every tile (outer join)
+  'broadcast'  pure expressions: (N,1,D) - (1,K,D), square, sum, argmin, one-hot sums -- map / reduce fusion
+  'shuffle'    one shuffle whose mapper updates three reducer targets
 
-`KMeans.fit` keeps the reference's four implementations and their argument meaning.
-One faithful quirk is kept as the default and made switchable: the reference's map2 /
-outer variants create the `counts` / `new_centers` targets WITHOUT a reducer
-(k_means_.py:133-141), so with more than one tile the value of the last tile to arrive
-replaces the others instead of being added.  `fit(..., reducer=np.add)` combines the
-per-tile partials (reduce / reduce-scatter over RCCL), which is the algorithm the
-'shuffle' variant implements with its `reduce_fn` (k_means_.py:236-239).
+Per tile the work is three kernels behind the backend:
+  nearest_center  labels = argmin_c |x - c|   sp_nearest_center (fp32 MFMA, candidate re-check in fp64)
+  bincount        counts of each label         sp_bincount_i64
+  segment_sum     per-cluster sums of rows     sp_segment_sum
+
+An iteration is  assign -> accumulate -> `_finish` (driver: re-seed empty clusters, divide).  Two behaviours of
+the reference are kept because its recorded outputs (tests/golden/examples_w*.npz) depend on them: the join
+variants create their count / sum targets WITHOUT a reducer (k_means_.py:133-141), so with several tiles the last
+tile's partial replaces the others -- pass `reducer=np.add` for the real update, as bench.py does -- and the
+'shuffle' variant divides by a (k, 1) count column.  Everything the driver draws at random is drawn by rank 0
+and sent to the other ranks: with one process per GPU every rank runs this loop and must step the same centers.
 """
 import numpy as np
 
@@ -21,164 +28,154 @@ from .... import context, expr
 from ....array import distarray, extent
 
 
-def _tile_op(method, out_shape, out_dtype, *tiles, **kw):
-  """backend.<method>(*tiles) on the executing rank, an Absent placeholder elsewhere."""
+def _replicated(draw):
+  """A driver-level random value, identical on every rank."""
+  value = draw()
+  if context.initialized():
+    value = context.get().world.broadcast_object(value, 0)
+  return value
+
+
+def _on_tile(method, out_shape, out_dtype, *tiles, **kw):
+  """backend.<method>(*tiles) where the tile lives; a shape/dtype placeholder on the other ranks."""
   if any(isinstance(t, distarray.Absent) for t in tiles):
     return distarray.Absent(tuple(out_shape), np.dtype(out_dtype))
   return getattr(context.get().backend, method)(*tiles, **kw)
 
 
-def _find_closest(pts, centers):
-  """k_means_.py:11-28 (first strict minimum) == argmin of the squared distances."""
-  return _tile_op('nearest_center', (pts.shape[0],), np.int64, pts, centers)
+def _nearest(points, centers):
+  return _on_tile('nearest_center', (points.shape[0],), np.int64, points, centers)
 
 
-def _find_cluster_mapper(inputs, ex, d_pts, old_centers, new_centers, new_counts, labels):
-  """k_means_.py:31-49: the 'shuffle' variant's per-tile body."""
-  centers = old_centers
-  pts = d_pts.fetch(ex)
-  k = centers.shape[0]
-  closest = _find_closest(pts, centers)
-  l_counts = _tile_op('bincount', (k,), np.int64, closest, k=k).reshape(k, 1)
-  l_centers = _tile_op('segment_sum', (k, centers.shape[1]), d_pts.dtype, pts, closest, k=k)
-  new_centers.update(extent.from_shape(new_centers.shape), l_centers)
-  new_counts.update(extent.from_shape(new_counts.shape), l_counts)
-  labels.update(extent.create(ex.ul, (ex.lr[0], 1), labels.shape), closest.reshape(pts.shape[0], 1))
-  return []
+def _rows_of(ex):
+  """Target region (rows of the point tile) in the 1-D label array."""
+  return extent.create((ex.ul[0],), (ex.lr[0],), (ex.array_shape[0],))
 
 
-def kmeans_outer_dist_mapper(ex_a, tile_a, ex_b, tile_b):
-  """k_means_.py:52-58."""
-  target_ex = extent.create((ex_a[0].ul[0],), (ex_a[0].lr[0],), (ex_a[0].array_shape[0],))
-  yield target_ex, _tile_op('nearest_center', (tile_a.shape[0],), np.int64, tile_a, tile_b)
+# ---- tile bodies of the join variants (the mapper protocols of map2 / outer) ---------------------------------
+def kmeans_map2_dist_mapper(extents, tiles, centers=None):
+  yield _rows_of(extents[0]), _nearest(tiles[0], centers)
 
 
-def kmeans_map2_dist_mapper(ex, tile, centers=None):
-  """k_means_.py:61-66."""
-  points = tile[0]
-  target_ex = extent.create((ex[0].ul[0],), (ex[0].lr[0],), (ex[0].array_shape[0],))
-  yield target_ex, _tile_op('nearest_center', (points.shape[0],), np.int64, points, centers)
+def kmeans_outer_dist_mapper(ex_points, points, ex_centers, centers):
+  yield _rows_of(ex_points), _nearest(points, centers)
 
 
 def kmeans_count_mapper(extents, tiles, centers_count):
-  """k_means_.py:69-72."""
-  target_ex = extent.create((0,), (centers_count,), (centers_count,))
-  yield target_ex, _tile_op('bincount', (centers_count,), np.int64, tiles[0], k=centers_count)
+  whole = extent.create((0,), (centers_count,), (centers_count,))
+  yield whole, _on_tile('bincount', (centers_count,), np.int64, tiles[0], k=centers_count)
 
 
 def kmeans_center_mapper(extents, tiles, centers_count):
-  """k_means_.py:75-97."""
-  points, labels = tiles[0], tiles[1]
-  target_ex = extent.create((0, 0), (centers_count, points.shape[1]), (centers_count, points.shape[1]))
-  yield target_ex, _tile_op('segment_sum', (centers_count, points.shape[1]),
-                            context.get().backend.dtype_of(points), points, labels, k=centers_count)
+  points, labels = tiles
+  dim = points.shape[1]
+  whole = extent.create((0, 0), (centers_count, dim), (centers_count, dim))
+  yield whole, _on_tile('segment_sum', (centers_count, dim), context.get().backend.dtype_of(points),
+                        points, labels, k=centers_count)
+
+
+for _m in (kmeans_map2_dist_mapper, kmeans_outer_dist_mapper, kmeans_count_mapper, kmeans_center_mapper):
+  _m.yields_fresh_tensors = True      # kernel outputs, never input tiles (see expr/map.join_mapper)
+
+
+def _find_cluster_mapper(inputs, ex, d_pts, old_centers, new_centers, new_counts, labels):
+  """Tile body of the 'shuffle' variant: all three products of one tile, pushed into reducer targets."""
+  points = d_pts.fetch(ex)
+  k, dim = old_centers.shape
+  nearest = _nearest(points, old_centers)
+  new_centers.update(extent.from_shape(new_centers.shape),
+                     _on_tile('segment_sum', (k, dim), d_pts.dtype, points, nearest, k=k))
+  new_counts.update(extent.from_shape(new_counts.shape),
+                    _on_tile('bincount', (k,), np.int64, nearest, k=k).reshape(k, 1))
+  labels.update(extent.create(ex.ul, (ex.lr[0], 1), labels.shape), nearest.reshape(points.shape[0], 1))
+  return []
 
 
 class KMeans(object):
   def __init__(self, n_clusters=8, n_iter=100):
-    """k_means_.py:100-115."""
     self.n_clusters = n_clusters
     self.n_iter = n_iter
 
-  def _reseed_and_divide(self, centers, counts, num_dim):
-    """k_means_.py:145-157: empty clusters are re-seeded from randn, then sums / counts."""
-    zcount_indices = (counts == 0).reshape(self.n_clusters)
-    if np.any(zcount_indices):
-      n_points = np.count_nonzero(zcount_indices)
-      counts[zcount_indices] = 1
-      centers[zcount_indices, :] = np.random.randn(n_points, num_dim)
-    return centers / counts.reshape(centers.shape[0], 1)
+  # ---- driver side of an iteration --------------------------------------------------------------------------
+  def _finish(self, sums, counts):
+    """Empty clusters get a fresh standard-normal center; the others the mean of their points."""
+    empty = (counts == 0).reshape(self.n_clusters)
+    n_empty = int(np.count_nonzero(empty))
+    if n_empty:
+      counts[empty] = 1
+      sums[empty, :] = _replicated(lambda: np.random.randn(n_empty, sums.shape[1]))
+    return sums, counts
+
+  def _accumulate_join(self, X, labels, reducer):
+    k, dim = self.n_clusters, X.shape[1]
+    counts = expr.map2(labels, 0, fn=kmeans_count_mapper, fn_kw={'centers_count': k}, shape=(k,),
+                       reducer=reducer)
+    sums = expr.map2((X, labels), (0, 0), fn=kmeans_center_mapper, fn_kw={'centers_count': k},
+                     shape=(k, dim), reducer=reducer)
+    counts = counts.optimized().glom()
+    sums = sums.optimized().glom()
+    sums, counts = self._finish(sums, counts)
+    return sums / counts.reshape(k, 1)
+
+  # ---- one iteration per implementation: (X, centers) -> (centers, labels) -----------------------------------
+  def _step_map2(self, X, centers, reducer):
+    labels = expr.map2(X, 0, fn=kmeans_map2_dist_mapper, fn_kw={'centers': centers}, shape=(X.shape[0],))
+    return self._accumulate_join(X, labels, reducer), labels
+
+  def _step_outer(self, X, centers, reducer):
+    labels = expr.outer((X, centers), (0, None), fn=kmeans_outer_dist_mapper, shape=(X.shape[0],))
+    return expr.from_numpy(self._accumulate_join(X, labels, reducer)), labels
+
+  def _step_broadcast(self, X, centers, reducer):
+    k, dim = centers.shape
+    x3 = expr.reshape(X, (X.shape[0], 1, dim))
+    c3 = expr.reshape(centers, (1, k, dim))
+    labels = expr.argmin(expr.sum(expr.square(x3 - c3), axis=2), axis=1)
+    onehot = (expr.reshape(labels, (labels.shape[0], 1)) == expr.arange((1, k))).astype(np.int64)
+    counts = expr.sum(onehot, axis=0)
+    sums = expr.sum(x3 * expr.reshape(onehot, (onehot.shape[0], k, 1)), axis=0)
+    counts = counts.optimized().glom()
+    sums = sums.optimized().glom()
+    sums, counts = self._finish(sums, counts)
+    return expr.from_numpy(sums / counts.reshape(k, 1)), labels
+
+  def _step_shuffle(self, X, centers, labels):
+    k, dim = self.n_clusters, X.shape[1]
+    sums = expr.ndarray((k, dim), reduce_fn=np.add)
+    counts = expr.ndarray((k, 1), dtype=np.int64, reduce_fn=np.add)
+    expr.shuffle(X, _find_cluster_mapper,
+                 kw={'d_pts': X, 'old_centers': centers, 'new_centers': sums, 'new_counts': counts,
+                     'labels': labels},
+                 shape_hint=(1,),
+                 cost_hint={hash(labels): {'00': 0, '01': np.prod(labels.shape)}}).evaluate()
+    sums, counts = self._finish(sums.glom(), counts.glom())
+    return sums / counts
 
   def fit(self, X, centers=None, implementation='map2', reducer=None):
-    """Compute k-means clustering (k_means_.py:117-267).
+    """Run `n_iter` iterations from `centers` (uniform random when None).
 
-    X: spartan matrix (n_samples, n_features), tiled by rows.
-    centers: initial centers (numpy.ndarray); random if None.
-    reducer: combine function of the per-tile counts / center sums of the 'map2' and
-      'outer' variants; None reproduces the reference (see the module docstring).
-    Returns (centers, labels).
+    X: expression / array of shape (n_samples, n_features), tiled by rows.
+    centers: start centers; a NumPy array for 'map2' / 'shuffle', an expression for 'outer' / 'broadcast'.
+    reducer: how the join variants combine the per-tile counts and sums (None: the reference's behaviour,
+      see the module docstring; np.add: the real update).
+    Returns (centers, labels); `labels` is an expression of the last assignment.
     """
-    num_dim = X.shape[1]
-    num_points = X.shape[0]
-    labels = expr.zeros((num_points, 1), dtype=np.int64)
-
-    if implementation == 'map2':
+    k, dim = self.n_clusters, X.shape[1]
+    labels = expr.zeros((X.shape[0], 1), dtype=np.int64)
+    if implementation in ('map2', 'shuffle'):
       if centers is None:
-        centers = np.random.rand(self.n_clusters, num_dim)
-      for i in range(self.n_iter):
-        labels = expr.map2(X, 0, fn=kmeans_map2_dist_mapper, fn_kw={"centers": centers},
-                           shape=(X.shape[0],))
-        counts = expr.map2(labels, 0, fn=kmeans_count_mapper,
-                           fn_kw={'centers_count': self.n_clusters},
-                           shape=(centers.shape[0],), reducer=reducer)
-        new_centers = expr.map2((X, labels), (0, 0), fn=kmeans_center_mapper,
-                                fn_kw={'centers_count': self.n_clusters},
-                                shape=(centers.shape[0], centers.shape[1]), reducer=reducer)
-        counts = counts.optimized().glom()
-        centers = new_centers.optimized().glom()
-        centers = self._reseed_and_divide(centers, counts, num_dim)
+        centers = _replicated(lambda: np.random.rand(k, dim))
+      for _ in range(self.n_iter):
+        if implementation == 'map2':
+          centers, labels = self._step_map2(X, centers, reducer)
+        else:
+          centers = self._step_shuffle(X, centers, labels)
       return centers, labels
-
-    elif implementation == 'outer':
+    if implementation in ('outer', 'broadcast'):
       if centers is None:
-        centers = expr.rand(self.n_clusters, num_dim)
-      for i in range(self.n_iter):
-        labels = expr.outer((X, centers), (0, None), fn=kmeans_outer_dist_mapper,
-                            shape=(X.shape[0],))
-        counts = expr.map2(labels, 0, fn=kmeans_count_mapper,
-                           fn_kw={'centers_count': self.n_clusters},
-                           shape=(centers.shape[0],), reducer=reducer)
-        new_centers = expr.map2((X, labels), (0, 0), fn=kmeans_center_mapper,
-                                fn_kw={'centers_count': self.n_clusters},
-                                shape=(centers.shape[0], centers.shape[1]), reducer=reducer)
-        counts = counts.optimized().glom()
-        centers = new_centers.optimized().glom()
-        centers = self._reseed_and_divide(centers, counts, num_dim)
-        centers = expr.from_numpy(centers)
+        centers = expr.rand(k, dim)
+      step = self._step_outer if implementation == 'outer' else self._step_broadcast
+      for _ in range(self.n_iter):
+        centers, labels = step(X, centers, reducer)
       return centers, labels
-
-    elif implementation == 'broadcast':
-      if centers is None:
-        centers = expr.rand(self.n_clusters, num_dim)
-      for i in range(self.n_iter):
-        X_broadcast = expr.reshape(X, (X.shape[0], 1, X.shape[1]))
-        centers_broadcast = expr.reshape(centers, (1, centers.shape[0], centers.shape[1]))
-        distances = expr.sum(expr.square(X_broadcast - centers_broadcast), axis=2)
-        labels = expr.argmin(distances, axis=1)
-        center_idx = expr.arange((1, centers.shape[0]))
-        matches = expr.reshape(labels, (labels.shape[0], 1)) == center_idx
-        matches = matches.astype(np.int64)
-        counts = expr.sum(matches, axis=0)
-        centers = expr.sum(X_broadcast * expr.reshape(matches, (matches.shape[0], matches.shape[1], 1)),
-                           axis=0)
-        counts = counts.optimized().glom()
-        centers = centers.optimized().glom()
-        centers = self._reseed_and_divide(centers, counts, num_dim)
-        centers = expr.from_numpy(centers)
-      return centers, labels
-
-    elif implementation == 'shuffle':
-      if centers is None:
-        centers = np.random.rand(self.n_clusters, num_dim)
-      for i in range(self.n_iter):
-        # (the reference passes `lambda a, b: a + b`; np.add is the same function with a combine kernel)
-        new_centers = expr.ndarray((self.n_clusters, num_dim), reduce_fn=np.add)
-        new_counts = expr.ndarray((self.n_clusters, 1), dtype=np.int64, reduce_fn=np.add)
-        _ = expr.shuffle(X, _find_cluster_mapper,
-                         kw={'d_pts': X, 'old_centers': centers, 'new_centers': new_centers,
-                             'new_counts': new_counts, 'labels': labels},
-                         shape_hint=(1,),
-                         cost_hint={hash(labels): {'00': 0, '01': np.prod(labels.shape)}})
-        _.evaluate()
-        new_counts = new_counts.glom()
-        new_centers = new_centers.glom()
-        zcount_indices = (new_counts == 0).reshape(self.n_clusters)
-        if np.any(zcount_indices):
-          n_points = np.count_nonzero(zcount_indices)
-          new_counts[zcount_indices] = 1
-          new_centers[zcount_indices, :] = np.random.randn(n_points, num_dim)
-        new_centers = new_centers / new_counts
-        centers = new_centers
-      return centers, labels
-
     raise ValueError('unknown implementation %r' % (implementation,))

@@ -253,16 +253,18 @@ _make_randint._sp_random = ('randint', np.int64)
 
 
 def set_random_seed(seed=None):
-  """srandom.py:23-35 re-seeds every worker from the clock; here: seed the backend's
-  generator (None = from the clock), mixed with the rank so workers draw distinct streams."""
+  """srandom.py:23-35 re-seeds every worker from the clock.  Here two generators are seeded: the backend's
+  per-tile generator, mixed with the rank so the ranks fill their tiles from distinct streams, and the DRIVER's
+  np.random, with the SAME value on every rank -- the driver program runs on every rank and whatever it draws
+  (start weights, start centers) is replicated state.  A clock seed is taken on rank 0 and sent to the others."""
   import os
   import time
   ctx = context.get()
   if seed is None:
-    seed = (int(time.time() * 100000) + os.getpid()) % 4294967295
+    seed = ctx.world.broadcast_object((int(time.time() * 100000) + os.getpid()) % 4294967295, 0)
   if hasattr(ctx.backend, 'seed_random'):
     ctx.backend.seed_random(int(seed) * 1000003 + ctx.world.rank)
-  np.random.seed((int(seed) + ctx.world.rank) % 4294967295)
+  np.random.seed(int(seed) % 4294967295)
 
 
 def _tile_hint_kw(kw):

@@ -33,7 +33,21 @@ def run_examples(total_workers):
   want = np.stack([x[lab == i].sum(axis=0) for i in range(5)]) / np.bincount(lab, minlength=5)[:, None]
   np.testing.assert_array_equal(T._val(labels), lab.astype(np.float32))
   np.testing.assert_allclose(centers, want, rtol=1e-6)
-  return count + 1
+  # What the driver draws at random is replicated state: with DIFFERENT np.random streams on the ranks the
+  # start centers / start weights must still be the same everywhere (rank 0 draws, the others receive).
+  from spartan_amd.examples import lreg
+  world = sp.get_context().world
+  np.random.seed(100 + world.rank)
+  c2, _ = T.KMeans(4, 2).fit(sp.from_numpy(x), None, implementation='map2', reducer=np.add)
+  w2 = lreg.fit(sp.from_numpy(T.INPUTS['reg_x']), sp.from_numpy(T.INPUTS['reg_y']), 2)
+  for mine, name in ((c2, 'centers'), (w2, 'weights')):
+    copies = world.all_gather_object(np.asarray(mine))
+    for other in copies[1:]:
+      np.testing.assert_array_equal(copies[0], other, err_msg='ranks diverged: ' + name)
+  sp.set_random_seed(None)                 # clock seed: taken on rank 0
+  draws = world.all_gather_object(np.random.rand(3))
+  np.testing.assert_array_equal(draws[0], draws[-1])
+  return count + 2
 
 
 def run_sparse(total_workers):

@@ -67,3 +67,23 @@ def test_unknown_reducer_is_loud_on_hip_names():
   from spartan_amd import backend_hip
   with pytest.raises(TypeError):
     backend_hip.HipBackend.reducer_name(None, lambda a, b: a)
+
+
+def test_pass_through_mapper_does_not_alias_its_input():
+  """A user map2 mapper that yields a fetched input tile unchanged, into a one-tile reducer target: the target
+  must not adopt the source array's storage (later merges would reduce into the source)."""
+  import spartan_amd as sp
+  from oracle.np_backend import NumpyBackend
+  from spartan_amd.array import extent
+  sp.initialize(backend=NumpyBackend(), num_workers=4)
+  try:
+    x = np.arange(32, dtype=np.float64).reshape(8, 4)
+    X = sp.from_numpy(x, tile_hint=(2, 4)).force()
+
+    def passthrough(extents, tiles):
+      yield extent.create((0, 0), (2, 4), (2, 4)), tiles[0]
+    got = sp.map2(X, 0, fn=passthrough, shape=(2, 4), tile_hint=(2, 4), reducer=np.add).glom()
+    np.testing.assert_array_equal(got, x.reshape(4, 2, 4).sum(axis=0))
+    np.testing.assert_array_equal(X.glom(), x)          # the input is untouched
+  finally:
+    sp.shutdown()
