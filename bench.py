@@ -2,21 +2,21 @@
 """Headline benchmark: BASELINE.json's metric
     "spartan.dot TFLOP/s + map/reduce HBM GB/s at 1/2/4/8 MI355X".
 
-One "step" = one `spartan.dot(A, B).force()` through the whole tile path
-(lazy DAG -> per-tile fp32 MFMA GEMM launch -> Tile.merge into the target),
-operands already resident in HBM:
+One "step" = one `spartan.dot(A, B).force()` through the whole tile path (lazy DAG -> per-tile fp32 MFMA GEMM
+launches -> merge into the target), operands already resident in HBM:
 
-  --gpus 1 : BASELINE configs[1] -- dot 8192 x 8192 x 8192 fp32, one tile.
-  --gpus N : weak scaling, fixed 8192^3 of GEMM per GPU: A is (8192 N) x 8192
-             and B 8192 x 8192, both row-tiled one tile per GPU; rows > cols so
-             the reference takes its outer-product path (dot.py:281-285): every
-             worker fetches all of B (ONE RCCL all-gather per step, the path's
-             real exchange step) and writes a disjoint row block of C.
+  --gpus 1 : BASELINE configs[1] -- dot 8192 x 8192 x 8192 fp32, one tile.  The same line carries the north-star
+             shape on one GPU (`northstar_32768`: dot 32768^3, timed with HIP events around whole `.force()` calls).
+  --gpus N : the north star, STRONG scaling: dot 32768 x 32768 x 32768 fp32 with A, B and the result row-tiled one
+             tile per GPU (`tile_hint=(M/N, N)`).  rows <= cols, so this is the reference's K-split map2 join
+             (dot.py:286-290): the all-to-all of A's column slabs, p GEMMs per column chunk of the partial, and
+             one reduce-scatter per chunk overlapped with the next chunk's GEMMs (spartan_amd/expr/dot.ksplit_plan).
+             `value` is whole-job TFLOP/s = 2 * 32768^3 * steps / max-over-ranks wall time; `dot_breakdown`
+             gives kernel-only time and the bytes each GPU moved per step against the xGMI link rates.
 
-`value` is whole-job TFLOP/s (2 M N K summed over ranks / max-over-ranks time).
-The same JSON line carries the roofline of the dominant kernel (sp_gemm_kernel,
-MFMA-bound, durations from HIP events on the launch stream), the fused-map and
-reduce HBM rates, and a CPU baseline (the NumPy oracle on the host cores).
+The line also carries the roofline of the dominant kernel (sp_gemm_kernel, MFMA-bound; durations from HIP events
+on the launch stream), the fused-map / reduce HBM rates, the k-means and sparse tile kernels, and the CPU
+baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thread worker processes.
 """
 import argparse
 import json
@@ -37,6 +37,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 SEED = 20150708
 SETUP_LAUNCHES = 8              # untimed set-up steps before the W warm-up steps (see main)
+NORTH_STAR = 32768
+XGMI_LINK_GBPS = 153.0          # per link, 7 links per GPU (MI355X_MICROARCH.md / task brief)
 
 
 def device_uniform(ex, lo, hi, seed):
@@ -257,10 +259,10 @@ def guarded(fn, timeout_s, rank, fallback_line):
   def watchdog():
     if not done.wait(timeout_s):
       if rank == 0:
-        fallback_line['extras_error'] = 'section timed out after %d s' % timeout_s
+        fallback_line['extras_error'] = 'FAILED: section did not complete within %d s (hung collective?)' % timeout_s
         print(json.dumps(fallback_line))
         sys.stdout.flush()
-      os._exit(0)
+      os._exit(0)   # the headline (measured before this section) stands; the failure is in the line itself
   threading.Thread(target=watchdog, daemon=True).start()
   try:
     res = fn()
@@ -270,92 +272,75 @@ def guarded(fn, timeout_s, rank, fallback_line):
   return res
 
 
-def sort_section(ctx):
-  """np.sort / np.argsort of a BASELINE configs[2] tile (8192 x 65536 fp32) along its rows -- the tile body of
-  spartan.sort -- and of 4096-wide lines (the LDS path).  8 B per element read + written once is the HBM floor."""
-  out = {}
-  for rows, cols, tag in ((8192, 65536, 'radix_8192x65536'), (131072, 4096, 'lds_131072x4096')):
-    x = torch.rand((rows, cols), device='cuda', dtype=torch.float32)
-    ms = event_time(lambda: kernels.sort_rows(x, values=True, indices=False), 3, warmup=1)
-    out[tag + '_ms'] = round(ms, 3)
-    out[tag + '_Gkeys_per_s'] = round(rows * cols / ms / 1e6, 2)
-    del x
-    torch.cuda.empty_cache()
-  return out
+def northstar_section(ctx):
+  """dot 32768 x 32768 x 32768 fp32 on ONE GPU (a single 4 GiB tile per operand): the north-star shape, timed
+  around whole `spartan.dot(A, B).force()` calls with HIP events on the launch stream."""
+  n = NORTH_STAR
+  A = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 51))
+  B = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 52))
+  A.force()
+  B.force()
+  keep = []
+
+  def step():
+    keep[:] = [sp.dot(A, B).force()]
+  step()
+  torch.cuda.synchronize()
+  ms = []
+  for _ in range(3):
+    e0, e1 = kernels.Event(), kernels.Event()
+    e0.record()
+    step()
+    e1.record()
+    e1.synchronize()
+    ms.append(e0.elapsed_ms(e1))
+  del keep[:]
+  avg = sum(ms) / len(ms)
+  flop = 2.0 * n ** 3
+  return {'workload': 'spartan.dot %dx%dx%d fp32, one tile' % (n, n, n), 'calls': len(ms),
+          'ms_per_call': round(avg, 2), 'min_ms': round(min(ms), 2), 'TFLOPs': round(flop / avg / 1e9, 2),
+          'frac_of_mfma_peak': round(flop / avg / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), 'flop_per_call': flop}
 
 
 def cpu_baseline():
-  """The NumPy oracle (a port of the reference's NumPy-worker path) on the host:
-  one worker == one core (spartan/worker.py:40), BLAS pinned to one thread."""
-  from oracle import spartan_np as O
+  """The reference's execution model on the host cores of this box: W = min(physical
+  cores, 64) worker processes, one per core, pinned, one BLAS thread each (spartan/worker.py:40,385-387), running
+  the oracle's NumPy tile bodies on bounded samples of the BASELINE shapes; the parent merges like the owner of
+  the target tile.  A reported baseline, not a target."""
+  from oracle import cpu_workers
+  t_all = time.perf_counter()
+  pool = cpu_workers.Workers(64)
   try:
-    from threadpoolctl import threadpool_limits
-  except ImportError:
-    threadpool_limits = None
-  n = 4096
-  rng = np.random.RandomState(SEED)
-  a = (rng.rand(n, n) * 2 - 1).astype(np.float32)
-  b = (rng.rand(n, n) * 2 - 1).astype(np.float32)
-  cl = O.Cluster(1)
-  A, B = cl.from_numpy(a), cl.from_numpy(b)
-
-  def run():
-    t0 = time.perf_counter()
-    cl.dot(A, B).glom()
-    return time.perf_counter() - t0
-  if threadpool_limits is not None:
-    with threadpool_limits(limits=1):
-      run()
-      dt = min(run(), run())
-    cores = 1
-  else:
-    run()
-    dt = min(run(), run())
-    cores = os.cpu_count() or 1
-  x = rng.rand(4096, 16384).astype(np.float32)
-  X = cl.from_numpy(x)
-  t0 = time.perf_counter()
-  cl.map(lambda t: t * t + t, X)
-  t_map = time.perf_counter() - t0
-  t0 = time.perf_counter()
-  cl.sum(X, 0).glom()
-  t_sum = time.perf_counter() - t0
-  # one k-means iteration of the reference's map2 variant (cdist + argmin, bincount, masked sums) on a
-  # 1/125 sample of the configs[3] per-GPU tile, same k and d
-  kn, kk, kd = 10000, 1024, 256
-  pts = rng.rand(kn, kd).astype(np.float32)
-  cen = rng.rand(kk, kd)
-  t0 = time.perf_counter()
-  O.kmeans_fit_map2(cl, cl.from_numpy(pts), cen, kk, 1, reducer=np.add)
-  t_km = time.perf_counter() - t0
-  # the sparse multiply of benchmark_pagerank.py on the same tile shape as the `sparse` section (scipy's CSR
-  # matvec, which is what the reference's dot mapper calls for a sparse tile, dot.py:212-216)
-  import scipy.sparse as sps
-  sn, sdeg = 900000, 10
-  srows = rng.randint(0, sn, size=sn * sdeg).astype(np.int32)
-  scols = np.repeat(np.arange(sn, dtype=np.int32), sdeg)
-  Wc = sps.coo_matrix((np.ones(sn * sdeg, np.float32), (srows, scols)), shape=(sn, sn)).tocsr()
-  xv = rng.rand(sn, 1).astype(np.float32)
-  Wc.dot(xv)
-  t0 = time.perf_counter()
-  for _ in range(5):
-    Wc.dot(xv)
-  t_spmv = (time.perf_counter() - t0) / 5
-  # np.sort along the rows of a 1/16 sample of the `sort` section's tile
-  xs = rng.rand(512, 65536).astype(np.float32)
-  t0 = time.perf_counter()
-  np.sort(xs, axis=1)
-  t_sort = time.perf_counter() - t0
-  return {'value': round(2.0 * n ** 3 / dt / 1e12, 4), 'unit': 'TFLOP/s', 'cores': cores, 'kind': 'port',
-          'sample': 'oracle (NumPy port) spartan.dot %dx%dx%d fp32, 1 worker, %d BLAS thread(s), best of 2 '
-                    '(%.2f s each); map x*x+x %.1f GB/s, sum axis0 %.1f GB/s on 4096x16384 fp32; '
-                    'k-means iteration (map2 variant) on %dx%d points, k=%d: %.2f s = %.4f TFLOP/s of 2nkd; '
-                    'sparse multiply %dx%d, %d links per page (scipy CSR matvec): %.2f ms = %.2f GB/s; '
-                    'np.sort of 512x65536 fp32 along rows: %.2f s = %.3f Gkeys/s'
-                    % (n, n, n, cores, dt, 8.0 * x.size / t_map / 1e9, 4.0 * x.size / t_sum / 1e9,
-                       kn, kd, kk, t_km, 2.0 * kn * kk * kd / t_km / 1e12,
-                       sn, sn, sdeg, t_spmv * 1e3, (Wc.nnz * 8 + sn * 16) / t_spmv / 1e9,
-                       t_sort, xs.size / t_sort / 1e9)}
+    W = pool.count
+    n = 4096
+    t_dot, t_dot_compute, n = pool.dot(n)                       # K-split, one target tile (dot.py:277-290)
+    rows, cols = 65536, 16384                                    # configs[2] scaled 1/4: 4 GiB fp32 in all
+    t_map, t_sum, rows = pool.map_and_sum(rows, cols)
+    ln, ld = 125000, 4096                                        # configs[4] scaled 1/8: one per-GPU tile
+    t_lreg, ln = pool.lreg_step(ln, ld)
+    kn, kd, kk = 2000 * W, 256, 1024                             # configs[3]: k and d as given, 2000 points / worker
+    t_km, kn = pool.kmeans_iteration(kn, kd, kk)
+  finally:
+    pool.close()
+  e = float(rows) * cols
+  return {'value': round(2.0 * n ** 3 / t_dot / 1e12, 4), 'unit': 'TFLOP/s', 'cores': W, 'kind': 'port',
+          'workers': '%d processes pinned to %d physical cores, 1 BLAS thread each' % (W, W),
+          'dot': {'shape': '%dx%dx%d fp32, K-split over %d workers, one target tile' % (n, n, n, W),
+                  'seconds': round(t_dot, 3), 'gemm_seconds': round(t_dot_compute, 3),
+                  'TFLOPs': round(2.0 * n ** 3 / t_dot / 1e12, 4),
+                  'note': 'the partials travel to the owner through pipes and are added there one by one, as the '
+                          'reference pickles them to the owner of its single target tile (dot.py:277-278)'},
+          'map_xx_plus_x_GBps': round(8.0 * e / t_map / 1e9, 2), 'sum_axis0_GBps': round(4.0 * e / t_sum / 1e9, 2),
+          'map_sum_shape': '%dx%d fp32 in %d row tiles' % (rows, cols, W),
+          'lreg_step': {'shape': '%dx%d fp32' % (ln, ld), 'seconds': round(t_lreg, 4),
+                        'GBps': round(2 * 4.0 * ln * ld / t_lreg / 1e9, 2)},
+          'kmeans_iteration': {'shape': '%dx%d points, k=%d' % (kn, kd, kk), 'seconds': round(t_km, 3),
+                               'TFLOPs_of_2nkd': round(2.0 * kn * kk * kd / t_km / 1e12, 4)},
+          'sample': 'oracle tile bodies (NumPy / BLAS / scipy cdist) on %d pinned one-thread workers: dot %d^3 '
+                    'K-split; x*x+x and sum(axis=0) on %dx%d; one lreg step on %dx%d; one k-means iteration on '
+                    '%dx%d, k=%d -- scaled from the BASELINE shapes to stay within ~20 s' %
+                    (W, n, rows, cols, ln, ld, kn, kd, kk),
+          'wall_seconds': round(time.perf_counter() - t_all, 1)}
 
 
 def main():
@@ -363,8 +348,8 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
-  ap.add_argument('--size', type=int, default=8192)
-  ap.add_argument('--no-extras', action='store_true', help='skip the map/reduce and CPU-baseline sections')
+  ap.add_argument('--size', type=int, default=0, help='matrix order (default: 8192 on one GPU, 32768 on several)')
+  ap.add_argument('--no-extras', action='store_true', help='skip the map/reduce, north-star and CPU-baseline sections')
   args = ap.parse_args()
 
   world = sp.World.from_env()
@@ -372,24 +357,30 @@ def main():
     raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)'
                      % (args.gpus, world.size, args.gpus))
   ctx = sp.initialize('hip', world=world)
-  n = args.size
   p = world.size
-  M = n * p
+  n = args.size or (8192 if p == 1 else NORTH_STAR)
   if p == 1:
     A = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED))
     B = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 1))
     hint = None
-    tag = {8192: 'BASELINE configs[1]', 32768: 'north-star shape'}.get(n, 'custom size')
+    tag = {8192: 'BASELINE configs[1]', NORTH_STAR: 'north-star shape'}.get(n, 'custom size')
     workload = 'spartan.dot %dx%dx%d fp32, one tile (%s)' % (n, n, n, tag)
     parallelism = 'single tile'
+    scaling = 'weak'
   else:
-    A = sp.from_tile_fn((M, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED), tile_hint=(n, n))
-    B = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 1))
-    hint = (n, n)
-    workload = ('spartan.dot (%dx%d).(%dx%d) fp32, A and C row-tiled %d x (%dx%d), B all-gathered per step'
-                % (M, n, n, n, p, n, n))
-    parallelism = ('row tiles, 1 worker per GPU; B re-gathered every step as asynchronous RCCL all-gathers of '
-                   'column chunks, one GEMM per chunk behind them')
+    if n % p:
+      raise SystemExit('--size %d is not a multiple of --gpus %d' % (n, p))
+    hint = (n // p, n)
+    A = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED), tile_hint=hint)
+    B = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 1), tile_hint=hint)
+    workload = ('spartan.dot %dx%dx%d fp32 (north star), A, B and the result row-tiled %d x (%dx%d)'
+                % (n, n, n, p, n // p, n))
+    parallelism = ('K-split map2 join, 1 worker per GPU: all-to-all of A blocks, %d GEMMs per column chunk, one '
+                   'asynchronous reduce-scatter per chunk behind the next chunk (transport: %s)'
+                   % (p, world.note or getattr(world.transport, 'name', '?')))
+    scaling = 'strong'
+  A.force()
+  B.force()
 
   keep = []
 
@@ -399,15 +390,17 @@ def main():
   # set-up launches (untimed, before the W warm-up steps): library load, allocator warm-up, and the
   # device's one-off dispatch stall (~30 ms, seen once per process about 50 ms into the first sustained
   # MFMA load on these boxes: profiles/r01_notes.md) -- so neither lands in the timed steps
-  for _ in range(SETUP_LAUNCHES):
+  for _ in range(SETUP_LAUNCHES if p == 1 else 2):
     step()
   torch.cuda.synchronize()
   ctx.backend.gemm_events = []
+  stats0 = dict(world.stats)
   dt = time_steps(ctx, step, args.steps, args.warmup)
   torch.cuda.synchronize()
+  stats1 = dict(world.stats)
   all_events = ctx.backend.gemm_events
   ctx.backend.gemm_events = None
-  # launches per step: 1 on one GPU; one per gathered column chunk of B on several (dot_chunked)
+  # launches per step: 1 on one GPU; p per column chunk of the partial on several (dot.ksplit_plan)
   per_step = max(1, len(all_events) // (args.steps + args.warmup))
   events = all_events[-args.steps * per_step:]
   kernel_ms = [e0.elapsed_ms(e1) for (e0, e1, _, _, _) in events]
@@ -415,13 +408,14 @@ def main():
   avg_ms = sum(kernel_ms) / len(kernel_ms)
   achieved = flops_launch / (avg_ms * 1e-3) / 1e12
 
-  total_flops = 2.0 * M * n * n * args.steps
-  value = total_flops / dt / 1e12
+  flop_step = 2.0 * n * n * n
+  value = flop_step * args.steps / dt / 1e12
   line = {
       'metric': 'spartan.dot TFLOP/s (+ map/reduce HBM GB/s)', 'value': round(value, 2), 'unit': 'TFLOP/s',
       'n_gpus': p, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-      'config': {'workload': workload, 'parallelism': parallelism, 'flop_per_step': 2.0 * M * n * n, 'setup_launches': SETUP_LAUNCHES,
+      'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': workload, 'parallelism': parallelism, 'flop_per_step': flop_step,
+                 'setup_launches': SETUP_LAUNCHES if p == 1 else 2,
                  'inputs': 'uniform[-1,1) fp32 generated on device, resident in HBM'},
       'roofline': {'bound': 'mfma', 'kernel': 'sp_gemm_kernel<256,128,16,2,2> (v_mfma_f32_32x32x2_f32)',
                    'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -433,24 +427,44 @@ def main():
   if os.path.exists(traffic_file):
     try:
       line['roofline']['traffic'] = json.load(open(traffic_file)).get('gemm_%d' % n)
+      line['roofline']['traffic_source'] = ('profiles/pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 '
+                                            '--pmc run of this kernel and shape (not of this run); algorithmic floor '
+                                            '%d bytes' % (12 * n * n))
     except Exception:
       pass
-  if world.rank == 0 and not args.no_extras:
-    if p == 1:
-      del keep[:]
-      torch.cuda.empty_cache()
-      line['hbm'] = hbm_section(ctx)
-      torch.cuda.empty_cache()
-      line['kmeans'] = kmeans_section(ctx)
-      torch.cuda.empty_cache()
-      line['sparse'] = sparse_section(ctx)
-      torch.cuda.empty_cache()
-      line['sort'] = sort_section(ctx)
-      line['cpu_baseline'] = cpu_baseline()
+  if p > 1:
+    # this rank's share of a step: kernel-only time vs wall, and the bytes it moved against the xGMI rates
+    sent = {k: (stats1[k] - stats0[k]) / float(args.steps + args.warmup) for k in stats0}
+    step_s = dt / args.steps
+    line['dot_breakdown'] = {
+        'gemm_kernel_ms_per_step': round(sum(kernel_ms) / args.steps, 3),
+        'step_ms': round(step_s * 1e3, 3),
+        'kernel_only_TFLOPs_whole_job': round(flop_step / (sum(kernel_ms) / args.steps * 1e-3) / 1e12, 2),
+        'all_to_all_bytes_per_gpu_per_step': int(sent['p2p_bytes']),
+        'reduce_scatter_bytes_per_gpu_per_step': int(sent['collective_bytes']),
+        'exchange_GBps_per_gpu_if_serial': round((sent['p2p_bytes'] + sent['collective_bytes']) / step_s / 1e9, 1),
+        'xgmi_GBps_per_gpu': {'one_link': XGMI_LINK_GBPS, 'seven_links': 7 * XGMI_LINK_GBPS},
+        'note': 'bytes are what ONE GPU sends per step ((p-1)/p of its 4*M*N partial and of its A tile); the '
+                'reduce-scatters run on a communication stream behind the GEMMs of the next chunk',
+    }
+  if world.rank == 0 and not args.no_extras and p == 1:
+    del keep[:]
+    torch.cuda.empty_cache()
+    line['northstar_%d' % NORTH_STAR] = northstar_section(ctx)
+    torch.cuda.empty_cache()
+    line['hbm'] = hbm_section(ctx)
+    torch.cuda.empty_cache()
+    line['kmeans'] = kmeans_section(ctx)
+    torch.cuda.empty_cache()
+    line['sparse'] = sparse_section(ctx)
+    torch.cuda.empty_cache()
+    line['cpu_baseline'] = cpu_baseline()
   if world.distributed:
     line['comm'] = dict(world.stats)
+    line['comm']['transport'] = world.note or getattr(world.transport, 'name', '?')
     if not args.no_extras:
       del keep[:]
+      del A, B
       torch.cuda.empty_cache()
       line['hbm_dist'] = guarded(lambda: dist_section(ctx), 240, world.rank, dict(line))
   world.barrier()
@@ -458,6 +472,7 @@ def main():
     print(json.dumps(line))
     sys.stdout.flush()
   sp.shutdown()
+  world.close()
   if world.distributed:
     torch.distributed.destroy_process_group()
 

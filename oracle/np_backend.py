@@ -96,6 +96,12 @@ class NumpyBackend(object):
   def reducer_name(self, fn):
     return _REDUCERS.get(fn, 'CALLABLE')
 
+  def gemm_into(self, a, b, out, accumulate=False):
+    self.launches += 1
+    prod = torch.from_numpy(np.ascontiguousarray(_np(a).dot(_np(b))))
+    out.copy_(out + prod if accumulate else prod)
+    return out
+
   def paste(self, dst, dst_slices, src):
     view = dst[dst_slices] if dst.dim() else dst
     view.copy_(src.reshape(view.shape))

@@ -92,8 +92,11 @@ class HipBackend(object):
     pickles it into every RunKernelReq, dot.py:172-187)."""
     key = (id(arr), tuple((s.start, s.stop) for s in slices))
     hit = self._np_cache.get(key)
-    if hit is None or hit[0] is not arr:
-      hit = (arr, self.from_numpy(arr[slices]))
+    # the driver may update the array in place between evaluations (`w -= alpha * grad`): the HBM copy is
+    # only re-used while the bytes are the same (the reference re-pickles the array into every request)
+    stamp = hash(arr[slices].tobytes()) if arr.nbytes <= (1 << 22) else None
+    if hit is None or hit[0] is not arr or stamp is None or hit[2] != stamp:
+      hit = (arr, self.from_numpy(arr[slices]), stamp)
       self._np_cache[key] = hit
       while len(self._np_cache) > 64:
         self._np_cache.popitem(last=False)
@@ -412,6 +415,20 @@ class HipBackend(object):
       prod = lower.apply('MUL', np.multiply, [va, vb])
       return self._run_reduce(prod, 'SUM', res_dt, (M, K, N), 1)
     raise lower.NotLowerable('dot of %d-d and %d-d operands' % (a.dim(), b.dim()))
+
+  def gemm_into(self, a, b, out, accumulate=False):
+    """out (+)= a . b for 2-D fp32 / fp64 tensors that may be strided views (inner stride 1): the building block
+    of the pipelined joins (dot.ksplit_plan), one sp_gemm launch, nothing allocated."""
+    self.launches += 1
+    if self.gemm_events is not None:
+      e0, e1 = kernels.Event(), kernels.Event()
+      e0.record()
+      kernels.gemm_f32(a, b, out, accumulate=accumulate)
+      e1.record()
+      self.gemm_events.append((e0, e1, a.shape[0], b.shape[1], a.shape[1]))
+    else:
+      kernels.gemm_f32(a, b, out, accumulate=accumulate)
+    return out
 
   def dot_chunked(self, a, rhs):
     """a . B with B arriving as column chunks (distarray.ChunkedWhole): one GEMM per chunk into the

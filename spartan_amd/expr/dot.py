@@ -1,159 +1,247 @@
-"""spartan.dot: dispatch to map2 / outer plus the per-tile GEMM mappers.
-Mirror of the reference's spartan/expr/dot.py:172-299; `tiles[0].dot(tiles[1])`
-is the fp32 MFMA GEMM (sp_gemm_f32) for matrix.matrix and a fused
-multiply-reduce launch for matrix.vector."""
+"""spartan.dot: which join carries a product, the per-tile bodies, and the collective plan of the K-split.
+
+Role of the reference's spartan/expr/dot.py:172-299.  `tiles[0].dot(tiles[1])` is the fp32 / fp64 MFMA GEMM
+(sp_gemm_f32 / sp_gemm_f64) for matrix.matrix and one fused multiply-reduce launch for matrix.vector.
+
+Forms (a is m x k or a k-vector, b is k x n or a k-vector):
+
+  b is a driver-side NumPy array   map2 on a's rows; b is replicated and sliced per tile        (dot.py:172-187)
+  vector . vector                   map2 (0, 0): per-tile inner products added into a 1-cell target (:189-191)
+  vector . matrix                   the vector as a 1 x k row, then the K-split below             (:296-299)
+  m > k  (tall a)                   outer: a's row tile times ALL of b -> disjoint rows of c       (:222-238)
+  m <= k (square / wide a)          K-split map2 (1, 0): worker i multiplies the column slab a[:, k_i] by its
+                                    own rows b[k_i, :] and the m x n partials are added           (:195-217)
+
+Across GPUs the K-split has one exchange before the GEMMs (the slab a[:, k_i] is spread over every worker's row
+tile: an all-to-all of (m/p x k/p) blocks) and one after (the partials are summed into the target).  When both
+operands and the target are row-tiled one tile per GPU -- dot(a, b, tile_hint=(m/p, n)) -- `ksplit_plan` runs the
+whole join as a pipeline instead of tile by tile:
+
+  * the all-to-all of a's blocks is issued asynchronously; the products that only need LOCAL data run behind it;
+  * row block j of the partial depends on ONE block of a (the one from rank j), so the partial is produced as p
+    independent GEMMs per column chunk -- no accumulation, no m x k slab is ever assembled;
+  * the partial is produced in column chunks (m x n_c, double-buffered) and each chunk is reduce-scattered by its
+    own asynchronous collective while the next chunk is multiplied: only the last chunk's reduce-scatter is
+    exposed, and the 4 GiB partial of the 32768^2 north-star shape never exists (2 x 512 MiB instead).
+"""
+import os
+
 import numpy as np
 
 from . import map as map_mod
 from . import outer as outer_mod
-from .base import Expr
+from . import views
 from .. import context
-from ..array import distarray, extent
+from ..array import distarray, extent, tile
+
+
+# ---- per-tile products -------------------------------------------------------------------------------------
+def _product_shape(ash, bsh):
+  if len(ash) == 1 and len(bsh) == 1:
+    return ()
+  if len(bsh) == 1:
+    return tuple(ash[:-1])
+  if len(ash) == 1:
+    return tuple(bsh[1:])
+  return (ash[0], bsh[1])
 
 
 def _dot(a, b):
-  """`a.dot(b)` on backend tensors (Absent on non-executing ranks)."""
-  ctx = context.get()
+  """`a.dot(b)` on backend tensors; a shape/dtype placeholder on ranks that do not execute the tile."""
+  be = context.get().backend
   if isinstance(b, distarray.ChunkedWhole):
     if isinstance(a, distarray.Absent):
       return distarray.Absent((a.shape[0], b.shape[1]), a.dtype)
-    return ctx.backend.dot_chunked(a, b)
+    return be.dot_chunked(a, b)
   if isinstance(a, distarray.Absent) or isinstance(b, distarray.Absent):
-    ash, bsh = tuple(a.shape), tuple(b.shape)
-    if len(ash) == 1 and len(bsh) == 1:
-      shp = ()
-    elif len(bsh) == 1:
-      shp = ash[:-1]
-    elif len(ash) == 1:
-      shp = bsh[1:]
-    else:
-      shp = (ash[0], bsh[1])
-    return distarray.Absent(shp, a.dtype)
-  return ctx.backend.dot(a, b)
+    return distarray.Absent(_product_shape(tuple(a.shape), tuple(b.shape)), a.dtype)
+  return be.dot(a, b)
 
 
 def dot_map2_np_mapper(extents, tiles, array2):
-  """dot.py:172-187: rhs is a driver-side NumPy array (replicated)."""
-  ctx = context.get()
+  """Row tile of `a` times the matching rows of the driver array (its rows follow a's LAST axis)."""
+  be = context.get().backend
   ex = extents[0]
-  if len(ex.ul) == 1:
-    target_ex = extent.create((0,), (1,), (1,))
-    rhs = ctx.backend.cached_numpy(array2, (slice(ex.ul[0], ex.lr[0]),))
-    target_tile = _dot(tiles[0], rhs).reshape(1,)
-  elif len(array2.shape) == 1:
-    target_ex = extent.create((ex.ul[0],), (ex.lr[0],), (ex.array_shape[0],))
-    rhs = ctx.backend.cached_numpy(array2, (slice(ex.ul[1], ex.lr[1]),))
-    target_tile = _dot(tiles[0], rhs)
+  k_axis = len(ex.ul) - 1
+  rhs = be.cached_numpy(array2, (slice(ex.ul[k_axis], ex.lr[k_axis]),))
+  out = _dot(tiles[0], rhs)
+  if len(ex.ul) == 1:                       # vector . host vector: a partial inner product
+    yield extent.create((0,), (1,), (1,)), out.reshape(1,)
+  elif array2.ndim == 1:                    # matrix . host vector: this tile's rows of the result
+    yield extent.create((ex.ul[0],), (ex.lr[0],), (ex.array_shape[0],)), out
   else:
-    target_ex = extent.create((ex.ul[0], 0), (ex.lr[0], array2.shape[1]),
-                              (ex.array_shape[0], array2.shape[1]))
-    rhs = ctx.backend.cached_numpy(array2, (slice(ex.ul[1], ex.lr[1]),))
-    target_tile = _dot(tiles[0], rhs)
-  yield target_ex, target_tile
+    n = array2.shape[1]
+    yield extent.create((ex.ul[0], 0), (ex.lr[0], n), (ex.array_shape[0], n)), out
 
 
 def dot_map2_vec_mapper(extents, tiles):
-  """dot.py:189-191."""
-  target_ex = extent.create((0,), (1,), (1,))
-  yield target_ex, _dot(tiles[0], tiles[1]).reshape(1,)
+  yield extent.create((0,), (1,), (1,)), _dot(tiles[0], tiles[1]).reshape(1,)
 
 
 def dot_map2_mapper(extents, tiles, is_vec=None):
-  """dot.py:195-217: the K-slab partial product of the map2 join."""
+  """Partial product of the K-split: a[:, k_i] . b[k_i, :] covers the WHOLE result."""
+  slab, rows = tiles
   if is_vec:
-    ul = (0,)
-    lr = (extents[1].lr[1],)
+    slab = slab.reshape(extents[0].shape[1],)
     shape = (extents[1].shape[1],)
-    tiles[0] = tiles[0].reshape(extents[0].shape[1],)
-  elif len(tiles[1].shape) == 1:
-    ul = (0,)
-    lr = (extents[0].lr[0],)
+  elif len(rows.shape) == 1:
     shape = (extents[0].shape[0],)
   else:
-    ul = (0, 0)
-    lr = (extents[0].lr[0], extents[1].lr[1])
     shape = (extents[0].shape[0], extents[1].shape[1])
-  target_ex = extent.create(ul, lr, shape)
-  yield target_ex, _dot(tiles[0], tiles[1])
+  yield extent.from_shape(shape), _dot(slab, rows)
 
 
 def dot_outer_mapper(ex_a, tile_a, ex_b, tile_b):
-  """dot.py:222-238: row block of A times all of B -> disjoint row block of C."""
+  """Row block of a times all of b: its own rows of the result, no reduction."""
   if len(tile_b.shape) == 1:
-    ul = (ex_a.ul[0],)
-    lr = (ex_a.lr[0],)
-    shape = (ex_a.array_shape[0],)
+    target = extent.create((ex_a.ul[0],), (ex_a.lr[0],), (ex_a.array_shape[0],))
   else:
-    ul = (ex_a.ul[0], ex_b.ul[1])
-    lr = (ex_a.lr[0], ex_b.lr[1])
-    shape = (ex_a.array_shape[0], ex_b.array_shape[1])
-  target_ex = extent.create(ul, lr, shape)
-  yield target_ex, _dot(tile_a, tile_b)
+    target = extent.create((ex_a.ul[0], ex_b.ul[1]), (ex_a.lr[0], ex_b.lr[1]),
+                           (ex_a.array_shape[0], ex_b.array_shape[1]))
+  yield target, _dot(tile_a, tile_b)
 
 
 def _fetch_whole_rhs(array, whole_extent):
-  """dot_outer_mapper's B: every worker needs ALL of it (outer.py:21-29).  Across GPUs the
-  gather is issued as a few asynchronous column-chunk all-gathers and the GEMM runs chunk by
-  chunk behind them (SPARTAN_RHS_CHUNK_COLS columns per chunk, 0 = one blocking gather)."""
-  import os
+  """dot_outer_mapper's b: every worker needs ALL of it (outer.py:21-29).  Across GPUs the gather is issued as a
+  few asynchronous column-chunk all-gathers and the GEMM runs chunk by chunk behind them
+  (SPARTAN_RHS_CHUNK_COLS columns per chunk, 0 = one blocking gather)."""
   chunk_cols = int(os.environ.get('SPARTAN_RHS_CHUNK_COLS', '2048'))
   if chunk_cols > 0 and len(array.shape) == 2 and hasattr(array, 'fetch_whole_chunked') \
       and hasattr(context.get().backend, 'dot_chunked'):
-    try:
-      whole = array.fetch_whole_chunked(chunk_cols)
-    except NotImplementedError:   # a transport without the asynchronous collective: same on every rank
-      whole = None
+    whole = array.fetch_whole_chunked(chunk_cols)
     if whole is not None:
       return whole
   return array.fetch(whole_extent)
 
 
+# ---- the K-split across GPUs as one pipeline ------------------------------------------------------------------
+def _row_tiles_in_rank_order(array, ctx):
+  """[(extent, tile id)] if `array` is a plain dense 2-D array cut into world.size equal row tiles, tile r on
+  rank r; else None."""
+  p = ctx.world.size
+  if not isinstance(array, distarray.DistArrayImpl) or array.sparse or len(array.shape) != 2:
+    return None
+  rows, cols = array.shape
+  if len(array.tiles) != p or rows % p:
+    return None
+  step = rows // p
+  tiles = sorted(array.tiles.items(), key=lambda kv: kv[0].ul)
+  for r, (ex, tid) in enumerate(tiles):
+    if ctx.rank_of(tid.worker) != r or ex.ul != (r * step, 0) or ex.lr != ((r + 1) * step, cols):
+      return None
+  return tiles
+
+
+def _chunk_columns(n):
+  """Columns of the partial per reduce-scatter (SPARTAN_DOT_CHUNK_COLS, default 4096): whole chunks only."""
+  want = int(os.environ.get('SPARTAN_DOT_CHUNK_COLS', '4096'))
+  if want <= 0 or want >= n:
+    return n
+  while n % want:
+    want -= 1
+  return want
+
+
+def ksplit_plan(arrays, axes, target, fn_kw):
+  """Run map2((a, b), (1, 0), dot_map2_mapper) into `target` as the pipeline described in the module docstring.
+  Returns False (nothing done) unless the pattern is the regular one; the decision only reads array metadata, so
+  every rank takes the same branch."""
+  ctx = context.get()
+  be, world = ctx.backend, ctx.world
+  if not world.distributed or ctx.num_workers != world.size or fn_kw or tuple(axes) != (1, 0):
+    return False
+  if len(arrays) != 2 or not hasattr(be, 'gemm_into'):
+    return False
+  a, b = arrays
+  ta, tb, tt = (_row_tiles_in_rank_order(x, ctx) for x in (a, b, target))
+  if ta is None or tb is None or tt is None or getattr(target, '_touched', False):
+    return False
+  dt = np.dtype(target.dtype)
+  if dt not in (np.dtype(np.float32), np.dtype(np.float64)) or np.dtype(a.dtype) != dt or np.dtype(b.dtype) != dt:
+    return False
+  if be.reducer_name(target.reducer_fn) != 'ADD':
+    return False
+  p, me = world.size, world.rank
+  m, k = a.shape
+  n = b.shape[1]
+  if k % p:
+    return False
+  mb, kb = m // p, k // p
+  my_a = ctx.tile(ta[me][1]).get(be, None)
+  my_b = ctx.tile(tb[me][1]).get(be, None)
+  if isinstance(my_a, tile.EmptyBlob) or isinstance(my_b, tile.EmptyBlob):
+    return False      # (identical on every rank only for written arrays: operands of a dot always are)
+
+  # 1. all-to-all of a's blocks: rank j needs my rows of ITS slab, a[r_me, k_j]
+  sends = [(j, be.copy(my_a[:, j * kb:(j + 1) * kb])) for j in range(p) if j != me]
+  blocks = {me: my_a[:, me * kb:(me + 1) * kb]}            # a[r_j, k_me] by source rank j (mine: a view)
+  recvs = []
+  for j in range(p):
+    if j != me:
+      blocks[j] = be.empty((mb, kb), dt)
+      recvs.append((j, blocks[j]))
+  arriving = world.exchange_async(sends, recvs)
+
+  # 2. partial in column chunks, each reduce-scattered while the next one is multiplied
+  nc = _chunk_columns(n)
+  bufs = [be.empty((m, nc), dt), be.empty((m, nc), dt) if nc < n else None]
+  result = be.empty((mb, n), dt)
+  in_flight = None                                          # (c0, reduced piece, handle) of the previous chunk
+
+  def land(item):
+    c0, piece, handle = item
+    if handle is not None:
+      handle.wait()
+    be.paste(result, (slice(0, mb), slice(c0, c0 + nc)), piece)
+
+  for ci, c0 in enumerate(range(0, n, nc)):
+    part = bufs[ci % 2]
+    for step in range(p):
+      j = (me + step) % p                                   # my own block first: it needs no transfer
+      if step == 1 and arriving is not None:
+        arriving.wait()
+        arriving = None
+      be.gemm_into(blocks[j], my_b[:, c0:c0 + nc], part[j * mb:(j + 1) * mb, :])
+    piece = be.empty((mb, nc), dt)
+    handle = world.reduce_scatter_async(piece, part, 'ADD')
+    if in_flight is not None:
+      land(in_flight)                                       # its buffer is the one the NEXT chunk overwrites
+    in_flight = (c0, piece, handle)
+  land(in_flight)
+  del sends
+  target._touched = True
+  ctx.tile(tt[me][1]).update(be, None, result, target.reducer_fn, owned=True)
+  return True
+
+
+dot_map2_mapper.collective_plan = ksplit_plan
 dot_outer_mapper.fetch_rhs = _fetch_whole_rhs
-# every tensor these mappers yield is the output of a kernel launched for it (never an input tile),
-# so the target may adopt it on a first full-tile write instead of copying
+# every tensor these mappers yield is the output of a kernel launched for it (never an input tile), so the
+# target may adopt it on a first full-tile write instead of copying
 for _m in (dot_map2_np_mapper, dot_map2_vec_mapper, dot_map2_mapper, dot_outer_mapper):
   _m.yields_fresh_tensors = True
 
 
+# ---- dispatch --------------------------------------------------------------------------------------------------
 def dot(a, b, tile_hint=None):
-  """dot.py:243-299."""
+  """The product of two arrays (1-D or 2-D each); `b` may be a driver-side NumPy array.  tile_hint tiles the
+  result (default: ONE tile, as the reference, dot.py:277-278; (m/p, n) gives the reduce-scatter target)."""
+  ra, rb = len(a.shape), len(b.shape)
+  if ra not in (1, 2) or rb not in (1, 2):
+    raise ValueError('dot of %d-d and %d-d arrays' % (ra, rb))
+  if a.shape[ra - 1] != b.shape[0]:
+    raise ValueError('objects are not aligned %d %d' % (a.shape[ra - 1], b.shape[0]))
+  shape = _product_shape(tuple(a.shape), tuple(b.shape)) or (1,)
   if isinstance(b, np.ndarray):
-    if len(a.shape) == 1 and len(b.shape) == 1:
-      shape = (1,)
-    elif len(a.shape) > 1 and len(b.shape) == 1:
-      shape = (a.shape[0],)
-    else:
-      shape = (a.shape[0], b.shape[1])
-    return map_mod.map2(a, axes=[0], fn=dot_map2_np_mapper, fn_kw={'array2': b}, shape=shape,
-                        reducer=np.add)
-  if len(a.shape) == 1 and len(b.shape) == 1:
-    if a.shape[0] != b.shape[0]:
-      raise ValueError('objects are not aligned %d %d' % (a.shape[0], b.shape[0]))
-    return map_mod.map2((a, b), (0, 0), fn=dot_map2_vec_mapper, shape=(1,), reducer=np.add)
-  elif len(a.shape) == 1 and len(b.shape) > 1:
-    if a.shape[0] != b.shape[0]:
-      raise ValueError('objects are not aligned %d %d' % (a.shape[0], b.shape[0]))
-    shape = (b.shape[1],)
-  elif len(a.shape) > 1 and len(b.shape) == 1:
-    if a.shape[1] != b.shape[0]:
-      raise ValueError('objects are not aligned %d %d' % (a.shape[1], b.shape[0]))
-    shape = (a.shape[0],)
-  elif len(a.shape) > 1 and len(b.shape) > 1:
-    if tile_hint is None:
-      tile_hint = (a.shape[0], b.shape[1])
-    if a.shape[1] != b.shape[0]:
-      raise ValueError('objects are not aligned %d %d' % (a.shape[1], b.shape[0]))
-    shape = (a.shape[0], b.shape[1])
-  else:
-    raise ValueError
-
-  if len(a.shape) > 1 and a.shape[0] > a.shape[1]:
-    # rows > cols: row-partitioned outer product (dot.py:281-285)
-    return outer_mod.outer((a, b), (0, None), dot_outer_mapper, shape=shape, tile_hint=tile_hint,
-                           reducer=np.add)
-  elif len(a.shape) > 1:
-    # rows <= cols: K-split map2 join (dot.py:286-290)
-    return map_mod.map2((a, b), (1, 0), dot_map2_mapper, shape=shape, tile_hint=tile_hint,
-                        reducer=np.add)
-  else:
-    raise NotImplementedError('vector . matrix needs reshape (SURVEY 8f.1)')
+    return map_mod.map2(a, axes=[0], fn=dot_map2_np_mapper, fn_kw={'array2': b}, shape=shape, reducer=np.add)
+  if ra == 1 and rb == 1:
+    return map_mod.map2((a, b), (0, 0), fn=dot_map2_vec_mapper, shape=shape, reducer=np.add)
+  if ra == 2 and rb == 2 and tile_hint is None:
+    tile_hint = shape
+  if ra == 1:
+    row = views.reshape(a, (1, a.shape[0]))
+    return map_mod.map2((row, b), (1, 0), dot_map2_mapper, fn_kw={'is_vec': True}, shape=shape,
+                        tile_hint=tile_hint, reducer=np.add)
+  if a.shape[0] > a.shape[1]:
+    return outer_mod.outer((a, b), (0, None), dot_outer_mapper, shape=shape, tile_hint=tile_hint, reducer=np.add)
+  return map_mod.map2((a, b), (1, 0), dot_map2_mapper, shape=shape, tile_hint=tile_hint, reducer=np.add)

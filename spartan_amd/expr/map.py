@@ -186,6 +186,11 @@ class Map2Expr(Expr):
     sparse = len(arrays) > 1 and bool(getattr(arrays[0], 'sparse', False) and getattr(arrays[1], 'sparse', False))   # map.py:323
     target = distarray.create(self.shape_, dtype, sharder=None, reducer=self.reducer,
                               tile_hint=self.tile_hint, sparse=sparse)
+    # a mapper may know how to run its whole join as one pipeline of transfers and kernels when operands and
+    # target are laid out regularly (dot: the K-split with its all-to-all and reduce-scatter, dot.ksplit_plan)
+    plan = getattr(self.fn, 'collective_plan', None)
+    if plan is not None and plan(arrays, self.axes, target, self.fn_kw):
+      return target
     arrays[0].foreach_tile(mapper_fn=join_mapper,
                            kw=dict(arrays=arrays, axes=self.axes, local_user_fn=self.fn,
                                    local_user_fn_kw=self.fn_kw, target=target))
