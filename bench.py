@@ -417,7 +417,7 @@ def main():
       'config': {'workload': workload, 'parallelism': parallelism, 'flop_per_step': flop_step,
                  'setup_launches': SETUP_LAUNCHES if p == 1 else 2,
                  'inputs': 'uniform[-1,1) fp32 generated on device, resident in HBM'},
-      'roofline': {'bound': 'mfma', 'kernel': 'sp_gemm_kernel<256,128,16,2,2> (v_mfma_f32_32x32x2_f32)',
+      'roofline': {'bound': 'mfma', 'kernel': 'sp_gemm_glds_kernel<256x128x16, 4 waves> (v_mfma_f32_32x32x2_f32, k-tiles by global_load_lds)',
                    'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                    'flop_per_launch': flops_launch, 'avg_launch_ms': round(avg_ms, 4),

@@ -6,7 +6,10 @@
 // :172-187 dot_map2_np_mapper); `accumulate` fuses the np.add reducer of the
 // dot target (dot.py:289-294 + tile.pyx:263-266) into the epilogue.
 //
-// Structure (per workgroup of NW waves, one 32x32 MFMA tile grid per wave):
+// Two kernels share the macro-tile, the MFMA schedule and the epilogue: sp_gemm_glds_kernel (direct-to-LDS
+// k-tiles, the default for large aligned problems, see its comment) and sp_gemm_kernel (register-staged, any
+// shape / alignment / K tail / split-K).
+// Structure of sp_gemm_kernel (per workgroup of NW waves, one 32x32 MFMA tile grid per wave):
 //   - BM x BN output macro-tile, K walked in steps of BK=16;
 //   - global -> VGPR (16-B loads) -> LDS, LDS double-buffered: the loads of
 //     k-tile t+1 are issued before the MFMAs of k-tile t and written to the
@@ -29,18 +32,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FETCH_SIZE): group 32 / 16 / 8 / 4 / 2 / 1 -> 23.7 / 22.3 / 18.6 / 12.9 / 10.6 / 10.1 GB of L2 misses and
 // 137.5 -> 139.5 TFLOP/s: only the A panel shared by the WGs of one tile ROW is reliably served from the
 // XCD's L2, so the plain row-major walk (group 1: 64 resident WGs = one 256-row A panel x 64 B panels) wins.
-#ifndef SP_GEMM_STAGES3
-#define SP_GEMM_STAGES3 0
-#endif
-#ifndef SP_GEMM_LDB_PAD
-#define SP_GEMM_LDB_PAD 0
-#endif
-#ifndef SP_GEMM_SETPRIO
-#define SP_GEMM_SETPRIO 0
-#endif
-#ifndef SP_GEMM_MID_STORE
-#define SP_GEMM_MID_STORE 0
-#endif
 #ifndef SP_GEMM_GROUP_M
 #define SP_GEMM_GROUP_M 1
 #endif
@@ -52,13 +43,11 @@ struct GemmCfg {
   static constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
   static constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
   static constexpr int LDA_S = BK + 4;                // padded LDS row (floats)
-  // B fragment reads: lanes 0-31 read 32 consecutive floats of row k, lanes 32-63 of row k + 4; with rows of BN
-  // floats both halves fall on banks 0-31 (2-way conflict); SP_GEMM_LDB_PAD = 8 moves the second half to banks 32-63
-  static constexpr int LDB_S = BN + SP_GEMM_LDB_PAD;
+  static constexpr int LDB_S = BN;
   static constexpr int A_FLOATS = BM * LDA_S;
   static constexpr int B_FLOATS = BK * LDB_S;
   static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
-  static constexpr int LDS_BYTES = (SP_GEMM_STAGES3 ? 3 : 2) * STAGE_FLOATS * 4;
+  static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
   static constexpr int A_VEC = (BM * BK / 4) / THREADS;  // float4 per thread per k-tile
   static constexpr int B_VEC = (BK * BN / 4) / THREADS;
   // 2 workgroups per CU when the wave tile needs 128 accumulator registers:
@@ -222,61 +211,6 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
 
   const int nt = (K + BK - 1) / BK;
   constexpr bool ktail = FAST && KTAIL;   // (the general path guards every element anyway)
-#if SP_GEMM_STAGES3
-  // (experiment) three LDS stages, tiles stored two k-steps ahead: the one barrier of a k-step sits between its two
-  // MFMA halves, with the fragments of the second half already in registers, so neither the wait for the global
-  // loads nor the LDS read latency follows it.
-  const int a_frag_off = (wm * Cfg::WTM + l31) * LDA_S + 4 * lh;
-  const int b_frag_off = (4 * lh) * LDB_S + wn * Cfg::WTN + l31;
-  static_assert(BK == 16, "SP_GEMM_STAGES3 is written for two fragment halves per k-tile");
-  if (ktail && nt == 1) SP_GEMM_LOAD_KTAIL(0);
-  else SP_GEMM_LOAD_TILE(0);
-  SP_GEMM_STORE_TILE(0);
-  if (nt > 1) {
-    if (ktail && nt == 2) SP_GEMM_LOAD_KTAIL(1);
-    else SP_GEMM_LOAD_TILE(1);
-    SP_GEMM_STORE_TILE(1);
-  }
-  __syncthreads();
-  int st_cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 2 < nt) {
-      if (ktail && t + 3 == nt) SP_GEMM_LOAD_KTAIL(t + 2);
-      else SP_GEMM_LOAD_TILE(t + 2);
-    }
-    const float* sA = smem + st_cur * Cfg::STAGE_FLOATS;
-    const float* sB = sA + Cfg::A_FLOATS;
-    f32x4 af[2][TM];
-    float bf[2][TN][4];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[c][i] = *(const f32x4*)(sA + a_frag_off + i * 32 * LDA_S + c * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bf[c][j][s] = sB[b_frag_off + (c * 8 + s) * LDB_S + j * 32];
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const float av = af[c][i][s];
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[c][j][s], acc[i][j], 0, 0, 0);
-        }
-      }
-      if (c == 0) __syncthreads();
-    }
-    const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;   // (t + 2) % 3
-    if (t + 2 < nt) SP_GEMM_STORE_TILE(st_next2);
-    st_cur = st_cur == 2 ? 0 : st_cur + 1;
-  }
-
-#else
   if (ktail && nt == 1) SP_GEMM_LOAD_KTAIL(0);
   else SP_GEMM_LOAD_TILE(0);
   SP_GEMM_STORE_TILE(0);
@@ -302,7 +236,6 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) bf[j][s] = sB[b_frag_off + (c * 8 + s) * LDB_S + j * 32];
-      if (SP_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);   // (experiment) MFMA issue ahead of the other wave's memory ops
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -313,20 +246,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[j][s], acc[i][j], 0, 0, 0);
         }
       }
-      if (SP_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
-      // SP_GEMM_MID_STORE: the next k-tile goes to its (free) LDS stage after the first half of this tile's
-      // MFMAs instead of after all of them, so the wait for the global loads is off the barrier's path
-      if (SP_GEMM_MID_STORE && BK / 8 > 1 && c == 0) {
-        if (t + 1 < nt) SP_GEMM_STORE_TILE((t + 1) & 1);
-      }
     }
-    if (!(SP_GEMM_MID_STORE && BK / 8 > 1)) {
-      if (t + 1 < nt) SP_GEMM_STORE_TILE((t + 1) & 1);
-    }
+    if (t + 1 < nt) SP_GEMM_STORE_TILE((t + 1) & 1);
     __syncthreads();
   }
 
-#endif
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -345,6 +269,196 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void sp_gemm_kernel(c
       }
     }
   }
+}
+
+// ---- direct-to-LDS variant (round 2) -------------------------------------------------------------------
+// The same macro-tile and MFMA schedule, but the k-tiles go from global memory straight into LDS
+// (global_load_lds_dwordx4: 16 B per lane, LDS address = wave-uniform base + 16 * lane), so there are no staging
+// registers, no ds_write pass and no wait for the global loads inside the k-loop: tile t+1 is requested right
+// after the barrier that frees its stage and only has to have landed at the NEXT barrier, a whole k-tile of MFMAs
+// later.  Such a load cannot pad or scatter its LDS image, so the A tile is kept [m][16] UNPADDED and made
+// conflict-free by permuting which 16-B chunk of a row each lane fetches (the permutation is on the SOURCE
+// address; the LDS image stays lane-linear): chunk q of row m lives in slot q ^ ((m >> 2) & 3).  A ds_read_b128
+// is served in four groups of 16 lanes whose rows fall into the four residues mod 4 four times each; rows of one
+// residue share their 16 banks, and the xor sends those four rows to four different chunks = four different bank
+// quads.  The B tile [16][BN] is read along n by ds_read_b32 exactly as before.
+// Preconditions (sp_gemm_f32 checks them, else the register-staged kernel runs): N % 4 == 0, lda % 4 == 0,
+// ldb % 4 == 0, 16-B aligned bases, K % 16 == 0.
+template <int BM, int BN, int WM, int WN>
+struct GldsCfg {
+  static constexpr int BK = 16;
+  static constexpr int NW = WM * WN, THREADS = NW * 64;
+  static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  static constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN, STAGE_FLOATS = A_FLOATS + B_FLOATS;
+  static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+  static constexpr int A_PIECES = (A_FLOATS / 256) / NW;   // 1 KiB wave-loads of A per wave and k-tile
+  static constexpr int B_PIECES = (B_FLOATS / 256) / NW;
+  static constexpr int MIN_WAVES = (NW == 4) ? 2 : 1;
+  static_assert((A_FLOATS / 256) % NW == 0 && (B_FLOATS / 256) % NW == 0, "tile / waves mismatch");
+};
+
+// PIPE: the fragments of the two 8-deep halves of a k-tile live in two register sets; the half-tile that follows is
+// read from LDS while the current one is multiplied, and the workgroup barrier sits between the two halves (the
+// reads that must precede it were issued a half-tile of MFMAs earlier, the reads that follow it have one to land).
+// WGS: workgroups per CU the register allocation aims for.
+template <typename Cfg, int BM, int BN, int WM, int WN, int PIPE, int WGS>
+__global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+    int64_t ldc, int M, int N, int K, int accumulate, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN;
+  constexpr int AP = Cfg::A_PIECES, BP = Cfg::B_PIECES;
+  int tm, tn;
+  sp_gemm_tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // ---- what each lane fetches: block-relative 32-bit element offsets, scalar bases
+  const float* __restrict__ Ablk = A + (int64_t)m0 * lda;
+  const float* __restrict__ Bblk = B + n0;
+  int a_off[AP], b_off[BP];
+#pragma unroll
+  for (int j = 0; j < AP; ++j) {
+    const int slot = (wid * AP + j) * 64 + lane;          // 16-B slot of the A image: row = slot / 4
+    int row = slot >> 2;
+    const int q = (slot & 3) ^ ((row >> 2) & 3);           // the chunk of that row this slot holds
+    if (m0 + row > M - 1) row = M - 1 - m0;                // clamp (masked on store)
+    a_off[j] = row * (int)lda + q * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < BP; ++j) {
+    const int slot = (wid * BP + j) * 64 + lane;          // 16-B slot of the B image: row = slot / (BN / 4)
+    const int krow = slot / (BN / 4);
+    int gc = (slot % (BN / 4)) * 4;
+    if (n0 + gc > N - 4) gc = N - 4 - n0;
+    b_off[j] = krow * (int)ldb + gc;
+  }
+  float* const sA_w = smem + wid * AP * 256;               // this wave's pieces inside a stage
+  float* const sB_w = smem + Cfg::A_FLOATS + wid * BP * 256;
+
+#define SP_GLDS_TILE(kt, stage)                                                        \
+  do {                                                                                 \
+    const float* Ak_ = Ablk + (kt) * BK;                                               \
+    const float* Bk_ = Bblk + (int64_t)((kt) * BK) * ldb;                              \
+    float* dA_ = sA_w + (stage) * Cfg::STAGE_FLOATS;                                   \
+    float* dB_ = sB_w + (stage) * Cfg::STAGE_FLOATS;                                   \
+    _Pragma("unroll") for (int j = 0; j < AP; ++j) SP_GLDS(Ak_ + a_off[j], dA_ + j * 256); \
+    _Pragma("unroll") for (int j = 0; j < BP; ++j) SP_GLDS(Bk_ + b_off[j], dB_ + j * 256); \
+  } while (0)
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: A row (wave tile row + l31), chunk (lh + 2c) ^ ((row >> 2) & 3); B row 4 lh + 8c + s
+  const int sw = (l31 >> 2) & 3;
+  const int a_row_off = (wm * Cfg::WTM + l31) * BK;
+  int a_chunk[BK / 8];
+#pragma unroll
+  for (int c = 0; c < BK / 8; ++c) a_chunk[c] = a_row_off + 4 * ((lh + 2 * c) ^ sw);
+  const int b_frag_off = (4 * lh) * BN + wn * Cfg::WTN + l31;
+
+  const int nt = K / BK;
+#define SP_FRAGS(af_, bf_, stage, c)                                                                \
+  do {                                                                                              \
+    const float* sA_ = smem + (stage) * Cfg::STAGE_FLOATS;                                          \
+    const float* sB_ = sA_ + Cfg::A_FLOATS;                                                         \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) af_[i] = *(const f32x4*)(sA_ + a_chunk[c] + i * 32 * BK); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
+      _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) bf_[j][s4] = sB_[b_frag_off + ((c) * 8 + s4) * BN + j * 32]; \
+  } while (0)
+#define SP_MFMAS(af_, bf_)                                                                          \
+  do {                                                                                              \
+    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                                                \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[i][s4], bf_[j][s4], acc[i][j], 0, 0, 0); \
+  } while (0)
+  if constexpr (PIPE) {
+    static_assert(BK == 16, "two fragment halves per k-tile");
+    f32x4 af0[TM], af1[TM];
+    float bf0[TN][4], bf1[TN][4];
+    SP_GLDS_TILE(0, 0);
+    if (nt > 1) SP_GLDS_TILE(1, 1);
+    SP_GLDS_LANDED();
+    __syncthreads();
+    SP_FRAGS(af0, bf0, 0, 0);
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      SP_FRAGS(af1, bf1, cur, 1);
+      SP_MFMAS(af0, bf0);
+      // keep the first half's MFMAs AHEAD of the barrier (hipcc otherwise sinks them below it and the wave stalls
+      // on the LDS reads it has just issued): the barrier's lgkmcnt wait then finds them long finished
+      __builtin_amdgcn_sched_barrier(0);
+      SP_GLDS_LANDED();
+      __syncthreads();    // every wave has read all of stage `cur`; tile t+1 has landed in the other stage
+      if (t + 2 < nt) SP_GLDS_TILE(t + 2, cur);
+      if (t + 1 < nt) SP_FRAGS(af0, bf0, cur ^ 1, 0);
+      SP_MFMAS(af1, bf1);
+    }
+  } else {
+    SP_GLDS_TILE(0, 0);
+    SP_GLDS_LANDED();
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) SP_GLDS_TILE(t + 1, (t + 1) & 1);
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        f32x4 af[TM];
+        float bf[TN][4];
+        SP_FRAGS(af, bf, t & 1, c);
+        SP_MFMAS(af, bf);
+      }
+      SP_GLDS_LANDED();
+      __syncthreads();    // tile t+1 has landed and every wave is done reading stage t
+    }
+  }
+#undef SP_FRAGS
+#undef SP_MFMAS
+#undef SP_GLDS_TILE
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * Cfg::WTN + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M && col < N) {
+          float* p = C + (int64_t)row * ldc + col;
+          float v = acc[i][j][r];
+          if (accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int PIPE, int WGS>
+static int sp_gemm_glds_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                               int64_t M, int64_t N, int64_t K, int acc, hipStream_t st) {
+  using Cfg = GldsCfg<BM, BN, WM, WN>;
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int64_t nblk = tiles_m * tiles_n;
+  if (nblk > 2147483647LL) SP_FAIL("sp_gemm_f32: too many tiles");
+  auto k = sp_gemm_glds_kernel<Cfg, BM, BN, WM, WN, PIPE, WGS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, A, lda, B, ldb, C, ldc, (int)M,
+                     (int)N, (int)K, acc, (int)tiles_m, (int)tiles_n);
+  SP_CHECK_LAUNCH();
+  return 0;
 }
 
 template <typename Cfg, typename KernelT>
@@ -413,19 +527,32 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
   int v = sp_gemm_variant();
   if (v < 0) {
     // default: big macro-tile for big problems, smaller tile to fill the chip otherwise
+    // (the 256 x 128 tile fetches its k-tiles straight into LDS when the operands allow it -- case 6 checks --
+    //  141.5 vs 139.7 TFLOP/s at 8192^3, profiles/r02_notes.md)
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 127) / 128);
-    v = big_tiles >= 256 ? 0 : 1;
+    v = big_tiles >= 256 ? 6 : 1;
   }
   switch (v) {
     case 0: return sp_gemm_launch<256, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 1: return sp_gemm_launch<128, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 2: return sp_gemm_launch<256, 256, 16, 2, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 3: return sp_gemm_launch<128, 256, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
-#if !SP_GEMM_STAGES3
-    // experimental (SP_GEMM_VARIANT only): k-tiles of 32 halve the barriers per contraction
+    // (SP_GEMM_VARIANT only) k-tiles of 32 halve the barriers per contraction: slower, profiles/r01_notes.md
     case 4: return sp_gemm_launch<128, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 5: return sp_gemm_launch<256, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
-#endif
+    // direct-to-LDS k-tiles (preconditions checked here; otherwise the register-staged kernel of the same tile)
+    case 6: case 9:
+      if (fast && K % 16 == 0 && (int64_t)256 * lda < 2147483647LL && (int64_t)16 * ldb < 2147483647LL) {
+        if (v == 6) return sp_gemm_glds_launch<256, 128, 2, 2, 0, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
+        // (SP_GEMM_VARIANT only) register double-buffered fragments, barrier between the k-tile's halves:
+        // 139.2 vs 141.5 TFLOP/s for case 6 -- profiles/r02_notes.md
+        return sp_gemm_glds_launch<256, 128, 2, 2, 1, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
+      }
+      return sp_gemm_launch<256, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+    case 7:
+      if (fast && K % 16 == 0 && (int64_t)128 * lda < 2147483647LL && (int64_t)16 * ldb < 2147483647LL)
+        return sp_gemm_glds_launch<128, 128, 2, 2, 0, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
+      return sp_gemm_launch<128, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     default: SP_FAIL("sp_gemm_f32: unknown SP_GEMM_VARIANT=%d", v);
   }
 }

@@ -316,12 +316,17 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_fused_kernel(const float* _
 // 256 centers instead of once per 128, and the epilogue is 4 VALU ops per score, once per 256-center block.
 // Scores and their error bound E are exactly those of the kernel above (acc = fmaf chain over the
 // features from 0, one subtraction from |c|^2/2), so the set of undecided points is the same.
+// The k-tiles go from global memory straight into LDS (global_load_lds_dwordx4, as in gemm.hip's
+// sp_gemm_glds_kernel: no staging registers, no ds_write pass): both images are [row][16] unpadded, chunk q of row
+// r in slot q ^ ((r >> 2) & 3) so that the 16-B fragment reads stay conflict-free, and the |c|^2/2 slice of a
+// center block is one more 1 KiB piece.  Point rows that are not 16-B aligned or not whole k-steps long
+// (FAST = false) take the register path for the point tile only, into the same image.
 constexpr int KN_BM = 256;                       // centers per block (KM_BN_MAX: kp is a multiple of it)
 constexpr int KN_BN = 128;                       // points per workgroup
-constexpr int KN_A_FLOATS = KN_BM * KM_LDA;      // 5120
-constexpr int KN_B_FLOATS = KN_BN * KM_LDA;      // 2560
+constexpr int KN_A_FLOATS = KN_BM * KM_BK;       // 4096: rows of 16 floats, UNPADDED (see the k-tile loads below)
+constexpr int KN_B_FLOATS = KN_BN * KM_BK;       // 2048
 constexpr int KN_STAGE = KN_A_FLOATS + KN_B_FLOATS;
-constexpr int KN_SMEM_FLOATS = 2 * KN_STAGE + 2 * KN_BM;   // two stages + two |c|^2/2 slices  (63 488 B)
+constexpr int KN_SMEM_FLOATS = 2 * KN_STAGE + 2 * KN_BM;   // two stages + two |c|^2/2 slices  (51 200 B)
 static_assert(KN_SMEM_FLOATS * 4 <= 65536, "static LDS limit");
 static_assert(KN_BM == KM_BN_MAX, "kp must be a multiple of the center block");
 
@@ -361,48 +366,54 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
     if (listed > n || m0 >= listed) return;
   }
 
-  int a_off[AV], a_lds[AV], b_lds[BV];
-  typename std::conditional<RECHECK, int64_t, int>::type b_off[BV];
+  // ---- k-tile pieces (1 KiB = one wave-wide 16-B load): slot -> (row, chunk) of the swizzled image
+  constexpr int AP = (KN_A_FLOATS / 256) / 4, BP = (KN_B_FLOATS / 256) / 4;   // 4 and 2 pieces per wave
+  int a_off[AP];
 #pragma unroll
-  for (int j = 0; j < AV; ++j) {
-    const int e = tid + j * THREADS;
-    const int row = e / KQ, kq = e % KQ;
-    a_lds[j] = row * KM_LDA + kq * 4;
-    a_off[j] = row * dp + kq * 4;
+  for (int j = 0; j < AP; ++j) {
+    const int slot = (wid * AP + j) * 64 + lane, row = slot >> 2;
+    a_off[j] = row * dp + ((slot & 3) ^ ((row >> 2) & 3)) * 4;
   }
   const float* __restrict__ Xblk = RECHECK ? X : X + (int64_t)m0 * ldx;
+  typename std::conditional<RECHECK, int64_t, int>::type b_off[BP];
+  int b_lds[BP];                                  // (register path) where this thread's 16 B go
 #pragma unroll
-  for (int j = 0; j < BV; ++j) {
-    const int e = tid + j * THREADS;
-    int row = e / KQ;
-    const int kq = e % KQ;
-    b_lds[j] = row * KM_LDA + kq * 4;
+  for (int j = 0; j < BP; ++j) {
+    // FAST: piece slots as for A; register path: thread e owns chunk e % 4 of row e / 4 (its guards are per k)
+    const int slot = FAST ? (wid * BP + j) * 64 + lane : tid + j * THREADS;
+    int row = slot >> 2;
+    const int q = FAST ? (slot & 3) ^ ((row >> 2) & 3) : (slot & 3);
+    b_lds[j] = row * KM_BK + ((slot & 3) ^ (FAST ? 0 : ((row >> 2) & 3))) * 4;
     if constexpr (RECHECK) {
-      const int slot = m0 + row < listed ? m0 + row : listed - 1;   // tail: repeat the last listed point
-      b_off[j] = (int64_t)amb_rows[slot] * ldx + kq * 4;
+      const int listed_row = m0 + row < listed ? m0 + row : listed - 1;   // tail: repeat the last listed point
+      b_off[j] = (int64_t)amb_rows[listed_row] * ldx + q * 4;
     } else {
       if (m0 + row > n - 1) row = n - 1 - m0;     // clamp: results of points >= n are discarded
-      b_off[j] = row * (int)ldx + kq * 4;
+      b_off[j] = row * (int)ldx + q * 4;
     }
   }
+  float* const sA_w = smem + wid * AP * 256;      // this wave's pieces inside a stage
+  float* const sB_w = smem + KN_A_FLOATS + wid * BP * 256;
   const int nt = dp / KM_BK;
   const int tm_first = RECHECK ? (int)blockIdx.y : 0;
   const int tiles_m = RECHECK ? 1 : kp / KN_BM;   // center blocks walked by this workgroup
   const int steps = nt * tiles_m;
-  km_f32x4 ra[AV], rb[BV], rch;
+  km_f32x4 rb[BP];
 
+  // request k-step `step` (into stage step & 1); KN_STORE completes it on the register path
 #define KN_LOAD(step)                                                                    \
   do {                                                                                   \
     const int tr_ = (step) / nt, kt_ = (step) - tr_ * nt;                                \
     const int tm_ = tm_first + tr_;                                                      \
     const int k0_ = kt_ * KM_BK;                                                         \
     const float* Ak_ = Cf + (int64_t)tm_ * KN_BM * dp + k0_;                             \
-    _Pragma("unroll") for (int j = 0; j < AV; ++j) ra[j] = *(const km_f32x4*)(Ak_ + a_off[j]); \
-    _Pragma("unroll") for (int j = 0; j < BV; ++j) {                                     \
+    float* dA_ = sA_w + ((step) & 1) * KN_STAGE;                                         \
+    _Pragma("unroll") for (int j = 0; j < AP; ++j) SP_GLDS(Ak_ + a_off[j], dA_ + j * 256); \
+    _Pragma("unroll") for (int j = 0; j < BP; ++j) {                                     \
       if constexpr (FAST) {                                                              \
-        rb[j] = *(const km_f32x4*)(Xblk + k0_ + b_off[j]);                               \
+        SP_GLDS(Xblk + k0_ + b_off[j], sB_w + ((step) & 1) * KN_STAGE + j * 256);        \
       } else {                                                                           \
-        const int kk = k0_ + ((tid + j * THREADS) % KQ) * 4;                             \
+        const int kk = k0_ + ((tid + j * THREADS) & 3) * 4;                              \
         const float* p = Xblk + k0_ + b_off[j];                                          \
         rb[j].x = kk + 0 < d ? p[0] : 0.f;                                               \
         rb[j].y = kk + 1 < d ? p[1] : 0.f;                                               \
@@ -410,16 +421,15 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
         rb[j].w = kk + 3 < d ? p[3] : 0.f;                                               \
       }                                                                                  \
     }                                                                                    \
-    if (kt_ == 0 && tid < KN_BM / 4) rch = *(const km_f32x4*)(chalf + tm_ * KN_BM + tid * 4); \
+    if (kt_ == 0 && wid == 0) SP_GLDS(chalf + tm_ * KN_BM + lane * 4, chs + (tr_ & 1) * KN_BM); \
   } while (0)
 #define KN_STORE(step)                                                                   \
   do {                                                                                   \
-    float* sA_ = smem + ((step) & 1) * KN_STAGE;                                         \
-    float* sB_ = sA_ + KN_A_FLOATS;                                                      \
-    _Pragma("unroll") for (int j = 0; j < AV; ++j) *(km_f32x4*)(sA_ + a_lds[j]) = ra[j]; \
-    _Pragma("unroll") for (int j = 0; j < BV; ++j) *(km_f32x4*)(sB_ + b_lds[j]) = rb[j]; \
-    const int tr_ = (step) / nt;                                                         \
-    if ((step) - tr_ * nt == 0 && tid < KN_BM / 4) *(km_f32x4*)(chs + (tr_ & 1) * KN_BM + tid * 4) = rch; \
+    if constexpr (!FAST) {                                                               \
+      float* sB_ = smem + ((step) & 1) * KN_STAGE + KN_A_FLOATS;                         \
+      _Pragma("unroll") for (int j = 0; j < BP; ++j) *(km_f32x4*)(sB_ + b_lds[j]) = rb[j]; \
+    }                                                                                    \
+    SP_GLDS_LANDED();                                                                    \
   } while (0)
 
   km_f32x16 acc[4][2];
@@ -437,8 +447,14 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
   KN_LOAD(0);
   KN_STORE(0);
   __syncthreads();
-  const int a_frag = (wm * 128 + l31) * KM_LDA + 4 * lh;
-  const int b_frag = (wn * 64 + l31) * KM_LDA + 4 * lh;
+  // fragments: row (wave tile row + l31), chunk (lh + 2c) ^ ((row >> 2) & 3) -- the same xor for both operands
+  const int sw = (l31 >> 2) & 3;
+  int a_frag[KM_BK / 8], b_frag[KM_BK / 8];
+#pragma unroll
+  for (int c = 0; c < KM_BK / 8; ++c) {
+    a_frag[c] = (wm * 128 + l31) * KM_BK + 4 * ((lh + 2 * c) ^ sw);
+    b_frag[c] = (wn * 64 + l31) * KM_BK + 4 * ((lh + 2 * c) ^ sw);
+  }
 
   int t = 0;
   for (int tr = 0; tr < tiles_m; ++tr) {
@@ -451,9 +467,9 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
       for (int c = 0; c < KM_BK / 8; ++c) {
         km_f32x4 af[4], bf[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *(const km_f32x4*)(sA + a_frag + i * 32 * KM_LDA + c * 8);
+        for (int i = 0; i < 4; ++i) af[i] = *(const km_f32x4*)(sA + a_frag[c] + i * 32 * KM_BK);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *(const km_f32x4*)(sB + b_frag + j * 32 * KM_LDA + c * 8);
+        for (int j = 0; j < 2; ++j) bf[j] = *(const km_f32x4*)(sB + b_frag[c] + j * 32 * KM_BK);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll

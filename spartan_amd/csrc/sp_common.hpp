@@ -56,6 +56,18 @@ static inline size_t sp_dtype_size(int32_t dt) {
 #define SP_BLOCKS_PER_CU 8
 #define SP_BLOCK 256
 
+// ---- direct-to-LDS loads (gfx950 global_load_lds_dwordx4): every lane fetches 16 B from its own global address
+// and the wave's 1 KiB lands at a wave-uniform LDS base + 16 * lane.
+#ifndef __HIPCC_RTC__
+// An LDS-DMA is complete for OTHER waves only after the issuing wave has waited for it (vmcnt) and a barrier: hipcc
+// does not reliably put that wait in front of a barrier inside a loop (seen missing in the PIPE loop's .s), so
+// it is stated here.
+#define SP_GLDS_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SP_GLDS(gptr, lptr)                                                                         \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+#endif
+
 struct sp_inputs {
   const void* p[SP_MAX_INPUTS];
 };

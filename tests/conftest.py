@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu on the GPU box)')
+  config.addinivalue_line('markers', 'host_logic: pure host arithmetic pinned by reference goldens (extents, tiling, '
+                                     'fusion); runs in the CPU suite here AND in the -m gpu suite on the GPU box')
 
 
 def _have_gpu():
@@ -20,8 +22,13 @@ def _have_gpu():
     return False
 
 
+@pytest.hookimpl(tryfirst=True)
 def pytest_collection_modifyitems(config, items):
   if _have_gpu():
+    # on the GPU box the golden-pinned host logic is part of the `-m gpu` run as well
+    for item in items:
+      if 'host_logic' in item.keywords:
+        item.add_marker(pytest.mark.gpu)
     return
   skip = pytest.mark.skip(reason='no GPU in this container')
   for item in items:

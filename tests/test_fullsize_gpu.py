@@ -147,3 +147,132 @@ def test_config4_kmeans_iteration(ctx):
   # sums = centers * counts (empty clusters were re-seeded by the driver: weight 0 here) -> column sums of X
   col = x_dev.double().sum(dim=0).cpu().numpy()
   np.testing.assert_allclose((new_centers * counts[:, None]).sum(axis=0), col, rtol=2e-6)
+
+
+# ---- the WHOLE arrays of configs[2] / [3] / [4] and the north star on one GPU, as 8 logical workers -------------
+# (the per-tile tests above never run the combine between tiles -- update / merge / reduce -- at full size; 16 GiB,
+#  10 GB and 16 GB arrays fit one 288 GB GPU, so the 8-tile path is exercised here before an 8-GPU node sees it)
+@pytest.fixture
+def ctx8():
+  free, _ = torch.cuda.mem_get_info()
+  if free < 80 * 2 ** 30:
+    pytest.skip('needs ~60 GiB of free HBM')
+  c = sp.initialize('hip', num_workers=8)
+  yield c
+  sp.shutdown()
+  torch.cuda.empty_cache()
+
+
+def _tile_of(ctx, array, row):
+  for ex, tid in array.tiles.items():
+    if ex.ul[0] <= row < ex.lr[0]:
+      return ctx.tile(tid).data, ex
+  raise KeyError(row)
+
+
+def test_config3_full_array_8_tiles(ctx8):
+  """sum over every axis and argmax / argmin of the 65536 x 65536 fp32 array (16 GiB, 8 tiles of 8192 x 65536),
+  extremes planted as duplicates ACROSS tiles: the first occurrence in row-major order must win after the combine."""
+  R = C = 65536
+  X = _uniform((R, C), 41).force()
+  assert sorted(ex.shape for ex in X.tiles) == [(8192, C)] * 8
+  plants = [(60000, 11, 9.0), (100, 11, 9.0), (20000, 40000, 9.0),          # max 9.0: first at (100, 11)
+            (50000, 7, -3.0), (9000, 7, -3.0), (9000, 65535, -3.0)]         # min -3.0: first at (9000, 7)
+  for r, c, v in plants:
+    t, ex = _tile_of(ctx8, X, r)
+    t[r - ex.ul[0], c] = v
+  Xv = sp.Val(val=X)
+  n = float(R) * C
+  total = float(sp.sum(Xv).glom())
+  by_col = sp.sum(Xv, 0).glom().astype(np.float64)        # 8 partials of (65536,) combined by the reducer
+  by_row = sp.sum(Xv, 1).glom().astype(np.float64)
+  assert by_col.shape == (C,) and by_row.shape == (R,)
+  assert abs(by_col.sum() - total) <= 1e-6 * n and abs(by_row.sum() - total) <= 1e-6 * n
+  assert abs(total - 0.5 * n) < 1e-3 * n
+  assert int(sp.argmax(Xv).glom()) == 100 * C + 11
+  assert int(sp.argmin(Xv).glom()) == 9000 * C + 7
+  am0 = sp.argmax(Xv, 0).glom()
+  assert am0[11] == 100 and am0[40000] == 20000
+  assert sp.argmin(Xv, 0).glom()[7] == 9000 and sp.argmin(Xv, 0).glom()[65535] == 9000
+  am1 = sp.argmax(Xv, 1).glom()
+  assert am1[60000] == 11 and am1[100] == 11 and am1[20000] == 40000
+  assert float(sp.max(Xv).glom()) == 9.0 and float(sp.min(Xv).glom()) == -3.0
+  # spot columns against float64 on the device
+  cols = [0, 11, 40000, 65535]
+  ref = np.zeros(len(cols))
+  for ex, tid in X.tiles.items():
+    ref += ctx8.tile(tid).data[:, cols].double().sum(0).cpu().numpy()
+  np.testing.assert_allclose(by_col[cols], ref, rtol=2e-6)
+
+
+def test_config4_full_kmeans_iteration_8_tiles(ctx8):
+  """One Lloyd iteration on all 10 000 000 x 256 fp32 points, k = 1024, as 8 tiles: the counts and per-cluster
+  sums of the tiles are combined by the np.add reducer."""
+  from scipy.spatial.distance import cdist
+  from spartan_amd.examples.sklearn.cluster import KMeans
+  n, k, d = 10000000, 1024, 256
+  X = _uniform((n, d), 43).force()
+  assert len(X.tiles) == 8
+  rng = np.random.RandomState(9)
+  centers = rng.rand(k, d)
+  centers[900] = centers[5]
+  new_centers, labels = KMeans(k, 1).fit(sp.Val(val=X), centers.copy(), implementation='map2', reducer=np.add)
+  lab = labels.glom().astype(np.int64)
+  assert lab.shape == (n,) and not np.any(lab == 900)
+  counts = np.bincount(lab, minlength=k)
+  assert counts.sum() == n
+  sample = rng.randint(0, n, size=400)
+  rows = []
+  for r in sample:
+    t, ex = _tile_of(ctx8, X, int(r))
+    rows.append(t[int(r) - ex.ul[0]].cpu().numpy())
+  np.testing.assert_array_equal(lab[sample], np.argmin(cdist(np.stack(rows), centers), axis=1))
+  col = np.zeros(d)
+  for ex, tid in X.tiles.items():
+    col += ctx8.tile(tid).data.double().sum(dim=0).cpu().numpy()
+  np.testing.assert_allclose((new_centers * counts[:, None]).sum(axis=0), col, rtol=2e-6)
+
+
+def test_config5_full_lreg_3_steps_8_tiles(ctx8):
+  """Three gradient steps on the whole 1 000 000 x 4096 fp32 problem as 8 tiles, against the same steps in
+  float64 on the device (the (D,) partial gradients of the tiles are merged by the np.add reducer)."""
+  from spartan_amd.examples import lreg
+  N, D = 1000000, 4096
+  X = _uniform((N, D), 45).force()
+  y = _uniform((N, 1), 46).force()
+  assert len(X.tiles) == 8
+  w0 = np.random.RandomState(3).rand(D, 1)
+  w = lreg.fit(sp.Val(val=X), sp.Val(val=y), 3, w=w0.copy())
+  ref = torch.from_numpy(w0).cuda()
+  ytiles = {ex.ul[0]: ctx8.tile(tid).data for ex, tid in y.tiles.items()}
+  for _ in range(3):
+    grad = torch.zeros(D, 1, dtype=torch.float64, device='cuda')
+    for ex, tid in X.tiles.items():
+      x = ctx8.tile(tid).data
+      r = x.double() @ ref - ytiles[ex.ul[0]].double()
+      grad += x.double().t() @ r
+    ref = ref - grad * 1e-6
+  assert w.shape == (D, 1)
+  np.testing.assert_allclose(w, ref.cpu().numpy(), rtol=2e-5, atol=1e-7)
+
+
+def test_northstar_dot_32768_spot_rows(ctx):
+  """dot 32768^3 fp32 on one tile: spot rows against float64, |dC| <= 2 K eps; integer-valued closed form."""
+  n = 32768
+  U = _uniform((n, n), 51, -1.0, 1.0).force()
+  V = _uniform((n, n), 52, -1.0, 1.0).force()
+  W = sp.dot(sp.Val(val=U), sp.Val(val=V)).force()
+  u = ctx.tile(list(U.tiles.values())[0]).data
+  v = ctx.tile(list(V.tiles.values())[0]).data
+  w = ctx.tile(list(W.tiles.values())[0]).data
+  rows = [0, 4097, 32767]
+  ref = u[rows].double() @ v.double()
+  assert float((w[rows].double() - ref).abs().max()) <= 2 * n * np.finfo(np.float32).eps
+  del W, w, ref
+  torch.cuda.empty_cache()
+  jj = torch.arange(n, device='cuda', dtype=torch.float32)
+  u.copy_(((jj[:, None] + 2 * jj[None, :]) % 5) - 2)            # integer-valued: the product is exact in fp32
+  v.fill_(1.0)
+  W = sp.dot(sp.Val(val=U), sp.Val(val=V)).force()
+  w = ctx.tile(list(W.tiles.values())[0]).data
+  assert torch.equal(w[:, 0], u.sum(1)) and torch.equal(w[:, n - 1], w[:, 0]) and torch.equal(w[12345], w[12345, 0].expand(n))

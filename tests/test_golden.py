@@ -39,6 +39,7 @@ def sl(t):
 
 
 # ------------------------------------------------------------------ extents
+@pytest.mark.host_logic
 def test_extent_pairs():
   for rec in EXT['pairs']:
     shape = tuple(rec['shape'])
@@ -58,6 +59,7 @@ def test_extent_pairs():
       assert list(extent.shape_for_reduction(shape, axis)) == rec['shape_for_reduction_%s' % axis]
 
 
+@pytest.mark.host_logic
 def test_extent_edge_cases():
   a = extent.create((0, 0), (5, 5), (10, 10))
   b = extent.create((5, 0), (10, 5), (10, 10))
@@ -79,12 +81,14 @@ def test_extent_edge_cases():
   assert got == EXT['is_complete']
 
 
+@pytest.mark.host_logic
 def test_change_partition_axis():
   for rec in EXT['change_partition_axis']:
     axis = tuple(rec['axis']) if isinstance(rec['axis'], list) else rec['axis']
     assert tup(extent.change_partition_axis(ex_of(rec['ex']), axis)) == rec['result'], rec
 
 
+@pytest.mark.host_logic
 def test_tiling_of_baseline_shapes():
   for rec in EXT['tiling']:
     shape = tuple(rec['shape'])
@@ -178,6 +182,7 @@ def test_programs_match_reference_gpu(workers):
   _check_programs(HipBackend, workers)
 
 
+@pytest.mark.host_logic
 def test_fusion_trees_match_reference():
   from oracle.np_backend import NumpyBackend
   sp.initialize(backend=NumpyBackend(), num_workers=1)
