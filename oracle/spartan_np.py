@@ -458,6 +458,12 @@ class Cluster(object):
       for ex, _, t in a.tiles:
         target.update(Extent((0,), (1,), (1,)), a.fetch(ex).dot(b.fetch(Extent(ex.ul, ex.lr, b.shape))).reshape(1,))
       return target
+    if len(a.shape) == 1:                                     # vector . matrix, dot.py:296-299: the vector as a
+      target = self.empty((b.shape[1],), a.dtype, np.add, tile_hint)   # 1 x n row, K-split join, is_vec
+      for ex, _, t in a.tiles:
+        rows = Extent((ex.ul[0], 0), (ex.lr[0], b.shape[1]), b.shape)
+        target.update(Extent((0,), (b.shape[1],), (b.shape[1],)), a.fetch(ex).dot(b.fetch(rows)))
+      return target
     if len(b.shape) == 1:
       shape = (a.shape[0],)
     else:

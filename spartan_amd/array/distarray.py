@@ -144,6 +144,8 @@ class DistArray(object):
     whole = self.select(np.index_exp[:])
     if tile.is_sparse_blob(whole):
       return ctx.backend.sparse_to_host(whole)   # a scipy.sparse matrix, like the reference's glom
+    if isinstance(whole, tile.MaskedBlob):
+      return whole.to_host(ctx.backend)          # a numpy.ma.MaskedArray, like the reference's glom
     return ctx.backend.to_numpy(whole)
 
   def map_to_array(self, mapper_fn, kw=None):
@@ -418,7 +420,11 @@ class DistArrayImpl(DistArray):
     """Tile.get(offset_slice) on the owning rank."""
     ctx = self.ctx
     t = ctx.tile(tile_id)
-    return t.get(ctx.backend, extent.offset_slice(ex, intersection))
+    piece = t.get(ctx.backend, extent.offset_slice(ex, intersection))
+    if isinstance(piece, tile.MaskedBlob) and ctx.world.distributed:
+      raise NotImplementedError('a region with never-written cells (reference: MaskedArray) can be read inside one '
+                                'process only; across ranks only fully written regions travel')
+    return piece
 
   def fetch(self, region):
     """distarray.py:294-367.  Inside a kernel the data is delivered to the rank
@@ -554,11 +560,20 @@ class DistArrayImpl(DistArray):
     if any(isinstance(p, tile.EmptyBlob) for p in pieces):
       return tile.EmptyBlob(region.shape, self.dtype)
     tgt = be.empty(region.shape, self.dtype)
+    # pieces with unwritten cells (tile.MaskedBlob) make the stitched region masked as well
+    valid = be.zeros(region.shape, np.uint8) if any(isinstance(p, tile.MaskedBlob) for p in pieces) else None
     for (ex, inter), piece in zip(splits, pieces):
       dst_slice = extent.offset_slice(region, inter)
-      if extent.all_nonzero_shape(piece.shape):
+      if not extent.all_nonzero_shape(piece.shape):
+        continue
+      if isinstance(piece, tile.MaskedBlob):
+        be.paste(tgt, dst_slice, piece.data)
+        be.paste(valid, dst_slice, piece.valid)
+      else:
         be.paste(tgt, dst_slice, piece)
-    return tgt
+        if valid is not None:
+          be.assign_box(valid, dst_slice, 1)
+    return tgt if valid is None else tile.MaskedBlob(tgt, valid)
 
   def _fetch_replicated(self, region, splits):
     """Every rank assembles `region` (glom and driver-level fetches): one

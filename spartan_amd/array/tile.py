@@ -39,6 +39,34 @@ class EmptyBlob(object):
     self.dtype = np.dtype(dtype)
 
 
+class MaskedBlob(object):
+  """What `Tile.get()` returns for a region in which some cells were never written: the values together with
+  the written-cells mask, both in HBM -- the device form of the numpy.ma.MaskedArray the reference builds there
+  (tile.pyx:100-113: `masked_all` + the written cells copied in).  `data` and `valid` are backend tensors of the
+  same shape (`valid` uint8, 1 = written); `to_host` gives the reference's MaskedArray.  Kernels do not take
+  masked operands: a program that computes on a partially written array is refused (lower.NotLowerable)."""
+  __slots__ = ('data', 'valid')
+
+  def __init__(self, data, valid):
+    self.data = data
+    self.valid = valid
+
+  @property
+  def shape(self):
+    return tuple(self.data.shape)
+
+  @property
+  def dtype(self):
+    return self.data.dtype
+
+  def to_host(self, backend):
+    data = backend.to_numpy(self.data)
+    valid = backend.to_numpy(self.valid).astype(bool)
+    out = np.ma.masked_all(data.shape, dtype=data.dtype)
+    out[valid] = data[valid]
+    return out
+
+
 def is_sparse_blob(x):
   """A backend sparse blob (device CSR) or a scipy.sparse matrix (what user mappers yield)."""
   if getattr(x, 'is_sparse_tile', False):
@@ -100,12 +128,10 @@ class Tile(object):
     Assert.le(len(subslice), len(self.shape), 'Selector has more dimensions than data!')
     if not self.mask_is_uniform():
       if not backend.mask_all_set(self.mask, subslice):
-        # the reference returns a numpy.ma.MaskedArray here (tile.pyx:104-112);
-        # masked arrays do not exist on the device
-        raise NotImplementedError('reading a region of a tile with unset cells '
-                                  '(reference: MaskedArray) is not supported on the GPU backend')
+        return MaskedBlob(self.data[subslice], self.mask[subslice])     # tile.pyx:104-112
     elif self.mask == MASK_ALL_CLEAR:
-      raise NotImplementedError('reading an initialised-but-unwritten tile (reference: MaskedArray)')
+      # initialised (zeros) but nothing written yet: everything masked
+      return MaskedBlob(self.data[subslice], backend.zeros(tuple(self.data[subslice].shape), np.uint8))
     return self.data[subslice]
 
   def update(self, backend, subslice, data, reducer, owned=False):

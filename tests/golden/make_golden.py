@@ -483,7 +483,16 @@ def merge_goldens():
       t = t.update(sl, upd, red[r])
       steps.append({'box': b, 'reducer': r, 'update': upd.tolist()})
     mask = t.mask if isinstance(t.mask, np.ndarray) else np.full((6, 8), bool(t.mask))
-    out[name] = {'steps': steps, 'data': np.asarray(t.data).tolist(), 'mask': np.asarray(mask).astype(int).tolist()}
+    # Tile.get of the whole tile and of a box: a MaskedArray where some cell was never written (tile.pyx:100-113)
+    reads = []
+    for box in ((0, 6, 0, 8), (1, 5, 3, 8)):
+      got = t.get((slice(box[0], box[1]), slice(box[2], box[3])))
+      masked = isinstance(got, np.ma.MaskedArray)
+      reads.append({'box': list(box), 'masked': bool(masked),
+                    'values': np.asarray(got.filled(0) if masked else got).tolist(),
+                    'valid': (~np.ma.getmaskarray(got)).astype(int).tolist()})
+    out[name] = {'steps': steps, 'data': np.asarray(t.data).tolist(), 'mask': np.asarray(mask).astype(int).tolist(),
+                 'reads': reads}
   # zero-dimensional tile (tile.pyx:212-217)
   t = tile.from_shape((), np.float32, tile.TYPE_DENSE)
   t = t.update(None, np.float32(3.0), np.add)

@@ -113,6 +113,7 @@ def programs():
   add(('dot_numpy_rhs', lambda sp: sp.dot(sm(sp, (100, 40)), small((40, 8))), lambda: small((100, 40)).dot(small((40, 8))), None))
   add(('dot_numpy_vec', lambda sp: sp.dot(sm(sp, (100, 40)), small((40,))), lambda: small((100, 40)).dot(small((40,))), None))
   add(('dot_2d_vec', lambda sp: sp.dot(sm(sp, (100, 40)), sm(sp, (40,))), lambda: small((100, 40)).dot(small((40,))), None))
+  add(('dot_vec_2d', lambda sp: sp.dot(sm(sp, (40,)), sm(sp, (40, 60))), lambda: small((40,)).dot(small((40, 60))), None))
   add(('dot_vec_vec', lambda sp: sp.dot(sm(sp, (333,)), sm(sp, (333,))), lambda: np.asarray([small((333,)).dot(small((333,)))]), None))
   add(('dot_tile_hint', lambda sp: sp.dot(sm(sp, (64, 128)), sm(sp, (128, 64)), tile_hint=(8, 64)),
        lambda: small((64, 128)).dot(small((128, 64))), None))

@@ -123,6 +123,19 @@ def _run_merge(backend):
     else:
       mask = backend.to_numpy(t.mask)
     np.testing.assert_array_equal(mask.astype(int), np.asarray(rec['mask']), err_msg=name)
+    # Tile.get: plain values where every cell of the box was written, else values + written-cells mask
+    # (the reference's MaskedArray, tile.pyx:100-113)
+    for rd in rec['reads']:
+      r0, r1, c0, c1 = rd['box']
+      got = t.get(backend, (slice(r0, r1), slice(c0, c1)))
+      assert isinstance(got, tile.MaskedBlob) == rd['masked'], (name, rd['box'])
+      if rd['masked']:
+        host = got.to_host(backend)
+        assert isinstance(host, np.ma.MaskedArray) and host.dtype == np.float32
+        np.testing.assert_array_equal((~np.ma.getmaskarray(host)).astype(int), np.asarray(rd['valid']), err_msg=name)
+        np.testing.assert_array_equal(host.filled(0), np.asarray(rd['values'], np.float32), err_msg=name)
+      else:
+        np.testing.assert_array_equal(backend.to_numpy(got), np.asarray(rd['values'], np.float32), err_msg=name)
 
 
 def test_merge_truth_table_cpu():
