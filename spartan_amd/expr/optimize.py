@@ -1,170 +1,222 @@
-"""DAG optimisation: the fusion passes that turn chains of maps (and a reduce
-over maps) into ONE LocalExpr tree = one HIP kernel per tile.
+"""Rewrites of the expression DAG before it is evaluated.
 
-Mirror of the reference's spartan/expr/operator/optimize.py:107-247
-(`fusable`, `merge_var`, MapMapFusion, ReduceMapFusion,
-CollapsedCachedExpressions) and `optimize` (:1072-1081); the auto-tiling pass
-(:459-1054) lives in expr/tiling.py.  Parakeet generation and slice rotation are
-outside the tile-kernel path.
+What the reference's spartan/expr/operator/optimize.py does for the tile path: chains of element-wise maps -- and a
+reduction over maps -- become ONE LocalExpr tree, i.e. one HIP kernel launch per tile (its MapMapFusion :133-187
+and ReduceMapFusion :190-227); subtrees that were already evaluated are replaced by their values
+(CollapsedCachedExpressions :230-247); slices are pushed below maps so that the maps above them can still fuse
+(RotateSlice :393-456); the tiling of new arrays is chosen (AutomaticTiling, here expr/tiling.py).
+
+Structure here: a rewrite is a `Pass` whose `rules` table maps an expression type to a method that receives the
+node AFTER its dependencies were rewritten and returns its replacement; `Pass.visit` is the memoised bottom-up walk
+(it is also the visitor `Expr.visit` calls back into).  The fused operator of a map is assembled by `_FusedInputs`,
+which keeps one entry per distinct input variable -- the same array reaching a fused tree through two sub-maps is
+read once by the kernel.
+
+The observable results are the reference's, pinned by tests/golden/fusion_golden.json: the fused operator trees
+print identically and have the same inputs.
 """
 import weakref
 
-from .base import AsArray, Expr, ListExpr, Val, expr_like, lazify
+from .base import AsArray, Expr, ListExpr, NotShapeable, Val, expr_like, lazify
 from .local import LocalInput, LocalMapLocationExpr, LocalReduceExpr, make_var
 from .map import MapExpr
 from .ndarray import NdArrayExpr
 from .reduce import ReduceExpr
 from .shuffle import ShuffleExpr
-from ..util import Assert
 
-_not_idempotent_list = set()
+FLAGS = {
+    'optimization': True,
+    'opt_collapse_cached': True,
+    # The reference turns auto-tiling on by default; the golden vectors were recorded with it off (the reference's
+    # solver is a CPython-2 extension that cannot be built here), so it is opt-in.
+    'opt_auto_tiling': False,
+    'opt_rotate_slice': False,        # off by default in the reference as well (optimize.py:1095)
+    'opt_map_fusion': True,
+    'opt_reduce_fusion': True,
+}
 
-FLAGS = {'optimization': True, 'opt_map_fusion': True, 'opt_reduce_fusion': True,
-         'opt_collapse_cached': True,
-         # the reference's default is True; the golden vectors were recorded with it off (its solver is a
-         # CPython-2 extension), so it is opt-in here
-         'opt_auto_tiling': False}
+# Results of builders whose value differs from call to call (rand, ...) must be computed exactly once: such a node
+# is never inlined into a consumer's kernel.  Keyed by expression id, which a rebuilt node keeps (the reference
+# keys its list by id() of the Python object, optimize.py:60-68, so the rebuilt copy of such a map -- a different
+# object -- IS inlined by its consumer there, and a recycled id() can stop an unrelated map from fusing).
+_keep_apart = set()
 
 
 def not_idempotent(fn):
-  """optimize.py:60-68: results of such builders are never fused."""
-  def wrapped(*args, **kw):
-    result = fn(*args, **kw)
-    if isinstance(result, Expr):
-      result.needs_cache = True
-      _not_idempotent_list.add(id(result))
-      # the reference keys this set by id() and never removes entries (optimize.py:60-68): once the expression is
-      # gone its id can be handed to an unrelated one, which would then silently stop fusing -- forget the id with it
-      weakref.finalize(result, _not_idempotent_list.discard, id(result))
-    return result
-  return wrapped
+  def build(*args, **kw):
+    node = fn(*args, **kw)
+    if isinstance(node, Expr):
+      node.needs_cache = True
+      _keep_apart.add(node.expr_id)
+      weakref.finalize(node, _keep_apart.discard, node.expr_id)
+    return node
+  return build
 
 
 def disable_parakeet(fn):
   return fn
 
 
-class OptimizePass(object):
-  """optimize.py:79-104."""
+def _inlinable(node):
+  """A map whose operator tree may be merged into its consumer's."""
+  return isinstance(node, MapExpr) and node.expr_id not in _keep_apart
+
+
+# What may sit under a map that is being fused: other maps are inlined, these are read as inputs.
+_PLAIN_INPUTS = (MapExpr, ReduceExpr, ShuffleExpr, NdArrayExpr, Val, AsArray)
+
+
+class Pass(object):
+  """Memoised bottom-up rewrite.  `rules`: {Expr subclass name: method name}; a rule gets the node with its
+  dependencies already rewritten.  Without a rule the rebuilt node is kept."""
+  name = None
+  rules = {}
 
   def __init__(self):
-    self.visited = {}
+    self._memo = {}
 
-  def visit(self, op):
-    if not isinstance(op, Expr):
-      return op
-    if op.expr_id in self.visited:
-      return self.visited[op.expr_id]
-    if hasattr(self, 'visit_default'):
-      opt_op = self.visit_default(op)
-    elif hasattr(self, 'visit_%s' % op.typename()):
-      opt_op = getattr(self, 'visit_%s' % op.typename())(op)
-    else:
-      opt_op = op.visit(self)
-    self.visited[opt_op.expr_id] = opt_op
-    return opt_op
+  def visit(self, node):
+    if not isinstance(node, Expr):
+      return node
+    done = self._memo.get(node.expr_id)
+    if done is None:
+      done = self.rewrite(node)
+      self._memo[node.expr_id] = done
+    return done
 
-
-def fusable(v):
-  """optimize.py:107-116 (restricted to the node types that exist here)."""
-  return isinstance(v, (MapExpr, ReduceExpr, ShuffleExpr, NdArrayExpr, Val, AsArray))
+  def rewrite(self, node):
+    rebuilt = node.visit(self)                    # same node type and id, rewritten dependencies
+    rule = self.rules.get(type(node).__name__)
+    return getattr(self, rule)(node, rebuilt) if rule else rebuilt
 
 
-def merge_var(children, child_to_var, k, v):
-  """optimize.py:119-130."""
-  try:
-    i = child_to_var.index(k)
-    Assert.eq(v.expr_id if isinstance(v, Expr) else id(v),
-              children[i].expr_id if isinstance(children[i], Expr) else id(children[i]))
-  except ValueError:
-    children.append(v)
-    child_to_var.append(k)
+class _FusedInputs(object):
+  """Inputs of a fused operator: (variable name, array expression) pairs, one per distinct variable."""
+
+  def __init__(self):
+    self.names, self.arrays = [], []
+
+  def take(self, name, array):
+    if name in self.names:
+      held = self.arrays[self.names.index(name)]
+      same = held.expr_id == array.expr_id if isinstance(array, Expr) and isinstance(held, Expr) else held is array
+      assert same, 'variable %s names two different inputs' % name
+      return
+    self.names.append(name)
+    self.arrays.append(array)
+
+  def inline(self, submap, into):
+    """Make `submap`'s operator tree a dependency of `into`; its inputs become ours."""
+    for name, array in zip(submap.child_to_var, submap.children):
+      self.take(name, array)
+    into.add_dep(submap.op)
+
+  def feed(self, array, into):
+    """`array` stays a kernel input under a fresh variable."""
+    name = make_var()
+    self.take(name, array)
+    into.add_dep(LocalInput(idx=name))
 
 
-class MapMapFusion(OptimizePass):
-  """optimize.py:133-187: map(f, map(g, map(h, x))) -> map(f . g . h, x)."""
+class MapMapFusion(Pass):
+  """map(f, map(g, x), y)  ->  map(f(g(.), .), x, y)"""
   name = 'map_fusion'
+  rules = {'MapExpr': 'fuse'}
 
-  def visit_MapExpr(self, expr):
-    map_children = self.visit(expr.children)
-    all_maps = True
-    Assert.isinstance(map_children, ListExpr)
-    for k, v in zip(expr.child_to_var, map_children):
-      if not fusable(v):
-        all_maps = False
-        break
-    if not all_maps or id(expr) in _not_idempotent_list:
-      return expr_like(expr, children=map_children, child_to_var=expr.child_to_var, op=expr.op)
-
-    children = []
-    child_to_var = []
-    combined_op = expr.op.__class__(fn=expr.op.fn, kw=expr.op.kw, pretty_fn=expr.op.pretty_fn)
-    for child_expr in map_children:
-      if isinstance(child_expr, MapExpr) and id(child_expr) not in _not_idempotent_list:
-        for k, v in zip(child_expr.child_to_var, child_expr.children):
-          merge_var(children, child_to_var, k, v)
-        combined_op.add_dep(child_expr.op)
+  def fuse(self, original, node):
+    if original.expr_id in _keep_apart or not all(isinstance(c, _PLAIN_INPUTS) for c in node.children):
+      return node
+    op = type(node.op)(fn=node.op.fn, kw=node.op.kw, pretty_fn=node.op.pretty_fn)
+    inputs = _FusedInputs()
+    for child in node.children:
+      if _inlinable(child):
+        inputs.inline(child, op)
       else:
-        children.append(child_expr)
-        key = make_var()
-        combined_op.add_dep(LocalInput(idx=key))
-        child_to_var.append(key)
-    if isinstance(combined_op, LocalMapLocationExpr):
-      combined_op.add_dep(LocalInput(idx='extent'))
-    return expr_like(expr, children=ListExpr(vals=children), child_to_var=child_to_var, op=combined_op)
+        inputs.feed(child, op)
+    if isinstance(op, LocalMapLocationExpr):
+      op.add_dep(LocalInput(idx='extent'))        # the tile's position is the operator's last argument
+    return expr_like(node, children=ListExpr(vals=inputs.arrays), child_to_var=inputs.names, op=op)
 
 
-class ReduceMapFusion(OptimizePass):
-  """optimize.py:190-227: reduce(f, map(g, X)) -> reduce(f . g, X)."""
+class ReduceMapFusion(Pass):
+  """reduce(f, map(g, x))  ->  reduce(f(g(.)), x): the map runs in the reduction kernel's prologue."""
   name = 'reduce_fusion'
+  rules = {'ReduceExpr': 'fuse'}
 
-  def visit_ReduceExpr(self, expr):
-    Assert.isinstance(expr.children, ListExpr)
-    old_children = self.visit(expr.children)
-    for v in old_children:
-      if not isinstance(v, MapExpr) or id(v) in _not_idempotent_list:
-        return expr_like(expr, children=old_children, child_to_var=expr.child_to_var, axis=expr.axis,
-                         dtype_fn=expr.dtype_fn, op=expr.op, accumulate_fn=expr.accumulate_fn,
-                         tile_hint=expr.tile_hint)
-    combined_op = LocalReduceExpr(fn=expr.op.fn, kw=expr.op.kw, deps=[expr.op.deps[0]])
-    new_children = []
-    new_child_to_var = []
-    for i in range(len(old_children)):
-      child_expr = old_children[i]
-      for j in range(len(child_expr.children)):
-        k = child_expr.child_to_var[j]
-        v = child_expr.children[j]
-        merge_var(new_children, new_child_to_var, k, v)
-      combined_op.add_dep(child_expr.op)
-    # NB: like the reference (reduce.py:110) dtype_fn is afterwards applied to the
-    # fused map's FIRST INPUT, so the output dtype follows that input.
-    return expr_like(expr, children=ListExpr(vals=new_children), child_to_var=new_child_to_var,
-                     axis=expr.axis, dtype_fn=expr.dtype_fn, accumulate_fn=expr.accumulate_fn,
-                     op=combined_op, tile_hint=expr.tile_hint)
+  def fuse(self, original, node):
+    if not all(_inlinable(c) for c in node.children):
+      return node
+    op = LocalReduceExpr(fn=node.op.fn, kw=node.op.kw, deps=[node.op.deps[0]])
+    inputs = _FusedInputs()
+    for child in node.children:
+      inputs.inline(child, op)
+    # (as in the reference, reduce.py:110, dtype_fn is afterwards applied to the fused tree's FIRST input)
+    return expr_like(node, children=ListExpr(vals=inputs.arrays), child_to_var=inputs.names, op=op, axis=node.axis,
+                     dtype_fn=node.dtype_fn, accumulate_fn=node.accumulate_fn, tile_hint=node.tile_hint)
 
 
-class CollapsedCachedExpressions(OptimizePass):
-  """optimize.py:230-247: replace already-evaluated subtrees by their value."""
+class CollapsedCachedExpressions(Pass):
+  """A subtree whose value already exists is replaced by that value."""
   name = 'collapse_cached'
 
-  def visit_default(self, expr):
-    cache = expr.cache()
-    if cache is not None:
-      return lazify(cache)
-    return expr.visit(self)
+  def rewrite(self, node):
+    value = node.cache()
+    return lazify(value) if value is not None else node.visit(self)
+
+
+class RotateSlice(Pass):
+  """(a + b)[idx]  ->  a'[idx] + b'[idx], with a', b' = a, b seen in the map's shape: a slice ABOVE a map is pushed
+  onto the map's inputs, recursively through chains of maps, so that the slice ends up on the arrays and the maps
+  above it are adjacent again and fuse into one kernel over the SLICED extent only."""
+  name = 'rotate_slice'
+
+  def rewrite(self, node):
+    from .views import SliceExpr
+    if not isinstance(node, SliceExpr) or not isinstance(node.src, MapExpr):
+      return node.visit(self)
+    return self.push(node.src, node.idx)
+
+  def push(self, mapped, idx):
+    """`mapped[idx]` as a map over sliced inputs."""
+    from .views import SliceExpr
+    try:
+      shape = mapped.compute_shape()
+    except NotShapeable:
+      return SliceExpr(src=self.visit(mapped), idx=idx, broadcast_to=None)
+    sliced = []
+    for child in mapped.children:
+      if isinstance(child, MapExpr):
+        sliced.append(self.push_through_broadcast(child, idx, shape))
+      else:
+        sliced.append(SliceExpr(src=self.visit(child), idx=idx, broadcast_to=shape))
+    # always a NEW node: it has the slice's shape, not the map's, so neither the map's id (its cached value)
+    # nor its shape cache may be carried over (the reference re-uses the id for the first slice of a map)
+    return MapExpr(children=ListExpr(vals=sliced), child_to_var=list(mapped.child_to_var), op=mapped.op)
+
+  def push_through_broadcast(self, child_map, idx, shape):
+    """A map under the sliced map: slice it further down when it already has the parent's shape; a map that is
+    broadcast by its parent keeps its own extent and is sliced as a whole (through the broadcast)."""
+    from .views import SliceExpr
+    try:
+      same = tuple(child_map.compute_shape()) == tuple(shape)
+    except NotShapeable:
+      same = False
+    if same:
+      return self.push(child_map, idx)
+    return SliceExpr(src=self.visit(child_map), idx=idx, broadcast_to=shape)
+
+
+def _passes():
+  from .tiling import AutomaticTiling   # (imports this module)
+  return (('opt_collapse_cached', CollapsedCachedExpressions), ('opt_auto_tiling', AutomaticTiling),
+          ('opt_rotate_slice', RotateSlice), ('opt_map_fusion', MapMapFusion), ('opt_reduce_fusion', ReduceMapFusion))
 
 
 def optimize(dag):
-  """optimize.py:1072-1099 (pass order: collapse cached, map fusion, reduce fusion)."""
+  """Apply the enabled passes in the reference's order (optimize.py:1093-1099)."""
   if not FLAGS['optimization']:
     return dag
-  if FLAGS['opt_collapse_cached']:
-    dag = CollapsedCachedExpressions().visit(dag)
-  if FLAGS['opt_auto_tiling']:            # optimize.py:1094: after the cached-value collapse, before the fusions
-    from .tiling import AutomaticTiling
-    dag = AutomaticTiling().visit(dag)
-  if FLAGS['opt_map_fusion']:
-    dag = MapMapFusion().visit(dag)
-  if FLAGS['opt_reduce_fusion']:
-    dag = ReduceMapFusion().visit(dag)
+  for flag, factory in _passes():
+    if FLAGS[flag]:
+      dag = factory().visit(dag)
   return dag

@@ -87,3 +87,32 @@ def test_pass_through_mapper_does_not_alias_its_input():
     np.testing.assert_array_equal(X.glom(), x)          # the input is untouched
   finally:
     sp.shutdown()
+
+
+def test_rotate_slice_pushes_slices_below_maps():
+  """(a + b * 2)[rows, cols] with the slice-rotation pass on: the slice lands on the arrays (the broadcast operand
+  through its stretched view), the maps above it fuse into ONE map over the sliced extent, values are NumPy's."""
+  import importlib
+  import spartan_amd as sp
+  from oracle.np_backend import NumpyBackend
+  from spartan_amd.expr.map import MapExpr
+  from spartan_amd.expr.views import SliceExpr
+  opt = importlib.import_module('spartan_amd.expr.optimize')
+  a = np.arange(40 * 30, dtype=np.float32).reshape(40, 30) % 11
+  b = np.arange(30, dtype=np.float32).reshape(1, 30) - 7
+  sp.initialize(backend=NumpyBackend(), num_workers=3)
+  opt.FLAGS['opt_rotate_slice'] = True
+  try:
+    A, B = sp.from_numpy(a).force(), sp.from_numpy(b).force()
+    whole = sp.Val(val=A) + sp.Val(val=B) * 2
+    for idx in ((slice(5, 25), slice(3, 17)), (slice(0, 40), slice(29, 30)), slice(7, 8)):
+      e = whole[idx]
+      o = e.optimized()
+      assert isinstance(o, MapExpr) and all(isinstance(c, SliceExpr) for c in o.children), o
+      np.testing.assert_array_equal(o.glom(), (a + b * 2)[idx])
+    # a map consumed whole AND sliced keeps its own value
+    np.testing.assert_array_equal(whole.optimized().glom(), a + b * 2)
+    np.testing.assert_array_equal((whole[2:4] - whole[3:5]).optimized().glom(), (a + b * 2)[2:4] - (a + b * 2)[3:5])
+  finally:
+    opt.FLAGS['opt_rotate_slice'] = False
+    sp.shutdown()
