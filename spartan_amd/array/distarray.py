@@ -743,17 +743,18 @@ DistArrayImpl._invoke_mapper = _invoke_default
 
 
 def create(shape, dtype=float, sharder=None, reducer=None, tile_hint=None, sparse=False):
-  """distarray.py:425-487 (round_robin tile assignment, the default)."""
+  """A new, empty array: cut into tiles (compute_extents), each tile given to a worker by the tile-assignment
+  policy (array/placement.py; reference distarray.py:425-487)."""
+  from . import placement
   ctx = context.get()
   dtype = np.dtype(dtype)
   shape = tuple(int(s) for s in shape)
   if sparse:
     Assert.eq(len(shape), 2, 'sparse arrays are two-dimensional')
   ttype = tile.TYPE_SPARSE if sparse else tile.TYPE_DENSE
-  extents = compute_extents(shape, tile_hint, ctx.num_workers)
+  cut = list(compute_extents(shape, tile_hint, ctx.num_workers).items())
   tiles = collections.OrderedDict()
-  for ex, i in extents.items():
-    worker = i % ctx.num_workers
+  for (ex, _), worker in zip(cut, placement.place(cut, ctx)):
     t = tile.from_shape(ex.shape, dtype, ttype) if ctx.is_local_worker(worker) else None
     tiles[ex] = ctx.create(t, hint=worker)
   return DistArrayImpl(shape=shape, dtype=dtype, tiles=tiles, reducer_fn=reducer, sparse=bool(sparse))

@@ -150,6 +150,18 @@ class Context(object):
             array.bad_tiles.append(ex)
           self._blobs.pop(tile_id, None)
 
+  def worker_scores(self):
+    """[(worker, bytes of live tiles it holds)], least loaded first (ties: lower id) -- the ranking behind the
+    'performance' tile assignment (reference: master.get_worker_scores, from the workers' status reports).
+    Computed from array metadata, which every rank holds identically."""
+    held = [0] * self.num_workers
+    for array in list(self._arrays):
+      item = np.dtype(array.dtype).itemsize
+      for ex, tile_id in array.tiles.items():
+        if 0 <= tile_id.worker < self.num_workers:
+          held[tile_id.worker] += item * int(np.prod(ex.shape, dtype=np.int64))
+    return sorted(enumerate(held), key=lambda kv: (kv[1], kv[0]))
+
   def get_workers_for_reload(self, array):
     """master.py:110-121: spread an array's bad tiles over the workers, least loaded first."""
     load = [[w, 0] for w in range(self.num_workers)]

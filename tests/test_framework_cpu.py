@@ -116,3 +116,52 @@ def test_rotate_slice_pushes_slices_below_maps():
   finally:
     opt.FLAGS['opt_rotate_slice'] = False
     sp.shutdown()
+
+
+def test_tile_assignment_strategies(tmp_path, monkeypatch):
+  """The reference's five tile-assignment policies (distarray.py:441-476): where the tiles go, and that results
+  do not depend on it."""
+  import spartan_amd as sp
+  from oracle.np_backend import NumpyBackend
+  from spartan_amd.array import placement
+  a = np.arange(96 * 8, dtype=np.float32).reshape(96, 8)
+
+  def workers_of(strategy, hint=(8, 8)):
+    monkeypatch.setattr(placement, 'STRATEGY', strategy)
+    sp.initialize(backend=NumpyBackend(), num_workers=4)
+    try:
+      X = sp.from_numpy(a, tile_hint=hint).force()
+      np.testing.assert_array_equal((sp.Val(val=X) * 2).glom(), a * 2)
+      np.testing.assert_array_equal(sp.sum(sp.Val(val=X), 0).glom(), a.sum(0))
+      return [tid.worker for ex, tid in sorted(X.tiles.items(), key=lambda kv: kv[0].ul)]
+    finally:
+      sp.shutdown()
+  assert workers_of('round_robin') == [0, 1, 2, 3] * 3
+  assert workers_of('serpentine') == [0, 1, 2, 3, 3, 2, 1, 0, 0, 1, 2, 3]
+  mapping = tmp_path / 'tiles_map'
+  mapping.write_text('\n'.join(str(w) for w in [3, 3, 2, 2, 1, 1, 0, 0, 3, 2, 1, 0]) + '\n')
+  monkeypatch.setenv('SPARTAN_TILES_MAP', str(mapping))
+  assert workers_of('static') == [3, 3, 2, 2, 1, 1, 0, 0, 3, 2, 1, 0]
+  placement.seed(5)
+  first = workers_of('random')
+  placement.seed(5)
+  assert workers_of('random') == first and set(first) <= {0, 1, 2, 3} and len(set(first)) > 1
+  # 'performance': the least loaded workers first -- worker 0 already holds a big array
+  monkeypatch.setattr(placement, 'STRATEGY', 'performance')
+  sp.initialize(backend=NumpyBackend(), num_workers=4)
+  try:
+    big = sp.from_numpy(np.zeros((64, 64), np.float32), tile_hint=(64, 64)).force()      # one tile, on worker 0
+    assert [t.worker for t in big.tiles.values()] == [0]
+    X = sp.from_numpy(a, tile_hint=(24, 8)).force()                                    # 4 tiles
+    got = [tid.worker for ex, tid in sorted(X.tiles.items(), key=lambda kv: kv[0].ul)]
+    assert got[-1] == 0 and sorted(got) == [0, 1, 2, 3], got
+    np.testing.assert_array_equal(X.glom(), a)
+  finally:
+    sp.shutdown()
+  monkeypatch.setattr(placement, 'STRATEGY', 'no_such_policy')
+  sp.initialize(backend=NumpyBackend(), num_workers=2)
+  try:
+    with pytest.raises(ValueError):
+      sp.from_numpy(a).force()
+  finally:
+    sp.shutdown()
