@@ -110,6 +110,11 @@ def initialize(backend='hip', num_workers=None, world=None):
 
 
 def shutdown():
+  if _context.initialized():
+    ctx = _context.get()
+    if ctx.heartbeat is not None:
+      ctx.heartbeat.stop()
+      ctx.heartbeat = None
   _context.set(None)
 
 

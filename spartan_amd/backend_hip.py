@@ -770,3 +770,17 @@ class HipBackend(object):
 
   def synchronize(self):
     torch.cuda.synchronize(self.device)
+
+  def liveness_probe(self, timeout_s=2.0):
+    """One round trip through the device on a stream of its own (heartbeat.py): False if it does not come back."""
+    import time
+    if getattr(self, '_probe_stream', None) is None:
+      self._probe_stream = torch.cuda.Stream(device=self.device)
+    ev = torch.cuda.Event()
+    ev.record(self._probe_stream)
+    deadline = time.time() + timeout_s
+    while not ev.query():
+      if time.time() > deadline:
+        return False
+      time.sleep(0.001)
+    return True

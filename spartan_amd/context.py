@@ -17,6 +17,7 @@ spartan/worker.py) for a static world of one process per GPU:
     processed and must launch kernels; the other ranks only take part in the
     transfers the mapper implies.
 """
+import builtins
 import collections
 import contextlib
 import weakref
@@ -71,6 +72,8 @@ class Context(object):
     self.fetch_cache = None                           # whole-array fetches shared inside one kernel
     self.pending_destructors = []                     # tiles of dead arrays (distarray.py:219-268)
     self._arrays = weakref.WeakSet()                  # live DistArrays (master.py:103-104 register_array)
+    self.heartbeat = None                             # failure detection (heartbeat.py), off unless started
+    self.failed_workers = builtins.set()              # (this module defines its own `set`)
 
   # -- placement --------------------------------------------------------------
   def rank_of(self, worker):
@@ -137,12 +140,39 @@ class Context(object):
   def register_array(self, array):
     self._arrays.add(array)
 
+  def start_heartbeat(self, interval=3.0, threshold=10, **kw):
+    """Start failure detection (master.py:142-146 / worker.py:347-368): see heartbeat.py."""
+    from . import heartbeat
+    if self.heartbeat is not None:
+      self.heartbeat.stop()
+    self.heartbeat = heartbeat.Heartbeat(self, interval, threshold, **kw).start()
+    return self.heartbeat
+
+  def apply_failures(self):
+    """Safe point of the driver thread: every logical worker of a rank the heartbeat declared silent is marked
+    failed (its tiles become bad tiles of their arrays).  Returns the workers marked now."""
+    if self.heartbeat is None:
+      return []
+    silent = self.heartbeat.take_failures()
+    if self.world.distributed:
+      # every rank watches on its own clock: take the union, so that all of them change their tile tables at
+      # the same point of the (SPMD) driver program
+      silent = sorted(builtins.set(r for part in self.world.all_gather_object(sorted(silent)) for r in part))
+    marked = []
+    for rank in silent:
+      for w in range(self.num_workers):
+        if self.rank_of(w) == rank and w not in self.failed_workers:
+          self.mark_failed_worker(w)
+          marked.append(w)
+    return marked
+
   def mark_failed_worker(self, worker_id):
     """master.py:134-140: every tile the worker held is recorded as bad in the array that owns it.  The GPU
     counterpart of a dead worker is a device that was reset: the rank is still there, its HBM contents are not --
     so the blobs are dropped here as well and the worker stays available for the reload / recompute that follows
     (Expr.cache() -> load_data, base.py:193-203: a checkpointed expression reloads the bad tiles from disk, any
     other is evaluated again from its dependencies)."""
+    self.failed_workers.add(worker_id)
     for array in list(self._arrays):
       for ex, tile_id in array.tiles.items():
         if tile_id.worker == worker_id:

@@ -121,10 +121,12 @@ class Expr(object):
 
   def evaluate(self):
     """base.py:272-313: dependencies first, then `_evaluate`, then cache."""
+    ctx = context.get()
+    if ctx.heartbeat is not None and ctx.current_worker is None:
+      ctx.apply_failures()          # safe point: workers the heartbeat declared silent lose their tiles here
     cache = self.cache()
     if cache is not None:
       return cache
-    ctx = context.get()
     deps = {}
     for k, vs in self.dependencies().items():
       if isinstance(vs, Expr):

@@ -1,0 +1,128 @@
+"""Failure detection: who is still there.
+
+The reference's workers report to the master every `heartbeat_interval` seconds (spartan/worker.py:347-368) and the
+master declares a worker failed once its last report is older than `heartbeat_interval *
+worker_failed_heartbeat_threshold` (spartan/master.py:142-146), recording every tile it held as bad
+(master.py:134-140); cached values with bad tiles are then reloaded from a checkpoint or recomputed
+(spartan/expr/operator/base.py:193-203).
+
+Here a worker is a GPU driven by one process, and "alive" means that GPU still completes work: the beat of a rank
+is a round trip through its device (an event recorded on a stream of its own and waited for -- a hung or reset GPU
+stops the beats even if the process lives).  Beats are counters in a key-value store every rank can read: the
+rendezvous store of torch.distributed when there are several ranks, a dictionary for one process.  Every rank
+watches every other rank, so all of them reach the same verdict without a master; a verdict is QUEUED and applied by
+the driver thread at its next safe point (`Context.apply_failures`, called when an expression starts to evaluate) --
+tile tables are never touched from the watcher thread.  Applying it is `Context.mark_failed_worker` for each logical
+worker of the silent rank.
+"""
+import threading
+import time
+
+
+class _LocalStore(object):
+  def __init__(self):
+    self._d = {}
+    self._lock = threading.Lock()
+
+  def set(self, key, value):
+    with self._lock:
+      self._d[key] = value
+
+  def get(self, key):
+    with self._lock:
+      return self._d.get(key)
+
+
+class _DistStore(object):
+  """The process group's rendezvous store (TCPStore); reads of a key that was never set must not block."""
+
+  def __init__(self):
+    import torch.distributed as dist
+    self._store = dist.distributed_c10d._get_default_store()
+
+  def set(self, key, value):
+    self._store.set(key, value)
+
+  def get(self, key):
+    if not self._store.check([key]):
+      return None
+    return self._store.get(key).decode()
+
+
+class Heartbeat(object):
+  """interval: seconds between beats; threshold: missed beats after which a rank is declared failed
+  (reference flags heartbeat_interval = 3, worker_failed_heartbeat_threshold = 10, spartan/cluster.py:62-63)."""
+
+  def __init__(self, ctx, interval=3.0, threshold=10, probe=None, store=None):
+    self.ctx = ctx
+    self.interval = float(interval)
+    self.threshold = int(threshold)
+    self.rank, self.size = ctx.world.rank, ctx.world.size
+    self.store = store if store is not None else (_DistStore() if ctx.world.distributed else _LocalStore())
+    self.probe = probe if probe is not None else getattr(ctx.backend, 'liveness_probe', lambda: True)
+    self.failed_ranks = set()
+    self._pending = []
+    self._lock = threading.Lock()
+    self._stop = threading.Event()
+    self._paused = threading.Event()          # tests: a rank that stops reporting
+    self._seen = {}                           # rank -> (last counter value, time it changed)
+    self._threads = []
+
+  # -- the two loops --------------------------------------------------------------------------------------
+  def _beat_loop(self):
+    beats = 0
+    while not self._stop.is_set():
+      if not self._paused.is_set():
+        try:
+          alive = self.probe()
+        except Exception:
+          alive = False
+        if alive:
+          beats += 1
+          self.store.set('spartan_hb/%d' % self.rank, str(beats))
+      self._stop.wait(self.interval)
+
+  def _watch_loop(self):
+    limit = self.interval * self.threshold
+    while not self._stop.is_set():
+      now = time.time()
+      for r in range(self.size):
+        if r in self.failed_ranks:
+          continue
+        try:
+          value = self.store.get('spartan_hb/%d' % r)
+        except Exception:
+          value = None
+        last = self._seen.get(r)
+        if last is None or (value is not None and value != last[0]):
+          self._seen[r] = (value, now)
+        elif now - last[1] > limit:
+          self.failed_ranks.add(r)
+          with self._lock:
+            self._pending.append(r)
+      self._stop.wait(min(self.interval, 1.0))
+
+  # -- control --------------------------------------------------------------------------------------------
+  def start(self):
+    for fn in (self._beat_loop, self._watch_loop):
+      t = threading.Thread(target=fn, daemon=True)
+      t.start()
+      self._threads.append(t)
+    return self
+
+  def stop(self):
+    self._stop.set()
+    for t in self._threads:
+      t.join(timeout=2 * self.interval + 1)
+
+  def pause(self):
+    self._paused.set()
+
+  def resume(self):
+    self._paused.clear()
+
+  def take_failures(self):
+    """Ranks declared failed since the last call (driver thread)."""
+    with self._lock:
+      out, self._pending = self._pending, []
+    return out

@@ -99,6 +99,32 @@ def run_auto_tiling(world):
   return 1
 
 
+def run_heartbeat(world):
+  """Two ranks: rank 1 stops reporting; BOTH ranks mark its workers failed at the same safe point (the watchers
+  agree through the control plane), and a cached value is recomputed on the survivors' tiles and rank 1's."""
+  import time
+  ctx = sp.get_context()
+  hb = ctx.start_heartbeat(interval=0.05, threshold=4, probe=lambda: True)
+  a = np.ones((16, 4), np.float32)
+  e = sp.ones((16, 4)) + 3             # (a value with lineage: it can be computed again)
+  first = e.evaluate()
+  world.barrier()
+  if world.rank == 1:
+    hb.pause()
+  deadline = time.time() + 10
+  while 1 not in hb.failed_ranks and world.rank == 0 and time.time() < deadline:
+    time.sleep(0.02)
+  world.barrier()                      # rank 0 has seen it; rank 1 may or may not have: the union decides
+  second = (e * 1).evaluate()
+  mine = sorted(w for w in range(ctx.num_workers) if ctx.rank_of(w) == 1)
+  assert sorted(ctx.failed_workers) == mine, (ctx.failed_workers, mine)
+  assert len(first.bad_tiles) == sum(1 for t in first.tiles.values() if ctx.rank_of(t.worker) == 1)
+  np.testing.assert_array_equal(second.glom(), a + 3)
+  hb.stop()
+  ctx.heartbeat = None
+  return 1
+
+
 def run_sort(workers):
   """sort / argsort along an axis and the sample sort (axis=None) with tiles on both ranks."""
   rng = np.random.RandomState(5)
@@ -192,6 +218,8 @@ def main():
   n += run_sparse(workers)
   n += run_auto_tiling(world)
   n += run_sort(workers)
+  if not use_hip:
+    n += run_heartbeat(world)
   world.barrier()
   print('RANK %d OK %d' % (world.rank, n))
   sys.stdout.flush()

@@ -175,3 +175,32 @@ def test_failed_worker_reload_and_recompute_cpu():
 def test_failed_worker_reload_and_recompute_gpu():
   from spartan_amd.backend_hip import HipBackend
   _failed_worker(HipBackend)
+
+
+def test_heartbeat_marks_a_silent_worker_failed_and_the_value_is_recomputed():
+  """Failure DETECTION (master.py:142-146, worker.py:347-368): the device stops answering the heartbeat's probe,
+  the watcher declares the rank failed after `threshold` missed beats, the driver's next evaluation applies it --
+  the workers' tiles become bad tiles -- and the cached value is recomputed from its dependencies."""
+  import time
+  from oracle.np_backend import NumpyBackend
+  sp.initialize(backend=NumpyBackend(), num_workers=3)
+  try:
+    ctx = sp.get_context()
+    alive = {'ok': True}
+    hb = ctx.start_heartbeat(interval=0.05, threshold=3, probe=lambda: alive['ok'])
+    a = np.ones((12, 5), np.float32)
+    e = sp.ones((12, 5)) * 2 + 1          # (a value with lineage: builders can be re-run, loaded data cannot)
+    first = e.evaluate()
+    time.sleep(0.4)
+    assert ctx.apply_failures() == [] and not first.bad_tiles          # beating: nobody is marked
+    alive['ok'] = False                                                 # the "GPU" hangs
+    deadline = time.time() + 5
+    while not hb.failed_ranks and time.time() < deadline:
+      time.sleep(0.02)
+    assert hb.failed_ranks == {0}
+    assert not first.bad_tiles                                          # nothing changes behind the driver's back
+    second = (e + 0).evaluate()                                         # safe point: failures are applied here
+    assert ctx.failed_workers == {0, 1, 2} and len(first.bad_tiles) == len(first.tiles)
+    np.testing.assert_array_equal(second.glom(), a * 2 + 1)            # e was recomputed, not read from dead tiles
+  finally:
+    sp.shutdown()
