@@ -157,14 +157,51 @@ class HipBackend(object):
     for a in v.args:
       self._prepare(a)
 
+  def _carve(self, root):
+    """The lowered tree does not fit one kernel (operands / registers / instructions, include/spartan_hip.h
+    SP_MAX_INPUTS, SP_NREG, SP_MAX_INSTR): run the largest proper sub-expression that certainly fits as a launch
+    of its own and put its result in its place.  Every call removes at least one operator, so repeated carving
+    ends with a tree that fits.  Returns False when nothing can be carved (a single operator over leaves)."""
+    best = [None, 0]            # (parent, index in parent.args), operators in the subtree
+
+    def survey(v, parent, idx):
+      """(operators, distinct tensor operands) of the subtree; remembers the biggest fitting proper subtree."""
+      if v.kind != 'op':
+        # (a position-dependent leaf belongs to the index space of the WHOLE program: never carved off)
+        return 0, ({id(v.tensor)} if v.kind == 'tensor' else ({'iota'} if v.kind == 'iota' else set()))
+      ops, tensors = 1, set()
+      for i, a in enumerate(v.args):
+        o, t = survey(a, v, i)
+        ops += o
+        tensors |= t
+      # conservative bounds: every operator may need a result register and a dtype normalisation
+      fits = 'iota' not in tensors and len(tensors) <= 4 and 2 * ops + len(tensors) <= 24
+      if parent is not None and fits and v.op not in ('FILL',) and ops > best[1]:
+        best[0], best[1] = (parent, idx), ops
+      return ops, tensors
+    survey(root, None, 0)
+    if best[0] is None:
+      return False
+    parent, idx = best[0]
+    sub = parent.args[idx]
+    piece = self._run_map(sub, sub.shape, sub.dtype)
+    parent.args[idx] = lower.V('tensor', dtype=sub.dtype, shape=sub.shape, tensor=piece)
+    return True
+
   def _run_map(self, root, out_shape, out_dtype=None):
     self._prepare(root)
     if root.kind == 'const':
       root = lower.V('op', dtype=root.dtype, shape=(), op='FILL', args=[root])
     out_dtype = np.dtype(out_dtype or root.dtype)
-    cls = lower.choose_class(root, [class_of(out_dtype)] if out_dtype != np.bool_ else [])
-    em = lower.Emitter(cls, out_shape, self.contiguous)
-    prog, tensors = em.finish(root, out_dtype)
+    while True:
+      cls = lower.choose_class(root, [class_of(out_dtype)] if out_dtype != np.bool_ else [])
+      em = lower.Emitter(cls, out_shape, self.contiguous)
+      try:
+        prog, tensors = em.finish(root, out_dtype)
+        break
+      except ProgramTooLarge:
+        if not self._carve(root):
+          raise
     out = self.empty(out_shape, out_dtype)
     if out.numel():
       self.launches += 1

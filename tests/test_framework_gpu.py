@@ -84,3 +84,32 @@ def test_planted_argmax_across_tiles(ctx):
   np.testing.assert_array_equal(sp.argmax(dx, 0).glom(), np.argmax(x, 0))
   np.testing.assert_array_equal(sp.argmax(dx, 1).glom(), np.argmax(x, 1))
   np.testing.assert_array_equal(sp.argmin(dx, 0).glom(), np.argmin(x, 0))
+
+
+@pytest.mark.gpu
+def test_trees_larger_than_one_kernel_are_carved_into_several_launches():
+  """More operands than a kernel has input slots, and more operators than a program has instructions
+  (include/spartan_hip.h SP_MAX_INPUTS = 8, SP_MAX_INSTR = 64): the lowered tree is cut into launches instead of
+  being refused -- results are NumPy's, bit for bit on integer-valued data."""
+  ctx = sp.initialize('hip', num_workers=2)
+  try:
+    rng = np.random.RandomState(3)
+    arrays = [rng.randint(-4, 5, size=(64, 48)).astype(np.float32) for _ in range(12)]
+    exprs = [sp.from_numpy(a) for a in arrays]
+
+    def many(*t):                      # ONE local function over 12 tiles (no sub-maps to split at)
+      return (t[0] + t[1]) * t[2] - t[3] * t[4] + t[5] - (t[6] + t[7] * t[8]) * t[9] + t[10] * t[11]
+    got = sp.map(exprs, many).optimized().glom()
+    np.testing.assert_array_equal(got, many(*arrays))
+    before = ctx.backend.launches
+    x = sp.from_numpy(arrays[0])
+    e = x
+    want = arrays[0].copy()
+    for i in range(1, 50):             # 98 operators in one fused tree, values stay small integers
+      e = (e + (i % 7)) - (i % 3)
+      want = (want + np.float32(i % 7)) - np.float32(i % 3)
+    got = e.optimized().glom()
+    np.testing.assert_array_equal(got, want)
+    assert ctx.backend.launches - before > 2 * 2        # more than one launch per tile
+  finally:
+    sp.shutdown()
