@@ -1,22 +1,31 @@
-"""Expr: the lazy-DAG node base class, the evaluation cache and the collection
-nodes.  Mirror of the reference's spartan/expr/operator/base.py (same names and
-evaluate/cache/optimized/glom semantics); `force()` is the alias of `evaluate()`
-that README.md:64-65 promises.
+"""Nodes of the lazy expression DAG, the value cache, and the containers that hold several nodes.
+
+API of the reference's spartan/expr/operator/base.py: `Expr` with evaluate / optimized / glom / shape / cache, the
+`Val` / `AsArray` leaves, `ListExpr` / `TupleExpr` / `DictExpr`, `expr_like`, and the module functions `evaluate`,
+`eager`, `glom`, `lazify`, `as_array`.  `force()` is `evaluate()` (README.md:64-65 of the reference calls the act
+of evaluating "forcing").
+
+How a node works here:
+  * a subclass lists its fields in `members`; the constructor takes exactly those as keywords;
+  * `dependencies()` says which fields hold sub-expressions -- `evaluate()` evaluates them first, hands the results
+    to `_evaluate(ctx, deps)` and remembers the value in `eval_cache` under the node's `expr_id`;
+  * `visit(visitor)` rebuilds the node from visited fields with THE SAME id (`expr_like`): a rewritten DAG finds
+    the values its unrewritten twin already computed;
+  * a cached value that lost tiles to a failed worker does not count (`cache()` -> `load_data()`), so the node is
+    evaluated again -- or re-read, for a checkpoint.
 """
-import collections
 import itertools
 
 import numpy as np
 
 from .. import context
 from ..array import distarray
-from ..util import Assert
 
 unique_id = itertools.count()
 
 
 class NotShapeable(Exception):
-  """base.py:30-34."""
+  """The shape of this node is only known once it has been evaluated."""
 
 
 class newaxis(object):
@@ -24,53 +33,53 @@ class newaxis(object):
 
 
 class EvalCache(object):
-  """base.py:73-114: results keyed by expression id, manually refcounted."""
+  """Values of evaluated nodes by expression id.  An id may be shared by several node objects (a node and its
+  rewritten copies): the value goes away when the last of them does."""
 
   def __init__(self):
-    self.refs = collections.defaultdict(int)
-    self.cache = {}
+    self._holders = {}     # expr id -> number of live node objects carrying it
+    self._values = {}
 
-  def set(self, exprid, value):
-    self.cache[exprid] = value
-
-  def get(self, exprid):
-    return self.cache.get(exprid, None)
-
-  def register(self, exprid):
-    self.refs[exprid] += 1
+  def register(self, expr_id):
+    self._holders[expr_id] = self._holders.get(expr_id, 0) + 1
 
   def deregister(self, expr_id):
-    self.refs[expr_id] -= 1
-    if self.refs[expr_id] == 0:
-      if expr_id in self.cache:
-        del self.cache[expr_id]
-      del self.refs[expr_id]
+    left = self._holders.get(expr_id, 0) - 1
+    if left > 0:
+      self._holders[expr_id] = left
+    else:
+      self._holders.pop(expr_id, None)
+      self._values.pop(expr_id, None)
+
+  def set(self, expr_id, value):
+    self._values[expr_id] = value
+
+  def get(self, expr_id):
+    return self._values.get(expr_id)
 
   def clear(self):
-    self.refs.clear()
-    self.cache.clear()
+    self._holders.clear()
+    self._values.clear()
 
 
 eval_cache = EvalCache()
 
 
-def expr_like(expr, **kw):
-  """base.py:51-69: same expression id (so cache entries carry over)."""
-  kw['expr_id'] = expr.expr_id
-  kw['shape_cache'] = expr.shape_cache
-  return expr.__class__(**kw)
+def expr_like(expr, **fields):
+  """A node of `expr`'s type built from `fields`, with expr's id and shape cache."""
+  return type(expr)(expr_id=expr.expr_id, shape_cache=expr.shape_cache, **fields)
 
 
 class Expr(object):
-  """base.py:163-505.  Subclasses list their dependency fields in `members`."""
   members = ()
   needs_cache = True
 
-  def __init__(self, expr_id=None, shape_cache=None, **kw):
-    for k in self.members:
-      setattr(self, k, kw.pop(k, None))
-    if kw:
-      raise TypeError('%s: unexpected fields %s' % (type(self).__name__, list(kw)))
+  def __init__(self, expr_id=None, shape_cache=None, **fields):
+    unknown = set(fields) - set(self.members)
+    if unknown:
+      raise TypeError('%s: unexpected fields %s' % (type(self).__name__, sorted(unknown)))
+    for name in self.members:
+      setattr(self, name, fields.get(name))
     self.expr_id = next(unique_id) if expr_id is None else expr_id
     self.shape_cache = shape_cache
     self.optimized_expr = None
@@ -79,109 +88,81 @@ class Expr(object):
   def __del__(self):
     try:
       eval_cache.deregister(self.expr_id)
-    except Exception:
+    except Exception:      # interpreter shutdown
       pass
 
-  @property
-  def ndim(self):
-    return len(self.shape)
-
-  def cache(self):
-    """base.py:193-203."""
-    result = eval_cache.get(self.expr_id)
-    if result is not None and len(getattr(result, 'bad_tiles', ())) == 0:
-      return result
-    return self.load_data(result)
-
-  def load_data(self, cached_result):
-    """base.py:189-191: nothing to reload -- an expression whose cached value lost tiles is evaluated again from
-    its dependencies (CheckpointExpr overrides this with a reload from disk)."""
-    return None
-
+  # -- structure ---------------------------------------------------------------------------------------------
   def dependencies(self):
-    return dict([(k, getattr(self, k)) for k in self.members])
-
-  def compute_shape(self):
-    raise NotShapeable
+    return {name: getattr(self, name) for name in self.members}
 
   def visit(self, visitor):
-    deps = {}
-    for k in self.members:
-      deps[k] = visitor.visit(getattr(self, k))
-    return expr_like(self, **deps)
-
-  def __repr__(self):
-    return self.pretty_str()
-
-  def pretty_str(self):
-    return '%s[%d]' % (type(self).__name__, self.expr_id)
+    return expr_like(self, **{name: visitor.visit(getattr(self, name)) for name in self.members})
 
   def typename(self):
-    return self.__class__.__name__
+    return type(self).__name__
+
+  def pretty_str(self):
+    return '%s[%d]' % (self.typename(), self.expr_id)
+
+  __repr__ = lambda self: self.pretty_str()
+
+  def __hash__(self):
+    return self.expr_id
+
+  # -- values ------------------------------------------------------------------------------------------------
+  def cache(self):
+    """The node's value if it was computed and is intact; else whatever `load_data` can restore; else None."""
+    value = eval_cache.get(self.expr_id)
+    if value is not None and not getattr(value, 'bad_tiles', None):
+      return value
+    return self.load_data(value)
+
+  def load_data(self, damaged):
+    """Nothing to restore from: the node is evaluated again from its dependencies (CheckpointExpr reloads)."""
+    return None
 
   def evaluate(self):
-    """base.py:272-313: dependencies first, then `_evaluate`, then cache."""
     ctx = context.get()
     if ctx.heartbeat is not None and ctx.current_worker is None:
       ctx.apply_failures()          # safe point: workers the heartbeat declared silent lose their tiles here
-    cache = self.cache()
-    if cache is not None:
-      return cache
-    deps = {}
-    for k, vs in self.dependencies().items():
-      if isinstance(vs, Expr):
-        deps[k] = vs.evaluate()
-      else:
-        deps[k] = vs
-    value = self._evaluate(ctx, deps)
-    if self.needs_cache:
-      eval_cache.set(self.expr_id, value)
+    value = self.cache()
+    if value is None:
+      ready = {k: (d.evaluate() if isinstance(d, Expr) else d) for k, d in self.dependencies().items()}
+      value = self._evaluate(ctx, ready)
+      if self.needs_cache:
+        eval_cache.set(self.expr_id, value)
     return value
 
   def force(self):
-    """README.md:64-65: expressions are "forced" -- alias of evaluate()."""
     return self.evaluate()
 
   def _evaluate(self, ctx, deps):
     raise NotImplementedError
 
-  def __hash__(self):
-    return self.expr_id
+  def glom(self):
+    return glom(self)
 
-  # -- operators (base.py:331-388) -> map(np.ufunc) -------------------------------
-  def __add__(self, other): return _map(self, other, fn=np.add)
-  def __sub__(self, other): return _map(self, other, fn=np.subtract)
-  def __mul__(self, other): return _map(self, other, fn=np.multiply)
-  def __mod__(self, other): return _map(self, other, fn=np.mod)
-  def __truediv__(self, other): return _map(self, other, fn=np.divide)
-  __div__ = __truediv__
-  def __floordiv__(self, other): return _map(self, other, fn=np.floor_divide)
-  def __eq__(self, other): return _map(self, other, fn=np.equal)
-  def __ne__(self, other): return _map(self, other, fn=np.not_equal)
-  def __lt__(self, other): return _map(self, other, fn=np.less)
-  def __le__(self, other): return _map(self, other, fn=np.less_equal)
-  def __gt__(self, other): return _map(self, other, fn=np.greater)
-  def __ge__(self, other): return _map(self, other, fn=np.greater_equal)
-  def __and__(self, other): return _map(self, other, fn=np.logical_and)
-  def __or__(self, other): return _map(self, other, fn=np.logical_or)
-  def __xor__(self, other): return _map(self, other, fn=np.logical_xor)
-  def __pow__(self, other): return _map(self, other, fn=np.power)
-  def __neg__(self): return _map(self, fn=np.negative)
-  def __rsub__(self, other): return _map(other, self, fn=np.subtract)
-  def __radd__(self, other): return _map(other, self, fn=np.add)
-  def __rmul__(self, other): return _map(other, self, fn=np.multiply)
-  def __rtruediv__(self, other): return _map(other, self, fn=np.divide)
-  __rdiv__ = __rtruediv__
+  def optimized(self):
+    """The node after the DAG rewrites (fusion is opt-in, as in the reference: `evaluate` runs the DAG as built).
+    Optimising an optimised node is the identity -- remembered with a flag rather than the reference's
+    self-reference (base.py:489), a cycle only the cyclic collector frees, which would keep the multi-GiB tiles
+    of dead results in HBM between collections."""
+    if getattr(self, '_is_optimized', False):
+      return self
+    if self.optimized_expr is None:
+      self.optimized_expr = optimized_dag(self)
+      self.optimized_expr._is_optimized = True
+    return self.optimized_expr
 
-  def __setitem__(self, k, val):
-    raise Exception('Expressions are read-only.')
+  # -- shape -------------------------------------------------------------------------------------------------
+  def compute_shape(self):
+    raise NotShapeable
 
   @property
   def shape(self):
-    """base.py:452-471."""
-    cache = self.cache()
-    if cache is not None:
-      return cache.shape
+    value = self.cache()
+    if value is not None:
+      return value.shape
     if self.shape_cache is None:
       try:
         self.shape_cache = tuple(self.compute_shape())
@@ -190,64 +171,69 @@ class Expr(object):
     return self.shape_cache
 
   @property
+  def ndim(self):
+    return len(self.shape)
+
+  @property
   def size(self):
     return int(np.prod(self.shape, dtype=np.int64))
 
-  def optimized(self):
-    """base.py:477-492 (fusion is opt-in, as in the reference)."""
-    # The reference makes the optimised node point at itself (base.py:489), a
-    # reference cycle that only the cyclic GC can free -- which would keep multi-GiB
-    # HBM tiles of dead results alive between collections.  A flag has the same
-    # effect (optimising an optimised node is the identity) without the cycle.
-    if getattr(self, '_is_optimized', False):
-      return self
-    if self.optimized_expr is None:
-      self.optimized_expr = optimized_dag(self)
-      self.optimized_expr._is_optimized = True
-    return self.optimized_expr
-
-  def glom(self):
-    return glom(self)
+  def __setitem__(self, k, val):
+    raise Exception('Expressions are read-only.')
 
 
-def _map(*args, **kw):
-  """base.py:39-48."""
-  fn = kw['fn']
+def _elementwise(fn, *operands):
   from .map import map
-  return map(args, fn)
+  return map(operands, fn)
 
 
-class AsArray(Expr):
-  """base.py:508-533."""
+def _install_operators():
+  """a + b, -a, 2 * a ... build element-wise maps over NumPy ufuncs (the reference spells out one method each,
+  base.py:331-388)."""
+  binary = {'add': np.add, 'sub': np.subtract, 'mul': np.multiply, 'mod': np.mod, 'truediv': np.divide,
+            'floordiv': np.floor_divide, 'pow': np.power, 'eq': np.equal, 'ne': np.not_equal, 'lt': np.less,
+            'le': np.less_equal, 'gt': np.greater, 'ge': np.greater_equal, 'and': np.logical_and,
+            'or': np.logical_or, 'xor': np.logical_xor}
+  for name, fn in binary.items():
+    setattr(Expr, '__%s__' % name, (lambda f: lambda self, other: _elementwise(f, self, other))(fn))
+  for name in ('add', 'sub', 'mul', 'truediv'):
+    setattr(Expr, '__r%s__' % name, (lambda f: lambda self, other: _elementwise(f, other, self))(binary[name]))
+  Expr.__div__, Expr.__rdiv__ = Expr.__truediv__, Expr.__rtruediv__        # the reference's Python-2 names
+  Expr.__neg__ = lambda self: _elementwise(np.negative, self)
+  Expr.__hash__ = lambda self: self.expr_id                                 # (defining __eq__ would drop it)
+
+
+_install_operators()
+
+
+# ---- leaves ----------------------------------------------------------------------------------------------------
+class _Leaf(Expr):
   members = ('val',)
 
   def visit(self, visitor):
     return self
-
-  def dependencies(self):
-    return {'val': self.val}
-
-  def compute_shape(self):
-    if hasattr(self.val, 'shape'):
-      return self.val.shape
-    if np.isscalar(self.val):
-      return np.asarray(self.val).shape
-    raise NotShapeable
-
-  def _evaluate(self, ctx, deps):
-    return distarray.as_array(deps['val'])
 
   def pretty_str(self):
     return str(self.val)
 
 
-class Val(Expr):
-  """base.py:536-557."""
-  members = ('val',)
-  needs_cache = False
+class AsArray(_Leaf):
+  """A driver-side operand (NumPy array or scalar) taking part in a map."""
 
-  def visit(self, visitor):
-    return self
+  def compute_shape(self):
+    if hasattr(self.val, 'shape'):
+      return self.val.shape
+    if np.isscalar(self.val):
+      return ()
+    raise NotShapeable
+
+  def _evaluate(self, ctx, deps):
+    return distarray.as_array(deps['val'])
+
+
+class Val(_Leaf):
+  """An existing value (a distributed array, usually) as a node; nothing to evaluate, nothing to cache."""
+  needs_cache = False
 
   def dependencies(self):
     return {}
@@ -258,14 +244,14 @@ class Val(Expr):
   def _evaluate(self, ctx, deps):
     return self.val
 
-  def pretty_str(self):
-    return str(self.val)
 
-
+# ---- containers ------------------------------------------------------------------------------------------------
 class CollectionExpr(Expr):
-  """base.py:560-577."""
+  """Several nodes as one dependency.  Sequence containers share everything but their Python type."""
   members = ('vals',)
   needs_cache = False
+  _ctor = None
+  _brackets = ('', '')
 
   def __getitem__(self, idx):
     return self.vals[idx]
@@ -276,76 +262,60 @@ class CollectionExpr(Expr):
   def __len__(self):
     return len(self.vals)
 
-  def compute_shape(self):
-    raise NotShapeable
+  def dependencies(self):
+    return {'v%d' % i: v for i, v in enumerate(self.vals)}
+
+  def _evaluate(self, ctx, deps):
+    return self._ctor(deps['v%d' % i] for i in range(len(self.vals)))
+
+  def visit(self, visitor):
+    return type(self)(vals=self._ctor(visitor.visit(v) for v in self.vals))
+
+  def pretty_str(self):
+    inner = ','.join(v.pretty_str() if isinstance(v, Expr) else str(v) for v in self.vals)
+    return self._brackets[0] + inner + self._brackets[1]
+
+
+class ListExpr(CollectionExpr):
+  _ctor = list
+  _brackets = ('[\n', '\n]')
+
+
+class TupleExpr(CollectionExpr):
+  _ctor = tuple
+  _brackets = ('( ', ' )')
 
 
 class DictExpr(CollectionExpr):
   def dependencies(self):
     return self.vals
 
+  def items(self):
+    return self.vals.items()
+
   def _evaluate(self, ctx, deps):
     return deps
 
   def visit(self, visitor):
-    return DictExpr(vals=dict([(k, visitor.visit(v)) for (k, v) in self.vals.items()]))
-
-  def items(self):
-    return self.vals.items()
+    return DictExpr(vals={k: visitor.visit(v) for k, v in self.vals.items()})
 
   def pretty_str(self):
-    return '{ %s } ' % ',\n'.join(['%s : %s' % (k, repr(v)) for k, v in self.vals.items()])
+    return '{ %s } ' % ',\n'.join('%s : %r' % kv for kv in self.vals.items())
 
 
-class ListExpr(CollectionExpr):
-  def dependencies(self):
-    return dict(('v%d' % i, self.vals[i]) for i in range(len(self.vals)))
-
-  def pretty_str(self):
-    return '[\n%s\n]' % ','.join([v.pretty_str() if isinstance(v, Expr) else str(v) for v in self.vals])
-
-  def _evaluate(self, ctx, deps):
-    return [deps['v%d' % i] for i in range(len(self.vals))]
-
-  def visit(self, visitor):
-    return ListExpr(vals=[visitor.visit(v) for v in self.vals])
-
-
-class TupleExpr(CollectionExpr):
-  def dependencies(self):
-    return dict(('v%d' % i, self.vals[i]) for i in range(len(self.vals)))
-
-  def pretty_str(self):
-    return '( %s )' % ','.join([v.pretty_str() if isinstance(v, Expr) else str(v) for v in self.vals])
-
-  def _evaluate(self, ctx, deps):
-    return tuple(deps['v%d' % i] for i in range(len(self.vals)))
-
-  def visit(self, visitor):
-    return TupleExpr(vals=tuple([visitor.visit(v) for v in self.vals]))
-
-
-def glom(value):
-  """base.py:652-662."""
-  if isinstance(value, Expr):
-    value = evaluate(value)
-  if isinstance(value, np.ndarray):
-    return value
-  return value.glom()
-
-
+# ---- module functions ----------------------------------------------------------------------------------------
 def optimized_dag(node):
   if not isinstance(node, Expr):
-    raise TypeError
+    raise TypeError('optimized_dag of %r' % type(node))
   from .optimize import optimize
   return optimize(node)
 
 
 def evaluate(node):
-  """base.py:678-688."""
   if isinstance(node, Expr):
     return node.evaluate()
-  Assert.isinstance(node, (np.ndarray, distarray.DistArray))
+  if not isinstance(node, (np.ndarray, distarray.DistArray)):
+    raise AssertionError('%r is neither an expression nor an array' % (node,))
   return node
 
 
@@ -353,21 +323,24 @@ def eager(node):
   return Val(val=evaluate(node))
 
 
-def lazify(val):
-  """base.py:701-722."""
-  if isinstance(val, Expr):
-    return val
-  if isinstance(val, dict):
-    return DictExpr(vals=val)
-  if isinstance(val, list):
-    return ListExpr(vals=val)
-  if isinstance(val, tuple):
-    return TupleExpr(vals=val)
-  return Val(val=val)
+def glom(value):
+  """The value of an expression (or array) as one host array."""
+  value = evaluate(value) if isinstance(value, Expr) else value
+  return value if isinstance(value, np.ndarray) else value.glom()
 
 
-def as_array(v):
-  """base.py:725-734."""
-  if isinstance(v, Expr):
-    return v
-  return AsArray(val=v)
+_CONTAINER_OF = ((dict, DictExpr), (list, ListExpr), (tuple, TupleExpr))
+
+
+def lazify(value):
+  """Anything as a node: expressions as they are, Python containers as container nodes, the rest as Val."""
+  if isinstance(value, Expr):
+    return value
+  for python_type, node_type in _CONTAINER_OF:
+    if isinstance(value, python_type):
+      return node_type(vals=value)
+  return Val(val=value)
+
+
+def as_array(value):
+  return value if isinstance(value, Expr) else AsArray(val=value)
