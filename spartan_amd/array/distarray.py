@@ -25,52 +25,38 @@ def take_first(a, b):
 
 
 def good_tile_shape(shape, num_shards=-1):
-  """distarray.py:26-48 (Python-2 integer division at :36,:45)."""
-  if num_shards != -1:
-    tile_size = int(np.prod(shape, dtype=np.int64)) // num_shards
-  else:
-    tile_size = DEFAULT_TILE_SIZE
+  """Default tile shape: about prod(shape) / num_shards elements per tile (DEFAULT_TILE_SIZE without a shard
+  count), spent on the innermost axes first -- so a 2-D array is cut into bands of whole rows.  Integer results
+  are the reference's (distarray.py:26-48, with its Python-2 floor divisions)."""
+  budget = DEFAULT_TILE_SIZE if num_shards == -1 else int(np.prod(shape, dtype=np.int64)) // num_shards
   tile_shape = [1] * len(shape)
-  idx = len(shape) - 1
-  while tile_size > 1:
-    tile_shape[idx] = min(shape[idx], tile_size)
-    tile_size //= shape[idx]
-    idx -= 1
+  for axis in reversed(range(len(shape))):
+    if budget <= 1:
+      break
+    tile_shape[axis] = min(shape[axis], budget)
+    budget //= shape[axis]
   return tile_shape
 
 
 def compute_splits(shape, tile_hint):
-  """distarray.py:51-70."""
-  splits = [None] * len(shape)
-  for dim in range(len(shape)):
-    dim_splits = []
-    step = tile_hint[dim]
-    for i in range(0, shape[dim], step):
-      dim_splits.append((i, min(shape[dim], i + step)))
-    splits[dim] = dim_splits
-  return splits
+  """Per axis, the [start, end) pieces of length tile_hint[axis] (the last one shorter)."""
+  return [[(lo, min(lo + step, n)) for lo in range(0, n, step)] for n, step in zip(shape, tile_hint)]
 
 
 def compute_extents(shape, tile_hint=None, num_shards=-1):
-  """distarray.py:73-110: {extent: shard index}, round-robin in product order."""
+  """{tile extent: shard index} for an array of `shape`, tiles in row-major order of their position, dealt to
+  the shards round-robin (reference distarray.py:73-110)."""
   if len(shape) == 0:
     return {extent.create([], [], ()): 0}
   if tile_hint is None:
     tile_hint = good_tile_shape(shape, num_shards)
-  else:
-    Assert.eq(len(tile_hint), len(shape),
-              '#dimensions in tile hint does not match shape %s vs %s' % (tile_hint, shape))
-  splits = compute_splits(shape, tile_hint)
-  result = collections.OrderedDict()
-  idx = 0
-  for slc in itertools.product(*splits):
-    if num_shards != -1:
-      idx = idx % num_shards
-    ul, lr = zip(*slc)
-    ex = extent.create(ul, lr, shape)
-    result[ex] = idx
-    idx += 1
-  return result
+  elif len(tile_hint) != len(shape):
+    raise AssertionError('#dimensions in tile hint does not match shape %s vs %s' % (tile_hint, shape))
+  tiles = collections.OrderedDict()
+  for position, box in enumerate(itertools.product(*compute_splits(shape, tile_hint))):
+    lows, highs = zip(*box)
+    tiles[extent.create(lows, highs, shape)] = position if num_shards == -1 else position % num_shards
+  return tiles
 
 
 def _tile_mapper(tile_id, blob, array=None, user_fn=None, **kw):

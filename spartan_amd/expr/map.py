@@ -1,165 +1,113 @@
-"""map / map2 / map_with_location: mirror of the reference's
-spartan/expr/operator/map.py and map_with_location.py.  The per-tile body
-(`op.evaluate` in the reference) is ONE fused HIP kernel launch issued through
-the backend."""
-import collections
-
+"""Element-wise maps and joins: the API of the reference's spartan/expr/operator/map.py and map_with_location.py
+(`map`, `map_with_location`, `map2`, `MapExpr`, `Map2Expr`, `tile_mapper`, `join_mapper`).  The per-tile body of a
+map -- the reference evaluates the operator tree node by node with NumPy -- is ONE fused HIP kernel launch issued
+through the backend."""
 from . import base
 from .base import Expr, ListExpr, TupleExpr, as_array
-from .broadcast import Broadcast, broadcast
-from .local import FnCallExpr, LocalInput, LocalMapExpr, LocalMapLocationExpr, make_var
+from .broadcast import Broadcast, broadcast, common_shape
+from .local import LocalInput, LocalMapExpr, LocalMapLocationExpr, make_var
 from .. import context, util
 from ..array import distarray, extent, tile
 from ..context import LocalKernelResult
-from ..util import Assert
 
 
 def get_local_values(ex, children, child_to_var):
-  """map.py:33-45."""
-  local_values = {}
-  for child, childv in zip(children, child_to_var):
-    if isinstance(child, Broadcast):
-      local_val = child.fetch_base_tile(ex)
-    else:
-      local_val = child.fetch(ex)
-    local_values[childv] = local_val
-  return local_values
+  """{variable name: the piece of that input under the tile `ex`} -- stretched inputs hand out their un-stretched
+  slab (the kernel broadcasts through zero strides)."""
+  return {name: (child.fetch_base_tile(ex) if isinstance(child, Broadcast) else child.fetch(ex))
+          for child, name in zip(children, child_to_var)}
 
 
 def tile_mapper(ex, children, child_to_var, op):
-  """map.py:48-88: evaluate the (fused) map on one tile -> new local tile."""
+  """One tile of an element-wise map: the (fused) operator `op` over the inputs' pieces, ONE kernel launch,
+  result kept as a new tile on the worker that ran it (reference tile_mapper, map.py:48-88)."""
   ctx = context.get()
-  local_values = get_local_values(ex, children, child_to_var)
-  local_values['extent'] = ex
+  operands = get_local_values(ex, children, child_to_var)
+  operands['extent'] = ex
   if not ctx.executing:
-    # another rank owns this tile: only the tile id is allocated here
-    return LocalKernelResult(result=[(ex, ctx.create(None))])
-  result = ctx.backend.evaluate_map(op, local_values, ex)
-  # (the reference's identity shortcut, map.py:76-77, is not taken: whether a
-  # result aliases its input is only known on the executing rank, and tile ids
-  # must advance identically on every rank)
-  Assert.eq(ex.shape, tuple(result.shape), 'Bad shape -- result = %s, op = (%s)', result.shape, op)
-  result_tile = tile.from_data(result, dtype=ctx.backend.dtype_of(result))
-  tile_id = ctx.create(result_tile)
-  return LocalKernelResult(result=[(ex, tile_id)])
+    return LocalKernelResult(result=[(ex, ctx.create(None))])      # another rank's tile: only the id advances
+  out = ctx.backend.evaluate_map(op, operands, ex)
+  # (the reference hands back the INPUT tile's id when the operator returned its input unchanged, map.py:76-77;
+  #  whether that happened is only known where the kernel ran, and tile ids must advance alike on all ranks)
+  if tuple(out.shape) != ex.shape:
+    raise AssertionError('Bad shape -- result = %s, op = (%s)' % (tuple(out.shape), op))
+  return LocalKernelResult(result=[(ex, ctx.create(tile.from_data(out, dtype=ctx.backend.dtype_of(out))))])
 
 
 class MapExpr(Expr):
-  """map.py:91-169."""
+  """Element-wise operator over broadcast-compatible inputs; the result is tiled like its largest input."""
   members = ('children', 'child_to_var', 'op')
 
   def pretty_str(self):
     return 'Map[%d](%s, %s)' % (self.expr_id, self.op.pretty_str(), self.children.pretty_str())
 
-  def dependencies(self):
-    return {'children': self.children, 'child_to_var': self.child_to_var, 'op': self.op}
-
   def visit(self, visitor):
-    return base.expr_like(self, children=visitor.visit(self.children),
-                          child_to_var=self.child_to_var, op=self.op)
+    return base.expr_like(self, children=visitor.visit(self.children), child_to_var=self.child_to_var, op=self.op)
 
   def compute_shape(self):
-    """map.py:105-128: NumPy broadcasting of the children's shapes."""
-    orig_shapes = [list(x.shape) for x in self.children]
-    dims = [len(shape) for shape in orig_shapes]
-    max_dim = max(dims)
-    new_shapes = []
-    for shp in orig_shapes:
-      diff = max_dim - len(shp)
-      new_shapes.append([1] * diff + shp)
-    output_shape = collections.defaultdict(int)
-    for s in new_shapes:
-      for i, v in enumerate(s):
-        output_shape[i] = max(output_shape[i], v)
-    return tuple([output_shape[i] for i in range(len(output_shape))])
+    return common_shape([tuple(c.shape) for c in self.children])
 
   def _evaluate(self, ctx, deps):
-    children = list(deps['children'])
-    child_to_var = list(deps['child_to_var'])
-    children = broadcast(children)
-    largest = distarray.largest_value(children)
-    i = children.index(largest)
-    children[0], children[i] = children[i], children[0]
-    child_to_var[0], child_to_var[i] = child_to_var[i], child_to_var[0]
-    return largest.map_to_array(tile_mapper, kw={'children': children,
-                                                 'child_to_var': child_to_var,
-                                                 'op': self.op})
+    inputs = broadcast(list(deps['children']))
+    names = list(deps['child_to_var'])
+    # the largest input drives the tile walk (its tiles are read in place, the others are fetched to them)
+    lead = inputs.index(distarray.largest_value(inputs))
+    inputs[0], inputs[lead] = inputs[lead], inputs[0]
+    names[0], names[lead] = names[lead], names[0]
+    return inputs[0].map_to_array(tile_mapper, kw={'children': inputs, 'child_to_var': names, 'op': self.op})
+
+
+def _map_node(inputs, fn, numpy_expr, fn_kw, op_type, extra_vars=()):
+  if fn is None:
+    raise AssertionError('map needs a function')
+  arrays = [as_array(v) for v in (inputs if util.is_iterable(inputs) else [inputs])]
+  names = [make_var() for _ in arrays]
+  op = op_type(fn=fn, kw=fn_kw, pretty_fn=numpy_expr, deps=[LocalInput(idx=n) for n in names + list(extra_vars)])
+  return MapExpr(children=ListExpr(vals=arrays), child_to_var=names, op=op)
 
 
 def map(inputs, fn, numpy_expr=None, fn_kw=None):
-  """map.py:172-205."""
-  assert fn is not None
-  if not util.is_iterable(inputs):
-    inputs = [inputs]
-  op_deps = []
-  children = []
-  child_to_var = []
-  for v in inputs:
-    v = as_array(v)
-    varname = make_var()
-    children.append(v)
-    child_to_var.append(varname)
-    op_deps.append(LocalInput(idx=varname))
-  children = ListExpr(vals=children)
-  op = LocalMapExpr(fn=fn, kw=fn_kw, pretty_fn=numpy_expr, deps=op_deps)
-  return MapExpr(children=children, child_to_var=child_to_var, op=op)
+  """fn applied element-wise to the inputs (arrays, expressions, scalars; NumPy broadcasting)."""
+  return _map_node(inputs, fn, numpy_expr, fn_kw, LocalMapExpr)
 
 
 def map_with_location(inputs, fn, numpy_expr=None, fn_kw=None):
-  """map_with_location.py:22-60: the mapper also sees the tile's extent."""
-  assert fn is not None
-  if not util.is_iterable(inputs):
-    inputs = [inputs]
-  op_deps = []
-  children = []
-  child_to_var = []
-  for v in inputs:
-    v = as_array(v)
-    varname = make_var()
-    children.append(v)
-    child_to_var.append(varname)
-    op_deps.append(LocalInput(idx=varname))
-  op_deps += [LocalInput(idx='extent')]
-  children = ListExpr(vals=children)
-  op = LocalMapLocationExpr(fn=fn, kw=fn_kw, pretty_fn=numpy_expr, deps=op_deps)
-  return MapExpr(children=children, child_to_var=child_to_var, op=op)
+  """Like map, but fn also receives the position of the tile it is applied to (its extent, last argument)."""
+  return _map_node(inputs, fn, numpy_expr, fn_kw, LocalMapLocationExpr, extra_vars=('extent',))
 
 
 def join_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target):
-  """map.py:243-286: join the tile with the matching slabs of the other arrays,
-  run the user fn and push its outputs into `target`."""
-  ctx = context.get()
-  if len(axes) == 0:
-    tiles = [arrays[i].fetch(ex) for i in range(len(arrays))]
-    join_extents = ex
+  """One tile of a join (reference join_mapper, map.py:243-286).  `ex` is a tile of arrays[0]; it is re-read as
+  the slab that cuts axis axes[0] the same way (change_partition_axis), every other array contributes the slab
+  with the same index range on ITS join axis, the user function gets ([extents], [slabs]) and what it yields,
+  (target extent, data) pairs, is pushed into `target` (merged there by the target's reducer)."""
+  if not axes:
+    extents = ex
+    slabs = [a.fetch(ex) for a in arrays]
   else:
-    first_extent = extent.change_partition_axis(ex, axes[0])
-    if first_extent is None:
+    lead = extent.change_partition_axis(ex, axes[0])
+    if lead is None:
       return LocalKernelResult(result=[])
-    keys = (first_extent.ul[axes[0]], first_extent.lr[axes[0]])
-    join_extents = [first_extent]
-    for i in range(1, len(arrays)):
-      ul = [0 for _ in range(len(arrays[i].shape))]
-      lr = list(arrays[i].shape)
-      ul[axes[i]] = keys[0]
-      lr[axes[i]] = keys[1]
-      join_extents.append(extent.create(ul, lr, arrays[i].shape))
-    tiles = [arrays[i].fetch(join_extents[i]) for i in range(len(arrays))]
-  if local_user_fn_kw is None:
-    local_user_fn_kw = {}
-  result = local_user_fn(join_extents, tiles, **local_user_fn_kw)
-  if result is not None:
+    lo, hi = lead.ul[axes[0]], lead.lr[axes[0]]
+    extents = [lead]
+    for arr, axis in zip(arrays[1:], axes[1:]):
+      ul, lr = [0] * len(arr.shape), list(arr.shape)
+      ul[axis], lr[axis] = lo, hi
+      extents.append(extent.create(ul, lr, arr.shape))
+    slabs = [arr.fetch(e) for arr, e in zip(arrays, extents)]
+  produced = local_user_fn(extents, slabs, **(local_user_fn_kw or {}))
+  if produced is not None:
     # only a mapper that declares its outputs freshly produced hands them over: what an arbitrary user
     # mapper yields may be (a view of) a fetched input tile, and a target tile adopting it would alias
     # -- and later reduce into -- the source array's storage
     fresh = bool(getattr(local_user_fn, 'yields_fresh_tensors', False))
-    for tex, v in result:
-      target.update(tex, v, wait=False, owned=fresh)
+    for where, data in produced:
+      target.update(where, data, wait=False, owned=fresh)
   return LocalKernelResult(result=[])
 
 
 class Map2Expr(Expr):
-  """map.py:289-334."""
+  """A join of arrays on chosen axes whose per-tile function writes into a new target array."""
   members = ('arrays', 'axes', 'fn', 'fn_kw', 'shape_', 'update_region', 'tile_hint', 'dtype', 'reducer')
 
   def pretty_str(self):
@@ -169,45 +117,38 @@ class Map2Expr(Expr):
     return {'arrays': self.arrays}
 
   def visit(self, visitor):
-    return base.expr_like(self, arrays=visitor.visit(self.arrays), axes=self.axes, fn=self.fn,
-                          fn_kw=self.fn_kw, shape_=self.shape_, update_region=self.update_region,
-                          tile_hint=self.tile_hint, dtype=self.dtype, reducer=self.reducer)
+    fields = {name: getattr(self, name) for name in self.members}
+    fields['arrays'] = visitor.visit(self.arrays)
+    return base.expr_like(self, **fields)
 
   def compute_shape(self):
     return self.shape_
 
   def _evaluate(self, ctx, deps):
     arrays = deps['arrays']
-    dtype = self.dtype
-    if dtype is None:
-      dtype = arrays[0].dtype
     if self.update_region is not None:
       raise NotImplementedError('map2(update_region=...) (region_join_mapper) is not on the tile path')
-    sparse = len(arrays) > 1 and bool(getattr(arrays[0], 'sparse', False) and getattr(arrays[1], 'sparse', False))   # map.py:323
-    target = distarray.create(self.shape_, dtype, sharder=None, reducer=self.reducer,
-                              tile_hint=self.tile_hint, sparse=sparse)
+    both_sparse = len(arrays) > 1 and all(bool(getattr(a, 'sparse', False)) for a in arrays[:2])   # map.py:323
+    target = distarray.create(self.shape_, self.dtype if self.dtype is not None else arrays[0].dtype,
+                              sharder=None, reducer=self.reducer, tile_hint=self.tile_hint, sparse=both_sparse)
     # a mapper may know how to run its whole join as one pipeline of transfers and kernels when operands and
     # target are laid out regularly (dot: the K-split with its all-to-all and reduce-scatter, dot.ksplit_plan)
     plan = getattr(self.fn, 'collective_plan', None)
-    if plan is not None and plan(arrays, self.axes, target, self.fn_kw):
-      return target
-    arrays[0].foreach_tile(mapper_fn=join_mapper,
-                           kw=dict(arrays=arrays, axes=self.axes, local_user_fn=self.fn,
-                                   local_user_fn_kw=self.fn_kw, target=target))
+    if plan is None or not plan(arrays, self.axes, target, self.fn_kw):
+      arrays[0].foreach_tile(mapper_fn=join_mapper,
+                             kw=dict(arrays=arrays, axes=self.axes, local_user_fn=self.fn,
+                                     local_user_fn_kw=self.fn_kw, target=target))
     return target
 
 
-def map2(arrays, axes=[], fn=None, fn_kw=None, shape=None, update_region=None,
+def map2(arrays, axes=(), fn=None, fn_kw=None, shape=None, update_region=None,
          tile_hint=None, dtype=None, reducer=None):
-  """map.py:337-375."""
-  if not util.is_iterable(arrays):
-    arrays = [arrays]
-  if not util.is_iterable(axes):
-    axes = [axes]
-  assert fn is not None
-  assert list(axes) == [] or len(arrays) == len(axes)
-  assert shape is not None
-  arrays = TupleExpr(vals=tuple(base.lazify(a) if not isinstance(a, Expr) else a for a in arrays))
-  axes = tuple(axes)
-  return Map2Expr(arrays=arrays, axes=axes, fn=fn, fn_kw=fn_kw, shape_=tuple(shape),
-                  update_region=update_region, tile_hint=tile_hint, dtype=dtype, reducer=reducer)
+  """Join `arrays` on `axes` (one axis per array, or none: the tiles as they are) with `fn(extents, tiles, **fn_kw)`
+  yielding (target extent, data) pairs into a new array of `shape` (reference map2, map.py:337-375)."""
+  arrays = list(arrays) if util.is_iterable(arrays) else [arrays]
+  axes = tuple(axes) if util.is_iterable(axes) else (axes,)
+  if fn is None or shape is None or (axes and len(axes) != len(arrays)):
+    raise AssertionError('map2 needs fn, shape and one axis per array (or none)')
+  nodes = TupleExpr(vals=tuple(a if isinstance(a, Expr) else base.lazify(a) for a in arrays))
+  return Map2Expr(arrays=nodes, axes=axes, fn=fn, fn_kw=fn_kw, shape_=tuple(shape), update_region=update_region,
+                  tile_hint=tile_hint, dtype=dtype, reducer=reducer)

@@ -215,6 +215,187 @@ class Reshape(distarray.DistArray):
     self.bad_tiles = []
     self._tile_shape = distarray.good_tile_shape(self.shape, context.get().num_workers)
     self.shape_array = None
+    # One extra axis of length 1 is the cheap case (the kmeans 'broadcast' program, argmin's reshape): a region of
+    # the view is the same region of the base with that axis dropped -- no index arithmetic, no copy.
+    self.new_dimension_idx = self._inserted_unit_axis()
+    self.is_add_dimension = self.new_dimension_idx is not None
+    self._same_tiles = self._tiles_line_up()
+
+  def _inserted_unit_axis(self):
+    """k if shape == base.shape with a 1 inserted at position k, else None."""
+    base_shape = tuple(self.base.shape)
+    if len(self.shape) != len(base_shape) + 1:
+      return None
+    for k, n in enumerate(self.shape):
+      if n == 1 and self.shape[:k] + self.shape[k + 1:] == base_shape:
+        return k
+    return None
+
+  def _tiles_line_up(self):
+    """Can the tiles of the base, re-read in the new shape, serve as the tiles of the view?  Yes when axes were
+    only appended (leading axes unchanged), or when every default tile of the new shape is one contiguous
+    rectangle of the base that starts where the tile does (reference reshape.py:91-118)."""
+    if len(self.shape) > len(self.base.shape) and tuple(self.shape[:len(self.base.shape)]) == tuple(self.base.shape):
+      return True
+    for box in itertools.product(*distarray.compute_splits(self.shape, self._tile_shape)):
+      ul, lr = zip(*box)
+      flat_ul, flat_lr = _ravelled_ex(ul, lr, self.shape)
+      rect_ul, rect_lr = extent.find_rect(flat_ul, flat_lr, self.base.shape)
+      if rect_ul or ul or rect_lr != lr:
+        return False
+    return True
+
+  def tile_shape(self):
+    return self._tile_shape
+
+  def foreach_tile(self, mapper_fn, kw=None):
+    """slice.py:73-77."""
+    return self.base.foreach_tile(mapper_fn=_slice_mapper,
+                                  kw={'fn_kw': kw, '_slice_extent': self.slice, '_slice_fn': mapper_fn})
+
+  def extent_for_blob(self, id):
+    base_ex = self.base.extent_for_blob(id)
+    return extent.intersection(self.slice, base_ex)
+
+  def fetch(self, idx):
+    offset = extent.compute_slice(self.slice, idx.to_slice())
+    return self.base.fetch(offset)
+
+
+class SliceExpr(Expr):
+  """slice.py:88-137."""
+  members = ('src', 'idx', 'broadcast_to')
+
+  def dependencies(self):
+    return {'src': self.src}
+
+  def visit(self, visitor):
+    return base_mod.expr_like(self, src=visitor.visit(self.src), idx=self.idx, broadcast_to=self.broadcast_to)
+
+  def compute_shape(self):
+    if isinstance(self.idx, (int, slice, tuple)):
+      src_shape = self.src.shape
+      ex = extent.from_shape(src_shape)
+      slice_ex = extent.compute_slice(ex, self.idx)
+      return slice_ex.shape
+    raise base_mod.NotShapeable
+
+  def pretty_str(self):
+    return 'Slice[%d](%s, %s)' % (self.expr_id, self.src, self.idx)
+
+  def _evaluate(self, ctx, deps):
+    src = deps['src']
+    idx = self.idx
+    if self.broadcast_to is not None and src.shape != self.broadcast_to:
+      src = Broadcast(src, self.broadcast_to)
+    return Slice(src, idx)
+
+
+# ------------------------------------------------------------------- Transpose
+def _transpose_mapper(ex, **kw):
+  """transpose.py:19-24."""
+  user_fn = kw['_fn']
+  fn_kw = kw['_fn_kw']
+  view = kw['_base']
+  if fn_kw is None:
+    fn_kw = {}
+  view_ex = extent.create(ex.ul[::-1], ex.lr[::-1], view.shape)
+  return user_fn(view_ex, **fn_kw)
+
+
+class Transpose(distarray.DistArray):
+  """transpose.py:27-67."""
+
+  def __init__(self, base):
+    Assert.isinstance(base, distarray.DistArray)
+    self.base = base
+    self.shape = self.base.shape[::-1]
+    self.dtype = base.dtype
+    self.sparse = self.base.sparse
+    self.tiles = base.tiles
+    self.bad_tiles = []
+
+  def tile_shape(self):
+    return self.base.tile_shape()[::-1]
+
+  def view_extent(self, ex):
+    return extent.create(ex.ul[::-1], ex.lr[::-1], self.shape)
+
+  def foreach_tile(self, mapper_fn, kw=None):
+    """transpose.py:54-58."""
+    return self.base.foreach_tile(mapper_fn=_transpose_mapper,
+                                  kw={'_fn_kw': kw, '_base': self, '_fn': mapper_fn})
+
+  def extent_for_blob(self, id):
+    base_ex = self.base.extent_for_blob(id)
+    return extent.create(base_ex.ul[::-1], base_ex.lr[::-1], self.shape)
+
+  def fetch(self, ex):
+    base_ex = extent.create(ex.ul[::-1], ex.lr[::-1], self.base.shape)
+    return _permute_all(self.base.fetch(base_ex))
+
+
+class TransposeExpr(Expr):
+  """transpose.py:70-84."""
+  members = ('array', 'tile_hint')
+
+  def dependencies(self):
+    return {'array': self.array}
+
+  def visit(self, visitor):
+    return base_mod.expr_like(self, array=visitor.visit(self.array), tile_hint=self.tile_hint)
+
+  def pretty_str(self):
+    return 'Transpose[%d] %s' % (self.expr_id, self.array)
+
+  def _evaluate(self, ctx, deps):
+    return Transpose(deps['array'])
+
+  def compute_shape(self):
+    return self.array.shape[::-1]
+
+
+def transpose(array, tile_hint=None):
+  """transpose.py:87-100."""
+  return TransposeExpr(array=lazify(array), tile_hint=tile_hint)
+
+
+# --------------------------------------------------------------------- Reshape
+def _ravelled_ex(ul, lr, shape):
+  """reshape.py:20-23."""
+  return extent.ravelled_pos(ul, shape), extent.ravelled_pos([l - 1 for l in lr], shape)
+
+
+def _unravelled_ex(ravelled_ul, ravelled_lr, shape):
+  """reshape.py:26-29."""
+  return extent.unravelled_pos(ravelled_ul, shape), extent.unravelled_pos(ravelled_lr, shape)
+
+
+def _reshape_invoke(self, tile_id, blob, mapper_fn, kw):
+  """reshape.py:32-44."""
+  if self.shape_array is None:
+    ex = self.base.extent_for_blob(tile_id)
+    r_ul, r_lr = _ravelled_ex(ex.ul, ex.lr, self.base.shape)
+    u_ul, u_lr = _unravelled_ex(r_ul, r_lr, self.shape)
+    ex = extent.create(u_ul, [v + 1 for v in u_lr], self.shape)
+  else:
+    ex = self.shape_array.extent_for_blob(tile_id)
+  return mapper_fn(ex, **kw)
+
+
+class Reshape(distarray.DistArray):
+  """reshape.py:47-193 (dense)."""
+
+  def __init__(self, base, shape, tile_hint=None):
+    Assert.isinstance(base, distarray.DistArray)
+    self.base = base
+    self.shape = tuple(int(s) for s in shape)
+    self.dtype = base.dtype
+    self.sparse = self.base.sparse
+    self.tiles = self.base.tiles
+    self.bad_tiles = []
+    self._tile_shape = distarray.good_tile_shape(self.shape, context.get().num_workers)
+    self.shape_array = None
     # adding one size-1 dimension is the cheap case (reshape.py:73-87)
     self.is_add_dimension = False
     if len(self.shape) == len(self.base.shape) + 1:
