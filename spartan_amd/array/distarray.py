@@ -88,20 +88,22 @@ def _slices_shape(slices, base_shape):
   return tuple(shp)
 
 
+def _abstract(name):
+  def missing(self, *args, **kw):
+    raise NotImplementedError('%s.%s' % (type(self).__name__, name))
+  return missing
+
+
 class DistArray(object):
-  """distarray.py:119-215."""
+  """What every array-like of the tile path offers (reference distarray.py:119-215): `fetch(extent)` a region,
+  `update(extent, data)` a region through the reducer, `foreach_tile(mapper_fn, kw)` the SPMD tile walk and
+  `extent_for_blob(tile_id)`; the rest is derived."""
+  fetch = _abstract('fetch')
+  update = _abstract('update')
+  foreach_tile = _abstract('foreach_tile')
+  extent_for_blob = _abstract('extent_for_blob')
 
-  def fetch(self, ex):
-    raise NotImplementedError
-
-  def update(self, ex, data):
-    raise NotImplementedError
-
-  def foreach_tile(self, mapper_fn, kw):
-    raise NotImplementedError
-
-  def extent_for_blob(self, id):
-    raise NotImplementedError
+  ndim = property(lambda self: len(self.shape))
 
   def real_size(self):
     return int(np.prod(self.shape, dtype=np.int64))
@@ -109,46 +111,37 @@ class DistArray(object):
   def __len__(self):
     return self.shape[0]
 
+  def __hash__(self):
+    return id(self)
+
   def __repr__(self):
     return '%s(id=%s, shape=%s, dtype=%s)' % (self.__class__.__name__, id(self), self.shape, self.dtype)
 
   def select(self, idx):
+    """array[idx] for an extent, a scalar index or (a tuple of) slices."""
     if isinstance(idx, extent.TileExtent):
       return self.fetch(idx)
     if np.isscalar(idx):
-      result = self.select(slice(idx, idx + 1))
-      return result[0]
-    ex = extent.from_slice(idx, self.shape)
-    return self.fetch(ex)
+      return self.select(slice(idx, idx + 1))[0]
+    return self.fetch(extent.from_slice(idx, self.shape))
 
-  def __getitem__(self, idx):
-    return self.select(idx)
+  __getitem__ = select
 
   def glom(self):
-    """distarray.py:198-200: the whole array as a NumPy array (on every rank)."""
+    """The whole array as one host array, on every rank (a scipy matrix for a sparse array, a numpy.ma array if
+    cells were never written -- like the reference's glom)."""
     ctx = context.get()
     whole = self.select(np.index_exp[:])
     if tile.is_sparse_blob(whole):
-      return ctx.backend.sparse_to_host(whole)   # a scipy.sparse matrix, like the reference's glom
+      return ctx.backend.sparse_to_host(whole)
     if isinstance(whole, tile.MaskedBlob):
-      return whole.to_host(ctx.backend)          # a numpy.ma.MaskedArray, like the reference's glom
+      return whole.to_host(ctx.backend)
     return ctx.backend.to_numpy(whole)
 
   def map_to_array(self, mapper_fn, kw=None):
-    """distarray.py:202-208."""
-    results = self.foreach_tile(mapper_fn=mapper_fn, kw=kw)
-    extents = collections.OrderedDict()
-    for tile_id, d in results.items():
-      for ex, id in d:
-        extents[ex] = id
-    return from_table(extents)
-
-  def __hash__(self):
-    return id(self)
-
-  @property
-  def ndim(self):
-    return len(self.shape)
+    """foreach_tile whose mapper returns the tiles of a NEW array: [(extent, tile id)] per input tile."""
+    made = self.foreach_tile(mapper_fn=mapper_fn, kw=kw)
+    return from_table(collections.OrderedDict(pair for produced in made.values() for pair in produced))
 
 
 class ChunkedWhole(object):
@@ -776,21 +769,10 @@ class LocalWrapper(DistArray):
     Assert.isinstance(data, (np.ndarray, int, float, bool, np.generic))
     self._dev = None
 
-  @property
-  def dtype(self):
-    return self._data.dtype
-
-  @property
-  def shape(self):
-    return self._data.shape
-
-  @property
-  def is_weak_scalar(self):
-    return self._scalar is not None
-
-  @property
-  def tiles(self):
-    return {self._ex: TileId(-1, 0)}
+  dtype = property(lambda self: self._data.dtype)
+  shape = property(lambda self: self._data.shape)
+  is_weak_scalar = property(lambda self: self._scalar is not None)
+  tiles = property(lambda self: {self._ex: TileId(-1, 0)})     # one pseudo-tile that lives on the driver
 
   def extent_for_blob(self, tile_id):
     return self._ex

@@ -43,14 +43,15 @@ class TileExtent(object):
   def to_tuple(self):
     return (self.ul, self.lr, self.array_shape)
 
-  def __repr__(self):
-    return 'extent(' + ','.join('%s:%s' % (a, b) for a, b in zip(self.ul, self.lr)) + ')'
+  def __getitem__(self, axis):
+    """The 1-D extent of one axis."""
+    return create(self.ul[axis:axis + 1], self.lr[axis:axis + 1], self.array_shape[axis:axis + 1])
 
-  def __getitem__(self, idx):
-    return create((self.ul[idx],), (self.lr[idx],), (self.array_shape[idx],))
+  def __repr__(self):
+    return 'extent(%s)' % ','.join('%s:%s' % bounds for bounds in zip(self.ul, self.lr))
 
   def __hash__(self):
-    return hash(self.ul)  # extent.pyx:93-94
+    return hash(self.ul)  # (by corner only, like extent.pyx:93-94: equal extents hash alike either way)
 
   def __eq__(self, other):
     return isinstance(other, TileExtent) and self.ul == other.ul and self.lr == other.lr
@@ -70,15 +71,16 @@ class TileExtent(object):
   def __gt__(self, other):
     return not self.__lt__(other)
 
+  def to_global(self, idx, axis):
+    """A tile-local index as an index of the whole array: along `axis`, or (axis None) a flat index into the
+    tile as the flat index of the same cell in the array (extent.pyx:121-127)."""
+    if axis is None:
+      inside = unravelled_pos(idx, self.shape)
+      return ravelled_pos(tuple(u + i for u, i in zip(self.ul, inside)), self.array_shape)
+    return idx + self.ul[axis]
+
   def ravelled_pos(self):
     return ravelled_pos(self.ul, self.array_shape)
-
-  def to_global(self, idx, axis):
-    """extent.pyx:121-127."""
-    if axis is not None:
-      return idx + self.ul[axis]
-    local_idx = unravelled_pos(idx, self.shape)
-    return ravelled_pos(tuple(u + l for u, l in zip(self.ul, local_idx)), self.array_shape)
 
   def add_dim(self):
     return create(self.ul + (0,), self.lr + (1,), self.array_shape + (1,))
@@ -287,69 +289,63 @@ def is_complete(shape, slices):
 
 
 def largest_dim_axis(shape, exclude_axes=None):
-  """extent.pyx:466-476."""
-  largest_dim = 0
-  largest_axis = 0
-  for i in range(len(shape)):
-    if exclude_axes is not None and i in exclude_axes:
-      continue
-    if largest_dim < shape[i]:
-      largest_dim = shape[i]
-      largest_axis = i
-  return largest_axis
+  """First axis of maximal length among those not excluded (0 when nothing is left or every length is 0)."""
+  allowed = [i for i in range(len(shape)) if not exclude_axes or i not in exclude_axes]
+  best = max(allowed, key=lambda i: (shape[i], -i), default=0)
+  return best if shape[best] > 0 else 0
 
 
 def partition_axes(ex):
-  """extent.pyx:493-499."""
+  """Axes along which the extent is a proper part of its array."""
   return [i for i in range(len(ex.shape)) if ex.shape[i] != ex.array_shape[i]]
 
 
-def change_partition_axis(ex, axis):
-  """extent.pyx:501-570: re-map a 1-D-partitioned extent onto another axis."""
-  if isinstance(axis, (list, tuple)):
-    old_axes = partition_axes(ex)
-    if len(old_axes) > 1:
-      return ex
-    old_axis = old_axes[0]
-    n_dim = len(axis)
-    step = ex.lr[old_axis] - ex.ul[old_axis]
-    ntiles = divup(ex.array_shape[old_axis], step)
-    original_index = int(ex.ul[old_axis] // step)
-    n = int(math.pow(ntiles, 1.0 / n_dim))
-    grid_index = [0 for _ in range(n_dim)]
-    for i in reversed(range(n_dim)):
-      grid_index[i] = original_index % n
-      original_index -= grid_index[i]
-      original_index //= n
-    steps = [divup(ex.array_shape[i], n) for i in range(n_dim)]
-    ul = [steps[i] * grid_index[i] for i in range(n_dim)]
-    lr = [steps[i] * (grid_index[i] + 1) for i in range(n_dim)]
-    for i in range(len(lr)):
-      if lr[i] > ex.array_shape[i]:
-        return None
-    return create(ul, lr, ex.array_shape)
+def _to_grid(ex, n_dim):
+  """A tile of a 1-D partition as the cell with the same ordinal number of an n x n (x ...) grid over the first
+  n_dim axes, cells numbered in row-major order (extent.pyx:502-530; its float n-th root and Python-2 integer
+  division kept)."""
+  cut = partition_axes(ex)
+  if len(cut) > 1:
+    return ex
+  step = ex.lr[cut[0]] - ex.ul[cut[0]]
+  ordinal = int(ex.ul[cut[0]] // step)
+  per_side = int(math.pow(divup(ex.array_shape[cut[0]], step), 1.0 / n_dim))
+  cell = []
+  for _ in range(n_dim):                       # base-`per_side` digits of the ordinal, last axis first
+    cell.insert(0, ordinal % per_side)
+    ordinal = (ordinal - cell[0]) // per_side
+  sides = [divup(ex.array_shape[i], per_side) for i in range(n_dim)]
+  ul = [side * c for side, c in zip(sides, cell)]
+  lr = [side * (c + 1) for side, c in zip(sides, cell)]
+  if any(hi > n for hi, n in zip(lr, ex.array_shape)):
+    return None
+  return create(ul, lr, ex.array_shape)
 
+
+def change_partition_axis(ex, axis):
+  """The tile with the same ordinal number when the array is cut along `axis` instead (the re-tiling step of the
+  joins: worker i's row tile of A becomes A's i-th column slab).  Integer results are the reference's
+  (extent.pyx:501-570).  `axis` may be a list of axes: a 1-D partition is mapped onto a grid over them."""
+  if isinstance(axis, (list, tuple)):
+    return _to_grid(ex, len(axis))
+  shape = ex.array_shape
   if axis < 0:
-    axis += len(ex.array_shape)
-  if len(ex.shape) == 1:  # vector special case, extent.pyx:537-542
-    if axis == 1:
-      return create((0,), ex.array_shape, ex.array_shape)
+    axis += len(shape)
+  if len(ex.shape) == 1:                       # a vector has one way to be cut; "axis 1" means all of it
+    return create((0,), shape, shape) if axis == 1 else ex
+  cut = partition_axes(ex)
+  if len(cut) > 1:
+    # a cell of a 2-D grid becomes the slab with the cell's row-major number, one index thick
+    number = (ex.ul[0] // ex.shape[0]) * divup(shape[1], ex.shape[1]) + ex.ul[1] // ex.shape[1]
+    ul, lr = [0, 0], list(shape)
+    ul[axis], lr[axis] = number, number + 1
+    return create(ul, lr, shape)
+  if not cut or cut[0] == axis:
     return ex
-  old_axes = partition_axes(ex)
-  if len(old_axes) > 1:  # grid -> 1-D, extent.pyx:545-552
-    blk_idx = (ex.ul[0] // ex.shape[0]) * divup(ex.array_shape[1], ex.shape[1]) + ex.ul[1] // ex.shape[1]
-    ul = [0, 0]
-    lr = list(ex.array_shape)
-    ul[axis] = blk_idx
-    lr[axis] = blk_idx + 1
-    return create(ul, lr, ex.array_shape)
-  if len(old_axes) == 0 or old_axes[0] == axis:
-    return ex
-  old_axis = old_axes[0]
-  new_ul = list(ex.ul)
-  new_lr = list(ex.lr)
-  new_ul[axis] = divup(new_ul[old_axis] * ex.array_shape[axis], ex.array_shape[old_axis])
-  new_ul[old_axis] = 0
-  new_lr[axis] = divup(new_lr[old_axis] * ex.array_shape[axis], ex.array_shape[old_axis])
-  new_lr[old_axis] = ex.array_shape[old_axis]
-  return create(new_ul, new_lr, ex.array_shape)
+  old = cut[0]
+  ul, lr = list(ex.ul), list(ex.lr)
+  # the same FRACTION of the new axis, rounded up at both ends
+  ul[axis] = divup(ex.ul[old] * shape[axis], shape[old])
+  lr[axis] = divup(ex.lr[old] * shape[axis], shape[old])
+  ul[old], lr[old] = 0, shape[old]
+  return create(ul, lr, shape)

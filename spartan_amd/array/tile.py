@@ -17,13 +17,9 @@ import numpy as np
 
 from ..util import Assert
 
-TYPE_EMPTY = 0
-TYPE_DENSE = 1
-TYPE_MASKED = 2
-TYPE_SPARSE = 3
+TYPE_EMPTY, TYPE_DENSE, TYPE_MASKED, TYPE_SPARSE = range(4)       # tile.pyx:11-14
 
-MASK_ALL_CLEAR = 0
-MASK_ALL_SET = 1
+MASK_ALL_CLEAR, MASK_ALL_SET = 0, 1                              # uniform mask states (see the module docstring)
 
 _ID = itertools.count()
 

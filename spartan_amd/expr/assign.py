@@ -106,19 +106,17 @@ def _assign_mapper(tile, ex, assign_region, value):
   """assign.py:11-33."""
   if np.isscalar(value):
     return value
-  intersection = extent.intersection(assign_region, ex)
-  value_slice = extent.offset_slice(assign_region, intersection)
-  region_shape = assign_region.shape
-  if len(region_shape) != len(value.shape):
-    j = -1
-    s = []
-    for axis_shape in value.shape:
-      j = region_shape.index(axis_shape, j + 1)
-      s.append(value_slice[j])
-    value_slice = tuple(s)
-  if isinstance(value, np.ndarray):
-    return value[value_slice]
-  return value.fetch(extent.from_slice(value_slice, value.shape))
+  # the part of `value` that lands on this tile: the tile's share of the region, as slices of the region
+  part = extent.offset_slice(assign_region, extent.intersection(assign_region, ex))
+  if len(assign_region.shape) != len(value.shape):
+    # value has fewer axes than the region (a[2, :, :] = v): match its axes to the region's by length, in order
+    # (the reference's rule, assign.py:41-47)
+    picked, at = [], -1
+    for n in value.shape:
+      at = assign_region.shape.index(n, at + 1)
+      picked.append(part[at])
+    part = tuple(picked)
+  return value[part] if isinstance(value, np.ndarray) else value.fetch(extent.from_slice(part, value.shape))
 
 
 def assign(a, idx, value):

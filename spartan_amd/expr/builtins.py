@@ -147,30 +147,18 @@ def _arange_mapper(tile, ex, start=None, stop=None, step=None, dtype=None):
 
 
 def arange(start=None, stop=None, step=1, dtype=float, tile_hint=None):
-  """creation.py:144-206."""
+  """np.arange spread over tiles.  Call forms are the reference's (creation.py:144-206): arange(stop),
+  arange(start, stop[, step]), and -- with a shape in first place -- arange(shape) / arange(shape, first_value):
+  an array of that shape counting on in row-major order."""
   if start is None and stop is None:
     raise ValueError('No valid parameters')
-  shape = None
   if isinstance(start, (tuple, list)):
-    shape = start
-    start = 0
-    if stop is not None:
-      start = stop
-      stop = None
-  elif start is None:
-    start = 0
-  elif stop is None:
-    stop = start
-    start = 0
-  if shape is None and stop is None:
-    raise ValueError('Shape or stop expected, none supplied.')
-  if shape is not None and stop is not None:
-    raise ValueError('Only shape OR stop can be supplied, not both.')
-  if shape is None:
-    length = int(np.ceil((stop - start) / float(step)))
-    shape = (length,)
+    shape, first, last = tuple(start), (0 if stop is None else stop), None
+  else:
+    first, last = (0, start) if stop is None else (0 if start is None else start, stop)
+    shape = (int(np.ceil((last - first) / float(step))),)
   return map_with_location(ndarray(shape, dtype, tile_hint), _arange_mapper,
-                           fn_kw={'start': start, 'stop': stop, 'step': step, 'dtype': dtype})
+                           fn_kw={'start': first, 'stop': last, 'step': step, 'dtype': dtype})
 
 
 def _eye_mapper(tile, ex, k=None, dtype=None):

@@ -45,11 +45,11 @@ class CheckpointExpr(Expr):
     return load("%s" % self.expr_id, path=self.path, iszip=False).evaluate()
 
   def _evaluate(self, ctx, deps):
-    result = deps['src']
-    if self.mode == 'disk':
-      save(result, "%s" % self.expr_id, path=self.path, iszip=False)
+    value = deps['src']
+    if self.mode == 'disk':            # one file per tile, written by the worker that holds it (fio.save)
+      save(value, str(self.expr_id), path=self.path, iszip=False)
     self.ready = True
-    return result
+    return value
 
 
 def checkpoint(x, mode='disk'):

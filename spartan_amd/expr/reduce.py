@@ -16,15 +16,9 @@ from ..util import Assert
 def _reduce_mapper(ex, children, child_to_var, op, axis, output):
   """reduce.py:21-70."""
   ctx = context.get()
-  local_values = {}
-  for i in range(len(children)):
-    if isinstance(children[i], broadcast.Broadcast):
-      lv = children[i].fetch_base_tile(ex)
-    else:
-      lv = children[i].fetch(ex)
-    local_values[child_to_var[i]] = lv
-  local_values['extent'] = ex
-  local_values['axis'] = axis
+  from .map import get_local_values
+  local_values = get_local_values(ex, children, child_to_var)
+  local_values.update(extent=ex, axis=axis)
   dst_extent = extent.index_for_reduction(ex, axis)
   if ctx.executing:
     local_reduction = ctx.backend.evaluate_reduce(op, local_values, ex, axis)
@@ -50,12 +44,9 @@ class ReduceExpr(Expr):
                           accumulate_fn=self.accumulate_fn, tile_hint=self.tile_hint)
 
   def compute_shape(self):
-    shapes = [i.shape for i in self.children]
-    child_shape = collections.defaultdict(int)
-    for s in shapes:
-      for i, v in enumerate(s):
-        child_shape[i] = max(child_shape[i], v)
-    input_shape = tuple([child_shape[i] for i in range(len(child_shape))])
+    # (per-axis maximum over the children, left-aligned as the reference does it, reduce.py:87-94)
+    nd = max(len(c.shape) for c in self.children)
+    input_shape = tuple(max([c.shape[i] for c in self.children if i < len(c.shape)] or [0]) for i in range(nd))
     return tuple(extent.shape_for_reduction(input_shape, self.axis))
 
   def pretty_str(self):

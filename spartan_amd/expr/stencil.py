@@ -24,13 +24,8 @@ from ..util import Assert, divup
 
 def tiles_like(array, target_shape):
   """stencil.py:18-26."""
-  orig_shape = array.shape
-  orig_tile = array.tile_shape()
-  new_tile = []
-  for i in range(len(orig_shape)):
-    scale = float(target_shape[i]) / orig_shape[i]
-    new_tile.append(int(math.ceil(orig_tile[i] * scale)))
-  return new_tile
+  return [int(math.ceil(t * (float(want) / have)))
+          for t, want, have in zip(array.tile_shape(), target_shape, array.shape)]
 
 
 def _convolve(local_image, local_filters):
@@ -59,11 +54,8 @@ def stencil_mapper(array, ex, filters=None, images=None, target_shape=None):
 
 def stencil(images, filters, stride=1):
   """stencil.py:103-132."""
-  images = eager(images)
-  filters = eager(filters)
-  images = images.evaluate()
-  n_img, n_col, w, h = images.shape
-  n_filt, f_col, fw, fh = filters.shape
+  images, filters = eager(images).evaluate(), eager(filters)
+  (n_img, n_col, w, h), (n_filt, f_col, fw, fh) = images.shape, filters.shape
   tile_hint = tiles_like(images, (n_img, n_filt, w, h))
   target = ndarray((n_img, n_filt, w, h), dtype=images.dtype, reduce_fn=np.add, tile_hint=tile_hint)
   return shuffle(images, stencil_mapper, target=target,
