@@ -202,8 +202,9 @@ int sp_program_static_id(const sp_program* prog, int32_t out_dtype);
  *   sp_jit_compiled_count kernels specialised so far.
  *   sp_jit_compile_check  does `template_expr` (a kernel template-id naming the program
  *                         type StaticProg<1000>) compile for `prog`?  Needs no device. */
-/* Environment: SPARTAN_JIT_CACHE=<directory> keeps the code objects hipRTC produced there (one file per library
- * build x header x kernel x program) and later processes load them instead of compiling. */
+/* The code objects hipRTC produced persist across processes (one file per library build x header x kernel x
+ * program; later processes load them instead of compiling): in $SPARTAN_JIT_CACHE, else
+ * $XDG_CACHE_HOME/spartan_amd/jit, else ~/.cache/spartan_amd/jit.  SPARTAN_JIT_CACHE=off keeps them in memory only. */
 int sp_jit_configure(int enabled, long long min_elems);
 void sp_jit_wait(void);
 int sp_jit_compiled_count(void);

@@ -136,9 +136,30 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
   return h;
 }
 
+// Where specialised code objects persist across processes.  On by default: $SPARTAN_JIT_CACHE, else
+// $XDG_CACHE_HOME/spartan_amd/jit, else ~/.cache/spartan_amd/jit (created on first use); SPARTAN_JIT_CACHE=off (or
+// an empty value) keeps them in memory only.  A second process that evaluates the same fused expression then
+// starts on the specialised kernel instead of spending its first launches on the interpreter tier.
 std::string cache_dir() {
+  static std::string dir;
+  static bool resolved = false;
+  if (resolved) return dir;
+  resolved = true;
   const char* e = getenv("SPARTAN_JIT_CACHE");
-  return e && *e ? std::string(e) : std::string();
+  if (e) {
+    dir = (*e && strcmp(e, "off") != 0 && strcmp(e, "0") != 0) ? std::string(e) : std::string();
+  } else {
+    const char* x = getenv("XDG_CACHE_HOME");
+    const char* h = getenv("HOME");
+    if (x && *x) dir = std::string(x) + "/spartan_amd/jit";
+    else if (h && *h) dir = std::string(h) + "/.cache/spartan_amd/jit";
+  }
+  if (!dir.empty()) {
+    // mkdir -p (errors are not fatal: an unwritable cache only means every process compiles for itself)
+    for (size_t i = 1; i <= dir.size(); ++i)
+      if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0755);
+  }
+  return dir;
 }
 
 std::string stat_id(const std::string& path) {
