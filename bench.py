@@ -19,6 +19,8 @@ on the launch stream), the fused-map / reduce HBM rates, the k-means and sparse 
 baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thread worker processes.
 """
 import argparse
+import os as _os
+_os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC between the per-GPU processes (RCCL)
 import json
 import os
 import sys

@@ -12,6 +12,9 @@ The public names mirror the reference's `spartan` / `spartan.expr` namespaces
 """
 __version__ = '0.1.0'
 
+import os as _os
+_os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # the host driver only supports dmabuf IPC (RCCL across processes)
+
 import numpy as _np
 
 from . import context as _context

@@ -65,7 +65,9 @@ class RcclTransport(object):
     handle = C.c_void_p()
     _hip.check(self.lib.sp_comm_init(world_size, rank, uid, C.byref(handle)))
     self.comm = handle
-    self.side = torch.cuda.Stream()          # asynchronous transfers run here
+    # asynchronous transfers run here; high priority, so that a collective's few workgroups are placed as soon as
+    # compute workgroups retire instead of queueing behind a whole GEMM launch (its peers on the other GPUs wait)
+    self.side = torch.cuda.Stream(priority=-1)
 
   @staticmethod
   def unique_id():

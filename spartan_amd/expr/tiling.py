@@ -45,6 +45,13 @@ _MAP2_UNITS = {(0, 0): 0, (0, 1): 1, (0, 2): 1, (0, -1): 1,
                (3, 0): 0, (3, 1): 0, (3, 2): 1, (3, -1): 1}
 
 
+def _dtype_of(x):
+  try:
+    return np.dtype(x.dtype)
+  except Exception:
+    return np.dtype(np.float32)
+
+
 def _nbytes(x):
   shape = x.shape
   n = 1
@@ -257,8 +264,11 @@ class AutomaticTiling(object):
     return self._join(expr, aligned)
 
   def _visit_ShuffleExpr(self, expr):
-    """optimize.py:700-770, without user cost hints: the shuffle runs in its source's tiling; every array in its
-    keyword arguments is fetched whole (one redistribution), and so is the target."""
+    """optimize.py:700-770: the shuffle runs in its source's tiling; every array in its keyword arguments, and its
+    target, is reached from there.  What that costs is the user's `cost_hint` when there is one -- ELEMENTS of the
+    array that move for a (tiling of the array, tiling of the shuffle) pair, keys '00' '01' '10' '11' with 0 = rows
+    and 1 = columns, as the reference defines it (shuffle.py:99-135, optimize.py:701-707) -- converted to bytes
+    over links; without a hint the array is fetched whole once."""
     ids = self._visit(expr.array)
     extra = []
     kw = expr.fn_kw
@@ -269,9 +279,18 @@ class AutomaticTiling(object):
     if not extra:
       return self._attach(ids, expr)
     out = self._tied(expr, ids, [self.nodes[i].tiling for i in ids]) if ids else [self._new_node([expr], ROW)]
+    hints = expr.cost_hint or {}
     for mine in out:
       for o in extra:
-        self._add_edge(o, mine, self._link_bytes(1, self.nodes[o].exprs[0]))
+        array = self.nodes[o].exprs[0]
+        hint = hints.get(hash(array))
+        key = '%d%d' % (self.nodes[o].tiling, self.nodes[mine].tiling)
+        if hint is not None and self.nodes[o].tiling in (ROW, COL) and self.nodes[mine].tiling in (ROW, COL) \
+            and key in hint:
+          moved = float(hint[key]) * np.dtype(_dtype_of(array)).itemsize * (self.p - 1) / max(self.p, 1)
+        else:
+          moved = self._link_bytes(1, array)
+        self._add_edge(o, mine, moved)
     return out
 
   def _aligned_view(self, expr, swap):

@@ -247,3 +247,30 @@ def test_random_programs_do_not_change_under_auto_tiling_gpu():
   """The same on the HIP backend: column- and block-tiled arrays chosen by the pass go through the strided kernels."""
   from spartan_amd.backend_hip import HipBackend
   _random_programs(HipBackend, range(4000, 4200), 40)
+
+
+def test_shuffle_cost_hint_steers_the_target_tiling():
+  """A shuffle's user cost hint (reference shuffle.py:99-135 / optimize.py:701-707): elements of its target that
+  move for each (target tiling, shuffle tiling) pair.  With "free when the target is column-tiled" the pass creates
+  the target column-tiled; with "free when row-tiled" row-tiled; without a hint every choice costs the same."""
+  import importlib
+  import spartan_amd as sp
+  from oracle.np_backend import NumpyBackend
+  from spartan_amd.expr import tiling
+  sp.initialize(backend=NumpyBackend(), num_workers=4)
+  try:
+    src = sp.from_numpy(np.ones((64, 64), np.float32)).force()          # row-tiled source
+
+    def fn(array, ex, out):
+      return []
+    for free_key, want in (('10', tiling.COL), ('00', tiling.ROW)):
+      target = sp.ndarray((64, 64), dtype=np.float32)
+      hint = {k: 64 * 64 for k in ('00', '01', '10', '11')}
+      hint[free_key] = 0
+      e = sp.shuffle(sp.Val(val=src), fn, kw={'out': target}, target=None, cost_hint={hash(target): hint})
+      pas = tiling.AutomaticTiling()
+      pas.visit(e)
+      assert pas.report['tilings'][target.expr_id] == want, (free_key, pas.report)
+      assert pas.report['link_bytes'] == 0
+  finally:
+    sp.shutdown()
