@@ -143,135 +143,6 @@ __global__ __launch_bounds__(256) void sp_nearest_exact_kernel(const TX* __restr
   }
 }
 
-// Re-check of the points the fused kernel listed as undecided.  One wavefront per R points; lanes own
-// centers.  Pass over ALL centers in fp32 (fmaf chain over the features, |error| <= E/2 like the fused
-// kernel's scores); a center can only be the exact answer if its fp32 score is within E of the point's
-// best fused score (best is within E/2 of its true value, the candidate within E/2 of its own), so only
-// those few centers -- typically the two or three that tied -- get the exact fp64 distance (cdist's
-// arithmetic, as in sp_nearest_exact_kernel).  Result: the exact tier's label at a fraction of its cost.
-__global__ __launch_bounds__(256) void sp_nearest_recheck_kernel(const float* __restrict__ X, int64_t ldx,
-                                                                 const float* __restrict__ Ct,
-                                                                 const double* __restrict__ Ct64,
-                                                                 const float* __restrict__ chalf,
-                                                                 const unsigned* __restrict__ cmax2_bits, int kp,
-                                                                 int k, int d, int64_t* __restrict__ labels,
-                                                                 const int* __restrict__ rows,
-                                                                 const float* __restrict__ row_best,
-                                                                 const int* __restrict__ n_rows) {
-  constexpr int G = 2, R = 4, J = 8;
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t count = *n_rows;
-  const float cmax2 = __uint_as_float(*cmax2_bits);
-  const float cmax = sqrtf(cmax2) * 1.0000002f;
-  for (int64_t it = wave * R; it < count; it += nwaves * R) {
-    int64_t row[R];
-    const float* __restrict__ xr[R];
-    float thr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t e = it + r < count ? it + r : count - 1;   // tail: repeat the last point
-      // wave-uniform by construction: tell the compiler, so the point's features come through the
-      // scalar cache (s_load) and feed the FMAs as SGPR operands instead of 32 vector loads per trip
-      row[r] = __builtin_amdgcn_readfirstlane(rows[e]);
-      xr[r] = X + row[r] * ldx;
-      thr[r] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(row_best[e])));
-    }
-    // |x|^2 -> E -> window (every lane computes the same values: the loads are uniform)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float xs = 0.f;
-      for (int j = 0; j < d; ++j) xs = __builtin_fmaf(xr[r][j], xr[r][j], xs);
-      const float xnorm = sqrtf(xs) * 1.001f;
-      const float E = 5.9604645e-8f * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
-      thr[r] = thr[r] + E * 1.001f + 1e-30f;
-    }
-    double best[R];
-    int best_k[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      best[r] = INFINITY;
-      best_k[r] = 0x7fffffff;
-    }
-    for (int c0 = 0; c0 < k; c0 += 64 * G) {
-      float h[R][G];
-      int col[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int c = c0 + g * 64 + lane;
-        col[g] = c < kp ? c : kp - 1;
-#pragma unroll
-        for (int r = 0; r < R; ++r) h[r][g] = 0.f;
-      }
-      int j = 0;
-      for (; j + J <= d; j += J) {
-        float xv[R][J], cv[J][G];
-#pragma unroll
-        for (int u = 0; u < J; ++u) {
-#pragma unroll
-          for (int g = 0; g < G; ++g) cv[u][g] = Ct[(int64_t)(j + u) * kp + col[g]];
-#pragma unroll
-          for (int r = 0; r < R; ++r) xv[r][u] = xr[r][j + u];
-        }
-#pragma unroll
-        for (int u = 0; u < J; ++u)
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int g = 0; g < G; ++g) h[r][g] = __builtin_fmaf(xv[r][u], cv[u][g], h[r][g]);
-      }
-      for (; j < d; ++j) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const float cvv = Ct[(int64_t)j * kp + col[g]];
-#pragma unroll
-          for (int r = 0; r < R; ++r) h[r][g] = __builtin_fmaf(xr[r][j], cvv, h[r][g]);
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int c = c0 + g * 64 + lane;
-        const float ch = chalf[col[g]];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const bool cand = c < k && (ch - h[r][g]) <= thr[r];
-          if (__ballot(cand)) {            // rare: a handful of centers per point pass the window
-            if (cand) {
-              double s = 0.0;
-              for (int jj = 0; jj < d; ++jj) {
-                const double diff = (double)xr[r][jj] - Ct64[(int64_t)jj * kp + c];
-                s += diff * diff;
-              }
-              s = sqrt(s);
-              if (s < best[r]) {           // ascending center index per lane: `<` keeps the first minimum
-                best[r] = s;
-                best_k[r] = c;
-              }
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      double b = best[r];
-      int bk = best_k[r];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(b, off);
-        const int ok = __shfl_xor(bk, off);
-        if (ob < b || (ob == b && ok < bk)) {
-          b = ob;
-          bk = ok;
-        }
-      }
-      // (the window always contains the fused kernel's own best center, so bk is set; the guard is for NaN input)
-      if (lane == 0) labels[row[r]] = bk == 0x7fffffff ? -1 - labels[row[r]] : bk;
-    }
-  }
-}
-
 // Last step of the fused tier: cdist's exact distance (sequential fp64 sum of squared differences in feature
 // order, sqrt) of the centers sp_nearest_nt_kernel<.., true> marked for each listed point -- typically the two
 // or three that tied -- and the lexicographic (distance, index) minimum = np.argmin's first minimum.
@@ -587,17 +458,10 @@ extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ld
     if (tier == SP_NEAREST_FUSED_UNCHECKED) return 0;   // diagnostics: leave the marks (-1 - best) in place
     // the points the fused kernel listed as undecided: fp32 window over all centers, exact fp64 distance
     // for the few inside it (SP_KM_FULL_RECHECK=1: the full exact kernel instead, for A/B measurements)
-    static int recheck_mode = -1;   // 0: MFMA candidate masks (default), 1: round-1 VALU window kernel, 2: exact kernel
+    static int recheck_mode = -1;   // 0: MFMA candidate masks (default); SP_KM_RECHECK=2: the exact kernel on the list
     if (recheck_mode < 0) {
       const char* e = getenv("SP_KM_RECHECK");
       recheck_mode = e ? atoi(e) : 0;
-    }
-    if (recheck_mode == 1) {
-      hipLaunchKernelGGL(sp_nearest_recheck_kernel, dim3(SP_CUS * 8), dim3(256), 0, st, (const float*)d_points, ldx,
-                         w.Ct, w.Ct64, w.cn, w.cmax2, (int)w.kp, (int)k, (int)d, d_labels, w.amb_rows, w.amb_best,
-                         w.amb_count);
-      SP_CHECK_LAUNCH();
-      return 0;
     }
     rows = w.amb_rows;
     n_rows = w.amb_count;
