@@ -32,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FETCH_SIZE): group 32 / 16 / 8 / 4 / 2 / 1 -> 23.7 / 22.3 / 18.6 / 12.9 / 10.6 / 10.1 GB of L2 misses and
 // 137.5 -> 139.5 TFLOP/s: only the A panel shared by the WGs of one tile ROW is reliably served from the
 // XCD's L2, so the plain row-major walk (group 1: 64 resident WGs = one 256-row A panel x 64 B panels) wins.
+#ifndef SP_GEMM_ABLATE
+#define SP_GEMM_ABLATE 0      // build with -DSP_GEMM_ABLATE=1 for the timing-only variants (tools/gemm_variants.py)
+#endif
 #ifndef SP_GEMM_GROUP_M
 #define SP_GEMM_GROUP_M 1
 #endif
@@ -290,7 +293,7 @@ struct GldsCfg {
   static constexpr int NW = WM * WN, THREADS = NW * 64;
   static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   static constexpr int A_FLOATS = BM * BK, B_FLOATS = BK * BN, STAGE_FLOATS = A_FLOATS + B_FLOATS;
-  static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+  static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;    // (3 stages for the deep-prefetch variant)
   static constexpr int A_PIECES = (A_FLOATS / 256) / NW;   // 1 KiB wave-loads of A per wave and k-tile
   static constexpr int B_PIECES = (B_FLOATS / 256) / NW;
   static constexpr int MIN_WAVES = (NW == 4) ? 2 : 1;
@@ -380,7 +383,43 @@ __global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_kernel(
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[i][s4], bf_[j][s4], acc[i][j], 0, 0, 0); \
   } while (0)
-  if constexpr (PIPE) {
+  if constexpr (PIPE >= 16) {
+    SP_GLDS_TILE(0, 0);
+    SP_GLDS_LANDED();
+    __syncthreads();
+  } else if constexpr (PIPE == 3) {
+    // Three LDS stages, k-tiles requested TWO ahead: a tile has two k-tiles of MFMAs to land, so the tail of the
+    // load latency distribution (one slow 1 KiB piece of 24 holds the whole workgroup at its barrier) is covered.
+    // The wait is counted -- the AP + BP pieces of the newest tile stay in flight across the barrier -- which
+    // needs the raw barrier: __syncthreads() carries a fence that drains the LDS-DMA queue.
+    static_assert(AP + BP == 6, "vmcnt immediate below");
+    auto body = [&](int t) {
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        f32x4 af[TM];
+        float bf[TN][4];
+        SP_FRAGS(af, bf, t % 3, c);
+        SP_MFMAS(af, bf);
+      }
+    };
+    SP_GLDS_TILE(0, 0);
+    if (nt > 1) SP_GLDS_TILE(1, 1);
+    if (nt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else SP_GLDS_LANDED();
+    __builtin_amdgcn_s_barrier();
+    int t = 0;
+    for (; t + 2 < nt; ++t) {
+      SP_GLDS_TILE(t + 2, (t + 2) % 3);
+      body(t);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile t+1 has landed; tile t+2 may still be on its way
+      __builtin_amdgcn_s_barrier();
+    }
+    for (; t < nt; ++t) {
+      body(t);
+      SP_GLDS_LANDED();
+      __builtin_amdgcn_s_barrier();
+    }
+  } else if constexpr (PIPE) {
     static_assert(BK == 16, "two fragment halves per k-tile");
     f32x4 af0[TM], af1[TM];
     float bf0[TN][4], bf1[TN][4];
@@ -419,6 +458,28 @@ __global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_kernel(
       __syncthreads();    // tile t+1 has landed and every wave is done reading stage t
     }
   }
+#if SP_GEMM_ABLATE
+  // Timing-only variants (SP_GEMM_VARIANT 16..23, results are WRONG by construction): which part of the k-loop the
+  // MFMA pipe waits for.  Bit 0: no k-tile loads after the first; bit 1: no barriers; bit 2: fragments read once;
+  // bit 3: loads issued but never waited for.
+  if constexpr (PIPE >= 16) {
+    constexpr int ABL = PIPE - 16;
+    f32x4 af[BK / 8][TM];
+    float bf[BK / 8][TN][4];
+    for (int t = 0; t < nt; ++t) {
+      if (!(ABL & 1) && t + 1 < nt) SP_GLDS_TILE(t + 1, (t + 1) & 1);
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        if (!(ABL & 4) || t == 0) SP_FRAGS(af[c], bf[c], t & 1, c);
+        SP_MFMAS(af[c], bf[c]);
+      }
+      if (!(ABL & 2)) {
+        if (!(ABL & 8)) SP_GLDS_LANDED();
+        __syncthreads();
+      }
+    }
+  }
+#endif
 #undef SP_FRAGS
 #undef SP_MFMAS
 #undef SP_GLDS_TILE
@@ -450,12 +511,13 @@ static int sp_gemm_glds_launch(const float* A, int64_t lda, const float* B, int6
   const int64_t nblk = tiles_m * tiles_n;
   if (nblk > 2147483647LL) SP_FAIL("sp_gemm_f32: too many tiles");
   auto k = sp_gemm_glds_kernel<Cfg, BM, BN, WM, WN, PIPE, WGS>;
+  constexpr int lds_bytes = (PIPE == 3 ? 3 : 2) * Cfg::STAGE_FLOATS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, A, lda, B, ldb, C, ldc, (int)M,
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(Cfg::THREADS), lds_bytes, st, A, lda, B, ldb, C, ldc, (int)M,
                      (int)N, (int)K, acc, (int)tiles_m, (int)tiles_n);
   SP_CHECK_LAUNCH();
   return 0;
@@ -541,14 +603,21 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
     case 4: return sp_gemm_launch<128, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 5: return sp_gemm_launch<256, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     // direct-to-LDS k-tiles (preconditions checked here; otherwise the register-staged kernel of the same tile)
-    case 6: case 9:
+    case 6: case 9: case 11:
       if (fast && K % 16 == 0 && (int64_t)256 * lda < 2147483647LL && (int64_t)16 * ldb < 2147483647LL) {
         if (v == 6) return sp_gemm_glds_launch<256, 128, 2, 2, 0, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
+        if (v == 11) return sp_gemm_glds_launch<256, 128, 2, 2, 3, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
         // (SP_GEMM_VARIANT only) register double-buffered fragments, barrier between the k-tile's halves:
         // 139.2 vs 141.5 TFLOP/s for case 6 -- profiles/r02_notes.md
         return sp_gemm_glds_launch<256, 128, 2, 2, 1, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
       }
       return sp_gemm_launch<256, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
+#if SP_GEMM_ABLATE
+#define SP_ABL_CASE(m) case 16 + m: return sp_gemm_glds_launch<256, 128, 2, 2, 16 + m, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
+    SP_ABL_CASE(0) SP_ABL_CASE(1) SP_ABL_CASE(2) SP_ABL_CASE(3) SP_ABL_CASE(4) SP_ABL_CASE(5) SP_ABL_CASE(6) SP_ABL_CASE(7)
+    SP_ABL_CASE(8) SP_ABL_CASE(10)
+#undef SP_ABL_CASE
+#endif
     case 7:
       if (fast && K % 16 == 0 && (int64_t)128 * lda < 2147483647LL && (int64_t)16 * ldb < 2147483647LL)
         return sp_gemm_glds_launch<128, 128, 2, 2, 0, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
