@@ -80,6 +80,23 @@ constexpr int KN_SMEM_FLOATS = 2 * KN_STAGE + 2 * KN_BM;   // two stages + two |
 static_assert(KN_SMEM_FLOATS * 4 <= 65536, "static LDS limit");
 static_assert(KN_BM == KM_BN_MAX, "kp must be a multiple of the center block");
 
+// The verdict on one point from its fp32 (best, second best) halved scores: the label when the gap clears the error
+// bound, else -1 - label and a place in the list the re-check works through.
+__device__ __forceinline__ void km_decide(float b, float s, int ix, float xn, int point, int d, float cmax,
+                                          float cmax2, int64_t* __restrict__ labels, int* __restrict__ amb_rows,
+                                          float* __restrict__ amb_best, int* __restrict__ amb_count) {
+  const float u = 5.9604645e-8f;                     // 2^-24
+  const float xnorm = sqrtf(xn) * 1.001f;            // fp32 sum of squares: generous slack
+  const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
+  const bool sure = 2.0f * (s - b) > 4.0f * E;       // (scores are halved) false for NaN / inf-inf as well
+  labels[point] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
+  if (!sure) {   // (order-free: each listed point is re-done on its own)
+    const int pos = atomicAdd(amb_count, 1);
+    amb_rows[pos] = point;
+    amb_best[pos] = b;   // its best (halved) fp32 score: the re-check's candidate window starts here
+  }
+}
+
 //
 // RECHECK = true is the second pass over the points the first pass could not decide (amb_rows[0 .. *amb_count),
 // gathered through the row list): the same contraction, one workgroup per (128 listed points, 256-center block
@@ -89,7 +106,12 @@ static_assert(KN_BM == KM_BN_MAX, "kp must be a multiple of the center block");
 // atomics, no zeroing.  sp_nearest_candidates_kernel (kmeans.hip) then takes cdist's fp64 distance of the marked
 // centers only.  (Round 1 re-computed all k scores of a listed point with VALU FMAs: 0.68 ms for 1.4 % of the
 // points at configs[3], against 5.5 ms for the whole first pass.)
-template <bool FAST, bool RECHECK>
+//
+// PARTIAL = true serves the points of the last, partly filled round of workgroups (see sp_nearest_fused_launch):
+// workgroup (x, y) walks only center blocks [y * per_tiles, (y + 1) * per_tiles) for its 128 points and leaves its
+// (best, second best, best's center) per point in part[y][0..2][point] (+ |x|^2 from y = 0);
+// sp_nearest_merge_parts_kernel combines the parts and decides exactly as the tail of this kernel does.
+template <bool FAST, bool RECHECK, bool PARTIAL = false>
 __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __restrict__ X, int64_t ldx,
                                                                const float* __restrict__ Cf,   // [kp][dp], zero padded
                                                                const float* __restrict__ chalf,
@@ -98,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
                                                                int* __restrict__ amb_rows,
                                                                float* __restrict__ amb_best,
                                                                int* __restrict__ amb_count,
-                                                               unsigned* __restrict__ cand_mask) {
+                                                               unsigned* __restrict__ cand_mask,
+                                                               float* __restrict__ part, int ldp, int per_tiles) {
   // ONE LDS object (stages, |c|^2/2 slices; the merge arrays alias stage 0 after the main loop)
   __shared__ __attribute__((aligned(16))) float smem[KN_SMEM_FLOATS];
   float* chs = smem + 2 * KN_STAGE;
@@ -145,8 +168,9 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
   float* const sA_w = smem + wid * AP * 256;      // this wave's pieces inside a stage
   float* const sB_w = smem + KN_A_FLOATS + wid * BP * 256;
   const int nt = dp / KM_BK;
-  const int tm_first = RECHECK ? (int)blockIdx.y : 0;
-  const int tiles_m = RECHECK ? 1 : kp / KN_BM;   // center blocks walked by this workgroup
+  const int tm_first = RECHECK ? (int)blockIdx.y : PARTIAL ? (int)blockIdx.y * per_tiles : 0;
+  // center blocks walked by this workgroup
+  const int tiles_m = RECHECK ? 1 : PARTIAL ? min(per_tiles, kp / KN_BM - tm_first) : kp / KN_BM;
   const int steps = nt * tiles_m;
   km_f32x4 rb[BP];
 
@@ -333,7 +357,6 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
   if (wm == 0 && lh == 0) {
     const float cmax2 = __uint_as_float(*cmax2_bits);
     const float cmax = sqrtf(cmax2) * 1.0000002f;
-    const float u = 5.9604645e-8f;   // 2^-24
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = wn * 64 + j * 32 + l31;
@@ -349,18 +372,47 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
         s = fminf(ob, s);
       }
       if (m0 + col < n) {
-        const float xnorm = sqrtf(xn[j]) * 1.001f;       // fp32 sum of squares: generous slack
-        const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
-        const bool sure = 2.0f * (s - b) > 4.0f * E;     // (scores are halved) false for NaN / inf-inf as well
-        labels[m0 + col] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
-        if (!sure) {   // (order-free: each listed point is re-done on its own)
-          const int pos = atomicAdd(amb_count, 1);
-          amb_rows[pos] = m0 + col;
-          amb_best[pos] = b;   // its best (halved) fp32 score: the re-check's candidate window starts here
+        if constexpr (PARTIAL) {
+          const int64_t at = (int64_t)blockIdx.y * 3 * ldp + m0 + col;
+          part[at] = b;
+          part[at + ldp] = s;
+          ((int*)part)[at + 2 * (int64_t)ldp] = ix;
+          if (blockIdx.y == 0) part[(int64_t)gridDim.y * 3 * ldp + m0 + col] = xn[j];
+        } else {
+          km_decide(b, s, ix, xn[j], m0 + col, d, cmax, cmax2, labels, amb_rows, amb_best, amb_count);
         }
       }
     }
   }
+}
+
+// Combines the per-center-range parts of the PARTIAL launch for tail point t (global point first + t).
+__global__ __launch_bounds__(256) void sp_nearest_merge_parts_kernel(const float* __restrict__ part, int S, int ldp,
+                                                                     int n_tail, int first, int d,
+                                                                     const unsigned* __restrict__ cmax2_bits,
+                                                                     int64_t* __restrict__ labels,
+                                                                     int* __restrict__ amb_rows,
+                                                                     float* __restrict__ amb_best,
+                                                                     int* __restrict__ amb_count) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_tail) return;
+  float b = part[t], s = part[ldp + t];
+  int ix = ((const int*)part)[2 * (int64_t)ldp + t];
+  for (int y = 1; y < S; ++y) {
+    const int64_t at = (int64_t)y * 3 * ldp + t;
+    const float ob = part[at], os = part[at + ldp];
+    const int oi = ((const int*)part)[at + 2 * (int64_t)ldp];
+    if (ob < b || (ob == b && oi < ix)) {
+      s = fminf(b, os);
+      b = ob;
+      ix = oi;
+    } else {
+      s = fminf(ob, s);
+    }
+  }
+  const float cmax2 = __uint_as_float(*cmax2_bits);
+  km_decide(b, s, ix, part[(int64_t)S * 3 * ldp + t], first + t, d, sqrtf(cmax2) * 1.0000002f, cmax2, labels, amb_rows,
+            amb_best, amb_count);
 }
 
 static inline int64_t km_round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
@@ -377,7 +429,15 @@ struct KmWorkspace {
   float* amb_best;   // [n]       their best (halved) fp32 score
   int64_t cand_cap;  //           listed points the candidate masks have room for
   unsigned* cand_mask;   // [cand_cap][kp / 32]  centers inside the error window of a listed point
+  float* part;       // [KM_TAIL_SPLIT][3][KM_TAIL_POINTS] + [KM_TAIL_POINTS]   parts of the tail points
 };
+
+// The last round of first-pass workgroups is rarely full (configs[3]: 9 766 workgroups over 512 slots = 19 rounds and
+// 38 workgroups that cost a 20th).  The points of that round are split over up to KM_TAIL_SPLIT ranges of center
+// blocks instead (PARTIAL launch + merge), so the round is ~1/split as long.
+constexpr int KM_WG_SLOTS = 512;                        // 256 CUs x 2 workgroups (launch bounds of the kernel)
+constexpr int KM_TAIL_SPLIT = 8;
+constexpr int KM_TAIL_POINTS = KM_WG_SLOTS * KN_BN;
 
 static inline size_t km_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -398,7 +458,8 @@ static inline int64_t km_cand_cap(int64_t n) {
 static size_t sp_nearest_fused_ws_bytes(int64_t n, int64_t k, int64_t d) {
   const int64_t kp = km_round_up(k < 1 ? 1 : k, KM_BN_MAX), dp = km_padded_features(d);
   return 256 + km_align((size_t)(d < 1 ? 1 : d) * kp * 8) + km_align((size_t)dp * kp * 4) + km_align((size_t)kp * 4) + 256 + 256 +
-         2 * km_align((size_t)(n < 1 ? 1 : n) * 4) + km_align((size_t)km_cand_cap(n) * (kp / 32) * 4);
+         2 * km_align((size_t)(n < 1 ? 1 : n) * 4) + km_align((size_t)km_cand_cap(n) * (kp / 32) * 4) +
+         km_align((size_t)KM_TAIL_POINTS * (3 * KM_TAIL_SPLIT + 1) * 4);
 }
 
 static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
@@ -422,6 +483,8 @@ static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
   p += km_align((size_t)(n < 1 ? 1 : n) * 4);
   w.cand_cap = km_cand_cap(n);
   w.cand_mask = (unsigned*)p;
+  p += km_align((size_t)w.cand_cap * (w.kp / 32) * 4);
+  w.part = (float*)p;
   return w;
 }
 
@@ -449,14 +512,45 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
   SP_CHECK_LAUNCH();
   // direct-to-LDS loads of the points need whole k-steps inside a row and 16-B alignment
   const bool fast = (d == dp) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
-  const unsigned blocks = (unsigned)((n + KN_BN - 1) / KN_BN);
+  const int64_t blocks = (n + KN_BN - 1) / KN_BN, tiles = kp / KN_BM;
+  // whole rounds walk all centers per workgroup; the workgroups of the partial last round are split over the centers
+  // when that shortens it: `rem` workgroups of `tiles` blocks become rem * split of `per` blocks
+  int64_t rem = blocks % KM_WG_SLOTS, split = 1, per = tiles;
+  static const bool tail_off = getenv("SP_KM_TAIL_SPLIT") && atoi(getenv("SP_KM_TAIL_SPLIT")) == 0;
+  if (rem > 0 && tiles > 1 && !tail_off) {
+    split = tiles < KM_TAIL_SPLIT ? tiles : KM_TAIL_SPLIT;
+    per = (tiles + split - 1) / split;
+    split = (tiles + per - 1) / per;
+    const int64_t rounds = (rem * split + KM_WG_SLOTS - 1) / KM_WG_SLOTS;
+    if (rounds * per >= tiles) split = 1;     // no shorter than the plain round
+  }
+  if (split == 1) rem = 0;
+  const int64_t whole = blocks - rem, n_whole = whole * KN_BN < n ? whole * KN_BN : n;
+#define KN_FIRST_PASS(FAST_)                                                                                          \
+  do {                                                                                                                \
+    if (whole > 0)                                                                                                    \
+      hipLaunchKernelGGL((sp_nearest_nt_kernel<FAST_, false, false>), dim3((unsigned)whole), dim3(256), 0, st, X, ldx, \
+                         w.Cf, w.cn, w.cmax2, (int)n_whole, (int)d, (int)dp, (int)kp, labels, w.amb_rows, w.amb_best, \
+                         w.amb_count, (unsigned*)nullptr, (float*)nullptr, 0, 0);                                      \
+    if (rem > 0)                                                                                                      \
+      hipLaunchKernelGGL((sp_nearest_nt_kernel<FAST_, false, true>), dim3((unsigned)rem, (unsigned)split), dim3(256), 0, \
+                         st, X + n_whole * ldx, ldx, w.Cf, w.cn, w.cmax2, (int)(n - n_whole), (int)d, (int)dp, (int)kp, \
+                         (int64_t*)nullptr, (int*)nullptr, (float*)nullptr, (int*)nullptr, (unsigned*)nullptr, w.part, \
+                         KM_TAIL_POINTS, (int)per);                                                                    \
+  } while (0)
   if (fast)
-    hipLaunchKernelGGL((sp_nearest_nt_kernel<true, false>), dim3(blocks), dim3(256), 0, st, X, ldx, w.Cf, w.cn, w.cmax2,
-                       (int)n, (int)d, (int)dp, (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count, (unsigned*)nullptr);
+    KN_FIRST_PASS(true);
   else
-    hipLaunchKernelGGL((sp_nearest_nt_kernel<false, false>), dim3(blocks), dim3(256), 0, st, X, ldx, w.Cf, w.cn, w.cmax2,
-                       (int)n, (int)d, (int)dp, (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count, (unsigned*)nullptr);
+    KN_FIRST_PASS(false);
+#undef KN_FIRST_PASS
   SP_CHECK_LAUNCH();
+  if (rem > 0) {
+    const int n_tail = (int)(n - n_whole);
+    hipLaunchKernelGGL(sp_nearest_merge_parts_kernel, dim3((unsigned)((n_tail + 255) / 256)), dim3(256), 0, st, w.part,
+                       (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, (int)d, w.cmax2, labels, w.amb_rows, w.amb_best,
+                       w.amb_count);
+    SP_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -467,11 +561,11 @@ static int sp_nearest_mark_candidates(const float* X, int64_t ldx, int64_t d, co
   if (fast)
     hipLaunchKernelGGL((sp_nearest_nt_kernel<true, true>), grid, dim3(256), 0, st, X, ldx, w.Cf, w.cn, w.cmax2,
                        (int)w.cand_cap, (int)d, (int)w.dp, (int)w.kp, (int64_t*)nullptr, w.amb_rows, w.amb_best,
-                       w.amb_count, w.cand_mask);
+                       w.amb_count, w.cand_mask, (float*)nullptr, 0, 0);
   else
     hipLaunchKernelGGL((sp_nearest_nt_kernel<false, true>), grid, dim3(256), 0, st, X, ldx, w.Cf, w.cn, w.cmax2,
                        (int)w.cand_cap, (int)d, (int)w.dp, (int)w.kp, (int64_t*)nullptr, w.amb_rows, w.amb_best,
-                       w.amb_count, w.cand_mask);
+                       w.amb_count, w.cand_mask, (float*)nullptr, 0, 0);
   SP_CHECK_LAUNCH();
   return 0;
 }

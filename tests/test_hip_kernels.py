@@ -598,6 +598,24 @@ def test_nearest_center_everything_undecided(n, k, d):
   assert np.all(unchecked < 0)           # the first pass listed every point
 
 
+@pytest.mark.parametrize('n,k,d', [(512 * 128 + 4000, 600, 32), (700, 2304, 40), (512 * 128, 513, 32)])
+def test_nearest_center_split_tail(n, k, d):
+  """The partly filled last round of first-pass workgroups runs split over ranges of centre blocks and is merged
+  afterwards (3 ranges; 9 blocks in 5 ranges of 2,2,2,2,1; a tile of whole rounds only): same labels as the exact
+  tier, with the duplicate centres in different ranges."""
+  from scipy.spatial.distance import cdist
+  x = RNG.rand(n, d).astype(np.float32)
+  c = RNG.rand(k, d)
+  c[k - 1] = c[3]                        # tie across the first and the last range
+  x[:50] = c[3].astype(np.float32)
+  fused = _nearest(x, c, _hip.NEAREST_FUSED)
+  want = np.argmin(cdist(x[-5000:], c), axis=1)
+  np.testing.assert_array_equal(fused[-5000:], want)
+  np.testing.assert_array_equal(fused[:50], np.argmin(cdist(x[:50], c), axis=1))
+  assert not np.any(fused == k - 1)
+  np.testing.assert_array_equal(fused, _nearest(x, c, _hip.NEAREST_EXACT))
+
+
 def test_nearest_center_strided_rows_and_auto_tier():
   from scipy.spatial.distance import cdist
   big = RNG.rand(6000, 96).astype(np.float32)
