@@ -314,21 +314,23 @@ __global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_kernel(
   int tm, tn;
   sp_gemm_tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: the LDS targets of the loads are scalar
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // ---- what each lane fetches: block-relative 32-bit element offsets, scalar bases
-  const float* __restrict__ Ablk = A + (int64_t)m0 * lda;
-  const float* __restrict__ Bblk = B + n0;
-  int a_off[AP], b_off[BP];
+  // ---- what each lane fetches: block-relative UNSIGNED 32-bit byte offsets off scalar bases, so that a load is
+  // `global_load_lds_dwordx4 v_off, s[base]` with nothing to compute per k-tile but the scalar base
+  const char* __restrict__ Ablk = (const char*)(A + (int64_t)m0 * lda);
+  const char* __restrict__ Bblk = (const char*)(B + n0);
+  unsigned a_off[AP], b_off[BP];
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
     const int slot = (wid * AP + j) * 64 + lane;          // 16-B slot of the A image: row = slot / 4
     int row = slot >> 2;
     const int q = (slot & 3) ^ ((row >> 2) & 3);           // the chunk of that row this slot holds
     if (m0 + row > M - 1) row = M - 1 - m0;                // clamp (masked on store)
-    a_off[j] = row * (int)lda + q * 4;
+    a_off[j] = (unsigned)(row * (int)lda + q * 4) * 4u;
   }
 #pragma unroll
   for (int j = 0; j < BP; ++j) {
@@ -336,19 +338,19 @@ __global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_kernel(
     const int krow = slot / (BN / 4);
     int gc = (slot % (BN / 4)) * 4;
     if (n0 + gc > N - 4) gc = N - 4 - n0;
-    b_off[j] = krow * (int)ldb + gc;
+    b_off[j] = (unsigned)(krow * (int)ldb + gc) * 4u;
   }
-  float* const sA_w = smem + wid * AP * 256;               // this wave's pieces inside a stage
-  float* const sB_w = smem + Cfg::A_FLOATS + wid * BP * 256;
+  const unsigned sA_w = SP_LDS_ADDR(smem) + wid * (AP * 1024);            // this wave's pieces inside a stage (bytes)
+  const unsigned sB_w = SP_LDS_ADDR(smem) + Cfg::A_FLOATS * 4 + wid * (BP * 1024);
 
 #define SP_GLDS_TILE(kt, stage)                                                        \
   do {                                                                                 \
-    const float* Ak_ = Ablk + (kt) * BK;                                               \
-    const float* Bk_ = Bblk + (int64_t)((kt) * BK) * ldb;                              \
-    float* dA_ = sA_w + (stage) * Cfg::STAGE_FLOATS;                                   \
-    float* dB_ = sB_w + (stage) * Cfg::STAGE_FLOATS;                                   \
-    _Pragma("unroll") for (int j = 0; j < AP; ++j) SP_GLDS(Ak_ + a_off[j], dA_ + j * 256); \
-    _Pragma("unroll") for (int j = 0; j < BP; ++j) SP_GLDS(Bk_ + b_off[j], dB_ + j * 256); \
+    const char* Ak_ = Ablk + (int64_t)(kt) * (BK * 4);                                 \
+    const char* Bk_ = Bblk + (int64_t)((kt) * BK) * ldb * 4;                           \
+    const unsigned dA_ = sA_w + (stage) * (Cfg::STAGE_FLOATS * 4);                     \
+    const unsigned dB_ = sB_w + (stage) * (Cfg::STAGE_FLOATS * 4);                     \
+    _Pragma("unroll") for (int j = 0; j < AP; ++j) SP_GLDS_S(Ak_, a_off[j], dA_ + j * 1024); \
+    _Pragma("unroll") for (int j = 0; j < BP; ++j) SP_GLDS_S(Bk_, b_off[j], dB_ + j * 1024); \
   } while (0)
 
   f32x16 acc[TM][TN];
@@ -604,7 +606,7 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
     case 5: return sp_gemm_launch<256, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     // direct-to-LDS k-tiles (preconditions checked here; otherwise the register-staged kernel of the same tile)
     case 6: case 9: case 11:
-      if (fast && K % 16 == 0 && (int64_t)256 * lda < 2147483647LL && (int64_t)16 * ldb < 2147483647LL) {
+      if (fast && K % 16 == 0 && (int64_t)256 * lda < (1LL << 30) && (int64_t)16 * ldb < (1LL << 30)) {
         if (v == 6) return sp_gemm_glds_launch<256, 128, 2, 2, 0, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
         if (v == 11) return sp_gemm_glds_launch<256, 128, 2, 2, 3, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
         // (SP_GEMM_VARIANT only) register double-buffered fragments, barrier between the k-tile's halves:
@@ -619,7 +621,7 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
 #undef SP_ABL_CASE
 #endif
     case 7:
-      if (fast && K % 16 == 0 && (int64_t)128 * lda < 2147483647LL && (int64_t)16 * ldb < 2147483647LL)
+      if (fast && K % 16 == 0 && (int64_t)128 * lda < (1LL << 30) && (int64_t)16 * ldb < (1LL << 30))
         return sp_gemm_glds_launch<128, 128, 2, 2, 0, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
       return sp_gemm_launch<128, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     default: SP_FAIL("sp_gemm_f32: unknown SP_GEMM_VARIANT=%d", v);

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
   constexpr int THREADS = 256;
   constexpr int KQ = KM_BK / 4;
   constexpr int AV = (KN_BM * KQ) / THREADS, BV = (KN_BN * KQ) / THREADS;   // 4, 2 float4 per thread per k-step
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the LDS targets of the k-tile loads are
   const int wm = wid >> 1, wn = wid & 1;          // wm: center half (128 rows), wn: point half (64 columns)
   const int l31 = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * KN_BN;              // first point (RECHECK: first list slot) of this workgroup
@@ -141,14 +142,16 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
 
   // ---- k-tile pieces (1 KiB = one wave-wide 16-B load): slot -> (row, chunk) of the swizzled image
   constexpr int AP = (KN_A_FLOATS / 256) / 4, BP = (KN_B_FLOATS / 256) / 4;   // 4 and 2 pieces per wave
-  int a_off[AP];
+  // (loads are `global_load_lds_dwordx4 v_off, s[base]`: per-lane unsigned BYTE offsets off scalar bases, see
+  // SP_GLDS_S; the gathered rows of the re-check take the 64-bit address form)
+  unsigned a_off[AP];
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
     const int slot = (wid * AP + j) * 64 + lane, row = slot >> 2;
-    a_off[j] = row * dp + ((slot & 3) ^ ((row >> 2) & 3)) * 4;
+    a_off[j] = (unsigned)(row * dp + ((slot & 3) ^ ((row >> 2) & 3)) * 4) * 4u;
   }
   const float* __restrict__ Xblk = RECHECK ? X : X + (int64_t)m0 * ldx;
-  typename std::conditional<RECHECK, int64_t, int>::type b_off[BP];
+  typename std::conditional<RECHECK, int64_t, unsigned>::type b_off[BP];
   int b_lds[BP];                                  // (register path) where this thread's 16 B go
 #pragma unroll
   for (int j = 0; j < BP; ++j) {
@@ -162,11 +165,12 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
       b_off[j] = (int64_t)amb_rows[listed_row] * ldx + q * 4;
     } else {
       if (m0 + row > n - 1) row = n - 1 - m0;     // clamp: results of points >= n are discarded
-      b_off[j] = row * (int)ldx + q * 4;
+      b_off[j] = (unsigned)(row * (int)ldx + q * 4) * (FAST ? 4u : 1u);   // FAST: bytes; register path: floats
     }
   }
-  float* const sA_w = smem + wid * AP * 256;      // this wave's pieces inside a stage
-  float* const sB_w = smem + KN_A_FLOATS + wid * BP * 256;
+  const unsigned sA_w = SP_LDS_ADDR(smem) + wid * (AP * 1024);      // this wave's pieces inside a stage (bytes)
+  const unsigned sB_w = SP_LDS_ADDR(smem) + KN_A_FLOATS * 4 + wid * (BP * 1024);
+  const unsigned chs_w = SP_LDS_ADDR(chs);
   const int nt = dp / KM_BK;
   const int tm_first = RECHECK ? (int)blockIdx.y : PARTIAL ? (int)blockIdx.y * per_tiles : 0;
   // center blocks walked by this workgroup
@@ -181,11 +185,13 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
     const int tm_ = tm_first + tr_;                                                      \
     const int k0_ = kt_ * KM_BK;                                                         \
     const float* Ak_ = Cf + (int64_t)tm_ * KN_BM * dp + k0_;                             \
-    float* dA_ = sA_w + ((step) & 1) * KN_STAGE;                                         \
-    _Pragma("unroll") for (int j = 0; j < AP; ++j) SP_GLDS(Ak_ + a_off[j], dA_ + j * 256); \
+    const unsigned dA_ = sA_w + ((step) & 1) * (KN_STAGE * 4);                           \
+    _Pragma("unroll") for (int j = 0; j < AP; ++j) SP_GLDS_S(Ak_, a_off[j], dA_ + j * 1024); \
     _Pragma("unroll") for (int j = 0; j < BP; ++j) {                                     \
-      if constexpr (FAST) {                                                              \
-        SP_GLDS(Xblk + k0_ + b_off[j], sB_w + ((step) & 1) * KN_STAGE + j * 256);        \
+      if constexpr (FAST && RECHECK) {                                                   \
+        SP_GLDS_V(Xblk + k0_ + b_off[j], sB_w + ((step) & 1) * (KN_STAGE * 4) + j * 1024); \
+      } else if constexpr (FAST) {                                                       \
+        SP_GLDS_S(Xblk + k0_, b_off[j], sB_w + ((step) & 1) * (KN_STAGE * 4) + j * 1024); \
       } else {                                                                           \
         const int kk = k0_ + ((tid + j * THREADS) & 3) * 4;                              \
         const float* p = Xblk + k0_ + b_off[j];                                          \
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
         rb[j].w = kk + 3 < d ? p[3] : 0.f;                                               \
       }                                                                                  \
     }                                                                                    \
-    if (kt_ == 0 && wid == 0) SP_GLDS(chalf + tm_ * KN_BM + lane * 4, chs + (tr_ & 1) * KN_BM); \
+    if (kt_ == 0 && wid == 0) SP_GLDS_S(chalf + tm_ * KN_BM, (unsigned)lane * 16u, chs_w + (tr_ & 1) * (KN_BM * 4)); \
   } while (0)
 #define KN_STORE(step)                                                                   \
   do {                                                                                   \
@@ -498,7 +504,7 @@ static bool sp_nearest_fused_applicable(int64_t n, int64_t k, int64_t d, int tie
 static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, int32_t cdtype, int64_t ldc,
                                    int64_t n, int64_t k, int64_t d, int64_t* labels, const KmWorkspace& w,
                                    hipStream_t st) {
-  if (ldx > 2147483647LL / KN_BN) SP_FAIL("sp_nearest_center: leading dimension too large for the fused tier");
+  if (ldx > (1LL << 30) / KN_BN) SP_FAIL("sp_nearest_center: leading dimension too large for the fused tier");
   const int64_t kp = w.kp, dp = w.dp;
   SP_HIP(hipMemsetAsync(w.Cf, 0, km_align((size_t)dp * kp * 4), st));
   SP_HIP(hipMemsetAsync(w.cmax2, 0, 512, st));   // cmax2 and amb_count
