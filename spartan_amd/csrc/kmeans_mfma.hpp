@@ -212,16 +212,12 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
     SP_GLDS_LANDED();                                                                    \
   } while (0)
 
-  km_f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  km_f32x16 acc[4][2];                            // (set by the first MFMA of each center block)
   // per point column j (points m0 + wn*64 + j*32 + l31), over the centers this lane has seen
   float best[2] = {INFINITY, INFINITY}, second[2] = {INFINITY, INFINITY};
-  int bcode[2] = {0, 0};                           // best's center, without this lane's 4 * lh
+  // best's center as (center block, position 16 i + 4 q + e inside this lane's 64 rows of the block): the position
+  // is an inline constant of the select (a full center number would cost a v_mov per score)
+  int bpos[2] = {0, 0}, bblk[2] = {0, 0};
   float xs[2] = {0.f, 0.f};                        // partial |x|^2 (this lane's k slots), once per pass
 
   KN_LOAD(0);
@@ -236,35 +232,47 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
     b_frag[c] = (wn * 64 + l31) * KM_BK + 4 * ((lh + 2 * c) ^ sw);
   }
 
+  // One k-step (k-tile t of center block tr).  FIRST: the block's first k-tile, whose first MFMA per accumulator
+  // takes 0 as its C operand -- the accumulators are never zeroed by VALU moves.
   int t = 0;
+  auto kstep = [&](auto first_of_block) {
+    constexpr bool FIRST = decltype(first_of_block)::value;
+    if (t + 1 < steps) KN_LOAD(t + 1);
+    const float* sA = smem + (t & 1) * KN_STAGE;
+    const float* sB = sA + KN_A_FLOATS;
+#pragma unroll
+    for (int c = 0; c < KM_BK / 8; ++c) {
+      km_f32x4 af[4], bf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const km_f32x4*)(sA + a_frag[c] + i * 32 * KM_BK);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *(const km_f32x4*)(sB + b_frag[c] + j * 32 * KM_BK);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xs[j] = __builtin_fmaf(bf[j][s], bf[j][s], xs[j]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (FIRST && c == 0 && s == 0) {
+              const km_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], zero, 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
+          }
+    }
+    if (t + 1 < steps) KN_STORE(t + 1);
+    __syncthreads();
+    ++t;
+  };
   for (int tr = 0; tr < tiles_m; ++tr) {
     const int tm = tm_first + tr;
-    for (int kt = 0; kt < nt; ++kt, ++t) {
-      if (t + 1 < steps) KN_LOAD(t + 1);
-      const float* sA = smem + (t & 1) * KN_STAGE;
-      const float* sB = sA + KN_A_FLOATS;
-#pragma unroll
-      for (int c = 0; c < KM_BK / 8; ++c) {
-        km_f32x4 af[4], bf[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *(const km_f32x4*)(sA + a_frag[c] + i * 32 * KM_BK);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *(const km_f32x4*)(sB + b_frag[c] + j * 32 * KM_BK);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) xs[j] = __builtin_fmaf(bf[j][s], bf[j][s], xs[j]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-      }
-      if (t + 1 < steps) KN_STORE(t + 1);
-      __syncthreads();
-    }
+    kstep(std::true_type());
+    for (int kt = 1; kt < nt; ++kt) kstep(std::false_type());
     // ---- epilogue of center block tm.  Halved scores h = |c|^2/2 - x.c; the rows of a lane ascend with
     // (i, q, e), so `<` keeps the first minimum; invariant best <= second, and the new second best is the
     // median of (best, second, h).
@@ -303,25 +311,34 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
       }
       return;
     }
+    const float before[2] = {best[0], best[1]};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const km_f32x4 ch4 = *(const km_f32x4*)(chb + i * 32 + 8 * q);   // rows i*32 + 8q + 4lh + (0..3)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int code = tm * KN_BM + wm * 128 + i * 32 + 8 * q + e;   // wave-uniform
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float v = ch4[e] - acc[i][j][4 * q + e];
-            const bool better = v < best[j];
-            second[j] = __builtin_amdgcn_fmed3f(best[j], second[j], v);
-            bcode[j] = better ? code : bcode[j];
-            best[j] = fminf(best[j], v);
-            acc[i][j][4 * q + e] = 0.f;
+          for (int h = 0; h < 2; ++h) {
+            // two adjacent rows at a time: |c|^2/2 and the accumulator are both in adjacent registers (one packed
+            // subtraction, no operand shuffling)
+            typedef float km_f32x2 __attribute__((ext_vector_type(2)));
+            const km_f32x2 c2 = {ch4[2 * h], ch4[2 * h + 1]};
+            const km_f32x2 a2 = {acc[i][j][4 * q + 2 * h], acc[i][j][4 * q + 2 * h + 1]};
+            const km_f32x2 v2 = c2 - a2;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+              const float v = v2[o];
+              const bool better = v < best[j];
+              second[j] = __builtin_amdgcn_fmed3f(best[j], second[j], v);
+              bpos[j] = better ? 16 * i + 4 * q + 2 * h + o : bpos[j];
+              best[j] = fminf(best[j], v);
+            }
           }
-        }
       }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bblk[j] = best[j] < before[j] ? tm : bblk[j];
   }
 #undef KN_LOAD
 #undef KN_STORE
@@ -335,7 +352,8 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     float b = best[j], s = second[j];
-    int ix = bcode[j] + 4 * lh;
+    // center = block * 256 + wave half * 128 + i * 32 + q * 8 + lane half * 4 + e
+    int ix = bblk[j] * KN_BM + wm * 128 + (bpos[j] >> 4) * 32 + ((bpos[j] >> 2) & 3) * 8 + (bpos[j] & 3) + 4 * lh;
     const float ob = __shfl_xor(b, 32), os = __shfl_xor(s, 32);
     const int oi = __shfl_xor(ix, 32);
     if (ob < b || (ob == b && oi < ix)) {
