@@ -324,6 +324,21 @@ class NumpyBackend(object):
   def sparse_to_host(self, b):
     return b
 
+  def sparse_parts(self, b):
+    c = sps.csr_matrix(b)
+    c.sum_duplicates()
+    c.sort_indices()
+    return (torch.from_numpy(c.indptr.astype(np.int64)), torch.from_numpy(c.indices.astype(np.int32)),
+            torch.from_numpy(np.ascontiguousarray(c.data)))
+
+  def sparse_parts_empty(self, shape, dtype, nnz):
+    return (torch.empty(int(shape[0]) + 1, dtype=torch.int64), torch.empty(int(nnz), dtype=torch.int32),
+            torch.empty(int(nnz), dtype=_NP2T[np.dtype(dtype)]))
+
+  def sparse_from_parts(self, shape, dtype, parts):
+    indptr, indices, data = (t.numpy() for t in parts)
+    return sps.csr_matrix((data.astype(dtype), indices, indptr), shape=tuple(shape))
+
   def sparse_empty(self, shape, dtype):
     return sps.coo_matrix(tuple(shape), dtype=dtype)     # tile.pyx:74-77
 

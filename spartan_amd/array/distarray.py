@@ -293,10 +293,39 @@ class UpdateBatch(object):
         t.update(be, None if full else dst_slice, piece, array.reducer_fn, owned=owned and full)
 
 
+def _ship_sparse(ctx, outgoing):
+  """Sparse blocks between ranks, device to device.  `outgoing`: {key: (destination ranks, block)} for the blocks
+  this rank sends; every rank calls this at the same point.  Returns {key: block} of what arrived here.
+  The three arrays of each block (row pointers, columns, values) travel in ONE grouped exchange; only the shapes
+  and entry counts go through the control plane first.  (The reference pickles the scipy objects into its RPCs,
+  core.py / rpc/zeromq.py; round 1 all-gathered host objects here.)"""
+  be, world = ctx.backend, ctx.world
+  parts = {k: be.sparse_parts(b) for k, (_, b) in outgoing.items()}
+  mine = {k: (tuple(b.shape), np.dtype(be.dtype_of(b)).str, int(parts[k][1].numel()), sorted(dsts))
+          for k, (dsts, b) in outgoing.items()}
+  sends, recvs, arriving = [], [], {}
+  for src, listing in enumerate(world.all_gather_object(mine)):
+    for k in sorted(listing):
+      shape, dstr, nnz, dsts = listing[k]
+      for dst in dsts:
+        if dst == src:
+          continue
+        if src == world.rank and nnz:
+          sends.extend((dst, t) for t in parts[k])
+          world.stats['sparse_blocks'] += 1
+        if dst == world.rank:
+          bufs = be.sparse_parts_empty(shape, np.dtype(dstr), nnz) if nnz else None
+          arriving[k] = (shape, np.dtype(dstr), bufs)
+          if nnz:
+            recvs.extend((src, t) for t in bufs)
+  world.exchange(sends, recvs)
+  return {k: (be.sparse_from_parts(shape, dt, bufs) if bufs is not None else be.sparse_empty(shape, dt))
+          for k, (shape, dt, bufs) in arriving.items()}
+
+
 def _flush_sparse(self, array, items):
   """Updates of a SPARSE target: blocks whose tile lives on the executing rank merge on the device;
-  blocks for other ranks travel as host (scipy) objects in one object all-gather per kernel -- building a
-  sparse array is the only place this happens (pagerank_sparse-style shuffles), not the iteration loop."""
+  blocks for other ranks travel device to device in one grouped exchange per kernel (_ship_sparse)."""
   ctx = self.ctx
   be = ctx.backend
   world = ctx.world
@@ -321,11 +350,8 @@ def _flush_sparse(self, array, items):
     if owner == world.rank:
       local[k] = piece
     else:
-      outbox[k] = be.sparse_to_host(piece)
-  inbox = {}
-  if crossing:
-    for part in world.all_gather_object(outbox):
-      inbox.update(part)
+      outbox[k] = ([owner], piece)
+  inbox = _ship_sparse(ctx, outbox) if crossing else {}
   for k, (seq, tile_id, dst_slice, exec_rank, owner, src_slice, whole, drv) in enumerate(plan):
     if owner != world.rank:
       continue
@@ -499,9 +525,8 @@ class DistArrayImpl(DistArray):
 
   def _fetch_sparse(self, region, splits, replicated, dst_rank, want):
     """Sparse counterpart of fetch (distarray.py:338-353: the pieces are placed into one sparse matrix).
-    Pieces owned by the destination stay on the device; pieces that have to cross ranks travel as host
-    (scipy) objects in ONE object all-gather -- a slow path kept off the dot / reduce hot loops, where
-    every sparse tile is used by the rank that owns it."""
+    Pieces owned by the destination stay where they are; pieces that have to cross ranks travel device to
+    device in ONE grouped exchange (_ship_sparse)."""
     ctx = self.ctx
     be = ctx.backend
     world = ctx.world
@@ -515,9 +540,9 @@ class DistArrayImpl(DistArray):
     if world.distributed:
       crossing = [i for i in range(len(splits)) if replicated or owners[i] != dst_rank]
       if crossing:   # known identically on every rank
-        mine = {i: be.sparse_to_host(local_piece(i)) for i in crossing if owners[i] == world.rank}
-        for part in world.all_gather_object(mine):
-          remote.update(part)
+        everyone = list(range(world.size))
+        remote = _ship_sparse(ctx, {i: (everyone if replicated else [dst_rank], local_piece(i))
+                                    for i in crossing if owners[i] == world.rank})
     if not want:
       return Absent(region.shape, self.dtype)
     pieces = []

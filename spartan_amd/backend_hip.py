@@ -677,6 +677,19 @@ class HipBackend(object):
   def sparse_to_host(self, b):
     return sparse_mod.to_scipy(b)
 
+  def sparse_parts(self, b):
+    """The three arrays of a sparse tile as they travel between ranks: int64 row pointers, int32 columns, values."""
+    return b.indptr.contiguous(), b.indices.contiguous(), b.data.contiguous()
+
+  def sparse_parts_empty(self, shape, dtype, nnz):
+    """Receive buffers for sparse_parts of a tile of `shape` with `nnz` stored entries."""
+    return (torch.empty(int(shape[0]) + 1, dtype=torch.int64, device=self.device),
+            torch.empty(int(nnz), dtype=torch.int32, device=self.device),
+            torch.empty(int(nnz), dtype=kernels.torch_dtype(dtype), device=self.device))
+
+  def sparse_from_parts(self, shape, dtype, parts):
+    return sparse_mod.CsrTile(shape, dtype, *parts)
+
   def sparse_empty(self, shape, dtype):
     return sparse_mod.empty(shape, dtype, self.device)
 

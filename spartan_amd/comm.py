@@ -280,7 +280,7 @@ class World(object):
     self.transport = transport
     if transport is None and size > 1:
       self.transport = TorchTransport(group, size, rank, staged=False)
-    self.stats = {'p2p_bytes': 0, 'collective_bytes': 0, 'p2p_msgs': 0, 'collectives': 0}
+    self.stats = {'p2p_bytes': 0, 'collective_bytes': 0, 'p2p_msgs': 0, 'collectives': 0, 'sparse_blocks': 0}
     self.note = ''                          # how the transport was chosen (bench.py prints it)
 
   @property

@@ -51,14 +51,17 @@ def run_examples(total_workers):
 
 
 def run_sparse(total_workers):
-  """Sparse arrays across two ranks: tiles are built and used by the rank that owns them (device path);
-  blocks that cross ranks (glom, sparse x sparse joins, row-tiled shuffles) travel as host objects."""
+  """Sparse arrays across two ranks: tiles are built and used by the rank that owns them; blocks that cross ranks
+  (sparse x sparse joins, row-tiled shuffles, fetches of remote regions) travel as their three arrays in grouped
+  exchanges (distarray._ship_sparse) -- only glom() of a sparse result gathers host objects."""
   import json
   from tests import sparse_programs as SP
   here = os.path.join(ROOT, 'tests', 'golden')
   meta = json.load(open(os.path.join(here, 'sparse_meta.json')))
   gold1 = np.load(os.path.join(here, 'sparse_w1.npz'))
   count = 0
+  from spartan_amd import context
+  shipped_before = context.get().world.stats['sparse_blocks']
   for name, build, tol in SP.programs():
     res = build(sp)
     res = res.force() if hasattr(res, 'force') else res
@@ -70,6 +73,8 @@ def run_sparse(total_workers):
     else:
       np.testing.assert_allclose(got, want, rtol=tol[0], atol=tol[1], err_msg=name)
     count += 1
+  # blocks did cross ranks as device arrays (every rank owns tiles other ranks read)
+  assert context.get().world.stats['sparse_blocks'] > shipped_before
   return count
 
 
