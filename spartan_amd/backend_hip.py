@@ -25,6 +25,19 @@ _REDUCER_NAMES = {
 }
 
 
+try:
+  from xxhash import xxh3_64_intdigest as _digest     # ~10 GB/s: 0.05 ms for the 2 MB of k-means centers
+except ImportError:                                     # pragma: no cover
+  from zlib import crc32 as _digest
+
+
+def _content_stamp(view):
+  """A number that changes when the bytes of a (small) driver-side operand do."""
+  if not view.flags['C_CONTIGUOUS']:
+    view = np.ascontiguousarray(view)
+  return (view.shape, view.dtype.str, _digest(memoryview(view).cast('B')))
+
+
 class HipBackend(object):
   name = 'hip'
 
@@ -94,7 +107,7 @@ class HipBackend(object):
     hit = self._np_cache.get(key)
     # the driver may update the array in place between evaluations (`w -= alpha * grad`): the HBM copy is
     # only re-used while the bytes are the same (the reference re-pickles the array into every request)
-    stamp = hash(arr[slices].tobytes()) if arr.nbytes <= (1 << 22) else None
+    stamp = _content_stamp(arr[slices]) if arr.nbytes <= (1 << 22) else None
     if hit is None or hit[0] is not arr or stamp is None or hit[2] != stamp:
       hit = (arr, self.from_numpy(arr[slices]), stamp)
       self._np_cache[key] = hit

@@ -112,8 +112,10 @@ class KMeans(object):
                        reducer=reducer)
     sums = expr.map2((X, labels), (0, 0), fn=kmeans_center_mapper, fn_kw={'centers_count': k},
                      shape=(k, dim), reducer=reducer)
-    counts = counts.optimized().glom()
-    sums = sums.optimized().glom()
+    counts, sums = counts.optimized(), sums.optimized()
+    counts.evaluate()
+    sums.evaluate()            # both joins are launched before the first glom() waits for the device
+    counts, sums = counts.glom(), sums.glom()
     sums, counts = self._finish(sums, counts)
     return sums / counts.reshape(k, 1)
 
