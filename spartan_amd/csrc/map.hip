@@ -102,8 +102,12 @@ static int sp_map_go_static(int sid, const sp_program* p, const sp_inputs& in, v
   switch (sid) {
 #define SP_CASE(ID)                                                                                   \
   case ID:                                                                                            \
-    hipLaunchKernelGGL((sp_map_kernel<float, 4, 1, LINEAR, StaticProg<ID>>), dim3((unsigned)blocks),  \
-                       dim3(SP_BLOCK), 0, st, *p, in, out, (int64_t)0, nvec);                         \
+    if (p->pad & SP_PAD_STREAM)                                                                       \
+      hipLaunchKernelGGL((sp_map_kernel<float, 4, 1, LINEAR, StaticProg<ID>, -1, false, 1>),          \
+                         dim3((unsigned)blocks), dim3(SP_BLOCK), 0, st, *p, in, out, (int64_t)0, nvec); \
+    else                                                                                              \
+      hipLaunchKernelGGL((sp_map_kernel<float, 4, 1, LINEAR, StaticProg<ID>, -1, false, 0>),          \
+                         dim3((unsigned)blocks), dim3(SP_BLOCK), 0, st, *p, in, out, (int64_t)0, nvec); \
     break;
     SP_FOR_EACH_STATIC(SP_CASE)
 #undef SP_CASE
@@ -122,8 +126,12 @@ static int sp_map_go_static_2d(int sid, int mask, const sp_program* p, const sp_
   *handled = true;
 #define SP_CASE2(ID, MSK)                                                                                  \
   if (sid == ID && mask == MSK) {                                                                          \
-    hipLaunchKernelGGL((sp_map_kernel<float, 4, 1, false, StaticProg<ID>, MSK>), dim3((unsigned)blocks),   \
-                       dim3(SP_BLOCK), 0, st, *p, in, out, (int64_t)0, nvec);                              \
+    if (p->pad & SP_PAD_STREAM)                                                                            \
+      hipLaunchKernelGGL((sp_map_kernel<float, 4, 1, false, StaticProg<ID>, MSK, false, 1>),               \
+                         dim3((unsigned)blocks), dim3(SP_BLOCK), 0, st, *p, in, out, (int64_t)0, nvec);    \
+    else                                                                                                   \
+      hipLaunchKernelGGL((sp_map_kernel<float, 4, 1, false, StaticProg<ID>, MSK, false, 0>),               \
+                         dim3((unsigned)blocks), dim3(SP_BLOCK), 0, st, *p, in, out, (int64_t)0, nvec);    \
     SP_CHECK_LAUNCH();                                                                                     \
     return 0;                                                                                              \
   }
@@ -144,8 +152,8 @@ static int sp_map_go_jit(const sp_program* p, const sp_inputs& in, void* out, in
   *handled = false;
   if (!sp_jit_enabled() || p->n_instr == 0 || nvec * V < sp_jit_min_elems()) return 0;
   char expr[176];
-  snprintf(expr, sizeof(expr), "sp_map_kernel<%s, %d, 1, %s, StaticProg<1000>, %d, %s>", sp_cls<T>::name(), V,
-           LINEAR ? "true" : "false", mask, ragged ? "true" : "false");
+  snprintf(expr, sizeof(expr), "sp_map_kernel<%s, %d, 1, %s, StaticProg<1000>, %d, %s, %d>", sp_cls<T>::name(), V,
+           LINEAR ? "true" : "false", mask, ragged ? "true" : "false", (p->pad & SP_PAD_STREAM) ? 1 : 0);
   void* fn = sp_jit_get("map_kernel.hpp", expr, p);
   if (!fn) return 0;
   int64_t blocks = (nvec + SP_BLOCK - 1) / SP_BLOCK;

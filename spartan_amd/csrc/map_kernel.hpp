@@ -13,7 +13,8 @@
 // RAGGED (strided programs whose innermost dimension is not a multiple of V, e.g. a map over the
 // slice x[1:, 1:]): the index space is walked as rows x ceil(inner / V) groups, so a group never
 // crosses a row end; the last group of a row is evaluated element by element.  (U == 1 only.)
-template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1, bool RAGGED = false>
+// NTM: see SP_STREAMS (sp_interp.hpp).
+template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1, bool RAGGED = false, int NTM = 2>
 __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, const sp_inputs in,
                                                           void* __restrict__ out, int64_t start,
                                                           int64_t nvec) {
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
     const int64_t gpr = (inner + V - 1) / V;   // groups per row
     for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK + threadIdx.x; i < nvec; i += stride) {
       int64_t row, g;
-      if (p.pad) {   // index space fits 32 bits
+      if (p.pad & SP_PAD_IDX32) {   // index space fits 32 bits
         const uint32_t r32 = (uint32_t)i / (uint32_t)gpr;
         row = r32;
         g = (uint32_t)i - r32 * (uint32_t)gpr;
@@ -37,12 +38,13 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
       if (col + V <= inner) {
         T res[1][V];
         if constexpr (MASK >= 0) {
-          sp_eval_2d<T, V, P, MASK>(p, in, (uint32_t)row, (uint32_t)col, L0, res[0]);
+          sp_eval_2d<T, V, P, MASK, NTM>(p, in, (uint32_t)row, (uint32_t)col, L0, res[0]);
         } else {
           const int64_t Ls[1] = {L0};
-          sp_eval_u<T, V, 1, false, P>(p, in, Ls, res);
+          sp_eval_u<T, V, 1, false, P, NTM>(p, in, Ls, res);
         }
-        sp_store_vec<T, V>(out, p.out_dtype, L0, res[0]);
+        if (SP_STREAMS(NTM, p)) sp_store_vec<T, V, true>(out, p.out_dtype, L0, res[0]);
+        else sp_store_vec<T, V>(out, p.out_dtype, L0, res[0]);
       } else {
         for (int64_t c = col; c < inner; ++c) {
           T one[1][1];
@@ -73,13 +75,16 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
       const uint32_t cols = (uint32_t)p.shape[1];
       const uint32_t l32 = (uint32_t)L[0];
       const uint32_t row = l32 / cols;
-      sp_eval_2d<T, V, P, MASK>(p, in, row, l32 - row * cols, L[0], res[0]);
+      sp_eval_2d<T, V, P, MASK, NTM>(p, in, row, l32 - row * cols, L[0], res[0]);
     } else {
-      sp_eval_u<T, V, U, LINEAR, P>(p, in, L, res);
+      sp_eval_u<T, V, U, LINEAR, P, NTM>(p, in, L, res);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (u == 0 || full || i + (int64_t)u * SP_BLOCK < nvec) sp_store_vec<T, V>(out, p.out_dtype, L[u], res[u]);
+      if (u == 0 || full || i + (int64_t)u * SP_BLOCK < nvec) {
+        if (SP_STREAMS(NTM, p)) sp_store_vec<T, V, true>(out, p.out_dtype, L[u], res[u]);
+        else sp_store_vec<T, V>(out, p.out_dtype, L[u], res[u]);
+      }
   }
 }
 

@@ -61,17 +61,34 @@ typedef sp_i64x2 sp_i64x2u __attribute__((aligned(8)));
 typedef sp_u8x4 sp_u8x4u __attribute__((aligned(1)));
 typedef sp_u8x2 sp_u8x2u __attribute__((aligned(1)));
 
+constexpr int32_t SP_PAD_IDX32 = 1, SP_PAD_STREAM = 2;
+// How a kernel learns that its launch streams (template parameter NTM of the evaluators): decided when the kernel
+// is chosen (0: no, 1: yes -- the specialised map kernels, whose two forms are separate instantiations) or read
+// from the program's flags at run time (2: reductions, interpreter).
+#define SP_STREAMS(NTM, p) ((NTM) == 1 || ((NTM) == 2 && ((p).pad & SP_PAD_STREAM) != 0))
+constexpr int64_t SP_STREAM_ELEMS = 8LL << 20;   // 32 MiB of fp32 = the aggregate L2
+
 // ---- typed loads: `n` consecutive elements (n == V, or 1) converted to T ----
-template <typename T, int N>
+// NT: the operand is read exactly once by the whole launch (no broadcast dimension), so its lines need not stay in
+// L2: non-temporal vector loads (`global_load_dwordx4 ... nt`).  On the 2 GiB tile this is worth 6.0 -> 6.6-6.8 TB/s
+// for the reductions and 6.25 -> 6.45 TB/s for the maps; a re-read operand (a row vector broadcast down the rows)
+// loses 3 % with it, hence the flag.
+// (a macro, not a function template: deducing the vector type would drop the reduced alignment of the `...u` types)
+// (the empty asm keeps LLVM from merging the non-temporal load with its plain twin in the other arm of a run-time
+// `if (stream)`: merged loads keep only the metadata both have, i.e. lose the hint)
+#define SP_VLD(TYPE, ptr) (NT ? (sp_nt_mark(), __builtin_nontemporal_load((const TYPE*)(ptr))) : *(const TYPE*)(ptr))
+__device__ __forceinline__ void sp_nt_mark() { asm volatile(""); }
+
+template <typename T, int N, bool NT = false>
 __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_t off, T* dst) {
   switch (dt) {
     case SP_F32: {
       const float* p = (const float*)base + off;
       if constexpr (N == 4) {
-        sp_f32x4u v = *(const sp_f32x4u*)p;
+        sp_f32x4u v = SP_VLD(sp_f32x4u, p);
         dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
       } else if constexpr (N == 2) {
-        sp_f32x2u v = *(const sp_f32x2u*)p;
+        sp_f32x2u v = SP_VLD(sp_f32x2u, p);
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -80,10 +97,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     case SP_F64: {
       const double* p = (const double*)base + off;
       if constexpr (N == 4) {
-        sp_f64x2u v0 = *(const sp_f64x2u*)p, v1 = *(const sp_f64x2u*)(p + 2);
+        sp_f64x2u v0 = SP_VLD(sp_f64x2u, p), v1 = SP_VLD(sp_f64x2u, (p + 2));
         dst[0] = (T)v0.x; dst[1] = (T)v0.y; dst[2] = (T)v1.x; dst[3] = (T)v1.y;
       } else if constexpr (N == 2) {
-        sp_f64x2u v = *(const sp_f64x2u*)p;
+        sp_f64x2u v = SP_VLD(sp_f64x2u, p);
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -92,10 +109,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     case SP_I32: {
       const int32_t* p = (const int32_t*)base + off;
       if constexpr (N == 4) {
-        sp_i32x4u v = *(const sp_i32x4u*)p;
+        sp_i32x4u v = SP_VLD(sp_i32x4u, p);
         dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
       } else if constexpr (N == 2) {
-        sp_i32x2u v = *(const sp_i32x2u*)p;
+        sp_i32x2u v = SP_VLD(sp_i32x2u, p);
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -104,10 +121,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     case SP_I64: {
       const int64_t* p = (const int64_t*)base + off;
       if constexpr (N == 4) {
-        sp_i64x2u v0 = *(const sp_i64x2u*)p, v1 = *(const sp_i64x2u*)(p + 2);
+        sp_i64x2u v0 = SP_VLD(sp_i64x2u, p), v1 = SP_VLD(sp_i64x2u, (p + 2));
         dst[0] = (T)v0.x; dst[1] = (T)v0.y; dst[2] = (T)v1.x; dst[3] = (T)v1.y;
       } else if constexpr (N == 2) {
-        sp_i64x2u v = *(const sp_i64x2u*)p;
+        sp_i64x2u v = SP_VLD(sp_i64x2u, p);
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -116,10 +133,10 @@ __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_
     default: {  // SP_BOOL / SP_U8
       const uint8_t* p = (const uint8_t*)base + off;
       if constexpr (N == 4) {
-        sp_u8x4u v = *(const sp_u8x4u*)p;
+        sp_u8x4u v = SP_VLD(sp_u8x4u, p);
         dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
       } else if constexpr (N == 2) {
-        sp_u8x2u v = *(const sp_u8x2u*)p;
+        sp_u8x2u v = SP_VLD(sp_u8x2u, p);
         dst[0] = (T)v.x; dst[1] = (T)v.y;
       } else {
         dst[0] = (T)p[0];
@@ -134,13 +151,20 @@ __device__ __forceinline__ int64_t sp_to_i64(T x) {
 }
 
 // ---- typed stores with the NumPy cast semantics of ndarray.astype ----
-template <typename T, int N>
+// NT: the output of a launch bigger than the L2 (non-temporal 16-B stores: 6.42 -> 6.51 TB/s on the 2 GiB map)
+#define SP_VST(TYPE, ptr, ...)                                        \
+  do {                                                                \
+    const TYPE v_ = __VA_ARGS__;                                      \
+    if constexpr (NT) { sp_nt_mark(); __builtin_nontemporal_store(v_, (TYPE*)(ptr)); } \
+    else *(TYPE*)(ptr) = v_;                                          \
+  } while (0)
+template <typename T, int N, bool NT = false>
 __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off, const T* src) {
   switch (dt) {
     case SP_F32: {
       float* p = (float*)base + off;
       if constexpr (N == 4) {
-        *(sp_f32x4u*)p = sp_f32x4{(float)src[0], (float)src[1], (float)src[2], (float)src[3]};
+        SP_VST(sp_f32x4u, p, {(float)src[0], (float)src[1], (float)src[2], (float)src[3]});
       } else if constexpr (N == 2) {
         *(sp_f32x2u*)p = sp_f32x2{(float)src[0], (float)src[1]};
       } else {
@@ -152,7 +176,7 @@ __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off
 #pragma unroll
       for (int j = 0; j < N; j += 2) {
         if constexpr (N >= 2) {
-          *(sp_f64x2u*)(p + j) = sp_f64x2{(double)src[j], (double)src[j + 1]};
+          SP_VST(sp_f64x2u, p + j, {(double)src[j], (double)src[j + 1]});
         } else {
           p[0] = (double)src[0];
         }
@@ -161,7 +185,7 @@ __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off
     case SP_I32: {
       int32_t* p = (int32_t*)base + off;
       if constexpr (N == 4) {
-        *(sp_i32x4u*)p = sp_i32x4{(int32_t)src[0], (int32_t)src[1], (int32_t)src[2], (int32_t)src[3]};
+        SP_VST(sp_i32x4u, p, {(int32_t)src[0], (int32_t)src[1], (int32_t)src[2], (int32_t)src[3]});
       } else if constexpr (N == 2) {
         *(sp_i32x2u*)p = sp_i32x2{(int32_t)src[0], (int32_t)src[1]};
       } else {
@@ -173,7 +197,7 @@ __device__ __forceinline__ void sp_store_vec(void* base, int32_t dt, int64_t off
 #pragma unroll
       for (int j = 0; j < N; j += 2) {
         if constexpr (N >= 2) {
-          *(sp_i64x2u*)(p + j) = sp_i64x2{(int64_t)src[j], (int64_t)src[j + 1]};
+          SP_VST(sp_i64x2u, p + j, {(int64_t)src[j], (int64_t)src[j + 1]});
         } else {
           p[0] = (int64_t)src[0];
         }
@@ -498,7 +522,7 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
 // Each group has its own 8 x V register file so that every dynamically indexed
 // array stays within the 32 dwords the s_set_gpr_idx path handles (a [U][32]
 // array would be one 32*U-dword alloca and go to scratch).
-template <typename T, int V, int U, bool LINEAR, typename P = DynProg>
+template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int NTM = 2>
 __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& in, const int64_t (&L)[U],
                                           T (&out)[U][V], const int64_t (*pre)[2] = nullptr) {
   T r0[SP_NREG * V], r1[SP_NREG * V], r2[SP_NREG * V], r3[SP_NREG * V];
@@ -533,7 +557,7 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
         idx[u][1] = pre[0][1];
         idx32[u][0] = (uint32_t)pre[0][0];
         idx32[u][1] = (uint32_t)pre[0][1];
-      } else if (p.pad) {
+      } else if (p.pad & SP_PAD_IDX32) {
         uint32_t rem = (uint32_t)L[u];
 #pragma unroll
         for (int d = SP_MAX_DIMS - 1; d >= 0; --d) {
@@ -576,9 +600,16 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
       if constexpr (LINEAR) {
         // dense operand (stride pattern == output) or scalar (all strides 0)
         if (p.in_stride[j][p.ndim - 1] != 0) {
-#define SP_LD(u) sp_load_vec<T, V>(in.p[j], dt, L[u], &r##u[j * V]);
-          SP_U_LIST(SP_LD)
+          // dense: read exactly once
+#define SP_LD(u) sp_load_vec<T, V, true>(in.p[j], dt, L[u], &r##u[j * V]);
+#define SP_LDC(u) sp_load_vec<T, V>(in.p[j], dt, L[u], &r##u[j * V]);
+          if (SP_STREAMS(NTM, p)) {
+            SP_U_LIST(SP_LD)
+          } else {
+            SP_U_LIST(SP_LDC)
+          }
 #undef SP_LD
+#undef SP_LDC
         } else {
           T s;
           sp_load_vec<T, 1>(in.p[j], dt, 0, &s);
@@ -588,10 +619,14 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
         }
       } else {
         const int64_t inner = p.in_stride[j][p.ndim - 1];
+        bool once = SP_STREAMS(NTM, p);   // big launch, no broadcast dimension: every element is read once
+#pragma unroll
+        for (int d = 0; d < SP_MAX_DIMS; ++d)
+          if (d < p.ndim && p.shape[d] > 1 && p.in_stride[j][d] == 0) once = false;
 #define SP_LDS(u)                                                                              \
   {                                                                                            \
     int64_t off = 0;                                                                           \
-    if (p.pad) {                                                                               \
+    if (p.pad & SP_PAD_IDX32) {                                                                \
       uint32_t o32 = 0;                                                                        \
       _Pragma("unroll") for (int d = 0; d < SP_MAX_DIMS; ++d)                                  \
           if (d < p.ndim) o32 += idx32[u][d] * (uint32_t)p.in_stride[j][d];                    \
@@ -600,7 +635,9 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
       _Pragma("unroll") for (int d = 0; d < SP_MAX_DIMS; ++d)                                  \
           if (d < p.ndim) off += idx[u][d] * p.in_stride[j][d];                                \
     }                                                                                          \
-    if (inner == 1 || V == 1) {                                                                \
+    if ((inner == 1 || V == 1) && once) {                                                      \
+      sp_load_vec<T, V, true>(in.p[j], dt, off, &r##u[j * V]);                                 \
+    } else if (inner == 1 || V == 1) {                                                         \
       sp_load_vec<T, V>(in.p[j], dt, off, &r##u[j * V]);                                       \
     } else if (inner == 0) {                                                                   \
       T s;                                                                                     \
@@ -648,7 +685,7 @@ __device__ __forceinline__ void sp_eval(const sp_program& p, const sp_inputs& in
 // and fits 32 bits, operand j is read with ONE 16-B load when bit j of MASK is
 // clear (inner stride 1) and with one broadcast dword when it is set (inner
 // stride 0); offsets are row*s0 + col*s1 in 32-bit arithmetic.
-template <typename T, int V, typename P, int MASK>
+template <typename T, int V, typename P, int MASK, int NTM = 2>
 __device__ __forceinline__ void sp_eval_2d(const sp_program& p, const sp_inputs& in, uint32_t row, uint32_t col,
                                            int64_t L, T (&out)[V]) {
   static_assert(P::kStatic, "sp_eval_2d is for specialised programs");
@@ -664,6 +701,8 @@ __device__ __forceinline__ void sp_eval_2d(const sp_program& p, const sp_inputs&
       sp_load_vec<T, 1>(in.p[j], P::in_dtype(j), (int64_t)off, &s);
 #pragma unroll
       for (int v = 0; v < V; ++v) r0[j * V + v] = s;
+    } else if (SP_STREAMS(NTM, p) && (p.in_stride[j][0] != 0 || p.shape[0] == 1)) {   // not a re-read row vector
+      sp_load_vec<T, V, true>(in.p[j], P::in_dtype(j), (int64_t)off, &r0[j * V]);
     } else {
       sp_load_vec<T, V>(in.p[j], P::in_dtype(j), (int64_t)off, &r0[j * V]);
     }
@@ -678,7 +717,7 @@ __device__ __forceinline__ void sp_eval_2d(const sp_program& p, const sp_inputs&
 // Host side: is the 2-D specialised path applicable, and with which MASK?
 // Returns -1 if not (then the general strided evaluator is used).
 static inline int sp_mask_2d(const sp_program* p, int nin) {
-  if (p->ndim != 2 || !p->pad || p->linear) return -1;
+  if (p->ndim != 2 || !(p->pad & SP_PAD_IDX32) || p->linear) return -1;
   int mask = 0;
   for (int j = 0; j < nin; ++j) {
     const int64_t s1 = p->in_stride[j][1];
@@ -689,13 +728,15 @@ static inline int sp_mask_2d(const sp_program* p, int nin) {
   return mask;
 }
 
-// Host side: the copy of the program handed to a kernel; `pad` carries the
-// "index space fits 32 bits" flag used by the strided evaluator.
+// Host side: the copy of the program handed to a kernel; `pad` carries launch flags: SP_PAD_IDX32 "index space
+// fits 32 bits" (strided evaluator), SP_PAD_STREAM "the launch walks more elements than the L2 holds": operands
+// read exactly once and the output are then accessed non-temporally (see sp_load_vec).
 static inline sp_program sp_prepare_program(const sp_program* p) {
   sp_program q = *p;
   int64_t n = 1;
   for (int d = 0; d < p->ndim; ++d) n *= p->shape[d];
-  q.pad = (n > 0 && n < (1LL << 32)) ? 1 : 0;
+  q.pad = (n > 0 && n < (1LL << 32)) ? SP_PAD_IDX32 : 0;
+  if (n >= SP_STREAM_ELEMS) q.pad |= SP_PAD_STREAM;
   return q;
 }
 
