@@ -371,8 +371,9 @@ __global__ __launch_bounds__(64) void sp_segment_sum_kernel(const T* __restrict_
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int row = __shfl(pidx, u0 + u);
-        if constexpr (V == 1) v[u][0] = Xc[(int64_t)row * ldx];
-        else v[u] = *(const vec_t*)(Xc + (int64_t)row * ldx);
+        // every row is read exactly once: non-temporal (the tile is far bigger than the L2)
+        if constexpr (V == 1) v[u][0] = __builtin_nontemporal_load(Xc + (int64_t)row * ldx);
+        else v[u] = __builtin_nontemporal_load((const vec_t*)(Xc + (int64_t)row * ldx));
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
