@@ -74,10 +74,18 @@ constexpr int64_t SP_STREAM_ELEMS = 8LL << 20;   // 32 MiB of fp32 = the aggrega
 // for the reductions and 6.25 -> 6.45 TB/s for the maps; a re-read operand (a row vector broadcast down the rows)
 // loses 3 % with it, hence the flag.
 // (a macro, not a function template: deducing the vector type would drop the reduced alignment of the `...u` types)
-// (the empty asm keeps LLVM from merging the non-temporal load with its plain twin in the other arm of a run-time
-// `if (stream)`: merged loads keep only the metadata both have, i.e. lose the hint)
-#define SP_VLD(TYPE, ptr) (NT ? (sp_nt_mark(), __builtin_nontemporal_load((const TYPE*)(ptr))) : *(const TYPE*)(ptr))
+// (the empty asm statements on both sides keep LLVM from merging the non-temporal load with its plain twin in the
+// other arm of a run-time `if (stream)` -- hoisted or sunk, a merged load keeps only the metadata both have, i.e.
+// loses the hint)
 __device__ __forceinline__ void sp_nt_mark() { asm volatile(""); }
+#define SP_VLD(TYPE, ptr)                                                  \
+  (NT ? ({                                                                 \
+    sp_nt_mark();                                                          \
+    const TYPE nt_ = __builtin_nontemporal_load((const TYPE*)(ptr));       \
+    sp_nt_mark();                                                          \
+    nt_;                                                                   \
+  })                                                                       \
+      : *(const TYPE*)(ptr))
 
 template <typename T, int N, bool NT = false>
 __device__ __forceinline__ void sp_load_vec(const void* base, int32_t dt, int64_t off, T* dst) {
@@ -155,7 +163,7 @@ __device__ __forceinline__ int64_t sp_to_i64(T x) {
 #define SP_VST(TYPE, ptr, ...)                                        \
   do {                                                                \
     const TYPE v_ = __VA_ARGS__;                                      \
-    if constexpr (NT) { sp_nt_mark(); __builtin_nontemporal_store(v_, (TYPE*)(ptr)); } \
+    if constexpr (NT) { sp_nt_mark(); __builtin_nontemporal_store(v_, (TYPE*)(ptr)); sp_nt_mark(); } \
     else *(TYPE*)(ptr) = v_;                                          \
   } while (0)
 template <typename T, int N, bool NT = false>
