@@ -13,8 +13,8 @@
 // RAGGED (strided programs whose innermost dimension is not a multiple of V, e.g. a map over the
 // slice x[1:, 1:]): the index space is walked as rows x ceil(inner / V) groups, so a group never
 // crosses a row end; the last group of a row is evaluated element by element.  (U == 1 only.)
-// NTM: see SP_STREAMS (sp_interp.hpp).
-template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1, bool RAGGED = false, int NTM = 2>
+// NTM: see SP_STREAMS (sp_interp.hpp); the interpreter kernels (dispatch-bound) do without the hint.
+template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int MASK = -1, bool RAGGED = false, int NTM = 0>
 __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, const sp_inputs in,
                                                           void* __restrict__ out, int64_t start,
                                                           int64_t nvec) {

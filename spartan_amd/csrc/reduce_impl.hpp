@@ -24,6 +24,10 @@
 
 #include "sp_interp.hpp"
 
+// Streaming policy of the evaluators inside the reduction kernels (SP_STREAMS, sp_interp.hpp): the specialised
+// kernels follow the program's flag at run time, the interpreter kernels (dispatch-bound) do without the hint.
+#define SP_RED_NTM(P) (P::kStatic ? 2 : 0)
+
 #ifndef __HIPCC_RTC__
 int sp_validate_program(const sp_program* p);
 int sp_static_enabled();
@@ -186,11 +190,11 @@ __device__ __forceinline__ T sp_eval_one(const sp_program& p, const sp_inputs& i
                                          bool have_rc) {
   T x[1][1];
   if constexpr (MASK >= 0) {
-    sp_eval_2d<T, 1, P, MASK>(p, in, (uint32_t)row, (uint32_t)col, L, x[0]);
+    sp_eval_2d<T, 1, P, MASK, SP_RED_NTM(P)>(p, in, (uint32_t)row, (uint32_t)col, L, x[0]);
   } else {
     const int64_t Ls[1] = {L};
     const int64_t rc[1][2] = {{row, col}};
-    sp_eval_u<T, 1, 1, LINEAR, P>(p, in, Ls, x, have_rc ? rc : nullptr);
+    sp_eval_u<T, 1, 1, LINEAR, P, SP_RED_NTM(P)>(p, in, Ls, x, have_rc ? rc : nullptr);
   }
   return x[0][0];
 }
@@ -220,10 +224,10 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
       }
       T x[U][V];
       if constexpr (MASK >= 0) {
-        sp_eval_2d<T, V, P, MASK>(p, in, (uint32_t)o, (uint32_t)a, L[0], x[0]);
+        sp_eval_2d<T, V, P, MASK, SP_RED_NTM(P)>(p, in, (uint32_t)o, (uint32_t)a, L[0], x[0]);
       } else {
         const int64_t rc[1][2] = {{o, a}};   // (row, column) when the program space is [O, A]
-        sp_eval_u<T, V, U, LINEAR, P>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr);
+        sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -277,10 +281,10 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
       }
       T x[U][V];
       if constexpr (MASK >= 0) {
-        sp_eval_2d<T, V, P, MASK>(p, in, (uint32_t)o, (uint32_t)a, L[0], x[0]);
+        sp_eval_2d<T, V, P, MASK, SP_RED_NTM(P)>(p, in, (uint32_t)o, (uint32_t)a, L[0], x[0]);
       } else {
         const int64_t rc[1][2] = {{o, a}};
-        sp_eval_u<T, V, U, LINEAR, P>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr);
+        sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -355,10 +359,10 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
         }
         T x[U][V];
         if constexpr (MASK >= 0) {
-          sp_eval_2d<T, V, P, MASK>(p, in, (uint32_t)(o * A + a), (uint32_t)c, L[0], x[0]);
+          sp_eval_2d<T, V, P, MASK, SP_RED_NTM(P)>(p, in, (uint32_t)(o * A + a), (uint32_t)c, L[0], x[0]);
         } else {
           const int64_t rc[1][2] = {{o * A + a, c}};   // (row, column) when the program space is [O*A, I]
-          sp_eval_u<T, V, U, LINEAR, P>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr);
+          sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_tail_kernel(const sp_
         const int64_t L[1] = {(o * A + a) * I + c};
         const int64_t rc[1][2] = {{o * A + a, c}};
         T x[1][1];
-        sp_eval_u<T, 1, 1, LINEAR, DynProg>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr);
+        sp_eval_u<T, 1, 1, LINEAR, DynProg, 0>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr);
         acc.add(op, x[0][0], a);
       }
     }
