@@ -63,14 +63,12 @@ static inline size_t sp_dtype_size(int32_t dt) {
 // does not reliably put that wait in front of a barrier inside a loop (seen missing in the PIPE loop's .s), so
 // it is stated here.
 #define SP_GLDS_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define SP_GLDS(gptr, lptr)                                                                         \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-// The same load as `global_load_lds_dwordx4 v_off, s[base:base+1]`: a wave-uniform 64-bit base in SGPRs plus an
-// unsigned 32-bit per-lane byte offset, LDS target (a wave-uniform byte address) through M0.  hipcc selects only the
-// 64-bit-VGPR-address form for the builtin -- one 64-bit VALU add per load and per k-tile, on the same address
-// register pair, between the MFMAs -- whereas here nothing but a scalar add precedes the load.  A kernel that uses
-// this must not use the builtin as well (the compiler does not know M0 changed).
+// `global_load_lds_dwordx4 v_off, s[base:base+1]`: a wave-uniform 64-bit base in SGPRs plus an unsigned 32-bit
+// per-lane byte offset, LDS target (a wave-uniform byte address) through M0.  Written in asm because hipcc selects
+// only the 64-bit-VGPR-address form for __builtin_amdgcn_global_load_lds -- one 64-bit VALU add per load and per
+// k-tile, on ONE address register pair, plus a v_readfirstlane for M0, between the MFMAs (8192^3 GEMM: 141 vs 150
+// TFLOP/s) -- whereas here nothing but scalar adds precede the load.  A kernel that uses these macros must not use
+// the builtin as well (the compiler does not know M0 changed).
 #define SP_GLDS_S(base, voff, lds_addr)                                                             \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                       \
                :: "s"(lds_addr), "v"(voff), "s"(base) : "memory")
