@@ -113,3 +113,27 @@ def test_trees_larger_than_one_kernel_are_carved_into_several_launches():
     assert ctx.backend.launches - before > 2 * 2        # more than one launch per tile
   finally:
     sp.shutdown()
+
+
+@pytest.mark.parametrize('shape', [(3001, 3001), (2048, 4100), (2896, 2896)])
+def test_streaming_policy_does_not_change_results(shape):
+  """Above 8 M elements a launch reads operands it touches once, and writes map outputs, non-temporally
+  (SP_PAD_STREAM): integer-valued data, so every result is exact -- a ragged inner dimension, an aligned one,
+  row / column broadcasts (which keep the default policy), reductions along both axes and argmax."""
+  sp.initialize('hip', num_workers=1)
+  try:
+    rows, cols = shape
+    rng = np.random.RandomState(11)
+    x = rng.randint(-8, 9, size=shape).astype(np.float32)
+    row = rng.randint(-3, 4, size=(cols,)).astype(np.float32)
+    col = rng.randint(-3, 4, size=(rows, 1)).astype(np.float32)
+    X, R, C = sp.from_numpy(x), sp.from_numpy(row), sp.from_numpy(col)
+    np.testing.assert_array_equal((X * R + C - X).optimized().glom(), x * row + col - x)
+    np.testing.assert_array_equal((X * X + X).optimized().glom(), x * x + x)
+    np.testing.assert_array_equal(sp.sum(X * R, axis=0).optimized().glom(), (x * row).sum(axis=0))
+    np.testing.assert_array_equal(sp.sum(X + C, axis=1).optimized().glom(), (x + col).sum(axis=1))
+    np.testing.assert_array_equal(sp.sum(X).glom(), x.sum(dtype=np.float64).astype(np.float32))
+    np.testing.assert_array_equal(sp.argmax(X, axis=1).glom(), np.argmax(x, axis=1))
+    np.testing.assert_array_equal(sp.argmin(X, axis=0).glom(), np.argmin(x, axis=0))
+  finally:
+    sp.shutdown()
