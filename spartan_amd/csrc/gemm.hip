@@ -590,11 +590,17 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
                     ((((uintptr_t)d_A) | ((uintptr_t)d_B)) & 15) == 0;
   int v = sp_gemm_variant();
   if (v < 0) {
-    // default: big macro-tile for big problems, smaller tile to fill the chip otherwise
-    // (the 256 x 128 tile fetches its k-tiles straight into LDS when the operands allow it -- case 6 checks --
-    //  141.5 vs 139.7 TFLOP/s at 8192^3, profiles/r02_notes.md)
-    const int64_t big_tiles = ((M + 255) / 256) * ((N + 127) / 128);
-    v = big_tiles >= 256 ? 6 : 1;
+    // default: the macro-tile whose workgroups keep the CUs busy for the shorter time.  A CU runs ceil(tiles / CUs)
+    // workgroups of its share; a 128 x 128 workgroup does half the work of a 256 x 128 one at ~0.93 of its rate
+    // (4 resident workgroups per CU instead of 2), and a workgroup alone on its CU loses ~10 % (nothing covers its
+    // barriers).  Measured (tools/gemm_shapes.py, TFLOP/s, 256x128 vs 128x128): 8192^3 150 / 146, 4096^3 145 / 140,
+    // 3072^3 84 / 109, 1536x8192x4096 111 / 140, 4096x2048x4096 136 / 140, 2048^3 67 / 126.
+    // Both fetch their k-tiles straight into LDS when the operands allow it (cases 6 / 7 check).
+    const int64_t tb = ((M + 255) / 256) * ((N + 127) / 128), ts = ((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t cb = (tb + SP_CUS - 1) / SP_CUS, cs = (ts + SP_CUS - 1) / SP_CUS;
+    const double cost_b = 2.0 * (double)cb * (cb == 1 ? 1.14 : 1.0);
+    const double cost_s = (double)cs / 0.93 * (cs == 1 ? 1.08 : 1.0);
+    v = cost_b <= cost_s ? 6 : 7;
   }
   switch (v) {
     case 0: return sp_gemm_launch<256, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
