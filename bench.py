@@ -21,6 +21,13 @@ baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thr
 import argparse
 import os as _os
 _os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC between the per-GPU processes (RCCL)
+# stdout carries ONE JSON line and nothing else.  Native libraries write there too -- RCCL's version banner
+# (NCCL_DEBUG=VERSION is set on the GPU boxes; it sits in the C stdout buffer until exit), gloo's "[Gloo] Rank ..."
+# lines -- so file descriptor 1 is pointed at stderr for the life of the process and the line is written to the
+# saved descriptor.
+_os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
+_REAL_STDOUT = _os.dup(1)
+_os.dup2(2, 1)
 import json
 import os
 import sys
@@ -260,10 +267,8 @@ def guarded(fn, timeout_s, rank, fallback_line):
 
   def watchdog():
     if not done.wait(timeout_s):
-      if rank == 0:
-        fallback_line['extras_error'] = 'FAILED: section did not complete within %d s (hung collective?)' % timeout_s
-        print(json.dumps(fallback_line))
-        sys.stdout.flush()
+      fallback_line['extras_error'] = 'FAILED: section did not complete within %d s (hung collective?)' % timeout_s
+      _emit(fallback_line, rank)
       os._exit(0)   # the headline (measured before this section) stands; the failure is in the line itself
   threading.Thread(target=watchdog, daemon=True).start()
   try:
@@ -343,6 +348,13 @@ def cpu_baseline():
                     '%dx%d, k=%d -- scaled from the BASELINE shapes to stay within ~20 s' %
                     (W, n, rows, cols, ln, ld, kn, kd, kk),
           'wall_seconds': round(time.perf_counter() - t_all, 1)}
+
+
+def _emit(line, rank):
+  """The ONE line of stdout, from rank 0 (see _REAL_STDOUT above)."""
+  sys.stdout.flush()
+  if rank == 0:
+    os.write(_REAL_STDOUT, (json.dumps(line) + '\n').encode())
 
 
 def main():
@@ -470,9 +482,7 @@ def main():
       torch.cuda.empty_cache()
       line['hbm_dist'] = guarded(lambda: dist_section(ctx), 240, world.rank, dict(line))
   world.barrier()
-  if world.rank == 0:
-    print(json.dumps(line))
-    sys.stdout.flush()
+  _emit(line, world.rank)
   sp.shutdown()
   world.close()
   if world.distributed:
