@@ -21,13 +21,7 @@ baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thr
 import argparse
 import os as _os
 _os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC between the per-GPU processes (RCCL)
-# stdout carries ONE JSON line and nothing else.  Native libraries write there too -- RCCL's version banner
-# (NCCL_DEBUG=VERSION is set on the GPU boxes; it sits in the C stdout buffer until exit), gloo's "[Gloo] Rank ..."
-# lines -- so file descriptor 1 is pointed at stderr for the life of the process and the line is written to the
-# saved descriptor.
-_os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
-_REAL_STDOUT = _os.dup(1)
-_os.dup2(2, 1)
+_os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')     # (see _claim_stdout)
 import json
 import os
 import sys
@@ -350,14 +344,30 @@ def cpu_baseline():
           'wall_seconds': round(time.perf_counter() - t_all, 1)}
 
 
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+  """stdout carries ONE JSON line and nothing else.  Native libraries write there too -- RCCL's version banner
+  (NCCL_DEBUG=VERSION is set on the GPU boxes; it sits in the C stdout buffer until exit), gloo's "[Gloo] Rank ..."
+  lines -- so file descriptor 1 is pointed at stderr for the rest of the process and the line is written to the
+  saved descriptor."""
+  global _REAL_STDOUT
+  if _REAL_STDOUT is None:
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
 def _emit(line, rank):
-  """The ONE line of stdout, from rank 0 (see _REAL_STDOUT above)."""
+  """The ONE line of stdout, from rank 0."""
   sys.stdout.flush()
   if rank == 0:
-    os.write(_REAL_STDOUT, (json.dumps(line) + '\n').encode())
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + '\n').encode())
 
 
 def main():
+  _claim_stdout()
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
