@@ -158,7 +158,7 @@ def kmeans_section(ctx):
   cdev = ctx.backend.from_numpy(centers)
   labels = torch.empty(n, dtype=torch.int64, device=x.device)
   out = {'tile': '%dx%d fp32, k=%d' % (n, d, k)}
-  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels), 5, warmup=2)
+  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels), 20, warmup=3)
   out['assign_ms'] = round(ms, 3)
   out['assign_TFLOPs'] = round(2.0 * n * k * d / ms / 1e9, 1)          # 2*N*K*D flop
   out['assign_frac_of_mfma_peak'] = round(2.0 * n * k * d / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)
