@@ -21,15 +21,19 @@ def _free_port():
 
 
 def _run_two_ranks(workers, extra=()):
+  _run_ranks(2, 'mp_worker.py', [str(workers)] + list(extra))
+
+
+def _run_ranks(size, script, args=()):
   port = _free_port()
   procs = []
-  for rank in range(2):
+  for rank in range(size):
     env = dict(os.environ)
-    env.update({'RANK': str(rank), 'WORLD_SIZE': '2', 'LOCAL_RANK': str(rank),
+    env.update({'RANK': str(rank), 'WORLD_SIZE': str(size), 'LOCAL_RANK': str(rank),
                 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
                 'OMP_NUM_THREADS': '1', 'GLOO_SOCKET_IFNAME': 'lo'})
-    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'mp_worker.py'), str(workers)] +
-                                  list(extra), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT))
+    procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', script)] + list(args),
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT))
   outs = []
   for p in procs:
     try:
@@ -47,6 +51,12 @@ def _run_two_ranks(workers, extra=()):
 @pytest.mark.parametrize('workers', [2, 4])
 def test_two_ranks_gloo(workers):
   _run_two_ranks(workers)
+
+
+@pytest.mark.parametrize('size', [3, 4])
+def test_ksplit_pipeline_more_ranks(size):
+  """The K-split dot pipeline, the reductions' collectives and a k-means iteration at 3 and 4 ranks."""
+  _run_ranks(size, 'mp_ksplit_worker.py')
 
 
 @pytest.mark.gpu
