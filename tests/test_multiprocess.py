@@ -53,9 +53,9 @@ def test_two_ranks_gloo(workers):
   _run_two_ranks(workers)
 
 
-@pytest.mark.parametrize('size', [3, 4])
+@pytest.mark.parametrize('size', [3, 4, 8])
 def test_ksplit_pipeline_more_ranks(size):
-  """The K-split dot pipeline, the reductions' collectives and a k-means iteration at 3 and 4 ranks."""
+  """The K-split dot pipeline, the reductions' collectives and a k-means iteration at 3, 4 and 8 ranks."""
   _run_ranks(size, 'mp_ksplit_worker.py')
 
 
