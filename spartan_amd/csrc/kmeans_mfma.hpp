@@ -178,10 +178,16 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
   const int steps = nt * tiles_m;
   km_f32x4 rb[BP];
 
-  // request k-step `step` (into stage step & 1); KN_STORE completes it on the register path
+  // request k-step `step` (into stage step & 1); KN_STORE completes it on the register path.  The steps are
+  // requested in order, so (center block, k-tile) of the next request are two counters (no division per k-step).
+  int ld_tr = 0, ld_kt = 0;
 #define KN_LOAD(step)                                                                    \
   do {                                                                                   \
-    const int tr_ = (step) / nt, kt_ = (step) - tr_ * nt;                                \
+    const int tr_ = ld_tr, kt_ = ld_kt;                                                  \
+    if (++ld_kt == nt) {                                                                 \
+      ld_kt = 0;                                                                         \
+      ++ld_tr;                                                                           \
+    }                                                                                    \
     const int tm_ = tm_first + tr_;                                                      \
     const int k0_ = kt_ * KM_BK;                                                         \
     const float* Ak_ = Cf + (int64_t)tm_ * KN_BM * dp + k0_;                             \
