@@ -459,6 +459,33 @@ __global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_kernel(
       SP_GLDS_LANDED();
       __syncthreads();    // tile t+1 has landed and every wave is done reading stage t
     }
+    // K tail (K % 16 != 0): the last, partial k-tile goes through registers into stage 0 in the same two images,
+    // zero beyond K in BOTH operands (so that whatever lies behind a row end never meets a product)
+    const int ktail = K - nt * BK;
+    if (ktail > 0) {
+      const int k0 = nt * BK;
+      for (int e = tid; e < BM * BK; e += Cfg::THREADS) {
+        const int r = e / BK, kk = e % BK;
+        int row = m0 + r;
+        if (row > M - 1) row = M - 1;
+        const float v = kk < ktail ? A[(int64_t)row * lda + k0 + kk] : 0.f;
+        smem[r * BK + (((kk >> 2) ^ ((r >> 2) & 3)) << 2) + (kk & 3)] = v;
+      }
+      for (int e = tid; e < BK * BN; e += Cfg::THREADS) {
+        const int kk = e / BN, c = e % BN;
+        int col = n0 + c;
+        if (col > N - 1) col = N - 1;
+        smem[Cfg::A_FLOATS + kk * BN + c] = kk < ktail ? B[(int64_t)(k0 + kk) * ldb + col] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        f32x4 af[TM];
+        float bf[TN][4];
+        SP_FRAGS(af, bf, 0, c);
+        SP_MFMAS(af, bf);
+      }
+    }
   }
 #if SP_GEMM_ABLATE
   // Timing-only variants (SP_GEMM_VARIANT 16..23, results are WRONG by construction): which part of the k-loop the
@@ -612,7 +639,7 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
     case 5: return sp_gemm_launch<256, 128, 32, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     // direct-to-LDS k-tiles (preconditions checked here; otherwise the register-staged kernel of the same tile)
     case 6: case 9: case 11:
-      if (fast && K % 16 == 0 && (int64_t)256 * lda < (1LL << 30) && (int64_t)16 * ldb < (1LL << 30)) {
+      if (fast && K >= 16 && (K % 16 == 0 || v == 6) && (int64_t)256 * lda < (1LL << 30) && (int64_t)16 * ldb < (1LL << 30)) {
         if (v == 6) return sp_gemm_glds_launch<256, 128, 2, 2, 0, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
         if (v == 11) return sp_gemm_glds_launch<256, 128, 2, 2, 3, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
         // (SP_GEMM_VARIANT only) register double-buffered fragments, barrier between the k-tile's halves:
@@ -627,7 +654,7 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
 #undef SP_ABL_CASE
 #endif
     case 7:
-      if (fast && K % 16 == 0 && (int64_t)128 * lda < (1LL << 30) && (int64_t)16 * ldb < (1LL << 30))
+      if (fast && K >= 16 && (int64_t)128 * lda < (1LL << 30) && (int64_t)16 * ldb < (1LL << 30))
         return sp_gemm_glds_launch<128, 128, 2, 2, 0, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
       return sp_gemm_launch<128, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     default: SP_FAIL("sp_gemm_f32: unknown SP_GEMM_VARIANT=%d", v);

@@ -10,7 +10,7 @@ t0 = time.time()
 for it in range(300):
   M = int(rng.choice([1, 7, 128, 129, 255, 256, 257, 384, 1000, 1024, 2048, 3072, 4100]))
   N = int(rng.choice([1, 4, 12, 128, 132, 256, 260, 1000, 1024, 2048, 3072]))
-  K = int(rng.choice([1, 8, 16, 17, 48, 64, 250, 256, 1024, 4096]))
+  K = int(rng.choice([1, 8, 16, 17, 20, 36, 48, 64, 100, 250, 256, 1000, 1024, 4096, 5000]))
   padA, padB, padC = (int(rng.choice([0, 0, 4, 3])) for _ in range(3))
   a = rng.randint(-4, 5, size=(M, K)).astype(np.float32)
   b = rng.randint(-4, 5, size=(K, N)).astype(np.float32)
