@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void sp_centers_prep_kernel(const TC* __restri
 // The k-tiles go from global memory straight into LDS (global_load_lds_dwordx4, as in gemm.hip's
 // sp_gemm_glds_kernel: no staging registers, no ds_write pass): both images are [row][16] unpadded, chunk q of row
 // r in slot q ^ ((r >> 2) & 3) so that the 16-B fragment reads stay conflict-free, and the |c|^2/2 slice of a
-// center block is one more 1 KiB piece.  Point rows that are not 16-B aligned or not whole k-steps long
-// (FAST = false) take the register path for the point tile only, into the same image.
+// center block is one more 1 KiB piece.  The last k-tile of a feature count that is not a multiple of 16, and every
+// k-tile of point rows that are not 16-B aligned (FAST = false), take the register path for the point tile only,
+// into the same image.
 constexpr int KN_BM = 256;                       // centers per block (KM_BN_MAX: kp is a multiple of it)
 constexpr int KN_BN = 128;                       // points per workgroup
 constexpr int KN_A_FLOATS = KN_BM * KM_BK;       // 4096: rows of 16 floats, UNPADDED (see the k-tile loads below)
@@ -151,23 +152,33 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
     a_off[j] = (unsigned)(row * dp + ((slot & 3) ^ ((row >> 2) & 3)) * 4) * 4u;
   }
   const float* __restrict__ Xblk = RECHECK ? X : X + (int64_t)m0 * ldx;
+  // Point tile, two ways.  FAST (rows 16-B aligned): whole k-tiles go straight into LDS like the centers (b_off:
+  // piece slots as for A); the last, partial k-tile of a feature count that is not a multiple of 16 -- and every
+  // k-tile when FAST is off -- goes through registers with per-element guards (r_off / b_lds: thread e owns chunk
+  // e % 4 of row e / 4), zero beyond d.
   typename std::conditional<RECHECK, int64_t, unsigned>::type b_off[BP];
+  typename std::conditional<RECHECK, int64_t, int>::type r_off[BP];
   int b_lds[BP];                                  // (register path) where this thread's 16 B go
-#pragma unroll
-  for (int j = 0; j < BP; ++j) {
-    // FAST: piece slots as for A; register path: thread e owns chunk e % 4 of row e / 4 (its guards are per k)
-    const int slot = FAST ? (wid * BP + j) * 64 + lane : tid + j * THREADS;
-    int row = slot >> 2;
-    const int q = FAST ? (slot & 3) ^ ((row >> 2) & 3) : (slot & 3);
-    b_lds[j] = row * KM_BK + ((slot & 3) ^ (FAST ? 0 : ((row >> 2) & 3))) * 4;
+  auto row_offset = [&](int row) {                // floats from Xblk to the start of tile row `row`
     if constexpr (RECHECK) {
       const int listed_row = m0 + row < listed ? m0 + row : listed - 1;   // tail: repeat the last listed point
-      b_off[j] = (int64_t)amb_rows[listed_row] * ldx + q * 4;
+      return (int64_t)amb_rows[listed_row] * ldx;
     } else {
       if (m0 + row > n - 1) row = n - 1 - m0;     // clamp: results of points >= n are discarded
-      b_off[j] = (unsigned)(row * (int)ldx + q * 4) * (FAST ? 4u : 1u);   // FAST: bytes; register path: floats
+      return row * (int)ldx;
     }
+  };
+#pragma unroll
+  for (int j = 0; j < BP; ++j) {
+    const int rs = tid + j * THREADS, rrow = rs >> 2;
+    b_lds[j] = rrow * KM_BK + ((rs & 3) ^ ((rrow >> 2) & 3)) * 4;
+    r_off[j] = row_offset(rrow) + (rs & 3) * 4;
+    const int fs = (wid * BP + j) * 64 + lane, frow = fs >> 2;
+    const auto f = row_offset(frow) + ((fs & 3) ^ ((frow >> 2) & 3)) * 4;
+    if constexpr (RECHECK) b_off[j] = f;          // floats, 64-bit (gathered rows)
+    else b_off[j] = (unsigned)f * 4u;             // bytes off the scalar base
   }
+  bool b_in_regs = false;                         // the k-tile being requested is a register one
   const unsigned sA_w = SP_LDS_ADDR(smem) + wid * (AP * 1024);      // this wave's pieces inside a stage (bytes)
   const unsigned sB_w = SP_LDS_ADDR(smem) + KN_A_FLOATS * 4 + wid * (BP * 1024);
   const unsigned chs_w = SP_LDS_ADDR(chs);
@@ -193,14 +204,19 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
     const float* Ak_ = Cf + (int64_t)tm_ * KN_BM * dp + k0_;                             \
     const unsigned dA_ = sA_w + ((step) & 1) * (KN_STAGE * 4);                           \
     _Pragma("unroll") for (int j = 0; j < AP; ++j) SP_GLDS_S(Ak_, a_off[j], dA_ + j * 1024); \
-    _Pragma("unroll") for (int j = 0; j < BP; ++j) {                                     \
-      if constexpr (FAST && RECHECK) {                                                   \
-        SP_GLDS_V(Xblk + k0_ + b_off[j], sB_w + ((step) & 1) * (KN_STAGE * 4) + j * 1024); \
-      } else if constexpr (FAST) {                                                       \
-        SP_GLDS_S(Xblk + k0_, b_off[j], sB_w + ((step) & 1) * (KN_STAGE * 4) + j * 1024); \
-      } else {                                                                           \
+    b_in_regs = !FAST || k0_ + KM_BK > d;                                                \
+    if (!b_in_regs) {                                                                    \
+      _Pragma("unroll") for (int j = 0; j < BP; ++j) {                                   \
+        if constexpr (RECHECK) {                                                         \
+          SP_GLDS_V(Xblk + k0_ + b_off[j], sB_w + ((step) & 1) * (KN_STAGE * 4) + j * 1024); \
+        } else {                                                                         \
+          SP_GLDS_S(Xblk + k0_, b_off[j], sB_w + ((step) & 1) * (KN_STAGE * 4) + j * 1024); \
+        }                                                                                \
+      }                                                                                  \
+    } else {                                                                             \
+      _Pragma("unroll") for (int j = 0; j < BP; ++j) {                                   \
         const int kk = k0_ + ((tid + j * THREADS) & 3) * 4;                              \
-        const float* p = Xblk + k0_ + b_off[j];                                          \
+        const float* p = Xblk + k0_ + r_off[j];                                          \
         rb[j].x = kk + 0 < d ? p[0] : 0.f;                                               \
         rb[j].y = kk + 1 < d ? p[1] : 0.f;                                               \
         rb[j].z = kk + 2 < d ? p[2] : 0.f;                                               \
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
   } while (0)
 #define KN_STORE(step)                                                                   \
   do {                                                                                   \
-    if constexpr (!FAST) {                                                               \
+    if (b_in_regs) {                                                                     \
       float* sB_ = smem + ((step) & 1) * KN_STAGE + KN_A_FLOATS;                         \
       _Pragma("unroll") for (int j = 0; j < BP; ++j) *(km_f32x4*)(sB_ + b_lds[j]) = rb[j]; \
     }                                                                                    \
@@ -540,8 +556,8 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
     hipLaunchKernelGGL((sp_centers_prep_kernel<double>), dim3(pblocks), dim3(256), 0, st, (const double*)C, ldc, (int)k,
                        (int)d, (int)kp, (int)dp, w.Cf, w.cn, w.cmax2);
   SP_CHECK_LAUNCH();
-  // direct-to-LDS loads of the points need whole k-steps inside a row and 16-B alignment
-  const bool fast = (d == dp) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+  // direct-to-LDS loads of the points need 16-B aligned rows (a partial last k-tile goes through registers)
+  const bool fast = (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
   const int64_t blocks = (n + KN_BN - 1) / KN_BN, tiles = kp / KN_BM;
   // whole rounds walk all centers per workgroup; the workgroups of the partial last round are split over the centers
   // when that shortens it: `rem` workgroups of `tiles` blocks become rem * split of `per` blocks
@@ -586,7 +602,7 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
 
 // Second pass over the listed points: marks the centers inside each point's error window (see the kernel).
 static int sp_nearest_mark_candidates(const float* X, int64_t ldx, int64_t d, const KmWorkspace& w, hipStream_t st) {
-  const bool fast = (d == w.dp) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+  const bool fast = (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
   const dim3 grid((unsigned)((w.cand_cap + KN_BN - 1) / KN_BN), (unsigned)(w.kp / KN_BM));
   if (fast)
     hipLaunchKernelGGL((sp_nearest_nt_kernel<true, true>), grid, dim3(256), 0, st, X, ldx, w.Cf, w.cn, w.cmax2,

@@ -566,7 +566,8 @@ def test_nearest_center_exact_is_cdist_argmin(n, k, d, xdt, cdt):
   np.testing.assert_array_equal(_nearest(x, c, _hip.NEAREST_EXACT), want)
 
 
-@pytest.mark.parametrize('n,k,d', [(5000, 300, 64), (4097, 129, 50), (3000, 1024, 256), (2048, 16, 8), (130, 5, 3)])
+@pytest.mark.parametrize('n,k,d', [(5000, 300, 64), (4097, 129, 50), (3000, 1024, 256), (2048, 16, 8), (130, 5, 3),
+                                   (6000, 520, 100), (3000, 260, 36)])   # aligned rows, partial last k-tile
 def test_nearest_center_fused_equals_exact(n, k, d):
   """The MFMA tier + exact re-check of near ties gives the exact tier's labels, bit for bit."""
   from scipy.spatial.distance import cdist
