@@ -351,7 +351,10 @@ def test_slice_copy():
 
 # ---------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('mnk', [(256, 128, 16), (512, 512, 512), (100, 60, 30), (1000, 24, 37),
-                                 (257, 129, 17), (64, 2000, 2000), (1250, 1024, 256), (1, 1, 1)])
+                                 (257, 129, 17), (64, 2000, 2000), (1250, 1024, 256), (1, 1, 1),
+                                 # aligned rows, K not a multiple of 16: the direct-to-LDS kernels' register tail,
+                                 # 128 x 128 and 256 x 128 macro-tiles
+                                 (300, 256, 100), (2048, 2048, 40), (4096, 4096, 20), (513, 260, 1000)])
 def test_gemm_integer_valued_exact(mnk):
   # small-integer operands: every partial sum is exact in fp32, so the result
   # must be bit-identical to NumPy (the reference tests use arange/ones inputs,
