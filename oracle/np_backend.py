@@ -242,12 +242,6 @@ class NumpyBackend(object):
       out[i] = pts[lab == i].sum(axis=0)
     return self._wrap(out)
 
-  def weighted_bincount(self, labels, weights, k):
-    """statistics.py:108-111."""
-    self.launches += 1
-    return self._wrap(np.bincount(_np(labels).reshape(-1).astype(np.int64), weights=_np(weights).reshape(-1),
-                                  minlength=int(k))[:int(k)])
-
   def concat(self, a, b, axis=0):
     """manipulation.py:51."""
     self.launches += 1
@@ -297,19 +291,6 @@ class NumpyBackend(object):
     self.launches += 1
     x = _np(t)
     return self._wrap((np.cumprod if product else np.cumsum)(x, axis=axis).astype(x.dtype).reshape(x.shape))
-
-  def diag_extract(self, t, slices):
-    """creation.py:275."""
-    self.launches += 1
-    return self._wrap(_np(t)[slices].diagonal().copy())
-
-  def diag_embed(self, t, width, col0):
-    """creation.py:236-241 (np.diagflat + zero blocks left / right)."""
-    self.launches += 1
-    flat = _np(t).ravel()
-    out = np.zeros((flat.shape[0], int(width)), flat.dtype)
-    out[np.arange(flat.shape[0]), int(col0) + np.arange(flat.shape[0])] = flat
-    return self._wrap(out)
 
   # -- sparse tiles: scipy.sparse, the library the reference's sparse tile bodies are written in
   # (spartan/array/sparse.pyx, tile.pyx:226-252, dot.py:212-240)

@@ -34,7 +34,6 @@ from .expr.reduce import reduce  # noqa: F401
 from .expr.shuffle import shuffle  # noqa: F401
 from .expr.views import ravel, reshape, transpose  # noqa: F401  (also installs Expr.__getitem__/.T/.reshape)
 from .expr.assign import assign, region_map, retile, write  # noqa: F401
-from .expr.extras import bincount, concatenate, diag, diagflat, diagonal, norm, normalize  # noqa: F401
 from .expr.scan import scan  # noqa: F401
 from .expr.sort import argpartition, argsort, partition, sort  # noqa: F401
 from .expr.fio import from_file, from_file_parallel, load, partial_load, partial_unpickle, pickle, save, unpickle  # noqa: F401
@@ -64,12 +63,11 @@ for _name, _fn in dict(
     __add__=add, __sub__=sub, __mul__=multiply, __mod__=mod, __truediv__=divide, __lt__=less,  # noqa: F405
     __gt__=greater, __and__=logical_and, __or__=logical_or, __pow__=power, __neg__=negative,  # noqa: F405
     __radd__=add, __rmul__=multiply, __rsub__=lambda a, b: sub(b, a), __rtruediv__=lambda a, b: divide(b, a),  # noqa: F405
-    all=all, any=any, argmax=argmax, argmin=argmin, astype=astype, diagonal=diagonal, dot=dot,  # noqa: F405
+    all=all, any=any, argmax=argmax, argmin=argmin, astype=astype, dot=dot,  # noqa: F405
     fill=full_like, flatten=ravel, max=max, mean=mean, min=min, prod=prod, ravel=ravel, reshape=reshape,  # noqa: F405
     std=std, sum=sum, transpose=transpose).items():  # noqa: F405
   setattr(distarray.DistArray, _name, _fn)
 distarray.DistArray.T = property(transpose)
-Expr.diagonal = diagonal
 Expr.fill = full_like  # noqa: F405
 Expr.flatten = ravel
 

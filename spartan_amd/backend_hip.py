@@ -549,15 +549,6 @@ class HipBackend(object):
     self.launches += 1
     return kernels.segment_sum(points, labels, int(k), out)
 
-  def weighted_bincount(self, labels, weights, k):
-    """np.bincount(labels, weights=weights, minlength=k) (statistics.py:108-111): the segment sums
-    of a one-column matrix."""
-    n = int(np.prod(labels.shape))
-    w = self.contiguous(weights).reshape(n, 1)
-    if self.dtype_of(w) not in (np.float32, np.float64):
-      w = self.astype(w, np.float64)
-    return self.segment_sum(w, labels, k).reshape(int(k))
-
   def concat(self, a, b, axis=0):
     """np.concatenate((a, b), axis) as two box copies (manipulation.py:51)."""
     dt = np.result_type(self.dtype_of(a), self.dtype_of(b))
@@ -651,27 +642,6 @@ class HipBackend(object):
     if out.numel():
       self.launches += 1
       kernels.cumscan(t, out, axis, product)
-    return out
-
-  def diag_extract(self, t, slices):
-    """t[slices].diagonal() of a 2-D tile: one strided copy (element i at i * (ld + 1))."""
-    view = t[slices]
-    n = min(view.shape)
-    out = self.empty((n,), self.dtype_of(t))
-    if n:
-      self.launches += 1
-      kernels.slice_copy(out, 0, (1,), t, view.storage_offset() - t.storage_offset(),
-                         (view.stride(0) + view.stride(1),), (n,))
-    return out
-
-  def diag_embed(self, t, width, col0):
-    """zeros((t.size, width)) with t.ravel() on the diagonal that starts at column col0 (np.diagflat + hstack)."""
-    flat = self.contiguous(t).reshape(-1)
-    m = flat.shape[0]
-    out = self.zeros((m, int(width)), self.dtype_of(t))
-    if m:
-      self.launches += 1
-      kernels.slice_copy(out, int(col0), (int(width) + 1,), flat, 0, (1,), (m,))
     return out
 
   # -- sparse tiles (SURVEY 8f.2): canonical CSR in HBM, spartan_amd/sparse.py over csrc/sparse.hip -----------
