@@ -561,14 +561,16 @@ class DistArrayImpl(DistArray):
   def _stitch(self, region, splits, pieces):
     """distarray.py:355-365: allocate the region and paste the pieces."""
     be = self.ctx.backend
-    if any(isinstance(p, tile.EmptyBlob) for p in pieces):
+    if all(isinstance(p, tile.EmptyBlob) for p in pieces):
       return tile.EmptyBlob(region.shape, self.dtype)
-    tgt = be.empty(region.shape, self.dtype)
-    # pieces with unwritten cells (tile.MaskedBlob) make the stitched region masked as well
-    valid = be.zeros(region.shape, np.uint8) if any(isinstance(p, tile.MaskedBlob) for p in pieces) else None
+    # pieces with unwritten cells (tile.MaskedBlob) and never-written pieces (tile.EmptyBlob: fully masked zeros)
+    # make the stitched region masked as well
+    partial = any(isinstance(p, (tile.MaskedBlob, tile.EmptyBlob)) for p in pieces)
+    tgt = be.zeros(region.shape, self.dtype) if partial else be.empty(region.shape, self.dtype)
+    valid = be.zeros(region.shape, np.uint8) if partial else None
     for (ex, inter), piece in zip(splits, pieces):
       dst_slice = extent.offset_slice(region, inter)
-      if not extent.all_nonzero_shape(piece.shape):
+      if not extent.all_nonzero_shape(piece.shape) or isinstance(piece, tile.EmptyBlob):
         continue
       if isinstance(piece, tile.MaskedBlob):
         be.paste(tgt, dst_slice, piece.data)
@@ -642,7 +644,9 @@ class DistArrayImpl(DistArray):
       return cache[key]
     ex, tid = tiles[world.rank]
     mine = self._tile_piece(tid, ex, ex)
-    if isinstance(mine, tile.EmptyBlob):
+    # only the owner knows whether its tile holds plain data: agreed over the control plane, so that either every
+    # rank enters the gathers below or none does
+    if not all(world.all_gather_object(not isinstance(mine, (tile.EmptyBlob, tile.MaskedBlob)))):
       return None
     chunks = []
     for c0 in range(0, cols, chunk_cols):

@@ -44,7 +44,8 @@ class TileExtent(object):
     return (self.ul, self.lr, self.array_shape)
 
   def __getitem__(self, axis):
-    """The 1-D extent of one axis."""
+    """The 1-D extent of one axis (negative axes count from the end, like the reference's `ul[idx]`)."""
+    axis %= len(self.ul)
     return create(self.ul[axis:axis + 1], self.lr[axis:axis + 1], self.array_shape[axis:axis + 1])
 
   def __repr__(self):
@@ -291,7 +292,9 @@ def is_complete(shape, slices):
 def largest_dim_axis(shape, exclude_axes=None):
   """First axis of maximal length among those not excluded (0 when nothing is left or every length is 0)."""
   allowed = [i for i in range(len(shape)) if not exclude_axes or i not in exclude_axes]
-  best = max(allowed, key=lambda i: (shape[i], -i), default=0)
+  if not allowed:
+    return 0
+  best = max(allowed, key=lambda i: (shape[i], -i))
   return best if shape[best] > 0 else 0
 
 

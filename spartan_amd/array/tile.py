@@ -40,7 +40,7 @@ class MaskedBlob(object):
   the written-cells mask, both in HBM -- the device form of the numpy.ma.MaskedArray the reference builds there
   (tile.pyx:100-113: `masked_all` + the written cells copied in).  `data` and `valid` are backend tensors of the
   same shape (`valid` uint8, 1 = written); `to_host` gives the reference's MaskedArray.  Kernels do not take
-  masked operands: a program that computes on a partially written array is refused (lower.NotLowerable)."""
+  masked operands: a program that computes on a partially written array is refused (MaskedOperandError)."""
   __slots__ = ('data', 'valid')
 
   def __init__(self, data, valid):
@@ -61,6 +61,20 @@ class MaskedBlob(object):
     out = np.ma.masked_all(data.shape, dtype=data.dtype)
     out[valid] = data[valid]
     return out
+
+
+class MaskedOperandError(TypeError):
+  """A kernel was asked to compute on a region with never-written cells."""
+
+
+def reject_masked(values, what):
+  """Kernels do not take operands with never-written cells (MaskedBlob -- the reference would hand a
+  numpy.ma.MaskedArray to the NumPy function): one explicit error instead of whatever the first attribute access
+  on the blob would raise."""
+  for v in (values.values() if isinstance(values, dict) else values):
+    if isinstance(v, MaskedBlob):
+      raise MaskedOperandError('%s of an array with never-written cells (a masked region, shape %s): write the '
+                               'whole region first, or read it with glom() / fetch()' % (what, tuple(v.shape)))
 
 
 def is_sparse_blob(x):

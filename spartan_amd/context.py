@@ -74,6 +74,8 @@ class Context(object):
     self._arrays = weakref.WeakSet()                  # live DistArrays (master.py:103-104 register_array)
     self.heartbeat = None                             # failure detection (heartbeat.py), off unless started
     self.failed_workers = builtins.set()              # (this module defines its own `set`)
+    self._given = [0] * self.num_workers               # bytes of tiles handed to each worker so far (worker_scores)
+    self.eval_depth = 0                               # nesting of Expr.evaluate (safe points are at depth 0)
 
   # -- placement --------------------------------------------------------------
   def rank_of(self, worker):
@@ -139,6 +141,10 @@ class Context(object):
   # -- failures ---------------------------------------------------------
   def register_array(self, array):
     self._arrays.add(array)
+    item = np.dtype(array.dtype).itemsize
+    for ex, tile_id in array.tiles.items():
+      if 0 <= tile_id.worker < self.num_workers:
+        self._given[tile_id.worker] += item * int(np.prod(ex.shape, dtype=np.int64))
 
   def start_heartbeat(self, interval=3.0, threshold=10, **kw):
     """Start failure detection (master.py:142-146 / worker.py:347-368): see heartbeat.py."""
@@ -149,19 +155,24 @@ class Context(object):
     return self.heartbeat
 
   def apply_failures(self):
-    """Safe point of the driver thread: every logical worker of a rank the heartbeat declared silent is marked
-    failed (its tiles become bad tiles of their arrays).  Returns the workers marked now."""
+    """Safe point of the driver thread (the start of a top-level evaluation): every logical worker of a rank the
+    heartbeat declared silent is marked failed (its tiles become bad tiles of their arrays).  Returns the workers
+    marked now.
+
+    Every rank watches on its own clock, and all of them must change their tile tables at the same point of the
+    SPMD driver program, so the ranks take the union of their verdicts first -- through the heartbeat's key-value
+    store, NOT through a collective: a rank that is really dead or hung never joins a collective, and the survivors
+    would block in it.  Each rank posts its verdicts under the number of this safe point and reads the others';
+    a rank that does not post within the heartbeat's limit is itself declared failed."""
     if self.heartbeat is None:
       return []
     silent = self.heartbeat.take_failures()
     if self.world.distributed:
-      # every rank watches on its own clock: take the union, so that all of them change their tile tables at
-      # the same point of the (SPMD) driver program
-      silent = sorted(builtins.set(r for part in self.world.all_gather_object(sorted(silent)) for r in part))
+      silent = self.heartbeat.agree(silent)
     marked = []
     for rank in silent:
       for w in range(self.num_workers):
-        if self.rank_of(w) == rank and w not in self.failed_workers:
+        if self.rank_of(w) == rank:
           self.mark_failed_worker(w)
           marked.append(w)
     return marked
@@ -171,7 +182,8 @@ class Context(object):
     counterpart of a dead worker is a device that was reset: the rank is still there, its HBM contents are not --
     so the blobs are dropped here as well and the worker stays available for the reload / recompute that follows
     (Expr.cache() -> load_data, base.py:193-203: a checkpointed expression reloads the bad tiles from disk, any
-    other is evaluated again from its dependencies)."""
+    other is evaluated again from its dependencies).  `failed_workers` is a record of who was ever marked, not a
+    state: a worker that fails again after it recovered is marked again."""
     self.failed_workers.add(worker_id)
     for array in list(self._arrays):
       for ex, tile_id in array.tiles.items():
@@ -181,16 +193,12 @@ class Context(object):
           self._blobs.pop(tile_id, None)
 
   def worker_scores(self):
-    """[(worker, bytes of live tiles it holds)], least loaded first (ties: lower id) -- the ranking behind the
-    'performance' tile assignment (reference: master.get_worker_scores, from the workers' status reports).
-    Computed from array metadata, which every rank holds identically."""
-    held = [0] * self.num_workers
-    for array in list(self._arrays):
-      item = np.dtype(array.dtype).itemsize
-      for ex, tile_id in array.tiles.items():
-        if 0 <= tile_id.worker < self.num_workers:
-          held[tile_id.worker] += item * int(np.prod(ex.shape, dtype=np.int64))
-    return sorted(enumerate(held), key=lambda kv: (kv[1], kv[0]))
+    """[(worker, bytes of the tiles it was given so far)], least loaded first (ties: lower id) -- the ranking behind
+    the 'performance' tile assignment (reference: master.get_worker_scores, from the workers' status reports).
+    A running total kept by register_array: every rank registers the same arrays in the same order, whereas the
+    set of arrays still ALIVE depends on when each process's garbage collector ran and could differ between
+    ranks -- and with it the tile tables."""
+    return sorted(enumerate(self._given), key=lambda kv: (kv[1], kv[0]))
 
   def get_workers_for_reload(self, array):
     """master.py:110-121: spread an array's bad tiles over the workers, least loaded first."""

@@ -123,14 +123,19 @@ class Expr(object):
 
   def evaluate(self):
     ctx = context.get()
-    if ctx.heartbeat is not None and ctx.current_worker is None:
-      ctx.apply_failures()          # safe point: workers the heartbeat declared silent lose their tiles here
-    value = self.cache()
-    if value is None:
-      ready = {k: (d.evaluate() if isinstance(d, Expr) else d) for k, d in self.dependencies().items()}
-      value = self._evaluate(ctx, ready)
-      if self.needs_cache:
-        eval_cache.set(self.expr_id, value)
+    top = ctx.eval_depth == 0
+    if top and ctx.heartbeat is not None and ctx.current_worker is None:
+      ctx.apply_failures()          # safe point (once per top-level evaluation): workers declared silent lose their tiles
+    ctx.eval_depth += 1
+    try:
+      value = self.cache()
+      if value is None:
+        ready = {k: (d.evaluate() if isinstance(d, Expr) else d) for k, d in self.dependencies().items()}
+        value = self._evaluate(ctx, ready)
+        if self.needs_cache:
+          eval_cache.set(self.expr_id, value)
+    finally:
+      ctx.eval_depth -= 1
     return value
 
   def force(self):

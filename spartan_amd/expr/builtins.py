@@ -470,6 +470,7 @@ def _argreduce_mapper1(ex, src, axis, which, val_out, state):
   ctx = context.get()
   array = src
   data = array.fetch(ex)
+  distarray.tile.reject_masked((data,), 'argmax / argmin')
   dst_extent = extent.index_for_reduction(ex, axis)
   if ctx.executing:
     if axis is None:

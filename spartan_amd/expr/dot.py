@@ -49,6 +49,7 @@ def _product_shape(ash, bsh):
 def _dot(a, b):
   """`a.dot(b)` on backend tensors; a shape/dtype placeholder on ranks that do not execute the tile."""
   be = context.get().backend
+  tile.reject_masked((a, b), 'dot')
   if isinstance(b, distarray.ChunkedWhole):
     if isinstance(a, distarray.Absent):
       return distarray.Absent((a.shape[0], b.shape[1]), a.dtype)
@@ -144,8 +145,10 @@ def _chunk_columns(n):
 
 def ksplit_plan(arrays, axes, target, fn_kw):
   """Run map2((a, b), (1, 0), dot_map2_mapper) into `target` as the pipeline described in the module docstring.
-  Returns False (nothing done) unless the pattern is the regular one; the decision only reads array metadata, so
-  every rank takes the same branch."""
+  Returns False (nothing done) unless the pattern is the regular one.  The decision reads array metadata, which
+  every rank holds identically, plus ONE thing only the owner knows -- whether its operand tiles hold plain, fully
+  written data (a never-written tile is an EmptyBlob, a partly written one a MaskedBlob) -- and that is agreed
+  over the control plane before any transfer is issued, so every rank takes the same branch."""
   ctx = context.get()
   be, world = ctx.backend, ctx.world
   if not world.distributed or ctx.num_workers != world.size or fn_kw or tuple(axes) != (1, 0):
@@ -169,8 +172,14 @@ def ksplit_plan(arrays, axes, target, fn_kw):
   mb, kb = m // p, k // p
   my_a = ctx.tile(ta[me][1]).get(be, None)
   my_b = ctx.tile(tb[me][1]).get(be, None)
-  if isinstance(my_a, tile.EmptyBlob) or isinstance(my_b, tile.EmptyBlob):
-    return False      # (identical on every rank only for written arrays: operands of a dot always are)
+  if not (getattr(a, '_all_plain', False) and getattr(b, '_all_plain', False)):
+    # (agreed once per array: written cells never become unwritten, so the answer is kept as array metadata)
+    plain = [not isinstance(t, (tile.EmptyBlob, tile.MaskedBlob)) for t in (my_a, my_b)]
+    votes = world.all_gather_object(plain)
+    a._all_plain = all(v[0] for v in votes)
+    b._all_plain = all(v[1] for v in votes)
+    if not (a._all_plain and b._all_plain):
+      return False    # some rank's tile is unwritten or masked: every rank takes the generic tile-by-tile join
 
   # 1. all-to-all of a's blocks: rank j needs my rows of ITS slab, a[r_me, k_j]
   sends = [(j, be.copy(my_a[:, j * kb:(j + 1) * kb])) for j in range(p) if j != me]

@@ -14,8 +14,10 @@ from ..context import LocalKernelResult
 def get_local_values(ex, children, child_to_var):
   """{variable name: the piece of that input under the tile `ex`} -- stretched inputs hand out their un-stretched
   slab (the kernel broadcasts through zero strides)."""
-  return {name: (child.fetch_base_tile(ex) if isinstance(child, Broadcast) else child.fetch(ex))
-          for child, name in zip(children, child_to_var)}
+  values = {name: (child.fetch_base_tile(ex) if isinstance(child, Broadcast) else child.fetch(ex))
+            for child, name in zip(children, child_to_var)}
+  tile.reject_masked(values, 'map / reduce')
+  return values
 
 
 def tile_mapper(ex, children, child_to_var, op):

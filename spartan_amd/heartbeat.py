@@ -87,8 +87,6 @@ class Heartbeat(object):
     while not self._stop.is_set():
       now = time.time()
       for r in range(self.size):
-        if r in self.failed_ranks:
-          continue
         try:
           value = self.store.get('spartan_hb/%d' % r)
         except Exception:
@@ -96,7 +94,9 @@ class Heartbeat(object):
         last = self._seen.get(r)
         if last is None or (value is not None and value != last[0]):
           self._seen[r] = (value, now)
-        elif now - last[1] > limit:
+          if last is not None:
+            self.failed_ranks.discard(r)     # it beats again: a later silence is a new failure
+        elif now - last[1] > limit and r not in self.failed_ranks:
           self.failed_ranks.add(r)
           with self._lock:
             self._pending.append(r)
@@ -126,3 +126,32 @@ class Heartbeat(object):
     with self._lock:
       out, self._pending = self._pending, []
     return out
+
+  def agree(self, mine):
+    """Union of the verdicts of all ranks at this safe point, without a collective (a dead rank would never join
+    one): every rank posts its list under the number of the safe point -- the driver programs are SPMD, so the
+    numbers match -- and reads the others' with a deadline of interval * threshold seconds; a rank that posts
+    nothing in time is added to the verdict.  Ranks currently known to be silent are not waited for."""
+    self._round = getattr(self, '_round', 0) + 1
+    mine = sorted(set(mine))
+    self.store.set('spartan_hb_agree/%d/%d' % (self._round, self.rank), ','.join(str(r) for r in mine) or '-')
+    verdict = set(mine)
+    waiting = [r for r in range(self.size) if r != self.rank and r not in self.failed_ranks]
+    deadline = time.time() + max(self.interval * self.threshold, 1.0)
+    while waiting:
+      for r in list(waiting):
+        try:
+          value = self.store.get('spartan_hb_agree/%d/%d' % (self._round, r))
+        except Exception:
+          value = None
+        if value is not None:
+          verdict.update(int(x) for x in value.split(',') if x != '-')
+          waiting.remove(r)
+      if not waiting:
+        break
+      if time.time() > deadline:
+        verdict.update(waiting)                # never reached the safe point: dead or hung
+        self.failed_ranks.update(waiting)
+        break
+      time.sleep(0.001)
+    return sorted(verdict)

@@ -30,6 +30,7 @@ class NotLowerable(TypeError):
   """The local function has no registered GPU lowering."""
 
 
+
 # --------------------------------------------------------------------- values
 class V(object):
   """A typed value in the tree being lowered."""

@@ -187,7 +187,7 @@ def test_heartbeat_marks_a_silent_worker_failed_and_the_value_is_recomputed():
   try:
     ctx = sp.get_context()
     alive = {'ok': True}
-    hb = ctx.start_heartbeat(interval=0.05, threshold=3, probe=lambda: alive['ok'])
+    hb = ctx.start_heartbeat(interval=0.05, threshold=12, probe=lambda: alive['ok'])   # (0.6 s of silence: a loaded test box may starve the beat thread for a while)
     a = np.ones((12, 5), np.float32)
     e = sp.ones((12, 5)) * 2 + 1          # (a value with lineage: builders can be re-run, loaded data cannot)
     first = e.evaluate()
@@ -202,5 +202,63 @@ def test_heartbeat_marks_a_silent_worker_failed_and_the_value_is_recomputed():
     second = (e + 0).evaluate()                                         # safe point: failures are applied here
     assert ctx.failed_workers == {0, 1, 2} and len(first.bad_tiles) == len(first.tiles)
     np.testing.assert_array_equal(second.glom(), a * 2 + 1)            # e was recomputed, not read from dead tiles
+  finally:
+    sp.shutdown()
+
+
+def test_heartbeat_second_failure_of_a_recovered_rank_and_agreement_without_the_dead_rank():
+  """(i) A rank whose beats resume can fail AGAIN and is marked again (failed_ranks is cleared when it beats);
+  (ii) the ranks agree on verdicts through the key-value store, so a rank that never reaches the safe point does
+  not block the others: it is added to the verdict after the deadline."""
+  import time
+  from oracle.np_backend import NumpyBackend
+  from spartan_amd import heartbeat
+  sp.initialize(backend=NumpyBackend(), num_workers=2)
+  try:
+    ctx = sp.get_context()
+    alive = {'ok': True}
+    hb = ctx.start_heartbeat(interval=0.03, threshold=10, probe=lambda: alive['ok'])
+    e = sp.ones((8, 3)) + 1
+    for episode in range(2):
+      first = e.evaluate()
+      alive['ok'] = False
+      deadline = time.time() + 5
+      while not hb.failed_ranks and time.time() < deadline:
+        time.sleep(0.01)
+      assert hb.failed_ranks == {0}, episode
+      assert sorted(ctx.apply_failures()) == [0, 1], episode            # marked in BOTH episodes
+      assert len(first.bad_tiles) == len(first.tiles)
+      alive['ok'] = True
+      deadline = time.time() + 5
+      while hb.failed_ranks and time.time() < deadline:
+        time.sleep(0.01)
+      assert not hb.failed_ranks                                        # beating again
+      np.testing.assert_array_equal((e + 0).evaluate().glom(), np.full((8, 3), 2, np.float32))
+    hb.stop()
+    ctx.heartbeat = None
+    # (ii) three ranks share one store; rank 2 never posts
+    store = heartbeat._LocalStore()
+
+    class W(object):
+      def __init__(self, rank):
+        self.rank, self.size, self.distributed = rank, 3, True
+
+    class C(object):
+      backend = None
+
+      def __init__(self, rank):
+        self.world = W(rank)
+    hbs = [heartbeat.Heartbeat(C(r), interval=0.02, threshold=5, probe=lambda: True, store=store) for r in range(2)]
+    import threading
+    out = [None, None]
+
+    def run(i):
+      out[i] = hbs[i].agree([] if i else [1])
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    t0 = time.time()
+    [t.start() for t in ts]
+    [t.join(10) for t in ts]
+    assert out[0] == out[1] == [1, 2], out                               # union of the posts + the rank that never came
+    assert time.time() - t0 < 5
   finally:
     sp.shutdown()

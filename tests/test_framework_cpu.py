@@ -165,3 +165,29 @@ def test_tile_assignment_strategies(tmp_path, monkeypatch):
       sp.from_numpy(a).force()
   finally:
     sp.shutdown()
+
+
+def test_partial_write_across_tiles_reads_masked_and_refuses_kernels():
+  """A region that spans a written and a never-written tile (distarray.py:355-365 + tile.pyx:100-113): glom gives
+  the reference's MaskedArray -- not zeros --, kernels refuse the masked operand with one explicit error, extents
+  take negative axes like the reference's `ul[idx]`."""
+  from oracle.np_backend import NumpyBackend
+  from spartan_amd.array import extent, tile
+  sp.initialize(backend=NumpyBackend(), num_workers=2)
+  try:
+    be = sp.get_context().backend
+    a = sp.ndarray((4, 4), dtype=np.float32).evaluate()
+    assert len(a.tiles) == 2
+    a.update(extent.create((0, 0), (1, 4), (4, 4)), be.from_numpy(np.ones((1, 4), np.float32)))
+    got = a.glom()
+    assert isinstance(got, np.ma.MaskedArray)
+    np.testing.assert_array_equal(got.mask, np.arange(16).reshape(4, 4) >= 4)
+    np.testing.assert_array_equal(got[0].filled(-1), np.ones(4, np.float32))
+    for build in (lambda v: v + 1, lambda v: sp.sum(v), lambda v: sp.argmax(v, 1), lambda v: sp.dot(v, v)):
+      with pytest.raises(tile.MaskedOperandError):
+        build(sp.Val(val=a)).evaluate()
+    e = extent.create((1, 2), (3, 5), (10, 10))
+    assert e[-1] == e[1] and e[-2] == e[0]
+    assert extent.largest_dim_axis(()) == 0
+  finally:
+    sp.shutdown()
