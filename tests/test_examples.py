@@ -83,6 +83,46 @@ def _check_regressions(workers, rtol):
     np.testing.assert_allclose(w, want, rtol=rtol)
 
 
+def _sgd(x, y, steps, update, alpha=1e-6):
+  """The reference's SGDRegressor loop (examples/sgd.py:34-39) over the expression API: w -= alpha * sum(update, 0)."""
+  d = x.shape[1]
+  w = lreg.initial_weights(d)
+  for _ in range(steps):
+    g = sp.sum(update(x, y, w), axis=0).optimized().glom().reshape((d, 1))
+    w = w - g * alpha
+  return w
+
+
+def _logistic_update(x, y, w):
+  g = sp.exp(sp.dot(x, w))
+  return x * (g / (g + 1) - y)
+
+
+def _ridge_update(lam):
+  def update(x, y, w):
+    xt = sp.transpose(x)
+    g = sp.dot(sp.dot(xt, x), w) + sp.dot(xt, y) + lam * w
+    return sp.reshape(g, (1, x.shape[1]))
+  return update
+
+
+def _check_other_regressions(workers, rtol):
+  """Logistic and ridge regression written against the expression API (exp / divide maps fused with the dot's
+  result; transpose views, a K-split dot of x^T . x, a dot with a driver array), three / two steps, against the
+  weights the reference's logistic_regression.py / ridge_regression.py produced (make_golden.py --examples)."""
+  gold = GOLD[workers]
+  x, y = INPUTS['reg_x'], INPUTS['reg_y']
+  for name, update, steps in (('logreg', _logistic_update, 3), ('ridge', _ridge_update(1), 2)):
+    np.random.seed(1234)
+    w = np.asarray(_sgd(sp.from_numpy(x), sp.from_numpy(y), steps, update))
+    want = gold[name + '_w']
+    assert w.dtype == want.dtype and w.shape == want.shape, name
+    if rtol == 0:
+      np.testing.assert_array_equal(w, want, err_msg=name)
+    else:
+      np.testing.assert_allclose(w, want, rtol=rtol, err_msg=name)
+
+
 # ------------------------------------------------------------------ CPU: host framework on the oracle backend
 @pytest.fixture(params=[1, 4], ids=lambda n: 'workers%d' % n)
 def cpu_ctx(request):
@@ -100,6 +140,7 @@ def test_kmeans_host_framework(cpu_ctx, impl, tag):
 
 def test_regressions_host_framework(cpu_ctx):
   _check_regressions(cpu_ctx, rtol=0)
+  _check_other_regressions(cpu_ctx, rtol=0)
 
 
 def test_kmeans_reducer_combines_tiles(cpu_ctx):
@@ -132,3 +173,4 @@ def test_kmeans_hip(gpu_ctx, impl, tag):
 @pytest.mark.gpu
 def test_regressions_hip(gpu_ctx):
   _check_regressions(gpu_ctx, rtol=2e-6)
+  _check_other_regressions(gpu_ctx, rtol=2e-6)
