@@ -6,17 +6,24 @@ One "step" = one `spartan.dot(A, B).force()` through the whole tile path (lazy D
 launches -> merge into the target), operands already resident in HBM:
 
   --gpus 1 : BASELINE configs[1] -- dot 8192 x 8192 x 8192 fp32, one tile.  The same line carries the north-star
-             shape on one GPU (`northstar_32768`: dot 32768^3, timed with HIP events around whole `.force()` calls).
+             shape on one GPU (`northstar_32768`: dot 32768^3, timed with HIP events around whole `.force()` calls),
+             the HBM-bound kernels, the k-means / lreg workloads of configs[3] / [4] on a per-GPU tile, and
+             `ksplit_rank_emulation`: ONE rank's share of the p-GPU north-star step for p = 2, 4, 8, with every
+             collective replaced by device copies of the same byte count on the communication stream (no multi-GPU
+             hardware is needed to see what the GEMMs lose to a concurrent transfer and what the pipeline exposes).
   --gpus N : the north star, STRONG scaling: dot 32768 x 32768 x 32768 fp32 with A, B and the result row-tiled one
              tile per GPU (`tile_hint=(M/N, N)`).  rows <= cols, so this is the reference's K-split map2 join
-             (dot.py:286-290): the all-to-all of A's column slabs, p GEMMs per column chunk of the partial, and
-             one reduce-scatter per chunk overlapped with the next chunk's GEMMs (spartan_amd/expr/dot.ksplit_plan).
-             `value` is whole-job TFLOP/s = 2 * 32768^3 * steps / max-over-ranks wall time; `dot_breakdown`
-             gives kernel-only time and the bytes each GPU moved per step against the xGMI link rates.
+             (dot.py:286-290): the all-to-all of A's column slabs into one slab buffer, one GEMM per column chunk of
+             the partial, and one reduce-scatter per chunk overlapped with the next chunk's GEMM
+             (spartan_amd/expr/dot.ksplit_pipeline).  `value` is whole-job TFLOP/s = 2 * 32768^3 * steps /
+             max-over-ranks wall time; `dot_breakdown` gives kernel-only time and the bytes each GPU moved per step.
 
-The line also carries the roofline of the dominant kernel (sp_gemm_kernel, MFMA-bound; durations from HIP events
-on the launch stream), the fused-map / reduce HBM rates, the k-means and sparse tile kernels, and the CPU
-baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thread worker processes.
+The line also carries the roofline of the dominant kernel (MFMA-bound GEMM; durations from HIP events on the launch
+stream), `profile_table` (what every timed section launched: kernel, launches, algorithmic units per launch -- the
+key tools/roofline.py uses to recompute each fraction from a rocprofv3 kernel trace of this very command), and the
+CPU baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thread worker processes.
+
+No torch in this process at N = 1; with N > 1 torch.distributed (gloo) is the control plane only.
 """
 import argparse
 import os as _os
@@ -28,13 +35,13 @@ import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import spartan_amd as sp  # noqa: E402
 from spartan_amd import _hip, kernels  # noqa: E402
+from spartan_amd import devarray as D  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
@@ -43,46 +50,70 @@ SETUP_LAUNCHES = 8              # untimed set-up steps before the W warm-up step
 NORTH_STAR = 32768
 XGMI_LINK_GBPS = 153.0          # per link, 7 links per GPU (MI355X_MICROARCH.md / task brief)
 
+GEMM_KERNEL = 'sp_gemm_glds_kernel'
+PROFILE_TABLE = []              # one entry per timed section (see the module docstring)
+
+
+def clocks():
+  """Host clocks in ns, one of which is the time base of rocprofv3's kernel timestamps on this box
+  (tools/roofline.py finds out which by counting the launches that fall into the windows)."""
+  return {'monotonic': time.clock_gettime_ns(time.CLOCK_MONOTONIC), 'boottime': time.clock_gettime_ns(time.CLOCK_BOOTTIME),
+          'monotonic_raw': time.clock_gettime_ns(time.CLOCK_MONOTONIC_RAW), 'realtime': time.time_ns()}
+
+
+def note_section(label, kernel, launches, units, unit, bound, t0, t1):
+  """One timed section: every launch of `kernel` issued between the host times t0 and t1 (the device was idle at
+  both) belongs to it."""
+  PROFILE_TABLE.append({'label': label, 'kernel': kernel, 'launches': int(launches), 'units_per_launch': units,
+                        'unit': unit, 'bound': bound, 't0': t0, 't1': t1})
+
 
 def device_uniform(ex, lo, hi, seed):
-  g = torch.Generator(device='cuda')
-  g.manual_seed(seed + 1000003 * ex.ul[0])
-  t = torch.rand(ex.shape, dtype=torch.float32, device='cuda', generator=g)
-  return t * (hi - lo) + lo
+  """One tile of uniform [lo, hi) fp32 from the library's counter-based generator (sp_random_fill)."""
+  out = D.empty(ex.shape, np.float32)
+  kernels.random_fill(out, 'uniform', seed + 1000003 * (ex.ul[0] if ex.ul else 0), 0)
+  if (lo, hi) != (0.0, 1.0):
+    out = out * np.float32(hi - lo) + np.float32(lo)
+  return out
 
 
 def time_steps(ctx, step, steps, warmup):
   for _ in range(warmup):
     step()
   ctx.world.barrier()
-  torch.cuda.synchronize()
+  D.synchronize()
   t0 = time.perf_counter()
   for _ in range(steps):
     step()
-  torch.cuda.synchronize()
+  D.synchronize()
   ctx.world.barrier()
   dt = time.perf_counter() - t0
   if ctx.world.distributed:
-    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-    ctx.world.all_reduce(t, 'MAX')
-    dt = float(t.item())
+    dt = max(ctx.world.all_gather_object(dt))       # max over ranks (control plane)
   return dt
 
 
-def event_time(fn, iters, warmup=4):
+def event_time(fn, iters, warmup=4, section=None):
+  """Average milliseconds of fn() over `iters` calls, by HIP events on the launch stream.
+  section = (label, kernel substring, algorithmic units per launch, unit, bound[, launches per call])."""
+  D.synchronize()
+  t0 = clocks()
   for _ in range(warmup):
     fn()
   # programs outside the prebuilt kernel library are specialised at run time on a
   # background thread (include/spartan_hip.h sp_jit_*): let the warm-up's requests land
   _hip.lib().sp_jit_wait()
   fn()
-  torch.cuda.synchronize()
-  e0, e1 = kernels.Event(), kernels.Event()
+  D.synchronize()
+  e0, e1 = D.Event(), D.Event()
   e0.record()
   for _ in range(iters):
     fn()
   e1.record()
   e1.synchronize()
+  if section is not None:
+    per_call = section[5] if len(section) > 5 else 1
+    note_section(section[0], section[1], (warmup + 1 + iters) * per_call, section[2], section[3], section[4], t0, clocks())
   return e0.elapsed_ms(e1) / iters
 
 
@@ -93,28 +124,30 @@ def hbm_section(ctx):
   X = sp.from_tile_fn((rows, cols), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 7)).force()
   Xv = sp.Val(val=X)
   out = {}
-  t = X.tiles
-  x = ctx.tile(list(t.values())[0]).data
-  y = torch.empty_like(x)
-  ms = event_time(lambda: kernels.stream_copy(y, x), 10)
+  x = ctx.tile(list(X.tiles.values())[0]).data
+  y = D.empty(x.shape, x.dtype)
+  ms = event_time(lambda: kernels.stream_copy(y, x), 10, section=('stream copy 2 GiB', 'sp_stream_copy_kernel', 8.0 * n, 'bytes', 'hbm'))
   out['stream_copy_GBps'] = round(2 * 4.0 * n / ms / 1e6, 1)
   del y
-  ms = event_time(lambda: (Xv * Xv + Xv).optimized().force(), 10)
+  ms = event_time(lambda: (Xv * Xv + Xv).optimized().force(), 10,
+                  section=('map x*x+x', 'sp_map_kernel', 8.0 * n, 'bytes', 'hbm'))
   out['map_xx_plus_x_GBps'] = round(8.0 * n / ms / 1e6, 1)          # 4*(n_in+1)*E bytes
-  ms = event_time(lambda: (Xv + 1).force(), 10)
+  ms = event_time(lambda: (Xv + 1).force(), 10, section=('map x+1', 'sp_map_kernel', 8.0 * n, 'bytes', 'hbm'))
   out['map_x_plus_1_GBps'] = round(8.0 * n / ms / 1e6, 1)
   # fused trees outside the prebuilt library: run-time specialised kernels (csrc/sp_jit.hip)
   ms = event_time(lambda: (((Xv * Xv + Xv) * 0.5 - Xv) / (Xv + 2.0)).optimized().force(), 10)
   out['map_5op_chain_jit_GBps'] = round(8.0 * n / ms / 1e6, 1)
   ms = event_time(lambda: sp.sum((Xv - 0.5) * (Xv - 0.5), axis=0).optimized().force(), 10)
   out['sum_sq_dev_axis0_jit_GBps'] = round(4.0 * n / ms / 1e6, 1)
-  for axis in (None, 0, 1):
-    ms = event_time(lambda: sp.sum(Xv, axis).force(), 10)
+  for axis, kern in ((None, 'sp_reduce_rows_kernel'), (0, 'sp_reduce_cols_kernel'), (1, 'sp_reduce_rows_kernel')):
+    ms = event_time(lambda: sp.sum(Xv, axis).force(), 10,
+                    section=('sum axis=%s' % axis, kern, 4.0 * n, 'bytes', 'hbm'))
     out['sum_axis%s_GBps' % axis] = round(4.0 * n / ms / 1e6, 1)    # 4*E bytes
-  ms = event_time(lambda: sp.argmax(Xv, 1).force(), 10)
+  ms = event_time(lambda: sp.argmax(Xv, 1).force(), 10,
+                  section=('argmax axis=1', 'sp_reduce_rows_kernel', 4.0 * n, 'bytes', 'hbm'))
   out['argmax_axis1_GBps'] = round(4.0 * n / ms / 1e6, 1)
   del X, Xv, x
-  torch.cuda.empty_cache()
+  D.trim_pool()
   # the reference's DEFAULT dtype is float64 (its builders make np.float arrays): same tile shape halved
   Xd = sp.astype(sp.from_tile_fn((rows, cols // 2), np.float32,
                                  lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 9)), np.float64).force()
@@ -125,20 +158,7 @@ def hbm_section(ctx):
   ms = event_time(lambda: sp.sum(Xdv, 0).force(), 10)
   out['sum_axis0_f64_jit_GBps'] = round(8.0 * nd / ms / 1e6, 1)
   del Xd, Xdv
-  torch.cuda.empty_cache()
-  # one linear-regression step on a BASELINE configs[4] per-GPU tile (125000 x 4096 fp32):
-  # yp = dot(X, w); grad = sum(X * (yp - y), axis=0)  (sgd.py:34-39) -- X streamed twice
-  N, D = 125000, 4096
-  Xl = sp.from_tile_fn((N, D), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 11))
-  yl = sp.from_tile_fn((N, 1), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 12))
-  w = np.random.RandomState(SEED).rand(D, 1).astype(np.float32)
-
-  def lreg_step():
-    yp = sp.dot(Xl, w)
-    return sp.sum(Xl * (yp - yl), axis=0).optimized().force()
-  ms = event_time(lreg_step, 10)
-  out['lreg_step_GBps'] = round(2 * 4.0 * N * D / ms / 1e6, 1)     # 2*4*N*D bytes
-  out['lreg_step_ms'] = round(ms, 4)
+  D.trim_pool()
   out['frac_of_measured_copy'] = {k: round(v / out['stream_copy_GBps'], 3) for k, v in out.items()
                                   if k.endswith('_GBps') and k != 'stream_copy_GBps'}
   out['hbm_peak_GBps'] = HBM_PEAK_GBPS
@@ -146,9 +166,43 @@ def hbm_section(ctx):
   return out
 
 
+def lreg_section(ctx, copy_gbps):
+  """BASELINE configs[4] on the per-GPU tile (125 000 x 4096 fp32): the benchmark's 100 gradient steps
+  (tests/benchmark_lreg.py:22-29 -> examples/lreg.fit), after 2 untimed ones; a step streams X twice
+  (yp = dot(X, w); grad = sum(X * (yp - y), axis=0): sgd.py:34-39), gloms the (D,) gradient and updates w on the
+  driver."""
+  from spartan_amd.examples import lreg
+  N, Dm = 125000, 4096
+  Xl = sp.from_tile_fn((N, Dm), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 11)).force()
+  yl = sp.from_tile_fn((N, 1), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 12)).force()
+  Xv, yv = sp.Val(val=Xl), sp.Val(val=yl)
+  w = np.random.RandomState(SEED).rand(Dm, 1).astype(np.float32)
+
+  def lreg_step():
+    yp = sp.dot(Xv, w)
+    return sp.sum(Xv * (yp - yv), axis=0).optimized().force()
+  ms = event_time(lreg_step, 10)
+  out = {'tile': '%dx%d fp32' % (N, Dm), 'step_kernels_ms': round(ms, 4),
+         'step_kernels_GBps': round(2 * 4.0 * N * Dm / ms / 1e6, 1)}     # SURVEY 8d: 2*4*N*D bytes
+  alpha = 1e-10               # (the example's default 1e-6 diverges on a 125 000-row tile of uniform data: gradients ~6e7)
+  w = lreg.fit(Xv, yv, 2, alpha=alpha, w=w)
+  D.synchronize()
+  t0 = time.perf_counter()
+  w = lreg.fit(Xv, yv, 100, alpha=alpha, w=w)
+  D.synchronize()
+  dt = time.perf_counter() - t0
+  out.update({'steps': 100, 'warmup_steps': 2, 'hundred_steps_ms': round(dt * 1e3, 2), 'ms_per_step': round(dt * 10, 4),
+              'GBps': round(100 * 2 * 4.0 * N * Dm / dt / 1e9, 1),
+              'frac_of_measured_copy': round(100 * 2 * 4.0 * N * Dm / dt / 1e9 / copy_gbps, 3),
+              'weights_finite': bool(np.isfinite(w).all()),
+              'note': 'whole driver loop: 2 launches + glom of the gradient + host update of w per step'})
+  return out
+
+
 def kmeans_section(ctx):
-  """One k-means iteration on a BASELINE configs[3] per-GPU tile (1 250 000 x 256 fp32 points,
-  k = 1024): distance+argmin is MFMA-bound (2*n*k*d flop), the accumulate HBM-bound (4*n*d bytes)."""
+  """BASELINE configs[3] on the per-GPU tile (1 250 000 x 256 fp32 points, k = 1024): distance + argmin is
+  MFMA-bound (2*n*k*d flop), the accumulate HBM-bound (4*n*d bytes); then the benchmark as specified -- 10 timed
+  iterations after 2 warm-up ones -- through KMeans.fit."""
   from spartan_amd.examples.sklearn.cluster import KMeans
   n, k, d = 1250000, 1024, 256
   X = sp.from_tile_fn((n, d), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 21)).force()
@@ -156,32 +210,35 @@ def kmeans_section(ctx):
   x = ctx.tile(list(X.tiles.values())[0]).data
   centers = np.random.RandomState(SEED).rand(k, d)
   cdev = ctx.backend.from_numpy(centers)
-  labels = torch.empty(n, dtype=torch.int64, device=x.device)
+  labels = D.empty((n,), np.int64)
   out = {'tile': '%dx%d fp32, k=%d' % (n, d, k)}
-  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels), 20, warmup=3)
+  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels), 20, warmup=3,
+                  section=('k-means assign (first pass)', 'sp_nearest_nt_kernel<true, false, false>', 2.0 * n * k * d, 'flop', 'mfma'))
   out['assign_ms'] = round(ms, 3)
   out['assign_TFLOPs'] = round(2.0 * n * k * d / ms / 1e9, 1)          # 2*N*K*D flop
   out['assign_frac_of_mfma_peak'] = round(2.0 * n * k * d / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)
   kernels.nearest_center(x, cdev, labels, _hip.NEAREST_FUSED_UNCHECKED)
   out['assign_rechecked_points'] = int((labels < 0).sum().item())   # re-done by the exact fp64 kernel
   kernels.nearest_center(x, cdev, labels)
-  sums = torch.empty(k, d, dtype=torch.float32, device=x.device)
-  counts = torch.empty(k, dtype=torch.int64, device=x.device)
+  sums = D.empty((k, d), np.float32)
+  counts = D.empty((k,), np.int64)
 
   def accumulate():
     kernels.bincount(labels, k, counts)
     kernels.segment_sum(x, labels, k, sums)
-  ms = event_time(accumulate, 10)
+  ms = event_time(accumulate, 10, section=('k-means segment sums', 'sp_segment_sum_kernel', 4.0 * n * d, 'bytes', 'hbm'))
   out['accumulate_ms'] = round(ms, 3)
   out['accumulate_GBps'] = round(4.0 * n * d / ms / 1e6, 1)             # 4*N*D bytes
-  km = KMeans(k, 1)
+  c = centers
   t = []
-  for _ in range(4):
-    torch.cuda.synchronize()
+  for it in range(12):                                                 # 2 warm-up + 10 timed iterations
+    D.synchronize()
     t0 = time.perf_counter()
-    km.fit(Xv, centers, implementation='map2', reducer=np.add)   # glom of counts / centres synchronises
+    c, _ = KMeans(k, 1).fit(Xv, c, implementation='map2', reducer=np.add)   # glom of counts / centres synchronises
     t.append(time.perf_counter() - t0)
-  out['iteration_ms'] = round(min(t[1:]) * 1e3, 3)                     # driver program end to end
+  out['ten_iterations_ms'] = round(sum(t[2:]) * 1e3, 2)
+  out['iteration_ms'] = round(sum(t[2:]) * 1e2, 3)                     # driver program end to end, mean of the 10
+  out['iterations'] = {'timed': 10, 'warmup': 2}
   return out
 
 
@@ -191,40 +248,38 @@ def sparse_section(ctx):
   HBM-bound: 8 B per stored entry (value + column index) + 16 B per row (indptr, y, x read once)."""
   from spartan_amd import sparse as S
   n, deg, sites = 900000, 10, 8
-  g = torch.Generator(device='cuda')
-  g.manual_seed(SEED + 31)
-  cols = torch.arange(n, device='cuda', dtype=torch.int64).repeat_interleave(deg)
-  local = (cols // (n // sites)) * (n // sites) + torch.randint(0, n // sites, (n * deg,), device='cuda', generator=g)
-  far = torch.randint(0, n, (n * deg,), device='cuda', generator=g)
-  rows = torch.where(torch.rand(n * deg, device='cuda', generator=g) <= 0.9, local, far).int()
-  cols = cols.int()
-  vals = torch.ones(n * deg, device='cuda', dtype=torch.float32)
+  rng = np.random.RandomState(SEED + 31)
+  cols = np.repeat(np.arange(n, dtype=np.int64), deg)
+  local = (cols // (n // sites)) * (n // sites) + rng.randint(0, n // sites, size=n * deg)
+  far = rng.randint(0, n, size=n * deg)
+  rows = D.from_numpy(np.where(rng.rand(n * deg) <= 0.9, local, far).astype(np.int32))
+  cols = D.from_numpy(cols.astype(np.int32))
+  vals = D.full((n * deg,), 1, np.float32)
   out = {'tile': '%dx%d fp32 CSR, %d links per page' % (n, n, deg)}
   ms = event_time(lambda: S.from_coo((n, n), np.float32, rows, cols, vals), 3, warmup=1)
   out['coo_to_csr_ms'] = round(ms, 3)
   W = S.from_coo((n, n), np.float32, rows, cols, vals)
   del rows, cols, vals, local, far
-  x = torch.rand((n, 1), device='cuda', dtype=torch.float32, generator=g)
-  y = torch.empty((n, 1), device='cuda', dtype=torch.float32)
+  x = D.from_numpy(rng.rand(n, 1).astype(np.float32))
+  y = D.empty((n, 1), np.float32)
   alg = W.nnz * 8 + n * 16
-  ms = event_time(lambda: S.spmm(W, x, out=y), 20, warmup=3)
+  ms = event_time(lambda: S.spmm(W, x, out=y), 20, warmup=3, section=('CSR x vector 900k', 'sp_csr_spmv', float(alg), 'bytes', 'hbm'))
   out.update({'nnz': W.nnz, 'spmv_ms': round(ms, 4), 'spmv_GBps': round(alg / ms / 1e6, 1),
               'spmv_bytes_per_launch': alg})
   # the driver program: 5 iterations of p = dot(wts, p) through the expression API on the same tile
-  if True:
-    wts = sp.from_tile_fn((n, n), np.float32, lambda ex: W, sparse=True).force()
-    p = sp.from_tile_fn((n, 1), np.float32, lambda ex: x).force()
-    t = []
-    for _ in range(3):
-      torch.cuda.synchronize()
-      t0 = time.perf_counter()
-      q = sp.Val(val=p)
-      for _ in range(5):
-        q = sp.dot(sp.Val(val=wts), q).optimized()
-      q.force()
-      torch.cuda.synchronize()
-      t.append(time.perf_counter() - t0)
-    out['five_iterations_ms'] = round(min(t[1:]) * 1e3, 3)
+  wts = sp.from_tile_fn((n, n), np.float32, lambda ex: W, sparse=True).force()
+  p = sp.from_tile_fn((n, 1), np.float32, lambda ex: x).force()
+  t = []
+  for _ in range(3):
+    D.synchronize()
+    t0 = time.perf_counter()
+    q = sp.Val(val=p)
+    for _ in range(5):
+      q = sp.dot(sp.Val(val=wts), q).optimized()
+    q.force()
+    D.synchronize()
+    t.append(time.perf_counter() - t0)
+  out['five_iterations_ms'] = round(min(t[1:]) * 1e3, 3)
   return out
 
 
@@ -254,8 +309,9 @@ def dist_section(ctx):
 
 
 def guarded(fn, timeout_s, rank, fallback_line):
-  """Run an informational section; if it does not come back (a collective that never completes), rank 0 prints the
-  line it already has and every rank leaves -- the headline measurement is never lost to an extra."""
+  """Run an informational section under a deadline.  If it does not come back (a collective that never completes)
+  rank 0 still prints the line it has -- the headline was measured before this section -- with the failure in
+  `extras_error`, and every rank exits NON-ZERO: a hung extra is a failed run."""
   import threading
   done = threading.Event()
 
@@ -263,11 +319,11 @@ def guarded(fn, timeout_s, rank, fallback_line):
     if not done.wait(timeout_s):
       fallback_line['extras_error'] = 'FAILED: section did not complete within %d s (hung collective?)' % timeout_s
       _emit(fallback_line, rank)
-      os._exit(0)   # the headline (measured before this section) stands; the failure is in the line itself
+      os._exit(3)
   threading.Thread(target=watchdog, daemon=True).start()
   try:
     res = fn()
-  except Exception as e:   # informational: report, do not fail the run
+  except Exception as e:   # informational: report in the line, do not lose the headline
     res = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
   done.set()
   return res
@@ -285,11 +341,13 @@ def northstar_section(ctx):
 
   def step():
     keep[:] = [sp.dot(A, B).force()]
+  D.synchronize()
+  t0 = clocks()
   step()
-  torch.cuda.synchronize()
+  D.synchronize()
   ms = []
   for _ in range(3):
-    e0, e1 = kernels.Event(), kernels.Event()
+    e0, e1 = D.Event(), D.Event()
     e0.record()
     step()
     e1.record()
@@ -298,15 +356,114 @@ def northstar_section(ctx):
   del keep[:]
   avg = sum(ms) / len(ms)
   flop = 2.0 * n ** 3
+  D.synchronize()
+  note_section('dot 32768^3 (north star)', GEMM_KERNEL, 4, flop, 'flop', 'mfma', t0, clocks())
   return {'workload': 'spartan.dot %dx%dx%d fp32, one tile' % (n, n, n), 'calls': len(ms),
           'ms_per_call': round(avg, 2), 'min_ms': round(min(ms), 2), 'TFLOPs': round(flop / avg / 1e9, 2),
           'frac_of_mfma_peak': round(flop / avg / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), 'flop_per_call': flop}
 
 
+# ---- one rank of the p-GPU K-split step, on one GPU ---------------------------------------------------------------
+class _SideWork(object):
+  def __init__(self, event, keep):
+    self.event, self.keep = event, keep
+
+  def wait(self):
+    D.current_stream().wait_event(self.event)
+    self.keep = None
+
+
+def ksplit_rank_emulation(ctx, one_gpu_ms):
+  """What ONE rank of the p-GPU north-star step does (spartan_amd/expr/dot.ksplit_pipeline, the very function the
+  multi-GPU job runs), measured on this GPU for p = 2, 4, 8: its (32768/p x 32768) tile of A, its rows of B, the
+  slab buffer, the chunk GEMMs, the pastes -- with the transport replaced by device copies of the SAME byte counts on
+  a high-priority side stream: per all-to-all block one copy (a block leaving + a block landing), per
+  reduce-scatter (p-1)/p of the chunk copied out and the rank's own piece produced.  The copies run on
+  `copy_workgroups` workgroups, the way a collective's channels occupy a bounded share of the CUs.
+  Reported per (p, chunk columns): the step with and without the transfers, the GEMM kernels' own time in both,
+  and the speed-up over the one-GPU step this rank's time would allow if the wire were no slower than the copies."""
+  import importlib
+  dot_mod = importlib.import_module('spartan_amd.expr.dot')     # (spartan_amd.expr.dot the ATTRIBUTE is the dot() builder)
+  be = ctx.backend
+  n = NORTH_STAR
+  wg = int(os.environ.get('SPARTAN_EMULATED_COMM_WORKGROUPS', '32'))
+  side = D.Stream(high_priority=True)
+  out = {'workload': 'one rank of dot %d^3 fp32 row-tiled over p GPUs' % n, 'copy_workgroups': wg,
+         'one_gpu_step_ms': round(one_gpu_ms, 2), 'cases': []}
+  flop = 2.0 * n ** 3
+  for p in (2, 4, 8):
+    mb = kb = n // p
+    my_a = device_uniform(sp.extent.from_shape((mb, n)), -1.0, 1.0, SEED + 61)
+    my_b = device_uniform(sp.extent.from_shape((kb, n)), -1.0, 1.0, SEED + 62)
+    scratch = D.empty((n, 8192), np.float32)
+    for nc in (2048, 4096, 8192):
+      moved = {'bytes': 0}
+
+      def exchange(sends, recvs, on=True):
+        if not on:
+          return None
+        side.wait_stream(D.current_stream())
+        for (_, src), (_, dst) in zip(sends, recvs):
+          kernels.stream_copy(dst, src, max_workgroups=wg, stream=side)
+          moved['bytes'] += src.nbytes
+        return _SideWork(D.Event().record(side), [t for _, t in sends] + [t for _, t in recvs])
+
+      def reduce_scatter(piece, part, on=True):
+        if not on:
+          return None
+        side.wait_stream(D.current_stream())
+        away = part.nbytes // p * (p - 1)                    # what this rank sends: every row block but its own
+        kernels.stream_copy(scratch, part, nbytes=away, max_workgroups=wg, stream=side)
+        kernels.stream_copy(piece, part, nbytes=piece.nbytes, max_workgroups=wg, stream=side)   # its reduced piece
+        moved['bytes'] += away
+        return _SideWork(D.Event().record(side), [piece, part])
+      res = {}
+      for mode in ('compute_only', 'with_transfers'):
+        on = mode == 'with_transfers'
+        step_ms, gemm_ms = [], []
+        for it in range(3):
+          moved['bytes'] = 0
+          be.gemm_events = []
+          e0, e1 = D.Event(), D.Event()
+          D.synchronize()
+          e0.record()
+          result = dot_mod.ksplit_pipeline(be, p, 1 % p, my_a, my_b, np.dtype(np.float32),
+                                           lambda s, r: exchange(s, r, on), lambda o, q: reduce_scatter(o, q, on), nc)
+          e1.record()
+          D.synchronize()
+          if it:
+            step_ms.append(e0.elapsed_ms(e1))
+            gemm_ms.append(sum(a.elapsed_ms(b) for (a, b, _, _, _) in be.gemm_events))
+          del result
+        be.gemm_events = None
+        res[mode] = (sum(step_ms) / len(step_ms), sum(gemm_ms) / len(gemm_ms))
+      step_on, gemm_on = res['with_transfers']
+      step_off, gemm_off = res['compute_only']
+      out['cases'].append({
+          'p': p, 'chunk_cols': nc, 'gemms_per_step': (n // nc - 1) + 3,
+          'step_ms': round(step_on, 2), 'step_ms_compute_only': round(step_off, 2),
+          'gemm_kernels_ms': round(gemm_on, 2), 'gemm_kernels_ms_compute_only': round(gemm_off, 2),
+          'gemm_TFLOPs_compute_only': round(flop / p / gemm_off / 1e9, 1),
+          'gemm_frac_of_mfma_peak_compute_only': round(flop / p / gemm_off / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
+          'gemm_slowdown_under_transfers': round(gemm_on / gemm_off, 3),
+          'transfer_bytes_per_step': moved['bytes'],
+          'implied_speedup_bound': round(one_gpu_ms / step_on, 2)})
+    del my_a, my_b, scratch
+    D.trim_pool()
+  best8 = max((c for c in out['cases'] if c['p'] == 8), key=lambda c: c['implied_speedup_bound'])
+  out['implied_8gpu_speedup_upper_bound'] = best8['implied_speedup_bound']
+  out['best_chunk_cols_at_p8'] = best8['chunk_cols']
+  out['note'] = ('an UPPER bound, not a scaling measurement: link bandwidth and RCCL latency are not modelled, only '
+                 'the CUs and HBM bandwidth a concurrent transfer takes from the GEMMs and what the pipeline leaves '
+                 'exposed; target >= 6x at 8 GPUs')
+  return out
+
+
 def cpu_baseline():
   """The reference's execution model on the host cores of this box: W = min(physical
   cores, 64) worker processes, one per core, pinned, one BLAS thread each (spartan/worker.py:40,385-387), running
-  the oracle's NumPy tile bodies on bounded samples of the BASELINE shapes; the parent merges like the owner of
+  the oracle's NumPy tile bodies on BOUNDED samples of the BASELINE shapes (the measurement contract asks for
+  about 10-30 s of CPU work in a default run; every shape below is stated); the parent merges like the owner of
   the target tile.  A reported baseline, not a target."""
   from oracle import cpu_workers
   t_all = time.perf_counter()
@@ -324,24 +481,45 @@ def cpu_baseline():
   finally:
     pool.close()
   e = float(rows) * cols
-  return {'value': round(2.0 * n ** 3 / t_dot / 1e12, 4), 'unit': 'TFLOP/s', 'cores': W, 'kind': 'port',
+  end_to_end = 2.0 * n ** 3 / t_dot / 1e12
+  gemm_only = 2.0 * n ** 3 / t_dot_compute / 1e12
+  return {'value': round(end_to_end, 4), 'unit': 'TFLOP/s', 'cores': W, 'kind': 'port',
+          'value_is': 'dot end to end: the W per-worker GEMMs AND the W M x N partials travelling to the owner of the '
+                      'one target tile and being added there (dot.py:277-278); the GEMMs alone: gemm_only_value',
+          'gemm_only_value': round(gemm_only, 4),
           'workers': '%d processes pinned to %d physical cores, 1 BLAS thread each' % (W, W),
           'dot': {'shape': '%dx%dx%d fp32, K-split over %d workers, one target tile' % (n, n, n, W),
                   'seconds': round(t_dot, 3), 'gemm_seconds': round(t_dot_compute, 3),
-                  'TFLOPs': round(2.0 * n ** 3 / t_dot / 1e12, 4),
-                  'note': 'the partials travel to the owner through pipes and are added there one by one, as the '
-                          'reference pickles them to the owner of its single target tile (dot.py:277-278)'},
+                  'TFLOPs_end_to_end': round(end_to_end, 4), 'TFLOPs_gemm_only': round(gemm_only, 4)},
           'map_xx_plus_x_GBps': round(8.0 * e / t_map / 1e9, 2), 'sum_axis0_GBps': round(4.0 * e / t_sum / 1e9, 2),
           'map_sum_shape': '%dx%d fp32 in %d row tiles' % (rows, cols, W),
           'lreg_step': {'shape': '%dx%d fp32' % (ln, ld), 'seconds': round(t_lreg, 4),
                         'GBps': round(2 * 4.0 * ln * ld / t_lreg / 1e9, 2)},
           'kmeans_iteration': {'shape': '%dx%d points, k=%d' % (kn, kd, kk), 'seconds': round(t_km, 3),
                                'TFLOPs_of_2nkd': round(2.0 * kn * kk * kd / t_km / 1e12, 4)},
-          'sample': 'oracle tile bodies (NumPy / BLAS / scipy cdist) on %d pinned one-thread workers: dot %d^3 '
-                    'K-split; x*x+x and sum(axis=0) on %dx%d; one lreg step on %dx%d; one k-means iteration on '
-                    '%dx%d, k=%d -- scaled from the BASELINE shapes to stay within ~20 s' %
+          'sample': 'oracle tile bodies (NumPy / BLAS / scipy cdist) on %d pinned one-thread workers, bounded samples '
+                    'of the BASELINE workloads: dot %d^3 K-split (configs[1] is 8192^3); x*x+x and sum(axis=0) on '
+                    '%dx%d (configs[2] is 65536x65536); one lreg step on %dx%d (configs[4] is 1000000x4096); one '
+                    'k-means iteration on %dx%d, k=%d (configs[3] is 10000000x256)' %
                     (W, n, rows, cols, ln, ld, kn, kd, kk),
           'wall_seconds': round(time.perf_counter() - t_all, 1)}
+
+
+def measured_traffic(n):
+  """HBM bytes per GEMM launch from the PMC passes tools/profile_round.sh took (profiles/roofline_traffic.json),
+  quoted only if those passes ran on THIS tree (the kernel sources' hash matches); else None + why."""
+  path = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
+  try:
+    rec = json.load(open(path))
+  except Exception:
+    return None, 'no profiles/roofline_traffic.json'
+  sha = _hip.source_sha()
+  if rec.get('tree_sha') != sha:
+    return None, ('profiles/roofline_traffic.json was measured on kernel sources %s, this tree is %s: not quoted'
+                  % (rec.get('tree_sha'), sha))
+  val = rec.get('gemm_%d' % n, {}).get('traffic_bytes')
+  return val, ('profiles/roofline_traffic.json (tree %s): 2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes '
+               'of this kernel and shape; algorithmic floor %d bytes' % (sha, 12 * n * n))
 
 
 _REAL_STDOUT = None
@@ -373,7 +551,8 @@ def main():
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--size', type=int, default=0, help='matrix order (default: 8192 on one GPU, 32768 on several)')
-  ap.add_argument('--no-extras', action='store_true', help='skip the map/reduce, north-star and CPU-baseline sections')
+  ap.add_argument('--no-extras', action='store_true', help='headline only: skip the HBM / workload / emulation / CPU sections')
+  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,lreg,kmeans,sparse,ksplit,cpu)')
   args = ap.parse_args()
 
   world = sp.World.from_env()
@@ -390,7 +569,7 @@ def main():
     tag = {8192: 'BASELINE configs[1]', NORTH_STAR: 'north-star shape'}.get(n, 'custom size')
     workload = 'spartan.dot %dx%dx%d fp32, one tile (%s)' % (n, n, n, tag)
     parallelism = 'single tile'
-    scaling = 'weak'
+    scaling = None                 # one GPU: neither weak nor strong
   else:
     if n % p:
       raise SystemExit('--size %d is not a multiple of --gpus %d' % (n, p))
@@ -399,9 +578,9 @@ def main():
     B = sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, SEED + 1), tile_hint=hint)
     workload = ('spartan.dot %dx%dx%d fp32 (north star), A, B and the result row-tiled %d x (%dx%d)'
                 % (n, n, n, p, n // p, n))
-    parallelism = ('K-split map2 join, 1 worker per GPU: all-to-all of A blocks, %d GEMMs per column chunk, one '
-                   'asynchronous reduce-scatter per chunk behind the next chunk (transport: %s)'
-                   % (p, world.note or getattr(world.transport, 'name', '?')))
+    parallelism = ('K-split map2 join, 1 worker per GPU: all-to-all of A blocks into one slab, one GEMM per column '
+                   'chunk, one asynchronous reduce-scatter per chunk behind the next chunk (transport: %s)'
+                   % (world.note or getattr(world.transport, 'name', '?')))
     scaling = 'strong'
   A.force()
   B.force()
@@ -414,48 +593,45 @@ def main():
   # set-up launches (untimed, before the W warm-up steps): library load, allocator warm-up, and the
   # device's one-off dispatch stall (~30 ms, seen once per process about 50 ms into the first sustained
   # MFMA load on these boxes: profiles/r01_notes.md) -- so neither lands in the timed steps
-  for _ in range(SETUP_LAUNCHES if p == 1 else 2):
+  setup = SETUP_LAUNCHES if p == 1 else 2
+  D.synchronize()
+  t_head = clocks()
+  for _ in range(setup):
     step()
-  torch.cuda.synchronize()
+  D.synchronize()
   ctx.backend.gemm_events = []
   stats0 = dict(world.stats)
   dt = time_steps(ctx, step, args.steps, args.warmup)
-  torch.cuda.synchronize()
+  D.synchronize()
   stats1 = dict(world.stats)
   all_events = ctx.backend.gemm_events
   ctx.backend.gemm_events = None
-  # launches per step: 1 on one GPU; p per column chunk of the partial on several (dot.ksplit_plan)
+  # launches per step: 1 on one GPU; 3 + (chunks - 1) on several (dot.ksplit_pipeline)
   per_step = max(1, len(all_events) // (args.steps + args.warmup))
   events = all_events[-args.steps * per_step:]
   kernel_ms = [e0.elapsed_ms(e1) for (e0, e1, _, _, _) in events]
-  flops_launch = 2.0 * events[0][2] * events[0][3] * events[0][4]
+  flops_timed = sum(2.0 * m_ * n_ * k_ for (_, _, m_, n_, k_) in events)
+  achieved = flops_timed / (sum(kernel_ms) * 1e-3) / 1e12
   avg_ms = sum(kernel_ms) / len(kernel_ms)
-  achieved = flops_launch / (avg_ms * 1e-3) / 1e12
-
   flop_step = 2.0 * n * n * n
+  if p == 1:
+    note_section('dot %d^3 (headline)' % n, GEMM_KERNEL, setup + args.warmup + args.steps, flop_step, 'flop', 'mfma', t_head, clocks())
   value = flop_step * args.steps / dt / 1e12
   line = {
       'metric': 'spartan.dot TFLOP/s (+ map/reduce HBM GB/s)', 'value': round(value, 2), 'unit': 'TFLOP/s',
       'n_gpus': p, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
       'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': workload, 'parallelism': parallelism, 'flop_per_step': flop_step,
-                 'setup_launches': SETUP_LAUNCHES if p == 1 else 2,
-                 'inputs': 'uniform[-1,1) fp32 generated on device, resident in HBM'},
+                 'setup_launches': setup,
+                 'inputs': 'uniform[-1,1) fp32 generated on device (sp_random_fill, Philox), resident in HBM',
+                 'host': 'no torch in this process' if 'torch' not in sys.modules else 'torch.distributed (gloo) control plane'},
       'roofline': {'bound': 'mfma', 'kernel': 'sp_gemm_glds_kernel<256x128x16, 4 waves> (v_mfma_f32_32x32x2_f32, k-tiles by global_load_lds)',
                    'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                   'flop_per_launch': flops_launch, 'avg_launch_ms': round(avg_ms, 4),
+                   'flop_per_launch': flops_timed / len(events), 'avg_launch_ms': round(avg_ms, 4),
                    'launches_per_step': per_step, 'traffic': None},
   }
-  traffic_file = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-  if os.path.exists(traffic_file):
-    try:
-      line['roofline']['traffic'] = json.load(open(traffic_file)).get('gemm_%d' % n)
-      line['roofline']['traffic_source'] = ('profiles/pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 '
-                                            '--pmc run of this kernel and shape (not of this run); algorithmic floor '
-                                            '%d bytes' % (12 * n * n))
-    except Exception:
-      pass
+  line['roofline']['traffic'], line['roofline']['traffic_source'] = measured_traffic(n)
   if p > 1:
     # this rank's share of a step: kernel-only time vs wall, and the bytes it moved against the xGMI rates
     sent = {k: (stats1[k] - stats0[k]) / float(args.steps + args.warmup) for k in stats0}
@@ -469,33 +645,51 @@ def main():
         'exchange_GBps_per_gpu_if_serial': round((sent['p2p_bytes'] + sent['collective_bytes']) / step_s / 1e9, 1),
         'xgmi_GBps_per_gpu': {'one_link': XGMI_LINK_GBPS, 'seven_links': 7 * XGMI_LINK_GBPS},
         'note': 'bytes are what ONE GPU sends per step ((p-1)/p of its 4*M*N partial and of its A tile); the '
-                'reduce-scatters run on a communication stream behind the GEMMs of the next chunk',
+                'reduce-scatters run on a communication stream behind the GEMM of the next chunk',
     }
-  if world.rank == 0 and not args.no_extras and p == 1:
+  only = set(x for x in args.only.split(',') if x)
+  want = lambda name: not args.no_extras and (not only or name in only)   # noqa: E731
+  if world.rank == 0 and p == 1:
     del keep[:]
-    torch.cuda.empty_cache()
-    line['northstar_%d' % NORTH_STAR] = northstar_section(ctx)
-    torch.cuda.empty_cache()
-    line['hbm'] = hbm_section(ctx)
-    torch.cuda.empty_cache()
-    line['kmeans'] = kmeans_section(ctx)
-    torch.cuda.empty_cache()
-    line['sparse'] = sparse_section(ctx)
-    torch.cuda.empty_cache()
-    line['cpu_baseline'] = cpu_baseline()
+    D.trim_pool()
+    if want('northstar'):
+      line['northstar_%d' % NORTH_STAR] = northstar_section(ctx)
+      D.trim_pool()
+    if want('hbm'):
+      line['hbm'] = hbm_section(ctx)
+      D.trim_pool()
+    if want('lreg'):
+      line['lreg'] = lreg_section(ctx, line.get('hbm', {}).get('stream_copy_GBps', 6400.0))
+      D.trim_pool()
+    if want('kmeans'):
+      line['kmeans'] = kmeans_section(ctx)
+      D.trim_pool()
+    if want('sparse'):
+      line['sparse'] = sparse_section(ctx)
+      D.trim_pool()
+    if want('ksplit'):
+      one = line.get('northstar_%d' % NORTH_STAR, {}).get('ms_per_call') or 2.0 * NORTH_STAR ** 3 / (value * 1e9)
+      line['ksplit_rank_emulation'] = ksplit_rank_emulation(ctx, one)
+      D.trim_pool()
+    if want('cpu'):
+      line['cpu_baseline'] = cpu_baseline()
+    line['profile_table'] = PROFILE_TABLE
+    live, pooled = D.blob_stats()
+    line['tile_store'] = {'live_blobs': live, 'pooled_bytes': pooled, 'kernel_sources': _hip.source_sha()}
   if world.distributed:
     line['comm'] = dict(world.stats)
     line['comm']['transport'] = world.note or getattr(world.transport, 'name', '?')
     if not args.no_extras:
       del keep[:]
       del A, B
-      torch.cuda.empty_cache()
+      D.trim_pool()
       line['hbm_dist'] = guarded(lambda: dist_section(ctx), 240, world.rank, dict(line))
   world.barrier()
   _emit(line, world.rank)
   sp.shutdown()
   world.close()
   if world.distributed:
+    import torch.distributed
     torch.distributed.destroy_process_group()
 
 

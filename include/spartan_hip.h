@@ -443,6 +443,12 @@ int sp_gather_rows(const void* d_src, int64_t src_row_stride_bytes, int64_t n_sr
 /* sp_stream_copy: STREAM-style float4 copy used by bench.py to measure the
  * achievable HBM bandwidth of the box ("measured HBM bandwidth"). */
 int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream);
+/* The same copy on at most `max_workgroups` workgroups (0 = the full grid): a transfer that occupies a bounded
+ * share of the CUs, the way a collective's channels do -- bench.py's one-GPU emulation of a rank of the K-split
+ * dot uses it in place of the RCCL kernels it cannot run on one device. */
+int sp_stream_copy_wg(void* d_dst, const void* d_src, size_t bytes, int32_t max_workgroups, void* stream);
+/* hipMemsetAsync on `stream` (zero-initialised tiles: `Tile._initialize`, spartan/array/tile.pyx:115-127). */
+int sp_memset(void* d_dst, int32_t value, size_t bytes, void* stream);
 
 /* ---- the tile store: HBM blobs owned by the library ------------------------------------------------------
  * What a worker's `_blobs: TileId -> Tile` dictionary stores (spartan/worker.py:70) and BlobCtx creates, reads,
@@ -511,7 +517,9 @@ int sp_comm_all_to_all_blocks(void* comm, int32_t n_sends, const int32_t* send_p
  * the events below (the reference's worker serialises tile mutation with a lock, worker.py:134,160,181; here it
  * is stream order). */
 int sp_set_device(int32_t device);
+int sp_device_synchronize(void);
 int sp_stream_create(void** stream);
+int sp_stream_create_priority(void** stream, int32_t high_priority);   /* high: collectives ahead of queued GEMMs */
 int sp_stream_destroy(void* stream);
 int sp_stream_synchronize(void* stream);
 int sp_stream_query(void* stream, int32_t* done);
@@ -523,6 +531,7 @@ int sp_event_create(void** ev);
 int sp_event_destroy(void* ev);
 int sp_event_record(void* ev, void* stream);
 int sp_event_synchronize(void* ev);
+int sp_event_query(void* ev, int32_t* done);
 int sp_event_elapsed_ms(void* start, void* stop, float* ms);
 
 #ifdef __cplusplus

@@ -12,28 +12,22 @@ NumPy (spartan/array/tile.pyx:200-297).  It exists so that
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  `spartan_amd.initialize()` never selects it by itself.
 
-Tile payloads are torch CPU tensors (so torch.distributed/gloo can move them);
-all arithmetic is NumPy on views of them.
+Tile payloads are NumPy arrays, exactly what the reference's workers hold (spartan/worker.py:70); across gloo
+ranks the transport wraps them as CPU tensors without copying (spartan_amd/comm.py TorchTransport).
 """
 import numpy as np
 import scipy.sparse as sps
-import torch
 
 from spartan_amd.array import distarray, tile
 from spartan_amd.expr.local import FnCallExpr, LocalInput, LocalMapLocationExpr
 
 _REDUCERS = {None: 'NONE', np.add: 'ADD', np.multiply: 'MUL', np.maximum: 'MAX', np.minimum: 'MIN',
              np.logical_and: 'AND', np.logical_or: 'OR'}
-_NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
-         np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64,
-         np.dtype(np.bool_): torch.bool, np.dtype(np.uint8): torch.uint8}
-_T2NP = {v: k for k, v in _NP2T.items()}
+_DTYPES = set(np.dtype(t) for t in (np.float32, np.float64, np.int32, np.int64, np.bool_, np.uint8))
 
 
 def _np(x):
   """NumPy view of a local value."""
-  if isinstance(x, torch.Tensor):
-    return x.numpy()
   if isinstance(x, tile.EmptyBlob):
     return np.ndarray(x.shape, x.dtype)  # uninitialised, like tile.pyx:72-79
   return x
@@ -48,30 +42,34 @@ class NumpyBackend(object):
 
   # -- memory
   def empty(self, shape, dtype):
-    return torch.empty(tuple(int(s) for s in shape), dtype=_NP2T[np.dtype(dtype)])
+    return np.empty(tuple(int(s) for s in shape), dtype=self._known(dtype))
 
   def zeros(self, shape, dtype):
-    return torch.zeros(tuple(int(s) for s in shape), dtype=_NP2T[np.dtype(dtype)])
+    return np.zeros(tuple(int(s) for s in shape), dtype=self._known(dtype))
+
+  @staticmethod
+  def _known(dtype):
+    dtype = np.dtype(dtype)
+    if dtype not in _DTYPES:
+      raise TypeError('unsupported dtype %s' % dtype)
+    return dtype
 
   def from_numpy(self, arr):
     arr = np.asarray(arr)
     arr = arr if arr.flags['C_CONTIGUOUS'] else arr.copy(order='C')  # (ascontiguousarray would make 0-d -> 1-d)
-    if arr.dtype not in _NP2T:
-      raise TypeError('unsupported dtype %s' % arr.dtype)
-    return torch.from_numpy(arr.copy())
+    self._known(arr.dtype)
+    return arr.copy()
 
   def to_numpy(self, t):
     if isinstance(t, np.ndarray):
       return t
     if isinstance(t, tile.EmptyBlob):
       return np.zeros(t.shape, t.dtype)
-    return t.numpy().copy()
+    return np.array(t, copy=True)
 
   def dtype_of(self, t):
     if sps.issparse(t):
       return np.dtype(t.dtype)
-    if isinstance(t, torch.Tensor):
-      return _T2NP[t.dtype]
     if isinstance(t, (tile.EmptyBlob, distarray.Absent, np.ndarray, np.generic)):
       return np.dtype(t.dtype)
     return np.asarray(t).dtype
@@ -80,10 +78,13 @@ class NumpyBackend(object):
     return self.dtype_of(t) == np.dtype(dtype)
 
   def contiguous(self, t):
-    return t.contiguous()
+    return t if t.flags['C_CONTIGUOUS'] else np.ascontiguousarray(t).reshape(t.shape)
 
   def copy(self, t):
-    return t.clone().contiguous()
+    return np.array(t, copy=True, order='C')
+
+  def same_memory(self, a, b):
+    return isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and np.shares_memory(a, b)
 
   def astype(self, t, dtype):
     if self.dtype_of(t) == np.dtype(dtype):
@@ -98,18 +99,19 @@ class NumpyBackend(object):
 
   def gemm_into(self, a, b, out, accumulate=False):
     self.launches += 1
-    prod = torch.from_numpy(np.ascontiguousarray(_np(a).dot(_np(b))))
-    out.copy_(out + prod if accumulate else prod)
+    self.gemms = getattr(self, 'gemms', 0) + 1
+    prod = _np(a).dot(_np(b))
+    out[...] = out + prod if accumulate else prod
     return out
 
   def paste(self, dst, dst_slices, src):
-    view = dst[dst_slices] if dst.dim() else dst
-    view.copy_(src.reshape(view.shape))
+    view = dst[dst_slices] if dst.ndim else dst
+    view[...] = src.reshape(view.shape)
 
   # -- Tile.merge (tile.pyx:250-283), on the box [ul, lr)
   def update_box(self, dst, ul, lr, src, reducer, mask_mode, mask):
     self.launches += 1
-    d = dst.numpy()
+    d = dst
     s = _np(src)
     if d.ndim == 0:
       d[...] = reducer(d, s) if reducer is not None else s
@@ -117,7 +119,7 @@ class NumpyBackend(object):
     box = tuple(slice(u, l) for u, l in zip(ul, lr))
     s = s.reshape(d[box].shape)
     if mask_mode == 2:
-      m = mask.numpy()[box].astype(bool)
+      m = mask[box].astype(bool)
     else:
       m = np.full(d[box].shape, mask_mode == tile.MASK_ALL_SET, dtype=bool)
     region = d[box]
@@ -130,13 +132,13 @@ class NumpyBackend(object):
       else:
         region[m] = s[m]
     if mask is not None:
-      mask.numpy()[box] = 1
+      mask[box] = 1
 
   def mask_all_set(self, mask, subslice):
-    return bool(np.all(mask.numpy()[subslice]))
+    return bool(np.all(mask[subslice]))
 
   def mask_first(self, mask):
-    return bool(mask.numpy().reshape(-1)[0])
+    return bool(mask.reshape(-1)[0])
 
   # -- LocalExpr evaluation exactly as the reference worker does it
   def _eval(self, op, inputs, ex):
@@ -178,11 +180,7 @@ class NumpyBackend(object):
     return self._wrap(self._eval(op, inputs, ex), ex.shape)
 
   def assign_box(self, dst, slices, value):
-    view = dst[slices]
-    if isinstance(value, torch.Tensor):
-      view.copy_(value.reshape(view.shape))
-    else:
-      view.copy_(torch.from_numpy(np.broadcast_to(np.asarray(value), tuple(view.shape)).astype(_T2NP[dst.dtype])))
+    dst[slices] = np.broadcast_to(np.asarray(value), dst[slices].shape).astype(dst.dtype)
 
   def evaluate_fn(self, fn, args, kw, out_shape):
     self.launches += 1
@@ -309,15 +307,13 @@ class NumpyBackend(object):
     c = sps.csr_matrix(b)
     c.sum_duplicates()
     c.sort_indices()
-    return (torch.from_numpy(c.indptr.astype(np.int64)), torch.from_numpy(c.indices.astype(np.int32)),
-            torch.from_numpy(np.ascontiguousarray(c.data)))
+    return c.indptr.astype(np.int64), c.indices.astype(np.int32), np.ascontiguousarray(c.data)
 
   def sparse_parts_empty(self, shape, dtype, nnz):
-    return (torch.empty(int(shape[0]) + 1, dtype=torch.int64), torch.empty(int(nnz), dtype=torch.int32),
-            torch.empty(int(nnz), dtype=_NP2T[np.dtype(dtype)]))
+    return np.empty(int(shape[0]) + 1, np.int64), np.empty(int(nnz), np.int32), np.empty(int(nnz), np.dtype(dtype))
 
   def sparse_from_parts(self, shape, dtype, parts):
-    indptr, indices, data = (t.numpy() for t in parts)
+    indptr, indices, data = parts
     return sps.csr_matrix((data.astype(dtype), indices, indptr), shape=tuple(shape))
 
   def sparse_empty(self, shape, dtype):
@@ -347,8 +343,8 @@ class NumpyBackend(object):
   def sparse_scatter(self, dst, ul, blob, mode, mask):
     """sparse.pyx:21-38 sparse_to_dense_update with REDUCE_ADD, entry by entry in COO order."""
     self.launches += 1
-    d = dst.numpy()
-    m = mask.numpy() if mask is not None else None
+    d = dst
+    m = mask if mask is not None else None
     coo = blob.tocoo()
     for r, c, v in zip(coo.row + ul[0], coo.col + ul[1], coo.data):
       if mode == 0 or (mode == 2 and not m[r, c]):
@@ -375,7 +371,7 @@ class NumpyBackend(object):
     return sps.rand(shape[0], shape[1], density=density, format='csr', dtype=dtype)
 
   def _as_device(self, t):
-    return t if isinstance(t, torch.Tensor) else self.from_numpy(np.asarray(t))
+    return np.asarray(t)
 
   def synchronize(self):
     pass

@@ -139,6 +139,11 @@ def _declare(lib):
   lib.sp_tiling_solve.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
   lib.sp_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp]
   lib.sp_stream_copy.argtypes = [vp, vp, sz, vp]
+  lib.sp_stream_copy_wg.argtypes = [vp, vp, sz, i32, vp]
+  lib.sp_memset.argtypes = [vp, i32, sz, vp]
+  lib.sp_device_synchronize.argtypes = []
+  lib.sp_stream_create_priority.argtypes = [pp, i32]
+  lib.sp_event_query.argtypes = [vp, C.POINTER(i32)]
   u64 = C.c_uint64
   lib.sp_blob_create.argtypes = [p64, i32, i32, C.POINTER(u64)]
   lib.sp_blob_destroy.argtypes = [u64]
@@ -189,8 +194,26 @@ EXPORTS = [
     'sp_blob_slice_copy', 'sp_comm_available', 'sp_comm_version', 'sp_comm_unique_id', 'sp_comm_init',
     'sp_comm_destroy', 'sp_comm_abort', 'sp_comm_async_error', 'sp_comm_all_reduce', 'sp_comm_reduce_scatter',
     'sp_comm_reduce', 'sp_comm_all_gather', 'sp_comm_bcast', 'sp_comm_all_to_all_blocks', 'sp_set_device',
-    'sp_stream_create', 'sp_stream_destroy', 'sp_stream_synchronize', 'sp_stream_query', 'sp_stream_wait_event',
+    'sp_stream_create', 'sp_stream_create_priority', 'sp_device_synchronize', 'sp_memset', 'sp_stream_copy_wg',
+    'sp_event_query', 'sp_stream_destroy', 'sp_stream_synchronize', 'sp_stream_query', 'sp_stream_wait_event',
 ]
+
+
+def source_sha():
+  """First 16 hex digits of the sha256 over the kernel sources (csrc/*.hip, *.hpp, the C-ABI header): profile
+  summaries under profiles/ are stamped with it, and bench.py quotes a counter measurement only for the tree it
+  was taken on."""
+  import glob
+  import hashlib
+  h = hashlib.sha256()
+  csrc = os.path.join(_HERE, 'csrc')
+  files = sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.hpp')))
+  files.append(os.path.join(os.path.dirname(_HERE), 'include', 'spartan_hip.h'))
+  for f in files:
+    h.update(os.path.basename(f).encode())
+    with open(f, 'rb') as fh:
+      h.update(fh.read())
+  return h.hexdigest()[:16]
 
 
 def lib():

@@ -66,18 +66,106 @@ def _tile_mapper(tile_id, blob, array=None, user_fn=None, **kw):
 
 
 class Absent(object):
-  """Stands for tile data that lives on another rank (this rank is not the
-  one executing the current mapper); carries shape/dtype only."""
+  """Stands for tile data that lives on another rank (this rank is not the one executing the current mapper).
+  It carries shape and dtype only, and answers the ndarray calls a user mapper makes on its tiles (`.T`,
+  `.reshape`, `.sum(axis, keepdims=...)`, `.dot`, arithmetic, NumPy ufuncs, slicing) with another placeholder of
+  the right shape and dtype -- so the SAME mapper runs on every rank, yields the same extents everywhere, and only
+  the executing rank touches data."""
   __slots__ = ('shape', 'dtype')
+  __array_priority__ = 2000.0
 
   def __init__(self, shape, dtype):
-    self.shape = tuple(shape)
+    self.shape = tuple(int(s) for s in shape)
     self.dtype = np.dtype(dtype)
+
+  ndim = property(lambda self: len(self.shape))
+  size = property(lambda self: int(np.prod(self.shape, dtype=np.int64)))
+
+  def _like(self, fn, *others, **kw):
+    """Shape / dtype of fn(self, *others) as NumPy would compute it, found on zero-stride dummies (no data)."""
+    def dummy(x):
+      if isinstance(x, Absent) or (hasattr(x, 'shape') and hasattr(x, 'dtype') and not isinstance(x, (np.ndarray, np.generic))):
+        return np.broadcast_to(np.zeros((), np.dtype(x.dtype)), tuple(x.shape))
+      return x
+    with np.errstate(all='ignore'):
+      res = fn(*[dummy(a) for a in (self,) + others], **kw)
+    res = np.asarray(res)
+    return Absent(res.shape, res.dtype)
 
   def reshape(self, *shape):
     if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
       shape = tuple(shape[0])
-    return Absent(shape, self.dtype)
+    return self._like(lambda a: a.reshape(shape))
+
+  def transpose(self, *axes):
+    return self._like(lambda a: a.transpose(*axes))
+
+  T = property(lambda self: self.transpose())
+
+  def astype(self, dtype, **kw):
+    return Absent(self.shape, dtype)
+
+  def copy(self):
+    return self
+
+  def dot(self, other):
+    return _absent_dot(self, other)
+
+  def __getitem__(self, idx):
+    return self._like(lambda a: a[idx])
+
+  def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+    kw.pop('out', None)
+    first = inputs[0] if isinstance(inputs[0], Absent) else Absent(np.shape(inputs[0]), np.asarray(inputs[0]).dtype if not hasattr(inputs[0], 'dtype') else inputs[0].dtype)
+    return first._like(lambda *a: getattr(ufunc, method)(*a, **kw), *inputs[1:])
+
+  def __array_function__(self, func, types, args, kwargs):
+    def dummy(x):
+      if isinstance(x, (list, tuple)):
+        return type(x)(dummy(v) for v in x)
+      if hasattr(x, 'shape') and hasattr(x, 'dtype') and not isinstance(x, (np.ndarray, np.generic)):
+        return np.broadcast_to(np.zeros((), np.dtype(x.dtype)), tuple(x.shape))
+      return x
+    with np.errstate(all='ignore'):
+      res = np.asarray(func(*dummy(list(args)), **kwargs))
+    return Absent(res.shape, res.dtype)
+
+
+def _absent_dot(a, b):
+  ash, bsh = tuple(a.shape), tuple(b.shape) if hasattr(b, 'shape') else tuple(np.shape(b))
+  dt = np.result_type(a.dtype, b.dtype if hasattr(b, 'dtype') else np.asarray(b).dtype)
+  if len(ash) == 1 and len(bsh) == 1:
+    return Absent((), dt)
+  if len(bsh) == 1:
+    return Absent(ash[:-1], dt)
+  if len(ash) == 1:
+    return Absent(bsh[1:], dt)
+  return Absent(ash[:-1] + bsh[1:], dt)
+
+
+def _absent_method(name):
+  def method(self, *args, **kw):
+    return self._like(lambda a: getattr(a, name)(*args, **kw))
+  return method
+
+
+def _absent_binary(ufunc, swap=False):
+  def op(self, other):
+    return self._like((lambda a, b: ufunc(b, a)) if swap else ufunc, other)
+  return op
+
+
+for _n in ('sum', 'prod', 'max', 'min', 'mean', 'all', 'any', 'argmax', 'argmin', 'ravel', 'flatten', 'squeeze', 'swapaxes'):
+  setattr(Absent, _n, _absent_method(_n))
+for _n, _u in dict(add=np.add, sub=np.subtract, mul=np.multiply, truediv=np.true_divide, floordiv=np.floor_divide,
+                   mod=np.remainder, pow=np.power).items():
+  setattr(Absent, '__%s__' % _n, _absent_binary(_u))
+  setattr(Absent, '__r%s__' % _n, _absent_binary(_u, swap=True))
+for _n, _u in dict(lt=np.less, le=np.less_equal, gt=np.greater, ge=np.greater_equal).items():
+  setattr(Absent, '__%s__' % _n, _absent_binary(_u))
+Absent.__neg__ = lambda self: self
+Absent.__abs__ = lambda self: self
+Absent.__matmul__ = lambda self, other: _absent_dot(self, other)
 
 
 def _slices_shape(slices, base_shape):
@@ -301,7 +389,7 @@ def _ship_sparse(ctx, outgoing):
   core.py / rpc/zeromq.py; round 1 all-gathered host objects here.)"""
   be, world = ctx.backend, ctx.world
   parts = {k: be.sparse_parts(b) for k, (_, b) in outgoing.items()}
-  mine = {k: (tuple(b.shape), np.dtype(be.dtype_of(b)).str, int(parts[k][1].numel()), sorted(dsts))
+  mine = {k: (tuple(b.shape), np.dtype(be.dtype_of(b)).str, int(parts[k][1].size), sorted(dsts))
           for k, (dsts, b) in outgoing.items()}
   sends, recvs, arriving = [], [], {}
   for src, listing in enumerate(world.all_gather_object(mine)):

@@ -1,7 +1,7 @@
 """Tile: the unit of storage (an HBM blob) and of the combine step.
 
 Mirror of the reference's spartan/array/tile.pyx.  `data` is a backend tensor
-(torch tensor in HBM for the HIP backend) instead of a NumPy array; the mask is
+(a device array in HBM for the HIP backend, spartan_amd/devarray.py) instead of a NumPy array; the mask is
 kept as a *state* (all-clear / all-set) and only materialised as a byte array in
 HBM when a sub-slice update makes it non-uniform -- the reference allocates a
 1 B/element bool array for every tile (tile.pyx:145-159), which would cost 25 %
@@ -180,7 +180,7 @@ def merge(backend, old_tile, subslice, update, reducer, owned=False):
     # tile.pyx:212-217: data None acts as the mask
     if old_tile.data is None or reducer is None:
       data = backend.astype(update.reshape(()), old_tile.dtype)
-      if not owned and data.data_ptr() == update.data_ptr():
+      if not owned and backend.same_memory(data, update):
         data = backend.copy(data)     # never alias the caller's tensor
       old_tile.data = data
     else:

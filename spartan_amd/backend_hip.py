@@ -2,18 +2,21 @@
 
 Implements the backend seam (the role ParakeetExpr.evaluate plays in the
 reference, spartan/expr/operator/local.py:187-209) on top of the C-ABI
-(include/spartan_hip.h) for tile blobs that live in HBM as torch tensors.
-Constructing it without a GPU or without the built library raises: there is no
-CPU fallback in the product path.
+(include/spartan_hip.h) for tile blobs that live in HBM in the library's tile store
+(spartan_amd/devarray.py: DevArray views of sp_blob_* allocations; streams and events are
+the C-ABI's too -- no torch on this path).  Constructing it without a GPU or without the
+built library raises: there is no CPU fallback in the product path.
 """
 import collections
 import os
 import time
 
+import ctypes
+
 import numpy as np
-import torch
 
 from . import _hip, kernels, lower
+from . import devarray as D
 from . import sparse as sparse_mod
 from .array import distarray, tile
 from .expr.local import FnCallExpr, LocalInput
@@ -42,42 +45,44 @@ class HipBackend(object):
   name = 'hip'
 
   def __init__(self, device=None):
-    _hip.lib()  # raises HipLibraryMissing if the extension has not been built
-    if not torch.cuda.is_available():
-      raise _hip.HipError('the HIP tile backend needs an AMD GPU (torch.cuda.is_available() is False); '
+    lib = _hip.lib()  # raises HipLibraryMissing if the extension has not been built
+    count = ctypes.c_int(0)
+    if lib.sp_device_count(ctypes.byref(count)) != 0 or count.value < 1:
+      raise _hip.HipError('the HIP tile backend needs an AMD GPU (no HIP device is visible); '
                           'there is no CPU fallback')
-    self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    self.device = 'hip'
     self._np_cache = collections.OrderedDict()   # bounded: iterative drivers pass a new array every step
     self.launches = 0
+    self.gemms = 0            # gemm_into launches (the K-split tests count them)
     self.gemm_events = None   # set to [] to record (start, stop) HIP events around every GEMM launch
     self._rng_seed = (int(time.time() * 100000) + os.getpid()) & (2**63 - 1)   # srandom.py:23-35: from the clock
     self._rng_offset = 0
 
   # -- memory -------------------------------------------------------------------
   def empty(self, shape, dtype):
-    return torch.empty(tuple(int(s) for s in shape), dtype=kernels.torch_dtype(dtype), device=self.device)
+    return D.empty(tuple(int(s) for s in shape), dtype)
 
   def zeros(self, shape, dtype):
-    return torch.zeros(tuple(int(s) for s in shape), dtype=kernels.torch_dtype(dtype), device=self.device)
+    return D.zeros(tuple(int(s) for s in shape), dtype)
 
   def from_numpy(self, arr):
-    arr = np.asarray(arr)
-    arr = arr if arr.flags['C_CONTIGUOUS'] else arr.copy(order='C')  # (ascontiguousarray would make 0-d -> 1-d)
-    return torch.from_numpy(arr).to(self.device)
+    return D.from_numpy(arr)
 
   def to_numpy(self, t):
     if isinstance(t, np.ndarray):
       return t
     if isinstance(t, tile.EmptyBlob):
       return np.zeros(t.shape, t.dtype)
-    return t.detach().cpu().numpy()
+    return t.numpy() if isinstance(t, D.DevArray) else np.asarray(t.cpu().numpy())
 
   def dtype_of(self, t):
     if isinstance(t, sparse_mod.CsrTile):
       return t.dtype
     if isinstance(t, (tile.EmptyBlob, distarray.Absent, np.ndarray, np.generic)):
       return np.dtype(t.dtype)
-    if isinstance(t, torch.Tensor):
+    if isinstance(t, D.DevArray):
+      return t.dtype
+    if hasattr(t, 'data_ptr'):
       return kernels.np_dtype_of(t)
     return np.asarray(t).dtype
 
@@ -88,10 +93,14 @@ class HipBackend(object):
     return t if t.is_contiguous() else self.copy(t)
 
   def copy(self, t):
-    out = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+    out = D.empty(tuple(t.shape), self.dtype_of(t))
     if t.numel():
       self.paste(out, tuple(slice(0, n) for n in t.shape), t)
     return out
+
+  def same_memory(self, a, b):
+    """Do the two device arrays start at the same HBM address (one is the other, or a view of all of it)?"""
+    return hasattr(a, 'data_ptr') and hasattr(b, 'data_ptr') and a.data_ptr() == b.data_ptr()
 
   def astype(self, t, dtype):
     dtype = np.dtype(dtype)
@@ -132,8 +141,8 @@ class HipBackend(object):
       src = src.reshape(view.shape)
     if view.numel() == 0:
       return
-    if view.dtype != src.dtype:
-      raise _hip.HipError('paste: dtype mismatch %s vs %s' % (view.dtype, src.dtype))
+    if self.dtype_of(view) != self.dtype_of(src):
+      raise _hip.HipError('paste: dtype mismatch %s vs %s' % (self.dtype_of(view), self.dtype_of(src)))
     nd = view.dim()
     base = view.storage_offset() - dst.storage_offset()
     if nd > _hip.SP_MAX_DIMS:
@@ -333,7 +342,7 @@ class HipBackend(object):
         v.dtype = self.dtype_of(a)
       vals.append(v)
     root = rule(vals, kw, None)
-    return self._run_map(root, out_shape)
+    return self._run_map(root, root.shape if out_shape is None else out_shape)
 
   def _axis_split(self, shape, axis):
     if axis is None:
@@ -470,6 +479,7 @@ class HipBackend(object):
     """out (+)= a . b for 2-D fp32 / fp64 tensors that may be strided views (inner stride 1): the building block
     of the pipelined joins (dot.ksplit_plan), one sp_gemm launch, nothing allocated."""
     self.launches += 1
+    self.gemms += 1
     if self.gemm_events is not None:
       e0, e1 = kernels.Event(), kernels.Event()
       e0.record()
@@ -666,9 +676,7 @@ class HipBackend(object):
 
   def sparse_parts_empty(self, shape, dtype, nnz):
     """Receive buffers for sparse_parts of a tile of `shape` with `nnz` stored entries."""
-    return (torch.empty(int(shape[0]) + 1, dtype=torch.int64, device=self.device),
-            torch.empty(int(nnz), dtype=torch.int32, device=self.device),
-            torch.empty(int(nnz), dtype=kernels.torch_dtype(dtype), device=self.device))
+    return (D.empty((int(shape[0]) + 1,), np.int64), D.empty((int(nnz),), np.int32), D.empty((int(nnz),), dtype))
 
   def sparse_from_parts(self, shape, dtype, parts):
     return sparse_mod.CsrTile(shape, dtype, *parts)
@@ -802,17 +810,16 @@ class HipBackend(object):
     return sparse_mod.row_sums(sparse_mod.transpose(t))
 
   def synchronize(self):
-    torch.cuda.synchronize(self.device)
+    D.synchronize()
 
   def liveness_probe(self, timeout_s=2.0):
     """One round trip through the device on a stream of its own (heartbeat.py): False if it does not come back."""
     import time
     if getattr(self, '_probe_stream', None) is None:
-      self._probe_stream = torch.cuda.Stream(device=self.device)
-    ev = torch.cuda.Event()
-    ev.record(self._probe_stream)
+      self._probe_stream = D.Stream()
+    ev = D.Event().record(self._probe_stream)
     deadline = time.time() + timeout_s
-    while not ev.query():
+    while not D._event_done(ev):
       if time.time() > deadline:
         return False
       time.sleep(0.001)

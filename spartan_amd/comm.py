@@ -19,9 +19,9 @@ Two transports carry them:
                   are enqueued on the compute stream (stream order is the only synchronisation); `async_` calls
                   run on a communication stream of their own, ordered against the compute stream by events, so
                   that kernels launched meanwhile overlap with the transfer.
-  TorchTransport  torch.distributed process groups: gloo for the CPU tests (NumPy tile backend), gloo with
-                  host staging as a debug transport for several ranks sharing one GPU, and ProcessGroupNCCL as
-                  the fallback when the direct binding does not pass its start-up self-test.
+  TorchTransport  a torch.distributed gloo group: the CPU tests (NumPy tile backend), and -- with host staging --
+                  a debug transport for several ranks sharing one GPU.  There is no second GPU data plane: if the
+                  direct RCCL binding does not come up or fails its start-up self-test the job fails, loudly.
 
 Small host objects (tile metadata, driver-level random draws, the RCCL rendezvous token) always travel over a
 gloo group: that is control plane, not tile data.
@@ -31,35 +31,64 @@ import os
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
+
+
+def _dist():
+  """torch.distributed: the CONTROL plane (host objects, barriers, rendezvous) and the CPU-test transport.
+  Imported on first use, so a single-process job on the HIP backend never loads torch."""
+  import torch.distributed as dist
+  return dist
 
 
 def _torch_red(reducer):
+  dist = _dist()
   return {'ADD': dist.ReduceOp.SUM, 'MUL': dist.ReduceOp.PRODUCT, 'MAX': dist.ReduceOp.MAX,
           'MIN': dist.ReduceOp.MIN}[reducer]
 
 
+def gpu_count():
+  """HIP devices visible to libspartan_hip.so (0 when the library is not built or no device answers)."""
+  try:
+    from . import _hip
+    n = C.c_int(0)
+    return n.value if _hip.lib().sp_device_count(C.byref(n)) == 0 else 0
+  except Exception:
+    return 0
+
+
 class _Done(object):
-  """Handle of an asynchronous transfer: wait() makes the CURRENT stream wait for it."""
+  """Handle of an asynchronous transfer: wait() makes the CURRENT stream wait for it.  The handle keeps the
+  arrays the transfer reads / writes alive: the tile store reuses freed memory in the order of the compute stream,
+  so nothing a side stream still works on may be given back before the compute stream has waited for it."""
 
   def __init__(self, event, keep):
     self.event = event
-    self.keep = keep          # tensors the transfer reads / writes
+    self.keep = keep
 
   def wait(self):
-    torch.cuda.current_stream().wait_event(self.event)
+    from . import devarray as D
+    D.current_stream().wait_event(self.event)
     self.keep = None
+
+  def __del__(self):
+    if self.keep:                      # dropped without wait(): hold the memory until the transfer is over
+      try:
+        from . import devarray as D
+        D.keep_alive_until(self.event, self.keep)
+      except Exception:
+        pass
 
 
 class RcclTransport(object):
-  """sp_comm_* of libspartan_hip.so on device tensors."""
+  """sp_comm_* of libspartan_hip.so on device arrays."""
   name = 'rccl'
   device_native = True
 
   def __init__(self, world_size, rank, uid):
     from . import _hip
+    from . import devarray as D
     self._hip = _hip
+    self._D = D
     self.lib = _hip.lib()
     self.size, self.rank = world_size, rank
     handle = C.c_void_p()
@@ -67,7 +96,7 @@ class RcclTransport(object):
     self.comm = handle
     # asynchronous transfers run here; high priority, so that a collective's few workgroups are placed as soon as
     # compute workgroups retire instead of queueing behind a whole GEMM launch (its peers on the other GPUs wait)
-    self.side = torch.cuda.Stream(priority=-1)
+    self.side = D.Stream(high_priority=True)
 
   @staticmethod
   def unique_id():
@@ -96,130 +125,139 @@ class RcclTransport(object):
   def _launch(self, fn, tensors, async_):
     """Run fn(stream) on the compute stream, or on the side stream behind everything the compute stream has
     been given so far."""
-    cur = torch.cuda.current_stream()
+    D = self._D
+    cur = D.current_stream()
     if not async_:
-      self._hip.check(fn(C.c_void_p(cur.cuda_stream)))
+      self._hip.check(fn(cur.ptr))
       return None
     self.side.wait_stream(cur)
-    self._hip.check(fn(C.c_void_p(self.side.cuda_stream)))
-    for t in tensors:
-      t.record_stream(self.side)             # the caching allocator must not hand the memory out early
-    done = torch.cuda.Event()
-    done.record(self.side)
-    return _Done(done, tensors)
+    self._hip.check(fn(self.side.ptr))
+    return _Done(D.Event().record(self.side), list(tensors))
 
-  # -- primitives (contiguous device tensors)
+  # -- primitives (contiguous device arrays)
   def exchange(self, sends, recvs, async_=False):
     ns, nr = len(sends), len(recvs)
     sp = (C.c_int32 * max(ns, 1))(*[d for d, _ in sends])
     rp = (C.c_int32 * max(nr, 1))(*[s for s, _ in recvs])
     sptr = self._hip.ptr_array([t.data_ptr() for _, t in sends])
     rptr = self._hip.ptr_array([t.data_ptr() for _, t in recvs])
-    sb = self._hip.i64_array([t.numel() * t.element_size() for _, t in sends])
-    rb = self._hip.i64_array([t.numel() * t.element_size() for _, t in recvs])
+    sb = self._hip.i64_array([t.nbytes for _, t in sends])
+    rb = self._hip.i64_array([t.nbytes for _, t in recvs])
     return self._launch(lambda st: self.lib.sp_comm_all_to_all_blocks(self.comm, ns, sp, sptr, sb, nr, rp, rptr, rb, st),
                         [t for _, t in sends] + [t for _, t in recvs], async_)
 
   def all_gather_into(self, out, tensor, async_=False):
     return self._launch(lambda st: self.lib.sp_comm_all_gather(self.comm, self._p(tensor), self._p(out),
-                                                               tensor.numel(), self._dt(tensor), st),
+                                                               tensor.size, self._dt(tensor), st),
                         [out, tensor], async_)
 
   def reduce_scatter(self, out, inp, reducer, async_=False):
-    return self._launch(lambda st: self.lib.sp_comm_reduce_scatter(self.comm, self._p(inp), self._p(out), out.numel(),
+    return self._launch(lambda st: self.lib.sp_comm_reduce_scatter(self.comm, self._p(inp), self._p(out), out.size,
                                                                    self._dt(inp), self._red(reducer), st),
                         [out, inp], async_)
 
   def all_reduce(self, tensor, reducer):
-    self._launch(lambda st: self.lib.sp_comm_all_reduce(self.comm, self._p(tensor), self._p(tensor), tensor.numel(),
+    self._launch(lambda st: self.lib.sp_comm_all_reduce(self.comm, self._p(tensor), self._p(tensor), tensor.size,
                                                         self._dt(tensor), self._red(reducer), st), [tensor], False)
 
   def reduce(self, tensor, dst, reducer):
-    self._launch(lambda st: self.lib.sp_comm_reduce(self.comm, self._p(tensor), self._p(tensor), tensor.numel(),
+    self._launch(lambda st: self.lib.sp_comm_reduce(self.comm, self._p(tensor), self._p(tensor), tensor.size,
                                                     self._dt(tensor), self._red(reducer), dst, st), [tensor], False)
 
   def broadcast(self, tensor, src):
-    self._launch(lambda st: self.lib.sp_comm_bcast(self.comm, self._p(tensor), tensor.numel(), self._dt(tensor),
+    self._launch(lambda st: self.lib.sp_comm_bcast(self.comm, self._p(tensor), tensor.size, self._dt(tensor),
                                                    src, st), [tensor], False)
 
   # -- start-up self-test
   def self_test(self, timeout_s=60.0):
     """Every primitive once on small buffers, results checked, with a deadline (a transport that hangs or
     miscomputes must be found here, not in the middle of a job).  Returns (ok, message)."""
+    D = self._D
     n, r = self.size, self.rank
-    dev = torch.device('cuda', torch.cuda.current_device())
-    stream = torch.cuda.Stream()
+    stream = D.Stream()
     try:
-      with torch.cuda.stream(stream):
-        words = 1 << 14
-        a = torch.full((words,), float(r + 1), dtype=torch.float32, device=dev)
+      words = 1 << 14
+      up = D.from_numpy
+      a = up(np.full(words, float(r + 1), np.float32))
+      parts = up(np.arange(n * words, dtype=np.float32) + r)
+      rs = D.empty((words,), np.float32)
+      mine = up(np.full(words, r, np.int64))
+      ag = D.empty((n * words,), np.int64)
+      b = up(np.full(words, float(r), np.float64))
+      red = up(np.full(words, float(r + 1), np.float32))
+      nxt, prv = (r + 1) % n, (r - 1) % n
+      out_ring = up(np.full(words, r, np.int32))
+      in_ring = D.empty((words,), np.int32)
+      D.synchronize()
+      with D.use_stream(stream):
         self.all_reduce(a, 'ADD')
-        parts = torch.arange(n * words, dtype=torch.float32, device=dev) + r
-        rs = torch.empty(words, dtype=torch.float32, device=dev)
         self.reduce_scatter(rs, parts, 'ADD')
-        mine = torch.full((words,), r, dtype=torch.int64, device=dev)
-        ag = torch.empty(n * words, dtype=torch.int64, device=dev)
         self.all_gather_into(ag, mine)
-        b = torch.full((words,), float(r), dtype=torch.float64, device=dev)
         self.broadcast(b, n - 1)
-        red = torch.full((words,), float(r + 1), dtype=torch.float32, device=dev)
         self.reduce(red, 0, 'MAX')
-        nxt, prv = (r + 1) % n, (r - 1) % n
-        out_ring = torch.full((words,), r, dtype=torch.int32, device=dev)
-        in_ring = torch.empty(words, dtype=torch.int32, device=dev)
         if n > 1:
           self.exchange([(nxt, out_ring)], [(prv, in_ring)])
         else:
-          in_ring.copy_(out_ring)
+          from . import kernels
+          kernels.stream_copy(in_ring, out_ring)
       deadline = time.time() + timeout_s
-      done = C.c_int32(0)
-      while True:
-        self._hip.check(self.lib.sp_stream_query(C.c_void_p(stream.cuda_stream), C.byref(done)))
-        if done.value:
-          break
+      while not stream.query():
         if time.time() > deadline:
           return False, 'RCCL self-test did not complete within %.0f s' % timeout_s
         time.sleep(0.002)
       self._hip.check(self.lib.sp_comm_async_error(self.comm))
       base = np.arange(words, dtype=np.float64)
       checks = [
-          ('all_reduce', a.cpu().numpy(), np.full(words, n * (n + 1) / 2.0)),
-          ('reduce_scatter', rs.cpu().numpy(), n * (base + r * words) + n * (n - 1) / 2.0),
-          ('all_gather', ag.cpu().numpy(), np.repeat(np.arange(n), words)),
-          ('broadcast', b.cpu().numpy(), np.full(words, float(n - 1))),
-          ('exchange', in_ring.cpu().numpy(), np.full(words, prv)),
+          ('all_reduce', a.numpy(), np.full(words, n * (n + 1) / 2.0)),
+          ('reduce_scatter', rs.numpy(), n * (base + r * words) + n * (n - 1) / 2.0),
+          ('all_gather', ag.numpy(), np.repeat(np.arange(n), words)),
+          ('broadcast', b.numpy(), np.full(words, float(n - 1))),
+          ('exchange', in_ring.numpy(), np.full(words, prv)),
       ]
       if r == 0:
-        checks.append(('reduce', red.cpu().numpy(), np.full(words, float(n))))
+        checks.append(('reduce', red.numpy(), np.full(words, float(n))))
       for name, got, want in checks:
         if not np.array_equal(got.astype(np.float64), want.astype(np.float64)):
           return False, 'RCCL self-test: wrong result from %s' % name
       return True, 'ok'
-    except Exception as e:   # HipError and friends: reported, the caller falls back
+    except Exception as e:   # HipError and friends: reported to the caller, which stops the job
       return False, 'RCCL self-test failed: %s' % (e,)
 
 
 class TorchTransport(object):
-  """torch.distributed process group (gloo: CPU tensors, or device tensors staged through the host; nccl)."""
+  """A torch.distributed gloo group.  Payloads are the NumPy backend's CPU tensors (the CPU tests), or -- `staged`
+  -- device arrays copied through the host (a debug transport for several ranks sharing one GPU; never the
+  transport of a real job, which is RcclTransport or nothing)."""
   device_native = False
 
   def __init__(self, group, size, rank, staged):
     self.group, self.size, self.rank, self.staged = group, size, rank, staged
     self.name = 'torch-staged' if staged else 'torch'
-    self.device_native = not staged
+    self.device_native = False
 
   def close(self, abort=False):
     pass
 
-  def _stage(self, t):
-    return t.cpu() if (self.staged and t.is_cuda) else t
+  @staticmethod
+  def _stage(t):
+    """The host tensor gloo moves: a device array is downloaded, a CPU tensor is used as it is."""
+    import torch
+    if isinstance(t, np.ndarray):
+      # the NumPy backend's tile, wrapped without a copy: what gloo receives lands in the array itself
+      return torch.from_numpy(t if t.flags['C_CONTIGUOUS'] and t.flags['WRITEABLE'] else np.array(t, order='C'))
+    return torch.from_numpy(np.ascontiguousarray(t.numpy()))
 
   @staticmethod
   def _unstage(dst, host):
-    if host is not dst:
-      dst.copy_(host)
+    got = host.numpy()
+    if isinstance(dst, np.ndarray):
+      if not np.shares_memory(dst, got):
+        dst[...] = got.reshape(dst.shape)
+    else:
+      dst.upload(got)
 
   def exchange(self, sends, recvs, async_=False):
+    dist = _dist()
     ops, staged = [], []
     for dst, t in sends:
       ops.append(dist.P2POp(dist.isend, self._stage(t), dst, group=self.group))
@@ -234,37 +272,34 @@ class TorchTransport(object):
     return None
 
   def all_gather_into(self, out, tensor, async_=False):
-    if self.staged or not tensor.is_cuda:
-      parts = [torch.empty(tensor.shape, dtype=tensor.dtype) for _ in range(self.size)]
-      dist.all_gather(parts, self._stage(tensor).contiguous(), group=self.group)
-      out.copy_(torch.cat([p.reshape(-1) for p in parts]).view(out.shape))
-      return None
-    return dist.all_gather_into_tensor(out, tensor, group=self.group, async_op=True) if async_ else \
-        dist.all_gather_into_tensor(out, tensor, group=self.group)
+    import torch
+    dist = _dist()
+    mine = self._stage(tensor).contiguous()
+    parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(self.size)]
+    dist.all_gather(parts, mine, group=self.group)
+    self._unstage(out, torch.cat([p.reshape(-1) for p in parts]).view(tuple(out.shape)))
+    return None
 
   def reduce_scatter(self, out, inp, reducer, async_=False):
-    if inp.is_cuda and not self.staged:
-      return dist.reduce_scatter_tensor(out, inp, op=_torch_red(reducer), group=self.group, async_op=True) if async_ \
-          else dist.reduce_scatter_tensor(out, inp, op=_torch_red(reducer), group=self.group)
-    # gloo has no reduce_scatter: all_reduce + take our piece (CPU tests / debug transport)
+    # gloo has no reduce_scatter: all_reduce + take our piece
     tmp = self._stage(inp).clone()
-    dist.all_reduce(tmp, op=_torch_red(reducer), group=self.group)
-    out.copy_(tmp.view(self.size, -1)[self.rank].view_as(out))
+    _dist().all_reduce(tmp, op=_torch_red(reducer), group=self.group)
+    self._unstage(out, tmp.view(self.size, -1)[self.rank].reshape(tuple(out.shape)).contiguous())
     return None
 
   def all_reduce(self, tensor, reducer):
     h = self._stage(tensor)
-    dist.all_reduce(h, op=_torch_red(reducer), group=self.group)
+    _dist().all_reduce(h, op=_torch_red(reducer), group=self.group)
     self._unstage(tensor, h)
 
   def reduce(self, tensor, dst, reducer):
     h = self._stage(tensor)
-    dist.reduce(h, dst, op=_torch_red(reducer), group=self.group)
+    _dist().reduce(h, dst, op=_torch_red(reducer), group=self.group)
     self._unstage(tensor, h)
 
   def broadcast(self, tensor, src):
     h = self._stage(tensor)
-    dist.broadcast(h, src, group=self.group)
+    _dist().broadcast(h, src, group=self.group)
     self._unstage(tensor, h)
 
 
@@ -303,42 +338,53 @@ class World(object):
   @staticmethod
   def from_env(backend=None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run), or
-    return the 1-process world.  backend: 'rccl' (sp_comm_* of the C-ABI; the default on GPUs, falls back to
-    'nccl' if its self-test fails), 'nccl' (torch's ProcessGroupNCCL), 'gloo' (CPU tensors; device tensors are
-    staged through the host -- a debug transport for ranks sharing one GPU).  SPARTAN_DIST_BACKEND overrides."""
+    return the 1-process world.  backend: 'rccl' (sp_comm_* of the C-ABI: the data plane of a GPU job; if it does
+    not come up or fails its self-test the job STOPS -- there is no second GPU transport to fall back to) or
+    'gloo' (CPU tensors; device arrays are staged through the host -- a debug transport for ranks sharing one GPU).
+    SPARTAN_DIST_BACKEND overrides."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if dist.is_available() and dist.is_initialized():
-      ws = dist.get_world_size()
-      rank = dist.get_rank()
-      if ws <= 1:
-        return World(rank, ws, None)
-    elif ws <= 1:
+    if ws <= 1:
+      try:
+        import sys
+        dist = sys.modules.get('torch.distributed')
+        if dist is not None and dist.is_available() and dist.is_initialized():
+          return World(dist.get_rank(), dist.get_world_size(), None) if dist.get_world_size() <= 1 else \
+              World._join(backend, dist.get_world_size(), dist.get_rank())
+      except Exception:
+        pass
       return World(0, 1, None)
-    else:
-      rank = int(os.environ['RANK'])
-    backend = backend or os.environ.get('SPARTAN_DIST_BACKEND') or ('rccl' if torch.cuda.is_available() else 'gloo')
+    dist = _dist()
+    rank = dist.get_rank() if dist.is_initialized() else int(os.environ['RANK'])
+    if dist.is_initialized():
+      ws = dist.get_world_size()
+    return World._join(backend, ws, rank)
+
+  @staticmethod
+  def _join(backend, ws, rank):
+    dist = _dist()
+    gpus = gpu_count()
+    backend = backend or os.environ.get('SPARTAN_DIST_BACKEND') or ('rccl' if gpus else 'gloo')
+    if backend not in ('rccl', 'gloo'):
+      raise ValueError("unknown data-plane backend %r (known: 'rccl', 'gloo')" % backend)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     local = int(os.environ.get('LOCAL_RANK', rank))
-    if torch.cuda.is_available():
-      torch.cuda.set_device(local % torch.cuda.device_count())
+    if gpus:
+      from . import _hip
+      _hip.check(_hip.lib().sp_set_device(local % gpus))
     if not dist.is_initialized():
       # the default group is gloo: host objects, barriers, and the CPU / staged data plane
       dist.init_process_group('gloo', rank=rank, world_size=ws)
     if backend == 'gloo':
-      w = World(rank, ws, None, TorchTransport(None, ws, rank, staged=torch.cuda.is_available()))
+      w = World(rank, ws, None, TorchTransport(None, ws, rank, staged=bool(gpus)))
       w.note = 'gloo'
       return w
-    if backend == 'rccl':
-      transport, note = _try_rccl(ws, rank)
-      if transport is not None:
-        w = World(rank, ws, None, transport)
-        w.note = note
-        return w
-    else:
-      note = 'requested'
-    group = dist.new_group(backend='nccl', device_id=torch.device('cuda', torch.cuda.current_device()))
-    w = World(rank, ws, None, TorchTransport(group, ws, rank, staged=False))
-    w.note = 'torch ProcessGroupNCCL (%s)' % note
+    transport, note = _try_rccl(ws, rank)
+    if transport is None:
+      raise RuntimeError('the RCCL data plane (sp_comm_* of libspartan_hip.so) did not come up: %s.  There is no '
+                         'fallback transport for tiles in HBM; set SPARTAN_DIST_BACKEND=gloo only to debug on '
+                         'one GPU.' % note)
+    w = World(rank, ws, None, transport)
+    w.note = note
     return w
 
   def close(self):
@@ -349,7 +395,7 @@ class World(object):
   # -- primitives -------------------------------------------------------------
   def barrier(self):
     if self.distributed:
-      dist.barrier(group=self.control)
+      _dist().barrier(group=self.control)
 
   def exchange(self, sends, recvs):
     """sends: [(dst_rank, tensor)], recvs: [(src_rank, tensor)]; contiguous tensors.  All ranks call this with
@@ -358,9 +404,9 @@ class World(object):
       return
     assert self.distributed, 'exchange() with remote peers in a 1-process world'
     for _, t in list(sends) + list(recvs):
-      assert t.is_contiguous()
+      assert t.is_contiguous() if hasattr(t, 'is_contiguous') else t.flags['C_CONTIGUOUS']
     for _, t in sends:
-      self.stats['p2p_bytes'] += t.numel() * t.element_size()
+      self.stats['p2p_bytes'] += t.nbytes
       self.stats['p2p_msgs'] += 1
     self.transport.exchange(sends, recvs)
 
@@ -370,7 +416,7 @@ class World(object):
     if not sends and not recvs:
       return None
     for _, t in sends:
-      self.stats['p2p_bytes'] += t.numel() * t.element_size()
+      self.stats['p2p_bytes'] += t.nbytes
       self.stats['p2p_msgs'] += 1
     return self.transport.exchange(sends, recvs, async_=True)
 
@@ -379,35 +425,35 @@ class World(object):
     self.stats['collective_bytes'] += int(nbytes)
 
   def all_gather_into(self, out, tensor):
-    self._count(tensor.numel() * tensor.element_size() * (self.size - 1))
+    self._count(tensor.nbytes * (self.size - 1))
     self.transport.all_gather_into(out, tensor)
 
   def all_gather_into_async(self, out, tensor):
     """all_gather_into without waiting: returns a handle whose wait() makes the CURRENT STREAM wait for the
     result (the collective runs on a communication stream, so kernels launched meanwhile overlap with it).
     Host-side transports complete immediately and return None."""
-    self._count(tensor.numel() * tensor.element_size() * (self.size - 1))
+    self._count(tensor.nbytes * (self.size - 1))
     return self.transport.all_gather_into(out, tensor, async_=True)
 
   def reduce_scatter(self, out, inp, reducer):
     """out[rank piece] = reduce over ranks of inp (inp = size equal pieces)."""
-    self._count(inp.numel() * inp.element_size() * (self.size - 1) // self.size)
+    self._count(inp.nbytes * (self.size - 1) // self.size)
     self.transport.reduce_scatter(out, inp, reducer)
 
   def reduce_scatter_async(self, out, inp, reducer):
-    self._count(inp.numel() * inp.element_size() * (self.size - 1) // self.size)
+    self._count(inp.nbytes * (self.size - 1) // self.size)
     return self.transport.reduce_scatter(out, inp, reducer, async_=True)
 
   def all_reduce(self, tensor, reducer):
-    self._count(2 * tensor.numel() * tensor.element_size() * (self.size - 1) // self.size)
+    self._count(2 * tensor.nbytes * (self.size - 1) // self.size)
     self.transport.all_reduce(tensor, reducer)
 
   def reduce(self, tensor, dst, reducer):
-    self._count(tensor.numel() * tensor.element_size())
+    self._count(tensor.nbytes)
     self.transport.reduce(tensor, dst, reducer)
 
   def broadcast(self, tensor, src):
-    self._count(tensor.numel() * tensor.element_size())
+    self._count(tensor.nbytes)
     self.transport.broadcast(tensor, src)
 
   # -- host objects (control plane) ----------------------------------------------
@@ -415,19 +461,21 @@ class World(object):
     if not self.distributed:
       return obj
     box = [obj if self.rank == src else None]
-    dist.broadcast_object_list(box, src=src, group=self.control)
+    _dist().broadcast_object_list(box, src=src, group=self.control)
     return box[0]
 
   def all_gather_object(self, obj):
     if not self.distributed:
       return [obj]
     out = [None] * self.size
-    dist.all_gather_object(out, obj, group=self.control)
+    _dist().all_gather_object(out, obj, group=self.control)
     return out
 
 
 def _agree(ok):
   """True iff every rank says ok (gloo)."""
+  import torch
+  dist = _dist()
   flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
   dist.all_reduce(flag, op=dist.ReduceOp.MIN)
   return bool(flag.item())
@@ -446,7 +494,7 @@ def _try_rccl(ws, rank):
   if not _agree(not why):
     return None, 'sp_comm unavailable: %s' % (why or 'on another rank')
   box = [RcclTransport.unique_id() if rank == 0 else None]
-  dist.broadcast_object_list(box, src=0)
+  _dist().broadcast_object_list(box, src=0)
   try:
     transport = RcclTransport(ws, rank, box[0])
   except Exception as e:

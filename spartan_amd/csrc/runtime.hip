@@ -85,6 +85,17 @@ bool box_is_whole(const Blob& b, const int64_t* ext) {
   return true;
 }
 
+// One contiguous byte range?  (every axis before the first cut one has extent 1, every axis after it is whole:
+// a run of rows of a matrix, any range of a 1-D blob.)
+bool box_is_contiguous(const Blob& b, const int64_t* ext) {
+  int i = 0;
+  while (i < b.ndim && ext[i] == 1 && b.shape[i] != 1) ++i;     // leading single indices
+  if (i < b.ndim) ++i;                                           // the one axis that may be a proper range
+  for (; i < b.ndim; ++i)
+    if (ext[i] != b.shape[i]) return false;
+  return true;
+}
+
 }  // namespace
 
 extern "C" int sp_blob_create(const int64_t* shape, int32_t ndim, int32_t dtype, uint64_t* handle) {
@@ -187,13 +198,18 @@ static int blob_transfer(uint64_t h, void* host, const int64_t* ul, const int64_
     else SP_HIP(hipMemcpyAsync(host, b.ptr, (size_t)count * es, hipMemcpyDeviceToHost, st));
     return 0;
   }
-  if (b.ndim > 4) SP_FAIL("sp_blob transfer: a proper box of a %d-d blob (boxes are supported up to 4-d)", b.ndim);
   int64_t bst[SP_BLOB_MAX_DIMS], pst[SP_BLOB_MAX_DIMS];
   dense_strides(b.shape, b.ndim, bst);
   dense_strides(ext, b.ndim, pst);
   int64_t off = 0;
   for (int i = 0; i < b.ndim; ++i) off += (ul ? ul[i] : 0) * bst[i];
   char* box = (char*)b.ptr + (size_t)off * es;
+  if (box_is_contiguous(b, ext)) {       // one byte range of the blob: a direct transfer, no staging
+    if (to_device) SP_HIP(hipMemcpyAsync(box, host, (size_t)count * es, hipMemcpyHostToDevice, st));
+    else SP_HIP(hipMemcpyAsync(host, box, (size_t)count * es, hipMemcpyDeviceToHost, st));
+    return 0;
+  }
+  if (b.ndim > 4) SP_FAIL("sp_blob transfer: a proper box of a %d-d blob (boxes are supported up to 4-d)", b.ndim);
   uint64_t stage_h;
   if (sp_blob_create(&count, 1, b.dtype, &stage_h)) return 1;
   Blob stage;
@@ -501,10 +517,18 @@ extern "C" int sp_comm_all_to_all_blocks(void* comm, int32_t n_sends, const int3
 // --------------------------------------------------------------------------------------------------------------
 // streams and ordering between them (a host without torch needs a compute and a communication stream)
 // --------------------------------------------------------------------------------------------------------------
-extern "C" int sp_stream_create(void** stream) {
+extern "C" int sp_stream_create(void** stream) { return sp_stream_create_priority(stream, 0); }
+
+extern "C" int sp_stream_create_priority(void** stream, int32_t high_priority) {
   if (!stream) SP_FAIL("sp_stream_create: NULL");
   hipStream_t s;
-  SP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  if (high_priority) {
+    int least = 0, greatest = 0;          // numerically lower = higher priority
+    SP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    SP_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
+  } else {
+    SP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  }
   *stream = s;
   return 0;
 }

@@ -67,6 +67,26 @@ extern "C" int sp_event_synchronize(void* ev) {
   SP_HIP(hipEventSynchronize((hipEvent_t)ev));
   return 0;
 }
+extern "C" int sp_event_query(void* ev, int32_t* done) {
+  if (!done) SP_FAIL("sp_event_query: NULL");
+  hipError_t e = hipEventQuery((hipEvent_t)ev);
+  if (e == hipSuccess) *done = 1;
+  else if (e == hipErrorNotReady) {
+    *done = 0;
+    (void)hipGetLastError();
+  } else SP_FAIL("sp_event_query: %s", hipGetErrorString(e));
+  return 0;
+}
+extern "C" int sp_device_synchronize(void) {
+  SP_HIP(hipDeviceSynchronize());
+  return 0;
+}
+extern "C" int sp_memset(void* d_dst, int32_t value, size_t bytes, void* stream) {
+  if (!bytes) return 0;
+  if (!d_dst) SP_FAIL("sp_memset: NULL pointer");
+  SP_HIP(hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
+  return 0;
+}
 extern "C" int sp_event_elapsed_ms(void* start, void* stop, float* ms) {
   if (!ms) SP_FAIL("sp_event_elapsed_ms: NULL");
   SP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
@@ -105,6 +125,10 @@ __global__ void sp_byte_copy_kernel(uint8_t* dst, const uint8_t* src, int64_t n)
 }
 
 extern "C" int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void* stream) {
+  return sp_stream_copy_wg(d_dst, d_src, bytes, 0, stream);
+}
+
+extern "C" int sp_stream_copy_wg(void* d_dst, const void* d_src, size_t bytes, int32_t max_workgroups, void* stream) {
   if (!bytes) return 0;
   if (!d_dst || !d_src) SP_FAIL("sp_stream_copy: NULL pointer");
   hipStream_t st = (hipStream_t)stream;
@@ -113,6 +137,7 @@ extern "C" int sp_stream_copy(void* d_dst, const void* d_src, size_t bytes, void
   if (main_bytes) {
     int64_t blocks = ((int64_t)(main_bytes / 16) + SP_BLOCK - 1) / SP_BLOCK;
     if (blocks > (1LL << 30)) blocks = 1LL << 30;
+    if (max_workgroups > 0 && blocks > max_workgroups) blocks = max_workgroups;   // (the kernel strides over the rest)
     if (main_bytes >= (size_t)SP_STREAM_ELEMS * 4)
       hipLaunchKernelGGL(sp_stream_copy_kernel<true>, dim3((unsigned)blocks), dim3(SP_BLOCK), 0, st,
                          (float4*)d_dst, (const float4*)d_src, (int64_t)(main_bytes / 16));

@@ -18,8 +18,9 @@ operands and the target are row-tiled one tile per GPU -- dot(a, b, tile_hint=(m
 whole join as a pipeline instead of tile by tile:
 
   * the all-to-all of a's blocks is issued asynchronously; the products that only need LOCAL data run behind it;
-  * row block j of the partial depends on ONE block of a (the one from rank j), so the partial is produced as p
-    independent GEMMs per column chunk -- no accumulation, no m x k slab is ever assembled;
+  * the blocks are received straight into the row blocks of ONE slab buffer a[:, k_me] (m x k/p), so after the
+    first column chunk -- whose rows are multiplied in up to three pieces, my own block first, behind the
+    transfer -- every chunk of the partial is ONE large GEMM slab . b[k_me, chunk];
   * the partial is produced in column chunks (m x n_c, double-buffered) and each chunk is reduce-scattered by its
     own asynchronous collective while the next chunk is multiplied: only the last chunk's reduce-scatter is
     exposed, and the 4 GiB partial of the 32768^2 north-star shape never exists (2 x 512 MiB instead).
@@ -181,18 +182,38 @@ def ksplit_plan(arrays, axes, target, fn_kw):
     if not (a._all_plain and b._all_plain):
       return False    # some rank's tile is unwritten or masked: every rank takes the generic tile-by-tile join
 
-  # 1. all-to-all of a's blocks: rank j needs my rows of ITS slab, a[r_me, k_j]
-  sends = [(j, be.copy(my_a[:, j * kb:(j + 1) * kb])) for j in range(p) if j != me]
-  blocks = {me: my_a[:, me * kb:(me + 1) * kb]}            # a[r_j, k_me] by source rank j (mine: a view)
-  recvs = []
-  for j in range(p):
-    if j != me:
-      blocks[j] = be.empty((mb, kb), dt)
-      recvs.append((j, blocks[j]))
-  arriving = world.exchange_async(sends, recvs)
+  result = ksplit_pipeline(be, p, me, my_a, my_b, dt, world.exchange_async,
+                           lambda out, part: world.reduce_scatter_async(out, part, 'ADD'), _chunk_columns(n))
+  target._touched = True
+  ctx.tile(tt[me][1]).update(be, None, result, target.reducer_fn, owned=True)
+  return True
 
-  # 2. partial in column chunks, each reduce-scattered while the next one is multiplied
-  nc = _chunk_columns(n)
+
+def ksplit_pipeline(be, p, me, my_a, my_b, dt, exchange_async, reduce_scatter_async, nc):
+  """One rank's share of the K-split dot: my row tile of a (m/p x k), my rows of b (k/p x n) -> my row tile of the
+  result (m/p x n).  `exchange_async(sends, recvs)` / `reduce_scatter_async(out, part)` are the transport's
+  (World's on a real job; bench.py --emulate-rank substitutes same-size device copies on a side stream to time a
+  rank's share on ONE GPU).
+
+    1. the slab a[:, k_me] (m x k/p) is ONE buffer whose row block j is the receive buffer of rank j's block, so
+       no block is copied after it lands; the all-to-all is asynchronous, my own block is a local copy;
+    2. the partial is produced in column chunks of nc columns, two chunk buffers: in chunk 0 the product of my
+       OWN block runs first (behind the transfer), the rows above and below it after the blocks have landed; every
+       later chunk is ONE GEMM slab . b[:, chunk] -- (m x k/p) . (k/p x nc), thousands of macro-tiles per launch
+       instead of p launches of one partly filled round each;
+    3. each finished chunk is reduce-scattered asynchronously while the next one is multiplied; the reduced
+       pieces are pasted into the result as they land.  Only the last chunk's reduce-scatter is exposed."""
+  mb, k = my_a.shape
+  kb = k // p
+  n = my_b.shape[1]
+  m = mb * p
+  slab = be.empty((m, kb), dt)
+  rows = lambda j0, j1: slice(j0 * mb, j1 * mb)           # noqa: E731
+  sends = [(j, be.copy(my_a[:, j * kb:(j + 1) * kb])) for j in range(p) if j != me]
+  recvs = [(j, slab[rows(j, j + 1), :]) for j in range(p) if j != me]
+  be.paste(slab, (rows(me, me + 1), slice(0, kb)), my_a[:, me * kb:(me + 1) * kb])
+  arriving = exchange_async(sends, recvs)
+
   bufs = [be.empty((m, nc), dt), be.empty((m, nc), dt) if nc < n else None]
   result = be.empty((mb, n), dt)
   in_flight = None                                          # (c0, reduced piece, handle) of the previous chunk
@@ -205,22 +226,24 @@ def ksplit_plan(arrays, axes, target, fn_kw):
 
   for ci, c0 in enumerate(range(0, n, nc)):
     part = bufs[ci % 2]
-    for step in range(p):
-      j = (me + step) % p                                   # my own block first: it needs no transfer
-      if step == 1 and arriving is not None:
+    b_chunk = my_b[:, c0:c0 + nc]
+    if ci == 0:
+      be.gemm_into(slab[rows(me, me + 1), :], b_chunk, part[rows(me, me + 1), :])     # needs no transfer
+      if arriving is not None:
         arriving.wait()
-        arriving = None
-      be.gemm_into(blocks[j], my_b[:, c0:c0 + nc], part[j * mb:(j + 1) * mb, :])
+      for j0, j1 in ((0, me), (me + 1, p)):
+        if j1 > j0:
+          be.gemm_into(slab[rows(j0, j1), :], b_chunk, part[rows(j0, j1), :])
+    else:
+      be.gemm_into(slab, b_chunk, part)
     piece = be.empty((mb, nc), dt)
-    handle = world.reduce_scatter_async(piece, part, 'ADD')
+    handle = reduce_scatter_async(piece, part)
     if in_flight is not None:
       land(in_flight)                                       # its buffer is the one the NEXT chunk overwrites
     in_flight = (c0, piece, handle)
   land(in_flight)
   del sends
-  target._touched = True
-  ctx.tile(tt[me][1]).update(be, None, result, target.reducer_fn, owned=True)
-  return True
+  return result
 
 
 dot_map2_mapper.collective_plan = ksplit_plan

@@ -22,7 +22,7 @@ def _reduce_mapper(ex, children, child_to_var, op, axis, output):
   dst_extent = extent.index_for_reduction(ex, axis)
   if ctx.executing:
     local_reduction = ctx.backend.evaluate_reduce(op, local_values, ex, axis)
-    Assert.eq(int(local_reduction.numel()) if hasattr(local_reduction, 'numel') else local_reduction.size,
+    Assert.eq(int(local_reduction.size),
               dst_extent.size)
     local_reduction = local_reduction.reshape(dst_extent.shape)
   else:

@@ -24,7 +24,7 @@ def _permute_all(t):
   if tile.is_sparse_blob(t):
     return context.get().backend.sparse_transpose(t)
   if hasattr(t, 'permute'):
-    return t.permute(*reversed(range(t.dim())))
+    return t.transpose()
   if isinstance(t, np.ndarray):
     return t.transpose()
   return t

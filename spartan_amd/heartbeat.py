@@ -61,6 +61,7 @@ class Heartbeat(object):
     self.store = store if store is not None else (_DistStore() if ctx.world.distributed else _LocalStore())
     self.probe = probe if probe is not None else getattr(ctx.backend, 'liveness_probe', lambda: True)
     self.failed_ranks = set()
+    self.agree_floor_s = 15.0                 # least time the ranks wait for each other's verdicts at a safe point
     self._pending = []
     self._lock = threading.Lock()
     self._stop = threading.Event()
@@ -137,7 +138,9 @@ class Heartbeat(object):
     self.store.set('spartan_hb_agree/%d/%d' % (self._round, self.rank), ','.join(str(r) for r in mine) or '-')
     verdict = set(mine)
     waiting = [r for r in range(self.size) if r != self.rank and r not in self.failed_ranks]
-    deadline = time.time() + max(self.interval * self.threshold, 1.0)
+    # generous: a rank that is merely slow to reach the safe point must not be declared dead (a really dead one
+    # costs the survivors this wait once)
+    deadline = time.time() + max(3 * self.interval * self.threshold, self.agree_floor_s)
     while waiting:
       for r in list(waiting):
         try:

@@ -1,39 +1,43 @@
-"""Pythonic launchers over the C-ABI (spartan_amd/_hip.py) for tile blobs held
-as torch tensors in HBM.  torch is plumbing here: device memory, the current
-HIP stream, and (elsewhere) torch.distributed; every kernel is ours.
+"""Pythonic launchers over the C-ABI (spartan_amd/_hip.py) for tile blobs in HBM.
+
+Operands are device arrays (spartan_amd/devarray.py: views of blobs the library's tile store owns); anything else
+that can say where its bytes live in HBM -- `data_ptr()`, `shape`, `stride()`, `dtype` -- is accepted as well, so
+a test may hand in memory from another allocator.  Launches go to devarray.current_stream().  No torch here.
 """
 import ctypes as C
 
 import numpy as np
-import torch
 
-from . import _hip
+from . import _hip, devarray
 from ._hip import check
+from .devarray import Event  # noqa: F401  (bench.py / tools time launches with it)
 
-_TORCH2NP = {
-    torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64),
-    torch.int32: np.dtype(np.int32), torch.int64: np.dtype(np.int64),
-    torch.bool: np.dtype(np.bool_), torch.uint8: np.dtype(np.uint8),
-}
-_NP2TORCH = {v: k for k, v in _TORCH2NP.items()}
+_KNOWN = {n: np.dtype(n) for n in ('float32', 'float64', 'int32', 'int64', 'bool', 'uint8')}
 
 
 def np_dtype_of(t):
-  return _TORCH2NP[t.dtype]
-
-
-def torch_dtype(np_dtype):
-  return _NP2TORCH[np.dtype(np_dtype)]
+  """NumPy dtype of a device operand (a DevArray carries one; foreign tensors name theirs, e.g. 'torch.float32')."""
+  dt = t.dtype
+  if isinstance(dt, np.dtype):
+    return dt
+  name = str(dt).split('.')[-1]
+  if name not in _KNOWN:
+    raise TypeError('dtype %s is not supported by the HIP tile backend' % (dt,))
+  return _KNOWN[name]
 
 
 def _stream():
-  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+  return devarray.current_stream().ptr
 
 
 def _require_device(*tensors):
   for t in tensors:
-    if t is not None and not t.is_cuda:
-      raise _hip.HipError('HIP tile kernels need device (HBM) tensors; got a %s tensor' % t.device)
+    if t is not None and not getattr(t, 'is_cuda', False):
+      raise _hip.HipError('HIP tile kernels need device (HBM) operands; got %s' % (type(t).__name__,))
+
+
+def _elsize(t):
+  return t.element_size() if hasattr(t, 'element_size') else t.itemsize
 
 
 class Workspace(object):
@@ -42,9 +46,9 @@ class Workspace(object):
   def __init__(self):
     self.buf = None
 
-  def get(self, nbytes, device):
-    if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-      self.buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+  def get(self, nbytes, device=None):
+    if self.buf is None or self.buf.numel() < nbytes:
+      self.buf = devarray.empty((max(int(nbytes), 1 << 20),), np.uint8)
     return self.buf
 
 
@@ -77,7 +81,7 @@ def argreduce(prog, inputs, which, outer, axis_len, inner, index_offset, nan_ind
   need = lib.sp_argreduce_workspace_bytes(prog.cls, outer, axis_len, inner)
   ws = _ws.get(need, out_idx.device)
   ptrs = _hip.ptr_array([t.data_ptr() for t in inputs])
-  assert out_idx.dtype == torch.int64
+  assert np_dtype_of(out_idx) == np.int64
   check(lib.sp_argreduce(C.byref(prog), ptrs, which, outer, axis_len, inner, int(index_offset),
                          int(nan_index), C.c_void_p(out_idx.data_ptr()),
                          C.c_void_p(out_val.data_ptr() if out_val is not None else 0),
@@ -100,8 +104,8 @@ def update(dst, ul, lr, src, reducer, mask_mode, mask=None):
 def slice_copy(dst, dst_offset, dst_strides, src, src_offset, src_strides, shape):
   """Strided box copy between two blobs of the same element size (strides/offsets in elements)."""
   _require_device(dst, src)
-  es = dst.element_size()
-  assert es == src.element_size()
+  es = _elsize(dst)
+  assert es == _elsize(src)
   nd = len(shape)
   check(_hip.lib().sp_slice_copy(
       C.c_void_p(dst.data_ptr() + int(dst_offset) * es), _hip.i64_array(dst_strides),
@@ -113,9 +117,10 @@ def slice_copy(dst, dst_offset, dst_strides, src, src_offset, src_strides, shape
 def gemm_f32(a, b, c, accumulate=False):
   """c (+)= a . b for 2-D row-major fp32 (or, all three, fp64) tensors (inner stride 1)."""
   _require_device(a, b, c)
-  assert a.dtype == b.dtype == c.dtype and a.dtype in (torch.float32, torch.float64)
+  adt = np_dtype_of(a)
+  assert adt == np_dtype_of(b) == np_dtype_of(c) and adt in (np.float32, np.float64)
   lib = _hip.lib()
-  dt = _hip.SP_F32 if a.dtype == torch.float32 else _hip.SP_F64
+  dt = _hip.SP_F32 if adt == np.float32 else _hip.SP_F64
   M, K = a.shape
   K2, N = b.shape
   assert K == K2 and tuple(c.shape) == (M, N), (a.shape, b.shape, c.shape)
@@ -144,7 +149,7 @@ def nearest_center(points, centers, labels, tier=_hip.NEAREST_AUTO):
   _require_device(points, centers, labels)
   n, d = points.shape
   k, d2 = centers.shape
-  assert d == d2 and labels.dtype == torch.int64 and labels.numel() == n and labels.is_contiguous()
+  assert d == d2 and np_dtype_of(labels) == np.int64 and labels.numel() == n and labels.is_contiguous()
   lib = _hip.lib()
   need = lib.sp_nearest_center_workspace_bytes(n, k, d)
   ws = _ws.get(need, points.device)
@@ -158,7 +163,7 @@ def nearest_center(points, centers, labels, tier=_hip.NEAREST_AUTO):
 def bincount(labels, k, counts):
   """counts[:k] = np.bincount(labels, minlength=k) (k_means_.py:69-72)."""
   _require_device(labels, counts)
-  assert labels.dtype == torch.int64 and counts.dtype == torch.int64 and counts.numel() == k
+  assert np_dtype_of(labels) == np.int64 and np_dtype_of(counts) == np.int64 and counts.numel() == k
   assert labels.is_contiguous() and counts.is_contiguous()
   check(_hip.lib().sp_bincount_i64(C.c_void_p(labels.data_ptr()), labels.numel(), k,
                                    C.c_void_p(counts.data_ptr()), _stream()))
@@ -169,8 +174,8 @@ def segment_sum(points, labels, k, out):
   """out[c] = points[labels == c].sum(axis=0) (k_means_.py:75-97)."""
   _require_device(points, labels, out)
   n, d = points.shape
-  assert labels.dtype == torch.int64 and labels.numel() == n and labels.is_contiguous()
-  assert out.dtype == points.dtype and tuple(out.shape) == (k, d) and out.is_contiguous()
+  assert np_dtype_of(labels) == np.int64 and labels.numel() == n and labels.is_contiguous()
+  assert np_dtype_of(out) == np_dtype_of(points) and tuple(out.shape) == (k, d) and out.is_contiguous()
   lib = _hip.lib()
   need = lib.sp_segment_sum_workspace_bytes(n, k, d)
   ws = _ws.get(need, points.device)
@@ -196,7 +201,7 @@ def random_fill(out, kind, seed, offset, lo=0, hi=1):
 def cumscan(src, out, axis, product=False):
   """out = np.cumsum / np.cumprod(src, axis) for dense tensors of one dtype (scan.py:42-63)."""
   _require_device(src, out)
-  assert src.is_contiguous() and out.is_contiguous() and src.dtype == out.dtype and src.shape == out.shape
+  assert src.is_contiguous() and out.is_contiguous() and np_dtype_of(src) == np_dtype_of(out) and tuple(src.shape) == tuple(out.shape)
   shape = tuple(src.shape)
   outer = int(np.prod(shape[:axis], dtype=np.int64))
   inner = int(np.prod(shape[axis + 1:], dtype=np.int64))
@@ -211,8 +216,8 @@ def sort_rows(src, values=True, indices=False):
   _require_device(src)
   assert src.dim() == 2 and src.is_contiguous()
   rows, cols = src.shape
-  vals = torch.empty_like(src) if values else None
-  idx = torch.empty((rows, cols), dtype=torch.int64, device=src.device) if indices else None
+  vals = devarray.empty((rows, cols), np_dtype_of(src)) if values else None
+  idx = devarray.empty((rows, cols), np.int64) if indices else None
   if rows and cols:
     lib = _hip.lib()
     dt = _hip.sp_dtype(np_dtype_of(src))
@@ -226,10 +231,10 @@ def sort_rows(src, values=True, indices=False):
 def gather_rows(src, idx):
   """src[idx] along axis 0 for a contiguous tensor and a device int64 index vector (filter.py:50-75)."""
   _require_device(src, idx)
-  assert src.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+  assert src.is_contiguous() and np_dtype_of(idx) == np.int64 and idx.is_contiguous()
   n = int(idx.numel())
-  row = int(np.prod(src.shape[1:], dtype=np.int64)) * src.element_size()
-  out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+  row = int(np.prod(src.shape[1:], dtype=np.int64)) * _elsize(src)
+  out = devarray.empty((n,) + tuple(src.shape[1:]), np_dtype_of(src))
   if row % 4:
     raise _hip.HipError('gather_rows: rows of %d bytes (need a multiple of 4)' % row)
   check(_hip.lib().sp_gather_rows(C.c_void_p(src.data_ptr()), row, int(src.shape[0]), C.c_void_p(idx.data_ptr()), n, row,
@@ -237,34 +242,11 @@ def gather_rows(src, idx):
   return out
 
 
-def stream_copy(dst, src):
+def stream_copy(dst, src, nbytes=None, max_workgroups=0, stream=None):
+  """dst <- src (contiguous bytes); max_workgroups > 0 bounds the grid (a transfer that takes a limited share of
+  the CUs, see sp_stream_copy_wg)."""
   _require_device(dst, src)
-  n = src.numel() * src.element_size()
-  check(_hip.lib().sp_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, _stream()))
+  n = src.numel() * _elsize(src) if nbytes is None else int(nbytes)
+  check(_hip.lib().sp_stream_copy_wg(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, int(max_workgroups),
+                                     (stream or devarray.current_stream()).ptr))
   return dst
-
-
-class Event(object):
-  """HIP event on the stream the kernels are launched on (bench.py timing)."""
-
-  def __init__(self):
-    self.h = C.c_void_p()
-    check(_hip.lib().sp_event_create(C.byref(self.h)))
-
-  def record(self):
-    check(_hip.lib().sp_event_record(self.h, _stream()))
-
-  def synchronize(self):
-    check(_hip.lib().sp_event_synchronize(self.h))
-
-  def elapsed_ms(self, later):
-    ms = C.c_float()
-    check(_hip.lib().sp_event_elapsed_ms(self.h, later.h, C.byref(ms)))
-    return ms.value
-
-  def __del__(self):
-    try:
-      if self.h:
-        _hip.lib().sp_event_destroy(self.h)
-    except Exception:
-      pass

@@ -2,7 +2,7 @@
 
 The reference stores a sparse tile as a scipy.sparse matrix of whatever format the producing mapper
 chose and converts it on every use (spartan/array/tile.pyx:149-156, sparse.pyx:232-242, dot.py:212-216).
-Here a sparse tile is a `CsrTile`: canonical CSR held as three torch tensors in HBM (int64 indptr, int32
+Here a sparse tile is a `CsrTile`: canonical CSR held as three device arrays in HBM (int64 indptr, int32
 column indices ascending inside a row without duplicates, f32 / f64 values).  scipy appears only at the
 host boundary -- what a user mapper yields (upload) and what `glom()` hands back (download).
 
@@ -12,19 +12,18 @@ Every structural operation is "edit a COO list on the device, then sp_coo_to_csr
 import ctypes as C
 
 import numpy as np
-import torch
 
-from . import _hip
+from . import _hip, kernels
+from . import devarray as D
 from ._hip import check
-from .kernels import _stream, _ws, np_dtype_of, torch_dtype, _ld
+from .kernels import _stream, _ws, np_dtype_of, _ld
 
 _VALUE_DTYPES = (np.dtype(np.float32), np.dtype(np.float64))
 _backend = None
 
 
 def _be():
-  """Value conversions / scaling go through the fused map kernel of the HIP backend (no torch arithmetic
-  on the product path; torch only allocates, copies and concatenates)."""
+  """Value conversions / scaling go through the fused map kernel of the HIP backend."""
   global _backend
   if _backend is None:
     from .backend_hip import HipBackend
@@ -40,6 +39,20 @@ def _cast(vals, dtype):
 
 def _p(t):
   return C.c_void_p(t.data_ptr() if t is not None and t.numel() else 0)
+
+
+def _cat(parts):
+  """The 1-D arrays of `parts` (one dtype) one after the other, as contiguous copies into a new array."""
+  parts = [p for p in parts if p.numel()] or parts[:1]
+  dt = np_dtype_of(parts[0])
+  out = D.empty((sum(int(p.numel()) for p in parts),), dt)
+  at = 0
+  for p in parts:
+    n = int(p.numel())
+    if n:
+      kernels.slice_copy(out, at, (1,), p, 0, (p.stride(0),), (n,))
+      at += n
+  return out
 
 
 class CsrTile(object):
@@ -77,7 +90,7 @@ def spmv_plan(t):
   per tile -- tiles are immutable -- and reused by every product with a vector."""
   if t._plan is None:
     lib = _hip.lib()
-    plan = torch.empty(int(lib.sp_csr_spmv_plan_entries(t.nnz)), dtype=torch.int64, device=t.device)
+    plan = D.empty((int(lib.sp_csr_spmv_plan_entries(t.nnz)),), np.int64)
     check(lib.sp_csr_spmv_plan(t.shape[0], t.nnz, _p(t.indptr), _p(plan), _stream()))
     t._plan = plan
   return t._plan
@@ -92,9 +105,7 @@ def _check_dtype(dtype):
 
 def empty(shape, dtype, device):
   dtype = _check_dtype(dtype)
-  return CsrTile(shape, dtype, torch.zeros(int(shape[0]) + 1, dtype=torch.int64, device=device),
-                 torch.empty(0, dtype=torch.int32, device=device),
-                 torch.empty(0, dtype=torch_dtype(dtype), device=device))
+  return CsrTile(shape, dtype, D.zeros((int(shape[0]) + 1,), np.int64), D.empty((0,), np.int32), D.empty((0,), dtype))
 
 
 def from_coo(shape, dtype, rows, cols, vals):
@@ -106,12 +117,12 @@ def from_coo(shape, dtype, rows, cols, vals):
   dev = rows.device
   if nnz == 0:
     return empty((m, n), dtype, dev)
-  assert rows.dtype == torch.int32 and cols.dtype == torch.int32 and rows.is_contiguous() and cols.is_contiguous()
+  assert np_dtype_of(rows) == np.int32 and np_dtype_of(cols) == np.int32 and rows.is_contiguous() and cols.is_contiguous()
   vals = _cast(vals.contiguous(), dtype)
   lib = _hip.lib()
-  indptr = torch.empty(m + 1, dtype=torch.int64, device=dev)
-  indices = torch.empty(nnz, dtype=torch.int32, device=dev)
-  out = torch.empty(nnz, dtype=vals.dtype, device=dev)
+  indptr = D.empty((m + 1,), np.int64)
+  indices = D.empty((nnz,), np.int32)
+  out = D.empty((nnz,), dtype)
   need = lib.sp_coo_to_csr_workspace_bytes(nnz)
   ws = _ws.get(need, dev)
   check(lib.sp_coo_to_csr(_hip.sp_dtype(dtype), m, n, nnz, _p(rows), _p(cols), _p(vals), _p(indptr), _p(indices),
@@ -127,21 +138,21 @@ def from_scipy(mat, device, dtype=None):
   dtype = _check_dtype(coo.dtype if dtype is None else dtype)
   if coo.shape[0] >= 2 ** 31 or coo.shape[1] >= 2 ** 31:
     raise NotImplementedError('sparse tile dimension exceeds the int32 index range')
-  rows = torch.from_numpy(np.ascontiguousarray(coo.row, dtype=np.int32)).to(device)
-  cols = torch.from_numpy(np.ascontiguousarray(coo.col, dtype=np.int32)).to(device)
-  vals = torch.from_numpy(np.ascontiguousarray(coo.data, dtype=dtype)).to(device)
+  rows = D.from_numpy(np.ascontiguousarray(coo.row, dtype=np.int32))
+  cols = D.from_numpy(np.ascontiguousarray(coo.col, dtype=np.int32))
+  vals = D.from_numpy(np.ascontiguousarray(coo.data, dtype=dtype))
   return from_coo(coo.shape, dtype, rows, cols, vals)
 
 
 def to_scipy(t):
   import scipy.sparse
-  return scipy.sparse.csr_matrix((t.data.cpu().numpy(), t.indices.cpu().numpy(), t.indptr.cpu().numpy()),
+  return scipy.sparse.csr_matrix((t.data.numpy(), t.indices.numpy(), t.indptr.numpy()),
                                  shape=t.shape)
 
 
 def rows_of(t):
   """int32 row index of every stored entry (CSR -> COO)."""
-  rows = torch.empty(t.nnz, dtype=torch.int32, device=t.device)
+  rows = D.empty((t.nnz,), np.int32)
   if t.nnz:
     check(_hip.lib().sp_csr_rows(t.shape[0], t.nnz, _p(t.indptr), _p(rows), _stream()))
   return rows
@@ -184,12 +195,12 @@ def add(a, b, sign=1):
   """a + sign * b (scipy's sparse + / - behind np.add / np.subtract on two sparse tiles)."""
   assert a.shape == b.shape
   dtype = np.result_type(a.dtype, b.dtype)
-  rows = torch.cat([rows_of(a), rows_of(b)])
-  cols = torch.cat([a.indices, b.indices])
+  rows = _cat([rows_of(a), rows_of(b)])
+  cols = _cat([a.indices, b.indices])
   bv = _cast(b.data, dtype)
   if sign < 0:
     bv = scale_values(bv, -1.0)
-  vals = torch.cat([_cast(a.data, dtype), bv])
+  vals = _cat([_cast(a.data, dtype), bv])
   return from_coo(a.shape, dtype, rows, cols, vals)
 
 
@@ -219,7 +230,7 @@ def paste(shape, dtype, pieces):
     vals.append(_cast(p.data, dtype))
   if not rows:
     return empty(shape, dtype, dev)
-  return from_coo(shape, dtype, torch.cat(rows), torch.cat(cols), torch.cat(vals))
+  return from_coo(shape, dtype, _cat(rows), _cat(cols), _cat(vals))
 
 
 def update_box(old, r0, r1, c0, c1, upd, add_to_old):
@@ -231,8 +242,7 @@ def update_box(old, r0, r1, c0, c1, upd, add_to_old):
     _box(orow, ocol, r0, r1, c0, c1, 0, 0, True)
   urow, ucol = rows_of(upd), upd.indices.clone()
   _box(urow, ucol, 0, upd.shape[0], 0, upd.shape[1], r0, c0, False)
-  return from_coo(old.shape, dtype, torch.cat([orow, urow]), torch.cat([ocol, ucol]),
-                  torch.cat([old.data, _cast(upd.data, dtype)]))
+  return from_coo(old.shape, dtype, _cat([orow, urow]), _cat([ocol, ucol]), _cat([old.data, _cast(upd.data, dtype)]))
 
 
 def spmm(a, b, out=None, accumulate=False, plan=True):
@@ -244,12 +254,11 @@ def spmm(a, b, out=None, accumulate=False, plan=True):
   if b2.shape[0] != a.shape[1]:
     raise ValueError('objects are not aligned')
   dtype = np.result_type(a.dtype, np_dtype_of(b2))
-  td = torch_dtype(dtype)
   av = _cast(a.data, dtype)
   b2 = _cast(b2, dtype)
   m, n = a.shape[0], int(b2.shape[1])
   if out is None:
-    out = torch.empty((m, n), dtype=td, device=a.device)
+    out = D.empty((m, n), dtype)
   if m and n:
     lib = _hip.lib()
     ws = _ws.get(lib.sp_csr_spmm_workspace_bytes(a.nnz, n), a.device)
@@ -261,7 +270,7 @@ def spmm(a, b, out=None, accumulate=False, plan=True):
 
 
 def row_sums(t):
-  out = torch.empty((t.shape[0], 1), dtype=t.data.dtype, device=t.device)
+  out = D.empty((t.shape[0], 1), np_dtype_of(t.data))
   if t.shape[0]:
     lib = _hip.lib()
     ws = _ws.get(lib.sp_csr_spmm_workspace_bytes(t.nnz, 1), t.device)
@@ -285,7 +294,7 @@ def scatter(t, out, row0=0, col0=0, mode=0, mask=None):
 
 
 def to_dense(t):
-  out = torch.zeros(t.shape, dtype=torch_dtype(t.dtype), device=t.device)
+  out = D.zeros(t.shape, t.dtype)
   return scatter(t, out)
 
 
@@ -294,14 +303,13 @@ def spgemm(a, b):
   if a.shape[1] != b.shape[0]:
     raise ValueError('objects are not aligned')
   dtype = np.result_type(a.dtype, b.dtype)
-  td = torch_dtype(dtype)
   dev = a.device
   shape = (a.shape[0], b.shape[1])
   if a.nnz == 0 or b.nnz == 0:
     return empty(shape, dtype, dev)
   lib = _hip.lib()
-  offs = torch.empty(a.nnz + 1, dtype=torch.int32, device=dev)
-  total = torch.empty(1, dtype=torch.int64, device=dev)
+  offs = D.empty((a.nnz + 1,), np.int32)
+  total = D.empty((1,), np.int64)
   need = lib.sp_spgemm_count_workspace_bytes(a.nnz)
   ws = _ws.get(need, dev)
   check(lib.sp_spgemm_count(a.nnz, _p(a.indices), _p(b.indptr), _p(offs), _p(total), _p(ws), ws.numel(), _stream()))
@@ -310,9 +318,9 @@ def spgemm(a, b):
     raise NotImplementedError('sparse x sparse: %d products do not fit one tile expansion' % n_prod)
   if n_prod == 0:
     return empty(shape, dtype, dev)
-  rows = torch.empty(n_prod, dtype=torch.int32, device=dev)
-  cols = torch.empty(n_prod, dtype=torch.int32, device=dev)
-  vals = torch.empty(n_prod, dtype=td, device=dev)
+  rows = D.empty((n_prod,), np.int32)
+  cols = D.empty((n_prod,), np.int32)
+  vals = D.empty((n_prod,), dtype)
   av, bv = _cast(a.data, dtype), _cast(b.data, dtype)
   check(lib.sp_spgemm_expand(_hip.sp_dtype(dtype), a.shape[0], a.nnz, _p(a.indptr), _p(a.indices), _p(av), _p(b.indptr),
                              _p(b.indices), _p(bv), _p(offs), _p(rows), _p(cols), _p(vals), _stream()))

@@ -25,16 +25,17 @@ def main():
   os.environ['SPARTAN_DOT_CHUNK_COLS'] = '16'          # whole chunks only: 40 columns -> 4 chunks of 10
   for dtype in (np.float32, np.float64):
     before = dict(world.stats)
-    launches = ctx.backend.launches
+    gemms = getattr(ctx.backend, 'gemms', 0)
     A = sp.from_numpy(a.astype(dtype), tile_hint=(m // p, k))
     B = sp.from_numpy(b.astype(dtype), tile_hint=(k // p, n))
     got = sp.dot(A, B, tile_hint=(m // p, n)).force()
     np.testing.assert_array_equal(got.glom(), a.dot(b).astype(dtype))
     assert got.dtype == dtype and sorted(ex.shape for ex in got.tiles) == [(m // p, n)] * p
-    # the plan ran: p - 1 blocks sent, one reduce-scatter per column chunk (+ the glom's gather), p GEMMs per chunk
+    # the plan ran: p - 1 blocks sent, one reduce-scatter per column chunk (+ the glom's gather); chunk 0 is my own
+    # block + the row ranges above / below it, every later chunk ONE GEMM on the whole slab
     assert world.stats['p2p_msgs'] - before['p2p_msgs'] == p - 1, world.stats
     assert world.stats['collectives'] - before['collectives'] == 4 + 1, world.stats
-    assert ctx.backend.launches - launches >= 4 * p
+    assert ctx.backend.gemms - gemms == 1 + (world.rank > 0) + (world.rank < p - 1) + 3, ctx.backend.gemms - gemms
   del os.environ['SPARTAN_DOT_CHUNK_COLS']
   # reductions over p row tiles, both axes, and the index reductions
   x = rng.randint(-9, 10, size=(12 * p, 20)).astype(np.float32)

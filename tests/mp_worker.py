@@ -187,20 +187,20 @@ def main():
         np.arange(64 * 32, dtype=np.float32).reshape(64, 32) % 7))
     assert world.stats['collectives'] > before['collectives'], world.stats
     # the north-star shape of the K-split: both operands AND the target row-tiled one tile per rank ->
-    # dot.ksplit_plan: one grouped exchange of A blocks, per column chunk p GEMMs + one reduce-scatter
+    # dot.ksplit_plan: one grouped exchange of A blocks into one slab, per column chunk one GEMM + one reduce-scatter
     os.environ['SPARTAN_DOT_CHUNK_COLS'] = '8'
     an = (np.arange(48 * 64, dtype=np.float32).reshape(48, 64) % 9) - 4
     bn = (np.arange(64 * 32, dtype=np.float32).reshape(64, 32) % 5) - 2
     for dtype in (np.float32, np.float64):
       before = dict(world.stats)
-      launches = ctx.backend.launches
+      gemms = getattr(ctx.backend, 'gemms', 0)
       got = sp.dot(sp.from_numpy(an.astype(dtype)), sp.from_numpy(bn.astype(dtype)), tile_hint=(24, 32)).force()
       np.testing.assert_array_equal(got.glom(), an.dot(bn).astype(dtype))
       assert got.dtype == dtype and sorted(ex.shape for ex in got.tiles) == [(24, 32), (24, 32)]
       assert world.stats['collectives'] - before['collectives'] == 4 + 1, world.stats     # 4 chunks (+ the glom)
       assert world.stats['p2p_msgs'] - before['p2p_msgs'] == 1, world.stats                # my block for the peer
       assert world.stats['p2p_bytes'] - before['p2p_bytes'] == 24 * 32 * an.astype(dtype).itemsize
-      assert ctx.backend.launches - launches >= 4 * 2                                     # p GEMMs per chunk
+      assert ctx.backend.gemms - gemms == 2 + 3, ctx.backend.gemms - gemms      # chunk 0: my block + the other; then one per chunk
     del os.environ['SPARTAN_DOT_CHUNK_COLS']
     n += 2
   # tall dot (outer path): B is gathered as asynchronous column chunks, one GEMM per chunk

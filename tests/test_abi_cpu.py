@@ -42,16 +42,18 @@ def test_struct_layout_matches_header():
 
 
 def test_no_device_is_a_loud_error_not_a_fallback():
-  torch = pytest.importorskip('torch')
-  if torch.cuda.is_available():
+  from spartan_amd import comm, kernels
+  if comm.gpu_count():
     pytest.skip('GPU present')
-  from spartan_amd import kernels
   p = Program()
   p.add_input(np.float32, dense_strides((4,)))
   prog = p.finish(_hip.SP_F32, (4,), np.float32, True)
-  x = torch.zeros(4)
+  x = np.zeros(4, np.float32)
   with pytest.raises(Exception):
-    kernels.map_fused(prog, [x], torch.empty(4))
+    kernels.map_fused(prog, [x], np.empty(4, np.float32))            # host memory is refused
+  import spartan_amd
+  with pytest.raises(Exception):
+    spartan_amd.initialize('hip')                                     # no device: no backend, no fallback
 
 
 def _chain_program(cls, dt):
@@ -85,3 +87,13 @@ def test_runtime_specialisation_source_compiles(cls, dt, t, v):
   ]
   for header, expr in exprs:
     assert lib.sp_jit_compile_check(header.encode(), expr.encode(), C.byref(prog)) == 1, expr
+
+
+def test_importing_the_package_does_not_import_torch():
+  """torch is not part of the product's single-process path: it appears only as torch.distributed (gloo), the
+  control plane of a multi-process job."""
+  import subprocess
+  import sys
+  out = subprocess.run([sys.executable, '-c', "import sys, spartan_amd\nfrom spartan_amd import kernels, backend_hip, sparse, comm\n"
+                        "assert 'torch' not in sys.modules\nprint('ok')"], cwd=ROOT, capture_output=True, text=True, timeout=120)
+  assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]

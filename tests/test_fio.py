@@ -249,6 +249,8 @@ def test_heartbeat_second_failure_of_a_recovered_rank_and_agreement_without_the_
       def __init__(self, rank):
         self.world = W(rank)
     hbs = [heartbeat.Heartbeat(C(r), interval=0.02, threshold=5, probe=lambda: True, store=store) for r in range(2)]
+    for h in hbs:
+      h.agree_floor_s = 0.5
     import threading
     out = [None, None]
 

@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
 import spartan_amd as sp  # noqa: E402
+from spartan_amd import devarray as D  # noqa: E402
+from tests.dev import T, uniform  # noqa: E402
 
 
 @pytest.fixture
@@ -22,21 +24,22 @@ def ctx():
   c = sp.initialize('hip')
   yield c
   sp.shutdown()
-  torch.cuda.empty_cache()
+  D.trim_pool()
 
 
 def _uniform(shape, seed, lo=0.0, hi=1.0):
-  def fn(ex):
-    g = torch.Generator(device='cuda')
-    g.manual_seed(seed + ex.ul[0])
-    return torch.rand(ex.shape, dtype=torch.float32, device='cuda', generator=g) * (hi - lo) + lo
-  return sp.from_tile_fn(shape, np.float32, fn)
+  return uniform(sp, shape, seed, lo, hi)
+
+
+def _data(ctx, array):
+  """The one tile of `array` as a torch view of its HBM bytes (the product's tile is a DevArray)."""
+  return T(ctx.tile(list(array.tiles.values())[0]).data)
 
 
 def test_config3_tile_reductions(ctx):
   R, C = 8192, 65536
   X = _uniform((R, C), 3).force()
-  x = ctx.tile(list(X.tiles.values())[0]).data
+  x = _data(ctx, X)
   # plant extremes (duplicates: the FIRST occurrence must be reported)
   x[100, 7] = 5.0
   x[4000, 7] = 5.0
@@ -68,12 +71,12 @@ def test_config3_tile_fused_maps(ctx):
   R, C = 8192, 65536
   X = _uniform((R, C), 5).force()
   Xv = sp.Val(val=X)
-  x = ctx.tile(list(X.tiles.values())[0]).data
+  x = _data(ctx, X)
   y = (Xv * Xv + Xv).optimized().force()
-  yt = ctx.tile(list(y.tiles.values())[0]).data
+  yt = _data(ctx, y)
   assert torch.equal(yt, x * x + x)                             # bit-exact vs the same fp32 ops (no FMA contraction)
   z = ((Xv + 1) - 1 - Xv).optimized().force()                   # exact in fp32 for x in [0,1): (x+1)-1 == x up to 1 ulp of 1
-  zt = ctx.tile(list(z.tiles.values())[0]).data
+  zt = _data(ctx, z)
   assert float(zt.abs().max()) <= 2 ** -23
   assert float(sp.sum((Xv > 2.0)).glom()) == 0
 
@@ -83,18 +86,18 @@ def test_config2_dot_8192(ctx):
   # closed form, integer-valued: A[i,k] = (i+k)%3-1, B = ones  =>  C[i,j] = sum_k A[i,k]
   ii = torch.arange(n, device='cuda', dtype=torch.float32)
   a = ((ii[:, None] + ii[None, :]) % 3) - 1
-  A = sp.from_tile_fn((n, n), np.float32, lambda ex: a)
+  A = sp.from_tile_fn((n, n), np.float32, lambda ex: D.from_numpy(a.cpu().numpy()))
   B = sp.ones((n, n))
   Cd = sp.dot(A, B).force()
-  c = ctx.tile(list(Cd.tiles.values())[0]).data
+  c = _data(ctx, Cd)
   assert torch.equal(c, a.sum(1, keepdim=True).expand(n, n))
   # uniform[-1,1): spot rows vs float64, |dC| <= 2 K eps
   U = _uniform((n, n), 11, -1.0, 1.0).force()
   V = _uniform((n, n), 12, -1.0, 1.0).force()
   W = sp.dot(sp.Val(val=U), sp.Val(val=V)).force()
-  u = ctx.tile(list(U.tiles.values())[0]).data
-  v = ctx.tile(list(V.tiles.values())[0]).data
-  w = ctx.tile(list(W.tiles.values())[0]).data
+  u = _data(ctx, U)
+  v = _data(ctx, V)
+  w = _data(ctx, W)
   rows = [0, 1, 4095, 8191]
   ref = u[rows].double() @ v.double()
   assert float((w[rows].double() - ref).abs().max()) <= 2 * n * np.finfo(np.float32).eps
@@ -108,8 +111,8 @@ def test_config5_lreg_step(ctx):
   Xv, yv = sp.Val(val=X), sp.Val(val=y)
   yp = sp.dot(Xv, w)
   grad = sp.sum(Xv * (yp - yv), axis=0).optimized().glom()
-  x = ctx.tile(list(X.tiles.values())[0]).data
-  yt = ctx.tile(list(y.tiles.values())[0]).data
+  x = _data(ctx, X)
+  yt = _data(ctx, y)
   r = x.double() @ torch.from_numpy(w).cuda().double() - yt.double()      # float64 reference on the device
   cols = [0, 1, 2047, 4095]
   ref = (x[:, cols].double() * r).sum(0).cpu().numpy()
@@ -126,7 +129,7 @@ def test_config4_kmeans_iteration(ctx):
   from spartan_amd.examples.sklearn.cluster import KMeans
   n, k, d = 1250000, 1024, 256
   X = _uniform((n, d), 31).force()
-  x_dev = ctx.tile(list(X.tiles.values())[0]).data
+  x_dev = _data(ctx, X)
   rng = np.random.RandomState(7)
   centers = rng.rand(k, d)
   centers[700] = centers[3]                                  # exact duplicate: index 3 must win ties
@@ -154,19 +157,20 @@ def test_config4_kmeans_iteration(ctx):
 #  10 GB and 16 GB arrays fit one 288 GB GPU, so the 8-tile path is exercised here before an 8-GPU node sees it)
 @pytest.fixture
 def ctx8():
+  D.trim_pool()
   free, _ = torch.cuda.mem_get_info()
   if free < 80 * 2 ** 30:
     pytest.skip('needs ~60 GiB of free HBM')
   c = sp.initialize('hip', num_workers=8)
   yield c
   sp.shutdown()
-  torch.cuda.empty_cache()
+  D.trim_pool()
 
 
 def _tile_of(ctx, array, row):
   for ex, tid in array.tiles.items():
     if ex.ul[0] <= row < ex.lr[0]:
-      return ctx.tile(tid).data, ex
+      return T(ctx.tile(tid).data), ex
   raise KeyError(row)
 
 
@@ -201,7 +205,7 @@ def test_config3_full_array_8_tiles(ctx8):
   cols = [0, 11, 40000, 65535]
   ref = np.zeros(len(cols))
   for ex, tid in X.tiles.items():
-    ref += ctx8.tile(tid).data[:, cols].double().sum(0).cpu().numpy()
+    ref += T(ctx8.tile(tid).data)[:, cols].double().sum(0).cpu().numpy()
   np.testing.assert_allclose(by_col[cols], ref, rtol=2e-6)
 
 
@@ -229,7 +233,7 @@ def test_config4_full_kmeans_iteration_8_tiles(ctx8):
   np.testing.assert_array_equal(lab[sample], np.argmin(cdist(np.stack(rows), centers), axis=1))
   col = np.zeros(d)
   for ex, tid in X.tiles.items():
-    col += ctx8.tile(tid).data.double().sum(dim=0).cpu().numpy()
+    col += T(ctx8.tile(tid).data).double().sum(dim=0).cpu().numpy()
   np.testing.assert_allclose((new_centers * counts[:, None]).sum(axis=0), col, rtol=2e-6)
 
 
@@ -244,11 +248,11 @@ def test_config5_full_lreg_3_steps_8_tiles(ctx8):
   w0 = np.random.RandomState(3).rand(D, 1)
   w = lreg.fit(sp.Val(val=X), sp.Val(val=y), 3, w=w0.copy())
   ref = torch.from_numpy(w0).cuda()
-  ytiles = {ex.ul[0]: ctx8.tile(tid).data for ex, tid in y.tiles.items()}
+  ytiles = {ex.ul[0]: T(ctx8.tile(tid).data) for ex, tid in y.tiles.items()}
   for _ in range(3):
     grad = torch.zeros(D, 1, dtype=torch.float64, device='cuda')
     for ex, tid in X.tiles.items():
-      x = ctx8.tile(tid).data
+      x = T(ctx8.tile(tid).data)
       r = x.double() @ ref - ytiles[ex.ul[0]].double()
       grad += x.double().t() @ r
     ref = ref - grad * 1e-6
@@ -262,17 +266,17 @@ def test_northstar_dot_32768_spot_rows(ctx):
   U = _uniform((n, n), 51, -1.0, 1.0).force()
   V = _uniform((n, n), 52, -1.0, 1.0).force()
   W = sp.dot(sp.Val(val=U), sp.Val(val=V)).force()
-  u = ctx.tile(list(U.tiles.values())[0]).data
-  v = ctx.tile(list(V.tiles.values())[0]).data
-  w = ctx.tile(list(W.tiles.values())[0]).data
+  u = _data(ctx, U)
+  v = _data(ctx, V)
+  w = _data(ctx, W)
   rows = [0, 4097, 32767]
   ref = u[rows].double() @ v.double()
   assert float((w[rows].double() - ref).abs().max()) <= 2 * n * np.finfo(np.float32).eps
   del W, w, ref
-  torch.cuda.empty_cache()
+  D.trim_pool()
   jj = torch.arange(n, device='cuda', dtype=torch.float32)
   u.copy_(((jj[:, None] + 2 * jj[None, :]) % 5) - 2)            # integer-valued: the product is exact in fp32
   v.fill_(1.0)
   W = sp.dot(sp.Val(val=U), sp.Val(val=V)).force()
-  w = ctx.tile(list(W.tiles.values())[0]).data
+  w = _data(ctx, W)
   assert torch.equal(w[:, 0], u.sum(1)) and torch.equal(w[:, n - 1], w[:, 0]) and torch.equal(w[12345], w[12345, 0].expand(n))

@@ -6,21 +6,19 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-torch = pytest.importorskip('torch')
-
 from spartan_amd import _hip, kernels  # noqa: E402
+from spartan_amd import devarray as D  # noqa: E402
 from spartan_amd.program import Program, broadcast_strides, collapse, dense_strides  # noqa: E402
 
-DEV = 'cuda:0'
 RNG = np.random.RandomState(20150708)
 
 
 def dev(a):
-  return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+  return D.from_numpy(a)
 
 
 def host(t):
-  return t.cpu().numpy()
+  return t.numpy()
 
 
 def build(cls, shape, inputs, body, out_dtype):
@@ -37,9 +35,9 @@ def build(cls, shape, inputs, body, out_dtype):
 
 def run_map(cls, shape, arrays, body, out_dtype):
   prog = build(cls, shape, [(a.dtype, a.shape) for a in arrays], body, out_dtype)
-  out = torch.empty(shape, dtype=kernels.torch_dtype(out_dtype), device=DEV)
+  out = D.empty(shape, out_dtype)
   kernels.map_fused(prog, [dev(a) for a in arrays], out)
-  torch.cuda.synchronize()
+  D.synchronize()
   return host(out)
 
 
@@ -164,9 +162,9 @@ def run_reduce(x, axis, op, cls, out_dtype, body=None, extra=()):
     p.add_input(a.dtype, st)
   p.result_reg = body(p) if body else 0
   prog = p.finish(cls, cshape, None, linear)
-  out = torch.empty(max(O * I, 1), dtype=kernels.torch_dtype(out_dtype), device=DEV)
+  out = D.empty((max(O * I, 1),), out_dtype)
   kernels.reduce(prog, [dev(a) for a in arrays], op, O, A, I, out)
-  torch.cuda.synchronize()
+  D.synchronize()
   res = host(out)
   if axis is None:
     return res[0]
@@ -233,10 +231,10 @@ def run_arg(x, axis, which, offset=0, sentinel=-7):
   p = Program()
   p.add_input(x.dtype, dense_strides((O, A, I)))
   prog = p.finish(_hip.SP_F32 if x.dtype == np.float32 else _hip.SP_I64, (O, A, I), None, True)
-  oi = torch.empty(max(O * I, 1), dtype=torch.int64, device=DEV)
-  ov = torch.empty(max(O * I, 1), dtype=torch.float32 if x.dtype == np.float32 else torch.int64, device=DEV)
+  oi = D.empty((max(O * I, 1),), np.int64)
+  ov = D.empty((max(O * I, 1),), np.float32 if x.dtype == np.float32 else np.int64)
   kernels.argreduce(prog, [dev(x)], which, O, A, I, offset, sentinel, oi, ov)
-  torch.cuda.synchronize()
+  D.synchronize()
   idx, val = host(oi), host(ov)
   if axis is None:
     return idx[0], val[0]
@@ -271,8 +269,8 @@ def test_argreduce_nan_sentinel():
 def test_update_truth_table():
   # tile.pyx:200-297, dense->dense branch (truth table captured in SURVEY 8c)
   tile_shape = (6, 8)
-  t = torch.zeros(tile_shape, dtype=torch.float32, device=DEV)
-  mask = torch.zeros(tile_shape, dtype=torch.uint8, device=DEV)
+  t = D.zeros(tile_shape, np.float32)
+  mask = D.zeros(tile_shape, np.uint8)
   u1 = RNG.rand(*tile_shape).astype(np.float32)
   # full-tile first write on an empty tile: replace
   kernels.update(t, (0, 0), tile_shape, dev(u1), 'ADD', _hip.MASK_ALL_CLEAR, None)
@@ -285,7 +283,7 @@ def test_update_truth_table():
   kernels.update(t, (0, 0), tile_shape, dev(u2), 'NONE', _hip.MASK_ALL_SET, None)
   np.testing.assert_array_equal(host(t), u2)
   # sub-slice writes into an empty (zero-initialised) tile with an explicit mask
-  t.zero_()
+  t.fill(0)
   s1 = RNG.rand(3, 4).astype(np.float32)
   kernels.update(t, (1, 2), (4, 6), dev(s1), 'ADD', _hip.MASK_ARRAY, mask)
   exp = np.zeros(tile_shape, np.float32)
@@ -319,12 +317,12 @@ def test_update_reducers_and_dtypes():
   kernels.update(t, (0, 0), a.shape, dev(bb), 'AND', _hip.MASK_ALL_SET, None)
   np.testing.assert_array_equal(host(t), np.logical_and(ba, bb))
   # update.astype(old.dtype): float64 update into a float32 tile
-  t = torch.zeros((33, 17), dtype=torch.float32, device=DEV)
+  t = D.zeros((33, 17), np.float32)
   upd = RNG.rand(33, 17)
   kernels.update(t, (0, 0), (33, 17), dev(upd), 'ADD', _hip.MASK_ALL_CLEAR, None)
   np.testing.assert_array_equal(host(t), upd.astype(np.float32))
   # 1-d and 3-d boxes
-  t = torch.zeros((4, 6, 8), dtype=torch.float64, device=DEV)
+  t = D.zeros((4, 6, 8), np.float64)
   upd = RNG.rand(2, 3, 4)
   kernels.update(t, (1, 2, 4), (3, 5, 8), dev(upd), 'NONE', _hip.MASK_ALL_CLEAR, None)
   exp = np.zeros((4, 6, 8))
@@ -334,17 +332,17 @@ def test_update_reducers_and_dtypes():
 
 def test_slice_copy():
   src = RNG.rand(40, 48).astype(np.float32)
-  dst = torch.zeros((20, 16), dtype=torch.float32, device=DEV)
+  dst = D.zeros((20, 16), np.float32)
   kernels.slice_copy(dst, 0, (16, 1), dev(src), 5 * 48 + 8, (48, 1), (20, 16))
   np.testing.assert_array_equal(host(dst), src[5:25, 8:24])
   src3 = RNG.randint(0, 100, size=(5, 7, 9)).astype(np.int64)
-  dst3 = torch.zeros((5, 7, 9), dtype=torch.int64, device=DEV)
+  dst3 = D.zeros((5, 7, 9), np.int64)
   kernels.slice_copy(dst3, 1 * 63 + 2 * 9 + 3, (63, 9, 1), dev(src3), 0, (63, 9, 1), (3, 4, 5))
   exp = np.zeros((5, 7, 9), np.int64)
   exp[1:4, 2:6, 3:8] = src3[0:3, 0:4, 0:5]
   np.testing.assert_array_equal(host(dst3), exp)
   b = RNG.rand(13, 7) > 0.5
-  db = torch.zeros((13, 7), dtype=torch.bool, device=DEV)
+  db = D.zeros((13, 7), np.bool_)
   kernels.slice_copy(db, 0, (7, 1), dev(b), 0, (7, 1), (13, 7))
   np.testing.assert_array_equal(host(db), b)
 
@@ -362,7 +360,7 @@ def test_gemm_integer_valued_exact(mnk):
   M, N, K = mnk
   a = RNG.randint(-3, 4, size=(M, K)).astype(np.float32)
   b = RNG.randint(-3, 4, size=(K, N)).astype(np.float32)
-  c = torch.full((M, N), 7.0, dtype=torch.float32, device=DEV)
+  c = D.full((M, N), 7.0, np.float32)
   kernels.gemm_f32(dev(a), dev(b), c, accumulate=False)
   np.testing.assert_array_equal(host(c), a.dot(b))
   kernels.gemm_f32(dev(a), dev(b), c, accumulate=True)
@@ -373,7 +371,7 @@ def test_gemm_random_tolerance_and_transpose_detect():
   M, N, K = 768, 640, 1024
   a = (RNG.rand(M, K) * 2 - 1).astype(np.float32)
   b = (RNG.rand(K, N) * 2 - 1).astype(np.float32)
-  c = torch.empty((M, N), dtype=torch.float32, device=DEV)
+  c = D.empty((M, N), np.float32)
   kernels.gemm_f32(dev(a), dev(b), c)
   ref = a.astype(np.float64).dot(b.astype(np.float64))
   # |dC| <= 2 K eps max|a| max|b|
@@ -381,7 +379,7 @@ def test_gemm_random_tolerance_and_transpose_detect():
   # A = I with an asymmetric B catches a row/col swap in the C write
   eye = np.eye(256, dtype=np.float32)
   bb = np.arange(256 * 128, dtype=np.float32).reshape(256, 128)
-  c2 = torch.empty((256, 128), dtype=torch.float32, device=DEV)
+  c2 = D.empty((256, 128), np.float32)
   kernels.gemm_f32(dev(eye), dev(bb), c2)
   np.testing.assert_array_equal(host(c2), bb)
 
@@ -391,7 +389,7 @@ def test_gemm_strided_views():
   a = RNG.randint(-2, 3, size=(128, 512)).astype(np.float32)
   b = RNG.randint(-2, 3, size=(512, 256)).astype(np.float32)
   da, db = dev(a), dev(b)
-  c = torch.zeros((128, 256), dtype=torch.float32, device=DEV)
+  c = D.zeros((128, 256), np.float32)
   for k0 in range(0, 512, 128):
     kernels.gemm_f32(da[:, k0:k0 + 128], db[k0:k0 + 128, :], c, accumulate=True)
   np.testing.assert_array_equal(host(c), a.dot(b))
@@ -399,7 +397,7 @@ def test_gemm_strided_views():
 
 def test_errors_are_loud():
   with pytest.raises(_hip.HipError):
-    kernels.gemm_f32(torch.zeros(4, 4), torch.zeros(4, 4), torch.zeros(4, 4))
+    kernels.gemm_f32(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))   # host memory
 
 
 def test_static_program_library():
@@ -451,7 +449,7 @@ def test_transposing_slice_copy(shape):
     a = RNG.randint(-1000, 1000, size=shape).astype(dt)
     da = dev(a)
     v = da.t()
-    out = torch.empty((shape[1], shape[0]), dtype=da.dtype, device=DEV)
+    out = D.empty((shape[1], shape[0]), da.dtype)
     kernels.slice_copy(out, 0, out.stride(), da, 0, v.stride(), v.shape)
     np.testing.assert_array_equal(host(out), a.T)
 
@@ -536,10 +534,10 @@ def test_jit_argreduce_bit_identical():
     p.emit('ABS', 2, 2)
     p.result_reg = 2
     prog = p.finish(_hip.SP_F32, (O, A, I), None, True)
-    oi = torch.empty(O * I, dtype=torch.int64, device=DEV)
-    ov = torch.empty(O * I, dtype=torch.float32, device=DEV)
+    oi = D.empty((O * I,), np.int64)
+    ov = D.empty((O * I,), np.float32)
     kernels.argreduce(prog, [dev(x), dev(y)], 0, O, A, I, 0, -7, oi, ov)
-    torch.cuda.synchronize()
+    D.synchronize()
     return np.stack([host(oi).astype(np.float64), host(ov).astype(np.float64)])
   for axis in (0, 1, None):
     want, got, got2 = _both_tiers(lambda: run(axis))
@@ -553,9 +551,9 @@ def test_jit_argreduce_bit_identical():
 
 # ---- k-means tile kernels (kmeans.hip) --------------------------------------------
 def _nearest(x, c, tier):
-  labels = torch.empty(x.shape[0], dtype=torch.int64, device=DEV)
+  labels = D.empty((x.shape[0],), np.int64)
   kernels.nearest_center(dev(x), dev(c), labels, tier)
-  torch.cuda.synchronize()
+  D.synchronize()
   return host(labels)
 
 
@@ -625,18 +623,18 @@ def test_nearest_center_strided_rows_and_auto_tier():
   big = RNG.rand(6000, 96).astype(np.float32)
   c = RNG.rand(64, 80).astype(np.float32)
   xt = dev(big)[:, 8:88]                 # row stride 96, 80 features, 32-B offset
-  labels = torch.empty(6000, dtype=torch.int64, device=DEV)
+  labels = D.empty((6000,), np.int64)
   kernels.nearest_center(xt, dev(c), labels)
-  torch.cuda.synchronize()
+  D.synchronize()
   np.testing.assert_array_equal(host(labels), np.argmin(cdist(big[:, 8:88], c), axis=1))
 
 
 @pytest.mark.parametrize('n,k', [(0, 4), (1, 1), (1000, 7), (100000, 1024), (5000, 16384)])
 def test_bincount(n, k):
   lab = RNG.randint(0, k, size=n).astype(np.int64)
-  counts = torch.empty(k, dtype=torch.int64, device=DEV)
-  kernels.bincount(dev(lab) if n else torch.empty(0, dtype=torch.int64, device=DEV), k, counts)
-  torch.cuda.synchronize()
+  counts = D.empty((k,), np.int64)
+  kernels.bincount(dev(lab) if n else D.empty((0,), np.int64), k, counts)
+  D.synchronize()
   np.testing.assert_array_equal(host(counts), np.bincount(lab, minlength=k))
 
 
@@ -647,9 +645,9 @@ def test_segment_sum_is_numpy_masked_sum(n, k, d, dt):
   lab = RNG.randint(0, k, size=n).astype(np.int64)
   if k > 2:
     lab[lab == 1] = 0                    # an empty cluster
-  out = torch.empty(k, d, dtype=kernels.torch_dtype(dt), device=DEV)
+  out = D.empty((k, d), dt)
   kernels.segment_sum(dev(x), dev(lab), k, out)
-  torch.cuda.synchronize()
+  D.synchronize()
   want = np.zeros((k, d), dt)
   for i in range(k):
     want[i] = x[lab == i].sum(axis=0)    # k_means_.py:91-95
@@ -669,9 +667,9 @@ def test_segment_sum_is_deterministic_and_balanced():
   lab[::7] = RNG.randint(1, k, size=len(lab[::7]))
   outs = []
   for _ in range(3):
-    out = torch.empty(k, d, dtype=torch.float32, device=DEV)
+    out = D.empty((k, d), np.float32)
     kernels.segment_sum(dev(x), dev(lab), k, out)
-    torch.cuda.synchronize()
+    D.synchronize()
     outs.append(host(out))
   np.testing.assert_array_equal(outs[0], outs[1])
   np.testing.assert_array_equal(outs[0], outs[2])
@@ -686,12 +684,12 @@ def test_gemm_f64_integer_valued_exact(mnk):
   M, N, K = mnk
   a = RNG.randint(-4, 5, size=(M, K)).astype(np.float64)
   b = RNG.randint(-4, 5, size=(K, N)).astype(np.float64)
-  c = torch.empty(M, N, dtype=torch.float64, device=DEV)
+  c = D.empty((M, N), np.float64)
   kernels.gemm_f32(dev(a), dev(b), c)
-  torch.cuda.synchronize()
+  D.synchronize()
   np.testing.assert_array_equal(host(c), a.dot(b))
   kernels.gemm_f32(dev(a), dev(b), c, accumulate=True)     # C += A.B (the np.add merge fused in)
-  torch.cuda.synchronize()
+  D.synchronize()
   np.testing.assert_array_equal(host(c), 2 * a.dot(b))
 
 
@@ -699,9 +697,9 @@ def test_gemm_f64_random_tolerance_and_strides():
   a = RNG.rand(300, 520)
   b = RNG.rand(520, 260)
   big_a = dev(np.pad(a, ((0, 0), (0, 8))))[:, :520]        # lda = 528
-  big_c = torch.zeros(300, 264, dtype=torch.float64, device=DEV)
+  big_c = D.zeros((300, 264), np.float64)
   kernels.gemm_f32(big_a, dev(b), big_c[:, :260])
-  torch.cuda.synchronize()
+  D.synchronize()
   np.testing.assert_allclose(host(big_c)[:, :260], a.dot(b), rtol=1e-13)
   assert np.all(host(big_c)[:, 260:] == 0)
 
@@ -730,20 +728,20 @@ def test_gemm_split_k(mnk, dt):
   assert _hip.lib().sp_gemm_workspace_bytes(_hip.sp_dtype(dt), M, N, K) > 0
   a = RNG.randint(-3, 4, size=(M, K)).astype(dt)
   b = RNG.randint(-3, 4, size=(K, N)).astype(dt)
-  c = torch.full((M, N), 5, dtype=kernels.torch_dtype(dt), device=DEV)
+  c = D.full((M, N), 5, dt)
   kernels.gemm_f32(dev(a), dev(b), c)
-  torch.cuda.synchronize()
+  D.synchronize()
   want = a.astype(np.float64).dot(b.astype(np.float64))
   np.testing.assert_array_equal(host(c), want.astype(dt))
   kernels.gemm_f32(dev(a), dev(b), c, accumulate=True)
-  torch.cuda.synchronize()
+  D.synchronize()
   np.testing.assert_array_equal(host(c), (2 * want).astype(dt))
   x = (RNG.rand(M, K) - 0.5).astype(dt)
   y = (RNG.rand(K, N) - 0.5).astype(dt)
   outs = []
   for _ in range(2):
     kernels.gemm_f32(dev(x), dev(y), c)
-    torch.cuda.synchronize()
+    D.synchronize()
     outs.append(host(c).copy())
   np.testing.assert_array_equal(outs[0], outs[1])
   ref = x.astype(np.float64).dot(y.astype(np.float64))
@@ -757,7 +755,7 @@ def test_jit_code_objects_persist_across_processes(tmp_path):
   import sys
   import os
   prog = (
-      "import numpy as np, torch, spartan_amd as sp\n"
+      "import numpy as np, spartan_amd as sp\n"
       "sp.initialize('hip')\n"
       "x = sp.from_numpy(np.arange(1 << 16, dtype=np.float32).reshape(256, 256) / 7)\n"
       "r = (sp.sqrt(sp.abs(x * 3 - 2)) * x + x / 5 - 1).optimized().glom()\n"

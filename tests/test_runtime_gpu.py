@@ -22,37 +22,68 @@ def test_torch_free_host_runs_the_tile_path():
   assert 'torch-free host OK' in text and 'collectives OK' in text, text[-2000:]
 
 
+def test_product_runs_without_torch():
+  """The whole host framework on the HIP backend -- builders, fusion, map / reduce / argmax / dot, glom -- in a fresh
+  interpreter in which torch is never imported: tiles are blobs of the library's own store (sp_blob_*), streams
+  and events the C-ABI's.  The store's counters are asserted as well: blobs are live while arrays are, and
+  destroyed ones are pooled for reuse."""
+  prog = (
+      "import sys, numpy as np\n"
+      "import spartan_amd as sp\n"
+      "from spartan_amd import devarray as D\n"
+      "ctx = sp.initialize('hip', num_workers=3)\n"
+      "live0 = D.blob_stats()[0]\n"
+      "a = np.arange(96 * 64, dtype=np.float32).reshape(96, 64) % 7 - 3\n"
+      "A = sp.from_numpy(a)\n"
+      "r = (A * A + A - 1).optimized().force()\n"
+      "assert D.blob_stats()[0] > live0\n"
+      "t = ctx.tile(list(r.tiles.values())[0]).data\n"
+      "assert isinstance(t, D.DevArray) and t.storage.on_device\n"
+      "np.testing.assert_array_equal(r.glom(), a * a + a - 1)\n"
+      "np.testing.assert_array_equal(sp.sum(A, 0).glom(), a.sum(0))\n"
+      "np.testing.assert_array_equal(sp.argmax(A, 1).glom(), a.argmax(1))\n"
+      "np.testing.assert_array_equal(sp.dot(A, sp.from_numpy(a.T.copy())).glom(), a.dot(a.T))\n"
+      "del r, t, A\n"
+      "sp.zeros((4, 4)).force()      # a safe point: tiles of dead arrays are destroyed here\n"
+      "live1, pooled = D.blob_stats()\n"
+      "assert pooled > 0, (live1, pooled)\n"
+      "assert 'torch' not in sys.modules, 'torch was imported'\n"
+      "print('NO TORCH OK', live0, live1, pooled)\n")
+  out = subprocess.run([sys.executable, '-c', prog], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+  text = out.stdout.decode('utf-8', 'replace')
+  assert out.returncode == 0 and 'NO TORCH OK' in text, text[-3000:]
+
+
 def test_rccl_transport_one_rank():
-  import torch
   from spartan_amd import comm
+  from spartan_amd import devarray as D
   t = comm.RcclTransport(1, 0, comm.RcclTransport.unique_id())
   try:
     ok, msg = t.self_test(60.0)
     assert ok, msg
-    dev = torch.device('cuda', 0)
-    x = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+    x = D.from_numpy(np.arange(1 << 20, dtype=np.float32))
     # asynchronous transfers: issued on the side stream behind the producer, consumed after wait()
-    y = torch.empty_like(x)
-    x.mul_(2.0)
+    y = D.empty(x.shape, np.float32)
+    x = x * np.float32(2.0)
     h = t.reduce_scatter(y, x, 'ADD', async_=True)
-    z = torch.empty_like(x)
+    z = D.empty(x.shape, np.float32)
     h2 = t.all_gather_into(z, x, async_=True)
     h.wait()
     h2.wait()
-    y.add_(1.0)
-    torch.cuda.synchronize()
+    y = y + np.float32(1.0)
+    D.synchronize()
     want = np.arange(1 << 20, dtype=np.float32) * 2
-    np.testing.assert_array_equal(y.cpu().numpy(), want + 1)
-    np.testing.assert_array_equal(z.cpu().numpy(), want)
-    b = torch.ones(1000, dtype=torch.bool, device=dev)
+    np.testing.assert_array_equal(y.numpy(), want + 1)
+    np.testing.assert_array_equal(z.numpy(), want)
+    b = D.from_numpy(np.ones(1000, np.bool_))
     t.all_reduce(b, 'ADD')                     # bool travels as bytes
-    i = torch.arange(777, dtype=torch.int64, device=dev)
+    i = D.from_numpy(np.arange(777, dtype=np.int64))
     t.reduce(i, 0, 'MAX')
     t.broadcast(i, 0)
-    h3 = t.exchange([(0, i)], [(0, torch.empty_like(i))], async_=True)
-    h3.wait()
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(i.cpu().numpy(), np.arange(777))
+    h3 = t.exchange([(0, i)], [(0, D.empty(i.shape, np.int64))], async_=True)
+    del h3                                     # dropped without wait(): the buffers are held until the transfer is over
+    D.synchronize()
+    np.testing.assert_array_equal(i.numpy(), np.arange(777))
   finally:
     t.close()
 

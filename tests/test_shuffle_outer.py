@@ -1,8 +1,10 @@
 """shuffle (target / no-target) and outer with a partitioned second operand:
 the remaining operators of the path (reference operator/shuffle.py,
 operator/outer.py:30-57), on the NumPy backend (CPU) and the HIP backend (GPU).
-User functions work on backend tensors (torch tensors: CPU for the NumPy
-backend, HBM for HIP), so the same function runs on both."""
+User functions are written against NumPy arrays, as the reference's mappers are (shuffle.py:41-96,
+outer.py:12-59, map.py:243-286: `data.T`, `data.sum(axis, keepdims=True)`, `tiles[0] * 2 + tiles[1]`,
+`np.maximum(...)`, `tile_a.dot(tile_b)`): they receive np.ndarray tiles on the NumPy backend and device arrays
+that answer the same calls with HIP kernels on the HIP backend -- the same function, unchanged, on both."""
 import numpy as np
 import pytest
 
@@ -30,9 +32,7 @@ def _transpose_fn(source, ex):
   """tile -> its transposed block (the body of the reference's tests/test_shuffle-style mappers)."""
   data = source.fetch(ex)
   tex = extent.create(ex.ul[::-1], ex.lr[::-1], source.shape[::-1])
-  if hasattr(data, 'shape') and not hasattr(data, 't'):
-    return [(tex, data.reshape(tex.shape))]      # Absent placeholder on non-executing ranks
-  return [(tex, data.t().contiguous())]
+  return [(tex, data.T)]
 
 
 @pytest.mark.parametrize('workers', [1, 3, 4])
@@ -52,9 +52,7 @@ def test_shuffle_target_accumulates(make_backend, workers):
   def colsum_fn(source, ex):
     data = source.fetch(ex)
     tex = extent.create((0, ex.ul[1]), (1, ex.lr[1]), (1, source.shape[1]))
-    if not hasattr(data, 'sum'):
-      return [(tex, data.reshape(tex.shape))]
-    return [(tex, data.sum(0, keepdim=True))]
+    return [(tex, data.sum(axis=0, keepdims=True))]
   target = sp.ndarray((1, 28), dtype=np.float32, reduce_fn=np.add)
   r = sp.shuffle(sp.from_numpy(a), colsum_fn, target=target)
   np.testing.assert_array_equal(r.glom(), a.sum(0, keepdims=True))
@@ -71,8 +69,7 @@ def test_outer_partitioned_rhs(make_backend, workers):
 
   def block_dot(ex_a, tile_a, ex_b, tile_b):
     tex = extent.create((ex_a.ul[0], ex_b.ul[1]), (ex_a.lr[0], ex_b.lr[1]), (48, 36))
-    from spartan_amd.expr.dot import _dot
-    yield tex, _dot(tile_a, tile_b)
+    yield tex, tile_a.dot(tile_b)
   r = sp.outer((sp.from_numpy(a), sp.from_numpy(b)), (0, 1), block_dot, shape=(48, 36), reducer=np.add,
                tile_hint=(16, 36))
   np.testing.assert_array_equal(r.glom(), a.dot(b))
@@ -87,7 +84,7 @@ def test_user_map2_join(make_backend):
 
   def join(extents, tiles):
     ex = extents[0]
-    yield ex, tiles[0] if not hasattr(tiles[0], 'mul') else tiles[0].mul(2.0).add(tiles[1])
+    yield ex, np.maximum(tiles[0] * 2.0 + tiles[1], tiles[1] - 1e9)
   r = sp.map2((sp.from_numpy(a), sp.from_numpy(b)), (0, 0), fn=join, shape=(90, 8))
   np.testing.assert_array_equal(r.glom(), a * 2 + b)
   sp.shutdown()

@@ -118,7 +118,7 @@ def _special(x, rng):
 @pytest.mark.parametrize('dtype', [np.float32, np.float64, np.int32, np.int64])
 @pytest.mark.parametrize('shape', [(1, 1), (5, 7), (1, 4096), (3, 4097), (1000, 33), (64, 64), (2, 100000), (70000, 3), (500, 300), (40, 2048)])
 def test_sort_rows_kernel(monkeypatch, shape, dtype, algo):
-  torch = pytest.importorskip('torch')
+  from spartan_amd import devarray as D
   from spartan_amd import kernels
   if algo == 'radix':
     monkeypatch.setenv('SP_SORT_ALGO', 'radix')
@@ -129,13 +129,13 @@ def test_sort_rows_kernel(monkeypatch, shape, dtype, algo):
     x = rng.randint(-50, 50, size=shape).astype(dtype)          # many ties
     x.flat[0] = np.iinfo(dtype).min
     x.flat[-1] = np.iinfo(dtype).max
-  t = torch.from_numpy(x).cuda()
+  t = D.from_numpy(x)
   vals, idx = kernels.sort_rows(t, values=True, indices=True)
   iview = {4: np.int32, 8: np.int64}[np.dtype(dtype).itemsize]
-  np.testing.assert_array_equal(idx.cpu().numpy(), np.argsort(x, 1, kind='stable'))
-  np.testing.assert_array_equal(vals.cpu().numpy().view(iview), np.sort(x, 1, kind='stable').view(iview))
+  np.testing.assert_array_equal(idx.numpy(), np.argsort(x, 1, kind='stable'))
+  np.testing.assert_array_equal(vals.numpy().view(iview), np.sort(x, 1, kind='stable').view(iview))
   only_idx = kernels.sort_rows(t, values=False, indices=True)[1]
-  assert torch.equal(only_idx, idx)
+  assert np.array_equal(only_idx.numpy(), idx.numpy())
 
 
 @pytest.mark.gpu
@@ -143,14 +143,16 @@ def test_sort_full_size_tile_properties():
   """configs[2] tile, 8192 x 65536 fp32 (537 M elements: the radix path, 4 key passes + 2 row passes): every row
   non-decreasing, the multiset of bit patterns of every row unchanged (XOR and wrapping sum of the int32 views),
   argsort a permutation that reproduces the sorted values."""
-  torch = pytest.importorskip('torch')
+  torch = pytest.importorskip('torch')             # an independent calculator on the device (tests/dev.py)
+  from spartan_amd import devarray as D
   from spartan_amd import kernels
+  from tests.dev import T, uniform_tile
   rows, cols = 8192, 65536
-  g = torch.Generator(device='cuda')
-  g.manual_seed(5)
-  x = torch.rand((rows, cols), device='cuda', dtype=torch.float32, generator=g) - 0.5
+  xd = uniform_tile((rows, cols), 5, -0.5, 0.5)
+  x = T(xd)
   x[17, 100:200] = 0.25                        # a run of ties
-  vals, idx = kernels.sort_rows(x, values=True, indices=True)
+  vals, idx = kernels.sort_rows(xd, values=True, indices=True)
+  vals, idx = T(vals), T(idx)
   assert bool(torch.all(vals[:, 1:] >= vals[:, :-1]))
   xi, vi = x.view(torch.int32), vals.view(torch.int32)
   assert torch.equal(xi.sum(dim=1), vi.sum(dim=1))
@@ -160,8 +162,8 @@ def test_sort_full_size_tile_properties():
     assert torch.equal(torch.sort(idx[r]).values, torch.arange(cols, device='cuda'))
     ref = torch.sort(x[r], stable=True)
     assert torch.equal(ref.values, vals[r]) and torch.equal(ref.indices, idx[r])
-  del vals, idx, x
-  torch.cuda.empty_cache()
+  del vals, idx, x, xd
+  D.trim_pool()
 
 
 def _sort_fuzz(backend_factory, n_cases=25):

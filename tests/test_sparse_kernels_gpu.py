@@ -9,11 +9,11 @@ import scipy.sparse as sps
 
 pytestmark = pytest.mark.gpu
 
-torch = pytest.importorskip('torch')
-
+from spartan_amd import devarray as D  # noqa: E402
 from spartan_amd import sparse as S  # noqa: E402
 
-DEV = 'cuda'
+DEV = 'hip'
+dev = D.from_numpy
 
 
 def _rand_coo(rng, m, n, nnz, dtype, dup=False, integer=False):
@@ -117,7 +117,7 @@ def test_csr_times_dense(shape, nnz, n, dtype):
   a = _canon(_rand_coo(rng, shape[0], shape[1], nnz, dtype))
   A = S.from_scipy(a, DEV)
   b = rng.standard_normal((shape[1], n)).astype(dtype)
-  got = S.spmm(A, torch.from_numpy(b).to(DEV)).cpu().numpy()
+  got = S.spmm(A, dev(b)).numpy()
   ref = a.astype(np.float64) @ b.astype(np.float64)
   scale = (abs(a).astype(np.float64) @ np.abs(b).astype(np.float64))
   eps = np.finfo(dtype).eps
@@ -127,7 +127,7 @@ def test_csr_times_dense(shape, nnz, n, dtype):
     # n > 1 walks a row's entries in storage order like scipy's csr_matvecs: bit-exact
     np.testing.assert_array_equal(got, a @ b)
   # vectors ([k]) give vectors ([m])
-  v = torch.from_numpy(b[:, 0].copy()).to(DEV)
+  v = dev(b[:, 0].copy())
   assert tuple(S.spmm(A, v).shape) == (shape[0],)
 
 
@@ -140,14 +140,14 @@ def test_spmv_integer_valued_is_exact_for_every_group_width(monkeypatch):
   monkeypatch.setenv('SP_SPMV_ALGO', 'vector')
   for g in (2, 4, 8, 16, 32, 64):
     monkeypatch.setenv('SP_SPMV_G', str(g))
-    np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV)).cpu().numpy(), ref)
+    np.testing.assert_array_equal(S.spmm(A, dev(x)).numpy(), ref)
   monkeypatch.delenv('SP_SPMV_G')
   monkeypatch.delenv('SP_SPMV_ALGO')
-  np.testing.assert_array_equal(S.row_sums(A).cpu().numpy(), np.asarray(a.sum(axis=1)).ravel())
+  np.testing.assert_array_equal(S.row_sums(A).numpy(), np.asarray(a.sum(axis=1)).ravel())
   # accumulate
-  y = torch.ones((3000, 1), dtype=torch.float32, device=DEV)
-  S.spmm(A, torch.from_numpy(x).to(DEV), out=y, accumulate=True)
-  np.testing.assert_array_equal(y.cpu().numpy(), ref + 1)
+  y = D.full((3000, 1), 1, np.float32)
+  S.spmm(A, dev(x), out=y, accumulate=True)
+  np.testing.assert_array_equal(y.numpy(), ref + 1)
 
 
 @pytest.mark.parametrize('algo', ['stream', 'vector'])
@@ -171,16 +171,16 @@ def test_spmv_rows_spanning_entry_chunks(monkeypatch, algo, seed):
   a = sps.csr_matrix((vals, (rows, cols)), shape=(len(lens), ncols))
   A = S.from_scipy(a, DEV)
   x = rng.randint(-2, 3, size=(ncols, 1)).astype(np.float32)
-  np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV)).cpu().numpy(), a @ x)
+  np.testing.assert_array_equal(S.spmm(A, dev(x)).numpy(), a @ x)
   # without the per-matrix plan every workgroup searches its own row range
-  np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV), plan=False).cpu().numpy(), a @ x)
-  np.testing.assert_array_equal(S.row_sums(A).cpu().numpy(), np.asarray(a.sum(axis=1)).ravel())
-  y = torch.full((len(lens), 1), 2.0, dtype=torch.float32, device=DEV)
-  S.spmm(A, torch.from_numpy(x).to(DEV), out=y, accumulate=True)
-  np.testing.assert_array_equal(y.cpu().numpy(), a @ x + 2)
+  np.testing.assert_array_equal(S.spmm(A, dev(x), plan=False).numpy(), a @ x)
+  np.testing.assert_array_equal(S.row_sums(A).numpy(), np.asarray(a.sum(axis=1)).ravel())
+  y = D.full((len(lens), 1), 2.0, np.float32)
+  S.spmm(A, dev(x), out=y, accumulate=True)
+  np.testing.assert_array_equal(y.numpy(), a @ x + 2)
   # float64 too
   a64 = a.astype(np.float64)
-  np.testing.assert_array_equal(S.spmm(S.from_scipy(a64, DEV), torch.from_numpy(x.astype(np.float64)).to(DEV)).cpu().numpy(),
+  np.testing.assert_array_equal(S.spmm(S.from_scipy(a64, DEV), dev(x.astype(np.float64))).numpy(),
                                 a64 @ x.astype(np.float64))
 
 
@@ -188,17 +188,17 @@ def test_scatter_modes():
   rng = np.random.RandomState(10)
   a = _canon(_rand_coo(rng, 40, 50, 300, np.float32, integer=True))
   A = S.from_scipy(a, DEV)
-  np.testing.assert_array_equal(S.to_dense(A).cpu().numpy(), a.toarray())
+  np.testing.assert_array_equal(S.to_dense(A).numpy(), a.toarray())
   base = rng.randint(0, 5, size=(64, 80)).astype(np.float32)
-  out = torch.from_numpy(base.copy()).to(DEV)
+  out = dev(base.copy())
   S.scatter(A, out, 7, 11, mode=1)
   ref = base.copy()
   ref[7:47, 11:61] += a.toarray()
-  np.testing.assert_array_equal(out.cpu().numpy(), ref)
+  np.testing.assert_array_equal(out.numpy(), ref)
   # sparse.pyx:21-38 with REDUCE_ADD: first write where the mask is clear, add where it is set
   mask = (rng.rand(64, 80) < 0.5)
-  out = torch.from_numpy(base.copy()).to(DEV)
-  mk = torch.from_numpy(mask.astype(np.uint8)).to(DEV)
+  out = dev(base.copy())
+  mk = dev(mask.astype(np.uint8))
   S.scatter(A, out, 7, 11, mode=2, mask=mk)
   ref, rmask = base.copy(), mask.copy()
   coo = a.tocoo()
@@ -208,8 +208,8 @@ def test_scatter_modes():
     else:
       ref[r, c] = v
       rmask[r, c] = True
-  np.testing.assert_array_equal(out.cpu().numpy(), ref)
-  np.testing.assert_array_equal(mk.cpu().numpy().astype(bool), rmask)
+  np.testing.assert_array_equal(out.numpy(), ref)
+  np.testing.assert_array_equal(mk.numpy().astype(bool), rmask)
 
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
@@ -229,27 +229,30 @@ def test_sparse_times_sparse(dtype):
 def test_pagerank_sized_tile_properties():
   """configs-style full size: 900 000 pages x 10 out-links (tests/benchmark_pagerank.py:124-127).  Size-independent
   checks: W x ones == in-degree histogram (integer-valued: exact), transpose twice == identity, structure sorted."""
+  torch = pytest.importorskip('torch')             # an independent calculator on the device (tests/dev.py)
+  from tests.dev import T
   n, deg = 900000, 10
-  g = torch.Generator(device=DEV)
-  g.manual_seed(1)
-  rows = torch.randint(0, n, (n * deg,), device=DEV, generator=g, dtype=torch.int32)
-  cols = torch.arange(n, device=DEV, dtype=torch.int32).repeat_interleave(deg)
-  vals = torch.ones(n * deg, device=DEV, dtype=torch.float32)
+  rng = np.random.RandomState(1)
+  rows_h = rng.randint(0, n, size=n * deg).astype(np.int32)
+  rows = dev(rows_h)
+  cols = dev(np.repeat(np.arange(n, dtype=np.int32), deg))
+  vals = D.full((n * deg,), 1, np.float32)
   W = S.from_coo((n, n), np.float32, rows, cols, vals)
   assert int(W.indptr[-1]) == W.nnz and W.nnz <= n * deg
   assert float(W.data.sum()) == n * deg                       # duplicates were added, nothing lost
-  indeg = torch.bincount(rows.long(), minlength=n).float()
-  ones = torch.ones((n, 1), device=DEV, dtype=torch.float32)
-  assert torch.equal(S.spmm(W, ones).reshape(-1), indeg)
-  assert torch.equal(S.row_sums(W), indeg)
+  indeg = torch.bincount(T(rows).long(), minlength=n).float()
+  ones = D.full((n, 1), 1, np.float32)
+  assert torch.equal(T(S.spmm(W, ones)).reshape(-1), indeg)
+  assert torch.equal(T(S.row_sums(W)), indeg)
   Wt = S.transpose(W)
-  assert torch.equal(S.spmm(Wt, ones).reshape(-1), torch.full((n,), float(deg), device=DEV))
+  assert torch.equal(T(S.spmm(Wt, ones)).reshape(-1), torch.full((n,), float(deg), device='cuda'))
   Wtt = S.transpose(Wt)
-  assert torch.equal(Wtt.indptr, W.indptr) and torch.equal(Wtt.indices, W.indices) and torch.equal(Wtt.data, W.data)
+  assert all(torch.equal(T(p), T(q)) for p, q in ((Wtt.indptr, W.indptr), (Wtt.indices, W.indices), (Wtt.data, W.data)))
   # column indices ascend strictly inside every row
-  d = W.indices[1:].long() - W.indices[:-1].long()
-  row_start = torch.zeros(W.nnz, dtype=torch.bool, device=DEV)
-  row_start[W.indptr[1:-1][W.indptr[1:-1] < W.nnz]] = True
+  ind, ptr = T(W.indices), T(W.indptr)
+  d = ind[1:].long() - ind[:-1].long()
+  row_start = torch.zeros(W.nnz, dtype=torch.bool, device='cuda')
+  row_start[ptr[1:-1][ptr[1:-1] < W.nnz]] = True
   assert bool(torch.all((d > 0) | row_start[1:]))
 
 
@@ -276,11 +279,11 @@ def test_sparse_fuzz_against_scipy():
     np.testing.assert_array_equal(got.data, ref.data, err_msg=tag)
     np.testing.assert_array_equal(S.to_scipy(S.add(A, S.transpose(S.transpose(A)), -1)).toarray(), np.zeros((m, k), dtype), err_msg=tag)
     x = rng.randint(-2, 3, size=(k, 1)).astype(dtype)
-    np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(x).to(DEV)).cpu().numpy(), a @ x, err_msg=tag)
+    np.testing.assert_array_equal(S.spmm(A, dev(x)).numpy(), a @ x, err_msg=tag)
     xm = rng.randint(-2, 3, size=(k, int(rng.choice([2, 5, 70])))).astype(dtype)
-    np.testing.assert_array_equal(S.spmm(A, torch.from_numpy(xm).to(DEV)).cpu().numpy(), a @ xm, err_msg=tag)
-    np.testing.assert_array_equal(S.row_sums(A).cpu().numpy(), np.asarray(a.sum(axis=1)).ravel(), err_msg=tag)
-    np.testing.assert_array_equal(S.to_dense(A).cpu().numpy(), a.toarray(), err_msg=tag)
+    np.testing.assert_array_equal(S.spmm(A, dev(xm)).numpy(), a @ xm, err_msg=tag)
+    np.testing.assert_array_equal(S.row_sums(A).numpy(), np.asarray(a.sum(axis=1)).ravel(), err_msg=tag)
+    np.testing.assert_array_equal(S.to_dense(A).numpy(), a.toarray(), err_msg=tag)
     prod = S.to_scipy(S.spgemm(A, B))
     np.testing.assert_array_equal(prod.toarray(), (a @ b).toarray(), err_msg=tag)
     assert prod.has_canonical_format
