@@ -386,8 +386,11 @@ int sp_coo_reshape(int64_t nnz, int32_t* d_rows, int32_t* d_cols, int64_t old_co
  * n == 1, rows of >= 1024 entries on average (or no workspace): 2..64 lanes per row, shuffle reduction; n > 1: entries of a row in storage order
  * (scipy's csr_matvecs order).  Without a workspace the lanes-per-row kernel is used for every n == 1.
  * d_plan (may be NULL): the output of sp_csr_spmv_plan for this matrix -- the first row that starts in each
- * 2048-entry chunk, sp_csr_spmv_plan_entries(nnz) int64 values -- computed once per matrix and reused by every
- * multiply (an iteration like p <- W.p keeps W); without it every workgroup searches indptr itself. */
+ * 2048-entry chunk, the length of the longest row and an arrival counter, sp_csr_spmv_plan_entries(nnz) int64 values
+ * -- computed once per matrix and reused by every multiply (an iteration like p <- W.p keeps W).  With a plan the
+ * n == 1 product is ONE launch (rows no longer than 65 entries are summed whole by the chunk they start in; longer
+ * rows: carries added by the last workgroup to arrive, which uses -- and resets -- the counter in the plan, so one
+ * plan serves one stream at a time); without it every workgroup searches indptr itself and a fix-up launch follows. */
 size_t sp_csr_spmm_workspace_bytes(int64_t nnz, int64_t n);
 int64_t sp_csr_spmv_plan_entries(int64_t nnz);
 int sp_csr_spmv_plan(int64_t m, int64_t nnz, const int64_t* d_indptr, int64_t* d_plan, void* stream);

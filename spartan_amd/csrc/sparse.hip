@@ -246,12 +246,159 @@ __global__ __launch_bounds__(256) void sp_csr_spmv_stream_kernel(const int64_t* 
   }
 }
 
-// plan[c] = first row starting at or after entry c * SPMV_CH (c < nchunk), plan[nchunk] = m
+// plan[c] = first row starting at or after entry c * SPMV_CH (c < nchunk), plan[nchunk] = m;
+// plan[nchunk + 1] = length of the longest row (zeroed by the launcher, atomicMax here);
+// plan[nchunk + 2] = arrival counter of the planned kernel's long-row mode (zero between launches).
 __global__ __launch_bounds__(256) void sp_csr_spmv_plan_kernel(const int64_t* __restrict__ indptr, int64_t m,
                                                                int nchunk, int64_t* __restrict__ plan) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c > nchunk) return;
-  plan[c] = c == nchunk ? m : sp_lower_bound(indptr, m, (int64_t)c * SPMV_CH);
+  if (c <= nchunk) plan[c] = c == nchunk ? m : sp_lower_bound(indptr, m, (int64_t)c * SPMV_CH);
+  long long longest = 0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m; r += (int64_t)gridDim.x * 256) {
+    const long long len = (long long)(indptr[r + 1] - indptr[r]);
+    longest = len > longest ? len : longest;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(longest, off);
+    longest = o > longest ? o : longest;
+  }
+  if ((threadIdx.x & 63) == 0 && longest > 0) atomicMax((long long*)&plan[nchunk + 1], longest);
+}
+
+// The planned form of the stream kernel: ONE launch, two dependent memory round trips per workgroup instead of
+// four.  Everything whose address does not depend on loaded data is requested up front -- the chunk's entries, the
+// SPMV_SPILL entries after the chunk, the plan's row range and, right behind it, the row pointers of the thread's
+// own row -- then the gathers of x, one barrier, and the row sums from LDS.
+// What bounds it (900 000 pages x 10 links, MI355X): 51.6 us, of which the random gather of x is 29 -- with x read
+// at the entry's own position instead (SP_SPMV_ABLATE=1, timing only) the same launch takes 22.5 us = 3.85 TB/s of
+// the algorithmic bytes.  Every gathered 4-byte value moves a whole cache line from the L2 to the CU (9 M lines
+// per launch); the entry stream itself is not the limit, and non-temporal entry loads (SP_SPMV_NT=1) cut the
+// counter traffic from 1.65 x to 1.33 x algorithmic but run slower (62 us).
+//   * longest row <= SPMV_SPILL + 1 (the plan knows): a row belongs to the chunk it STARTS in and is summed whole
+//     there, in storage order; what spills over the chunk's end is in the extra entries every workgroup loaded.
+//     No carries, no second pass.
+//   * longer rows: partial sums per chunk and carries as in sp_csr_spmv_stream_kernel; the LAST workgroup to
+//     arrive (a ticket in the plan) adds the carries of every row in chunk order -- deterministic, no
+//     floating-point atomics, and still one launch.
+constexpr int SPMV_SPILL = 64;
+
+template <typename T, bool NT, bool ABLATE_GATHER = false>
+__global__ __launch_bounds__(256) void sp_csr_spmv_planned_kernel(const int64_t* __restrict__ indptr,
+                                                                  const int32_t* __restrict__ indices,
+                                                                  const T* __restrict__ vals,
+                                                                  const T* __restrict__ x, int64_t ldx,
+                                                                  T* __restrict__ y, int64_t ldy, int64_t m,
+                                                                  int64_t nnz, int nchunk, int accumulate, T* carry,
+                                                                  int64_t* carry_row, int64_t* plan) {
+  __shared__ T prod[SPMV_CH + SPMV_SPILL];
+  __shared__ int is_last;
+  const int per = (nchunk + 7) >> 3;
+  const int c = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);   // XCD k walks chunks [k*per, (k+1)*per)
+  if (c >= nchunk) return;
+  const int64_t e0 = (int64_t)c * SPMV_CH;
+  const int64_t e1 = e0 + SPMV_CH < nnz ? e0 + SPMV_CH : nnz;
+  const int tid = threadIdx.x;
+  const int64_t r_lo = plan[c], r_hi = plan[c + 1];
+  const bool whole_rows = plan[nchunk + 1] <= SPMV_SPILL + 1;
+  T v[SPMV_CH / 256];
+  int32_t col[SPMV_CH / 256];
+#pragma unroll
+  for (int u = 0; u < SPMV_CH / 256; ++u) {
+    const int64_t e = e0 + u * 256 + tid;
+    v[u] = 0;
+    col[u] = 0;
+    if (e < e1) {
+      v[u] = NT ? __builtin_nontemporal_load(vals + e) : vals[e];
+      col[u] = NT ? __builtin_nontemporal_load(indices + e) : indices[e];
+    }
+  }
+  T vs = 0;
+  int32_t cs = 0;
+  const bool spill = whole_rows && tid < SPMV_SPILL && e1 + tid < nnz;
+  if (spill) {
+    vs = vals[e1 + tid];
+    cs = indices[e1 + tid];
+  }
+  int64_t r = r_lo + tid;
+  int64_t ra = 0, rb = 0;
+  if (r < r_hi) {
+    ra = indptr[r];
+    rb = indptr[r + 1];
+  }
+#pragma unroll
+  for (int u = 0; u < SPMV_CH / 256; ++u) {
+    // (timing ablation only: x read at the entry's own position instead of its column -- a coalesced stream)
+    const int64_t xi = ABLATE_GATHER ? (e0 + u * 256 + tid) % m : (int64_t)col[u];
+    prod[u * 256 + tid] = x ? v[u] * x[xi * ldx] : v[u];
+  }
+  if (tid < SPMV_SPILL) prod[SPMV_CH + tid] = spill ? (x ? vs * x[(int64_t)cs * ldx] : vs) : (T)0;
+  __syncthreads();
+  if (whole_rows) {
+    while (r < r_hi) {
+      const int a = (int)(ra - e0), b = (int)(rb - e0);       // b <= SPMV_CH + SPMV_SPILL: the row starts before e1
+      T s = 0;
+      for (int i = a; i < b; ++i) s += prod[i];
+      y[r * ldy] = accumulate ? y[r * ldy] + s : s;
+      r += 256;
+      if (r < r_hi) {
+        ra = indptr[r];
+        rb = indptr[r + 1];
+      }
+    }
+    return;
+  }
+  // ---- long rows: per-chunk partial sums + carries
+  int64_t c_end = r_lo < m ? indptr[r_lo] : nnz;
+  if (c_end > e1) c_end = e1;
+  if (tid < 64) {
+    const int len = (int)(c_end - e0);
+    if (len > 0) {
+      T s = 0;
+      for (int i = tid; i < len; i += 64) s += prod[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (tid == 0) {
+        carry[c] = s;
+        carry_row[c] = r_lo - 1;
+      }
+    } else if (tid == 0) {
+      carry_row[c] = -1;
+    }
+  }
+  while (r < r_hi) {
+    const int a = (int)(ra - e0);
+    const int b = (int)((rb < e1 ? rb : e1) - e0);
+    T s = 0;
+    for (int i = a; i < b; ++i) s += prod[i];
+    y[r * ldy] = accumulate ? y[r * ldy] + s : s;
+    r += 256;
+    if (r < r_hi) {
+      ra = indptr[r];
+      rb = indptr[r + 1];
+    }
+  }
+  __threadfence();                       // my rows and my carry are visible device-wide before I take a ticket
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long t = atomicAdd((unsigned long long*)&plan[nchunk + 2], 1ull);
+    is_last = (t == (unsigned long long)(nchunk - 1));
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  for (int cc = tid; cc < nchunk; cc += 256) {
+    const int64_t row = __builtin_nontemporal_load(carry_row + cc);
+    if (row < 0) continue;
+    // only the FIRST chunk carrying into `row` adds (in chunk order) every carry of that row
+    if (cc > 0 && __builtin_nontemporal_load(carry_row + cc - 1) == row) continue;
+    const int64_t row_end = indptr[row + 1];
+    T s = __builtin_nontemporal_load(y + row * ldy);
+    for (int k = cc; k < nchunk && (int64_t)k * SPMV_CH < row_end && __builtin_nontemporal_load(carry_row + k) == row; ++k)
+      s += __builtin_nontemporal_load(carry + k);
+    y[row * ldy] = s;
+  }
+  if (tid == 0) plan[nchunk + 2] = 0;    // the next launch starts from zero
 }
 
 template <typename T>
@@ -527,6 +674,22 @@ int spmm_go(int64_t m, int64_t n, int64_t nnz, const int64_t* indptr, const int3
       T* carry = (T*)ws;
       int64_t* carry_row = (int64_t*)((char*)ws + sp_al256((size_t)nchunk * sizeof(T)));
       const int per = (nchunk + 7) / 8;
+      const char* ep = getenv("SP_SPMV_PLANNED");      // "0": the two-launch form even with a plan (A/B knob)
+      if (plan && !(ep && ep[0] == '0')) {
+        const char* en = getenv("SP_SPMV_NT");
+        const char* ab = getenv("SP_SPMV_ABLATE");        // timing-only: wrong results
+        if (ab && ab[0] == '1')
+          hipLaunchKernelGGL((sp_csr_spmv_planned_kernel<T, false, true>), dim3(per * 8), dim3(256), 0, st, indptr, indices, vals, B, ldb,
+                             C, ldc, m, nnz, nchunk, accumulate, carry, carry_row, const_cast<int64_t*>(plan));
+        else if (!(en && en[0] == '1'))      // default: plain loads (non-temporal entry loads measured slower here: 62 vs 52 us)
+          hipLaunchKernelGGL((sp_csr_spmv_planned_kernel<T, false>), dim3(per * 8), dim3(256), 0, st, indptr, indices, vals, B, ldb,
+                             C, ldc, m, nnz, nchunk, accumulate, carry, carry_row, const_cast<int64_t*>(plan));
+        else
+          hipLaunchKernelGGL((sp_csr_spmv_planned_kernel<T, true>), dim3(per * 8), dim3(256), 0, st, indptr, indices, vals, B, ldb,
+                             C, ldc, m, nnz, nchunk, accumulate, carry, carry_row, const_cast<int64_t*>(plan));
+        SP_CHECK_LAUNCH();
+        return 0;
+      }
       hipLaunchKernelGGL((sp_csr_spmv_stream_kernel<T>), dim3(per * 8), dim3(256), 0, st, indptr, indices, vals, B, ldb,
                          C, ldc, m, nnz, nchunk, accumulate, carry, carry_row, plan);
       SP_CHECK_LAUNCH();
@@ -584,13 +747,17 @@ extern "C" size_t sp_csr_spmm_workspace_bytes(int64_t nnz, int64_t n) {
   return sp_al256(nchunk * 8) + sp_al256(nchunk * 8) + 256;
 }
 
-extern "C" int64_t sp_csr_spmv_plan_entries(int64_t nnz) { return nnz < 1 ? 1 : (int64_t)spmv_chunks(nnz) + 1; }
+extern "C" int64_t sp_csr_spmv_plan_entries(int64_t nnz) { return nnz < 1 ? 3 : (int64_t)spmv_chunks(nnz) + 3; }
 
 extern "C" int sp_csr_spmv_plan(int64_t m, int64_t nnz, const int64_t* d_indptr, int64_t* d_plan, void* stream) {
   if (m < 0 || nnz < 0) SP_FAIL("sp_csr_spmv_plan: bad sizes");
   if (!d_indptr || !d_plan) SP_FAIL("sp_csr_spmv_plan: NULL pointer");
   const int nchunk = nnz < 1 ? 0 : spmv_chunks(nnz);
-  hipLaunchKernelGGL(sp_csr_spmv_plan_kernel, dim3((nchunk + 256) / 256), dim3(256), 0, (hipStream_t)stream, d_indptr,
+  SP_HIP(hipMemsetAsync(d_plan + nchunk + 1, 0, 16, (hipStream_t)stream));      // longest row, arrival counter
+  int blocks = (nchunk + 256) / 256;
+  const int64_t want = (m + 255) / 256;            // the longest-row scan strides over the rows
+  if (want > blocks) blocks = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(sp_csr_spmv_plan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_indptr,
                      m, nchunk, d_plan);
   SP_CHECK_LAUNCH();
   return 0;

@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+try:
+  # Test infrastructure only (tests/dev.py uses torch as an independent calculator on the device; the product never
+  # imports it).  Loaded FIRST on purpose: torch ships its own copy of the HIP runtime, and a process in which
+  # libspartan_hip.so brought the system's runtime up before torch loads its own ends with two runtimes and torch
+  # seeing no GPU.
+  import torch  # noqa: F401
+except ImportError:
+  pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)

@@ -92,6 +92,8 @@ def pmc_values(dirs):
   """{short kernel name: {counter: median value over launches (first launch of each kernel dropped when there are more)}}"""
   vals = {}
   for d in dirs:
+    if os.path.isfile(d) and not d.endswith('.csv'):
+      continue
     files = [d] if os.path.isfile(d) else glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
     for f in files:
       for r in csv.DictReader(open(f)):
