@@ -138,12 +138,33 @@ def full_like(array, fill_value, dtype=None, tile_hint=None):
   return full(array.shape, fill_value, dtype, tile_hint)
 
 
+def ravel_contiguous(ul, lr, array_shape):
+  """Do the elements of the box [ul, lr) follow one another in the row-major order of the whole array?  (Every axis
+  after the LAST cut one is complete by definition; every axis before it must have extent 1: row bands of a
+  matrix, any range of a vector.)"""
+  cut = [i for i in range(len(array_shape)) if lr[i] - ul[i] != array_shape[i]]
+  if not cut:
+    return True
+  for i in range(cut[-1]):          # (`all` is the array builder in this module)
+    if lr[i] - ul[i] != 1:
+      return False
+  return True
+
+
 def _arange_mapper(tile, ex, start=None, stop=None, step=None, dtype=None):
-  """creation.py:134-141."""
-  pos = extent.ravelled_pos(ex[0], ex[2])
-  ex_start = pos * step + start
-  ex_stop = np.prod(tile.shape) * step + ex_start
-  return np.arange(ex_start, ex_stop, step, dtype=dtype).reshape(tile.shape)
+  """creation.py:134-141: a tile whose elements are consecutive in the array's row-major order counts on from the
+  position of its first element.  The reference applies that formula to EVERY tile, which is wrong for a column
+  or block tile (its auto-tiling pass produces them, and its arange then differs from np.arange); such a tile gets
+  the value of each element's own position here."""
+  ul, lr, array_shape = ex
+  if ravel_contiguous(ul, lr, array_shape):
+    pos = extent.ravelled_pos(ul, array_shape)
+    ex_start = pos * step + start
+    ex_stop = np.prod(tile.shape) * step + ex_start
+    return np.arange(ex_start, ex_stop, step, dtype=dtype).reshape(tile.shape)
+  where = np.ravel_multi_index([np.arange(u, l).reshape([-1 if j == i else 1 for j in range(len(ul))])
+                                for i, (u, l) in enumerate(zip(ul, lr))], array_shape)
+  return np.asarray(where * step + start).astype(dtype).reshape(tile.shape)
 
 
 def arange(start=None, stop=None, step=1, dtype=float, tile_hint=None):

@@ -12,8 +12,10 @@ C-ABI (sp_tiling_solve, csrc/tiling.hip -- the reference's tiling.cc is a CPytho
 written into the `tile_hint` of NdArrayExpr / ReduceExpr / Map2Expr / OuterProductExpr nodes exactly as
 AutomaticTiling.tile_expr does (optimize.py:922-935).
 
-Off by default (`optimize.FLAGS['opt_auto_tiling']`): the golden vectors of tests/golden were recorded with the
-reference's pass disabled (its solver cannot be built for Python 3).
+On by default, like the reference's (`optimize.FLAGS['opt_auto_tiling']`, optimize.py:1094).  The solver is pinned
+against the reference's own tiling.cc on the cost graphs its pass builds for the shared test programs
+(tests/golden/tiling_golden.json <- make_golden.py --tiling; tests/test_tiling.py): the same optimum as its exhaustive
+best_tiling on every graph, never worse than its default mincost heuristic.
 """
 import ctypes as C
 import math

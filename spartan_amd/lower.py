@@ -180,13 +180,26 @@ def _arange(args, kw, ex):
   from .array import extent as extent_mod
   src = args[0]
   dt = np.dtype(kw.get('dtype') or float)
-  pos = extent_mod.ravelled_pos(ex.ul, ex.array_shape)
   step, start = kw['step'], kw['start']
-  # np.arange(ex_start, ex_stop, step, dtype): element i = ex_start + i*step,
-  # computed in the (float64 / int64) type of the Python arguments, then cast
   iot = V('iota', dtype=np.int64, shape=src.shape)
-  v = apply('MUL', np.multiply, [iot, const(step)])
-  v = apply('ADD', np.add, [v, const(pos * step + start)])
+  if B.ravel_contiguous(ex.ul, ex.lr, ex.array_shape):
+    # np.arange(ex_start, ex_stop, step, dtype): element i = ex_start + i*step,
+    # computed in the (float64 / int64) type of the Python arguments, then cast
+    pos = extent_mod.ravelled_pos(ex.ul, ex.array_shape)
+    v = apply('MUL', np.multiply, [iot, const(step)])
+    v = apply('ADD', np.add, [v, const(pos * step + start)])
+    return cast(v, dt)
+  # a column / block tile (builtins._arange_mapper): position of every element in the whole array, from the
+  # tile-local index digit by digit
+  where, rest, gstride = None, iot, 1
+  for axis in reversed(range(len(ex.ul))):
+    n = ex.lr[axis] - ex.ul[axis]
+    digit = apply('MOD', np.mod, [rest, const(n)]) if axis else rest
+    rest = apply('FLOORDIV', np.floor_divide, [rest, const(n)]) if axis else rest
+    term = apply('MUL', np.multiply, [apply('ADD', np.add, [digit, const(int(ex.ul[axis]))]), const(int(gstride))])
+    where = term if where is None else apply('ADD', np.add, [where, term])
+    gstride *= ex.array_shape[axis]
+  v = apply('ADD', np.add, [apply('MUL', np.multiply, [where, const(step)]), const(start)])
   return cast(v, dt)
 
 

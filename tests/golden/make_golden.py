@@ -270,12 +270,14 @@ def import_reference():
       os.remove(os.path.join(rpc_dir, f))
   open(os.path.join(rpc_dir, '__init__.py'), 'w').write(FAKE_RPC)
   open(os.path.join(rpc_dir, 'zeromq.py'), 'w').write('')
-  # CPython-2 tiling extension: off the path
-  open(os.path.join(SCRATCH, 'spartan', 'expr', 'operator', 'tiling.py'), 'w').write(
-      'def mincost_tiling(*a, **k): raise NotImplementedError\n'
-      'def maxedge_tiling(*a, **k): raise NotImplementedError\n'
-      'def best_tiling(*a, **k): raise NotImplementedError\n'
-      'def worse_tiling(*a, **k): raise NotImplementedError\n')
+  # CPython-2 tiling extension: off the path, unless --tiling built it for this interpreter (build_tiling_ext)
+  opdir = os.path.join(SCRATCH, 'spartan', 'expr', 'operator')
+  if not [f for f in os.listdir(opdir) if f.startswith('tiling.') and f.endswith('.so')]:
+    open(os.path.join(opdir, 'tiling.py'), 'w').write(
+        'def mincost_tiling(*a, **k): raise NotImplementedError\n'
+        'def maxedge_tiling(*a, **k): raise NotImplementedError\n'
+        'def best_tiling(*a, **k): raise NotImplementedError\n'
+        'def worse_tiling(*a, **k): raise NotImplementedError\n')
   os.makedirs(os.path.join(SCRATCH, 'cfg'), exist_ok=True)
   sys.argv = [sys.argv[0]]
   import spartan  # noqa
@@ -542,6 +544,93 @@ def fusion_goldens(sp):
   out['sum_mul_add_nchildren'] = len(r.children)
   return out
 
+def build_tiling_ext():
+  """The reference's solver (spartan/expr/operator/tiling.cc: mincost / maxedge / best / worse tiling) as an
+  extension of THIS interpreter.  The source is compiled from where it lies, included by a three-line translation
+  unit written to the scratch directory that renames the two Python-2 C-API calls it makes (PyInt_AsLong,
+  Py_InitModule) and supplies a Python-3 module definition for its own method table -- the same kind of
+  transliteration lib2to3 does for the .py files.  Nothing of it is stored in the repository."""
+  import sysconfig
+  bdir = os.path.join(SCRATCH, 'tiling_build')
+  os.makedirs(bdir, exist_ok=True)
+  tu = os.path.join(bdir, 'tiling_py3.cc')
+  open(tu, 'w').write(
+      '#include <Python.h>\n'
+      '#define PyInt_AsLong PyLong_AsLong\n'
+      '#undef PyMODINIT_FUNC\n'
+      '#define PyMODINIT_FUNC static void\n'
+      '#define Py_InitModule(name, methods) ((PyObject*)(methods))\n'
+      '#include "%s"\n'
+      'static struct PyModuleDef sp_tiling_def = {PyModuleDef_HEAD_INIT, "tiling", NULL, -1, TilingMethods};\n'
+      'extern "C" PyObject* PyInit_tiling(void) { (void)inittiling; return PyModule_Create(&sp_tiling_def); }\n'
+      % os.path.join(REF, 'spartan', 'expr', 'operator', 'tiling.cc'))
+  opdir = os.path.join(SCRATCH, 'spartan', 'expr', 'operator')
+  out = os.path.join(opdir, 'tiling' + sysconfig.get_config_var('EXT_SUFFIX'))
+  subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', '-std=c++11', '-w', '-I' + sysconfig.get_paths()['include'],
+                         tu, '-o', out])
+  stub = os.path.join(opdir, 'tiling.py')
+  if os.path.exists(stub):
+    os.remove(stub)
+  return out
+
+
+def tiling_goldens(sp):
+  """Cost graphs the reference's AutomaticTiling pass builds for the shared test programs (tests/programs.py), as
+  it hands them to its solver -- (number of nodes, edges (u, v, cost), groups of four alternatives) -- with what
+  its `mincost` (the default, FLAGS.tiling_alg) and exhaustive `best` solvers choose, the cost of both choices
+  under the solver's own objective, and whether the program's value survived the pass.  (Run under Python 3 the
+  reference's pass changes the VALUE of most reductions -- sum(arange((11, 12, 13)), 0) comes back divided by the
+  number of row tiles it chose -- and cannot build the graph of some programs (None < int comparisons); such
+  records carry value_unchanged = false / skipped.  What is pinned from here is the SOLVER: graph in, choice out.)"""
+  sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+  from tests import programs
+  from spartan.config import FLAGS
+  from spartan.expr.operator import optimize
+  real = optimize.tiling
+  out = []
+  for workers in (4, 8):
+    for name, build, expected, tol in programs.programs():
+      rec = {'program': name, 'workers': workers}
+      for alg in ('mincost', 'best'):
+        start_cluster(sp, workers)
+        FLAGS.opt_auto_tiling = True
+        FLAGS.tiling_alg = alg
+        FLAGS.num_workers = workers
+        optimize._tiled_exprlist.clear() if hasattr(optimize, '_tiled_exprlist') else None
+        calls = []
+
+        class Spy(object):
+          def __getattr__(self, fn):
+            def call(t, edges, groups):
+              if alg == 'best' and len(groups) > 9:
+                raise OverflowError('4^%d assignments' % len(groups))
+              # (costs reach the solver as C longs: Python 2 truncated a float cost silently, Python 3's
+              #  PyArg_ParseTuple refuses it)
+              edges = [(int(u), int(v), int(c)) for u, v, c in edges]
+              res = getattr(real, fn)(t, edges, groups)
+              calls.append({'t': int(t), 'edges': [[int(u), int(v), int(c)] for u, v, c in edges],
+                            'groups': [[int(x) for x in g] for g in groups], 'chosen': sorted(int(x) for x in res)})
+              return res
+            return call
+        optimize.tiling = Spy()
+        try:
+          expr = build(sp)
+          if not hasattr(expr, 'optimized'):
+            raise TypeError('not an expression')
+          opt = expr.optimized()
+          val = np.asarray(opt.evaluate().glom())
+          want = expected()
+          ok = bool(np.allclose(val, want, rtol=1e-5, atol=1e-5, equal_nan=True)) and val.shape == want.shape
+          rec[alg] = {'calls': calls, 'value_unchanged': ok}
+        except Exception as e:   # the reference's pass cannot handle the program
+          rec[alg] = {'skipped': '%s: %s' % (type(e).__name__, str(e)[:160])}
+        finally:
+          optimize.tiling = real
+          FLAGS.opt_auto_tiling = False
+      out.append(rec)
+  return out
+
+
 def prepare_examples():
   """lib2to3 over the reference's example drivers that BASELINE benchmarks (k-means, SGD regressions)."""
   os.chdir(SCRATCH)
@@ -640,6 +729,31 @@ if __name__ == '__main__':
         if 'skipped' in m:
           print('   skipped', k, m['skipped'][:200])
     json.dump(allmeta, open(os.path.join(OUT, 'sparse_meta.json'), 'w'), indent=0, sort_keys=True)
+    sys.stdout.flush()
+    os._exit(0)
+  if '--tiling' in sys.argv:
+    if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
+      prepare_tree()
+      build_cython()
+    print('built', build_tiling_ext())
+    # optimize.py calls the Python-2 builtin reduce() (optimize.py:914; lib2to3's `reduce` fixer is off because it
+    # would also rewrite Spartan's own reduce)
+    opt_py = os.path.join(SCRATCH, 'spartan', 'expr', 'operator', 'optimize.py')
+    text = open(opt_py).read()
+    if 'from functools import reduce' not in text:
+      open(opt_py, 'w').write('from functools import reduce\n' + text)
+    install_stubs()
+    sp = import_reference()
+    res = tiling_goldens(sp)
+    json.dump(res, open(os.path.join(OUT, 'tiling_golden.json'), 'w'), indent=0, sort_keys=True)
+    n_graphs = sum(len(r[a].get('calls', [])) for r in res for a in ('mincost', 'best') if a in r)
+    print('programs x workers:', len(res), ' solver calls recorded:', n_graphs)
+    for r in res:
+      for a in ('mincost', 'best'):
+        if 'skipped' in r.get(a, {}):
+          print('   skipped', r['program'], r['workers'], a, r[a]['skipped'])
+        elif not r[a]['value_unchanged']:
+          print('   VALUE CHANGED', r['program'], r['workers'], a)
     sys.stdout.flush()
     os._exit(0)
   if '--examples' in sys.argv:

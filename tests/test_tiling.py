@@ -274,3 +274,101 @@ def test_shuffle_cost_hint_steers_the_target_tiling():
       assert pas.report['link_bytes'] == 0
   finally:
     sp.shutdown()
+
+
+# ---- the solver against the REFERENCE's solver (tests/golden/tiling_golden.json: make_golden.py --tiling) ----------
+def _reference_cost(t, edges, groups, chosen):
+  """tiling.cc:172-206 calc_cost: the objective of the reference's best_tiling -- edge costs along everything
+  reachable from node 0 through chosen nodes; negative (infeasible) when a chosen node has an edge into a group
+  but none to the group's chosen member, or into an ungrouped node that is not chosen."""
+  out, member = {}, {}
+  for u, v, c in edges:
+    out.setdefault(u, []).append((v, c))
+  for g in groups:
+    for n in g:
+      member[n] = g
+  chosen = set(chosen)
+  visited = set()
+
+  def walk(s):
+    if s == t or s in visited:
+      return 0
+    cost = 0
+    for v, c in out.get(s, ()):
+      if v in chosen:
+        below = walk(v)
+        if below < 0:
+          cost = below
+          break
+        cost += below + c
+      elif v in member:
+        pick = [m for m in member[v] if m in chosen][0]
+        if not any(w == pick for w, _ in out.get(s, ())):
+          cost = -1
+          break
+      else:
+        cost = -1
+        break
+    visited.add(s)
+    return cost
+  return walk(0)
+
+
+def _for_our_solver(t, edges, groups):
+  """The reference's graph in sp_tiling_solve's terms: a node with an edge into a group but none to one of its
+  members cannot be chosen together with that member (the reference prices the gap as infinite, tiling.cc:103)."""
+  have = {(u, v) for u, v, _ in edges}
+  member = {n: g for g in groups for n in g}
+  extra = []
+  for u in sorted({u for u, _, _ in edges}):
+    for g in groups:
+      if any((u, m) in have for m in g):
+        extra += [(u, m, 1e30) for m in g if (u, m) not in have]
+  return t + 1, [(u, v, float(c)) for u, v, c in edges] + extra, [list(g) for g in groups]
+
+
+@pytest.mark.host_logic
+def test_solver_matches_the_reference_solver_on_its_own_graphs():
+  """Every cost graph the reference's AutomaticTiling pass built for the shared test programs (4 and 8 workers),
+  as recorded on its way into the reference's tiling.cc: (i) the recorded choice of its exhaustive `best_tiling`
+  is an optimum of its own objective (pins the restatement of that objective used here); (ii) sp_tiling_solve finds
+  a choice of the SAME cost on every graph; (iii) it is never worse than the reference's default heuristic
+  (`mincost_tiling`), whose recorded choices are feasible but not always optimal."""
+  import json
+  import os
+  gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tiling_golden.json')))
+  graphs = 0
+  heuristic_worse = 0
+  for rec in gold:
+    by_alg = {}
+    for alg in ('best', 'mincost'):
+      for call in rec.get(alg, {}).get('calls', []):
+        by_alg.setdefault(json.dumps([call['t'], call['edges'], call['groups']]), {})[alg] = call
+    for key, calls in by_alg.items():
+      t, edges, groups = json.loads(key)
+      grouped = {n for g in groups for n in g}
+      fixed = set(range(t + 1)) - grouped
+
+      def cost_of(chosen_members):
+        return _reference_cost(t, edges, groups, fixed | set(chosen_members))
+      optimum = None
+      if len(groups) <= 7:
+        for pick in itertools.product(*groups):
+          c = cost_of(pick)
+          if c >= 0 and (optimum is None or c < optimum):
+            optimum = c
+      if 'best' in calls:
+        assert optimum is not None
+        assert cost_of([n for n in calls['best']['chosen'] if n in grouped]) == optimum, rec['program']
+      n_nodes, our_edges, our_groups = _for_our_solver(t, edges, groups)
+      choice, total = tiling.solve(n_nodes, our_edges, our_groups)
+      ours = cost_of([g[s] for g, s in zip(our_groups, choice)])
+      assert ours >= 0, (rec['program'], 'infeasible choice')
+      if optimum is not None:
+        assert ours == optimum, (rec['program'], rec['workers'], ours, optimum)
+      if 'mincost' in calls:
+        theirs = cost_of([n for n in calls['mincost']['chosen'] if n in grouped])
+        assert theirs < 0 or ours <= theirs, (rec['program'], ours, theirs)
+        heuristic_worse += (theirs < 0 or theirs > ours)
+      graphs += 1
+  assert graphs >= 100, graphs
