@@ -339,6 +339,7 @@ class UpdateBatch(object):
         data = mine[3]
         red = be.reducer_name(array.reducer_fn)
         array._touched = True
+        array.mark_written()
         data = be.astype(data, array.dtype)
         if plan[0] == 'reduce':
           buf = data if (mine[4] or data is not mine[3]) else be.copy(data)
@@ -361,6 +362,9 @@ class UpdateBatch(object):
         for tile_id, src_slice, dst_slice in array._update_splits(region):
           owner = ctx.rank_of(tile_id.worker)
           whole = _slices_shape(src_slice, region.shape) == tuple(region.shape)
+          tile_ex = array.blob_to_ex[tile_id]
+          if array.written is not None and _slices_shape(dst_slice, tile_ex.shape) == tuple(tile_ex.shape):
+            array.mark_written(tile_ex)
           if exec_rank == world.rank and owner == world.rank:
             piece = data if whole else data[src_slice]
             merges.append((tile_id, dst_slice, piece, owned and whole))
@@ -475,6 +479,11 @@ class DistArrayImpl(DistArray):
       Assert.isinstance(v, TileId)
       self.blob_to_ex[v] = k
     self.tiles = tiles
+    # which tiles are known to be written everywhere: None = all of them (arrays made of produced tiles); a set of
+    # tile extents for an array that was created empty (`create`) and is filled by updates.  Array METADATA: every
+    # rank sees every update's region, so every rank keeps the same set -- a fetch that crosses ranks uses it to
+    # decide, identically everywhere, whether written-cells masks have to travel with the data.
+    self.written = None
     self.id = next(DistArrayImpl._ids)
     self.ctx.register_array(self)
     pend = self.ctx.pending_destructors
@@ -491,6 +500,21 @@ class DistArrayImpl(DistArray):
 
   def extent_for_blob(self, id):
     return self.blob_to_ex[id]
+
+  def mark_written(self, tile_extent=None):
+    """The whole array (None) or one of its tiles has been written completely."""
+    if tile_extent is None or self.written is None:
+      self.written = None
+      return
+    self.written.add(tile_extent)
+    if len(self.written) == len(self.tiles):
+      self.written = None
+
+  def _maybe_unwritten(self, splits):
+    """Could a read of these tiles meet written AND never-written cells?  (An array nothing was written to yet is
+    all placeholders on every rank -- creation mappers read its tiles for their shape only -- and needs no masks.)"""
+    return (self.written is not None and getattr(self, '_touched', False) and
+            any(ex not in self.written for ex, _ in splits))
 
   def tile_shape(self):
     """distarray.py:276-281: most common tile shape."""
@@ -513,11 +537,53 @@ class DistArrayImpl(DistArray):
     """Tile.get(offset_slice) on the owning rank."""
     ctx = self.ctx
     t = ctx.tile(tile_id)
-    piece = t.get(ctx.backend, extent.offset_slice(ex, intersection))
-    if isinstance(piece, tile.MaskedBlob) and ctx.world.distributed:
-      raise NotImplementedError('a region with never-written cells (reference: MaskedArray) can be read inside one '
-                                'process only; across ranks only fully written regions travel')
-    return piece
+    return t.get(ctx.backend, extent.offset_slice(ex, intersection))
+
+  def _fetch_with_masks(self, region, splits, replicated, dst_rank, want):
+    """fetch of a region that may hold never-written cells, across ranks (distarray.py:355-365 + tile.pyx:100-113:
+    the reference ships whatever Tile.get returned, MaskedArrays included).  Every piece travels as a (values,
+    written-cells) pair -- only its owner knows which of the three forms it has (plain, masked, never written),
+    and the ranks must issue the same transfers -- and the destination gives back plain data if every cell turns out
+    to be written, the masked form otherwise."""
+    ctx = self.ctx
+    be, world = ctx.backend, ctx.world
+    pieces = []
+    for ex, inter in splits:
+      tid = self.tiles[ex]
+      owner = ctx.rank_of(tid.worker)
+      shape = _slices_shape(extent.offset_slice(ex, inter), ex.shape)
+      if owner == world.rank:
+        p = self._tile_piece(tid, ex, inter)
+        if isinstance(p, tile.EmptyBlob):
+          data, valid = be.zeros(shape, self.dtype), be.zeros(shape, np.uint8)
+        elif isinstance(p, tile.MaskedBlob):
+          data, valid = be.copy(p.data), be.copy(p.valid)
+        else:
+          data, valid = be.copy(p), be.zeros(shape, np.uint8)
+          be.assign_box(valid, tuple(slice(0, n) for n in shape), 1)
+      elif replicated or want:
+        data, valid = be.empty(shape, self.dtype), be.empty(shape, np.uint8)
+      else:
+        data = valid = None
+      if replicated:
+        world.broadcast(data, owner)
+        world.broadcast(valid, owner)
+      elif owner != dst_rank:
+        if owner == world.rank:
+          world.exchange([(dst_rank, data), (dst_rank, valid)], [])
+        elif want:
+          world.exchange([], [(owner, data), (owner, valid)])
+        else:
+          world.exchange([], [])
+      if want:
+        pieces.append(tile.MaskedBlob(data.reshape(inter.shape), valid.reshape(inter.shape)))
+    if not want:
+      return Absent(region.shape, self.dtype)
+    whole = pieces[0] if len(splits) == 1 else self._stitch(region, splits, pieces)
+    full = tuple(slice(0, n) for n in whole.shape)
+    if be.mask_all_set(whole.valid, full):
+      return whole.data
+    return whole
 
   def fetch(self, region):
     """distarray.py:294-367.  Inside a kernel the data is delivered to the rank
@@ -547,6 +613,9 @@ class DistArrayImpl(DistArray):
       if len(splits) == 1:
         return pieces[0]
       return self._stitch(region, splits, pieces)
+
+    if self._maybe_unwritten(splits):
+      return self._fetch_with_masks(region, splits, replicated, dst_rank, want)
 
     # distributed: owners serve, the destination(s) assemble
     if len(splits) == 1:
@@ -853,7 +922,10 @@ def create(shape, dtype=float, sharder=None, reducer=None, tile_hint=None, spars
   for (ex, _), worker in zip(cut, placement.place(cut, ctx)):
     t = tile.from_shape(ex.shape, dtype, ttype) if ctx.is_local_worker(worker) else None
     tiles[ex] = ctx.create(t, hint=worker)
-  return DistArrayImpl(shape=shape, dtype=dtype, tiles=tiles, reducer_fn=reducer, sparse=bool(sparse))
+  arr = DistArrayImpl(shape=shape, dtype=dtype, tiles=tiles, reducer_fn=reducer, sparse=bool(sparse))
+  if not sparse:
+    arr.written = set()        # nothing written yet (a sparse tile has no mask: tile.pyx:129-132)
+  return arr
 
 
 def from_table(extents):

@@ -54,6 +54,8 @@ class HipBackend(object):
     self._np_cache = collections.OrderedDict()   # bounded: iterative drivers pass a new array every step
     self.launches = 0
     self.gemms = 0            # gemm_into launches (the K-split tests count them)
+    self.host_round_trips = 0  # local functions that had to run on host copies of their tiles (call_local_fn)
+    self._warned_host = set()
     self.gemm_events = None   # set to [] to record (start, stop) HIP events around every GEMM launch
     self._rng_seed = (int(time.time() * 100000) + os.getpid()) & (2**63 - 1)   # srandom.py:23-35: from the clock
     self._rng_offset = 0
@@ -260,6 +262,60 @@ class HipBackend(object):
       return self._run_map(root, root.shape if root.kind != 'const' else ex.shape)
     except ProgramTooLarge:
       return self._evaluate_split(op, inputs, ex)
+    except lower.NotLowerable:
+      return self._evaluate_eager(op, inputs, ex)
+
+  # -- local functions that are not element-wise kernels ---------------------------------------------------------
+  def _evaluate_eager(self, op, inputs, ex):
+    """The reference runs ANY Python callable on its NumPy tiles (FnCallExpr.evaluate, local.py:115-127).  A tree
+    that cannot become one fused kernel is evaluated node by node, like there: every sub-tree that does lower still
+    runs as a kernel; a function that does not is called on the device tiles themselves -- they answer the ndarray
+    calls mappers make (devarray.py), each with its own kernel launch -- and, only if it asks for something they
+    cannot do, on host copies (device -> host, the call, host -> device: the slow path, counted in
+    `host_round_trips` and announced once per function).  Never the oracle, never silently."""
+    def ev(node):
+      if isinstance(node, LocalInput):
+        if node.idx == 'extent':
+          return ex.to_tuple()
+        v = inputs[node.idx]
+        return np.ndarray(v.shape, v.dtype) if isinstance(v, tile.EmptyBlob) else v      # (tile.pyx:72-79: uninitialised)
+      if not isinstance(node, FnCallExpr):
+        raise lower.NotLowerable('cannot evaluate local expression %r' % (node,))
+      if node is not op:
+        try:
+          root = lower.infer(node, inputs, ex, self.dtype_of)
+          return self._run_map(root, root.shape if root.kind != 'const' else ex.shape)
+        except (lower.NotLowerable, ProgramTooLarge):
+          pass
+      return self.call_local_fn(node.fn, [ev(d) for d in node.deps], dict(node.kw or {}), node.fn_name())
+    out = ev(op)
+    if not isinstance(out, D.DevArray):
+      out = self.from_numpy(np.broadcast_to(np.asarray(out), ex.shape))
+    elif tuple(out.shape) != tuple(ex.shape) and out.size == 1:
+      out = self.from_numpy(np.broadcast_to(out.numpy(), ex.shape))
+    return out
+
+  def call_local_fn(self, fn, args, kw, name='local function'):
+    """fn(*args) on device tiles; on host copies if the device tiles cannot answer it."""
+    import warnings
+    self.launches += 1
+    try:
+      res = fn(*args, **kw)
+      if res is NotImplemented:
+        raise TypeError('NotImplemented')
+      return res
+    except (TypeError, NotImplementedError, AttributeError, lower.NotLowerable, IndexError):
+      pass
+    self.host_round_trips += 1
+    if fn not in self._warned_host:
+      self._warned_host.add(fn)
+      warnings.warn('%s cannot run on device tiles: evaluated on host copies (device -> host -> device round trip '
+                    'per tile)' % name, RuntimeWarning, stacklevel=3)
+    host_args = [a.numpy() if isinstance(a, D.DevArray) else a for a in args]
+    res = fn(*host_args, **kw)
+    if isinstance(res, (np.ndarray, np.generic, bool, int, float)):
+      return self.from_numpy(np.asarray(res))
+    return res
 
   def _call_tile_fn(self, op, inputs, ex):
     """A local function that works on backend tensors itself (region_map, k-means bodies ...)."""
@@ -377,7 +433,16 @@ class HipBackend(object):
     """_reduce_mapper's local reduction (reduce.py:54) incl. the fused map prologue."""
     rule = lower.REDUCE_RULES.get(op.fn)
     if rule is None:
-      raise lower.NotLowerable('no GPU lowering registered for local reduce function %s' % op.fn_name())
+      # a user's local reduce function fn(extent, data, axis) (reduce.py:130-167): called on the device tile
+      # (DevArray.sum / max / ... are kernels), on a host copy if that is not enough
+      args = []
+      for d in op.deps:
+        if isinstance(d, LocalInput):
+          args.append(ex if d.idx == 'extent' else (axis if d.idx == 'axis' else inputs[d.idx]))
+        else:
+          args.append(self.evaluate_map(d, inputs, ex))
+      out = self.call_local_fn(op.fn, args, dict(op.kw or {}), op.fn_name())
+      return out if isinstance(out, D.DevArray) else self.from_numpy(np.asarray(out))
     data_deps = [d for d in op.deps if not (isinstance(d, LocalInput) and d.idx in ('extent', 'axis'))]
     if len(data_deps) != 1:
       raise lower.NotLowerable('reduce over %d operands' % len(data_deps))

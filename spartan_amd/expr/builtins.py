@@ -211,6 +211,7 @@ def from_numpy(npa, tile_hint=None):
       if ctx.is_local(tid):
         ctx.tile(tid).update(ctx.backend, None, ctx.backend.sparse_blob(csr[ex.to_slice()], csr.dtype), None)
     arr._touched = True
+    arr.mark_written()
     return base.Val(val=arr)
   npa = np.asarray(npa)
   arr = distarray.create(npa.shape, npa.dtype, tile_hint=tile_hint)
@@ -219,6 +220,7 @@ def from_numpy(npa, tile_hint=None):
       data = ctx.backend.from_numpy(np.ascontiguousarray(npa[ex.to_slice()]))
       ctx.tile(tid).update(ctx.backend, None, data.reshape(ex.shape), None, owned=True)
   arr._touched = True
+  arr.mark_written()
   return base.Val(val=arr)
 
 
@@ -235,6 +237,7 @@ def from_tile_fn(shape, dtype, fn, tile_hint=None, sparse=False):
         data = data.reshape(ex.shape)
       ctx.tile(tid).update(ctx.backend, None, data, None, owned=True)
   arr._touched = True
+  arr.mark_written()
   return base.Val(val=arr)
 
 

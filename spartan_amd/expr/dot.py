@@ -185,6 +185,7 @@ def ksplit_plan(arrays, axes, target, fn_kw):
   result = ksplit_pipeline(be, p, me, my_a, my_b, dt, world.exchange_async,
                            lambda out, part: world.reduce_scatter_async(out, part, 'ADD'), _chunk_columns(n))
   target._touched = True
+  target.mark_written()
   ctx.tile(tt[me][1]).update(be, None, result, target.reducer_fn, owned=True)
   return True
 

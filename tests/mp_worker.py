@@ -98,9 +98,36 @@ def run_auto_tiling(world):
       np.testing.assert_array_equal(got0.glom(), (a + 2).sum(0))
       return (after['collective_bytes'] + after['p2p_bytes']) - (before['collective_bytes'] + before['p2p_bytes'])
     finally:
-      opt.FLAGS['opt_auto_tiling'] = False
+      opt.FLAGS['opt_auto_tiling'] = True   # (the default)
   plain, tiled = moved(False), moved(True)
   assert tiled <= plain, (plain, tiled)
+  return 1
+
+
+def run_masked_fetch(world):
+  """A region with never-written cells read ACROSS ranks (distarray.py:355-365 + tile.pyx:100-113): glom gives the
+  reference's MaskedArray on every rank; once every cell is written the same read is plain again."""
+  from spartan_amd.array import extent
+  ctx = sp.get_context()
+  be = ctx.backend
+  a = sp.ndarray((8, 6), dtype=np.float32, tile_hint=(2, 6)).evaluate()        # 4 row tiles over the ranks
+  assert a.written == set()
+  row = np.arange(6, dtype=np.float32).reshape(1, 6)
+  a.update(extent.create((3, 0), (4, 6), (8, 6)), be.from_numpy(row))            # half of the second tile
+  a.update(extent.create((4, 0), (6, 6), (8, 6)), be.from_numpy(np.ones((2, 6), np.float32)))   # all of the third
+  assert a.written == {extent.create((4, 0), (6, 6), (8, 6))}
+  got = a.glom()
+  assert isinstance(got, np.ma.MaskedArray)
+  want_mask = np.ones((8, 6), bool)
+  want_mask[3:6] = False
+  np.testing.assert_array_equal(np.ma.getmaskarray(got), want_mask)
+  np.testing.assert_array_equal(got[3].filled(-1), row[0])
+  np.testing.assert_array_equal(got[4:6].filled(-1), np.ones((2, 6), np.float32))
+  part = a.fetch(extent.create((4, 1), (6, 3), (8, 6)))                          # inside the written tile: plain
+  np.testing.assert_array_equal(be.to_numpy(part), np.ones((2, 2), np.float32))
+  a.update(extent.create((0, 0), (8, 6), (8, 6)), be.from_numpy(np.full((8, 6), 2, np.float32)))
+  assert a.written is None
+  np.testing.assert_array_equal(a.glom(), np.full((8, 6), 2, np.float32))
   return 1
 
 
@@ -223,6 +250,7 @@ def main():
   n += run_sparse(workers)
   n += run_auto_tiling(world)
   n += run_sort(workers)
+  n += run_masked_fetch(world)
   if not use_hip:
     n += run_heartbeat(world)
   world.barrier()

@@ -40,14 +40,29 @@ def test_hip_backend_is_the_one_running(ctx):
   assert _hip.lib().sp_abi_version() == 1
 
 
-def test_user_callables_are_traced_or_refused_loudly(ctx):
-  """An element-wise Python function becomes part of the kernel (traced); anything else is refused --
-  there is no CPU fallback to run it on."""
-  from spartan_amd.lower import NotLowerable
-  np.testing.assert_array_equal(sp.map(sp.ones((8, 8)), fn=lambda x: x * 3 + 1).glom(), np.full((8, 8), 4, np.float32))
-  for bad in (lambda x: np.cumsum(x), lambda x: x[::2], lambda x: x.sum(), lambda x: x + 1 if x > 0 else x):
-    with pytest.raises(NotLowerable):
-      sp.map(sp.ones((8, 8)), fn=bad).force()
+def test_user_callables_traced_then_device_tiles_then_host(ctx):
+  """`map` takes any Python callable, as the reference does (FnCallExpr.evaluate, local.py:115-127): an element-wise
+  function becomes part of the fused kernel (traced); one that is not runs on the device tiles, which answer ndarray
+  calls with kernels; one that needs more than they offer runs on host copies -- announced, counted, never silent.
+  A function NumPy itself refuses is refused."""
+  import warnings
+  be = ctx.backend
+  ones = lambda: sp.ones((8, 8))    # noqa: E731
+  np.testing.assert_array_equal(sp.map(ones(), fn=lambda x: x * 3 + 1).glom(), np.full((8, 8), 4, np.float32))
+  assert be.host_round_trips == 0
+  # not element-wise, but within what device tiles do: reductions, views, NumPy functions
+  got = sp.map(sp.arange((8, 8), dtype=np.float32), fn=lambda x: x - x.sum(axis=1, keepdims=True) / 8 + np.maximum(x.T, 0).T * 0).glom()
+  ref = np.arange(64, dtype=np.float32).reshape(8, 8)
+  np.testing.assert_array_equal(got, ref - ref.sum(axis=1, keepdims=True) / 8)
+  assert be.host_round_trips == 0
+  # beyond them: host copies
+  with warnings.catch_warnings(record=True) as seen:
+    warnings.simplefilter('always')
+    got = sp.map(sp.arange((8, 8), dtype=np.float32), fn=lambda x: np.cumsum(x, axis=1)).glom()
+  np.testing.assert_array_equal(got, np.cumsum(ref, axis=1))
+  assert be.host_round_trips >= 1 and any('host copies' in str(w.message) for w in seen)
+  with pytest.raises(ValueError):
+    sp.map(ones(), fn=lambda x: x + 1 if x > 0 else x).force()      # ambiguous truth value: NumPy's own error
 
 
 def test_fused_map_is_one_launch_per_tile(ctx):

@@ -72,7 +72,7 @@ def ctx4():
   c = sp.initialize(backend=NumpyBackend(), num_workers=4)
   opt.FLAGS['opt_auto_tiling'] = True
   yield c
-  opt.FLAGS['opt_auto_tiling'] = False
+  opt.FLAGS['opt_auto_tiling'] = True   # (the default)
   sp.shutdown()
 
 
@@ -154,9 +154,9 @@ def test_modelled_bytes_never_exceed_the_default_tiling(ctx4):
   np.testing.assert_array_equal(e.optimized().glom(), np.full(64, 128, np.float32))
 
 
-def test_pass_is_off_by_default_and_a_no_op_on_one_worker():
+def test_pass_is_on_by_default_and_a_no_op_on_one_worker():
   from oracle.np_backend import NumpyBackend
-  assert opt.FLAGS['opt_auto_tiling'] is False
+  assert opt.FLAGS['opt_auto_tiling'] is True          # as in the reference (optimize.py:1094)
   sp.initialize(backend=NumpyBackend(), num_workers=1)
   try:
     e = sp.sum(sp.ones((8, 8)), axis=0)
@@ -188,7 +188,7 @@ def test_auto_tiled_programs_on_the_hip_backend():
     at.visit(e)
     assert at.report['link_bytes'] == 0
   finally:
-    opt.FLAGS['opt_auto_tiling'] = False
+    opt.FLAGS['opt_auto_tiling'] = True   # (the default)
     sp.shutdown()
 
 
@@ -215,7 +215,7 @@ def _random_programs(backend_factory, seeds, n_dots):
         except Exception as e:   # noqa: BLE001
           out['dot%d' % s] = type(e).__name__
     finally:
-      opt.FLAGS['opt_auto_tiling'] = False
+      opt.FLAGS['opt_auto_tiling'] = True   # (the default)
       sp.shutdown()
     return out
   off, on = run(False), run(True)
