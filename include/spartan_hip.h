@@ -209,6 +209,12 @@ int sp_jit_configure(int enabled, long long min_elems);
 void sp_jit_wait(void);
 int sp_jit_compiled_count(void);
 int sp_jit_compile_check(const char* header, const char* template_expr, const sp_program* prog);
+/* Seed mode: between sp_jit_seed_begin(dir) (NULL / "": <library directory>/jit_seed) and sp_jit_seed_end() every
+ * specialisation a launch asks for is compiled at once and WRITTEN to dir instead of being loaded -- no device is
+ * needed, the launches themselves fail.  A process that later finds no code object for a program in its own cache
+ * looks there before compiling.  sp_jit_seed_end returns the number of code objects written. */
+int sp_jit_seed_begin(const char* dir);
+int sp_jit_seed_end(void);
 
 /* sp_reduce: fused map -> reduce over ONE axis of the program's index space
  * viewed as [outer, axis_len, inner] (prod == prod(prog->shape)); axis=None is

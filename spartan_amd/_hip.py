@@ -94,6 +94,8 @@ def _declare(lib):
   lib.sp_jit_wait.argtypes = []
   lib.sp_jit_wait.restype = None
   lib.sp_jit_compile_check.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(sp_program)]
+  lib.sp_jit_seed_begin.argtypes = [C.c_char_p]
+  lib.sp_jit_seed_end.argtypes = []
   lib.sp_reduce_workspace_bytes.argtypes = [i32, i64, i64, i64]
   lib.sp_reduce_workspace_bytes.restype = sz
   lib.sp_reduce.argtypes = [C.POINTER(sp_program), pp, i32, i64, i64, i64, vp, i32, vp, sz, vp]
@@ -183,7 +185,7 @@ def _declare(lib):
 # every symbol include/spartan_hip.h declares
 EXPORTS = [
     'sp_abi_version', 'sp_last_error', 'sp_device_count', 'sp_device_info', 'sp_map_fused',
-    'sp_program_static_id', 'sp_jit_configure', 'sp_jit_wait', 'sp_jit_compiled_count', 'sp_jit_compile_check',
+    'sp_program_static_id', 'sp_jit_configure', 'sp_jit_wait', 'sp_jit_compiled_count', 'sp_jit_compile_check', 'sp_jit_seed_begin', 'sp_jit_seed_end',
     'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
     'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
     'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_random_fill', 'sp_cumscan',

@@ -125,9 +125,9 @@ std::string program_key(const char* header, const char* expr, const sp_program* 
 }
 
 // ---- code objects kept across processes (opt-in: SPARTAN_JIT_CACHE=<directory>) -------------------------------
-// One file per (library build, header, template expression, program): the lowered kernel name and the code object
-// hipRTC produced.  The build id is the size and modification time of this shared library and of the header the
-// kernel is instantiated from, so a rebuilt library never loads code compiled from older sources.
+// One file per (kernel sources, header, template expression, program): the lowered kernel name and the code object
+// hipRTC produced.  The sources' id is a hash of the CONTENTS of the headers the kernels are instantiated from, so
+// changed sources never load code compiled from older ones, and a copy of the tree elsewhere keeps its files valid.
 uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
   for (unsigned char c : s) {
     h ^= c;
@@ -162,13 +162,44 @@ std::string cache_dir() {
   return dir;
 }
 
-std::string stat_id(const std::string& path) {
-  struct stat st;
-  if (stat(path.c_str(), &st) != 0) return "?";
-  return std::to_string((long long)st.st_size) + "." + std::to_string((long long)st.st_mtime);
+// identity of a source file by CONTENT (a copy of the tree on another machine keeps it; size + mtime would not)
+std::string content_id(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return "?";
+  uint64_t h = 1469598103934665603ull;
+  char buf[65536];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0)
+    for (size_t i = 0; i < n; ++i) {
+      h ^= (unsigned char)buf[i];
+      h *= 1099511628211ull;
+    }
+  fclose(f);
+  char out[24];
+  snprintf(out, sizeof out, "%016llx", (unsigned long long)h);
+  return out;
 }
 
-std::string cache_path(const char* header, const char* expr, const sp_program* p);
+// the kernels are instantiated from these headers only
+const std::string& sources_id() {
+  static std::string id;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const std::string dir = source_dir();
+    for (const char* f : {"sp_common.hpp", "sp_interp.hpp", "map_kernel.hpp", "reduce_impl.hpp", "sp_jit.hip",
+                          "../../include/spartan_hip.h"})
+      id += content_id(dir + "/" + f) + "|";
+  });
+  return id;
+}
+
+// Code objects that travel with the tree: <csrc>/jit_seed, filled by __graft_entry__.build() (spartan_amd/jit_seed.py
+// drives the real launch path in seed mode on a machine without a GPU) for the fused programs the workloads are
+// known to force, so that on a fresh machine their FIRST launch already runs specialised.
+std::string seed_dir() { return source_dir() + "/jit_seed"; }
+std::string g_seed_target;     // non-empty: seed mode (sp_jit_seed_begin)
+
+std::string cache_file(const char* header, const char* expr, const sp_program* p);
 
 hipFunction_t cache_load(const std::string& path) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -225,12 +256,16 @@ hipFunction_t compile(const char* header, const char* expr, const sp_program* p,
   Rtc& r = rtc();
   if (!r.ok) return nullptr;
   const std::string dir = source_dir();
-  const std::string disk = load && !cache_dir().empty() ? cache_path(header, expr, p) : std::string();
-  if (!disk.empty()) {
-    hipFunction_t cached = cache_load(disk);
-    if (cached) {
-      if (verbose()) fprintf(stderr, "[spartan_hip jit] loaded %s from %s\n", expr, disk.c_str());
-      return cached;
+  const std::string file = cache_file(header, expr, p);
+  const std::string disk = load && !cache_dir().empty() ? cache_dir() + file : std::string();
+  if (load) {
+    for (const std::string& where : {disk, seed_dir() + file}) {
+      if (where.empty()) continue;
+      hipFunction_t cached = cache_load(where);
+      if (cached) {
+        if (verbose()) fprintf(stderr, "[spartan_hip jit] loaded %s from %s\n", expr, where.c_str());
+        return cached;
+      }
     }
   }
   std::string src = "#include \"" + std::string(header) + "\"\n" + program_struct(p);
@@ -267,6 +302,14 @@ hipFunction_t compile(const char* header, const char* expr, const sp_program* p,
     }
   } else if (!load) {
     if (compiled) *compiled = 1;
+    if (!g_seed_target.empty()) {        // seed mode: keep the code object, do not load it (there may be no device)
+      const char* lowered = nullptr;
+      size_t n = 0;
+      if (r.lowered(prog, expr, &lowered) == 0 && lowered && r.codeSize(prog, &n) == 0 && n) {
+        std::vector<char> code(n);
+        if (r.code(prog, code.data()) == 0) cache_store(g_seed_target + file, lowered, code);
+      }
+    }
   } else {
     const char* lowered = nullptr;
     size_t n = 0;
@@ -287,18 +330,17 @@ hipFunction_t compile(const char* header, const char* expr, const sp_program* p,
   return fn;
 }
 
-std::string cache_path(const char* header, const char* expr, const sp_program* p) {
-  const std::string dir = source_dir();
-  const std::string id = stat_id(dir + "/libspartan_hip.so") + "|" + stat_id(dir + "/" + header) + "|" + stat_id(dir + "/sp_interp.hpp");
+std::string cache_file(const char* header, const char* expr, const sp_program* p) {
   char name[64];
-  snprintf(name, sizeof(name), "/%016llx.spco", (unsigned long long)fnv1a(program_key(header, expr, p), fnv1a(id)));
-  return cache_dir() + name;
+  snprintf(name, sizeof(name), "/%016llx.spco", (unsigned long long)fnv1a(program_key(header, expr, p), fnv1a(sources_id())));
+  return name;
 }
 
 }  // namespace
 
 static int g_enabled = -1;
 static long long g_min_elems = -1;
+static int g_seeded = 0;
 
 int sp_jit_enabled() {
   if (g_enabled < 0) g_enabled = getenv("SP_NO_JIT") == nullptr ? 1 : 0;
@@ -357,6 +399,17 @@ static int sync_mode() {
 
 void* sp_jit_get(const char* header, const char* template_expr, const sp_program* p) {
   if (!sp_jit_enabled()) return nullptr;
+  if (!g_seed_target.empty()) {         // seed mode: compile now, store, and let the caller go on (to nowhere)
+    std::lock_guard<std::mutex> lock(g_mu);
+    const std::string key = "seed|" + program_key(header, template_expr, p);
+    if (g_cache.find(key) == g_cache.end()) {
+      int ok = 0;
+      compile(header, template_expr, p, false, &ok);
+      g_cache.emplace(key, nullptr);
+      g_seeded += ok;
+    }
+    return nullptr;
+  }
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return nullptr;
   const std::string key = std::to_string(device) + "|" + program_key(header, template_expr, p);
@@ -369,6 +422,20 @@ void* sp_jit_get(const char* header, const char* template_expr, const sp_program
     return (void*)fn;
   }
   if (g_stop) return nullptr;
+  {
+    // a code object already on disk (the user's cache, or the seeds that travel with the tree) is loaded right
+    // here -- milliseconds, not a compile -- so that such a program runs specialised from its FIRST launch
+    const std::string file = cache_file(header, template_expr, p);
+    for (const std::string& where : {cache_dir().empty() ? std::string() : cache_dir() + file, seed_dir() + file}) {
+      if (where.empty()) continue;
+      hipFunction_t fn = cache_load(where);
+      if (fn) {
+        if (verbose()) fprintf(stderr, "[spartan_hip jit] loaded %s from %s\n", template_expr, where.c_str());
+        g_cache.emplace(key, fn);
+        return (void*)fn;
+      }
+    }
+  }
   g_cache.emplace(key, nullptr);   // pending: callers use the interpreter meanwhile
   g_jobs.push_back(Job{key, header, template_expr, *p, device});
   ++g_inflight;
@@ -400,6 +467,25 @@ extern "C" int sp_jit_compile_check(const char* header, const char* template_exp
   int ok = 0;
   compile(header, template_expr, p, false, &ok);
   return ok;
+}
+
+// Seed mode (spartan_amd/jit_seed.py, called by __graft_entry__.build()): between begin and end every
+// specialisation a launch asks for is compiled at once and written to `dir` (default: <csrc>/jit_seed) instead of
+// being loaded -- no device is needed; the launches themselves fail and are ignored by the caller.  Returns the
+// number of code objects written.
+extern "C" int sp_jit_seed_begin(const char* dir) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_seed_target = dir && *dir ? std::string(dir) : seed_dir();
+  for (size_t i = 1; i <= g_seed_target.size(); ++i)
+    if (i == g_seed_target.size() || g_seed_target[i] == '/') mkdir(g_seed_target.substr(0, i).c_str(), 0755);
+  g_seeded = 0;
+  return rtc().ok ? 1 : 0;
+}
+
+extern "C" int sp_jit_seed_end(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_seed_target.clear();
+  return g_seeded;
 }
 
 // Test / diagnostics hook: number of run-time specialised kernels compiled so far.

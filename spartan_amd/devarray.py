@@ -711,11 +711,14 @@ _NP_FUNCTIONS = {
 
 
 # ------------------------------------------------------------------------------------------------ constructors
+_storage_cls = [Storage]       # (jit_seed.py swaps in HostStorage to drive the launch path on a machine without a GPU)
+
+
 def empty(shape, dtype, storage_cls=None):
   shape = _norm_shape((shape,)) if not isinstance(shape, (tuple, list)) else tuple(int(s) for s in shape)
   dtype = np.dtype(dtype)
   _hip.sp_dtype(dtype)          # raises for dtypes the tile kernels do not take
-  st = (storage_cls or Storage)(_prod(shape) * dtype.itemsize)
+  st = (storage_cls or _storage_cls[0])(_prod(shape) * dtype.itemsize)
   return DevArray(st, 0, shape, dense_strides(shape), dtype)
 
 
