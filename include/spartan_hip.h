@@ -421,17 +421,6 @@ int sp_spgemm_expand(int32_t dtype, int64_t m_a, int64_t nnz_a, const int64_t* d
                      const int32_t* d_indices_b, const void* d_vals_b, const int32_t* d_offs, int32_t* d_rows,
                      int32_t* d_cols, void* d_vals, void* stream);
 
-/* sp_sort_rows: np.sort / np.argsort along the LAST axis of a contiguous [rows, cols] tile -- the tile bodies of the
- * sort operators (spartan/expr/operator/sort.py:68-69 _sort_mapper, :137-138 _argsort_mapper, :24 / :65 the
- * flat np.sort of the sample sort; rows == 1 sorts a flattened tile).  Stable (np.argsort(kind='stable')), NaN
- * last, -0.0 == +0.0; d_out_vals (sorted values, may be NULL) and d_out_idx (int64 column of each sorted value,
- * may be NULL) are out of place.  dtype: SP_F32 | SP_F64 | SP_I32 | SP_I64.  Rows of <= 4096 32-bit elements are
- * sorted in LDS in one pass over HBM; anything else by an LSD radix sort of the whole tile (key bytes, then the
- * row of each position). */
-size_t sp_sort_rows_workspace_bytes(int32_t dtype, int64_t rows, int64_t cols);
-int sp_sort_rows(const void* d_in, int32_t dtype, int64_t rows, int64_t cols, void* d_out_vals, int64_t* d_out_idx,
-                 void* d_ws, size_t ws_bytes, void* stream);
-
 /* sp_tiling_solve: the solver behind the auto-tiling pass (reference: the CPython-2 extension
  * spartan/expr/operator/tiling.cc called from AutomaticTiling.calc_tiling, optimize.py:937-975).  HOST code, no GPU
  * work.  Nodes 0..n_nodes-1 are (expression, tiling) alternatives; group g owns the nodes

@@ -135,9 +135,6 @@ def _declare(lib):
   lib.sp_spgemm_count_workspace_bytes.restype = sz
   lib.sp_spgemm_count.argtypes = [i64, vp, vp, vp, vp, vp, sz, vp]
   lib.sp_spgemm_expand.argtypes = [i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-  lib.sp_sort_rows_workspace_bytes.argtypes = [i32, i64, i64]
-  lib.sp_sort_rows_workspace_bytes.restype = sz
-  lib.sp_sort_rows.argtypes = [vp, i32, i64, i64, vp, vp, vp, sz, vp]
   lib.sp_tiling_solve.argtypes = [i32, i64, vp, vp, vp, i32, vp, vp, vp, vp]
   lib.sp_gather_rows.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp]
   lib.sp_stream_copy.argtypes = [vp, vp, sz, vp]
@@ -190,7 +187,7 @@ EXPORTS = [
     'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
     'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_random_fill', 'sp_cumscan',
     'sp_coo_to_csr_workspace_bytes', 'sp_coo_to_csr', 'sp_csr_rows', 'sp_coo_box', 'sp_coo_reshape', 'sp_csr_spmm_workspace_bytes', 'sp_csr_spmv_plan_entries', 'sp_csr_spmv_plan', 'sp_csr_spmm', 'sp_csr_scatter',
-    'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_sort_rows_workspace_bytes', 'sp_sort_rows', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',
+    'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',
     'sp_blob_create', 'sp_blob_destroy', 'sp_blob_trim', 'sp_blob_info', 'sp_blob_stats', 'sp_blob_h2d', 'sp_blob_d2h',
     'sp_blob_slice_copy', 'sp_comm_available', 'sp_comm_version', 'sp_comm_unique_id', 'sp_comm_init',
@@ -216,6 +213,29 @@ def source_sha():
     with open(f, 'rb') as fh:
       h.update(fh.read())
   return h.hexdigest()[:16]
+
+
+# every symbol include/spartan_hip_extras.h declares (libspartan_hip_extras.so: `make extras`)
+EXTRAS_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), 'libspartan_hip_extras.so')
+EXPORTS_EXTRAS = ['sp_sort_rows_workspace_bytes', 'sp_sort_rows']
+_extras = None
+
+
+def extras():
+  """The library of kernels outside the tile path (sort); raises if it has not been built."""
+  global _extras
+  if _extras is None:
+    lib()
+    if not os.path.exists(EXTRAS_LIB_PATH):
+      raise HipLibraryMissing('%s not found: build it with `make -C spartan_amd/csrc extras` (or '
+                              '__graft_entry__.build())' % EXTRAS_LIB_PATH)
+    x = C.CDLL(EXTRAS_LIB_PATH)
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    x.sp_sort_rows_workspace_bytes.argtypes = [i32, i64, i64]
+    x.sp_sort_rows_workspace_bytes.restype = sz
+    x.sp_sort_rows.argtypes = [vp, i32, i64, i64, vp, vp, vp, sz, vp]
+    _extras = x
+  return _extras
 
 
 def lib():

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "sp_common.hpp"
+#include "../../include/spartan_hip_extras.h"
 #include "sp_radix.hpp"
 
 namespace {

@@ -219,7 +219,7 @@ def sort_rows(src, values=True, indices=False):
   vals = devarray.empty((rows, cols), np_dtype_of(src)) if values else None
   idx = devarray.empty((rows, cols), np.int64) if indices else None
   if rows and cols:
-    lib = _hip.lib()
+    lib = _hip.extras()        # (sort is outside the tile path: libspartan_hip_extras.so)
     dt = _hip.sp_dtype(np_dtype_of(src))
     ws = _ws.get(lib.sp_sort_rows_workspace_bytes(dt, rows, cols), src.device)
     check(lib.sp_sort_rows(C.c_void_p(src.data_ptr()), dt, rows, cols, C.c_void_p(vals.data_ptr() if values else 0),

@@ -16,8 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'spartan_hip.h')
 
 
-def _declared_functions():
-  text = open(HEADER).read()
+EXTRAS_HEADER = os.path.join(ROOT, 'include', 'spartan_hip_extras.h')
+
+
+def _declared_functions(header=HEADER):
+  text = open(header).read()
   text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
   return sorted(set(re.findall(r'\b(sp_[a-z0-9_]+)\s*\(', text)))
 
@@ -31,6 +34,12 @@ def test_library_loads_and_exports_every_declared_symbol():
   # and the Python binding declares the same set
   assert sorted(_hip.EXPORTS) == names
   assert _hip.lib().sp_abi_version() == 1
+  # the operators outside the tile path live in a library of their own (`make extras`), with a header of their own
+  extra = _declared_functions(EXTRAS_HEADER)
+  assert sorted(_hip.EXPORTS_EXTRAS) == extra and not set(extra) & set(names)
+  xraw = C.CDLL(_hip.EXTRAS_LIB_PATH)
+  assert not [n for n in extra if not hasattr(xraw, n)]
+  assert not [n for n in extra if hasattr(raw, n)], 'the default library must not carry the extras'
 
 
 def test_struct_layout_matches_header():
