@@ -1,22 +1,20 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/drv
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/drv/km -o km -- python $R/tools/driver_profile.py kmeans > $R/gpurun_out/drv/kmeans_prof.txt 2>&1
-cd $R
+cd $GRAFT_REPO_ROOT
 python - <<'PY'
-import glob, sys
-sys.path.insert(0, 'tools')
-import roofline
-rows = roofline.load_trace(glob.glob('gpurun_out/drv/km/**/*kernel_trace.csv', recursive=True))
-# the last 20 fit() iterations = the last 20 launches of the first-pass assign kernel; take everything after the 21st-from-last
-idx = [i for i, r in enumerate(rows) if r['name'].startswith('sp_nearest_nt_kernel<true, false, false>')]
-start = idx[-20]
-sel = rows[start:]
-tot = {}
-for r in sel:
-  t = tot.setdefault(r['name'], [0, 0.0]); t[0] += 1; t[1] += (r['end'] - r['start']) / 1e3
-span = (sel[-1]['end'] - sel[0]['start']) / 1e3
-print('20 iterations: span %.1f us per iteration, kernel sum %.1f us per iteration' % (span / 20, sum(v[1] for v in tot.values()) / 20))
-for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1]):
-  print('%9.1f us/iter %5.1f calls/iter  %s' % (v[1] / 20, v[0] / 20.0, k[:100]))
+import cProfile, pstats, io, sys, os
+import numpy as np
+sys.path.insert(0, '.')
+import bench
+import spartan_amd as sp
+from spartan_amd import devarray as D
+from spartan_amd.examples import lreg
+ctx = sp.initialize('hip')
+N, Dm = 125000, 4096
+X = sp.Val(val=sp.from_tile_fn((N, Dm), np.float32, lambda ex: bench.device_uniform(ex, 0.0, 1.0, 11)).force())
+y = sp.Val(val=sp.from_tile_fn((N, 1), np.float32, lambda ex: bench.device_uniform(ex, 0.0, 1.0, 12)).force())
+w = np.random.RandomState(0).rand(Dm, 1).astype(np.float32)
+w = lreg.fit(X, y, 5, alpha=1e-10, w=w)
+pr = cProfile.Profile(); pr.enable()
+w = lreg.fit(X, y, 200, alpha=1e-10, w=w)
+pr.disable()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(40); print(s.getvalue()[:7000])
 PY
