@@ -1,10 +1,10 @@
 """Random (n, k, d, dtypes, scales, row strides, duplicate centres, points on centres) for sp_nearest_center against
 argmin(cdist) in fp64.  Usage: python tools/fuzz_kmeans.py [seed]"""
-import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-import numpy as np, torch
+import sys, time
+import numpy as np
 from scipy.spatial.distance import cdist
-from spartan_amd import kernels, _hip
+from _dev import D, kernels
+from spartan_amd import _hip
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 t0 = time.time()
@@ -20,18 +20,17 @@ for it in range(400):
   m = min(n, k)
   if rng.rand() < 0.5: x[:m] = c[:m].astype(xdt)
   pad = int(rng.choice([0, 0, 4, 7]))
-  xt = torch.from_numpy(np.ascontiguousarray(np.pad(x, ((0, 0), (0, pad))))).cuda()[:, :d]
-  ct = torch.from_numpy(c).cuda()
-  lab = torch.empty(n, dtype=torch.int64, device='cuda')
+  xt = D.from_numpy(np.pad(x, ((0, 0), (0, pad))))[:, :d]
+  ct = D.from_numpy(c)
+  lab = D.empty((n,), np.int64)
   tier = int(rng.choice([_hip.NEAREST_AUTO, _hip.NEAREST_FUSED]))
   try:
     kernels.nearest_center(xt, ct, lab, tier)
   except Exception as e:
     if xdt == np.float64 and tier == _hip.NEAREST_FUSED: continue   # fused tier is fp32 points only
     print('EXC', n, k, d, xdt, cdt, tier, e); bad += 1; continue
-  torch.cuda.synchronize()
   want = np.argmin(cdist(x.astype(np.float64), c.astype(np.float64)), axis=1)
-  got = lab.cpu().numpy()
+  got = lab.numpy()
   if not np.array_equal(got, want):
     # ties in exact fp64 arithmetic may differ from cdist's rounding: accept only equal distances
     dd = cdist(x.astype(np.float64), c.astype(np.float64))

@@ -36,5 +36,4 @@ done
 if [ "$MAXN" -gt 1 ]; then
   for cols in 2048 8192 16384; do run "$MAXN" "chunk$cols" SPARTAN_DOT_CHUNK_COLS=$cols; done
   for ch in 8 16 32; do run "$MAXN" "channels$ch" NCCL_MAX_NCHANNELS=$ch; done
-  run "$MAXN" torch_nccl SPARTAN_DIST_BACKEND=nccl
 fi

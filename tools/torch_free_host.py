@@ -12,8 +12,9 @@ import types
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the package's __init__ imports torch (the repository's own host uses it for memory and streams): expose the
-# two torch-free modules -- the ctypes binding and the program builder -- without running it
+# Only the ctypes binding and the program builder are used -- not the repository's host framework (which, since round
+# 3, is itself such a ctypes + NumPy host: spartan_amd/devarray.py, kernels.py): this file stays the minimal binding
+# INTEGRATION.md describes, so the package's __init__ is not run.
 pkg = types.ModuleType('spartan_amd')
 pkg.__path__ = [os.path.join(ROOT, 'spartan_amd')]
 sys.modules['spartan_amd'] = pkg
