@@ -394,7 +394,12 @@ __global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_kernel(
     // load latency distribution (one slow 1 KiB piece of 24 holds the whole workgroup at its barrier) is covered.
     // The wait is counted -- the AP + BP pieces of the newest tile stay in flight across the barrier -- which
     // needs the raw barrier: __syncthreads() carries a fence that drains the LDS-DMA queue.
-    static_assert(AP + BP == 6, "vmcnt immediate below");
+    static_assert(AP + BP == 6 || AP + BP == 4, "vmcnt immediates below");
+#define SP_WAIT_BUT_NEWEST()                                                   \
+  do {                                                                         \
+    if constexpr (AP + BP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
+  } while (0)
     auto body = [&](int t) {
 #pragma unroll
       for (int c = 0; c < BK / 8; ++c) {
@@ -406,14 +411,14 @@ __global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_kernel(
     };
     SP_GLDS_TILE(0, 0);
     if (nt > 1) SP_GLDS_TILE(1, 1);
-    if (nt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (nt > 1) SP_WAIT_BUT_NEWEST();
     else SP_GLDS_LANDED();
     __builtin_amdgcn_s_barrier();
     int t = 0;
     for (; t + 2 < nt; ++t) {
       SP_GLDS_TILE(t + 2, (t + 2) % 3);
       body(t);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile t+1 has landed; tile t+2 may still be on its way
+      SP_WAIT_BUT_NEWEST();      // tile t+1 has landed; tile t+2 may still be on its way
       __builtin_amdgcn_s_barrier();
     }
     for (; t < nt; ++t) {
@@ -552,6 +557,279 @@ static int sp_gemm_glds_launch(const float* A, int64_t lda, const float* B, int6
   return 0;
 }
 
+// ---- balanced ("stream-K") variant of the direct-to-LDS kernel ------------------------------------------
+// Data-parallel tiling leaves CUs idle whenever the tile count is not a multiple of the resident workgroups
+// (3072^3: 288 tiles of 256 x 128 on 512 slots; 5000^3: 800 on 512 -> the last round is 56 % full).  Here the unit
+// of work is one k-tile of one output tile: the tiles * (K / 16) units are laid out tile-major and cut into
+// gridDim.x EQUAL contiguous ranges, one per workgroup, W = all resident slots.  A range is a run of segments
+// (tile, k-tile interval): a segment that spans its tile's whole contraction stores to C like the data-parallel
+// kernel; a partial one (at most the first and the last of a range) stores its accumulators to one of the
+// workgroup's two workspace slots, and sp_gemm_sk_fixup_kernel adds the partials of every cut tile in k order.
+// No atomics, no inter-workgroup waits: the result does not depend on scheduling.  (Summation order differs from
+// the data-parallel kernel's single k-ordered chain only at the cuts.)
+template <typename Cfg, int BM, int BN, int WM, int WN, int WGS>
+__global__ __launch_bounds__(Cfg::THREADS, WGS) void sp_gemm_glds_sk_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+    int64_t ldc, int M, int N, int K, int accumulate, int tiles_n, unsigned tiles, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN;
+  constexpr int AP = Cfg::A_PIECES, BP = Cfg::B_PIECES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const unsigned KT = (unsigned)(K / BK);
+  const int ktail = K - (int)KT * BK;
+
+  // logical workgroup index: the workgroups of one XCD (blockIdx & 7) take a contiguous run of tiles / ranges, so
+  // that the tiles an XCD's L2 sees are neighbours (the same remap as sp_gemm_tile_of_block)
+  const unsigned W = gridDim.x;
+  unsigned lw;
+  {
+    const unsigned xcd = blockIdx.x & 7, local = blockIdx.x >> 3, q8 = W >> 3, r8 = W & 7;
+    lw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  }
+  const unsigned rounds = tiles / W, tiles_full = rounds * W;
+  const unsigned total = (tiles - tiles_full) * KT;
+  const unsigned q = total / W, r = total % W;
+  const unsigned first = lw * q + (lw < r ? lw : r);
+  const unsigned end = first + q + (lw < r ? 1u : 0u);
+
+  const unsigned sA_w = SP_LDS_ADDR(smem) + wid * (AP * 1024);
+  const unsigned sB_w = SP_LDS_ADDR(smem) + Cfg::A_FLOATS * 4 + wid * (BP * 1024);
+  const int sw = (l31 >> 2) & 3;
+  const int a_row_off = (wm * Cfg::WTM + l31) * BK;
+  int a_chunk[BK / 8];
+#pragma unroll
+  for (int c = 0; c < BK / 8; ++c) a_chunk[c] = a_row_off + 4 * ((lh + 2 * c) ^ sw);
+  const int b_frag_off = (4 * lh) * BN + wn * Cfg::WTN + l31;
+
+  unsigned round = 0;
+  for (unsigned it = first;;) {
+    unsigned tile, k0, len;
+    const bool whole_rounds = round < rounds;
+    if (whole_rounds) {            // the data-parallel rounds: whole tiles, every workgroup at the same k
+      tile = round * W + lw;
+      k0 = 0;
+      len = KT;
+      ++round;
+    } else if (it < end) {         // this workgroup's range of the remainder
+      tile = it / KT;
+      k0 = it - tile * KT;
+      tile += tiles_full;
+      len = KT - k0;
+      if (len > end - it) len = end - it;
+    } else {
+      break;
+    }
+    const int tm = (int)(tile / (unsigned)tiles_n), tn = (int)(tile - (unsigned)tm * (unsigned)tiles_n);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const char* __restrict__ Ablk = (const char*)(A + (int64_t)m0 * lda) + (int64_t)k0 * (BK * 4);
+    const char* __restrict__ Bblk = (const char*)(B + n0) + (int64_t)k0 * BK * ldb * 4;
+    unsigned a_off[AP], b_off[BP];
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      const int slot = (wid * AP + j) * 64 + lane;
+      int row = slot >> 2;
+      const int qq = (slot & 3) ^ ((row >> 2) & 3);
+      if (m0 + row > M - 1) row = M - 1 - m0;
+      a_off[j] = (unsigned)(row * (int)lda + qq * 4) * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      const int slot = (wid * BP + j) * 64 + lane;
+      const int krow = slot / (BN / 4);
+      int gc = (slot % (BN / 4)) * 4;
+      if (n0 + gc > N - 4) gc = N - 4 - n0;
+      b_off[j] = (unsigned)(krow * (int)ldb + gc) * 4u;
+    }
+#define SP_SK_TILE(kt, stage)                                                          \
+  do {                                                                                 \
+    const char* Ak_ = Ablk + (int64_t)(kt) * (BK * 4);                                 \
+    const char* Bk_ = Bblk + (int64_t)((kt) * BK) * ldb * 4;                           \
+    const unsigned dA_ = sA_w + (stage) * (Cfg::STAGE_FLOATS * 4);                     \
+    const unsigned dB_ = sB_w + (stage) * (Cfg::STAGE_FLOATS * 4);                     \
+    _Pragma("unroll") for (int j = 0; j < AP; ++j) SP_GLDS_S(Ak_, a_off[j], dA_ + j * 1024); \
+    _Pragma("unroll") for (int j = 0; j < BP; ++j) SP_GLDS_S(Bk_, b_off[j], dB_ + j * 1024); \
+  } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    SP_SK_TILE(0, 0);
+    SP_GLDS_LANDED();
+    __syncthreads();
+    const int nt = (int)len;
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) SP_SK_TILE(t + 1, (t + 1) & 1);
+      const float* sA_ = smem + (t & 1) * Cfg::STAGE_FLOATS;
+      const float* sB_ = sA_ + Cfg::A_FLOATS;
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        f32x4 af[TM];
+        float bf[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(sA_ + a_chunk[c] + i * 32 * BK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) bf[j][s4] = sB_[b_frag_off + (c * 8 + s4) * BN + j * 32];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s4], bf[j][s4], acc[i][j], 0, 0, 0);
+      }
+      SP_GLDS_LANDED();
+      __syncthreads();    // tile t+1 has landed and every wave is done reading stage t (and, after the last
+                          // k-tile, with both stages: the next segment may overwrite them)
+    }
+#undef SP_SK_TILE
+    if (ktail > 0 && k0 + len == KT) {
+      // K % 16 != 0: the segment that ends its tile's contraction also takes the partial k-tile, through registers
+      // into stage 0, zero beyond K in both operands (as in sp_gemm_glds_kernel)
+      const int kbase = (int)KT * BK;
+      for (int e = tid; e < BM * BK; e += Cfg::THREADS) {
+        const int rr = e / BK, kk = e % BK;
+        int row = m0 + rr;
+        if (row > M - 1) row = M - 1;
+        const float v = kk < ktail ? A[(int64_t)row * lda + kbase + kk] : 0.f;
+        smem[rr * BK + (((kk >> 2) ^ ((rr >> 2) & 3)) << 2) + (kk & 3)] = v;
+      }
+      for (int e = tid; e < BK * BN; e += Cfg::THREADS) {
+        const int kk = e / BN, c = e % BN;
+        int col = n0 + c;
+        if (col > N - 1) col = N - 1;
+        smem[Cfg::A_FLOATS + kk * BN + c] = kk < ktail ? B[(int64_t)(kbase + kk) * ldb + col] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        f32x4 af[TM];
+        float bf[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(smem + a_chunk[c] + i * 32 * BK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) bf[j][s4] = smem[Cfg::A_FLOATS + b_frag_off + (c * 8 + s4) * BN + j * 32];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s4], bf[j][s4], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+
+    // (the per-lane bases below pass through an empty asm so that the 128 row / column offsets of the two stores
+    // are computed here and not hoisted out of the segment loop, where they would live across the k-loop and spill)
+    if (len == KT) {
+      int64_t row_b = m0 + wm * Cfg::WTM + 4 * lh;
+      int col_b = n0 + wn * Cfg::WTN + l31;
+      asm volatile("" : "+v"(row_b), "+v"(col_b));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = col_b + j * 32;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t row = row_b + i * 32 + (e & 3) + 8 * (e >> 2);
+            if (row < M && col < N) {
+              float* p = C + row * ldc + col;
+              float v = acc[i][j][e];
+              if (accumulate) v += *p;
+              *p = v;
+            }
+          }
+        }
+      }
+    } else {
+      // the whole BM x BN tile image, row-major, into this workgroup's slot 0 (its first segment) or 1 (its last)
+      int off_b = (wm * Cfg::WTM + 4 * lh) * BN + wn * Cfg::WTN + l31;
+      asm volatile("" : "+v"(off_b));
+      float* __restrict__ P = part + (size_t)(2 * lw + (it != first ? 1u : 0u)) * (BM * BN) + off_b;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) P[(i * 32 + (e & 3) + 8 * (e >> 2)) * BN + j * 32] = acc[i][j][e];
+        }
+      }
+    }
+    if (!whole_rounds) it += len;
+  }
+}
+
+// Adds the partial images of every cut tile in k order (= workgroup order) and stores the tile; tiles one workgroup
+// computed whole were stored by the main kernel.  One workgroup per 4096 tile elements.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void sp_gemm_sk_fixup_kernel(const float* __restrict__ part, float* __restrict__ C,
+                                                               int64_t ldc, int M, int N, int accumulate, int tiles_n,
+                                                               unsigned KT, unsigned tiles_full, unsigned total, unsigned W) {
+  constexpr unsigned CHUNKS = BM * BN / 4096;
+  const unsigned rt = blockIdx.x / CHUNKS, chunk = blockIdx.x % CHUNKS;     // rt: index among the remainder tiles
+  const unsigned q = total / W, r = total % W;
+  const unsigned lo = rt * KT, hi = lo + KT - 1;
+  const unsigned edge = r * (q + 1);
+  const unsigned w0 = lo < edge ? lo / (q + 1) : r + (lo - edge) / q;
+  const unsigned w1 = hi < edge ? hi / (q + 1) : r + (hi - edge) / q;
+  if (w0 == w1) return;
+  const unsigned tile = tiles_full + rt;
+  const int tm = (int)(tile / (unsigned)tiles_n), tn = (int)(tile - (unsigned)tm * (unsigned)tiles_n);
+  const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned e = chunk * 4096 + (i * 256 + threadIdx.x) * 4;
+    const int row = m0 + (int)(e / BN), col = n0 + (int)(e % BN);
+    if (row >= M || col >= N) continue;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned w = w0; w <= w1; ++w) {
+      const unsigned start = w * q + (w < r ? w : r);
+      const f32x4 p = *(const f32x4*)(part + (size_t)(2 * w + (start >= lo ? 0u : 1u)) * (BM * BN) + e);
+      v = (w == w0) ? p : v + p;
+    }
+    f32x4* dst = (f32x4*)(C + (int64_t)row * ldc + col);
+    if (accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int WGS>
+static int sp_gemm_sk_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                             int64_t N, int64_t K, int acc, float* part, hipStream_t st) {
+  using Cfg = GldsCfg<BM, BN, WM, WN>;
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+  const unsigned W = SP_CUS * WGS;
+  const unsigned tiles_full = (unsigned)(tiles / W) * W, rem = (unsigned)tiles - tiles_full;
+  auto k = sp_gemm_glds_sk_kernel<Cfg, BM, BN, WM, WN, WGS>;
+  constexpr int lds_bytes = 2 * Cfg::STAGE_FLOATS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SP_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(W), dim3(Cfg::THREADS), lds_bytes, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, acc,
+                     (int)tiles_n, (unsigned)tiles, part);
+  if (rem)
+    hipLaunchKernelGGL((sp_gemm_sk_fixup_kernel<BM, BN>), dim3(rem * (BM * BN / 4096)), dim3(256), 0, st,
+                       (const float*)part, C, ldc, (int)M, (int)N, acc, (int)tiles_n, (unsigned)(K / 16), tiles_full,
+                       rem * (unsigned)(K / 16), W);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename Cfg, typename KernelT>
 static int sp_gemm_go(KernelT k, bool* attr_set, unsigned nblk, unsigned splits, hipStream_t st, const float* A,
                       int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int acc,
@@ -598,6 +876,27 @@ static int sp_gemm_variant() {
   return v;
 }
 
+// The data-parallel macro-tile whose workgroups keep the CUs busy for the shorter time, and that time in units of one
+// 128 x 128 x K tile at the full CU rate.  A CU runs ceil(tiles / CUs) workgroups of its share; a 128 x 128
+// workgroup does half the work of a 256 x 128 one at ~0.93 of its rate (4 resident workgroups per CU instead of 2),
+// a 64 x 128 one a quarter at ~0.90, and a workgroup alone on its CU loses ~10 % (nothing covers its barriers).
+// Measured (tools/gemm_shapes.py, TFLOP/s, 256x128 / 128x128 / 64x128): 8192^3 150 / 146 / -, 4096^3 147 / 146 / -,
+// 3072^3 84 / 109 / -, 1536x8192x4096 111 / 140 / -, 2304^3 - / 91 / 117, 2048^3 67 / 128 / 134,
+// 2048x2048x16384 69 / 134 / 140.  All fetch their k-tiles straight into LDS when the operands allow it.
+static int sp_gemm_dp_choice(int64_t M, int64_t N, double* cost) {
+  const int64_t tb = ((M + 255) / 256) * ((N + 127) / 128), ts = ((M + 127) / 128) * ((N + 127) / 128);
+  const int64_t tt = ((M + 63) / 64) * ((N + 127) / 128);
+  const int64_t cb = (tb + SP_CUS - 1) / SP_CUS, cs = (ts + SP_CUS - 1) / SP_CUS, ct = (tt + SP_CUS - 1) / SP_CUS;
+  const double cost_b = 2.0 * (double)cb * (cb == 1 ? 1.14 : 1.0);
+  const double cost_s = (double)cs / 0.93 * (cs == 1 ? 1.08 : 1.0);
+  const double cost_t = 0.5 * (double)ct / 0.90 * (ct == 1 ? 1.08 : 1.0);
+  int v = 6;
+  *cost = cost_b;
+  if (cost_s < *cost) v = 7, *cost = cost_s;
+  if (cost_t < *cost) v = 8, *cost = cost_t;
+  return v;
+}
+
 extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int64_t ldb, float* d_C,
                            int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t accumulate, void* stream) {
   if (M < 0 || N < 0 || K < 0) SP_FAIL("sp_gemm_f32: negative dimension");
@@ -617,17 +916,8 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
                     ((((uintptr_t)d_A) | ((uintptr_t)d_B)) & 15) == 0;
   int v = sp_gemm_variant();
   if (v < 0) {
-    // default: the macro-tile whose workgroups keep the CUs busy for the shorter time.  A CU runs ceil(tiles / CUs)
-    // workgroups of its share; a 128 x 128 workgroup does half the work of a 256 x 128 one at ~0.93 of its rate
-    // (4 resident workgroups per CU instead of 2), and a workgroup alone on its CU loses ~10 % (nothing covers its
-    // barriers).  Measured (tools/gemm_shapes.py, TFLOP/s, 256x128 vs 128x128): 8192^3 150 / 146, 4096^3 145 / 140,
-    // 3072^3 84 / 109, 1536x8192x4096 111 / 140, 4096x2048x4096 136 / 140, 2048^3 67 / 126.
-    // Both fetch their k-tiles straight into LDS when the operands allow it (cases 6 / 7 check).
-    const int64_t tb = ((M + 255) / 256) * ((N + 127) / 128), ts = ((M + 127) / 128) * ((N + 127) / 128);
-    const int64_t cb = (tb + SP_CUS - 1) / SP_CUS, cs = (ts + SP_CUS - 1) / SP_CUS;
-    const double cost_b = 2.0 * (double)cb * (cb == 1 ? 1.14 : 1.0);
-    const double cost_s = (double)cs / 0.93 * (cs == 1 ? 1.08 : 1.0);
-    v = cost_b <= cost_s ? 6 : 7;
+    double cost;
+    v = sp_gemm_dp_choice(M, N, &cost);
   }
   switch (v) {
     case 0: return sp_gemm_launch<256, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
@@ -653,6 +943,10 @@ extern "C" int sp_gemm_f32(const float* d_A, int64_t lda, const float* d_B, int6
     SP_ABL_CASE(8) SP_ABL_CASE(10)
 #undef SP_ABL_CASE
 #endif
+    case 8:   // 64 x 128: twice the workgroups where 128 x 128 would leave one (or three) per CU
+      if (fast && K >= 16 && (int64_t)128 * lda < (1LL << 30) && (int64_t)16 * ldb < (1LL << 30))
+        return sp_gemm_glds_launch<64, 128, 2, 2, 0, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
+      return sp_gemm_launch<128, 128, 16, 2, 2>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, fast, st);
     case 7:
       if (fast && K >= 16 && (int64_t)128 * lda < (1LL << 30) && (int64_t)16 * ldb < (1LL << 30))
         return sp_gemm_glds_launch<128, 128, 2, 2, 0, 4>(d_A, lda, d_B, ldb, d_C, ldc, M, N, K, accumulate, st);
@@ -703,10 +997,46 @@ static SplitPlan sp_split_plan(int64_t M, int64_t N, int64_t K, int bk) {
 int sp_dgemm_split_launch(const double* A, int64_t lda, const double* B, int64_t ldb, double* part, int64_t M,
                           int64_t N, int64_t K, int splits, int klen, hipStream_t st);
 
+// When the balanced kernel (sp_gemm_glds_sk_kernel, 256 x 128 tiles on 512 workgroups) is expected to beat both
+// data-parallel tilings, in the units of sp_gemm_f32's cost model (one 128 x 128 x K tile at the full CU rate):
+// every CU gets tiles / 256 of the work (+3 % for the segment prologues) plus the fix-up pass, which moves about
+// 1.5 partial images per workgroup out and back in.  SP_GEMM_SK=0 / 1 turns it off / forces it (where it applies).
+static const size_t SP_SK_WS_BYTES = (size_t)2 * SP_CUS * 2 * 256 * 128 * 4;
+// measured (tools/gemm_shapes.py, SP_GEMM_SK=0 / 1 over 2304^3 .. 10000^3): the whole rounds run at the data-parallel
+// kernel's rate, the balanced remainder at ~0.93 of peak (ranges start at different k: less sharing in L2), and
+// the last partial stores + the fix-up pass cost ~33 us
+#define SP_SK_EFF_ROUNDS 0.95
+#define SP_SK_EFF_REM 0.93
+#define SP_SK_FIXED_S 33e-6
+static bool sp_sk_plan(int64_t M, int64_t N, int64_t K) {
+  static int mode = -2;
+  if (mode == -2) {
+    const char* e = getenv("SP_GEMM_SK");
+    mode = e ? atoi(e) : -1;
+  }
+  if (mode == 0 || sp_gemm_variant() >= 0) return false;
+  if (K < 256 || N % 4 != 0 || N < 4) return false;
+  const int64_t tb = ((M + 255) / 256) * ((N + 127) / 128);
+  if (tb >= 2147483647LL) return false;
+  const int64_t W = 2 * SP_CUS, rem = tb % W;
+  if (rem * (K / 16) < W * 8) return false;      // nothing (or next to nothing) left over to balance
+  if (mode > 0) return true;
+  double dp_cost;
+  sp_gemm_dp_choice(M, N, &dp_cost);
+  const double unit_s = 128.0 * 128.0 * (double)K * 2.0 / (157.3e12 * 0.95 / SP_CUS);
+  const double dp_s = dp_cost * unit_s;
+  const double tile_flop = 256.0 * 128.0 * (double)K * 2.0;
+  const double sk_s = (double)(tb - rem) * tile_flop / (157.3e12 * SP_SK_EFF_ROUNDS) +
+                      (double)rem * tile_flop / (157.3e12 * SP_SK_EFF_REM) + SP_SK_FIXED_S;
+  return sk_s < 0.97 * dp_s;
+}
+
 extern "C" size_t sp_gemm_workspace_bytes(int32_t dtype, int64_t M, int64_t N, int64_t K) {
   if (M < 1 || N < 1 || (dtype != SP_F32 && dtype != SP_F64)) return 0;
   const SplitPlan pl = sp_split_plan(M, N, K, dtype == SP_F32 ? 16 : 8);
-  return pl.splits > 1 ? (size_t)pl.splits * M * N * (dtype == SP_F32 ? 4 : 8) + 256 : 0;
+  if (pl.splits > 1) return (size_t)pl.splits * M * N * (dtype == SP_F32 ? 4 : 8) + 256;
+  if (dtype == SP_F32 && sp_sk_plan(M, N, K)) return SP_SK_WS_BYTES + 256;
+  return 0;
 }
 
 extern "C" int sp_gemm_f64(const double*, int64_t, const double*, int64_t, double*, int64_t, int64_t, int64_t, int64_t,
@@ -718,6 +1048,14 @@ extern "C" int sp_gemm_ws(int32_t dtype, const void* d_A, int64_t lda, const voi
   if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_gemm_ws: dtype must be f32 or f64");
   const SplitPlan pl = (M > 0 && N > 0) ? sp_split_plan(M, N, K, dtype == SP_F32 ? 16 : 8) : SplitPlan{1, 0};
   const size_t need = sp_gemm_workspace_bytes(dtype, M, N, K);
+  if (pl.splits <= 1 && need && d_ws && ws_bytes >= need && dtype == SP_F32 && d_A && d_B && d_C && lda >= K &&
+      ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
+      ((((uintptr_t)d_A) | ((uintptr_t)d_B) | ((uintptr_t)d_C)) & 15) == 0 && (int64_t)256 * lda < (1LL << 30) &&
+      (int64_t)16 * ldb < (1LL << 30) && M <= 2147483647LL && N <= 2147483647LL) {
+    float* part = (float*)(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
+    return sp_gemm_sk_launch<256, 128, 2, 2, 2>((const float*)d_A, lda, (const float*)d_B, ldb, (float*)d_C, ldc, M, N, K,
+                                                accumulate, part, (hipStream_t)stream);
+  }
   if (pl.splits <= 1 || !d_ws || ws_bytes < need) {
     return dtype == SP_F32 ? sp_gemm_f32((const float*)d_A, lda, (const float*)d_B, ldb, (float*)d_C, ldc, M, N, K, accumulate, stream)
                            : sp_gemm_f64((const double*)d_A, lda, (const double*)d_B, ldb, (double*)d_C, ldc, M, N, K, accumulate, stream);

@@ -748,6 +748,70 @@ def test_gemm_split_k(mnk, dt):
   np.testing.assert_allclose(outs[0], ref, rtol=0, atol=(2e-4 if dt == np.float32 else 1e-10) * np.sqrt(K))
 
 
+@pytest.mark.parametrize('mnk', [(2304, 2304, 2304),      # 162 tiles of 256 x 128: all remainder, every tile cut
+                                 (3000, 3000, 3000),      # ragged edges and a K tail on the cut tiles
+                                 (4608, 4608, 1024),      # one whole round of 512 tiles + 136 balanced
+                                 (3584, 3584, 1000),      # short contraction with a tail
+                                 (2300, 2304, 2056)])
+def test_gemm_balanced_remainder(mnk):
+  """Tile counts that do not fill the resident workgroups: the balanced kernel (whole data-parallel rounds, then the
+  k-tiles of the remaining tiles cut into equal ranges; partial images added in k order by the fix-up pass).  Exact
+  for integer-valued operands, `accumulate` honoured, identical bits on every run, within the plain kernel's
+  tolerance otherwise, padded leading dimensions."""
+  M, N, K = mnk
+  assert _hip.lib().sp_gemm_workspace_bytes(_hip.SP_F32, M, N, K) > 0
+  a = RNG.randint(-3, 4, size=(M, K)).astype(np.float32)
+  b = RNG.randint(-3, 4, size=(K, N)).astype(np.float32)
+  want = a.astype(np.float64).dot(b.astype(np.float64)).astype(np.float32)
+  c = D.full((M, N), 5, np.float32)
+  kernels.gemm_f32(dev(a), dev(b), c)
+  np.testing.assert_array_equal(host(c), want)
+  kernels.gemm_f32(dev(a), dev(b), c, accumulate=True)
+  np.testing.assert_array_equal(host(c), 2 * want)
+  big_a, big_b, big_c = D.zeros((M, K + 8), np.float32), D.zeros((K, N + 4), np.float32), D.zeros((M, N + 12), np.float32)
+  big_a[:, :K] = dev(a)
+  big_b[:, :N] = dev(b)
+  kernels.gemm_f32(big_a[:, :K], big_b[:, :N], big_c[:, :N])
+  np.testing.assert_array_equal(host(big_c)[:, :N], want)
+  assert not host(big_c)[:, N:].any()
+  x = (RNG.rand(M, K) - 0.5).astype(np.float32)
+  y = (RNG.rand(K, N) - 0.5).astype(np.float32)
+  outs = []
+  for _ in range(2):
+    kernels.gemm_f32(dev(x), dev(y), c)
+    outs.append(host(c).copy())
+  np.testing.assert_array_equal(outs[0], outs[1])
+  ref = x.astype(np.float64).dot(y.astype(np.float64))
+  assert np.abs(outs[0] - ref).max() <= 2 * K * np.finfo(np.float32).eps * 0.25
+
+
+def test_gemm_balanced_forced_fuzz():
+  """SP_GEMM_SK=1 sends every shape the balanced kernel applies to through it (the default only where its cost model
+  predicts a win): tools/fuzz_gemm.py's random shapes / paddings / accumulate flags, all exact."""
+  import os
+  import subprocess
+  import sys
+  tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+  out = subprocess.run([sys.executable, os.path.join(tools, 'fuzz_gemm.py'), '11'], cwd=tools, capture_output=True, text=True,
+                       env=dict(os.environ, SP_GEMM_SK='1'), timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  assert ' 0 bad' in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize('mnk', [(2048, 2048, 256), (2048, 1920, 1000), (40, 4096, 4096), (2000, 2048, 72)])
+def test_gemm_64x128_tiles(mnk):
+  """Shapes whose 128 x 128 tiling leaves one workgroup per CU (or fewer): the 64 x 128 macro-tile."""
+  M, N, K = mnk
+  a = RNG.randint(-3, 4, size=(M, K)).astype(np.float32)
+  b = RNG.randint(-3, 4, size=(K, N)).astype(np.float32)
+  c = D.full((M, N), 5, np.float32)
+  kernels.gemm_f32(dev(a), dev(b), c)
+  want = a.astype(np.float64).dot(b.astype(np.float64)).astype(np.float32)
+  np.testing.assert_array_equal(host(c), want)
+  kernels.gemm_f32(dev(a), dev(b), c, accumulate=True)
+  np.testing.assert_array_equal(host(c), 2 * want)
+
+
 def test_jit_code_objects_persist_across_processes(tmp_path):
   """SPARTAN_JIT_CACHE=<dir>: the first process compiles a run-time specialised kernel and leaves its code object in
   the directory, the second loads it instead of compiling (same result; `loaded ... from` in the verbose log)."""
