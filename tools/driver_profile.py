@@ -47,5 +47,5 @@ fn()
 D.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
-print(s.getvalue()[:9000])
+pstats.Stats(pr, stream=s).sort_stats(os.environ.get('SORT', 'cumulative')).print_stats(int(os.environ.get('ROWS', '45')))
+print(s.getvalue()[:20000])
