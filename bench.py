@@ -274,7 +274,13 @@ def sparse_section(ctx):
   x = D.from_numpy(rng.rand(n, 1).astype(np.float32))
   y = D.empty((n, 1), np.float32)
   alg = W.nnz * 8 + n * 16
-  ms = event_time(lambda: S.spmm(W, x, out=y), 20, warmup=3, section=('CSR x vector 900k', 'sp_csr_spmv_planned_kernel', float(alg), 'bytes', 'hbm'))
+  D.synchronize()
+  t0 = time.perf_counter()
+  blocked = S.spmv_block_plan(W) is not False      # the column-blocked copy of the entries: once per tile
+  D.synchronize()
+  out['spmv_block_plan_ms'] = round((time.perf_counter() - t0) * 1e3, 3)
+  out['spmv_kernel'] = 'sp_bsp_spmv_kernel' if blocked else 'sp_csr_spmv_planned_kernel'
+  ms = event_time(lambda: S.spmm(W, x, out=y), 20, warmup=3, section=('CSR x vector 900k', out['spmv_kernel'], float(alg), 'bytes', 'hbm'))
   out.update({'nnz': W.nnz, 'spmv_ms': round(ms, 4), 'spmv_GBps': round(alg / ms / 1e6, 1),
               'spmv_bytes_per_launch': alg})
   # the driver program: 5 iterations of p = dot(wts, p) through the expression API on the same tile

@@ -403,6 +403,21 @@ int sp_csr_spmv_plan(int64_t m, int64_t nnz, const int64_t* d_indptr, int64_t* d
 int sp_csr_spmm(int32_t dtype, int64_t m, int64_t k, int64_t n, int64_t nnz, const int64_t* d_indptr,
                 const int32_t* d_indices, const void* d_vals, const void* d_b, int64_t ldb, void* d_c, int64_t ldc,
                 int32_t accumulate, const int64_t* d_plan, void* d_ws, size_t ws_bytes, void* stream);
+/* Column-blocked y (+)= A . x for an fp32 CSR tile whose rows are sorted by column (csrc/spmv_blocked.hip): the same
+ * product as sp_csr_spmm with n == 1, bit for bit, for matrices whose row blocks draw most of their columns from a
+ * few 44 KB slices of x (PageRank's site-local link structure, spartan/examples/pagerank.py): those slices are
+ * staged through LDS instead of being gathered line by line from the L2.
+ *   sp_csr_spmv_blockplan_bytes: size of the plan buffer, or 0 when no blocked plan exists for the shape (not fp32,
+ *     fewer than 262 144 entries or 4 096 rows, more than 64 entries per row on average): keep sp_csr_spmm.
+ *   sp_csr_spmv_blockplan: builds the plan (a re-ordered copy of the entries, 10 bytes each, plus a segment table
+ *     per row block) -- once per tile.  The first int64 of the plan is 1 afterwards, or 0 if some row is not sorted
+ *     by column or holds a column outside [0, k): then the plan must not be used.
+ *   sp_csr_spmv_blocked: the product; d_x contiguous and 16-byte aligned, y with stride ldy. */
+size_t sp_csr_spmv_blockplan_bytes(int32_t dtype, int64_t m, int64_t k, int64_t nnz);
+int sp_csr_spmv_blockplan(int32_t dtype, int64_t m, int64_t k, int64_t nnz, const int64_t* d_indptr,
+                          const int32_t* d_indices, const void* d_vals, void* d_plan, size_t plan_bytes, void* stream);
+int sp_csr_spmv_blocked(int32_t dtype, int64_t m, int64_t k, int64_t nnz, const int64_t* d_indptr, const void* d_plan,
+                        const void* d_x, void* d_y, int64_t ldy, int32_t accumulate, void* stream);
 /* sp_csr_scatter: write a CSR tile into the box of a dense tile whose upper-left corner is (row0, col0).
  * mode 0: assign, 1: add, 2: sparse_to_dense_update with REDUCE_ADD (sparse.pyx:21-38; tile.pyx:229-233):
  * where mask == 0 assign and set the mask, else add. */

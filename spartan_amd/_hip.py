@@ -129,6 +129,10 @@ def _declare(lib):
   lib.sp_csr_spmv_plan_entries.argtypes = [i64]
   lib.sp_csr_spmv_plan_entries.restype = i64
   lib.sp_csr_spmv_plan.argtypes = [i64, i64, vp, vp, vp]
+  lib.sp_csr_spmv_blockplan_bytes.argtypes = [i32, i64, i64, i64]
+  lib.sp_csr_spmv_blockplan_bytes.restype = sz
+  lib.sp_csr_spmv_blockplan.argtypes = [i32, i64, i64, i64, vp, vp, vp, vp, sz, vp]
+  lib.sp_csr_spmv_blocked.argtypes = [i32, i64, i64, i64, vp, vp, vp, vp, i64, i32, vp]
   lib.sp_csr_spmm.argtypes = [i32, i64, i64, i64, i64, vp, vp, vp, vp, i64, vp, i64, i32, vp, vp, sz, vp]
   lib.sp_csr_scatter.argtypes = [i32, i64, i64, vp, vp, vp, vp, i64, i64, i64, vp, i64, i32, vp]
   lib.sp_spgemm_count_workspace_bytes.argtypes = [i64]
@@ -186,7 +190,7 @@ EXPORTS = [
     'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
     'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
     'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_random_fill', 'sp_cumscan',
-    'sp_coo_to_csr_workspace_bytes', 'sp_coo_to_csr', 'sp_csr_rows', 'sp_coo_box', 'sp_coo_reshape', 'sp_csr_spmm_workspace_bytes', 'sp_csr_spmv_plan_entries', 'sp_csr_spmv_plan', 'sp_csr_spmm', 'sp_csr_scatter',
+    'sp_coo_to_csr_workspace_bytes', 'sp_coo_to_csr', 'sp_csr_rows', 'sp_coo_box', 'sp_coo_reshape', 'sp_csr_spmm_workspace_bytes', 'sp_csr_spmv_plan_entries', 'sp_csr_spmv_plan', 'sp_csr_spmv_blockplan_bytes', 'sp_csr_spmv_blockplan', 'sp_csr_spmv_blocked', 'sp_csr_spmm', 'sp_csr_scatter',
     'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',
     'sp_blob_create', 'sp_blob_destroy', 'sp_blob_trim', 'sp_blob_info', 'sp_blob_stats', 'sp_blob_h2d', 'sp_blob_d2h',

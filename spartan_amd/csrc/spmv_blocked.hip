@@ -1,0 +1,452 @@
+// Column-blocked sparse matrix x vector (fp32): y = A . x with the slices of x a row block uses heavily staged
+// through LDS.  Replaces `tile.dot(vector)` of a sparse tile on the multiply of the reference's PageRank
+// (spartan/examples/pagerank.py via array/sparse.pyx:103-158 / scipy csr_matvec) where sp_csr_spmv_planned_kernel
+// (sparse.hip) is bound by the random gather of x: every gathered 4-byte value moves a 128-byte line from the L2 to
+// the CU (9 M lines per launch on 900 000 pages x 10 links, 29 of its 52 us).
+//
+// The plan (built once per tile, tiles are immutable) cuts the rows into blocks of RB and the columns into slices
+// of S = 11 264 values (44 KB).  Per row block, a slice holding >= BSP_STAGE_MIN of the block's entries becomes a
+// STAGED segment; each run of the other slices between them becomes one DIRECT segment.  The block's entries are
+// stably partitioned by segment -- inside a segment they keep CSR order, (row, column) ascending -- and stored as
+// (value, key): key = row-in-block << 16 | column-in-slice for a staged segment, the column itself (and the row
+// in a 16-bit side array) for a direct one.
+//
+// The kernel gives a row block to one workgroup: for each segment in column order it copies the slice of x into
+// LDS (one coalesced read; the slice for the NEXT segment is already on its way in registers), multiplies the
+// segment's entries against it 2048 at a time (entries prefetched two chunks ahead, the direct segments' gathers
+// of x one chunk ahead), leaves the products in LDS, and the first lane of every run of equal rows adds the run
+// to the row's accumulator, also in LDS.  A row's entries therefore meet its accumulator in ascending column
+// order, segment after segment -- CSR storage order for a tile with sorted rows, which is the order csr_matvec
+// adds in: results are bit-identical to sp_csr_spmv_planned_kernel's.  Rows that are not sorted by column (the
+// builder checks) make the plan invalid and the caller keeps the stream kernel.
+#include "sp_common.hpp"
+
+namespace {
+
+constexpr int BSP_THREADS = 512;
+constexpr int BSP_CAP = 2048;             // products per pass: 4 per lane
+constexpr int BSP_PER = BSP_CAP / BSP_THREADS;
+constexpr int BSP_MAXSEG = 64;
+constexpr int BSP_XS_BYTES = 44 * 1024;
+constexpr int BSP_S = BSP_XS_BYTES / 4;   // columns per slice
+constexpr int BSP_MAX_RB = 2048;          // rows per block (16-bit row ids; 8 KB of accumulators)
+constexpr int BSP_STAGE_MIN = 768;        // a 44 KB slice is 352 lines: staging pays from about twice as many gathers
+constexpr int BSP_MAX_SLICES = 16384;
+constexpr int BSP_XV_N = (BSP_XS_BYTES / 16 + BSP_THREADS - 1) / BSP_THREADS;
+
+struct BspSeg {
+  int32_t col_lo, width, count, staged;
+};
+
+inline size_t sp_al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct BspLayout {
+  int64_t rb, nb, ns;
+  size_t nseg_off, seg_off, key_off, drow_off, val_off, total;
+};
+
+bool bsp_layout(int32_t dtype, int64_t m, int64_t k, int64_t nnz, BspLayout* L) {
+  if (dtype != SP_F32 || nnz < (1 << 18) || m < 4096 || k < 1 || nnz > 64 * m || k > 2147483647LL) return false;
+  const int64_t ns = (k + BSP_S - 1) / BSP_S;
+  if (ns > BSP_MAX_SLICES) return false;
+  int64_t j = 1;
+  while ((m + 2 * SP_CUS * j - 1) / (2 * SP_CUS * j) > BSP_MAX_RB) ++j;
+  L->rb = (m + 2 * SP_CUS * j - 1) / (2 * SP_CUS * j);
+  L->nb = (m + L->rb - 1) / L->rb;
+  L->ns = ns;
+  size_t at = 256;                                   // header: 8 x int64
+  L->nseg_off = at;
+  at += sp_al256((size_t)L->nb * 4);
+  L->seg_off = at;
+  at += sp_al256((size_t)L->nb * BSP_MAXSEG * sizeof(BspSeg));
+  L->key_off = at;
+  at += sp_al256((size_t)nnz * 4);
+  L->drow_off = at;
+  at += sp_al256((size_t)nnz * 2);
+  L->val_off = at;
+  at += sp_al256((size_t)nnz * 4);
+  L->total = at;
+  return true;
+}
+
+__device__ __forceinline__ int bsp_block_exscan(int v, int* wsum) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  __syncthreads();                 // wsum may still be read from the previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int i = 0; i < w; ++i) woff += wsum[i];
+  return woff + inc - v;
+}
+
+// One workgroup per row block: slice histogram, segment table, sortedness check, stable partition.
+__global__ __launch_bounds__(BSP_THREADS) void sp_bsp_build_kernel(const int64_t* __restrict__ indptr,
+                                                                   const int32_t* __restrict__ indices,
+                                                                   const float* __restrict__ vals, int64_t m, int64_t k,
+                                                                   int rb, int ns, long long* __restrict__ header,
+                                                                   int* __restrict__ nseg_out, BspSeg* __restrict__ segtab,
+                                                                   uint32_t* __restrict__ keys, uint16_t* __restrict__ drow,
+                                                                   float* __restrict__ pvals) {
+  extern __shared__ int slice_cnt[];      // [ns]
+  __shared__ BspSeg segs[BSP_MAXSEG];
+  __shared__ int seg_off[BSP_MAXSEG + 1];
+  __shared__ int wsum[BSP_THREADS / 64];
+  __shared__ int s_nseg, s_bad;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t r0 = (int64_t)b * rb, r1 = r0 + rb < m ? r0 + rb : m;
+  const int64_t e0 = indptr[r0], e1 = indptr[r1];
+  for (int i = tid; i < ns; i += BSP_THREADS) slice_cnt[i] = 0;
+  if (tid == 0) s_bad = (e1 - e0 > 2147483647LL) ? 1 : 0;
+  __syncthreads();
+  for (int64_t e = e0 + tid; e < e1; e += BSP_THREADS) {
+    const int c = indices[e];
+    if (c < 0 || c >= k) s_bad = 1;
+    else atomicAdd(&slice_cnt[c / BSP_S], 1);
+  }
+  // my rows (contiguous, so that thread order is row order) -- and are their columns ascending?
+  const int q = (rb + BSP_THREADS - 1) / BSP_THREADS;      // <= 4
+  const int64_t ra = r0 + (int64_t)tid * q;
+  int64_t cursor[BSP_MAX_RB / BSP_THREADS], rend[BSP_MAX_RB / BSP_THREADS];
+#pragma unroll
+  for (int j = 0; j < BSP_MAX_RB / BSP_THREADS; ++j) {
+    const int64_t r = ra + j;
+    if (j < q && r < r1) {
+      cursor[j] = indptr[r];
+      rend[j] = indptr[r + 1];
+      for (int64_t e = cursor[j] + 1; e < rend[j]; ++e)
+        if (indices[e] < indices[e - 1]) s_bad = 1;
+    } else {
+      cursor[j] = rend[j] = 0;
+    }
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) {
+      atomicExch((unsigned long long*)&header[0], 0ull);
+      nseg_out[b] = 0;
+    }
+    return;
+  }
+  if (tid == 0) {
+    int n = 0, open = -1;
+    bool overflow = false;
+    for (int s = 0; s < ns && !overflow; ++s) {
+      const int c = slice_cnt[s];
+      if (c >= BSP_STAGE_MIN) {
+        if (open >= 0) {
+          segs[open].width = s * BSP_S - segs[open].col_lo;
+          open = -1;
+        }
+        if (n == BSP_MAXSEG) overflow = true;
+        else {
+          const int64_t w = k - (int64_t)s * BSP_S;
+          segs[n++] = BspSeg{s * BSP_S, (int)(w < BSP_S ? w : BSP_S), c, 1};
+        }
+      } else if (c > 0 || open >= 0) {
+        if (open < 0) {
+          if (n == BSP_MAXSEG) overflow = true;
+          else {
+            open = n;
+            segs[n++] = BspSeg{s * BSP_S, 0, 0, 0};
+          }
+        }
+        if (!overflow) segs[open].count += c;
+      }
+    }
+    if (open >= 0 && !overflow) segs[open].width = (int)(k - segs[open].col_lo);
+    if (overflow) {       // too many segments: everything through the direct path (always valid)
+      n = 1;
+      segs[0] = BspSeg{0, (int)k, (int)(e1 - e0), 0};
+    }
+    int run = 0;
+    for (int s = 0; s < n; ++s) {
+      seg_off[s] = run;
+      run += segs[s].count;
+    }
+    seg_off[n] = run;
+    s_nseg = n;
+    nseg_out[b] = n;
+  }
+  __syncthreads();
+  const int n = s_nseg;
+  for (int i = tid; i < n * 4; i += BSP_THREADS) ((int*)(segtab + (int64_t)b * BSP_MAXSEG))[i] = ((const int*)segs)[i];
+  for (int s = 0; s < n; ++s) {
+    const int64_t col_hi = (int64_t)segs[s].col_lo + segs[s].width;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < BSP_MAX_RB / BSP_THREADS; ++j)
+      for (int64_t e = cursor[j]; e < rend[j] && indices[e] < col_hi; ++e) ++cnt;
+    int64_t pos = e0 + seg_off[s] + bsp_block_exscan(cnt, wsum);
+    const bool staged = segs[s].staged != 0;
+    const int col_lo = segs[s].col_lo;
+#pragma unroll
+    for (int j = 0; j < BSP_MAX_RB / BSP_THREADS; ++j) {
+      int64_t e = cursor[j];
+      const uint32_t rl = (uint32_t)(tid * q + j);
+      for (; e < rend[j] && indices[e] < col_hi; ++e, ++pos) {
+        const int c = indices[e];
+        keys[pos] = staged ? (rl << 16) | (uint32_t)(c - col_lo) : (uint32_t)c;
+        drow[pos] = (uint16_t)rl;
+        pvals[pos] = vals[e];
+      }
+      cursor[j] = e;
+    }
+  }
+}
+
+typedef float bsp_f4 __attribute__((ext_vector_type(4)));
+
+// (second launch bound: waves per SIMD -- two workgroups of 8 waves per CU)
+__global__ __launch_bounds__(BSP_THREADS, 4) void sp_bsp_spmv_kernel(const int64_t* __restrict__ indptr, int64_t m, int rb,
+                                                                     int nb, const int* __restrict__ nseg,
+                                                                     const BspSeg* __restrict__ segtab,
+                                                                     const uint32_t* __restrict__ keys,
+                                                                     const uint16_t* __restrict__ drow,
+                                                                     const float* __restrict__ pvals,
+                                                                     const float* __restrict__ x, float* __restrict__ y,
+                                                                     int64_t ldy, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* xs = (float*)lds;                                  // [BSP_S]
+  float* acc = xs + BSP_S;                                  // [BSP_MAX_RB]
+  float* prod = acc + BSP_MAX_RB;                           // [2][BSP_CAP]
+  uint16_t* rid = (uint16_t*)(prod + 2 * BSP_CAP);          // [2][BSP_CAP]
+  __shared__ BspSeg segs[BSP_MAXSEG];
+  // XCD k (blockIdx & 7) walks a contiguous range of row blocks: neighbours share their slices of x in its L2
+  const int per = (nb + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (b >= nb) return;
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)b * rb, r1 = r0 + rb < m ? r0 + rb : m;
+  const int nrows = (int)(r1 - r0);
+  const int n = nseg[b];
+  for (int i = tid; i < n * 4; i += BSP_THREADS) ((int*)segs)[i] = ((const int*)(segtab + (int64_t)b * BSP_MAXSEG))[i];
+  for (int i = tid; i < nrows; i += BSP_THREADS) acc[i] = 0.f;
+  const int64_t e0 = indptr[r0];
+  __syncthreads();
+
+  // the chunk sequence: segment by segment, BSP_CAP entries at a time; entries are stored in that order from e0 on.
+  // A lane owns BSP_PER CONSECUTIVE entries of a chunk (one 16-byte load each of keys and values).
+  struct Chunk {
+    int seg, cnt, staged, before;      // before: entries of the block in the segments before `seg`
+    int64_t e;
+  };
+  auto next_chunk = [&](const Chunk& c) {       // the chunk after c (seg == n: none)
+    Chunk o;
+    const int used = (int)(c.e - e0) + c.cnt;
+    o.seg = c.seg;
+    o.before = c.before;
+    if (o.seg < n && used >= o.before + segs[o.seg].count) {
+      o.before += segs[o.seg].count;
+      ++o.seg;
+    }
+    o.e = e0 + used;
+    o.cnt = 0;
+    o.staged = 0;
+    if (o.seg < n) {
+      const int left = o.before + segs[o.seg].count - used;
+      o.cnt = left < BSP_CAP ? left : BSP_CAP;
+      o.staged = segs[o.seg].staged;
+    }
+    return o;
+  };
+  Chunk c0;
+  c0.seg = 0;
+  c0.before = 0;
+  c0.e = e0;
+  c0.cnt = n > 0 ? (segs[0].count < BSP_CAP ? segs[0].count : BSP_CAP) : 0;
+  c0.staged = n > 0 ? segs[0].staged : 0;
+
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+  static_assert(BSP_PER == 4, "one 16-byte load per lane and chunk");
+  const int i0 = tid * BSP_PER;
+  u32x4 kA = {0, 0, 0, 0}, kB = {0, 0, 0, 0};      // A: being gathered (next chunk), B: being loaded (the one after)
+  bsp_f4 vA = {0.f, 0.f, 0.f, 0.f}, vB = {0.f, 0.f, 0.f, 0.f}, xA = {0.f, 0.f, 0.f, 0.f};
+  u16x4 rA = {0, 0, 0, 0}, rB = {0, 0, 0, 0};
+  // (a lane whose entries start inside the chunk loads all four: what lies behind the chunk's end is the next
+  // chunk's, or the padding of the plan arrays, and is never used)
+  auto load_entries = [&](const Chunk& c, u32x4& kk, bsp_f4& vv, u16x4& rr) {
+    if (c.seg < n && i0 < c.cnt) {
+      kk = *(const u32x4*)(keys + c.e + i0);
+      vv = (bsp_f4)(*(const f32x4u*)(pvals + c.e + i0));
+      if (!c.staged) {
+#pragma unroll
+        for (int u = 0; u < BSP_PER; ++u) rr[u] = drow[c.e + i0 + u];
+      }
+    }
+  };
+  auto gather_direct = [&](const Chunk& c, const u32x4& kk, bsp_f4& xx) {
+    if (c.seg < n && !c.staged && i0 < c.cnt) {
+#pragma unroll
+      for (int u = 0; u < BSP_PER; ++u) xx[u] = i0 + u < c.cnt ? x[kk[u]] : 0.f;
+    }
+  };
+  // slices of x travel global -> registers -> LDS, requested one staged segment ahead (two ahead, 48 more registers,
+  // measured slower: 44.5 vs 40.6 us)
+  bsp_f4 xr0[BSP_XV_N];
+  auto prefetch_slice = [&](int s, bsp_f4* xr) {
+    const int lo = segs[s].col_lo, w = segs[s].width;
+#pragma unroll
+    for (int u = 0; u < BSP_XV_N; ++u) {
+      const int i = (u * BSP_THREADS + tid) * 4;
+      bsp_f4 t = {0.f, 0.f, 0.f, 0.f};
+      if (i + 4 <= w) t = *(const bsp_f4*)(x + lo + i);
+      else
+        for (int e = 0; e < 4; ++e)
+          if (i + e < w) t[e] = x[lo + i + e];
+      xr[u] = t;
+    }
+  };
+  auto next_staged = [&](int s) {       // first staged segment after s (n: none)
+    for (++s; s < n; ++s)
+      if (segs[s].staged) return s;
+    return n;
+  };
+
+  // pipeline fill: chunk 0 in A (with its gathers), chunk 1 in B, the first staged slice in registers
+  Chunk cur = c0, nxt = next_chunk(c0);
+  load_entries(cur, kA, vA, rA);
+  load_entries(nxt, kB, vB, rB);
+  gather_direct(cur, kA, xA);
+  int slice_in_lds = -1;
+  int ahead0 = next_staged(-1);     // the segment whose slice is in xr0
+  if (ahead0 < n) prefetch_slice(ahead0, xr0);
+  int buf = 0;
+  while (cur.seg < n) {
+    if (cur.staged && slice_in_lds != cur.seg) {
+      // (xr0 holds this segment's slice: staged segments are met in order; every lane is past the barrier that
+      // followed the last products read from the previous slice)
+#pragma unroll
+      for (int u = 0; u < BSP_XV_N; ++u) {
+        const int i = (u * BSP_THREADS + tid) * 4;
+        if (i < BSP_S) *(bsp_f4*)(xs + i) = xr0[u];
+      }
+      slice_in_lds = cur.seg;
+      __syncthreads();
+      ahead0 = next_staged(ahead0);
+      if (ahead0 < n) prefetch_slice(ahead0, xr0);
+    }
+    // products of the current chunk (entries and direct gathers were requested one / two chunks ago)
+    float* pb = prod + buf * BSP_CAP;
+    uint16_t* rbuf = rid + buf * BSP_CAP;
+    if (i0 < cur.cnt) {
+      bsp_f4 p;
+      u16x4 r;
+#pragma unroll
+      for (int u = 0; u < BSP_PER; ++u) {
+        const float xv = cur.staged ? xs[kA[u] & 0xffffu] : xA[u];
+        p[u] = vA[u] * xv;
+        r[u] = cur.staged ? (uint16_t)(kA[u] >> 16) : rA[u];
+      }
+      *(bsp_f4*)(pb + i0) = p;
+      *(u16x4*)(rbuf + i0) = r;
+    }
+    // rotate the pipeline: B -> A (+ its gathers), the chunk after that -> B
+    const Chunk done = cur;
+    cur = nxt;
+    nxt = next_chunk(cur);
+    kA = kB;
+    vA = vB;
+    rA = rB;
+    gather_direct(cur, kA, xA);
+    load_entries(nxt, kB, vB, rB);
+    __syncthreads();                   // products of `done` are in LDS (and everybody is past the runs of the chunk before)
+    // Runs of equal rows: the lane holding a run's first entry adds the run, in order, to the row's accumulator --
+    // its own entries from registers, what continues in later lanes' entries from LDS.
+    if (i0 < done.cnt) {
+      const bsp_f4 p = *(const bsp_f4*)(pb + i0);
+      const u16x4 r = *(const u16x4*)(rbuf + i0);
+      const int nvalid = done.cnt - i0 < BSP_PER ? done.cnt - i0 : BSP_PER;
+      const bool first_is_start = i0 == 0 || rbuf[i0 - 1] != r[0];
+      bool active = false;
+      float sum = 0.f;
+      unsigned row = 0;
+#pragma unroll
+      for (int u = 0; u < BSP_PER; ++u) {
+        if (u < nvalid) {
+          const bool start = u == 0 ? first_is_start : (r[u] != r[u - 1]);
+          if (start) {
+            if (active) acc[row] = sum;
+            row = r[u];
+            sum = acc[row];
+            active = true;
+          }
+          if (active) sum += p[u];
+        }
+      }
+      if (active) {
+        for (int j = i0 + nvalid; j < done.cnt && rbuf[j] == row; ++j) sum += pb[j];
+        acc[row] = sum;
+      }
+    }
+    buf ^= 1;
+  }
+  __syncthreads();
+  for (int i = tid; i < nrows; i += BSP_THREADS) {
+    float* p = y + (r0 + i) * ldy;
+    *p = accumulate ? *p + acc[i] : acc[i];
+  }
+}
+
+}  // namespace
+
+extern "C" size_t sp_csr_spmv_blockplan_bytes(int32_t dtype, int64_t m, int64_t k, int64_t nnz) {
+  BspLayout L;
+  return bsp_layout(dtype, m, k, nnz, &L) ? L.total : 0;
+}
+
+extern "C" int sp_csr_spmv_blockplan(int32_t dtype, int64_t m, int64_t k, int64_t nnz, const int64_t* d_indptr,
+                                     const int32_t* d_indices, const void* d_vals, void* d_plan, size_t plan_bytes,
+                                     void* stream) {
+  BspLayout L;
+  if (!bsp_layout(dtype, m, k, nnz, &L)) SP_FAIL("sp_csr_spmv_blockplan: no blocked plan for this matrix (see sp_csr_spmv_blockplan_bytes)");
+  if (!d_indptr || !d_indices || !d_vals || !d_plan) SP_FAIL("sp_csr_spmv_blockplan: NULL pointer");
+  if (plan_bytes < L.total) SP_FAIL("sp_csr_spmv_blockplan: plan buffer too small (%zu < %zu)", plan_bytes, L.total);
+  hipStream_t st = (hipStream_t)stream;
+  char* P = (char*)d_plan;
+  const long long header[8] = {1, (long long)L.rb, (long long)L.nb, BSP_S, (long long)L.ns, (long long)nnz, (long long)m, (long long)k};
+  SP_HIP(hipMemcpyAsync(P, header, sizeof(header), hipMemcpyHostToDevice, st));
+  SP_HIP(hipStreamSynchronize(st));      // (header is a stack array)
+  static bool attr_set = false;
+  if (!attr_set) {
+    SP_HIP(hipFuncSetAttribute((const void*)sp_bsp_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BSP_MAX_SLICES * 4));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sp_bsp_build_kernel, dim3((unsigned)L.nb), dim3(BSP_THREADS), (size_t)L.ns * 4, st, d_indptr, d_indices,
+                     (const float*)d_vals, m, k, (int)L.rb, (int)L.ns, (long long*)P, (int*)(P + L.nseg_off),
+                     (BspSeg*)(P + L.seg_off), (uint32_t*)(P + L.key_off), (uint16_t*)(P + L.drow_off),
+                     (float*)(P + L.val_off));
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int sp_csr_spmv_blocked(int32_t dtype, int64_t m, int64_t k, int64_t nnz, const int64_t* d_indptr,
+                                   const void* d_plan, const void* d_x, void* d_y, int64_t ldy, int32_t accumulate,
+                                   void* stream) {
+  BspLayout L;
+  if (!bsp_layout(dtype, m, k, nnz, &L)) SP_FAIL("sp_csr_spmv_blocked: no blocked plan for this matrix");
+  if (!d_indptr || !d_plan || !d_x || !d_y) SP_FAIL("sp_csr_spmv_blocked: NULL pointer");
+  if (((uintptr_t)d_x & 15) != 0) SP_FAIL("sp_csr_spmv_blocked: x must be 16-byte aligned");
+  if (ldy < 1) SP_FAIL("sp_csr_spmv_blocked: bad ldy");
+  const char* P = (const char*)d_plan;
+  constexpr int lds_bytes = BSP_XS_BYTES + BSP_MAX_RB * 4 + 2 * BSP_CAP * 4 + 2 * BSP_CAP * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SP_HIP(hipFuncSetAttribute((const void*)sp_bsp_spmv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  const int per = (int)((L.nb + 7) / 8);
+  hipLaunchKernelGGL(sp_bsp_spmv_kernel, dim3((unsigned)(per * 8)), dim3(BSP_THREADS), lds_bytes, (hipStream_t)stream, d_indptr, m,
+                     (int)L.rb, (int)L.nb, (const int*)(P + L.nseg_off), (const BspSeg*)(P + L.seg_off),
+                     (const uint32_t*)(P + L.key_off), (const uint16_t*)(P + L.drow_off), (const float*)(P + L.val_off),
+                     (const float*)d_x, (float*)d_y, ldy, (int)accumulate);
+  SP_CHECK_LAUNCH();
+  return 0;
+}

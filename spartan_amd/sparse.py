@@ -10,6 +10,7 @@ Every structural operation is "edit a COO list on the device, then sp_coo_to_csr
 (spartan_amd/csrc/sparse.hip); the numeric hot op is sp_csr_spmm.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -57,7 +58,7 @@ def _cat(parts):
 
 class CsrTile(object):
   """Device blob of a sparse tile."""
-  __slots__ = ('shape', 'dtype', 'indptr', 'indices', 'data', '_plan', '_transposed')
+  __slots__ = ('shape', 'dtype', 'indptr', 'indices', 'data', '_plan', '_block_plan', '_transposed')
   is_sparse_tile = True
 
   def __init__(self, shape, dtype, indptr, indices, data):
@@ -67,6 +68,7 @@ class CsrTile(object):
     self.indices = indices
     self.data = data
     self._plan = None      # sp_csr_spmv_plan output, made on the first matrix x vector product and kept
+    self._block_plan = None   # spmv_block_plan's: the column-blocked copy of the entries, or False (none for this tile)
     self._transposed = None   # the transposed tile, made on first use and kept (tiles are immutable)
 
   @property
@@ -94,6 +96,23 @@ def spmv_plan(t):
     check(lib.sp_csr_spmv_plan(t.shape[0], t.nnz, _p(t.indptr), _p(plan), _stream()))
     t._plan = plan
   return t._plan
+
+
+def spmv_block_plan(t):
+  """The column-blocked plan of csrc/spmv_blocked.hip (fp32 tiles with sorted rows, large enough to pay): built on
+  the tile's first product with a vector and kept; False when the tile has none and sp_csr_spmm's kernels stay."""
+  if t._block_plan is None:
+    lib = _hip.lib()
+    dt = _hip.sp_dtype(t.dtype) if t.dtype in (np.float32, np.float64) else -1
+    need = int(lib.sp_csr_spmv_blockplan_bytes(dt, t.shape[0], t.shape[1], t.nnz)) if dt >= 0 and os.environ.get('SP_SPMV_BLOCKED', '1') != '0' else 0
+    t._block_plan = False
+    if need:
+      plan = D.empty((need,), np.uint8)
+      check(lib.sp_csr_spmv_blockplan(dt, t.shape[0], t.shape[1], t.nnz, _p(t.indptr), _p(t.indices), _p(t.data), _p(plan),
+                                      need, _stream()))
+      if int(plan[:8].numpy().view(np.int64)[0]) == 1:      # (0: a row not sorted by column)
+        t._block_plan = plan
+  return t._block_plan
 
 
 def _check_dtype(dtype):
@@ -261,6 +280,13 @@ def spmm(a, b, out=None, accumulate=False, plan=True):
     out = D.empty((m, n), dtype)
   if m and n:
     lib = _hip.lib()
+    if n == 1 and plan and dtype == a.dtype and b2.data_ptr() % 16 == 0:
+      bp = spmv_block_plan(a)
+      if bp is not False:
+        check(lib.sp_csr_spmv_blocked(_hip.sp_dtype(dtype), m, a.shape[1], a.nnz, _p(a.indptr), _p(bp),
+                                      C.c_void_p(b2.data_ptr()), C.c_void_p(out.data_ptr()), 1, 1 if accumulate else 0,
+                                      _stream()))
+        return out.reshape(m) if vec else out
     ws = _ws.get(lib.sp_csr_spmm_workspace_bytes(a.nnz, n), a.device)
     check(lib.sp_csr_spmm(_hip.sp_dtype(dtype), m, a.shape[1], n, a.nnz, _p(a.indptr), _p(a.indices), _p(av),
                           C.c_void_p(b2.data_ptr()), _ld(b2) if b2.shape[0] > 1 else max(n, 1),

@@ -287,3 +287,66 @@ def test_sparse_fuzz_against_scipy():
     prod = S.to_scipy(S.spgemm(A, B))
     np.testing.assert_array_equal(prod.toarray(), (a @ b).toarray(), err_msg=tag)
     assert prod.has_canonical_format
+
+
+def _site_matrix(rng, n, deg, sites, local_frac, dtype=np.float32, integer=False):
+  """benchmark_pagerank.py-style links: `deg` out-links per page, `local_frac` of them inside the page's site."""
+  cols = np.repeat(np.arange(n, dtype=np.int64), deg)
+  per = n // sites
+  local = np.minimum((cols // per) * per + rng.randint(0, per, size=n * deg), n - 1)
+  far = rng.randint(0, n, size=n * deg)
+  rows = np.where(rng.rand(n * deg) <= local_frac, local, far)
+  vals = rng.randint(-3, 4, size=n * deg).astype(dtype) if integer else rng.standard_normal(n * deg).astype(dtype)
+  return _canon(sps.coo_matrix((vals, (rows, cols)), shape=(n, n)))
+
+
+@pytest.mark.parametrize('n,deg,sites,local_frac', [(120000, 10, 4, 0.9),     # staged site slices + far links both sides
+                                                    (70000, 6, 1, 1.0),       # every slice staged or none
+                                                    (50000, 12, 16, 0.5),     # small sites: mostly direct segments
+                                                    (8000, 40, 2, 0.8)])      # few rows, longer ones
+def test_spmv_column_blocked_plan_is_bit_identical(monkeypatch, n, deg, sites, local_frac):
+  """The column-blocked product (csrc/spmv_blocked.hip) against scipy and the planned stream kernel: same bits for
+  random fp32 values -- a row's products are added in storage order by all three -- with and without `accumulate`.
+  (Without any plan the stream kernel adds the rows that span two of its chunks as partial sums + carries.)"""
+  rng = np.random.RandomState(n + deg)
+  a = _site_matrix(rng, n, deg, sites, local_frac)
+  A = S.from_scipy(a, DEV)
+  assert S.spmv_block_plan(A) is not False
+  x = rng.standard_normal((n, 1)).astype(np.float32)
+  got = S.spmm(A, dev(x)).numpy()
+  np.testing.assert_array_equal(got, a @ x)
+  y = D.from_numpy(np.arange(n, dtype=np.float32).reshape(n, 1))
+  S.spmm(A, dev(x), out=y, accumulate=True)
+  np.testing.assert_array_equal(y.numpy(), np.arange(n, dtype=np.float32).reshape(n, 1) + (a @ x))
+  v = dev(x.reshape(-1))
+  np.testing.assert_array_equal(S.spmm(A, v).numpy(), (a @ x).reshape(-1))
+  # the knob that keeps the stream kernel
+  monkeypatch.setenv('SP_SPMV_BLOCKED', '0')
+  B = S.from_scipy(a, DEV)
+  assert S.spmv_block_plan(B) is False
+  if int(np.diff(a.indptr).max()) <= 65:
+    # (rows of more than 65 entries: the stream kernel adds per-chunk partial sums, not storage order)
+    np.testing.assert_array_equal(S.spmm(B, dev(x)).numpy(), got)
+  else:
+    np.testing.assert_allclose(S.spmm(B, dev(x)).numpy(), got, rtol=1e-5, atol=1e-5)
+
+
+def test_spmv_column_blocked_plan_refuses_unsorted_rows_and_small_tiles():
+  rng = np.random.RandomState(5)
+  a = _site_matrix(rng, 60000, 8, 2, 0.9, integer=True)
+  A = S.from_scipy(a, DEV)
+  # swap two columns inside one row of a copy of the tile: no longer canonical, the builder must say so
+  ind = A.indices.numpy().copy()
+  ptr = A.indptr.numpy()
+  r = int(np.argmax(np.diff(ptr) >= 2))
+  val = A.data.numpy().copy()
+  ind[ptr[r]], ind[ptr[r] + 1] = ind[ptr[r] + 1], ind[ptr[r]]
+  val[ptr[r]], val[ptr[r] + 1] = val[ptr[r] + 1], val[ptr[r]]
+  B = S.CsrTile(A.shape, A.dtype, A.indptr, dev(ind), dev(val))
+  assert S.spmv_block_plan(B) is False
+  x = rng.randint(-2, 3, size=(60000, 1)).astype(np.float32)
+  np.testing.assert_array_equal(S.spmm(B, dev(x)).numpy(), a @ x)       # integer values: order-free
+  small = S.from_scipy(_site_matrix(rng, 3000, 5, 1, 1.0), DEV)
+  assert S.spmv_block_plan(small) is False
+  a64 = _site_matrix(rng, 60000, 8, 2, 0.9, dtype=np.float64)
+  assert S.spmv_block_plan(S.from_scipy(a64, DEV)) is False
