@@ -207,6 +207,10 @@ int sp_program_static_id(const sp_program* prog, int32_t out_dtype);
  * $XDG_CACHE_HOME/spartan_amd/jit, else ~/.cache/spartan_amd/jit.  SPARTAN_JIT_CACHE=off keeps them in memory only. */
 int sp_jit_configure(int enabled, long long min_elems);
 void sp_jit_wait(void);
+/* Loads every code object of csrc/jit_seed and of SPARTAN_JIT_CACHE onto `device` (about a millisecond each) so that
+ * the first launch of a seeded program does not wait for the file; the backend calls it on a background thread
+ * when it comes up.  Returns the number of functions loaded. */
+int sp_jit_preload(int device);
 int sp_jit_compiled_count(void);
 int sp_jit_compile_check(const char* header, const char* template_expr, const sp_program* prog);
 /* Seed mode: between sp_jit_seed_begin(dir) (NULL / "": <library directory>/jit_seed) and sp_jit_seed_end() every
@@ -530,6 +534,7 @@ int sp_comm_all_to_all_blocks(void* comm, int32_t n_sends, const int32_t* send_p
  * the events below (the reference's worker serialises tile mutation with a lock, worker.py:134,160,181; here it
  * is stream order). */
 int sp_set_device(int32_t device);
+int sp_get_device(int32_t* device);                 /* the calling thread's current device */
 int sp_device_synchronize(void);
 int sp_stream_create(void** stream);
 int sp_stream_create_priority(void** stream, int32_t high_priority);   /* high: collectives ahead of queued GEMMs */

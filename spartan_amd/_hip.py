@@ -170,6 +170,8 @@ def _declare(lib):
   lib.sp_comm_bcast.argtypes = [vp, vp, i64, i32, i32, vp]
   lib.sp_comm_all_to_all_blocks.argtypes = [vp, i32, C.POINTER(i32), pp, p64, i32, C.POINTER(i32), pp, p64, vp]
   lib.sp_set_device.argtypes = [i32]
+  lib.sp_get_device.argtypes = [vp]
+  lib.sp_jit_preload.argtypes = [C.c_int]
   lib.sp_stream_create.argtypes = [pp]
   lib.sp_stream_destroy.argtypes = [vp]
   lib.sp_stream_synchronize.argtypes = [vp]
@@ -196,7 +198,7 @@ EXPORTS = [
     'sp_blob_create', 'sp_blob_destroy', 'sp_blob_trim', 'sp_blob_info', 'sp_blob_stats', 'sp_blob_h2d', 'sp_blob_d2h',
     'sp_blob_slice_copy', 'sp_comm_available', 'sp_comm_version', 'sp_comm_unique_id', 'sp_comm_init',
     'sp_comm_destroy', 'sp_comm_abort', 'sp_comm_async_error', 'sp_comm_all_reduce', 'sp_comm_reduce_scatter',
-    'sp_comm_reduce', 'sp_comm_all_gather', 'sp_comm_bcast', 'sp_comm_all_to_all_blocks', 'sp_set_device',
+    'sp_comm_reduce', 'sp_comm_all_gather', 'sp_comm_bcast', 'sp_comm_all_to_all_blocks', 'sp_set_device', 'sp_get_device', 'sp_jit_preload',
     'sp_stream_create', 'sp_stream_create_priority', 'sp_device_synchronize', 'sp_memset', 'sp_stream_copy_wg',
     'sp_event_query', 'sp_stream_destroy', 'sp_stream_synchronize', 'sp_stream_query', 'sp_stream_wait_event',
 ]

@@ -59,6 +59,15 @@ class HipBackend(object):
     self.gemm_events = None   # set to [] to record (start, stop) HIP events around every GEMM launch
     self._rng_seed = (int(time.time() * 100000) + os.getpid()) & (2**63 - 1)   # srandom.py:23-35: from the clock
     self._rng_offset = 0
+    # the code objects that travel with the tree (csrc/jit_seed) are loaded while the host builds its first
+    # expressions: ctypes drops the GIL for the call, a seeded program then starts specialised at once
+    dev = ctypes.c_int32(0)
+    if os.environ.get('SP_JIT_PRELOAD', '1') != '0' and lib.sp_get_device(ctypes.byref(dev)) == 0:
+      import atexit
+      import threading
+      t = threading.Thread(target=lib.sp_jit_preload, args=(dev.value,), daemon=True, name='sp_jit_preload')
+      t.start()
+      atexit.register(t.join)     # (never inside hipModuleLoadData when the runtime is torn down)
 
   # -- memory -------------------------------------------------------------------
   def empty(self, shape, dtype):

@@ -564,3 +564,11 @@ extern "C" int sp_set_device(int32_t device) {
   SP_HIP(hipSetDevice(device));
   return 0;
 }
+
+extern "C" int sp_get_device(int32_t* device) {
+  if (!device) SP_FAIL("sp_get_device: NULL pointer");
+  int d = 0;
+  SP_HIP(hipGetDevice(&d));
+  *device = d;
+  return 0;
+}

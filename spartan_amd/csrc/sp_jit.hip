@@ -25,6 +25,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include <dirent.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -235,6 +236,7 @@ void cache_store(const std::string& path, const char* lowered, const std::vector
 
 std::mutex g_mu;
 std::unordered_map<std::string, hipFunction_t> g_cache;   // value NULL = pending, or tried and failed
+std::unordered_map<std::string, hipFunction_t> g_preloaded;   // "<device>/<file>.spco" -> function (sp_jit_preload)
 
 // Compiles run on ONE background thread: a launch that finds its program not yet
 // specialised enqueues the job and carries on with the interpreter kernel, so the
@@ -424,8 +426,14 @@ void* sp_jit_get(const char* header, const char* template_expr, const sp_program
   if (g_stop) return nullptr;
   {
     // a code object already on disk (the user's cache, or the seeds that travel with the tree) is loaded right
-    // here -- milliseconds, not a compile -- so that such a program runs specialised from its FIRST launch
+    // here -- milliseconds, not a compile -- so that such a program runs specialised from its FIRST launch;
+    // sp_jit_preload (called in the background when the backend comes up) may have loaded it already
     const std::string file = cache_file(header, template_expr, p);
+    auto pre = g_preloaded.find(std::to_string(device) + file);
+    if (pre != g_preloaded.end()) {
+      g_cache.emplace(key, pre->second);
+      return (void*)pre->second;
+    }
     for (const std::string& where : {cache_dir().empty() ? std::string() : cache_dir() + file, seed_dir() + file}) {
       if (where.empty()) continue;
       hipFunction_t fn = cache_load(where);
@@ -447,6 +455,44 @@ void* sp_jit_get(const char* header, const char* template_expr, const sp_program
   lock.unlock();
   g_cv.notify_one();
   return nullptr;
+}
+
+// Loads every code object of the seed directory and of SPARTAN_JIT_CACHE onto `device` (about a millisecond each),
+// so that the first launch of a seeded program does not wait for the file and hipModuleLoadData.  Meant to run on a
+// background thread while the host builds its first expressions; returns the number of functions loaded.
+extern "C" int sp_jit_preload(int device) {
+  if (!sp_jit_enabled() || !g_seed_target.empty()) return 0;
+  if (hipSetDevice(device) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int loaded = 0;
+  for (const std::string& dir : {cache_dir(), seed_dir()}) {
+    if (dir.empty()) continue;
+    DIR* d = opendir(dir.c_str());
+    if (!d) continue;
+    std::vector<std::string> files;
+    while (struct dirent* e = readdir(d)) {
+      const std::string f = e->d_name;
+      if (f.size() > 5 && f.compare(f.size() - 5, 5, ".spco") == 0) files.push_back("/" + f);
+    }
+    closedir(d);
+    for (const std::string& f : files) {
+      const std::string key = std::to_string(device) + f;
+      {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (g_stop) return loaded;
+        if (g_preloaded.count(key)) continue;
+      }
+      hipFunction_t fn = cache_load(dir + f);
+      if (!fn) continue;
+      std::lock_guard<std::mutex> lock(g_mu);
+      g_preloaded.emplace(key, fn);
+      ++loaded;
+    }
+  }
+  if (verbose()) fprintf(stderr, "[spartan_hip jit] preloaded %d code objects on device %d\n", loaded, device);
+  return loaded;
 }
 
 // Block until every queued specialisation has been compiled (tests, benchmarks).

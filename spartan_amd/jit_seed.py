@@ -41,6 +41,12 @@ def _seed_mode(directory=None):
   for m, _ in saved:
     m.check = lambda rc: None
   devarray._storage_cls[0] = devarray.HostStorage
+  # code objects of earlier builds (other source hashes in their names) would only be loaded for nothing
+  target = directory or os.path.join(os.path.dirname(os.path.abspath(_hip.__file__)), 'csrc', 'jit_seed')
+  if os.path.isdir(target):
+    for name in os.listdir(target):
+      if name.endswith('.spco'):
+        os.remove(os.path.join(target, name))
   ok = lib.sp_jit_seed_begin(directory.encode() if directory else None)
   try:
     yield bool(ok)
