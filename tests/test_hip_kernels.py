@@ -824,7 +824,8 @@ def test_jit_code_objects_persist_across_processes(tmp_path):
       "x = sp.from_numpy(np.arange(1 << 16, dtype=np.float32).reshape(256, 256) / 7)\n"
       "r = (sp.sqrt(sp.abs(x * 3 - 2)) * x + x / 5 - 1).optimized().glom()\n"
       "print('SUM %.6f' % float(r.astype(np.float64).sum()))\n")
-  env = dict(os.environ, SPARTAN_JIT_CACHE=str(tmp_path), SP_JIT_SYNC='1', SP_JIT_MIN_ELEMS='0', SP_JIT_VERBOSE='1')
+  env = dict(os.environ, SPARTAN_JIT_CACHE=str(tmp_path), SP_JIT_SYNC='1', SP_JIT_MIN_ELEMS='0', SP_JIT_VERBOSE='1',
+             SP_JIT_PRELOAD='0')       # (the background preload of the backend logs `preloaded N code objects`)
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   outs = []
   for _ in range(2):
@@ -836,3 +837,11 @@ def test_jit_code_objects_persist_across_processes(tmp_path):
   assert 'compiled' in outs[0].stderr and 'loaded' not in outs[0].stderr
   assert 'loaded' in outs[1].stderr and ' compiled ' not in outs[1].stderr
   assert outs[0].stdout.strip().splitlines()[-1] == outs[1].stdout.strip().splitlines()[-1]
+  # with the preload on (the default) a third process finds the code object already loaded: nothing compiled,
+  # nothing read on the launch path, same result
+  env3 = dict(env, SP_JIT_PRELOAD='1', SP_JIT_SYNC='0')
+  wait = prog.replace("sp.initialize('hip')\n", "sp.initialize('hip')\nimport time; time.sleep(1.0)\n")
+  p3 = subprocess.run([sys.executable, '-c', wait], env=env3, cwd=root, capture_output=True, text=True, timeout=300)
+  assert p3.returncode == 0, p3.stderr[-2000:]
+  assert 'preloaded' in p3.stderr and ' compiled ' not in p3.stderr and 'loaded sp_map_kernel' not in p3.stderr, p3.stderr[-2000:]
+  assert p3.stdout.strip().splitlines()[-1] == outs[0].stdout.strip().splitlines()[-1]
