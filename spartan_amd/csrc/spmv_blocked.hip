@@ -214,7 +214,7 @@ __global__ __launch_bounds__(BSP_THREADS, 4) void sp_bsp_spmv_kernel(const int64
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float* xs = (float*)lds;                                  // [BSP_S]
   float* acc = xs + BSP_S;                                  // [BSP_MAX_RB]
-  float* prod = acc + BSP_MAX_RB;                           // [2][BSP_CAP]
+  float* prod = acc + BSP_MAX_RB + 4;                       // [2][BSP_CAP]   (acc[BSP_MAX_RB]: the spare slot of the run sums)
   uint16_t* rid = (uint16_t*)(prod + 2 * BSP_CAP);          // [2][BSP_CAP]
   __shared__ BspSeg segs[BSP_MAXSEG];
   // XCD k (blockIdx & 7) walks a contiguous range of row blocks: neighbours share their slices of x in its L2
@@ -293,15 +293,20 @@ __global__ __launch_bounds__(BSP_THREADS, 4) void sp_bsp_spmv_kernel(const int64
   bsp_f4 xr0[BSP_XV_N];
   auto prefetch_slice = [&](int s, bsp_f4* xr) {
     const int lo = segs[s].col_lo, w = segs[s].width;
+    const float* __restrict__ xl = x + lo;
+    if (w == BSP_S) {                   // every slice but the matrix's last: no per-lane guards
 #pragma unroll
-    for (int u = 0; u < BSP_XV_N; ++u) {
-      const int i = (u * BSP_THREADS + tid) * 4;
-      bsp_f4 t = {0.f, 0.f, 0.f, 0.f};
-      if (i + 4 <= w) t = *(const bsp_f4*)(x + lo + i);
-      else
-        for (int e = 0; e < 4; ++e)
-          if (i + e < w) t[e] = x[lo + i + e];
-      xr[u] = t;
+      for (int u = 0; u < BSP_XV_N; ++u) {
+        const int i = (u * BSP_THREADS + tid) * 4;
+        if ((u + 1) * BSP_THREADS * 4 <= BSP_S || i < BSP_S) xr[u] = *(const bsp_f4*)(xl + i);
+      }
+    } else {                            // clamped element loads: what lies past the slice's end is never used
+#pragma unroll
+      for (int u = 0; u < BSP_XV_N; ++u) {
+        const int i = (u * BSP_THREADS + tid) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xr[u][e] = xl[i + e < w ? i + e : w - 1];
+      }
     }
   };
   auto next_staged = [&](int s) {       // first staged segment after s (n: none)
@@ -363,26 +368,33 @@ __global__ __launch_bounds__(BSP_THREADS, 4) void sp_bsp_spmv_kernel(const int64
     if (i0 < done.cnt) {
       const bsp_f4 p = *(const bsp_f4*)(pb + i0);
       const u16x4 r = *(const u16x4*)(rbuf + i0);
-      const int nvalid = done.cnt - i0 < BSP_PER ? done.cnt - i0 : BSP_PER;
-      const bool first_is_start = i0 == 0 || rbuf[i0 - 1] != r[0];
+      const int nvalid = done.cnt - i0;                       // >= 1; entries u >= nvalid are not this chunk's
+      const unsigned prev = i0 == 0 ? 0xffffffffu : (unsigned)rbuf[i0 - 1];
+      // straight-line over the lane's four entries: selects instead of branches (a row's accumulator is read for
+      // every entry and used where a run starts; a run that ends inside the lane is stored, one that does not --
+      // or entries that belong to an earlier lane's run -- goes to the spare slot behind the accumulators)
+      float a4[BSP_PER];
+#pragma unroll
+      for (int u = 0; u < BSP_PER; ++u) a4[u] = acc[u < nvalid ? r[u] : r[0]];
       bool active = false;
       float sum = 0.f;
       unsigned row = 0;
 #pragma unroll
       for (int u = 0; u < BSP_PER; ++u) {
-        if (u < nvalid) {
-          const bool start = u == 0 ? first_is_start : (r[u] != r[u - 1]);
-          if (start) {
-            if (active) acc[row] = sum;
-            row = r[u];
-            sum = acc[row];
-            active = true;
-          }
-          if (active) sum += p[u];
+        const bool valid = u < nvalid;
+        const bool start = valid && (u == 0 ? (unsigned)r[0] != prev : r[u] != r[u - 1]);
+        sum = start ? a4[u] : sum;
+        row = start ? (unsigned)r[u] : row;
+        active = active || start;
+        sum = (valid && active) ? sum + p[u] : sum;
+        if (u + 1 < BSP_PER) {
+          // the run ends here if the next entry of the lane starts another one
+          const bool ends = active && u + 1 < nvalid && r[u + 1] != r[u];
+          acc[ends ? row : (unsigned)BSP_MAX_RB] = sum;
         }
       }
-      if (active) {
-        for (int j = i0 + nvalid; j < done.cnt && rbuf[j] == row; ++j) sum += pb[j];
+      if (active) {      // the lane's last run: it may go on in later lanes' entries
+        for (int j = i0 + (nvalid < BSP_PER ? nvalid : BSP_PER); j < done.cnt && rbuf[j] == row; ++j) sum += pb[j];
         acc[row] = sum;
       }
     }
@@ -436,7 +448,7 @@ extern "C" int sp_csr_spmv_blocked(int32_t dtype, int64_t m, int64_t k, int64_t 
   if (((uintptr_t)d_x & 15) != 0) SP_FAIL("sp_csr_spmv_blocked: x must be 16-byte aligned");
   if (ldy < 1) SP_FAIL("sp_csr_spmv_blocked: bad ldy");
   const char* P = (const char*)d_plan;
-  constexpr int lds_bytes = BSP_XS_BYTES + BSP_MAX_RB * 4 + 2 * BSP_CAP * 4 + 2 * BSP_CAP * 2;
+  constexpr int lds_bytes = BSP_XS_BYTES + (BSP_MAX_RB + 4) * 4 + 2 * BSP_CAP * 4 + 2 * BSP_CAP * 2;
   static bool attr_set = false;
   if (!attr_set) {
     SP_HIP(hipFuncSetAttribute((const void*)sp_bsp_spmv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));

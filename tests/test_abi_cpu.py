@@ -106,3 +106,25 @@ def test_importing_the_package_does_not_import_torch():
   out = subprocess.run([sys.executable, '-c', "import sys, spartan_amd\nfrom spartan_amd import kernels, backend_hip, sparse, comm\n"
                         "assert 'torch' not in sys.modules\nprint('ok')"], cwd=ROOT, capture_output=True, text=True, timeout=120)
   assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+def test_host_side_plans_need_no_device():
+  """The planning entry points are host code: which GEMM schedule a shape gets (sp_gemm_workspace_bytes > 0: split-K
+  for few output tiles and a long contraction, the balanced kernel when the 256 x 128 tiles do not fill the 512
+  resident workgroups and the cost model predicts a win) and whether a sparse tile gets a column-blocked plan."""
+  lib = _hip.lib()
+  ws = lambda m, n, k, dt=_hip.SP_F32: int(lib.sp_gemm_workspace_bytes(dt, m, n, k))   # noqa: E731
+  balanced = 2 * 256 * 2 * 256 * 128 * 4 + 256          # two 256 x 128 images per resident workgroup
+  for shape in ((3072, 3072, 3072), (5000, 5000, 5000), (2304, 2304, 2304), (9216, 9216, 9216), (10000, 10000, 10000)):
+    assert ws(*shape) == balanced, shape
+  for shape in ((8192, 8192, 8192), (32768, 32768, 32768), (4096, 4096, 4096),     # tile count a multiple of 512
+                (2048, 2048, 2048), (3072, 3072, 512), (100, 60, 30)):               # the model says: data-parallel
+    assert ws(*shape) == 0, shape
+  sk = ws(64, 64, 100000)                                                           # split-K: slices of 64 x 64 partials
+  assert sk > 256 and (sk - 256) % (64 * 64 * 4) == 0 and 64 <= (sk - 256) // (64 * 64 * 4) <= 512
+  assert ws(3072, 3072, 3072, _hip.SP_F64) == 0
+  plan = lambda m, k, nnz, dt=_hip.SP_F32: int(lib.sp_csr_spmv_blockplan_bytes(dt, m, k, nnz))   # noqa: E731
+  assert plan(900000, 900000, 9000000) > 10 * 9000000         # 10 bytes per entry + tables
+  assert plan(900000, 900000, 9000000, _hip.SP_F64) == 0      # fp32 only
+  assert plan(3000, 3000, 300000) == 0 and plan(900000, 900000, 100000) == 0      # too few rows / entries
+  assert plan(5000, 5000, 5000 * 100) == 0                    # long rows: the lanes-per-row kernels
