@@ -127,8 +127,11 @@ class HipBackend(object):
     hit = self._np_cache.get(key)
     # the driver may update the array in place between evaluations (`w -= alpha * grad`): the HBM copy is
     # only re-used while the bytes are the same (the reference re-pickles the array into every request)
-    stamp = _content_stamp(arr[slices]) if arr.nbytes <= (1 << 22) else None
-    if hit is None or hit[0] is not arr or stamp is None or hit[2] != stamp:
+    # An array object seen for the first time is uploaded without being hashed (an iterative driver hands over a new
+    # array every step: `w = w - g * alpha`, `centers = sums / counts`); the stamp is taken when the object comes back.
+    known = hit is not None and hit[0] is arr
+    stamp = _content_stamp(arr[slices]) if known and arr.nbytes <= (1 << 22) else None
+    if not known or stamp is None or hit[2] != stamp:
       hit = (arr, self.from_numpy(arr[slices]), stamp)
       self._np_cache[key] = hit
       while len(self._np_cache) > 64:

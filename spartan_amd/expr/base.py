@@ -75,15 +75,18 @@ class Expr(object):
   needs_cache = True
 
   def __init__(self, expr_id=None, shape_cache=None, **fields):
-    unknown = set(fields) - set(self.members)
-    if unknown:
-      raise TypeError('%s: unexpected fields %s' % (type(self).__name__, sorted(unknown)))
+    # (a driver loop builds and rewrites some fifty nodes per forced expression: plain dict stores, no set algebra)
+    d = self.__dict__
+    pop = fields.pop
     for name in self.members:
-      setattr(self, name, fields.get(name))
-    self.expr_id = next(unique_id) if expr_id is None else expr_id
-    self.shape_cache = shape_cache
-    self.optimized_expr = None
-    eval_cache.register(self.expr_id)
+      d[name] = pop(name, None)
+    if fields:
+      raise TypeError('%s: unexpected fields %s' % (type(self).__name__, sorted(fields)))
+    d['expr_id'] = expr_id = next(unique_id) if expr_id is None else expr_id
+    d['shape_cache'] = shape_cache
+    d['optimized_expr'] = None
+    holders = eval_cache._holders
+    holders[expr_id] = holders.get(expr_id, 0) + 1
 
   def __del__(self):
     try:

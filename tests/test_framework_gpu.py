@@ -152,3 +152,25 @@ def test_streaming_policy_does_not_change_results(shape):
     np.testing.assert_array_equal(sp.argmin(X, axis=0).glom(), np.argmin(x, axis=0))
   finally:
     sp.shutdown()
+
+
+def test_driver_arrays_are_uploaded_again_when_their_bytes_change():
+  """`dot(x, w)` with a driver-side NumPy `w` (dot.py:172-187: the reference pickles it into every request): a new
+  array object is uploaded without being hashed, an object that comes back is re-used only while its bytes are the
+  same -- a driver that updates `w` in place between steps must see the new values."""
+  ctx = sp.initialize('hip', num_workers=3)
+  try:
+    rng = np.random.RandomState(3)
+    xh = rng.randint(-3, 4, size=(300, 40)).astype(np.float32)
+    x = sp.from_numpy(xh)
+    w = rng.randint(-3, 4, size=(40, 1)).astype(np.float32)
+    np.testing.assert_array_equal(sp.dot(x, w).glom(), xh.dot(w))       # first sight: uploaded, not hashed
+    np.testing.assert_array_equal(sp.dot(x, w).glom(), xh.dot(w))       # same object, same bytes
+    w[5, 0] += 2.0                                                       # the driver steps its weights in place
+    np.testing.assert_array_equal(sp.dot(x, w).glom(), xh.dot(w))
+    w[:] = 0
+    np.testing.assert_array_equal(sp.dot(x, w).glom(), np.zeros((300, 1), np.float32))
+    w2 = w + 1.0                                                         # a new object every step
+    np.testing.assert_array_equal(sp.dot(x, w2).glom(), xh.dot(w2))
+  finally:
+    sp.shutdown()

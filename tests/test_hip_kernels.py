@@ -839,7 +839,8 @@ def test_jit_code_objects_persist_across_processes(tmp_path):
   assert outs[0].stdout.strip().splitlines()[-1] == outs[1].stdout.strip().splitlines()[-1]
   # with the preload on (the default) a third process finds the code object already loaded: nothing compiled,
   # nothing read on the launch path, same result
-  env3 = dict(env, SP_JIT_PRELOAD='1', SP_JIT_SYNC='0')
+  env3 = dict(env, SP_JIT_PRELOAD='1')
+  del env3['SP_JIT_SYNC']        # (set at all = compile / load in the caller)
   wait = prog.replace("sp.initialize('hip')\n", "sp.initialize('hip')\nimport time; time.sleep(1.0)\n")
   p3 = subprocess.run([sys.executable, '-c', wait], env=env3, cwd=root, capture_output=True, text=True, timeout=300)
   assert p3.returncode == 0, p3.stderr[-2000:]
