@@ -211,6 +211,7 @@ void sp_jit_wait(void);
  * the first launch of a seeded program does not wait for the file; the backend calls it on a background thread
  * when it comes up.  Returns the number of functions loaded. */
 int sp_jit_preload(int device);
+void sp_jit_shutdown(void);         /* stop the compile thread (an in-flight compile finishes first) */
 int sp_jit_compiled_count(void);
 int sp_jit_compile_check(const char* header, const char* template_expr, const sp_program* prog);
 /* Seed mode: between sp_jit_seed_begin(dir) (NULL / "": <library directory>/jit_seed) and sp_jit_seed_end() every

@@ -172,6 +172,8 @@ def _declare(lib):
   lib.sp_set_device.argtypes = [i32]
   lib.sp_get_device.argtypes = [vp]
   lib.sp_jit_preload.argtypes = [C.c_int]
+  lib.sp_jit_shutdown.argtypes = []
+  lib.sp_jit_shutdown.restype = None
   lib.sp_stream_create.argtypes = [pp]
   lib.sp_stream_destroy.argtypes = [vp]
   lib.sp_stream_synchronize.argtypes = [vp]
@@ -198,7 +200,7 @@ EXPORTS = [
     'sp_blob_create', 'sp_blob_destroy', 'sp_blob_trim', 'sp_blob_info', 'sp_blob_stats', 'sp_blob_h2d', 'sp_blob_d2h',
     'sp_blob_slice_copy', 'sp_comm_available', 'sp_comm_version', 'sp_comm_unique_id', 'sp_comm_init',
     'sp_comm_destroy', 'sp_comm_abort', 'sp_comm_async_error', 'sp_comm_all_reduce', 'sp_comm_reduce_scatter',
-    'sp_comm_reduce', 'sp_comm_all_gather', 'sp_comm_bcast', 'sp_comm_all_to_all_blocks', 'sp_set_device', 'sp_get_device', 'sp_jit_preload',
+    'sp_comm_reduce', 'sp_comm_all_gather', 'sp_comm_bcast', 'sp_comm_all_to_all_blocks', 'sp_set_device', 'sp_get_device', 'sp_jit_preload', 'sp_jit_shutdown',
     'sp_stream_create', 'sp_stream_create_priority', 'sp_device_synchronize', 'sp_memset', 'sp_stream_copy_wg',
     'sp_event_query', 'sp_stream_destroy', 'sp_stream_synchronize', 'sp_stream_query', 'sp_stream_wait_event',
 ]
@@ -255,6 +257,10 @@ def lib():
     _lib = _declare(C.CDLL(LIB_PATH))
     if _lib.sp_abi_version() != 1:
       raise HipError('libspartan_hip.so ABI version mismatch')
+    # the run-time compile thread is stopped (after the compile it may be in) while the interpreter is still whole,
+    # ahead of every C exit handler -- a short-lived process must not tear the compiler down under it
+    import atexit
+    atexit.register(_lib.sp_jit_shutdown)
   return _lib
 
 

@@ -449,6 +449,11 @@ void* sp_jit_get(const char* header, const char* template_expr, const sp_program
   ++g_inflight;
   if (!g_worker_started) {
     g_worker_started = true;
+    // libhiprtc (and the compiler library it brings) is loaded HERE, before the exit handler is registered: exit
+    // handlers run in reverse order, so the compiler's own teardown comes after stop_worker has joined a compile
+    // that may be in flight (loaded lazily on the worker thread it was torn down under a running compile: a
+    // short-lived process could hang at exit)
+    (void)rtc();
     g_worker = std::thread(worker_main);
     atexit(stop_worker);   // registered after the HIP runtime came up => runs before its teardown
   }
@@ -494,6 +499,10 @@ extern "C" int sp_jit_preload(int device) {
   if (verbose()) fprintf(stderr, "[spartan_hip jit] preloaded %d code objects on device %d\n", loaded, device);
   return loaded;
 }
+
+// Stops the compile thread (an in-flight compile finishes first); launches after this use what is already compiled,
+// loaded or interpreted.  The Python host calls it from its own atexit, ahead of every C exit handler.
+extern "C" void sp_jit_shutdown(void) { stop_worker(); }
 
 // Block until every queued specialisation has been compiled (tests, benchmarks).
 extern "C" void sp_jit_wait(void) {
