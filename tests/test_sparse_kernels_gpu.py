@@ -350,3 +350,33 @@ def test_spmv_column_blocked_plan_refuses_unsorted_rows_and_small_tiles():
   assert S.spmv_block_plan(small) is False
   a64 = _site_matrix(rng, 60000, 8, 2, 0.9, dtype=np.float64)
   assert S.spmv_block_plan(S.from_scipy(a64, DEV)) is False
+
+
+def test_spmv_column_blocked_plan_ragged_shapes():
+  """Row and column counts that are multiples of nothing (a partly filled last row block, a last slice of x narrower
+  than the others and staged), a band of empty rows, a rectangular tile, and a vector that is not 16-byte aligned
+  (the stream kernel takes that one): all bit-identical to scipy."""
+  rng = np.random.RandomState(77)
+  m, k, deg = 100003, 90001, 9
+  cols = np.repeat(np.arange(k, dtype=np.int64), deg)
+  rows = rng.randint(0, m, size=k * deg)
+  rows[(rows >= 40000) & (rows < 43000)] = 39999               # rows 40000..42999 stay empty; one row gets very long?
+  near = rng.rand(k * deg) < 0.85                              # most links of the last columns go to the last rows
+  rows = np.where(near, np.minimum(m - 1, (cols * m) // k + rng.randint(-3000, 3000, size=k * deg)).clip(0), rows)
+  rows[(rows >= 40000) & (rows < 43000)] = 43000
+  a = _canon(sps.coo_matrix((rng.standard_normal(k * deg).astype(np.float32), (rows, cols)), shape=(m, k)))
+  assert int(np.diff(a.indptr)[40000:43000].max()) == 0
+  A = S.from_scipy(a, DEV)
+  assert S.spmv_block_plan(A) is not False
+  x = rng.standard_normal((k, 1)).astype(np.float32)
+  np.testing.assert_array_equal(S.spmm(A, dev(x)).numpy(), a @ x)
+  pad = dev(np.concatenate([np.zeros((1, 1), np.float32), x]))
+  xv = pad[1:]                                                 # same values, 4 bytes off a 16-byte boundary
+  assert xv.data_ptr() % 16 != 0
+  want = a @ x
+  got = S.spmm(A, xv).numpy()
+  if int(np.diff(a.indptr).max()) <= 65:
+    np.testing.assert_array_equal(got, want)
+  else:
+    # (row 43000 holds thousands of entries: the stream kernel adds it as per-chunk partial sums)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-4)
