@@ -6,9 +6,11 @@
 // :172-187 dot_map2_np_mapper); `accumulate` fuses the np.add reducer of the
 // dot target (dot.py:289-294 + tile.pyx:263-266) into the epilogue.
 //
-// Two kernels share the macro-tile, the MFMA schedule and the epilogue: sp_gemm_glds_kernel (direct-to-LDS
-// k-tiles, the default for large aligned problems, see its comment) and sp_gemm_kernel (register-staged, any
-// shape / alignment / K tail / split-K).
+// Three kernels share the macro-tile, the MFMA schedule and the epilogue: sp_gemm_glds_kernel (direct-to-LDS
+// k-tiles, the default for large aligned problems, see its comment), sp_gemm_glds_sk_kernel (the same k-loop over
+// whole data-parallel rounds of tiles plus equal ranges of the remaining tiles' k-tiles, for tile counts that do not
+// fill the chip; sp_gemm_ws picks it by a cost model) and sp_gemm_kernel (register-staged, any shape / alignment /
+// K tail / split-K).
 // Structure of sp_gemm_kernel (per workgroup of NW waves, one 32x32 MFMA tile grid per wave):
 //   - BM x BN output macro-tile, K walked in steps of BK=16;
 //   - global -> VGPR (16-B loads) -> LDS, LDS double-buffered: the loads of

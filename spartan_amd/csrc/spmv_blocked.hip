@@ -14,8 +14,9 @@
 // The kernel gives a row block to one workgroup: for each segment in column order it copies the slice of x into
 // LDS (one coalesced read; the slice for the NEXT segment is already on its way in registers), multiplies the
 // segment's entries against it 2048 at a time (entries prefetched two chunks ahead, the direct segments' gathers
-// of x one chunk ahead), leaves the products in LDS, and the first lane of every run of equal rows adds the run
-// to the row's accumulator, also in LDS.  A row's entries therefore meet its accumulator in ascending column
+// of x one chunk ahead; a lane owns four consecutive entries), leaves the products in LDS, and the lane holding the
+// first entry of a run of equal rows adds the run to the row's accumulator, also in LDS (its own entries from
+// registers and without branches, what continues in later lanes' entries from LDS).  A row's entries therefore meet its accumulator in ascending column
 // order, segment after segment -- CSR storage order for a tile with sorted rows, which is the order csr_matvec
 // adds in: results are bit-identical to sp_csr_spmv_planned_kernel's.  Rows that are not sorted by column (the
 // builder checks) make the plan invalid and the caller keeps the stream kernel.
