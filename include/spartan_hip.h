@@ -303,6 +303,16 @@ int sp_gemm_ws(int32_t dtype, const void* d_A, int64_t lda, const void* d_B, int
  * a broadcast stride on the vector operand (row kernels for A.x, column
  * kernels for A^T.x). */
 
+/* sp_rowdot_colsum_f32: out[c] (+)= sum_i X[i][c] * (X[i,:] . w - y[i])  (y == NULL: no subtraction) in ONE pass
+ * over the row tile X [n][d] -- the fused form of `sum(x * (dot(x, w) - y), axis=0)`, the gradient of the
+ * least-squares workload (spartan/examples/linear_regression.py:10-24: a matrix.vector launch and a fused map ->
+ * column-reduce launch, X read twice).  A row stays in its wavefront's registers between the two uses: 4 <= d <= 4096,
+ * d % 4 == 0, rows of X, w and out 16-byte aligned, y with stride ldy.  Deterministic (per-wave partial sums in the
+ * workspace, added in wave order); agrees with the two-launch form to rounding, not bit for bit. */
+size_t sp_rowdot_colsum_workspace_bytes(int64_t n, int64_t d);          /* 0: shape not supported */
+int sp_rowdot_colsum_f32(const float* d_x, int64_t ldx, int64_t n, int64_t d, const float* d_w, const float* d_y,
+                         int64_t ldy, float* d_out, int32_t accumulate, void* d_ws, size_t ws_bytes, void* stream);
+
 /* k-means tile kernels: the bodies of the reference's k-means mappers
  * (spartan/examples/sklearn/cluster/k_means_.py), BASELINE configs[3].
  *

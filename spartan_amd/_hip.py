@@ -109,6 +109,9 @@ def _declare(lib):
   lib.sp_gemm_workspace_bytes.argtypes = [i32, i64, i64, i64]
   lib.sp_gemm_workspace_bytes.restype = sz
   lib.sp_gemm_ws.argtypes = [i32, vp, i64, vp, i64, vp, i64, i64, i64, i64, i32, vp, sz, vp]
+  lib.sp_rowdot_colsum_workspace_bytes.argtypes = [i64, i64]
+  lib.sp_rowdot_colsum_workspace_bytes.restype = sz
+  lib.sp_rowdot_colsum_f32.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp, i32, vp, sz, vp]
   lib.sp_nearest_center_workspace_bytes.argtypes = [i64, i64, i64]
   lib.sp_nearest_center_workspace_bytes.restype = sz
   lib.sp_nearest_center.argtypes = [vp, i32, i64, vp, i32, i64, i64, i64, i64, vp, i32, vp, sz, vp]
@@ -192,7 +195,7 @@ EXPORTS = [
     'sp_abi_version', 'sp_last_error', 'sp_device_count', 'sp_device_info', 'sp_map_fused',
     'sp_program_static_id', 'sp_jit_configure', 'sp_jit_wait', 'sp_jit_compiled_count', 'sp_jit_compile_check', 'sp_jit_seed_begin', 'sp_jit_seed_end',
     'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
-    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
+    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_rowdot_colsum_workspace_bytes', 'sp_rowdot_colsum_f32', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
     'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_random_fill', 'sp_cumscan',
     'sp_coo_to_csr_workspace_bytes', 'sp_coo_to_csr', 'sp_csr_rows', 'sp_coo_box', 'sp_coo_reshape', 'sp_csr_spmm_workspace_bytes', 'sp_csr_spmv_plan_entries', 'sp_csr_spmv_plan', 'sp_csr_spmv_blockplan_bytes', 'sp_csr_spmv_blockplan', 'sp_csr_spmv_blocked', 'sp_csr_spmm', 'sp_csr_scatter',
     'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',

@@ -499,6 +499,23 @@ class HipBackend(object):
     return out_idx, out_val
 
   # -- contraction ------------------------------------------------------------------
+  def rowdot_colsum(self, x, w, y):
+    """(d,) partial of `sum(x * (dot(x, w) - y), axis=0)` for one row tile (expr/rowdot.py): one pass over x when
+    the layout allows (sp_rowdot_colsum_f32), else the two launches the rewrite replaced."""
+    d = int(x.shape[1])
+    wd = self.cached_numpy(w, (slice(0, d),))
+    wd = wd.reshape(d)
+    yd = None
+    if y is not None:
+      yd = y.reshape(y.shape[0]) if y.dim() == 2 and y.shape[1] == 1 else y
+    out = self.empty((d,), np.float32)
+    self.launches += 1
+    if wd.is_contiguous() and (yd is None or yd.dim() == 1) and kernels.rowdot_colsum(x, wd, yd, out):
+      return out
+    t = self.dot(x, wd.reshape(d, 1))
+    r = t if y is None else t - y.reshape(t.shape)
+    return (x * r).sum(0)
+
   def dot(self, a, b):
     """ndarray.dot for backend tensors: MFMA GEMM for fp32 matrix.matrix, fused
     multiply-reduce launches for everything else."""

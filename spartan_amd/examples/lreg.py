@@ -9,7 +9,9 @@ One step, for X (N, D) row-tiled over the workers, y (N, 1) and driver-side weig
                               the tiles are combined by reduce-scatter, the result is all-gathered
     w   -= alpha * g          on the driver (every rank holds the same w)
 
-so X is streamed twice per step and nothing of size N ever leaves HBM.  The arithmetic is the
+so X is streamed twice per step as stated; on the HIP backend the optimizer rewrites the gradient's DAG into ONE
+pass over X (expr/rowdot.py: the rows stay in registers between the two uses, sp_rowdot_colsum_f32) -- the same
+sums in another order.  Nothing of size N ever leaves HBM.  The arithmetic is the
 reference's (`w - grad * alpha` with grad the glommed float sum), which the committed goldens pin.
 """
 import numpy as np

@@ -35,6 +35,9 @@ FLAGS = {
     'opt_rotate_slice': False,        # off by default in the reference as well (optimize.py:1095)
     'opt_map_fusion': True,
     'opt_reduce_fusion': True,
+    # not a rewrite of the reference's: sum(x * (dot(x, w) - y), axis=0) in one pass over x (expr/rowdot.py), applied
+    # only where the backend has the kernel
+    'opt_rowdot_fusion': True,
 }
 
 # Results of builders whose value differs from call to call (rand, ...) must be computed exactly once: such a node
@@ -157,6 +160,88 @@ class ReduceMapFusion(Pass):
                      dtype_fn=node.dtype_fn, accumulate_fn=node.accumulate_fn, tile_hint=node.tile_hint)
 
 
+class RowDotColSumFusion(Pass):
+  """reduce(sum, axis=0, x * (dot(x, w) - y))  ->  one pass over the rows of x (expr/rowdot.py).  Runs after
+  ReduceMapFusion, on the shape that pass leaves: a column sum whose fused operator is multiply(a, subtract(b, c))
+  (or multiply(a, b)) over the inputs x, dot(x, w) = the map2 join with a driver-side vector, and y."""
+  name = 'rowdot_fusion'
+  rules = {'ReduceExpr': 'fuse'}
+
+  def fuse(self, original, node):
+    found = self.match(node)
+    if found is None:
+      return node
+    from .rowdot import RowDotColSumExpr
+    x, w, y = found
+    return RowDotColSumExpr(expr_id=node.expr_id, x=x, y=y, w=w, tile_hint=node.tile_hint)
+
+  @staticmethod
+  def match(node):
+    import numpy as np
+    from .. import context
+    from ..array import distarray
+    import importlib
+    from . import builtins
+    dot_mod = importlib.import_module(__package__ + '.dot')      # (the package attribute `dot` is the builder)
+    from .local import LocalMapExpr
+    from .map import Map2Expr
+    if not context.initialized() or getattr(context.get().backend, 'rowdot_colsum', None) is None:
+      return None
+    if node.axis != 0 or node.accumulate_fn is not np.add or node.op.fn is not builtins._sum_local:
+      return None
+    data = [d for d in node.op.deps if not isinstance(d, LocalInput)]
+    if len(data) != 1 or not isinstance(data[0], LocalMapExpr) or data[0].fn is not np.multiply or len(data[0].deps) != 2:
+      return None
+    by_var = dict(zip(node.child_to_var, node.children))
+
+    def leaf(d):
+      return by_var.get(d.idx) if isinstance(d, LocalInput) else None
+
+    def as_x(e):
+      v = e.val if isinstance(e, Val) else None
+      if not isinstance(v, distarray.DistArrayImpl) or v.sparse or len(v.shape) != 2 or v.dtype != np.float32:
+        return None
+      cols = v.shape[1]
+      if cols < 4 or cols > 4096 or cols % 4 or not all(t.ul[1] == 0 and t.lr[1] == cols for t in v.tiles):
+        return None
+      return e
+
+    def as_dot(e, x):
+      if not isinstance(e, Map2Expr) or e.fn is not dot_mod.dot_map2_np_mapper or tuple(e.axes) != (0,):
+        return None
+      arrays = list(e.arrays.vals)
+      w = (e.fn_kw or {}).get('array2')
+      if len(arrays) != 1 or arrays[0].expr_id != x.expr_id or e.update_region is not None:
+        return None
+      if not isinstance(w, np.ndarray) or w.dtype != np.float32 or w.shape not in ((x.val.shape[1], 1), (x.val.shape[1],)):
+        return None
+      return w
+
+    def as_y(e, x):
+      v = e.val if isinstance(e, Val) else None
+      if not isinstance(v, distarray.DistArrayImpl) or v.sparse or v.dtype != np.float32 or tuple(v.shape) != (x.val.shape[0], 1):
+        return None
+      return e
+
+    for a, b in (data[0].deps, data[0].deps[::-1]):
+      x = leaf(a) and as_x(leaf(a))
+      if not x:
+        continue
+      if isinstance(b, LocalInput):                      # x * dot(x, w)
+        w = as_dot(leaf(b), x)
+        if w is not None and (w.ndim == 2):
+          return x, w, None
+      elif isinstance(b, LocalMapExpr) and b.fn is np.subtract and len(b.deps) == 2:   # x * (dot(x, w) - y)
+        t, yv = leaf(b.deps[0]), leaf(b.deps[1])
+        if t is None or yv is None:
+          continue
+        w = as_dot(t, x)
+        y = as_y(yv, x)
+        if w is not None and w.ndim == 2 and y is not None:
+          return x, w, y
+    return None
+
+
 class CollapsedCachedExpressions(Pass):
   """A subtree whose value already exists is replaced by that value."""
   name = 'collapse_cached'
@@ -211,7 +296,8 @@ class RotateSlice(Pass):
 def _passes():
   from .tiling import AutomaticTiling   # (imports this module)
   return (('opt_collapse_cached', CollapsedCachedExpressions), ('opt_auto_tiling', AutomaticTiling),
-          ('opt_rotate_slice', RotateSlice), ('opt_map_fusion', MapMapFusion), ('opt_reduce_fusion', ReduceMapFusion))
+          ('opt_rotate_slice', RotateSlice), ('opt_map_fusion', MapMapFusion), ('opt_reduce_fusion', ReduceMapFusion),
+          ('opt_rowdot_fusion', RowDotColSumFusion))
 
 
 def optimize(dag):

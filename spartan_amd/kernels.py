@@ -135,6 +135,25 @@ def gemm_f32(a, b, c, accumulate=False):
   return c
 
 
+def rowdot_colsum(x, w, y, out, accumulate=False):
+  """out[c] (+)= sum_i x[i, c] * (x[i, :] . w - y[i]) in one pass over the fp32 row tile x [n, d] (y may be None);
+  False when the operands do not meet sp_rowdot_colsum_f32's layout (the caller then takes the two-launch form)."""
+  _require_device(x, w, out)
+  n, d = x.shape
+  lib = _hip.lib()
+  need = lib.sp_rowdot_colsum_workspace_bytes(n, d) if n else 256
+  ldx = x.stride(0) if n > 1 else d
+  if (not need or x.stride(1) != 1 or ldx % 4 or (x.data_ptr() | w.data_ptr() | out.data_ptr()) % 16
+      or any(np_dtype_of(t) != np.float32 for t in (x, w, out) + ((y,) if y is not None else ()))):
+    return False
+  ws = _ws.get(need, x.device)
+  check(lib.sp_rowdot_colsum_f32(C.c_void_p(x.data_ptr()), ldx, n, d, C.c_void_p(w.data_ptr()),
+                                 C.c_void_p(y.data_ptr() if y is not None else 0),
+                                 (y.stride(0) if y is not None and n > 1 else 1), C.c_void_p(out.data_ptr()),
+                                 1 if accumulate else 0, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
+  return True
+
+
 gemm = gemm_f32   # dtype-dispatching: fp32 -> sp_gemm_f32, fp64 -> sp_gemm_f64
 
 

@@ -846,3 +846,70 @@ def test_jit_code_objects_persist_across_processes(tmp_path):
   assert p3.returncode == 0, p3.stderr[-2000:]
   assert 'preloaded' in p3.stderr and ' compiled ' not in p3.stderr and 'loaded sp_map_kernel' not in p3.stderr, p3.stderr[-2000:]
   assert p3.stdout.strip().splitlines()[-1] == outs[0].stdout.strip().splitlines()[-1]
+
+
+# ---- one-pass least-squares gradient (rowdot.hip) ------------------------------------------------
+@pytest.mark.parametrize('n,d,pad', [(1000, 4096, 0), (257, 64, 0), (5, 260, 4), (3000, 4092, 8), (1, 4, 0), (70000, 512, 0)])
+@pytest.mark.parametrize('with_y', [True, False])
+def test_rowdot_colsum_kernel(n, d, pad, with_y):
+  """out[c] = sum_i x[i, c] * (x[i, :] . w - y[i]) against float64 NumPy: the error of an fp32 row dot of d terms
+  carried through a column sum of n terms; rows in a padded buffer; `accumulate`; identical bits on every run."""
+  x = (RNG.rand(n, d) - 0.5).astype(np.float32)
+  w = (RNG.rand(d) - 0.5).astype(np.float32)
+  y = (RNG.rand(n) - 0.5).astype(np.float32) if with_y else None
+  big = D.zeros((n, d + pad), np.float32)
+  big[:, :d] = dev(x)
+  xd = big[:, :d]
+  out = D.full((d,), 3.0, np.float32)
+  assert kernels.rowdot_colsum(xd, dev(w), dev(y) if with_y else None, out)
+  x64 = x.astype(np.float64)
+  t = x64.dot(w.astype(np.float64))
+  r = t - y if with_y else t
+  want = (x64 * r[:, None]).sum(0)
+  scale = (np.abs(x64) * (np.abs(x64).dot(np.abs(w.astype(np.float64))) + (np.abs(y) if with_y else 0))[:, None]).sum(0)
+  eps = np.finfo(np.float32).eps
+  got = host(out)
+  assert np.all(np.abs(got - want) <= (d + n + 8) * eps * scale + 1e-30)
+  first = got.copy()
+  assert kernels.rowdot_colsum(xd, dev(w), dev(y) if with_y else None, out)
+  np.testing.assert_array_equal(host(out), first)
+  assert kernels.rowdot_colsum(xd, dev(w), dev(y) if with_y else None, out, accumulate=True)
+  np.testing.assert_array_equal(host(out), first + first)
+  # layouts the kernel does not take are reported, not guessed at
+  if d > 4:
+    assert kernels.rowdot_colsum(big[:, 1:d - 3], dev(w[:d - 4]), None, D.empty((d - 4,), np.float32)) is False
+
+
+def test_lreg_gradient_runs_as_one_pass_per_tile():
+  """examples.lreg through the expression API: the gradient DAG is rewritten (expr/rowdot.py) and each step is one
+  pass over a row tile; the weights agree with the two-launch form (rewrite off) to rounding."""
+  import importlib
+  import spartan_amd as sp
+  from spartan_amd.examples import lreg
+  from spartan_amd.expr.rowdot import RowDotColSumExpr
+  optimize = importlib.import_module('spartan_amd.expr.optimize')
+  ctx = sp.initialize('hip', num_workers=3)
+  try:
+    rng = np.random.RandomState(4)
+    xh, yh = rng.rand(3001, 256).astype(np.float32), rng.rand(3001, 1).astype(np.float32)
+    w = rng.rand(256, 1).astype(np.float32)
+    x, y = sp.Val(val=sp.from_numpy(xh).force()), sp.Val(val=sp.from_numpy(yh).force())
+    g = lreg.gradient(x, y, w).optimized()
+    assert isinstance(g, RowDotColSumExpr)
+    calls = []
+    inner = ctx.backend.rowdot_colsum
+    ctx.backend.rowdot_colsum = lambda *a: (calls.append(1), inner(*a))[1]
+    got = g.glom()
+    del ctx.backend.rowdot_colsum
+    assert len(calls) == len(x.val.tiles)                            # one pass per row tile
+    want = (xh.astype(np.float64) * (xh.astype(np.float64).dot(w.astype(np.float64)) - yh)).sum(0)
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    w1 = lreg.fit(x, y, 10, alpha=1e-5, w=w)
+    optimize.FLAGS['opt_rowdot_fusion'] = False
+    try:
+      w0 = lreg.fit(x, y, 10, alpha=1e-5, w=w)
+    finally:
+      optimize.FLAGS['opt_rowdot_fusion'] = True
+    np.testing.assert_allclose(w1, w0, rtol=1e-5, atol=2e-6)      # fp32 sums in two different orders, ten steps
+  finally:
+    sp.shutdown()
