@@ -183,6 +183,32 @@ def run_sort(workers):
   return 2
 
 
+def run_rowdot(ctx):
+  """The one-pass gradient node (expr/rowdot.py) across ranks: every rank's row tiles contribute a (d,) partial that
+  joins the target like a reduction's.  On the oracle backend the kernel is a NumPy stand-in attached for this check
+  only (the rewrite never fires without one)."""
+  from spartan_amd.examples import lreg
+  from spartan_amd.expr.rowdot import RowDotColSumExpr
+  rng = np.random.RandomState(11)
+  xh, yh = rng.rand(101, 32).astype(np.float32), rng.rand(101, 1).astype(np.float32)
+  w = rng.rand(32, 1).astype(np.float32)
+  attached = not hasattr(ctx.backend, 'rowdot_colsum')
+  if attached:
+    def stand_in(x, wv, y):
+      t = x.dot(np.asarray(wv, np.float32).reshape(-1, 1))
+      return (x * (t if y is None else t - np.asarray(y).reshape(t.shape))).sum(0).astype(np.float32)
+    ctx.backend.rowdot_colsum = stand_in
+  try:
+    x, y = sp.Val(val=sp.from_numpy(xh).force()), sp.Val(val=sp.from_numpy(yh).force())
+    g = lreg.gradient(x, y, w).optimized()
+    assert isinstance(g, RowDotColSumExpr)
+    np.testing.assert_allclose(g.glom(), (xh * (xh.dot(w) - yh)).sum(0), rtol=2e-5)
+  finally:
+    if attached:
+      del ctx.backend.rowdot_colsum
+  return 1
+
+
 def main():
   workers = int(sys.argv[1])
   use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
@@ -251,6 +277,7 @@ def main():
   n += run_auto_tiling(world)
   n += run_sort(workers)
   n += run_masked_fetch(world)
+  n += run_rowdot(ctx)
   if not use_hip:
     n += run_heartbeat(world)
   world.barrier()
