@@ -18,7 +18,7 @@ echo "traced bench rc=$?"
 for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $ctr | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_head_$tag --output-format csv -o p -- python $R/bench.py --no-extras --steps 3 --warmup 1 > /dev/null 2> $OUT/pmc_head_$tag.err
-  rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_work_$tag --output-format csv -o p -- python $R/bench.py --steps 1 --warmup 0 --only hbm,kmeans,sparse > /dev/null 2> $OUT/pmc_work_$tag.err
+  rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_work_$tag --output-format csv -o p -- python $R/bench.py --steps 1 --warmup 0 --only hbm,lreg,kmeans,sparse > /dev/null 2> $OUT/pmc_work_$tag.err
 done
 cd $R
 python tools/roofline.py --trace "$OUT/trace/**/*kernel_trace.csv" --bench $OUT/bench_traced.json --pmc $OUT/pmc_head_* $OUT/pmc_work_* \
