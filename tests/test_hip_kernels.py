@@ -913,3 +913,30 @@ def test_lreg_gradient_runs_as_one_pass_per_tile():
     np.testing.assert_allclose(w1, w0, rtol=1e-5, atol=2e-6)      # fp32 sums in two different orders, ten steps
   finally:
     sp.shutdown()
+
+
+@pytest.mark.parametrize('workers', [1, 8])
+@pytest.mark.parametrize('n,d', [(17, 4), (1000, 4096), (5000, 132), (64, 260)])
+def test_lreg_gradient_rewrite_shapes(workers, n, d):
+  """The rewritten gradient through the expression API on ragged row tilings and the smallest / largest widths,
+  with and without y, against float64 NumPy."""
+  import spartan_amd as sp
+  from spartan_amd.expr.rowdot import RowDotColSumExpr
+  sp.initialize('hip', num_workers=workers)
+  try:
+    rng = np.random.RandomState(n + d)
+    xh, yh = (rng.rand(n, d) - 0.5).astype(np.float32), (rng.rand(n, 1) - 0.5).astype(np.float32)
+    w = (rng.rand(d, 1) - 0.5).astype(np.float32)
+    x, y = sp.Val(val=sp.from_numpy(xh).force()), sp.Val(val=sp.from_numpy(yh).force())
+    x64, w64 = xh.astype(np.float64), w.astype(np.float64)
+    for build, want in ((lambda: sp.sum(x * (sp.dot(x, w) - y), axis=0), (x64 * (x64.dot(w64) - yh)).sum(0)),
+                        (lambda: sp.sum((sp.dot(x, w) - y) * x, axis=0), (x64 * (x64.dot(w64) - yh)).sum(0)),
+                        (lambda: sp.sum(x * sp.dot(x, w), axis=0), (x64 * x64.dot(w64)).sum(0))):
+      e = build().optimized()
+      assert isinstance(e, RowDotColSumExpr)
+      got = e.glom()
+      assert got.dtype == np.float32 and got.shape == (d,)
+      scale = (np.abs(x64) * (np.abs(x64).dot(np.abs(w64)) + np.abs(yh))).sum(0)
+      assert np.all(np.abs(got - want) <= (n + d + 8) * np.finfo(np.float32).eps * scale + 1e-30)
+  finally:
+    sp.shutdown()
