@@ -15,7 +15,11 @@ read once by the kernel.
 The observable results are the reference's, pinned by tests/golden/fusion_golden.json: the fused operator trees
 print identically and have the same inputs.
 """
+import importlib
+import sys
 import weakref
+
+import numpy as np
 
 from .base import AsArray, Expr, ListExpr, NotShapeable, Val, expr_like, lazify
 from .local import LocalInput, LocalMapLocationExpr, LocalReduceExpr, make_var
@@ -177,14 +181,13 @@ class RowDotColSumFusion(Pass):
 
   @staticmethod
   def match(node):
-    import numpy as np
     from .. import context
     from ..array import distarray
-    import importlib
     from . import builtins
-    dot_mod = importlib.import_module(__package__ + '.dot')      # (the package attribute `dot` is the builder)
     from .local import LocalMapExpr
     from .map import Map2Expr
+    dot_mod = sys.modules.get(__package__ + '.dot') or importlib.import_module(__package__ + '.dot')   # (the package
+    # attribute `dot` is the builder, not the module)
     if not context.initialized() or getattr(context.get().backend, 'rowdot_colsum', None) is None:
       return None
     if node.axis != 0 or node.accumulate_fn is not np.add or node.op.fn is not builtins._sum_local:
