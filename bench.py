@@ -340,6 +340,79 @@ def dist_section(ctx):
   return out
 
 
+def lreg_dist_section(ctx):
+  """N > 1: BASELINE configs[4] -- X 1 000 000 x 4096 fp32 row-tiled over the N GPUs (strong scaling: rows / N per
+  GPU), 100 gradient steps after 2 untimed ones through examples/lreg.fit: per step one pass over the rank's rows,
+  the (D,) partial gradients combined by reduce-scatter + all-gather (glom), w updated on every rank's driver."""
+  from spartan_amd.examples import lreg
+  p = ctx.world.size
+  N = int(os.environ.get('SPARTAN_BENCH_LREG_ROWS', '1000000'))
+  Dm = int(os.environ.get('SPARTAN_BENCH_LREG_COLS', '4096'))
+  N -= N % p
+  hint = (N // p, Dm)
+  Xl = sp.from_tile_fn((N, Dm), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 11), tile_hint=hint).force()
+  yl = sp.from_tile_fn((N, 1), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 12), tile_hint=(N // p, 1)).force()
+  Xv, yv = sp.Val(val=Xl), sp.Val(val=yl)
+  w = ctx.world.broadcast_object(np.random.RandomState(SEED).rand(Dm, 1).astype(np.float32), 0)
+  alpha = 1e-11
+  w = lreg.fit(Xv, yv, 2, alpha=alpha, w=w)
+  steps = int(os.environ.get('SPARTAN_BENCH_LREG_STEPS', '100'))
+  box = [w]
+
+  def run():
+    box[0] = lreg.fit(Xv, yv, 1, alpha=alpha, w=box[0])
+  dt = time_steps(ctx, run, steps, 0)
+  return {'array': '%d x %d fp32, %d row tiles of %d rows (configs[4], strong scaling)' % (N, Dm, p, N // p),
+          'steps': steps, 'warmup_steps': 2, 'ms_per_step': round(dt / steps * 1e3, 4),
+          'two_pass_equivalent_GBps': round(steps * 2 * 4.0 * N * Dm / dt / 1e9, 1),
+          'streamed_GBps': round(steps * 4.0 * N * Dm / dt / 1e9, 1),
+          'weights_finite': bool(np.isfinite(box[0]).all())}
+
+
+def kmeans_dist_section(ctx):
+  """N > 1: BASELINE configs[3] -- 10 000 000 x 256 fp32 points row-tiled over the N GPUs, k = 1024: 10 timed
+  Lloyd iterations after 2 untimed ones through KMeans.fit ('map2', reducer np.add): assign + accumulate per tile,
+  counts and sums combined across the ranks, centers re-derived on every rank's driver."""
+  from spartan_amd.examples.sklearn.cluster import KMeans
+  p = ctx.world.size
+  n = int(os.environ.get('SPARTAN_BENCH_KMEANS_POINTS', '10000000'))
+  k, d = int(os.environ.get('SPARTAN_BENCH_KMEANS_K', '1024')), 256
+  n -= n % p
+  X = sp.from_tile_fn((n, d), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 21), tile_hint=(n // p, d)).force()
+  Xv = sp.Val(val=X)
+  box = [ctx.world.broadcast_object(np.random.RandomState(SEED).rand(k, d), 0)]
+
+  def run():
+    box[0], _ = KMeans(k, 1).fit(Xv, box[0], implementation='map2', reducer=np.add)
+  dt = time_steps(ctx, run, 10, 2)
+  return {'array': '%d x %d fp32 points, k=%d, %d row tiles of %d rows (configs[3], strong scaling)' % (n, d, k, p, n // p),
+          'iterations': {'timed': 10, 'warmup': 2}, 'iteration_ms': round(dt * 1e2, 3),
+          'assign_TFLOPs_whole_job_incl_everything': round(10 * 2.0 * n * k * d / dt / 1e12, 1)}
+
+
+def rccl_report(world):
+  """What carried the tile payloads between the ranks: `ranks` is the size of the RCCL communicator every rank
+  joined and self-tested (0 when the job ran on the staged debug transport)."""
+  import ctypes
+  t = world.transport
+  v = ctypes.c_int(0)
+  version = None
+  try:
+    if _hip.lib().sp_comm_available() and _hip.lib().sp_comm_version(ctypes.byref(v)) == 0:
+      version = v.value
+  except Exception:
+    pass
+  if getattr(t, 'name', '') == 'rccl':
+    return {'ranks': t.size, 'version': version, 'self_test': 'passed', 'visible_gpus': comm_gpu_count()}
+  return {'ranks': 0, 'version': version, 'self_test': 'not run: transport is %s (ranks share devices)' % getattr(t, 'name', '?'),
+          'visible_gpus': comm_gpu_count()}
+
+
+def comm_gpu_count():
+  from spartan_amd import comm
+  return comm.gpu_count()
+
+
 def guarded(fn, timeout_s, rank, fallback_line):
   """Run an informational section under a deadline.  If it does not come back (a collective that never completes)
   rank 0 still prints the line it has -- the headline was measured before this section -- with the failure in
@@ -554,6 +627,82 @@ def measured_traffic(n):
                'of this kernel and shape; algorithmic floor %d bytes' % (sha, 12 * n * n))
 
 
+def _free_port():
+  import socket
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def self_launch(n, argv, deadline_s):
+  """`python3 bench.py --gpus N` as a plain process: start the N ranks ourselves (RANK / LOCAL_RANK / WORLD_SIZE /
+  MASTER_ADDR / a free MASTER_PORT -- what torch.distributed.run would set; the reference's bench runner starts its
+  own workers too, tests/test_common.py:86-125), hand rank 0's one JSON line through, and exit non-zero with the
+  reason in a line of the same shape if any rank fails or the deadline passes.  With fewer visible GPUs than ranks
+  the ranks share devices over the staged debug transport and the line says so (`rccl.ranks` = 0): a functional
+  run, not a scaling measurement."""
+  import subprocess
+  import tempfile
+  from spartan_amd import comm
+  gpus = comm.gpu_count()
+  port = _free_port()
+  base = dict(os.environ)
+  base.update({'WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+               'SPARTAN_BENCH_LAUNCHER': 'self', 'SPARTAN_BENCH_VISIBLE_GPUS': str(gpus)})
+  if gpus < n and 'SPARTAN_DIST_BACKEND' not in base:
+    base['SPARTAN_DIST_BACKEND'] = 'gloo'        # RCCL wants one device per rank
+  out0 = tempfile.TemporaryFile()
+  procs = []
+  for rank in range(n):
+    env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                  stdout=out0 if rank == 0 else subprocess.DEVNULL))
+  t_end = time.time() + deadline_s
+  why = None
+  while why is None:
+    codes = [q.poll() for q in procs]
+    bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+    if bad:
+      why = 'rank %d exited with code %d' % bad[0]
+    elif all(c == 0 for c in codes):
+      break
+    elif time.time() > t_end:
+      why = 'deadline of %d s passed (ranks still running: %s)' % (deadline_s, [r for r, c in enumerate(codes) if c is None])
+    else:
+      time.sleep(0.05)
+  if why is not None:
+    time.sleep(1.0)                       # a rank that saw its peer die reports on its own
+    for q in procs:
+      if q.poll() is None:
+        q.kill()                          # the exact children started above
+    for q in procs:
+      q.wait()
+  out0.seek(0)
+  text = out0.read().decode('utf-8', 'replace').strip()
+  last = text.splitlines()[-1] if text else ''
+  if why is None:
+    try:
+      json.loads(last)
+    except ValueError:
+      why = 'rank 0 printed no JSON line'
+  if why is None:
+    os.write(1, (last + '\n').encode())
+    return 0
+  line = {'metric': 'spartan.dot TFLOP/s (+ map/reduce HBM GB/s)', 'value': None, 'unit': 'TFLOP/s', 'n_gpus': n,
+          'higher_is_better': True, 'error': 'FAILED: ' + why, 'launcher': 'bench.py self-launch, %d ranks on %d visible GPUs' % (n, gpus)}
+  try:
+    part = json.loads(last)               # a watchdog line from rank 0 (headline measured, an extra hung)
+    part.setdefault('extras_error', line['error'])
+    part['error'] = line['error']
+    line = part
+  except ValueError:
+    pass
+  os.write(1, (json.dumps(line) + '\n').encode())
+  return 1
+
+
 _REAL_STDOUT = None
 
 
@@ -577,20 +726,22 @@ def _emit(line, rank):
 
 
 def main():
-  _claim_stdout()
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--size', type=int, default=0, help='matrix order (default: 8192 on one GPU, 32768 on several)')
   ap.add_argument('--no-extras', action='store_true', help='headline only: skip the HBM / workload / emulation / CPU sections')
-  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,lreg,kmeans,sparse,ksplit,cpu)')
+  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,lreg,kmeans,sparse,ksplit,cpu; N > 1: hbm_dist,lreg_dist,kmeans_dist)')
+  ap.add_argument('--deadline', type=int, default=1500, help='seconds the self-launched ranks of --gpus N > 1 may take')
   args = ap.parse_args()
 
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(self_launch(args.gpus, sys.argv[1:], args.deadline))      # plain `python3 bench.py --gpus N`
+  _claim_stdout()
   world = sp.World.from_env()
   if world.size != args.gpus:
-    raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)'
-                     % (args.gpus, world.size, args.gpus))
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world.size))
   ctx = sp.initialize('hip', world=world)
   p = world.size
   n = args.size or (8192 if p == 1 else NORTH_STAR)
@@ -711,11 +862,18 @@ def main():
   if world.distributed:
     line['comm'] = dict(world.stats)
     line['comm']['transport'] = world.note or getattr(world.transport, 'name', '?')
-    if not args.no_extras:
-      del keep[:]
-      del A, B
-      D.trim_pool()
-      line['hbm_dist'] = guarded(lambda: dist_section(ctx), 240, world.rank, dict(line))
+    line['rccl'] = rccl_report(world)
+    line['launcher'] = ('bench.py self-launch' if os.environ.get('SPARTAN_BENCH_LAUNCHER') == 'self'
+                        else 'torch.distributed.run (RANK / WORLD_SIZE from the environment)')
+    if line['rccl']['ranks'] != p:
+      line['valid_scaling_measurement'] = False      # ranks share devices over the staged debug transport
+    del keep[:]
+    del A, B
+    D.trim_pool()
+    for name, section in (('hbm_dist', dist_section), ('lreg_dist', lreg_dist_section), ('kmeans_dist', kmeans_dist_section)):
+      if want(name):
+        line[name] = guarded(lambda: section(ctx), 300, world.rank, dict(line))
+        D.trim_pool()
   world.barrier()
   _emit(line, world.rank)
   sp.shutdown()

@@ -93,3 +93,37 @@ def test_world_counts_and_one_rank_world():
   w = comm.World()
   assert not w.distributed and w.transport is None
   assert w.broadcast_object({'a': 1}, 0) == {'a': 1} and w.all_gather_object(3) == [3]
+
+
+def test_bench_launches_its_own_ranks():
+  """`python3 bench.py --gpus 2` as a PLAIN process (no torch.distributed.run): the script starts its two ranks
+  itself; on this one-GPU box they share the device over the staged debug transport, and the one JSON line says
+  so (`rccl.ranks` == 0, `valid_scaling_measurement` false) -- on a multi-GPU node the same command yields the
+  RCCL run."""
+  import json
+  env = dict(os.environ, SPARTAN_BENCH_DIST_ROWS='256', SPARTAN_BENCH_LREG_ROWS='4096', SPARTAN_BENCH_LREG_COLS='256',
+             SPARTAN_BENCH_LREG_STEPS='3', SPARTAN_BENCH_KMEANS_POINTS='8192', SPARTAN_BENCH_KMEANS_K='64')
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '2048', '--steps', '2',
+                        '--warmup', '1'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+  text = out.stdout.decode('utf-8', 'replace').strip()
+  assert out.returncode == 0, (text[-2000:], out.stderr.decode('utf-8', 'replace')[-3000:])
+  lines = text.splitlines()
+  assert len(lines) == 1, 'stdout must carry exactly one line, got %d' % len(lines)
+  line = json.loads(lines[0])
+  assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0
+  assert line['launcher'].startswith('bench.py self-launch')
+  assert line['rccl']['ranks'] in (0, 2)
+  if line['rccl']['ranks'] == 0:
+    assert line['valid_scaling_measurement'] is False
+  for key in ('dot_breakdown', 'hbm_dist', 'lreg_dist', 'kmeans_dist'):
+    assert key in line and 'error' not in line[key], (key, line.get(key))
+
+
+def test_bench_launcher_reports_a_failed_rank():
+  """A rank that dies gives rc != 0 and the reason in the line (here: an order the ranks cannot split)."""
+  import json
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '2049', '--steps', '1',
+                        '--no-extras'], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+  assert out.returncode != 0
+  line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+  assert line['value'] is None and 'FAILED' in line['error']

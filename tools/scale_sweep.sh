@@ -11,12 +11,11 @@ mkdir -p "$OUT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 run() {  # run <n> <tag> [env assignments...]
   local n=$1 tag=$2; shift 2
+  # the plain form: bench.py starts its own N ranks (torch.distributed.run ... bench.py --gpus N works as well)
   if [ "$n" = 1 ]; then
     env "$@" python "$ROOT/bench.py" --gpus 1 > "$OUT/n${n}_$tag.json" 2> "$OUT/n${n}_$tag.err"
   else
-    env "$@" python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 \
-      --master-port $((29500 + RANDOM % 400)) "$ROOT/bench.py" --gpus "$n" --steps 10 --warmup 2 \
-      > "$OUT/n${n}_$tag.json" 2> "$OUT/n${n}_$tag.err"
+    env "$@" python "$ROOT/bench.py" --gpus "$n" --steps 10 --warmup 2 > "$OUT/n${n}_$tag.json" 2> "$OUT/n${n}_$tag.err"
   fi
   python - "$OUT/n${n}_$tag.json" "$n" "$tag" <<'PY'
 import json, sys
