@@ -108,6 +108,37 @@ def join_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target):
   return LocalKernelResult(result=[])
 
 
+def region_join_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target, region):
+  """One tile of a join that REWRITES regions of arrays[0] (reference region_join_mapper, map.py:208-241; its only
+  user is the blocked Cholesky factorisation).  axes[0] is a LIST of axes: tile `ex` of arrays[0] is re-read as the
+  cell with the same number of a grid over those axes.  The target gets that cell unchanged -- unless the cell meets
+  one of the `region` boxes: then the user function is called with the cell and, from every further array, the slab
+  whose range on ITS join axis (an int, or None: the whole array) equals the cell's range on grid axis i-1; the
+  function returns ONE (extent, data) pair and `data` overwrites the cell's part under the first box it meets."""
+  ctx = context.get()
+  cell = extent.change_partition_axis(ex, axes[0])
+  data = arrays[0].fetch(cell)
+  for box in region:
+    hit = extent.intersection(box, cell)
+    if not hit:
+      continue
+    extents, slabs = [cell], [data]
+    for i, (arr, axis) in enumerate(zip(arrays[1:], axes[1:])):
+      ul, lr = [0] * len(arr.shape), list(arr.shape)
+      if axis is not None:
+        ul[axis], lr[axis] = cell.ul[axes[0][i]], cell.lr[axes[0][i]]
+      extents.append(extent.create(ul, lr, arr.shape))
+      slabs.append(arr.fetch(extents[-1]))
+    _, value = local_user_fn(extents, slabs, **(local_user_fn_kw or {}))
+    if not isinstance(data, distarray.Absent):       # the rank that runs this worker's kernels
+      be = ctx.backend
+      data = be.copy(data)                           # the fetched cell may be a view of the source tile
+      be.assign_box(data, extent.offset_slice(cell, hit), value)
+    break
+  target.update(cell, data, wait=False)
+  return LocalKernelResult(result=[])
+
+
 class Map2Expr(Expr):
   """A join of arrays on chosen axes whose per-tile function writes into a new target array."""
   members = ('arrays', 'axes', 'fn', 'fn_kw', 'shape_', 'update_region', 'tile_hint', 'dtype', 'reducer')
@@ -128,15 +159,17 @@ class Map2Expr(Expr):
 
   def _evaluate(self, ctx, deps):
     arrays = deps['arrays']
-    if self.update_region is not None:
-      raise NotImplementedError('map2(update_region=...) (region_join_mapper) is not on the tile path')
     both_sparse = len(arrays) > 1 and all(bool(getattr(a, 'sparse', False)) for a in arrays[:2])   # map.py:323
     target = distarray.create(self.shape_, self.dtype if self.dtype is not None else arrays[0].dtype,
                               sharder=None, reducer=self.reducer, tile_hint=self.tile_hint, sparse=both_sparse)
     # a mapper may know how to run its whole join as one pipeline of transfers and kernels when operands and
     # target are laid out regularly (dot: the K-split with its all-to-all and reduce-scatter, dot.ksplit_plan)
     plan = getattr(self.fn, 'collective_plan', None)
-    if plan is None or not plan(arrays, self.axes, target, self.fn_kw):
+    if self.update_region is not None:
+      arrays[0].foreach_tile(mapper_fn=region_join_mapper,
+                             kw=dict(arrays=arrays, axes=self.axes, local_user_fn=self.fn,
+                                     local_user_fn_kw=self.fn_kw, target=target, region=self.update_region))
+    elif plan is None or not plan(arrays, self.axes, target, self.fn_kw):
       arrays[0].foreach_tile(mapper_fn=join_mapper,
                              kw=dict(arrays=arrays, axes=self.axes, local_user_fn=self.fn,
                                      local_user_fn_kw=self.fn_kw, target=target))
@@ -152,5 +185,7 @@ def map2(arrays, axes=(), fn=None, fn_kw=None, shape=None, update_region=None,
   if fn is None or shape is None or (axes and len(axes) != len(arrays)):
     raise AssertionError('map2 needs fn, shape and one axis per array (or none)')
   nodes = TupleExpr(vals=tuple(a if isinstance(a, Expr) else base.lazify(a) for a in arrays))
+  if update_region is not None:
+    update_region = tuple(update_region) if util.is_iterable(update_region) else (update_region,)
   return Map2Expr(arrays=nodes, axes=axes, fn=fn, fn_kw=fn_kw, shape_=tuple(shape), update_region=update_region,
                   tile_hint=tile_hint, dtype=dtype, reducer=reducer)

@@ -712,7 +712,31 @@ def sparse_goldens(sp, workers):
   return arrays, meta
 
 
+def region_goldens(sp, workers):
+  """map2(update_region=...) -- region_join_mapper, map.py:208-241 -- run by the reference."""
+  sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+  from tests import region_programs
+  arrays = {}
+  for name, build in region_programs.programs():
+    start_cluster(sp, workers)
+    res = build(sp).evaluate()
+    arrays[name] = np.asarray(res.glom())
+    arrays[name + '__tiles'] = np.asarray(sorted([list(ex.ul) + list(ex.lr) + [int(tid.worker)] for ex, tid in res.tiles.items()]))
+  return arrays
+
+
 if __name__ == '__main__':
+  if '--region' in sys.argv:
+    if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
+      prepare_tree()
+      build_cython()
+    install_stubs()
+    sp = import_reference()
+    res = region_goldens(sp, 4)
+    np.savez_compressed(os.path.join(OUT, 'region_w4.npz'), **res)
+    print('workers 4 :', sorted(k for k in res if not k.endswith('__tiles')))
+    sys.stdout.flush()
+    os._exit(0)
   if '--sparse' in sys.argv:
     if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
       prepare_tree()
