@@ -33,13 +33,30 @@ from .expr.outer import outer  # noqa: F401
 from .expr.reduce import reduce  # noqa: F401
 from .expr.shuffle import shuffle  # noqa: F401
 from .expr.views import ravel, reshape, transpose  # noqa: F401  (also installs Expr.__getitem__/.T/.reshape)
-from .expr.assign import assign, region_map, retile, write  # noqa: F401
-from .expr.scan import scan  # noqa: F401
-from .expr.sort import argpartition, argsort, partition, sort  # noqa: F401
-from .expr.fio import from_file, from_file_parallel, load, partial_load, partial_unpickle, pickle, save, unpickle  # noqa: F401
-from .expr.tile_operation import tile_operation  # noqa: F401
-from .expr.checkpoint import checkpoint  # noqa: F401
-from .expr.stencil import _convolve, maxpool, stencil  # noqa: F401
+from .expr.write import write  # noqa: F401
+
+# Operators next to the tile path (outside section 8): not part of the default import; the names
+# resolve on first use (module __getattr__ below), their kernels live in libspartan_hip_extras.so.
+_EXTRAS = {
+    'scan': 'expr.scan', 'sort': 'expr.sort', 'argsort': 'expr.sort', 'partition': 'expr.sort',
+    'argpartition': 'expr.sort', 'from_file': 'expr.fio', 'from_file_parallel': 'expr.fio', 'load': 'expr.fio',
+    'partial_load': 'expr.fio', 'partial_unpickle': 'expr.fio', 'pickle': 'expr.fio', 'save': 'expr.fio',
+    'unpickle': 'expr.fio', 'tile_operation': 'expr.tile_operation', 'checkpoint': 'expr.checkpoint',
+    'stencil': 'expr.stencil', 'maxpool': 'expr.stencil', '_convolve': 'expr.stencil',
+}
+
+
+def __getattr__(name):
+  where = _EXTRAS.get(name)
+  if where is None:
+    raise AttributeError('module %r has no attribute %r' % (__name__, name))
+  import importlib
+  value = getattr(importlib.import_module('.' + where, __name__), name)
+  globals()[name] = value
+  from . import expr as _expr
+  setattr(_expr, name, value)          # the flat spartan.expr namespace (over the submodule of the same name)
+  return value
+
 
 # ndarray-style methods on expressions (spartan/expr/__init__.py:66-92)
 Expr.all = all
