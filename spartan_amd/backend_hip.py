@@ -308,15 +308,15 @@ class HipBackend(object):
     return out
 
   def call_local_fn(self, fn, args, kw, name='local function'):
-    """fn(*args) on device tiles; on host copies if the device tiles cannot answer it."""
+    """fn(*args) on device tiles; on host copies if the device tiles say they cannot answer it -- and only then:
+    D.DeviceTileCannot is raised by DevArray alone (lower.NotLowerable by the lowering of an operator it forwards),
+    so an exception of the user function's own is the user's error and propagates from its FIRST run (a function
+    with side effects is never run twice because of a bug in it)."""
     import warnings
     self.launches += 1
     try:
-      res = fn(*args, **kw)
-      if res is NotImplemented:
-        raise TypeError('NotImplemented')
-      return res
-    except (TypeError, NotImplementedError, AttributeError, lower.NotLowerable, IndexError):
+      return fn(*args, **kw)
+    except (D.DeviceTileCannot, lower.NotLowerable):
       pass
     self.host_round_trips += 1
     if fn not in self._warned_host:

@@ -270,6 +270,14 @@ class _HostCopy(object):
     return self._arr if dtype is None else self._arr.astype(dtype)
 
 
+class DeviceTileCannot(TypeError, AttributeError):
+  """A device tile was asked for something only a host ndarray can do (an attribute or NumPy function it does not
+  have, an index array, a ufunc method without a kernel).  Raised by DevArray itself and by nothing else, so that the
+  backend can tell "run this user function on host copies instead" (backend_hip.call_local_fn) from an error of the
+  user function's own.  A TypeError (what NumPy raises for an array-like it cannot dispatch on) and an AttributeError
+  (so that hasattr() probes keep working)."""
+
+
 # ------------------------------------------------------------------------------------------------ the array
 class DevArray(object):
   __slots__ = ('storage', 'offset', 'shape', 'strides', 'dtype', '__weakref__')
@@ -339,7 +347,7 @@ class DevArray(object):
     if not isinstance(idx, tuple):
       idx = (idx,)
     if any(isinstance(i, (DevArray, np.ndarray, list)) for i in idx):
-      raise TypeError('device arrays take basic indices only (integers, slices, None, ...)')
+      raise DeviceTileCannot('device arrays take basic indices only (integers, slices, None, ...)')
     n_real = sum(1 for i in idx if i is not None and i is not Ellipsis)
     if n_real > len(self.shape):
       raise IndexError('too many indices for a %d-d array' % len(self.shape))
@@ -596,13 +604,17 @@ class DevArray(object):
     if method == 'reduce' and ufunc in _UFUNC_REDUCE:
       axis = kw.get('axis', 0)
       return inputs[0]._reduce(_UFUNC_REDUCE[ufunc], axis, kw.get('keepdims', False), kw.get('dtype'))
-    return NotImplemented
+    raise DeviceTileCannot('no kernel behind %s.%s(%s) on a device array' % (ufunc.__name__, method, ', '.join(sorted(kw))))
 
   def __array_function__(self, func, types, args, kwargs):
     impl = _NP_FUNCTIONS.get(func)
     if impl is None:
-      return NotImplemented
+      raise DeviceTileCannot('numpy.%s is not implemented for device arrays' % getattr(func, '__name__', func))
     return impl(*args, **kwargs)
+
+  def __getattr__(self, name):
+    # (only reached for names the class does not define)
+    raise DeviceTileCannot('device arrays have no attribute %r' % name)
 
 
 _UFUNC_REDUCE = {np.add: 'SUM', np.multiply: 'PROD', np.maximum: 'MAX', np.minimum: 'MIN',
@@ -639,7 +651,7 @@ DevArray.__invert__ = _unary(np.logical_not)
 # -- the NumPy functions user mappers call on tiles -------------------------------------------------------------
 def _np_where(cond, a=None, b=None):
   if a is None and b is None:
-    raise NotImplementedError('np.where(cond) (index form) on a device array')
+    raise DeviceTileCannot('np.where(cond) (index form) on a device array')
   return _be().evaluate_fn(np.where, [cond, a, b], {}, None)
 
 
@@ -654,7 +666,7 @@ def _np_concatenate(arrays, axis=0, **kw):
 
 def _np_bincount(x, weights=None, minlength=0):
   if weights is not None:
-    raise NotImplementedError('np.bincount(weights=...) on a device array')
+    raise DeviceTileCannot('np.bincount(weights=...) on a device array')
   be = _be()
   k = max(int(minlength), int(x.max().item()) + 1 if x.size else 0)
   return be.bincount(x, k)

@@ -105,3 +105,49 @@ def test_scalars_and_edge_cases():
   np.testing.assert_array_equal(d.squeeze().numpy(), a)
   np.testing.assert_array_equal(d[None, :, None].squeeze().numpy(), a)
   np.testing.assert_array_equal(d.swapaxes(0, 1).numpy(), a.swapaxes(0, 1))
+
+
+def test_device_tile_cannot_is_the_only_fallback_signal():
+  """What a device tile cannot do is said with ONE exception type, raised by DevArray alone: that (and nothing a user
+  function raises itself) is what sends a local function to host copies (backend_hip.call_local_fn)."""
+  d = host(np.arange(12, dtype=np.float32).reshape(3, 4))
+  with pytest.raises(D.DeviceTileCannot):
+    np.cumsum(d, axis=1)                    # a NumPy function without a kernel behind it
+  with pytest.raises(D.DeviceTileCannot):
+    d[np.array([0, 2])]                     # index arrays
+  with pytest.raises(D.DeviceTileCannot):
+    d.no_such_method
+  with pytest.raises(D.DeviceTileCannot):
+    np.add.accumulate(d)                    # a ufunc method without a kernel
+  assert not hasattr(d, 'no_such_method') and hasattr(d, 'reshape')
+  assert issubclass(D.DeviceTileCannot, TypeError) and issubclass(D.DeviceTileCannot, AttributeError)
+
+
+def test_call_local_fn_runs_a_failing_user_function_once():
+  """A bug in the user's function is the user's error: it propagates from the first run, the function is not run
+  again on host copies (a function with side effects would not be idempotent)."""
+  from spartan_amd import backend_hip
+  be = backend_hip.HipBackend.__new__(backend_hip.HipBackend)      # (no device: only the dispatch is under test)
+  be.launches = be.host_round_trips = 0
+  be._warned_host = set()
+  d = host(np.ones((2, 2), np.float32))
+  calls = []
+
+  def buggy(x):
+    calls.append(1)
+    return x.shape[5]                        # IndexError of the function's own
+
+  with pytest.raises(IndexError):
+    be.call_local_fn(buggy, [d], {})
+  assert len(calls) == 1 and be.host_round_trips == 0
+
+  def needs_host(x):
+    calls.append(2)
+    return np.cumsum(x, axis=0) if isinstance(x, np.ndarray) else x.cumsum(0)
+
+  with pytest.warns(RuntimeWarning, match='host copies'):
+    try:
+      be.call_local_fn(needs_host, [d], {})
+    except Exception:                        # (uploading the result needs the device library: not under test here)
+      pass
+  assert calls.count(2) == 2 and be.host_round_trips == 1
