@@ -121,23 +121,34 @@ class HipBackend(object):
     return self._run_map(v, tuple(t.shape))
 
   def cached_numpy(self, arr, slices):
-    """A (slice of a) driver-side NumPy operand, uploaded once (the reference
-    pickles it into every RunKernelReq, dot.py:172-187)."""
+    """A (slice of a) driver-side NumPy operand in HBM (the reference pickles it into every RunKernelReq,
+    dot.py:172-187).  All tiles of ONE top-level evaluation share one upload, found by object identity alone (the
+    driver does not run while an evaluation does).  Across evaluations the driver may have updated the array in place
+    (`w -= alpha * grad`), so the copy is re-used only while a content stamp says the bytes are the same; the stamp
+    is taken when the same object comes back in a LATER evaluation, not at the first upload -- an iterative driver
+    hands over a new array every step (`w = w - g * alpha`, `centers = sums / counts`) and never pays for a hash --
+    and arrays above 4 MiB are not hashed at all: one upload per evaluation."""
+    from . import context
+    ctx = context.get() if context.initialized() else None
+    epoch = ctx.eval_epoch if ctx is not None and ctx.eval_depth > 0 else None     # (a direct backend call: no epoch)
     key = (id(arr), tuple((s.start, s.stop) for s in slices))
     hit = self._np_cache.get(key)
-    # the driver may update the array in place between evaluations (`w -= alpha * grad`): the HBM copy is
-    # only re-used while the bytes are the same (the reference re-pickles the array into every request)
-    # An array object seen for the first time is uploaded without being hashed (an iterative driver hands over a new
-    # array every step: `w = w - g * alpha`, `centers = sums / counts`); the stamp is taken when the object comes back.
-    known = hit is not None and hit[0] is arr
-    stamp = _content_stamp(arr[slices]) if known and arr.nbytes <= (1 << 22) else None
-    if not known or stamp is None or hit[2] != stamp:
-      hit = (arr, self.from_numpy(arr[slices]), stamp)
-      self._np_cache[key] = hit
-      while len(self._np_cache) > 64:
-        self._np_cache.popitem(last=False)
+    if hit is not None and hit[0] is arr:
+      if epoch is not None and hit[3] == epoch:
+        self._np_cache.move_to_end(key)
+        return hit[1]
+      stamp = _content_stamp(arr[slices]) if arr.nbytes <= (1 << 22) else None
+      if stamp is not None and hit[2] == stamp:
+        self._np_cache[key] = (arr, hit[1], stamp, epoch)
+        self._np_cache.move_to_end(key)
+        return hit[1]
     else:
-      self._np_cache.move_to_end(key)
+      stamp = None
+    hit = (arr, self.from_numpy(arr[slices]), stamp, epoch)
+    self._np_cache[key] = hit
+    self._np_cache.move_to_end(key)
+    while len(self._np_cache) > 64:
+      self._np_cache.popitem(last=False)
     return hit[1]
 
   def reducer_name(self, fn):

@@ -76,6 +76,7 @@ class Context(object):
     self.failed_workers = builtins.set()              # (this module defines its own `set`)
     self._given = [0] * self.num_workers               # bytes of tiles handed to each worker so far (worker_scores)
     self.eval_depth = 0                               # nesting of Expr.evaluate (safe points are at depth 0)
+    self.eval_epoch = 0                               # number of the running top-level evaluation
 
   # -- placement --------------------------------------------------------------
   def rank_of(self, worker):

@@ -543,15 +543,21 @@ class DevArray(object):
       src = src.reshape(shape)
     return src
 
+  def _accumulator(self, dtype, what):
+    """NumPy's promotion for sum / prod: bool and small signed integers accumulate in int64; unsigned ones in uint64,
+    which has no device type (include/spartan_hip.h: sp_dtype) -- said with the sentinel instead of answering int64."""
+    if dtype is not None or self.dtype.kind not in 'bui' or self.dtype.itemsize >= 8:
+      return dtype
+    if self.dtype.kind == 'u':
+      raise DeviceTileCannot('%s of a %s tile accumulates in uint64, which device tiles do not have; '
+                             'pass dtype=np.int64' % (what, self.dtype))
+    return np.int64
+
   def sum(self, axis=None, dtype=None, keepdims=False, **kw):
-    if dtype is None and self.dtype.kind in 'bui' and self.dtype.itemsize < 8:
-      dtype = np.uint64 if self.dtype.kind == 'u' and self.dtype.itemsize == 8 else np.int64    # NumPy's sum promotion
-    return self._reduce('SUM', axis, keepdims, dtype)
+    return self._reduce('SUM', axis, keepdims, self._accumulator(dtype, 'sum'))
 
   def prod(self, axis=None, dtype=None, keepdims=False, **kw):
-    if dtype is None and self.dtype.kind in 'bui' and self.dtype.itemsize < 8:
-      dtype = np.int64
-    return self._reduce('PROD', axis, keepdims, dtype)
+    return self._reduce('PROD', axis, keepdims, self._accumulator(dtype, 'prod'))
 
   def max(self, axis=None, keepdims=False, **kw):
     return self._reduce('MAX', axis, keepdims)

@@ -127,6 +127,8 @@ class Expr(object):
   def evaluate(self):
     ctx = context.get()
     top = ctx.eval_depth == 0
+    if top:
+      ctx.eval_epoch += 1           # one number per top-level evaluation (what the tiles of one evaluation share)
     if top and ctx.heartbeat is not None and ctx.current_worker is None:
       ctx.apply_failures()          # safe point (once per top-level evaluation): workers declared silent lose their tiles
     ctx.eval_depth += 1

@@ -337,7 +337,13 @@ class AutomaticTiling(object):
     for t in top:
       self._add_edge(t, sink, 0)
     edges = [(u, v, c) for (u, v), c in self.edges.items()]
-    choice, total = solve(len(self.nodes), edges, self.groups)
+    try:
+      choice, total = solve(len(self.nodes), edges, self.groups)
+    except ImportError as e:       # _hip.HipLibraryMissing: the solver is native code of libspartan_hip.so
+      # without the built library (a CPU-only checkout driving the test backend) the pass is skipped -- every
+      # expression keeps the tiling it would have had with opt_auto_tiling off
+      self.report = {'skipped': str(e)}
+      return dag
     chosen = set(range(len(self.nodes)))
     for g, members in enumerate(self.groups):
       for s, n in enumerate(members):

@@ -32,6 +32,10 @@ class _LocalStore(object):
     with self._lock:
       return self._d.get(key)
 
+  def delete(self, key):
+    with self._lock:
+      self._d.pop(key, None)
+
 
 class _DistStore(object):
   """The process group's rendezvous store (TCPStore); reads of a key that was never set must not block."""
@@ -47,6 +51,12 @@ class _DistStore(object):
     if not self._store.check([key]):
       return None
     return self._store.get(key).decode()
+
+  def delete(self, key):
+    try:
+      self._store.delete_key(key)
+    except Exception:
+      pass
 
 
 class Heartbeat(object):
@@ -129,32 +139,64 @@ class Heartbeat(object):
     return out
 
   def agree(self, mine):
-    """Union of the verdicts of all ranks at this safe point, without a collective (a dead rank would never join
-    one): every rank posts its list under the number of the safe point -- the driver programs are SPMD, so the
-    numbers match -- and reads the others' with a deadline of interval * threshold seconds; a rank that posts
-    nothing in time is added to the verdict.  Ranks currently known to be silent are not waited for."""
+    """The verdict all ranks apply at this safe point, without a collective (a dead rank would never join one).  The
+    driver programs are SPMD, so the safe points carry the same number on every rank; under that number
+
+      phase 1  every rank posts the ranks ITS watcher declared silent and reads the post of EVERY other rank --
+               whatever its own watcher thinks of them: the set of posts read must not depend on a local clock --
+               until a deadline; a rank that posted nothing by then is added (dead or hung);
+      phase 2  every rank posts the union it arrived at and takes the union of all unions posted.  A rank that
+               reached the safe point late finds the others' posts still there, reads in them that it was given up
+               on, and applies that verdict to ITSELF like everyone else (its workers' tiles become bad tiles on
+               every rank including its own: the tile tables stay equal, the tiles are reloaded or recomputed).
+
+    The posts of safe point N - 2 are deleted when N is posted (one small key per rank and phase is alive at a time).
+    Deadlines are generous -- 3 x interval x threshold, at least `agree_floor_s`: a rank that is merely slow must
+    not be declared dead; a really dead one costs the survivors this wait once."""
     self._round = getattr(self, '_round', 0) + 1
-    mine = sorted(set(mine))
-    self.store.set('spartan_hb_agree/%d/%d' % (self._round, self.rank), ','.join(str(r) for r in mine) or '-')
-    verdict = set(mine)
-    waiting = [r for r in range(self.size) if r != self.rank and r not in self.failed_ranks]
-    # generous: a rank that is merely slow to reach the safe point must not be declared dead (a really dead one
-    # costs the survivors this wait once)
-    deadline = time.time() + max(3 * self.interval * self.threshold, self.agree_floor_s)
-    while waiting:
-      for r in list(waiting):
-        try:
-          value = self.store.get('spartan_hb_agree/%d/%d' % (self._round, r))
-        except Exception:
-          value = None
+    n = self._round
+    key = lambda phase, rnd, rank: 'spartan_hb_agree/%d/%d/%d' % (rnd, phase, rank)     # noqa: E731
+    if n > 2:
+      for phase in (1, 2):
+        self.store.delete(key(phase, n - 2, self.rank))
+    wait_s = max(3 * self.interval * self.threshold, self.agree_floor_s)
+
+    def post(phase, ranks):
+      self.store.set(key(phase, n, self.rank), ','.join(str(r) for r in sorted(ranks)) or '-')
+
+    def collect(phase, wait_for, also_read):
+      """Posts of phase `phase`: waits (with the deadline) for the ranks in wait_for, takes what is there of the
+      ranks in also_read; returns (union of what was read, ranks that never posted)."""
+      union, waiting, deadline = set(), list(wait_for), time.time() + wait_s
+      while waiting:
+        for r in list(waiting):
+          value = self._read(key(phase, n, r))
+          if value is not None:
+            union.update(int(x) for x in value.split(',') if x != '-')
+            waiting.remove(r)
+        if not waiting or time.time() > deadline:
+          break
+        time.sleep(0.001)
+      for r in also_read:
+        value = self._read(key(phase, n, r))
         if value is not None:
-          verdict.update(int(x) for x in value.split(',') if x != '-')
-          waiting.remove(r)
-      if not waiting:
-        break
-      if time.time() > deadline:
-        verdict.update(waiting)                # never reached the safe point: dead or hung
-        self.failed_ranks.update(waiting)
-        break
-      time.sleep(0.001)
+          union.update(int(x) for x in value.split(',') if x != '-')
+      return union, waiting
+
+    others = [r for r in range(self.size) if r != self.rank]
+    mine = set(mine)
+    post(1, mine)
+    seen, absent = collect(1, others, ())
+    union = mine | seen | set(absent)
+    post(2, union)
+    # the unions of the ranks this one still counts on are waited for; those it gave up on are read if they exist
+    final, absent2 = collect(2, [r for r in others if r not in union], [r for r in others if r in union])
+    verdict = union | final | set(absent2)
+    self.failed_ranks.update(r for r in verdict if r != self.rank)
     return sorted(verdict)
+
+  def _read(self, key):
+    try:
+      return self.store.get(key)
+    except Exception:
+      return None

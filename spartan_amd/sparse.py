@@ -276,22 +276,40 @@ def spmm(a, b, out=None, accumulate=False, plan=True):
   av = _cast(a.data, dtype)
   b2 = _cast(b2, dtype)
   m, n = a.shape[0], int(b2.shape[1])
+  # both kernels write rows of n consecutive values: a caller's strided `out` (a column of a wider matrix, a view
+  # with a step) is computed into a packed buffer and pasted over itself afterwards
+  strided_out = None
   if out is None:
     out = D.empty((m, n), dtype)
+  elif not out.is_contiguous():
+    strided_out, out = out, (out.contiguous() if accumulate else D.empty((m, n), dtype))
   if m and n:
     lib = _hip.lib()
-    if n == 1 and plan and dtype == a.dtype and b2.data_ptr() % 16 == 0:
+    if n == 1 and plan and dtype == a.dtype:
       bp = spmv_block_plan(a)
       if bp is not False:
+        # the blocked kernel reads x as ONE packed vector (include/spartan_hip.h: d_x contiguous): a (k, 1) view of
+        # a wider matrix -- X[:, 0:1], what Tile.get hands out -- or a vector with a step is packed first
+        xv = b2 if b2.is_contiguous() else b2.copy()
+        if xv.data_ptr() % 16:
+          xv = xv.copy()
         check(lib.sp_csr_spmv_blocked(_hip.sp_dtype(dtype), m, a.shape[1], a.nnz, _p(a.indptr), _p(bp),
-                                      C.c_void_p(b2.data_ptr()), C.c_void_p(out.data_ptr()), 1, 1 if accumulate else 0,
+                                      C.c_void_p(xv.data_ptr()), C.c_void_p(out.data_ptr()), 1, 1 if accumulate else 0,
                                       _stream()))
-        return out.reshape(m) if vec else out
+        return _spmm_result(out, strided_out, m, vec)
     ws = _ws.get(lib.sp_csr_spmm_workspace_bytes(a.nnz, n), a.device)
     check(lib.sp_csr_spmm(_hip.sp_dtype(dtype), m, a.shape[1], n, a.nnz, _p(a.indptr), _p(a.indices), _p(av),
                           C.c_void_p(b2.data_ptr()), _ld(b2) if b2.shape[0] > 1 else max(n, 1),
                           C.c_void_p(out.data_ptr()), n, 1 if accumulate else 0,
                           _p(spmv_plan(a)) if plan and n == 1 and a.nnz else C.c_void_p(0), _p(ws), ws.numel(), _stream()))
+  return _spmm_result(out, strided_out, m, vec)
+
+
+def _spmm_result(out, strided_out, m, vec):
+  if strided_out is not None:
+    from . import context
+    context.get().backend.paste(strided_out, tuple(slice(0, k) for k in strided_out.shape), out.reshape(strided_out.shape))
+    out = strided_out
   return out.reshape(m) if vec else out
 
 

@@ -151,3 +151,17 @@ def test_call_local_fn_runs_a_failing_user_function_once():
     except Exception:                        # (uploading the result needs the device library: not under test here)
       pass
   assert calls.count(2) == 2 and be.host_round_trips == 1
+
+
+def test_sum_prod_accumulator_dtypes_follow_numpy():
+  """The dtype table of ndarray.sum / prod (bool, int32 -> int64; floats and int64 unchanged); an unsigned tile
+  would accumulate in uint64, which no device tile can hold: the sentinel, not a silently different dtype."""
+  for dt in (np.bool_, np.int32, np.int64, np.float32, np.float64):
+    d = host(np.ones((2, 3), dt))
+    for what in ('sum', 'prod'):
+      want = getattr(np.ones((2, 3), dt), what)().dtype
+      acc = d._accumulator(None, what)
+      assert np.dtype(acc if acc is not None else dt) == want, (dt, what)
+  with pytest.raises(D.DeviceTileCannot):
+    host(np.ones((2, 3), np.uint8))._accumulator(None, 'sum')
+  assert host(np.ones((2, 3), np.uint8))._accumulator(np.int64, 'sum') == np.int64

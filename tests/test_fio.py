@@ -262,5 +262,28 @@ def test_heartbeat_second_failure_of_a_recovered_rank_and_agreement_without_the_
     [t.join(10) for t in ts]
     assert out[0] == out[1] == [1, 2], out                               # union of the posts + the rank that never came
     assert time.time() - t0 < 5
+    # (iii) a live rank that reaches the safe point AFTER the others gave up on it finds their posts, reads that it
+    # was given up on, and arrives at the same verdict (it marks its own workers' tiles bad like everyone else)
+    store = heartbeat._LocalStore()
+    hbs = [heartbeat.Heartbeat(C(r), interval=0.02, threshold=5, probe=lambda: True, store=store) for r in range(3)]
+    for h in hbs:
+      h.agree_floor_s = 0.4
+    hbs[0].failed_ranks.add(1)          # the local watchers disagree about rank 1: must not change who is read
+    out = [None, None, None]
+
+    def run3(i):
+      if i == 2:
+        time.sleep(1.2)
+      out[i] = hbs[i].agree([])
+    ts = [threading.Thread(target=run3, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join(10) for t in ts]
+    assert out[0] == out[1] == out[2] == [2], out
+    # (iv) the posts of old safe points are deleted: after many rounds the store holds two rounds' worth at most
+    for rnd in range(6):
+      ts = [threading.Thread(target=lambda i=i: hbs[i].agree([])) for i in range(3)]
+      [t.start() for t in ts]
+      [t.join(10) for t in ts]
+    assert len([k for k in store._d if k.startswith('spartan_hb_agree/')]) <= 2 * 2 * 3, sorted(store._d)
   finally:
     sp.shutdown()

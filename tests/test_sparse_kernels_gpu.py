@@ -355,7 +355,7 @@ def test_spmv_column_blocked_plan_refuses_unsorted_rows_and_small_tiles():
 def test_spmv_column_blocked_plan_ragged_shapes():
   """Row and column counts that are multiples of nothing (a partly filled last row block, a last slice of x narrower
   than the others and staged), a band of empty rows, a rectangular tile, and a vector that is not 16-byte aligned
-  (the stream kernel takes that one): all bit-identical to scipy."""
+  (packed into an aligned buffer first): all bit-identical to scipy."""
   rng = np.random.RandomState(77)
   m, k, deg = 100003, 90001, 9
   cols = np.repeat(np.arange(k, dtype=np.int64), deg)
@@ -380,3 +380,32 @@ def test_spmv_column_blocked_plan_ragged_shapes():
   else:
     # (row 43000 holds thousands of entries: the stream kernel adds it as per-chunk partial sums)
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-4)
+
+
+def test_spmv_column_blocked_plan_strided_operands():
+  """x as a column VIEW of a wider matrix (X[:, 1:2]: strides (4, 1) -- what Tile.get hands out), x as a vector with
+  a step, and a caller's `out` that is a column of a wider matrix: the blocked kernel wants packed vectors
+  (include/spartan_hip.h), so the host packs / pastes; values must be those of the packed operands."""
+  rng = np.random.RandomState(91)
+  n = 60000
+  a = _site_matrix(rng, n, 8, 2, 0.9)
+  A = S.from_scipy(a, DEV)
+  assert S.spmv_block_plan(A) is not False
+  wide = rng.standard_normal((n, 4)).astype(np.float32)
+  W = dev(wide)
+  col = W[:, 1:2]
+  assert not col.is_contiguous()
+  np.testing.assert_array_equal(S.spmm(A, col).numpy(), a @ wide[:, 1:2])
+  stepped = dev(wide.reshape(-1))[::4]                          # column 0 as a 1-D view with a step
+  np.testing.assert_array_equal(S.spmm(A, stepped).numpy(), a @ wide[:, 0])
+  np.testing.assert_array_equal(S.spmm(A, stepped.reshape(-1, 1)).numpy(), a @ wide[:, 0:1])
+  out_wide = dev(np.full((n, 3), 7, np.float32))
+  target = out_wide[:, 2:3]
+  got = S.spmm(A, col, out=target)
+  assert got.data_ptr() == target.data_ptr()
+  want = np.full((n, 3), 7, np.float32)
+  want[:, 2:3] = a @ wide[:, 1:2]
+  np.testing.assert_array_equal(out_wide.numpy(), want)
+  S.spmm(A, col, out=target, accumulate=True)
+  want[:, 2:3] = want[:, 2:3] + (a @ wide[:, 1:2])
+  np.testing.assert_array_equal(out_wide.numpy(), want)
