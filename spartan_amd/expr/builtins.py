@@ -341,6 +341,20 @@ def norm_cdf(v):
   return map(v, fn=scipy.stats.norm.cdf)
 
 
+# dtype rules of the reductions: module-level functions (the reference writes lambdas at the call sites; one object per
+# rule lets two DAGs built by the same calls be recognised as the same structure, expr/plan.py)
+def _same_dtype(input):
+  return input.dtype
+
+
+def _bool_dtype(input):
+  return np.bool_
+
+
+def _count_dtype(input):
+  return np.int64
+
+
 def _sum_local(ex, data, axis):
   """mathematics.py:126-127."""
   return data.sum(axis)
@@ -348,7 +362,7 @@ def _sum_local(ex, data, axis):
 
 def sum(x, axis=None, tile_hint=None):
   """mathematics.py:130-143."""
-  return reduce(x, axis=axis, dtype_fn=lambda input: input.dtype, local_reduce_fn=_sum_local,
+  return reduce(x, axis=axis, dtype_fn=_same_dtype, local_reduce_fn=_sum_local,
                 accumulate_fn=np.add, tile_hint=tile_hint)
 
 
@@ -382,13 +396,13 @@ def _min_local(ex, data, axis):
 
 def max(x, axis=None, tile_hint=None):
   """statistics.py:26-42."""
-  return reduce(x, axis=axis, dtype_fn=lambda input: input.dtype, local_reduce_fn=_max_local,
+  return reduce(x, axis=axis, dtype_fn=_same_dtype, local_reduce_fn=_max_local,
                 accumulate_fn=np.maximum, tile_hint=tile_hint)
 
 
 def min(x, axis=None, tile_hint=None):
   """statistics.py:45-61."""
-  return reduce(x, axis=axis, dtype_fn=lambda input: input.dtype, local_reduce_fn=_min_local,
+  return reduce(x, axis=axis, dtype_fn=_same_dtype, local_reduce_fn=_min_local,
                 accumulate_fn=np.minimum, tile_hint=tile_hint)
 
 
@@ -413,7 +427,7 @@ def _all_reducer(ex, tile, axis=None):
 
 def all(array, axis=None):
   """logic.py:29-34."""
-  return reduce(array, axis=axis, dtype_fn=lambda input: np.bool_, local_reduce_fn=_all_reducer,
+  return reduce(array, axis=axis, dtype_fn=_bool_dtype, local_reduce_fn=_all_reducer,
                 accumulate_fn=np.logical_and)
 
 
@@ -423,7 +437,7 @@ def _any_reducer(ex, tile, axis=None):
 
 def any(array, axis=None):
   """logic.py:41-46."""
-  return reduce(array, axis=axis, dtype_fn=lambda input: np.bool_, local_reduce_fn=_any_reducer,
+  return reduce(array, axis=axis, dtype_fn=_bool_dtype, local_reduce_fn=_any_reducer,
                 accumulate_fn=np.logical_or)
 
 
@@ -466,7 +480,7 @@ def _countnonzero_local(ex, data, axis):
 
 def count_nonzero(array, axis=None, tile_hint=None):
   """sorting.py:136-150."""
-  return reduce(array, axis, dtype_fn=lambda input: np.int64, local_reduce_fn=_countnonzero_local,
+  return reduce(array, axis, dtype_fn=_count_dtype, local_reduce_fn=_countnonzero_local,
                 accumulate_fn=np.add, tile_hint=tile_hint)
 
 
@@ -479,7 +493,7 @@ def _countzero_local(ex, data, axis):
 
 def count_zero(array, axis=None):
   """sorting.py:160-172."""
-  return reduce(array, axis, dtype_fn=lambda input: np.int64, local_reduce_fn=_countzero_local,
+  return reduce(array, axis, dtype_fn=_count_dtype, local_reduce_fn=_countzero_local,
                 accumulate_fn=np.add)
 
 

@@ -42,6 +42,8 @@ FLAGS = {
     # not a rewrite of the reference's: sum(x * (dot(x, w) - y), axis=0) in one pass over x (expr/rowdot.py), applied
     # only where the backend has the kernel
     'opt_rowdot_fusion': True,
+    # not a rewrite: DAGs with the structure of one seen before take its recorded result (expr/plan.py)
+    'opt_plan_cache': True,
 }
 
 # Results of builders whose value differs from call to call (rand, ...) must be computed exactly once: such a node
@@ -303,11 +305,20 @@ def _passes():
           ('opt_rowdot_fusion', RowDotColSumFusion))
 
 
-def optimize(dag):
-  """Apply the enabled passes in the reference's order (optimize.py:1093-1099)."""
-  if not FLAGS['optimization']:
-    return dag
+def _run_passes(dag):
   for flag, factory in _passes():
     if FLAGS[flag]:
       dag = factory().visit(dag)
   return dag
+
+
+def optimize(dag):
+  """Apply the enabled passes in the reference's order (optimize.py:1093-1099).  A DAG with the structure of one
+  that was optimised before is answered from the plan table (expr/plan.py): the recorded result, instantiated over
+  this DAG's leaves."""
+  if not FLAGS['optimization']:
+    return dag
+  if not FLAGS['opt_plan_cache']:
+    return _run_passes(dag)
+  from . import plan
+  return plan.optimized(dag, tuple(FLAGS.values()), _run_passes)

@@ -307,8 +307,7 @@ def spmm(a, b, out=None, accumulate=False, plan=True):
 
 def _spmm_result(out, strided_out, m, vec):
   if strided_out is not None:
-    from . import context
-    context.get().backend.paste(strided_out, tuple(slice(0, k) for k in strided_out.shape), out.reshape(strided_out.shape))
+    D._be().paste(strided_out, tuple(slice(0, k) for k in strided_out.shape), out.reshape(strided_out.shape))
     out = strided_out
   return out.reshape(m) if vec else out
 
