@@ -8,6 +8,7 @@ the hot path, one collective (see `UpdateBatch.flush` and `DistArrayImpl.glom`).
 """
 import collections
 import itertools
+import math
 
 import numpy as np
 
@@ -194,7 +195,7 @@ class DistArray(object):
   ndim = property(lambda self: len(self.shape))
 
   def real_size(self):
-    return int(np.prod(self.shape, dtype=np.int64))
+    return math.prod(self.shape)
 
   def __len__(self):
     return self.shape[0]
@@ -229,7 +230,11 @@ class DistArray(object):
   def map_to_array(self, mapper_fn, kw=None):
     """foreach_tile whose mapper returns the tiles of a NEW array: [(extent, tile id)] per input tile."""
     made = self.foreach_tile(mapper_fn=mapper_fn, kw=kw)
-    return from_table(collections.OrderedDict(pair for produced in made.values() for pair in produced))
+    table = collections.OrderedDict()
+    for produced in made.values():
+      for ex, tile_id in produced:
+        table[ex] = tile_id
+    return from_table(table)
 
 
 class ChunkedWhole(object):
@@ -473,11 +478,12 @@ class DistArrayImpl(DistArray):
     self.bad_tiles = []
     self.ctx = context.get()
     Assert.not_null(dtype)
-    self.blob_to_ex = {}
+    self.blob_to_ex = blob_to_ex = {}
     for k, v in tiles.items():
-      Assert.isinstance(k, extent.TileExtent)
-      Assert.isinstance(v, TileId)
-      self.blob_to_ex[v] = k
+      if type(k) is not extent.TileExtent or type(v) is not TileId:
+        Assert.isinstance(k, extent.TileExtent)
+        Assert.isinstance(v, TileId)
+      blob_to_ex[v] = k
     self.tiles = tiles
     # which tiles are known to be written everywhere: None = all of them (arrays made of produced tiles); a set of
     # tile extents for an array that was created empty (`create`) and is filled by updates.  Array METADATA: every
@@ -589,10 +595,12 @@ class DistArrayImpl(DistArray):
     """distarray.py:294-367.  Inside a kernel the data is delivered to the rank
     owning the executing worker (other ranks get `Absent` and just serve their
     pieces); at driver level every rank receives it (replicated fetch)."""
-    Assert.isinstance(region, extent.TileExtent)
-    Assert.eq(region.array_shape, self.shape)
-    assert all(l <= s for l, s in zip(region.lr, self.shape)), \
-        'Requested region is out of bounds: %s > %s' % (region, self.shape)
+    if type(region) is not extent.TileExtent:
+      Assert.isinstance(region, extent.TileExtent)
+    if region.array_shape != self.shape:
+      Assert.eq(region.array_shape, self.shape)
+    for l, n in zip(region.lr, self.shape):
+      assert l <= n, 'Requested region is out of bounds: %s > %s' % (region, self.shape)
     ctx = self.ctx
     be = ctx.backend
     world = ctx.world
@@ -844,8 +852,10 @@ class DistArrayImpl(DistArray):
     """distarray.py:372-422.  `data` is a backend tensor on the executing rank
     (`Absent` elsewhere).  Inside a kernel the update joins the kernel's batch;
     at driver level it is applied immediately."""
-    Assert.isinstance(region, extent.TileExtent)
-    Assert.eq(region.shape, tuple(data.shape), 'Size of extent does not match size of data')
+    if type(region) is not extent.TileExtent:
+      Assert.isinstance(region, extent.TileExtent)
+    if region.shape != tuple(data.shape):
+      Assert.eq(region.shape, tuple(data.shape), 'Size of extent does not match size of data')
     ctx = self.ctx
     if tile.is_sparse_blob(data) and not ctx.executing:
       data = Absent(region.shape, self.dtype)    # a mapper that builds its block on every rank: only the executing rank's counts
@@ -880,11 +890,12 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
   batch = UpdateBatch(ctx)
   ctx.pending = batch
   ctx.fetch_cache = {}
+  outer_worker = ctx.current_worker
+  blobs, invoke = ctx._blobs, array._invoke_mapper
   try:
     for tile_id in tile_ids:
-      with ctx.on_worker(tile_id.worker):
-        blob = ctx.tile(tile_id) if ctx.is_local(tile_id) else None
-        res = array._invoke_mapper(tile_id, blob, mapper_fn, kw)
+      ctx.current_worker = tile_id.worker          # (Context.on_worker, without the context manager)
+      res = invoke(tile_id, blobs.get(tile_id), mapper_fn, kw)
       if res is None:
         continue
       results[tile_id] = res.result
@@ -894,9 +905,11 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
           if tid == tile_id:
             ctx.incref(tid)
   finally:
+    ctx.current_worker = outer_worker
     ctx.pending = outer
     ctx.fetch_cache = outer_cache
-  batch.flush()
+  if batch.items:
+    batch.flush()
   return results
 
 
@@ -930,7 +943,7 @@ def create(shape, dtype=float, sharder=None, reducer=None, tile_hint=None, spars
 
 def from_table(extents):
   """distarray.py:519-550."""
-  Assert.no_duplicates(list(extents.keys()))
+  # (keys of a dict: no duplicates by construction -- the reference's check, distarray.py:528, guards its list form)
   if not extents:
     shape = tuple()
   else:
@@ -954,9 +967,17 @@ class LocalWrapper(DistArray):
     self._data = np.asarray(data)
     self.sparse = False
     self.bad_tiles = []
-    self._ex = extent.from_slice(np.index_exp[:], self.shape)
-    Assert.isinstance(data, (np.ndarray, int, float, bool, np.generic))
+    self._whole = None
+    if not isinstance(data, (np.ndarray, int, float, bool, np.generic)):
+      Assert.isinstance(data, (np.ndarray, int, float, bool, np.generic))
     self._dev = None
+
+  @property
+  def _ex(self):
+    """The one pseudo-tile: all of the data."""
+    if self._whole is None:
+      self._whole = extent.from_slice(np.index_exp[:], self.shape)
+    return self._whole
 
   dtype = property(lambda self: self._data.dtype)
   shape = property(lambda self: self._data.shape)

@@ -17,21 +17,30 @@ MAX_DIM = 32  # extent.pyx:21-22
 
 class TileExtent(object):
   """Half-open box [ul, lr) inside an array of `array_shape` (extent.pyx:23-136)."""
-  __slots__ = ('ul', 'lr', 'array_shape')
+  __slots__ = ('ul', 'lr', 'array_shape', '_shape')
 
   def __init__(self, ul, lr, array_shape):
-    self.ul = tuple(int(v) for v in ul)
-    self.lr = tuple(int(v) for v in lr)
-    self.array_shape = None if array_shape is None else tuple(int(v) for v in array_shape)
+    # (an extent never changes: the tuples are taken as they are when they already are tuples of ints -- `create`
+    #  and the algebra below build them that way -- and the derived shape is computed once)
+    self.ul = ul if type(ul) is tuple and all(type(v) is int for v in ul) else tuple(int(v) for v in ul)
+    self.lr = lr if type(lr) is tuple and all(type(v) is int for v in lr) else tuple(int(v) for v in lr)
+    if array_shape is None or (type(array_shape) is tuple and all(type(v) is int for v in array_shape)):
+      self.array_shape = array_shape
+    else:
+      self.array_shape = tuple(int(v) for v in array_shape)
+    self._shape = None
 
   @property
   def size(self):
-    return int(np.prod(self.shape, dtype=np.int64)) if len(self.shape) else 1
+    return math.prod(self.shape)
 
   @property
   def shape(self):
     # extent.pyx:66-72 -- a zero-length dimension reports 1
-    return tuple(1 if (l - u) == 0 else (l - u) for u, l in zip(self.ul, self.lr))
+    shape = self._shape
+    if shape is None:
+      shape = self._shape = tuple([1 if (l - u) == 0 else (l - u) for u, l in zip(self.ul, self.lr)])
+    return shape
 
   @property
   def ndim(self):
@@ -92,8 +101,8 @@ class TileExtent(object):
 
 def create(ul, lr, array_shape):
   """extent.pyx:141-182 -- returns None for an unrealistic box (any ul >= lr)."""
-  ul = tuple(int(v) for v in ul)
-  lr = tuple(int(v) for v in lr)
+  ul = tuple([int(v) for v in ul])
+  lr = tuple([int(v) for v in lr])
   if len(ul) > MAX_DIM:
     raise AssertionError('more than %d dimensions' % MAX_DIM)
   for u, l in zip(ul, lr):
@@ -227,7 +236,8 @@ def intersection(a, b):
   turns into None (the reference compares with `<`, not `<=`)."""
   if a is None:
     return None
-  Assert.eq(a.array_shape, b.array_shape, 'Tiles must have compatible shapes!')
+  if a.array_shape != b.array_shape:
+    Assert.eq(a.array_shape, b.array_shape, 'Tiles must have compatible shapes!')
   ul, lr = [], []
   for i in range(a.ndim):
     if b.lr[i] < a.ul[i]:
@@ -272,9 +282,8 @@ def index_for_reduction(index, axis):
 
 def find_shape(extents):
   """extent.pyx:434-443."""
-  shape = np.max([ex.lr for ex in extents], axis=0)
-  shape[shape == 0] = 1
-  return tuple(int(v) for v in shape)
+  corners = [ex.lr for ex in extents]
+  return tuple([max(axis) or 1 for axis in zip(*corners)]) if corners and corners[0] else ()
 
 
 def is_complete(shape, slices):

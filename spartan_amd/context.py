@@ -20,6 +20,7 @@ spartan/worker.py) for a static world of one process per GPU:
 import builtins
 import collections
 import contextlib
+import math
 import weakref
 
 import numpy as np
@@ -143,9 +144,10 @@ class Context(object):
   def register_array(self, array):
     self._arrays.add(array)
     item = np.dtype(array.dtype).itemsize
+    given, n = self._given, self.num_workers
     for ex, tile_id in array.tiles.items():
-      if 0 <= tile_id.worker < self.num_workers:
-        self._given[tile_id.worker] += item * int(np.prod(ex.shape, dtype=np.int64))
+      if 0 <= tile_id.worker < n:
+        given[tile_id.worker] += item * math.prod(ex.shape)
 
   def start_heartbeat(self, interval=3.0, threshold=10, **kw):
     """Start failure detection (master.py:142-146 / worker.py:347-368): see heartbeat.py."""

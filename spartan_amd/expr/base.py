@@ -126,11 +126,10 @@ class Expr(object):
 
   def evaluate(self):
     ctx = context.get()
-    top = ctx.eval_depth == 0
-    if top:
+    if ctx.eval_depth == 0:
       ctx.eval_epoch += 1           # one number per top-level evaluation (what the tiles of one evaluation share)
-    if top and ctx.heartbeat is not None and ctx.current_worker is None:
-      ctx.apply_failures()          # safe point (once per top-level evaluation): workers declared silent lose their tiles
+      if ctx.heartbeat is not None and ctx.current_worker is None:
+        ctx.apply_failures()        # safe point (once per top-level evaluation): workers declared silent lose their tiles
     ctx.eval_depth += 1
     try:
       value = self.cache()
@@ -138,7 +137,7 @@ class Expr(object):
         ready = {k: (d.evaluate() if isinstance(d, Expr) else d) for k, d in self.dependencies().items()}
         value = self._evaluate(ctx, ready)
         if self.needs_cache:
-          eval_cache.set(self.expr_id, value)
+          eval_cache._values[self.expr_id] = value
     finally:
       ctx.eval_depth -= 1
     return value
@@ -254,6 +253,12 @@ class Val(_Leaf):
   def _evaluate(self, ctx, deps):
     return self.val
 
+  def evaluate(self):
+    # nothing to compute and nothing to remember; as the root of an evaluation it is still a safe point
+    if context.get().eval_depth == 0:
+      return Expr.evaluate(self)
+    return self.val
+
 
 # ---- containers ------------------------------------------------------------------------------------------------
 class CollectionExpr(Expr):
@@ -277,6 +282,12 @@ class CollectionExpr(Expr):
 
   def _evaluate(self, ctx, deps):
     return self._ctor(deps['v%d' % i] for i in range(len(self.vals)))
+
+  def evaluate(self):
+    # (a container inside a DAG: its members' values, without the bookkeeping of a node that has a value of its own)
+    if type(self.vals) is dict or context.get().eval_depth == 0:
+      return Expr.evaluate(self)
+    return self._ctor([v.evaluate() if isinstance(v, Expr) else v for v in self.vals])
 
   def visit(self, visitor):
     return type(self)(vals=self._ctor(visitor.visit(v) for v in self.vals))

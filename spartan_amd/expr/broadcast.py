@@ -84,14 +84,19 @@ class Broadcast(distarray.DistArray):
 def common_shape(shapes):
   """NumPy's broadcasting rule on a list of shapes (right-aligned; per axis all lengths equal or 1)."""
   nd = max(len(s) for s in shapes)
-  table = np.ones((len(shapes), nd), dtype=np.int64)
-  for row, s in zip(table, shapes):
-    if len(s):
-      row[nd - len(s):] = s
-  out = table.max(axis=0)
-  if not np.all((table == out) | (table == 1)):
-    raise AssertionError('Mismatched shapes for broadcast: %s' % [list(s) for s in shapes])
-  return tuple(int(n) for n in out)
+  out = [1] * nd
+  for s in shapes:
+    at = nd - len(s)
+    for n in s:
+      n = int(n)
+      have = out[at]
+      if n != have:
+        if have == 1:
+          out[at] = n
+        elif n != 1:
+          raise AssertionError('Mismatched shapes for broadcast: %s' % [list(x) for x in shapes])
+      at += 1
+  return tuple(out)
 
 
 def broadcast(args):

@@ -20,7 +20,10 @@ class Assert(object):
 
   @staticmethod
   def eq(a, b, msg='', *args):
-    if not np.all(np.asarray(a == b)):
+    same = a == b
+    if same is True:
+      return
+    if not np.all(np.asarray(same)):
       raise AssertionError('%s != %s %s' % (a, b, (msg % args) if args else msg))
 
   @staticmethod
