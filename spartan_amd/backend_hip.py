@@ -19,7 +19,7 @@ from . import _hip, kernels, lower
 from . import devarray as D
 from . import sparse as sparse_mod
 from .array import distarray, tile
-from .expr.local import FnCallExpr, LocalInput
+from .expr.local import LocalMapLocationExpr, FnCallExpr, LocalInput
 from .program import ProgramTooLarge, class_of, join_class
 
 _REDUCER_NAMES = {
@@ -59,6 +59,10 @@ class HipBackend(object):
     self.gemm_events = None   # set to [] to record (start, stop) HIP events around every GEMM launch
     self._rng_seed = (int(time.time() * 100000) + os.getpid()) & (2**63 - 1)   # srandom.py:23-35: from the clock
     self._rng_offset = 0
+    # lowered programs of fused operator trees seen before: (operator structure, operand types, tile shape) ->
+    # program + operand order (see _lowering_key); a hit skips type inference and code emission, not the launch
+    self._lowered = collections.OrderedDict()
+    self.lowering_hits = 0
     # the code objects that travel with the tree (csrc/jit_seed) are loaded while the host builds its first
     # expressions: ctypes drops the GIL for the call, a seeded program then starts specialised at once
     dev = ctypes.c_int32(0)
@@ -253,7 +257,87 @@ class HipBackend(object):
     if out.numel():
       self.launches += 1
       kernels.map_fused(prog, tensors, out)
+      self._last_map = (prog, tensors, tuple(out.shape), out_dtype)      # (evaluate_map may remember it)
     return out
+
+  # -- lowered programs of operator trees seen before ---------------------------------------------------------
+  def _op_structure(self, op):
+    """(structure, variable names in order of appearance, reads the tile's position?) of an operator tree made of
+    registered operators only -- None if it calls anything that is TRACED (a user's function: what it computes may
+    depend on values it closes over, which no key can see).  Remembered on the operator object: trees of optimised
+    DAGs answered from the plan table (expr/plan.py) are shared between evaluations."""
+    memo = getattr(op, '_lowering_structure', False)
+    if memo is not False:
+      return memo
+    names, positional = [], [False]
+
+    def walk(o):
+      if isinstance(o, LocalInput):
+        if o.idx in ('extent', 'axis'):
+          if o.idx == 'extent':
+            positional[0] = True
+          return o.idx
+        if o.idx not in names:
+          names.append(o.idx)
+        return names.index(o.idx)
+      if not isinstance(o, FnCallExpr) or (o.fn not in lower.MAP_RULES and o.fn not in lower.REDUCE_RULES):
+        raise lower.NotLowerable('traced')
+      if getattr(o.fn, '_sp_random', None) is not None or getattr(o.fn, '_sp_tile_fn', False):
+        raise lower.NotLowerable('not a kernel')
+      kw = ()
+      if o.kw:
+        kw = tuple(sorted((k, v if isinstance(v, (bool, int, float, str, type(None))) else np.dtype(v).str)
+                          for k, v in o.kw.items()))
+      if isinstance(o, LocalMapLocationExpr):
+        positional[0] = True
+      return (type(o).__name__, id(o.fn), kw, tuple([walk(d) for d in o.deps]))
+    try:
+      memo = (walk(op), tuple(names), positional[0])
+      hash(memo)
+    except (lower.NotLowerable, TypeError):
+      memo = None
+    try:
+      op._lowering_structure = memo
+    except AttributeError:
+      pass
+    return memo
+
+  def _lowering_key(self, op, inputs, ex, extra):
+    st = self._op_structure(op)
+    if st is None:
+      return None
+    structure, names, positional = st
+    described, ptrs = [], []
+    for n in names:
+      v = inputs.get(n)
+      t = type(v)
+      if t is D.DevArray:
+        # (address: two names may read the same bytes -- the emitter then loads them once -- and alignment decides
+        #  the kernel's vector width; both are functions of the low bits and of equality between operands)
+        p = v.data_ptr()
+        described.append((v.dtype, v.shape, v.strides, p & 15, ptrs.index(p) if p in ptrs else len(ptrs)))
+        ptrs.append(p)
+      elif t in (bool, int, float):
+        described.append((t, v))
+      elif isinstance(v, np.generic):
+        described.append((v.dtype.str, v.item()))
+      else:
+        return None          # NumPy operands (uploaded through the driver-array cache), empty / sparse / masked tiles
+    where = (ex.ul, ex.lr, ex.array_shape) if positional else ex.shape
+    return (structure, tuple(described), where, extra)
+
+  def _remember(self, key, launch, inputs, op):
+    """Keep the program of a launch whose operands were exactly (some of) the device tiles handed in; operands are
+    remembered by their POSITION among the operator tree's variables (two trees of one structure name them apart)."""
+    prog, tensors, out_shape, out_dtype = launch[:4]
+    names = op._lowering_structure[1]
+    by_id = {id(inputs[n]): i for i, n in enumerate(names) if type(inputs.get(n)) is D.DevArray}
+    order = [by_id.get(id(t)) for t in tensors]
+    if None in order:
+      return              # a carved sub-expression, a dense copy of a view, an uploaded operand: not replayable as is
+    self._lowered[key] = (prog, order, out_shape, np.dtype(out_dtype)) + tuple(launch[4:])
+    while len(self._lowered) > 512:
+      self._lowered.popitem(last=False)
 
   def seed_random(self, seed):
     self._rng_seed = int(seed) & (2**63 - 1)
@@ -280,9 +364,24 @@ class HipBackend(object):
     if any(tile.is_sparse_blob(v) for v in inputs.values()):
       return self._evaluate_sparse_map(op, inputs, ex)
     op, inputs = self._materialise_random(op, inputs, ex)
+    key = self._lowering_key(op, inputs, ex, None)
+    if key is not None:
+      hit = self._lowered.get(key)
+      if hit is not None:
+        prog, order, out_shape, out_dtype = hit
+        names = op._lowering_structure[1]
+        out = D.empty(out_shape, out_dtype)
+        self.launches += 1
+        self.lowering_hits += 1
+        kernels.map_fused(prog, [inputs[names[i]] for i in order], out)
+        return out
     try:
       root = lower.infer(op, inputs, ex, self.dtype_of)
-      return self._run_map(root, root.shape if root.kind != 'const' else ex.shape)
+      self._last_map = None
+      out = self._run_map(root, root.shape if root.kind != 'const' else ex.shape)
+      if key is not None and self._last_map is not None:
+        self._remember(key, self._last_map, inputs, op)
+      return out
     except ProgramTooLarge:
       return self._evaluate_split(op, inputs, ex)
     except lower.NotLowerable:
@@ -448,9 +547,12 @@ class HipBackend(object):
     self.launches += 1
     kernels.reduce(prog, tensors, red_op, O, A, I, out)
     if axis is None:
-      return out.reshape(())
-    ax = axis if axis >= 0 else axis + len(full_shape)
-    return out.reshape(full_shape[:ax] + full_shape[ax + 1:])
+      shape = ()
+    else:
+      ax = axis if axis >= 0 else axis + len(full_shape)
+      shape = full_shape[:ax] + full_shape[ax + 1:]
+    self._last_reduce = (prog, tensors, shape, nat_dtype, red_op, O, A, I)
+    return out.reshape(shape)
 
   def evaluate_reduce(self, op, inputs, ex, axis):
     """_reduce_mapper's local reduction (reduce.py:54) incl. the fused map prologue."""
@@ -471,13 +573,28 @@ class HipBackend(object):
       raise lower.NotLowerable('reduce over %d operands' % len(data_deps))
     if any(tile.is_sparse_blob(v) for v in inputs.values()):
       return self._evaluate_sparse_reduce(op, data_deps[0], inputs, ex, axis)
+    key = self._lowering_key(op, inputs, ex, ('reduce', axis))
+    if key is not None:
+      hit = self._lowered.get(key)
+      if hit is not None:
+        prog, order, shape, nat, red_op, O, A, I = hit
+        names = op._lowering_structure[1]
+        out = D.empty((O * I,), nat)
+        self.launches += 1
+        self.lowering_hits += 1
+        kernels.reduce(prog, [inputs[names[i]] for i in order], red_op, O, A, I, out)
+        return out.reshape(shape)
     try:
       data = lower.infer(data_deps[0], inputs, ex, self.dtype_of)
     except ProgramTooLarge:
       raise
     red_op, data, nat = rule(data, axis, ex)
     try:
-      return self._run_reduce(data, red_op, nat, ex.shape, axis)
+      self._last_reduce = None
+      out = self._run_reduce(data, red_op, nat, ex.shape, axis)
+      if key is not None and self._last_reduce is not None:
+        self._remember(key, self._last_reduce, inputs, op)
+      return out
     except ProgramTooLarge:
       # materialise the map, then reduce the dense result
       dense = self.evaluate_map(data_deps[0], inputs, ex)
