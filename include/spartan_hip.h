@@ -497,6 +497,14 @@ int sp_blob_trim(void);
 int sp_blob_info(uint64_t handle, void** d_ptr, int64_t* shape, int32_t* ndim, int32_t* dtype);
 int sp_blob_stats(int64_t* live_blobs, int64_t* pooled_bytes);
 int sp_blob_h2d(uint64_t handle, const void* host, const int64_t* ul, const int64_t* lr, void* stream);
+/* sp_blob_h2d for small driver-side operands (up to 4 MiB, a contiguous byte range of the blob): the host buffer is
+ * copied into a pinned staging slot of the library before the call returns (*host_consumed = 1: the caller may
+ * reuse or free it at once and need not synchronise) and reaches the device by an asynchronous copy on `stream`.
+ * Anything else is handed to sp_blob_h2d as it is (*host_consumed = 0: the buffer must stay valid until the stream
+ * has run the copy).  The reference pickles such operands into every kernel request (spartan/expr/operator/dot.py:
+ * 172-187, worker.py:232-263). */
+int sp_blob_h2d_staged(uint64_t handle, const void* host, const int64_t* ul, const int64_t* lr, void* stream,
+                       int32_t* host_consumed);
 int sp_blob_d2h(uint64_t handle, void* host, const int64_t* ul, const int64_t* lr, void* stream);
 int sp_blob_slice_copy(uint64_t dst, const int64_t* dst_ul, uint64_t src, const int64_t* src_ul,
                        const int64_t* extent, void* stream);

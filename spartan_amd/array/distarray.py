@@ -44,11 +44,21 @@ def compute_splits(shape, tile_hint):
   return [[(lo, min(lo + step, n)) for lo in range(0, n, step)] for n, step in zip(shape, tile_hint)]
 
 
+_cuts = {}          # (shape, tile hint, shards) -> ((extent, shard index), ...): extents never change, cuts repeat
+
+
 def compute_extents(shape, tile_hint=None, num_shards=-1):
   """{tile extent: shard index} for an array of `shape`, tiles in row-major order of their position, dealt to
   the shards round-robin (reference distarray.py:73-110)."""
   if len(shape) == 0:
     return {extent.create([], [], ()): 0}
+  try:
+    key = (tuple(shape), None if tile_hint is None else tuple(tile_hint), num_shards)
+    known = _cuts.get(key)
+  except TypeError:
+    key = known = None
+  if known is not None:
+    return collections.OrderedDict(known)
   if tile_hint is None:
     tile_hint = good_tile_shape(shape, num_shards)
   elif len(tile_hint) != len(shape):
@@ -57,6 +67,10 @@ def compute_extents(shape, tile_hint=None, num_shards=-1):
   for position, box in enumerate(itertools.product(*compute_splits(shape, tile_hint))):
     lows, highs = zip(*box)
     tiles[extent.create(lows, highs, shape)] = position if num_shards == -1 else position % num_shards
+  if key is not None and len(tiles) <= 4096:
+    if len(_cuts) > 512:
+      _cuts.clear()
+    _cuts[key] = tuple(tiles.items())
   return tiles
 
 
@@ -602,8 +616,17 @@ class DistArrayImpl(DistArray):
     for l, n in zip(region.lr, self.shape):
       assert l <= n, 'Requested region is out of bounds: %s > %s' % (region, self.shape)
     ctx = self.ctx
-    be = ctx.backend
     world = ctx.world
+    # the common case first: exactly one tile, plain dense data written everywhere, held by the rank that asks
+    # (any rank of a one-process world; the executing worker's own rank otherwise) -- the tile's tensor itself
+    tid = self.tiles.get(region)
+    if tid is not None:
+      t = ctx._blobs.get(tid)
+      if (t is not None and type(t.mask) is int and t.mask == tile.MASK_ALL_SET and t.type == tile.TYPE_DENSE and t.data is not None
+              and t.shape and (world.size == 1 or (ctx.current_worker is not None and
+                                                    ctx.current_worker % world.size == world.rank))):
+        return t.data
+    be = ctx.backend
     replicated = ctx.current_worker is None
     dst_rank = None if replicated else ctx.rank_of(ctx.current_worker)
     want = replicated or dst_rank == world.rank

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -228,6 +229,53 @@ static int blob_transfer(uint64_t h, void* host, const int64_t* ul, const int64_
 
 extern "C" int sp_blob_h2d(uint64_t h, const void* host, const int64_t* ul, const int64_t* lr, void* stream) {
   return blob_transfer(h, const_cast<void*>(host), ul, lr, true, stream);
+}
+
+// Small driver-side operands (the weight vector of a gradient step, the centres of a k-means iteration) go through a
+// ring of pinned staging slots: the caller's buffer is consumed by a host memcpy before the call returns, the copy
+// to the device is a true asynchronous DMA from pinned memory, so the host neither waits for the stream (a pageable
+// hipMemcpyAsync makes it) nor has to keep its buffer alive.
+namespace {
+constexpr int kStageSlots = 8;
+constexpr size_t kStageBytes = 4u << 20;
+struct StageSlot {
+  void* host = nullptr;
+  hipEvent_t done = nullptr;
+  bool used = false;
+};
+StageSlot g_stage[kStageSlots];
+int g_stage_next = 0;
+std::mutex g_stage_mu;
+}  // namespace
+
+extern "C" int sp_blob_h2d_staged(uint64_t h, const void* host, const int64_t* ul, const int64_t* lr, void* stream,
+                                  int32_t* host_consumed) {
+  if (host_consumed) *host_consumed = 0;
+  Blob b;
+  if (blob_lookup(h, &b)) return 1;
+  int64_t ext[SP_BLOB_MAX_DIMS], count;
+  if (check_box(b, ul, lr, ext, &count)) return 1;
+  const size_t bytes = (size_t)count * sp_dtype_size(b.dtype);
+  if (!host || bytes == 0 || bytes > kStageBytes || !(box_is_whole(b, ext) || box_is_contiguous(b, ext)))
+    return blob_transfer(h, const_cast<void*>(host), ul, lr, true, stream);
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  StageSlot& s = g_stage[g_stage_next];
+  g_stage_next = (g_stage_next + 1) % kStageSlots;
+  if (!s.host) {
+    SP_HIP(hipHostMalloc(&s.host, kStageBytes, hipHostMallocDefault));
+    SP_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+  if (s.used) SP_HIP(hipEventSynchronize(s.done));      // the copy that last read this slot has finished
+  memcpy(s.host, host, bytes);
+  int64_t bst[SP_BLOB_MAX_DIMS], off = 0;
+  dense_strides(b.shape, b.ndim, bst);
+  for (int i = 0; i < b.ndim; ++i) off += (ul ? ul[i] : 0) * bst[i];
+  char* dst = (char*)b.ptr + (size_t)off * sp_dtype_size(b.dtype);
+  SP_HIP(hipMemcpyAsync(dst, s.host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  SP_HIP(hipEventRecord(s.done, (hipStream_t)stream));
+  s.used = true;
+  if (host_consumed) *host_consumed = 1;
+  return 0;
 }
 
 extern "C" int sp_blob_d2h(uint64_t h, void* host, const int64_t* ul, const int64_t* lr, void* stream) {

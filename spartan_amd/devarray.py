@@ -137,9 +137,11 @@ class Storage(object):
   def h2d(self, byte_offset, host_ptr, nbytes):
     if nbytes:
       st = current_stream().ptr
-      check(_hip.lib().sp_blob_h2d(self.handle, C.c_void_p(host_ptr), _hip.i64_array([byte_offset]),
-                                   _hip.i64_array([byte_offset + nbytes]), st))
-      check(_hip.lib().sp_stream_synchronize(st))      # the host buffer may be a temporary
+      consumed = C.c_int32(0)
+      check(_hip.lib().sp_blob_h2d_staged(self.handle, C.c_void_p(host_ptr), _hip.i64_array([byte_offset]),
+                                          _hip.i64_array([byte_offset + nbytes]), st, C.byref(consumed)))
+      if not consumed.value:
+        check(_hip.lib().sp_stream_synchronize(st))      # the host buffer may be a temporary
 
   def d2h(self, byte_offset, host_ptr, nbytes):
     if nbytes:

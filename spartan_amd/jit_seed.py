@@ -31,6 +31,11 @@ class _SeedBackend(HipBackend):
     self._warned_host = set()
     self.gemm_events = None
     self._rng_seed, self._rng_offset = 1, 0
+    self._lowered = collections.OrderedDict()
+    self.lowering_hits = 0
+
+  def _lowering_key(self, op, inputs, ex, extra):
+    return None          # every program is lowered (and its specialisation requested) afresh
 
 
 @contextlib.contextmanager
