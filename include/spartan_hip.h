@@ -505,6 +505,9 @@ int sp_blob_h2d(uint64_t handle, const void* host, const int64_t* ul, const int6
  * 172-187, worker.py:232-263). */
 int sp_blob_h2d_staged(uint64_t handle, const void* host, const int64_t* ul, const int64_t* lr, void* stream,
                        int32_t* host_consumed);
+/* sp_blob_d2h + wait: the box is in `host` when the call returns.  Up to 4 MiB (a contiguous byte range of the
+ * blob) it travels through a pinned staging slot -- `glom` of a reduction's result, distarray.py:294-367. */
+int sp_blob_d2h_staged(uint64_t handle, void* host, const int64_t* ul, const int64_t* lr, void* stream);
 int sp_blob_d2h(uint64_t handle, void* host, const int64_t* ul, const int64_t* lr, void* stream);
 int sp_blob_slice_copy(uint64_t dst, const int64_t* dst_ul, uint64_t src, const int64_t* src_ul,
                        const int64_t* extent, void* stream);

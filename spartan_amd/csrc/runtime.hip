@@ -278,6 +278,40 @@ extern "C" int sp_blob_h2d_staged(uint64_t h, const void* host, const int64_t* u
   return 0;
 }
 
+// The way back for small results (a glommed gradient, the counts and sums of a k-means iteration): DMA into a pinned
+// slot, wait for the stream, copy out -- COMPLETE when the call returns.  A pageable destination would make the
+// runtime stage the transfer itself, at a fraction of the rate.
+extern "C" int sp_blob_d2h_staged(uint64_t h, void* host, const int64_t* ul, const int64_t* lr, void* stream) {
+  Blob b;
+  if (blob_lookup(h, &b)) return 1;
+  int64_t ext[SP_BLOB_MAX_DIMS], count;
+  if (check_box(b, ul, lr, ext, &count)) return 1;
+  const size_t bytes = (size_t)count * sp_dtype_size(b.dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (!host || bytes == 0 || bytes > kStageBytes || !(box_is_whole(b, ext) || box_is_contiguous(b, ext))) {
+    if (blob_transfer(h, host, ul, lr, false, stream)) return 1;
+    SP_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  StageSlot& s = g_stage[g_stage_next];
+  g_stage_next = (g_stage_next + 1) % kStageSlots;
+  if (!s.host) {
+    SP_HIP(hipHostMalloc(&s.host, kStageBytes, hipHostMallocDefault));
+    SP_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+  if (s.used) SP_HIP(hipEventSynchronize(s.done));
+  int64_t bst[SP_BLOB_MAX_DIMS], off = 0;
+  dense_strides(b.shape, b.ndim, bst);
+  for (int i = 0; i < b.ndim; ++i) off += (ul ? ul[i] : 0) * bst[i];
+  const char* src = (const char*)b.ptr + (size_t)off * sp_dtype_size(b.dtype);
+  SP_HIP(hipMemcpyAsync(s.host, src, bytes, hipMemcpyDeviceToHost, st));
+  SP_HIP(hipStreamSynchronize(st));
+  memcpy(host, s.host, bytes);
+  s.used = false;
+  return 0;
+}
+
 extern "C" int sp_blob_d2h(uint64_t h, void* host, const int64_t* ul, const int64_t* lr, void* stream) {
   return blob_transfer(h, host, ul, lr, false, stream);
 }

@@ -146,9 +146,8 @@ class Storage(object):
   def d2h(self, byte_offset, host_ptr, nbytes):
     if nbytes:
       st = current_stream().ptr
-      check(_hip.lib().sp_blob_d2h(self.handle, C.c_void_p(host_ptr), _hip.i64_array([byte_offset]),
-                                   _hip.i64_array([byte_offset + nbytes]), st))
-      check(_hip.lib().sp_stream_synchronize(st))
+      check(_hip.lib().sp_blob_d2h_staged(self.handle, C.c_void_p(host_ptr), _hip.i64_array([byte_offset]),
+                                          _hip.i64_array([byte_offset + nbytes]), st))      # (complete on return)
 
   def __del__(self):
     try:

@@ -1,0 +1,167 @@
+"""The plan table (spartan_amd/expr/plan.py): a DAG with the structure of one optimised before is answered by the
+recorded result instantiated over ITS leaves.  What must hold: same values as the long way for every variation a
+driver loop produces (other arrays, other driver-side operands, other scalars), no confusion between DAGs that differ
+only in which leaves are the same object, values shared between a node and its optimised twin, nothing kept alive,
+and everything the walk cannot describe optimised the long way."""
+import gc
+import importlib
+import weakref
+
+import numpy as np
+import pytest
+
+import spartan_amd as sp
+
+plan = importlib.import_module('spartan_amd.expr.plan')
+optimize = importlib.import_module('spartan_amd.expr.optimize')
+
+
+@pytest.fixture
+def ctx():
+  from oracle.np_backend import NumpyBackend
+  c = sp.initialize(backend=NumpyBackend(), num_workers=3)
+  plan.clear()
+  for k in plan.stats:
+    plan.stats[k] = 0
+  yield c
+  sp.shutdown()
+
+
+def _arr(seed, shape=(30, 8)):
+  return (np.random.RandomState(seed).randint(-4, 5, size=shape)).astype(np.float32)
+
+
+def test_same_structure_other_leaves_hits_and_computes_on_the_new_leaves(ctx):
+  a, b = _arr(1), _arr(2)
+  A, B = sp.from_numpy(a), sp.from_numpy(b)
+  got1 = ((A * A + A) * 0.5 - A).optimized().glom()
+  assert plan.stats == {'hits': 0, 'misses': 1, 'unplannable': 0}
+  got2 = ((B * B + B) * 0.5 - B).optimized().glom()
+  assert plan.stats['hits'] == 1
+  np.testing.assert_array_equal(got1, (a * a + a) * np.float32(0.5) - a)
+  np.testing.assert_array_equal(got2, (b * b + b) * np.float32(0.5) - b)
+  # the instantiated DAG is the fused one: ONE map whose inputs are the leaves themselves
+  e = ((B * B + B) * 0.5 - B).optimized()
+  assert type(e).__name__ == 'MapExpr' and e._is_optimized
+  assert all(type(c).__name__ in ('Val', 'AsArray') for c in e.children)
+  assert all(c.val is B.val for c in e.children if type(c).__name__ == 'Val')
+
+
+def test_which_leaves_are_the_same_object_is_part_of_the_key(ctx):
+  a, b = _arr(3), _arr(4)
+  A, B = sp.from_numpy(a), sp.from_numpy(b)
+  np.testing.assert_array_equal((A * A + 1).optimized().glom(), a * a + 1)
+  np.testing.assert_array_equal((A * B + 1).optimized().glom(), a * b + 1)      # not the plan of A * A
+  np.testing.assert_array_equal((B * A + 1).optimized().glom(), b * a + 1)
+  np.testing.assert_array_equal((B * B + 1).optimized().glom(), b * b + 1)
+  assert plan.stats['misses'] == 2 and plan.stats['hits'] == 2
+  # the same ARRAY behind two different leaf nodes is told from two arrays as well
+  A2 = sp.Val(val=A.val)
+  np.testing.assert_array_equal((A * A2 + 1).optimized().glom(), a * a + 1)
+  assert plan.stats['misses'] == 3
+
+
+def test_scalars_are_keyed_by_value_and_driver_arrays_by_type(ctx):
+  a = _arr(5)
+  A = sp.from_numpy(a)
+  for s in (2.0, 3.0, 2.0):
+    np.testing.assert_array_equal((A * s + 1).optimized().glom(), a * np.float32(s) + 1)
+  assert plan.stats['misses'] == 2 and plan.stats['hits'] == 1
+  w = np.arange(8, dtype=np.float32).reshape(8, 1) - 3
+  for step in range(3):
+    got = sp.dot(A, w).optimized().glom()          # a NEW driver array every step, as a gradient loop hands over
+    np.testing.assert_array_equal(got, a.dot(w))
+    w = w + 1
+  w -= 5                                           # ... and one updated in place
+  np.testing.assert_array_equal(sp.dot(A, w).optimized().glom(), a.dot(w))
+  assert plan.stats['hits'] >= 3
+
+
+def test_reductions_and_the_lreg_step_through_plans(ctx):
+  from spartan_amd.examples import lreg
+  x, y = _arr(6, (40, 8)), _arr(7, (40, 1))
+  X, Y = sp.from_numpy(x), sp.from_numpy(y)
+  w = np.ones((8, 1), np.float32)
+  for _ in range(4):
+    g = lreg.gradient(X, Y, w).optimized().glom()
+    np.testing.assert_allclose(g, (x * (x.dot(w) - y)).sum(0), rtol=1e-5)     # (three tiles: another summation tree)
+    w = w - g.reshape(8, 1) * np.float32(0.001)
+  assert plan.stats['misses'] == 1 and plan.stats['hits'] == 3
+  for axis in (None, 0, 1, 0):
+    np.testing.assert_array_equal(sp.sum(X * 2, axis).optimized().glom(), (x * 2).sum(axis))
+  assert plan.stats['misses'] == 4     # axis is part of the structure
+
+
+def test_a_node_and_its_optimised_twin_share_their_value(ctx):
+  a = _arr(8)
+  A = sp.from_numpy(a)
+  (A * 3 - 1).optimized().force()                  # records the plan
+  e = A * 3 - 1
+  o = e.optimized()
+  assert plan.stats['hits'] == 1 and o.expr_id == e.expr_id
+  o.force()
+  assert e.cache() is not None                     # found under the id the instantiated root took over
+  np.testing.assert_array_equal(e.glom(), a * 3 - 1)
+
+
+def test_dags_with_values_and_random_builders_are_optimised_the_long_way(ctx):
+  a = _arr(9)
+  A = sp.from_numpy(a)
+  inner = A * 2
+  inner.force()                                    # the collapse pass would cut the DAG at this node
+  before = dict(plan.stats)
+  np.testing.assert_array_equal((inner + 1).optimized().glom(), a * 2 + 1)
+  assert plan.stats['unplannable'] == before['unplannable'] + 1 and plan.stats['misses'] == before['misses']
+  r1 = (sp.rand(6, 5) + 1).optimized().glom()
+  r2 = (sp.rand(6, 5) + 1).optimized().glom()
+  assert not np.array_equal(r1, r2)                # never answered from a recording
+  assert plan.stats['hits'] == before['hits']
+
+
+def test_plans_keep_no_array_alive(ctx):
+  a = _arr(10)
+  A = sp.from_numpy(a)
+  ref = weakref.ref(A.val)
+  np.testing.assert_array_equal((A * A - 2).optimized().glom(), a * a - 2)
+  assert len(plan._plans) == 1
+  del A
+  gc.collect()
+  assert ref() is None, 'the recorded plan holds the array it was recorded on'
+
+
+def test_flags_and_worker_count_are_part_of_the_key(ctx):
+  a = _arr(11)
+  A = sp.from_numpy(a)
+  (A + 1 + 1).optimized().force()
+  optimize.FLAGS['opt_map_fusion'] = False
+  try:
+    e = (A + 1 + 1).optimized()
+    assert plan.stats['misses'] == 2               # not the fused recording
+    assert len(e.children) == 2 and type(e.children[0]).__name__ == 'MapExpr'
+    np.testing.assert_array_equal(e.glom(), a + 2)
+  finally:
+    optimize.FLAGS['opt_map_fusion'] = True
+  optimize.FLAGS['opt_plan_cache'] = False
+  try:
+    before = dict(plan.stats)
+    (A + 1 + 1).optimized().force()
+    assert plan.stats == before
+  finally:
+    optimize.FLAGS['opt_plan_cache'] = True
+
+
+def test_kmeans_iterations_through_plans(ctx):
+  from spartan_amd.examples.sklearn.cluster import KMeans
+  from scipy.spatial.distance import cdist
+  x = np.random.RandomState(12).rand(60, 4).astype(np.float32)
+  X = sp.from_numpy(x)
+  c = np.random.RandomState(13).rand(5, 4)
+  for _ in range(4):       # (the start centers are float64, the updated ones float32: two structures)
+    lab = np.argmin(cdist(x, c), axis=1)
+    cnt = np.bincount(lab, minlength=5)
+    want = np.stack([x[lab == i].sum(axis=0) for i in range(5)]) / np.maximum(cnt, 1)[:, None]
+    c_new, _ = KMeans(5, 1).fit(X, c, implementation='map2', reducer=np.add)
+    if cnt.min() > 0:
+      np.testing.assert_allclose(c_new, want, rtol=1e-6)
+    c = c_new
+  assert plan.stats['hits'] >= 4
