@@ -24,13 +24,22 @@
 
 namespace {
 
-constexpr int BSP_THREADS = 512;
-constexpr int BSP_CAP = 2048;             // products per pass: 4 per lane
+// Geometry (round 4): ONE workgroup of 1024 lanes per CU owning up to 4096 rows.  A staged slice then serves twice
+// the entries it served with two 512-lane workgroups of 2048 rows per CU (round 3: -DBSP_WIDE=0), so the slice
+// copies -- every row block of a site pulls the site's whole x through the L2 -- and the barriers around them halve
+// per entry: 42.2 -> 37.4 us on the 900 000-page tile.  (Timed with the slice loads / the run sums removed:
+// 32.3 / 29.7 us, both 23.9 us: what is left is the serial chunk pipeline, not bytes.)
+#ifndef BSP_WIDE
+#define BSP_WIDE 1
+#endif
+constexpr int BSP_THREADS = BSP_WIDE ? 1024 : 512;
+constexpr int BSP_WGS_PER_CU = BSP_WIDE ? 1 : 2;
+constexpr int BSP_CAP = 4 * BSP_THREADS;  // products per pass: 4 per lane
 constexpr int BSP_PER = BSP_CAP / BSP_THREADS;
 constexpr int BSP_MAXSEG = 64;
 constexpr int BSP_XS_BYTES = 44 * 1024;
 constexpr int BSP_S = BSP_XS_BYTES / 4;   // columns per slice
-constexpr int BSP_MAX_RB = 2048;          // rows per block (16-bit row ids; 8 KB of accumulators)
+constexpr int BSP_MAX_RB = BSP_WIDE ? 4096 : 2048;   // rows per block (16-bit row ids; 4 B of accumulator each)
 constexpr int BSP_STAGE_MIN = 768;        // a 44 KB slice is 352 lines: staging pays from about twice as many gathers
 constexpr int BSP_MAX_SLICES = 16384;
 constexpr int BSP_XV_N = (BSP_XS_BYTES / 16 + BSP_THREADS - 1) / BSP_THREADS;
@@ -51,8 +60,8 @@ bool bsp_layout(int32_t dtype, int64_t m, int64_t k, int64_t nnz, BspLayout* L) 
   const int64_t ns = (k + BSP_S - 1) / BSP_S;
   if (ns > BSP_MAX_SLICES) return false;
   int64_t j = 1;
-  while ((m + 2 * SP_CUS * j - 1) / (2 * SP_CUS * j) > BSP_MAX_RB) ++j;
-  L->rb = (m + 2 * SP_CUS * j - 1) / (2 * SP_CUS * j);
+  while ((m + BSP_WGS_PER_CU * SP_CUS * j - 1) / (BSP_WGS_PER_CU * SP_CUS * j) > BSP_MAX_RB) ++j;
+  L->rb = (m + BSP_WGS_PER_CU * SP_CUS * j - 1) / (BSP_WGS_PER_CU * SP_CUS * j);
   L->nb = (m + L->rb - 1) / L->rb;
   L->ns = ns;
   size_t at = 256;                                   // header: 8 x int64
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(BSP_THREADS) void sp_bsp_build_kernel(const int64_t
 typedef float bsp_f4 __attribute__((ext_vector_type(4)));
 
 // (second launch bound: waves per SIMD -- two workgroups of 8 waves per CU)
-__global__ __launch_bounds__(BSP_THREADS, 4) void sp_bsp_spmv_kernel(const int64_t* __restrict__ indptr, int64_t m, int rb,
+__global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) void sp_bsp_spmv_kernel(const int64_t* __restrict__ indptr, int64_t m, int rb,
                                                                      int nb, const int* __restrict__ nseg,
                                                                      const BspSeg* __restrict__ segtab,
                                                                      const uint32_t* __restrict__ keys,
