@@ -68,6 +68,9 @@ def _dummy(v):
   return np.zeros((), dtype=v.dtype)
 
 
+_result_dtypes = {}
+
+
 def _bshape(*shapes):
   return tuple(np.broadcast_shapes(*shapes))
 
@@ -81,10 +84,24 @@ def apply(opname, np_fn, args):
     # (np.abs(2) + 1 is np.int64(3); fp32 % np.int64(3) is float64) -- the same value the unfused evaluation of
     # this sub-tree produces as a 0-d tile
     return const(np.asarray(r)[()])
-  with np.errstate(all='ignore'):
-    res = np_fn(*[_dummy(a) for a in args])
-  dt = np.asarray(res).dtype
-  return V('op', dtype=dt, shape=_bshape(*[a.shape for a in args]), op=opname, args=args)
+  # NumPy's own answer, asked once per (function, operand types): the dummy call costs tens of microseconds
+  # (np.errstate alone ~10), a fused tree has one per operator, and a driver loop lowers the same trees for ever
+  try:
+    key = (np_fn, tuple([(type(a.value), a.value) if (a.kind == 'const' and a.weak) else a.dtype for a in args]))
+    dt = _result_dtypes.get(key)
+  except TypeError:
+    key = dt = None
+  if dt is None:
+    with np.errstate(all='ignore'):
+      res = np_fn(*[_dummy(a) for a in args])
+    dt = np.asarray(res).dtype
+    if key is not None:
+      if len(_result_dtypes) > 4096:
+        _result_dtypes.clear()
+      _result_dtypes[key] = dt
+  shapes = [a.shape for a in args]
+  shape = shapes[0] if all(s == shapes[0] or s == () for s in shapes[1:]) and shapes[0] != () else _bshape(*shapes)
+  return V('op', dtype=dt, shape=shape, op=opname, args=args)
 
 
 def cast(v, dtype):
