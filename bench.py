@@ -182,6 +182,35 @@ def hbm_section(ctx):
   return out
 
 
+def host_section(ctx):
+  """Host time of the driver-side paths (what the device waits for between launches): microseconds until force()
+  RETURNS on a 16 MiB tile (launches are asynchronous; the tile is small enough for the queue never to fill), and the
+  state of the two tables that make a repeated DAG cheap -- optimised DAGs by structure (expr/plan.py) and lowered
+  programs by operator structure (backend_hip._lowered)."""
+  import importlib
+  plan = importlib.import_module('spartan_amd.expr.plan')
+  X = sp.from_tile_fn((1024, 4096), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 3)).force()
+  Xv = sp.Val(val=X)
+
+  def host_us(fn, reps=200):
+    for _ in range(20):
+      fn()
+    D.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      fn()
+    dt = time.perf_counter() - t0
+    D.synchronize()
+    return round(dt / reps * 1e6, 1)
+  out = {'tile': '1024x4096 fp32',
+         'x_plus_1_force_us': host_us(lambda: (Xv + 1).force()),
+         'xx_plus_x_optimized_force_us': host_us(lambda: (Xv * Xv + Xv).optimized().force()),
+         'chain5_optimized_force_us': host_us(lambda: (((Xv * Xv + Xv) * 0.5 - Xv) / (Xv + 2.0)).optimized().force()),
+         'sum_axis0_force_us': host_us(lambda: sp.sum(Xv, 0).force()),
+         'plan_table': dict(plan.stats), 'lowered_program_hits': ctx.backend.lowering_hits}
+  return out
+
+
 def lreg_section(ctx, copy_gbps):
   """BASELINE configs[4] on the per-GPU tile (125 000 x 4096 fp32): the benchmark's 100 gradient steps
   (tests/benchmark_lreg.py:22-29 -> examples/lreg.fit), after 2 untimed ones; a step is yp = dot(X, w);
@@ -564,24 +593,54 @@ def ksplit_rank_emulation(ctx, one_gpu_ms):
   return out
 
 
+def _host_memory_gib():
+  """(available, total) host RAM in GiB (MemAvailable of /proc/meminfo)."""
+  info = {}
+  try:
+    for line in open('/proc/meminfo'):
+      k, v = line.split(':', 1)
+      info[k] = float(v.split()[0]) / (1 << 20)
+  except (IOError, OSError, ValueError):
+    return 0.0, 0.0
+  return info.get('MemAvailable', 0.0), info.get('MemTotal', 0.0)
+
+
 def cpu_baseline():
   """The reference's execution model on the host cores of this box: W = min(physical
   cores, 64) worker processes, one per core, pinned, one BLAS thread each (spartan/worker.py:40,385-387), running
-  the oracle's NumPy tile bodies on BOUNDED samples of the BASELINE shapes (the measurement contract asks for
-  about 10-30 s of CPU work in a default run; every shape below is stated); the parent merges like the owner of
-  the target tile.  A reported baseline, not a target."""
+  the oracle's NumPy tile bodies ON THE BASELINE SHAPES -- configs[1] whole, configs[2] whole, configs[4] / [3] on
+  the per-GPU tile the GPU numbers of this line are quoted on -- scaled down only where the host's free memory
+  forces it (the reason is printed); the parent merges like the owner of the target tile.  A reported baseline, not
+  a target."""
   from oracle import cpu_workers
   t_all = time.perf_counter()
+  avail, total = _host_memory_gib()
+  avail = avail or 32.0               # (no /proc/meminfo: assume a small host)
+  scaled = []
   pool = cpu_workers.Workers(64)
   try:
     W = pool.count
-    n = 4096
-    t_dot, t_dot_compute, n = pool.dot(n)                       # K-split, one target tile (dot.py:277-290)
-    rows, cols = 65536, 16384                                    # configs[2] scaled 1/4: 4 GiB fp32 in all
+    # configs[1]: dot 8192^3, K-split over W workers, one target tile (dot.py:277-290): W partials of 256 MiB stay
+    # in the workers, 4 ring slots + the target with the owner
+    n = 8192
+    need = (W + 5) * n * n * 4 / float(1 << 30) + 1.0
+    if avail and need > 0.6 * avail:
+      while n > 1024 and (W + 5) * n * n * 4 / float(1 << 30) + 1.0 > 0.6 * avail:
+        n //= 2
+      scaled.append('dot: %d^3 instead of 8192^3 (%.0f GiB free, the K-split partials of %d workers need %.0f GiB)'
+                    % (n, avail, W, need))
+    t_dot, t_dot_compute, n = pool.dot_shared(n)
+    # configs[2]: 65536 x 65536 fp32 = 16 GiB of input, x*x+x keeps a temporary and a result per tile
+    rows, cols = 65536, 65536
+    need = 3.2 * rows * cols * 4 / float(1 << 30)
+    if avail and need > 0.6 * avail:
+      while rows > 4096 and 3.2 * rows * cols * 4 / float(1 << 30) > 0.6 * avail:
+        rows //= 2
+      scaled.append('map / sum: %d x %d instead of 65536 x 65536 (%.0f GiB free, %.0f GiB needed)' % (rows, cols, avail, need))
     t_map, t_sum, rows = pool.map_and_sum(rows, cols)
-    ln, ld = 125000, 4096                                        # configs[4] scaled 1/8: one per-GPU tile
+    ln, ld = 125000, 4096                                        # configs[4]: the per-GPU tile of the 8-GPU run
     t_lreg, ln = pool.lreg_step(ln, ld)
-    kn, kd, kk = 2000 * W, 256, 1024                             # configs[3]: k and d as given, 2000 points / worker
+    kn, kd, kk = 1250000, 256, 1024                              # configs[3]: the per-GPU tile of the 8-GPU run
     t_km, kn = pool.kmeans_iteration(kn, kd, kk)
   finally:
     pool.close()
@@ -589,8 +648,9 @@ def cpu_baseline():
   end_to_end = 2.0 * n ** 3 / t_dot / 1e12
   gemm_only = 2.0 * n ** 3 / t_dot_compute / 1e12
   return {'value': round(end_to_end, 4), 'unit': 'TFLOP/s', 'cores': W, 'kind': 'port',
-          'value_is': 'dot end to end: the W per-worker GEMMs AND the W M x N partials travelling to the owner of the '
-                      'one target tile and being added there (dot.py:277-278); the GEMMs alone: gemm_only_value',
+          'value_is': 'dot end to end: the W per-worker GEMMs AND the W M x N partials travelling (through a shared-'
+                      'memory ring, not pickled pipes) to the owner of the one target tile and being added there '
+                      '(dot.py:277-278); the GEMMs alone: gemm_only_value',
           'gemm_only_value': round(gemm_only, 4),
           'workers': '%d processes pinned to %d physical cores, 1 BLAS thread each' % (W, W),
           'dot': {'shape': '%dx%dx%d fp32, K-split over %d workers, one target tile' % (n, n, n, W),
@@ -602,11 +662,13 @@ def cpu_baseline():
                         'GBps': round(2 * 4.0 * ln * ld / t_lreg / 1e9, 2)},
           'kmeans_iteration': {'shape': '%dx%d points, k=%d' % (kn, kd, kk), 'seconds': round(t_km, 3),
                                'TFLOPs_of_2nkd': round(2.0 * kn * kk * kd / t_km / 1e12, 4)},
-          'sample': 'oracle tile bodies (NumPy / BLAS / scipy cdist) on %d pinned one-thread workers, bounded samples '
-                    'of the BASELINE workloads: dot %d^3 K-split (configs[1] is 8192^3); x*x+x and sum(axis=0) on '
-                    '%dx%d (configs[2] is 65536x65536); one lreg step on %dx%d (configs[4] is 1000000x4096); one '
-                    'k-means iteration on %dx%d, k=%d (configs[3] is 10000000x256)' %
-                    (W, n, rows, cols, ln, ld, kn, kd, kk),
+          'host_memory_GiB': {'available': round(avail, 1), 'total': round(total, 1)},
+          'scaled_for_memory': scaled,
+          'sample': 'oracle tile bodies (NumPy / BLAS / scipy cdist) on %d pinned one-thread workers: configs[1] dot '
+                    '%d^3 K-split, one target tile; configs[2] x*x+x and sum(axis=0) on %dx%d; one lreg step on the '
+                    'per-GPU tile %dx%d of configs[4]; one k-means iteration on the per-GPU tile %dx%d, k=%d of '
+                    'configs[3]%s' % (W, n, rows, cols, ln, ld, kn, kd, kk,
+                                      '' if not scaled else ' -- scaled for host memory: ' + '; '.join(scaled)),
           'wall_seconds': round(time.perf_counter() - t_all, 1)}
 
 
@@ -732,7 +794,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--size', type=int, default=0, help='matrix order (default: 8192 on one GPU, 32768 on several)')
   ap.add_argument('--no-extras', action='store_true', help='headline only: skip the HBM / workload / emulation / CPU sections')
-  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,lreg,kmeans,sparse,ksplit,cpu; N > 1: hbm_dist,lreg_dist,kmeans_dist)')
+  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,host,lreg,kmeans,sparse,ksplit,cpu; N > 1: hbm_dist,lreg_dist,kmeans_dist)')
   ap.add_argument('--deadline', type=int, default=1500, help='seconds the self-launched ranks of --gpus N > 1 may take')
   args = ap.parse_args()
 
@@ -841,6 +903,8 @@ def main():
     if want('hbm'):
       line['hbm'] = hbm_section(ctx)
       D.trim_pool()
+    if want('host'):
+      line['host'] = host_section(ctx)
     if want('lreg'):
       line['lreg'] = lreg_section(ctx, line.get('hbm', {}).get('stream_copy_GBps', 6400.0))
       D.trim_pool()
@@ -856,6 +920,28 @@ def main():
       D.trim_pool()
     if want('cpu'):
       line['cpu_baseline'] = cpu_baseline()
+    # the second half of the metric and the north-star shape, inside `roofline` (the object the driver keeps whole):
+    # every HBM-bound section as GB/s and as a fraction of the copy rate measured in this run and of the 8 TB/s spec
+    ns = line.get('northstar_%d' % NORTH_STAR)
+    if ns and 'ms_per_call' in ns:
+      line['roofline']['northstar'] = {'workload': ns['workload'], 'ms': ns['ms_per_call'], 'TFLOPs': ns['TFLOPs'],
+                                       'frac': ns['frac_of_mfma_peak']}
+    hbm = line.get('hbm')
+    if hbm and 'stream_copy_GBps' in hbm:
+      copy = hbm['stream_copy_GBps']
+      sections = {k[:-5]: {'GBps': v, 'frac_of_measured_copy': round(v / copy, 3), 'frac_of_spec': round(v / HBM_PEAK_GBPS, 3)}
+                  for k, v in hbm.items() if k.endswith('_GBps') and k != 'stream_copy_GBps'}
+      for name in ('lreg', 'kmeans', 'sparse'):
+        sec = line.get(name) or {}
+        for key, label in (('GBps', name + '_driver_loop'), ('step_kernels_GBps', name + '_step_kernels'),
+                           ('accumulate_GBps', name + '_accumulate'), ('spmv_GBps', name + '_spmv')):
+          if key in sec:
+            sections[label] = {'GBps': sec[key], 'frac_of_measured_copy': round(sec[key] / copy, 3),
+                               'frac_of_spec': round(sec[key] / HBM_PEAK_GBPS, 3)}
+      line['roofline']['hbm_sections'] = {'measured_copy_GBps': copy, 'spec_GBps': HBM_PEAK_GBPS, 'sections': sections}
+    km = line.get('kmeans')
+    if km and 'assign_TFLOPs' in km:
+      line['roofline']['kmeans_assign'] = {'TFLOPs': km['assign_TFLOPs'], 'frac': km['assign_frac_of_mfma_peak'], 'ms': km['assign_ms']}
     line['profile_table'] = PROFILE_TABLE
     live, pooled = D.blob_stats()
     line['tile_store'] = {'live_blobs': live, 'pooled_bytes': pooled, 'kernel_sources': _hip.source_sha()}

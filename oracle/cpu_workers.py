@@ -60,6 +60,16 @@ def _worker(conn, cpu, index, count):
       part = state['a_slab'].dot(state['b_rows'])
       conn.send(None)
       conn.send_bytes(part)
+    elif op == 'dot_compute':     # the same partial, kept in the worker's memory until the owner asks for it
+      state['part'] = state['a_slab'].dot(state['b_rows'])
+      conn.send(None)
+    elif op == 'dot_push':        # ... and copied into a slot of the shared transfer ring (the "send")
+      path, offset = msg[1], msg[2]
+      part = state.pop('part')
+      ring = np.memmap(path, dtype=np.float32, mode='r+', offset=offset, shape=part.shape)
+      ring[...] = part
+      del ring
+      conn.send(None)
     elif op == 'make_tile':
       rows, cols = msg[1], msg[2]
       state['x'] = rng.rand(rows, cols).astype(np.float32)
@@ -137,10 +147,8 @@ class Workers(object):
         p.wait(timeout=5)
       except subprocess.TimeoutExpired:
         p.kill()
-    try:
-      os.rmdir(self._dir)
-    except OSError:
-      pass
+    import shutil
+    shutil.rmtree(self._dir, ignore_errors=True)
 
   # ---- the timed programs: each returns (seconds, what was computed) -------------------------------------------
   def dot(self, n):
@@ -162,6 +170,52 @@ class Workers(object):
         c.recv_bytes_into(scratch.reshape(-1).view(np.uint8))
         np.add(target, scratch, out=target)
     return time.perf_counter() - t0, t_compute, n
+
+  def dot_shared(self, n, slots=4):
+    """The K-split dot with the partials travelling through SHARED MEMORY (a ring of `slots` M x N buffers in a
+    memory-mapped file) instead of pickled pipe messages: every worker computes its M x N partial in parallel and
+    keeps it; the owner of the one target tile then takes them one after the other -- the worker copies its partial
+    into a free slot (the transfer), the owner merges it (first write replaces, later ones add: tile.pyx:263-268)
+    while the next worker fills the next slot.  What is timed is the reference's model -- W GEMMs, W M x N
+    transfers, W - 1 merges at one owner -- not the cost of pickling through a pipe.
+    Returns (seconds end to end, seconds until the last GEMM finished, n)."""
+    import numpy as np
+    n = n // self.count * self.count
+    self.all('make_dot', n)
+    path = os.path.join(self._dir, 'ring')
+    slot_bytes = n * n * 4
+    with open(path, 'wb') as f:
+      f.truncate(slot_bytes * slots)
+    ring = np.memmap(path, dtype=np.float32, mode='r+', shape=(slots, n, n))
+    target = np.empty((n, n), np.float32)
+    try:
+      t0 = time.perf_counter()
+      self.all('dot_compute')
+      t_compute = time.perf_counter() - t0
+      waiting = list(range(self.count))
+      in_flight = []                       # (worker, slot), in the order the pushes were requested
+      free = list(range(slots))
+      merged = 0
+      while merged < self.count:
+        while waiting and free:
+          w, s_ = waiting.pop(0), free.pop(0)
+          self.conns[w].send(('dot_push', path, s_ * slot_bytes))
+          in_flight.append((w, s_))
+        w, s_ = in_flight.pop(0)
+        self.conns[w].recv()
+        if merged == 0:
+          target[...] = ring[s_]
+        else:
+          np.add(target, ring[s_], out=target)
+        merged += 1
+        free.append(s_)
+      return time.perf_counter() - t0, t_compute, n
+    finally:
+      del ring
+      try:
+        os.remove(path)
+      except OSError:
+        pass
 
   def map_and_sum(self, rows_total, cols):
     import numpy as np
