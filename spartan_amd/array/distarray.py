@@ -248,7 +248,7 @@ class DistArray(object):
     for produced in made.values():
       for ex, tile_id in produced:
         table[ex] = tile_id
-    return from_table(table)
+    return from_table(table, meta=getattr(made, 'meta', None))
 
 
 class ChunkedWhole(object):
@@ -902,12 +902,19 @@ class DistArrayImpl(DistArray):
     return None
 
 
+class KernelResults(collections.OrderedDict):
+  """{tile id: what its mapper produced}; `meta`: the (dtype, is_sparse) every mapper call derived for the tiles it
+  made -- the same on every rank -- or None."""
+  meta = None
+
+
 def run_kernel(array, tile_ids, mapper_fn, kw):
   """blob_ctx.map + Worker._run_kernel: call the mapper for every tile (in a
   deterministic order, on every rank) and join the updates it issued."""
   ctx = context.get()
   kw = dict(kw)
-  results = collections.OrderedDict()
+  results = KernelResults()
+  metas = []
   outer = ctx.pending
   outer_cache = ctx.fetch_cache
   batch = UpdateBatch(ctx)
@@ -922,6 +929,7 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
       if res is None:
         continue
       results[tile_id] = res.result
+      metas.append(getattr(res, 'meta', None))
       # a mapper returning an existing tile id shares it (worker.py:285-295)
       if res.result:
         for ex, tid in res.result:
@@ -933,6 +941,8 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
     ctx.fetch_cache = outer_cache
   if batch.items:
     batch.flush()
+  if metas and metas[0] is not None and all(m == metas[0] for m in metas):
+    results.meta = metas[0]
   return results
 
 
@@ -964,14 +974,17 @@ def create(shape, dtype=float, sharder=None, reducer=None, tile_hint=None, spars
   return arr
 
 
-def from_table(extents):
-  """distarray.py:519-550."""
+def from_table(extents, meta=None):
+  """distarray.py:519-550.  meta: (dtype, is_sparse) of the tiles when the caller knows it on every rank; otherwise
+  the owner of the first tile is asked (the reference's tile_op RPC, distarray.py:542)."""
   # (keys of a dict: no duplicates by construction -- the reference's check, distarray.py:528, guards its list form)
   if not extents:
     shape = tuple()
   else:
     shape = extent.find_shape(list(extents.keys()))
-  if len(extents) > 0:
+  if len(extents) > 0 and meta is not None:
+    dtype, sparse = np.dtype(meta[0]), bool(meta[1])
+  elif len(extents) > 0:
     key, tile_id = next(iter(extents.items()))
     dtype, sparse = context.get().tile_meta(tile_id)
   else:

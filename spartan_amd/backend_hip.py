@@ -387,6 +387,40 @@ class HipBackend(object):
     except lower.NotLowerable:
       return self._evaluate_eager(op, inputs, ex)
 
+  def map_result_meta(self, op, inputs, ex):
+    """(dtype, is_sparse) of what evaluate_map(op, inputs, ex) will produce, from the operator tree and the operands'
+    dtypes and shapes alone -- `inputs` may hold placeholders of tiles that live on other ranks -- or None when only
+    running it can tell (sparse operands, whole-tile functions, a user function that cannot be traced).  The answer
+    depends on nothing a rank holds alone, so every rank gets the same one."""
+    fn = getattr(op, 'fn', None)
+    rnd = getattr(fn, '_sp_random', None)
+    if rnd is not None:
+      return (np.dtype(rnd[1]), False)
+    if getattr(fn, '_sp_tile_fn', False) or self._op_structure(op) is None:
+      return None          # (a user's function would have to be RUN to be traced: never for a derivation)
+    described = {}
+    for name, v in inputs.items():
+      if tile.is_sparse_blob(v) or isinstance(v, tile.MaskedBlob):
+        return None
+      if isinstance(v, (distarray.Absent, D.DevArray)):
+        v = lower.V('tensor', dtype=v.dtype, shape=tuple(v.shape), tensor=None)
+      described[name] = v
+    try:
+      if self._materialise_random_needed(op):
+        return None
+      root = lower.infer(op, described, ex, self.dtype_of)
+      return (np.dtype(root.dtype), False) if root.dtype is not None else None
+    except Exception:   # noqa: BLE001  (whatever stops the derivation stops it on every rank alike)
+      return None
+
+  def _materialise_random_needed(self, op):
+    for d in getattr(op, 'deps', ()):
+      if getattr(getattr(d, 'fn', None), '_sp_random', None) is not None:
+        return True
+      if isinstance(d, FnCallExpr) and self._materialise_random_needed(d):
+        return True
+    return False
+
   # -- local functions that are not element-wise kernels ---------------------------------------------------------
   def _evaluate_eager(self, op, inputs, ex):
     """The reference runs ANY Python callable on its NumPy tiles (FnCallExpr.evaluate, local.py:115-127).  A tree

@@ -53,9 +53,10 @@ class TileId(object):
 class LocalKernelResult(object):
   """spartan/core.pyx:159-169."""
 
-  def __init__(self, result=None, futures=None):
+  def __init__(self, result=None, futures=None, meta=None):
     self.result = result
     self.futures = futures
+    self.meta = meta          # (dtype, is_sparse) of the produced tiles when EVERY rank can derive it (see map.tile_mapper)
 
 
 class Context(object):

@@ -2,6 +2,8 @@
 (`map`, `map_with_location`, `map2`, `MapExpr`, `Map2Expr`, `tile_mapper`, `join_mapper`).  The per-tile body of a
 map -- the reference evaluates the operator tree node by node with NumPy -- is ONE fused HIP kernel launch issued
 through the backend."""
+import numpy as np
+
 from . import base
 from .base import Expr, ListExpr, TupleExpr, as_array
 from .broadcast import Broadcast, broadcast, common_shape
@@ -26,14 +28,24 @@ def tile_mapper(ex, children, child_to_var, op):
   ctx = context.get()
   operands = get_local_values(ex, children, child_to_var)
   operands['extent'] = ex
+  # With several ranks every rank needs the dtype of the new array, and only the rank that ran the kernel has a
+  # tile to look at: the backend derives it from the operator tree and the operands' dtypes where it can -- on EVERY
+  # rank, from metadata all of them hold, so all of them take the same decision -- and the array is then built
+  # without asking the owner of its first tile (from_table -> Context.tile_meta, one control-plane broadcast per map)
+  meta = None
+  if ctx.world.size > 1:
+    derive = getattr(ctx.backend, 'map_result_meta', None)
+    meta = derive(op, operands, ex) if derive is not None else None
   if not ctx.executing:
-    return LocalKernelResult(result=[(ex, ctx.create(None))])      # another rank's tile: only the id advances
+    return LocalKernelResult(result=[(ex, ctx.create(None))], meta=meta)      # another rank's tile: only the id advances
   out = ctx.backend.evaluate_map(op, operands, ex)
   # (the reference hands back the INPUT tile's id when the operator returned its input unchanged, map.py:76-77;
   #  whether that happened is only known where the kernel ran, and tile ids must advance alike on all ranks)
   if tuple(out.shape) != ex.shape:
     raise AssertionError('Bad shape -- result = %s, op = (%s)' % (tuple(out.shape), op))
-  return LocalKernelResult(result=[(ex, ctx.create(tile.from_data(out, dtype=ctx.backend.dtype_of(out))))])
+  if meta is not None and (np.dtype(ctx.backend.dtype_of(out)) != meta[0] or tile.is_sparse_blob(out) != meta[1]):
+    raise AssertionError('derived tile type %s, kernel produced %s (op = %s)' % (meta, ctx.backend.dtype_of(out), op))
+  return LocalKernelResult(result=[(ex, ctx.create(tile.from_data(out, dtype=ctx.backend.dtype_of(out))))], meta=meta)
 
 
 class MapExpr(Expr):
