@@ -930,7 +930,7 @@ def main():
     if hbm and 'stream_copy_GBps' in hbm:
       copy = hbm['stream_copy_GBps']
       sections = {k[:-5]: {'GBps': v, 'frac_of_measured_copy': round(v / copy, 3), 'frac_of_spec': round(v / HBM_PEAK_GBPS, 3)}
-                  for k, v in hbm.items() if k.endswith('_GBps') and k != 'stream_copy_GBps'}
+                  for k, v in hbm.items() if k.endswith('_GBps') and k not in ('stream_copy_GBps', 'hbm_peak_GBps')}
       for name in ('lreg', 'kmeans', 'sparse'):
         sec = line.get(name) or {}
         for key, label in (('GBps', name + '_driver_loop'), ('step_kernels_GBps', name + '_step_kernels'),

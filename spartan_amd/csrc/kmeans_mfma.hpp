@@ -257,8 +257,15 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
   // One k-step (k-tile t of center block tr).  FIRST: the block's first k-tile, whose first MFMA per accumulator
   // takes 0 as its C operand -- the accumulators are never zeroed by VALU moves.
   int t = 0;
-  auto kstep = [&](auto first_of_block) {
+  // |x|^2 is summed during the FIRST center block a workgroup walks only (it does not depend on the centers; round 3
+  // summed it in every block and divided by their number): 28 VALU instructions per k-step less in the other blocks
+  // -- and on this chip every VALU instruction issued beside the MFMAs of a SIMD costs MFMA issue time (PMC, round 4:
+  // MFMA idle tracks the non-MFMA VALU count, 1.35 per MFMA here against 0.14 in the plain GEMM).
+  // (a compile-time switch of the k-step: as a run-time condition the compiler keeps the FMAs and selects)
+  const bool xs_first = !PARTIAL || blockIdx.y == 0;
+  auto kstep = [&](auto first_of_block, auto with_xs) {
     constexpr bool FIRST = decltype(first_of_block)::value;
+    constexpr bool XS = decltype(with_xs)::value;
     if (t + 1 < steps) KN_LOAD(t + 1);
     const float* sA = smem + (t & 1) * KN_STAGE;
     const float* sB = sA + KN_A_FLOATS;
@@ -269,10 +276,12 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
       for (int i = 0; i < 4; ++i) af[i] = *(const km_f32x4*)(sA + a_frag[c] + i * 32 * KM_BK);
 #pragma unroll
       for (int j = 0; j < 2; ++j) bf[j] = *(const km_f32x4*)(sB + b_frag[c] + j * 32 * KM_BK);
+      if constexpr (XS) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xs[j] = __builtin_fmaf(bf[j][s], bf[j][s], xs[j]);
+          for (int s = 0; s < 4; ++s) xs[j] = __builtin_fmaf(bf[j][s], bf[j][s], xs[j]);
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -293,8 +302,13 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
   };
   for (int tr = 0; tr < tiles_m; ++tr) {
     const int tm = tm_first + tr;
-    kstep(std::true_type());
-    for (int kt = 1; kt < nt; ++kt) kstep(std::false_type());
+    if (tr == 0 && xs_first) {
+      kstep(std::true_type(), std::true_type());
+      for (int kt = 1; kt < nt; ++kt) kstep(std::false_type(), std::true_type());
+    } else {
+      kstep(std::true_type(), std::false_type());
+      for (int kt = 1; kt < nt; ++kt) kstep(std::false_type(), std::false_type());
+    }
     // ---- epilogue of center block tm.  Halved scores h = |c|^2/2 - x.c; the rows of a lane ascend with
     // (i, q, e), so `<` keeps the first minimum; invariant best <= second, and the new second best is the
     // median of (best, second, h).
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
     bb[j] = b;
     ss[j] = s;
     ii[j] = ix;
-    xn[j] = (xs[j] + __shfl_xor(xs[j], 32)) / (float)tiles_m;
+    xn[j] = xs[j] + __shfl_xor(xs[j], 32);
   }
   if (wm == 1 && lh == 0) {
 #pragma unroll

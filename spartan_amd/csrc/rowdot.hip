@@ -10,7 +10,8 @@
 //     is d / 256 wave-wide loads of 1 KiB, all in flight together);
 //   * t = x . w: per-lane products added in column order, then a butterfly over the lanes; r = t - y[i];
 //   * g_lane[c] += x[c] * r for the lane's columns (product rounded, then added: -ffp-contract=off);
-//   * every wave writes its partial g to the workspace, and a second small kernel adds the partials in wave order.
+//   * the four waves of a workgroup add their partial g in LDS (wave order), the workgroup writes ONE partial to the
+//     workspace, and a second small kernel adds the partials in workgroup order.
 // No atomics: the result does not depend on scheduling.  Summation order differs from the two-launch form (its row
 // sums and column sums have their own trees), so results agree to rounding, not bit for bit; the expression
 // rewrite that selects this kernel (spartan_amd/expr/optimize.py: RowDotColSumFusion) is applied on the HIP
@@ -62,10 +63,28 @@ __global__ __launch_bounds__(256, 2) void sp_rowdot_colsum_kernel(const float* _
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[j][e] += x[j][e] * r;
   }
-  float* __restrict__ out = part + (int64_t)wave * d + 4 * lane;
+  // the four waves of the workgroup add up in LDS, in wave order, and ONE partial per workgroup goes to the workspace
+  // (round 3 wrote one per wave: 32 MB written and read again by the finishing kernel at configs[4], 3 % of the bytes
+  // of the pass itself)
+  __shared__ __attribute__((aligned(16))) float wsum[3][RD_MAX_D];
+  const int wv_in_wg = threadIdx.x >> 6;
+  if (wv_in_wg > 0) {
 #pragma unroll
-  for (int j = 0; j < RD_J; ++j)
-    if (j < nj || (j == nj && tail_lane)) *(rd_f4*)(out + 256 * j) = g[j];
+    for (int j = 0; j < RD_J; ++j)
+      if (j < nj || (j == nj && tail_lane)) *(rd_f4*)(&wsum[wv_in_wg - 1][256 * j + 4 * lane]) = g[j];
+  }
+  __syncthreads();
+  if (wv_in_wg == 0) {
+    float* __restrict__ out = part + (int64_t)blockIdx.x * d + 4 * lane;
+#pragma unroll
+    for (int j = 0; j < RD_J; ++j)
+      if (j < nj || (j == nj && tail_lane)) {
+        rd_f4 t = g[j];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t += *(const rd_f4*)(&wsum[k][256 * j + 4 * lane]);
+        *(rd_f4*)(out + 256 * j) = t;
+      }
+  }
 }
 
 // out[c] (+)= part[0][c] + part[1][c] + ... in wave order.  Workgroup: 64 columns x 16 groups of waves.
@@ -127,8 +146,8 @@ extern "C" int sp_rowdot_colsum_f32(const float* d_x, int64_t ldx, int64_t n, in
   const int waves = rd_waves(n);
   hipLaunchKernelGGL(sp_rowdot_colsum_kernel, dim3(waves / 4), dim3(256), 0, st, d_x, ldx, n, (int)d, d_w, d_y, ldy < 1 ? 1 : ldy, part);
   SP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sp_rowdot_finish_kernel, dim3((unsigned)((d + 63) / 64)), dim3(1024), 0, st, (const float*)part, waves, (int)d,
-                     d_out, (int)accumulate);
+  hipLaunchKernelGGL(sp_rowdot_finish_kernel, dim3((unsigned)((d + 63) / 64)), dim3(1024), 0, st, (const float*)part, waves / 4,
+                     (int)d, d_out, (int)accumulate);
   SP_CHECK_LAUNCH();
   return 0;
 }
