@@ -28,7 +28,9 @@ namespace {
 // the entries it served with two 512-lane workgroups of 2048 rows per CU (round 3: -DBSP_WIDE=0), so the slice
 // copies -- every row block of a site pulls the site's whole x through the L2 -- and the barriers around them halve
 // per entry: 42.2 -> 37.4 us on the 900 000-page tile.  (Timed with the slice loads / the run sums removed:
-// 32.3 / 29.7 us, both 23.9 us: what is left is the serial chunk pipeline, not bytes.)
+// 32.3 / 29.7 us, both 23.9 us: what is left is the serial chunk pipeline, not bytes.)  Entry loads and gathers
+// without conditions (exact s_waitcnt counts, see the kernel) and the row of a direct entry packed into its key:
+// 35.8 us.
 #ifndef BSP_WIDE
 #define BSP_WIDE 1
 #endif
@@ -42,6 +44,10 @@ constexpr int BSP_S = BSP_XS_BYTES / 4;   // columns per slice
 constexpr int BSP_MAX_RB = BSP_WIDE ? 4096 : 2048;   // rows per block (16-bit row ids; 4 B of accumulator each)
 constexpr int BSP_STAGE_MIN = 768;        // a 44 KB slice is 352 lines: staging pays from about twice as many gathers
 constexpr int BSP_MAX_SLICES = 16384;
+// direct segments: with at most 2^20 columns the row-in-block (12 bits) rides in the key above the column, and the
+// 16-bit row array is never read
+constexpr int BSP_PACK_SHIFT = 20;
+constexpr int64_t BSP_PACK_COLS = 1LL << BSP_PACK_SHIFT;
 constexpr int BSP_XV_N = (BSP_XS_BYTES / 16 + BSP_THREADS - 1) / BSP_THREADS;
 
 struct BspSeg {
@@ -56,7 +62,7 @@ struct BspLayout {
 };
 
 bool bsp_layout(int32_t dtype, int64_t m, int64_t k, int64_t nnz, BspLayout* L) {
-  if (dtype != SP_F32 || nnz < (1 << 18) || m < 4096 || k < 1 || nnz > 64 * m || k > 2147483647LL) return false;
+  if (dtype != SP_F32 || nnz < (1 << 18) || m < 4096 || k < 4 || nnz > 64 * m || k > 2147483647LL) return false;
   const int64_t ns = (k + BSP_S - 1) / BSP_S;
   if (ns > BSP_MAX_SLICES) return false;
   int64_t j = 1;
@@ -148,7 +154,9 @@ __global__ __launch_bounds__(BSP_THREADS) void sp_bsp_build_kernel(const int64_t
     bool overflow = false;
     for (int s = 0; s < ns && !overflow; ++s) {
       const int c = slice_cnt[s];
-      if (c >= BSP_STAGE_MIN) {
+      // (the matrix's last, narrower slice is staged only if 16-byte loads of it stay inside x)
+      const bool may_stage = (int64_t)(s + 1) * BSP_S <= k || (k & 3) == 0;
+      if (c >= BSP_STAGE_MIN && may_stage) {
         if (open >= 0) {
           segs[open].width = s * BSP_S - segs[open].col_lo;
           open = -1;
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(BSP_THREADS) void sp_bsp_build_kernel(const int64_t
       for (int64_t e = cursor[j]; e < rend[j] && indices[e] < col_hi; ++e) ++cnt;
     int64_t pos = e0 + seg_off[s] + bsp_block_exscan(cnt, wsum);
     const bool staged = segs[s].staged != 0;
+    const bool packed = k <= BSP_PACK_COLS;
     const int col_lo = segs[s].col_lo;
 #pragma unroll
     for (int j = 0; j < BSP_MAX_RB / BSP_THREADS; ++j) {
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(BSP_THREADS) void sp_bsp_build_kernel(const int64_t
       const uint32_t rl = (uint32_t)(tid * q + j);
       for (; e < rend[j] && indices[e] < col_hi; ++e, ++pos) {
         const int c = indices[e];
-        keys[pos] = staged ? (rl << 16) | (uint32_t)(c - col_lo) : (uint32_t)c;
+        keys[pos] = staged ? (rl << 16) | (uint32_t)(c - col_lo) : (packed ? (rl << BSP_PACK_SHIFT) | (uint32_t)c : (uint32_t)c);
         drow[pos] = (uint16_t)rl;
         pvals[pos] = vals[e];
       }
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(BSP_THREADS) void sp_bsp_build_kernel(const int64_t
 typedef float bsp_f4 __attribute__((ext_vector_type(4)));
 
 // (second launch bound: waves per SIMD -- two workgroups of 8 waves per CU)
+template <bool PACKED>
 __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) void sp_bsp_spmv_kernel(const int64_t* __restrict__ indptr, int64_t m, int rb,
                                                                      int nb, const int* __restrict__ nseg,
                                                                      const BspSeg* __restrict__ segtab,
@@ -280,43 +290,43 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
   u32x4 kA = {0, 0, 0, 0}, kB = {0, 0, 0, 0};      // A: being gathered (next chunk), B: being loaded (the one after)
   bsp_f4 vA = {0.f, 0.f, 0.f, 0.f}, vB = {0.f, 0.f, 0.f, 0.f}, xA = {0.f, 0.f, 0.f, 0.f};
   u16x4 rA = {0, 0, 0, 0}, rB = {0, 0, 0, 0};
-  // (a lane whose entries start inside the chunk loads all four: what lies behind the chunk's end is the next
-  // chunk's, or the padding of the plan arrays, and is never used)
+  // EVERY load of the loop below is issued by every lane in every iteration, with its address clamped into valid
+  // memory where the lane has nothing to fetch -- no load sits under a condition.  That is what lets the compiler
+  // count the loads in flight and wait for exactly the ones an instruction needs (s_waitcnt vmcnt(N > 0)): with
+  // conditional loads (round 3) it could not, every wait was vmcnt(0), and the entries "prefetched two chunks ahead"
+  // and the slice "requested one segment ahead" were in fact waited for as soon as they were issued -- each of the
+  // ~11 iterations of a row block paid a full memory latency (the 24 us floor of the round-4 ablation).
+  const int64_t e_first = e0;
   auto load_entries = [&](const Chunk& c, u32x4& kk, bsp_f4& vv, u16x4& rr) {
-    if (c.seg < n && i0 < c.cnt) {
-      kk = *(const u32x4*)(keys + c.e + i0);
-      vv = (bsp_f4)(*(const f32x4u*)(pvals + c.e + i0));
-      if (!c.staged) {
+    // (a lane whose entries start inside the chunk loads all four: what lies behind the chunk's end is the next
+    // chunk's, or the padding of the plan arrays, and is never used; a lane past the chunk re-reads its start)
+    const int64_t at = c.seg < n ? c.e + (i0 < c.cnt ? i0 : 0) : e_first;
+    kk = *(const u32x4*)(keys + at);
+    vv = (bsp_f4)(*(const f32x4u*)(pvals + at));
+    if constexpr (!PACKED) {
 #pragma unroll
-        for (int u = 0; u < BSP_PER; ++u) rr[u] = drow[c.e + i0 + u];
-      }
+      for (int u = 0; u < BSP_PER; ++u) rr[u] = drow[at + u];
     }
   };
   auto gather_direct = [&](const Chunk& c, const u32x4& kk, bsp_f4& xx) {
-    if (c.seg < n && !c.staged && i0 < c.cnt) {
+    const bool live = c.seg < n && !c.staged;
 #pragma unroll
-      for (int u = 0; u < BSP_PER; ++u) xx[u] = i0 + u < c.cnt ? x[kk[u]] : 0.f;
+    for (int u = 0; u < BSP_PER; ++u) {
+      const uint32_t col = PACKED ? (kk[u] & (uint32_t)(BSP_PACK_COLS - 1)) : kk[u];
+      xx[u] = x[(live && i0 + u < c.cnt) ? col : 0u];
     }
   };
   // slices of x travel global -> registers -> LDS, requested one staged segment ahead (two ahead, 48 more registers,
-  // measured slower: 44.5 vs 40.6 us)
+  // measured slower: 44.5 vs 40.6 us).  16-byte loads; a vector past the slice's end reads the start of x instead
+  // (the plan stages a narrower last slice only when k is a multiple of 4: no vector straddles the end of x).
   bsp_f4 xr0[BSP_XV_N];
   auto prefetch_slice = [&](int s, bsp_f4* xr) {
-    const int lo = segs[s].col_lo, w = segs[s].width;
+    const int lo = s < n ? segs[s].col_lo : 0, w = s < n ? segs[s].width : 4;
     const float* __restrict__ xl = x + lo;
-    if (w == BSP_S) {                   // every slice but the matrix's last: no per-lane guards
 #pragma unroll
-      for (int u = 0; u < BSP_XV_N; ++u) {
-        const int i = (u * BSP_THREADS + tid) * 4;
-        if ((u + 1) * BSP_THREADS * 4 <= BSP_S || i < BSP_S) xr[u] = *(const bsp_f4*)(xl + i);
-      }
-    } else {                            // clamped element loads: what lies past the slice's end is never used
-#pragma unroll
-      for (int u = 0; u < BSP_XV_N; ++u) {
-        const int i = (u * BSP_THREADS + tid) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xr[u][e] = xl[i + e < w ? i + e : w - 1];
-      }
+    for (int u = 0; u < BSP_XV_N; ++u) {
+      const int i = (u * BSP_THREADS + tid) * 4;
+      xr[u] = i < w ? *(const bsp_f4*)(xl + i) : *(const bsp_f4*)x;
     }
   };
   auto next_staged = [&](int s) {       // first staged segment after s (n: none)
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
   gather_direct(cur, kA, xA);
   int slice_in_lds = -1;
   int ahead0 = next_staged(-1);     // the segment whose slice is in xr0
-  if (ahead0 < n) prefetch_slice(ahead0, xr0);
+  prefetch_slice(ahead0, xr0);
   int buf = 0;
   while (cur.seg < n) {
     if (cur.staged && slice_in_lds != cur.seg) {
@@ -345,8 +355,10 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
       }
       slice_in_lds = cur.seg;
       __syncthreads();
+      // (requested only when a slice was taken: asking for the same slice again in every iteration, to have this
+      // load unconditional like the others, measured slower -- 37.1 against 35.8 us)
       ahead0 = next_staged(ahead0);
-      if (ahead0 < n) prefetch_slice(ahead0, xr0);
+      prefetch_slice(ahead0, xr0);
     }
     // products of the current chunk (entries and direct gathers were requested one / two chunks ago)
     float* pb = prod + buf * BSP_CAP;
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
       for (int u = 0; u < BSP_PER; ++u) {
         const float xv = cur.staged ? xs[kA[u] & 0xffffu] : xA[u];
         p[u] = vA[u] * xv;
-        r[u] = cur.staged ? (uint16_t)(kA[u] >> 16) : rA[u];
+        r[u] = cur.staged ? (uint16_t)(kA[u] >> 16) : (PACKED ? (uint16_t)(kA[u] >> BSP_PACK_SHIFT) : rA[u]);
       }
       *(bsp_f4*)(pb + i0) = p;
       *(u16x4*)(rbuf + i0) = r;
@@ -461,14 +473,21 @@ extern "C" int sp_csr_spmv_blocked(int32_t dtype, int64_t m, int64_t k, int64_t 
   constexpr int lds_bytes = BSP_XS_BYTES + (BSP_MAX_RB + 4) * 4 + 2 * BSP_CAP * 4 + 2 * BSP_CAP * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    SP_HIP(hipFuncSetAttribute((const void*)sp_bsp_spmv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    SP_HIP(hipFuncSetAttribute((const void*)sp_bsp_spmv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    SP_HIP(hipFuncSetAttribute((const void*)sp_bsp_spmv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   const int per = (int)((L.nb + 7) / 8);
-  hipLaunchKernelGGL(sp_bsp_spmv_kernel, dim3((unsigned)(per * 8)), dim3(BSP_THREADS), lds_bytes, (hipStream_t)stream, d_indptr, m,
-                     (int)L.rb, (int)L.nb, (const int*)(P + L.nseg_off), (const BspSeg*)(P + L.seg_off),
-                     (const uint32_t*)(P + L.key_off), (const uint16_t*)(P + L.drow_off), (const float*)(P + L.val_off),
-                     (const float*)d_x, (float*)d_y, ldy, (int)accumulate);
+  if (k <= BSP_PACK_COLS)
+    hipLaunchKernelGGL(sp_bsp_spmv_kernel<true>, dim3((unsigned)(per * 8)), dim3(BSP_THREADS), lds_bytes, (hipStream_t)stream,
+                       d_indptr, m, (int)L.rb, (int)L.nb, (const int*)(P + L.nseg_off), (const BspSeg*)(P + L.seg_off),
+                       (const uint32_t*)(P + L.key_off), (const uint16_t*)(P + L.drow_off), (const float*)(P + L.val_off),
+                       (const float*)d_x, (float*)d_y, ldy, (int)accumulate);
+  else
+    hipLaunchKernelGGL(sp_bsp_spmv_kernel<false>, dim3((unsigned)(per * 8)), dim3(BSP_THREADS), lds_bytes, (hipStream_t)stream,
+                       d_indptr, m, (int)L.rb, (int)L.nb, (const int*)(P + L.nseg_off), (const BspSeg*)(P + L.seg_off),
+                       (const uint32_t*)(P + L.key_off), (const uint16_t*)(P + L.drow_off), (const float*)(P + L.val_off),
+                       (const float*)d_x, (float*)d_y, ldy, (int)accumulate);
   SP_CHECK_LAUNCH();
   return 0;
 }
