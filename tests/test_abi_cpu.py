@@ -128,3 +128,28 @@ def test_host_side_plans_need_no_device():
   assert plan(900000, 900000, 9000000, _hip.SP_F64) == 0      # fp32 only
   assert plan(3000, 3000, 300000) == 0 and plan(900000, 900000, 100000) == 0      # too few rows / entries
   assert plan(5000, 5000, 5000 * 100) == 0                    # long rows: the lanes-per-row kernels
+
+
+def test_rccl_is_found_in_the_documented_order():
+  """libspartan_hip.so binds RCCL with dlopen: $SPARTAN_RCCL_LIB first, then librccl.so.1, librccl.so,
+  /opt/rocm/lib/librccl.so.1 (README.md).  In fresh interpreters: a path given in the variable is the library that
+  gets loaded; a path that does not exist falls through to the default names."""
+  import subprocess
+  import sys
+  system = '/opt/rocm/lib/librccl.so.1'
+  if not os.path.exists(system):
+    pytest.skip('no RCCL in this image')
+  prog = ("import ctypes, os, sys\n"
+          "sys.path.insert(0, %r)\n"
+          "from spartan_amd import _hip\n"
+          "lib = _hip.lib()\n"
+          "assert lib.sp_comm_available() == 1, lib.sp_last_error()\n"
+          "v = ctypes.c_int(0)\n"
+          "assert lib.sp_comm_version(ctypes.byref(v)) == 0 and v.value > 20000\n"
+          "print('LOADED', sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l)))\n") % ROOT
+  for value, expect in ((os.path.realpath(system), os.path.realpath(system)), ('/nonexistent/librccl.so', 'librccl')):
+    env = dict(os.environ, SPARTAN_RCCL_LIB=value)
+    out = subprocess.run([sys.executable, '-c', prog], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    text = out.stdout.decode('utf-8', 'replace')
+    assert out.returncode == 0 and 'LOADED' in text, text[-2000:]
+    assert expect in text.split('LOADED', 1)[1], text[-500:]
