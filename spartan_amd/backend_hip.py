@@ -135,7 +135,9 @@ class HipBackend(object):
     from . import context
     ctx = context.get() if context.initialized() else None
     epoch = ctx.eval_epoch if ctx is not None and ctx.eval_depth > 0 else None     # (a direct backend call: no epoch)
-    key = (id(arr), tuple((s.start, s.stop) for s in slices))
+    # (one key per box however it is spelt: missing trailing axes, None bounds)
+    key = (id(arr), tuple([(s.start or 0, arr.shape[i] if s.stop is None else s.stop) for i, s in enumerate(slices)] +
+                          [(0, n) for n in arr.shape[len(slices):]]))
     hit = self._np_cache.get(key)
     if hit is not None and hit[0] is arr:
       if epoch is not None and hit[3] == epoch:
