@@ -63,6 +63,7 @@ class HipBackend(object):
     # program + operand order (see _lowering_key); a hit skips type inference and code emission, not the launch
     self._lowered = collections.OrderedDict()
     self.lowering_hits = 0
+    lower.warm_result_dtypes()
     # the code objects that travel with the tree (csrc/jit_seed) are loaded while the host builds its first
     # expressions: ctypes drops the GIL for the call, a seeded program then starts specialised at once
     dev = ctypes.c_int32(0)

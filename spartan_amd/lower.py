@@ -71,6 +71,42 @@ def _dummy(v):
 _result_dtypes = {}
 
 
+def _weak_key(value):
+  """What a weak Python scalar contributes to a result dtype (NEP 50): its kind -- its value only where it could
+  overflow the other operand's integer type."""
+  t = type(value)
+  if t is float or t is bool or (t is int and -2147483648 <= value < 2147483648):
+    return ('weak', t)
+  return (t, value)
+
+
+def warm_result_dtypes():
+  """Ask NumPy once, when the backend comes up, for the result dtype of every registered ufunc over the operand
+  types programs are made of (fp32 / fp64 / int64 / int32 / bool tiles, weak Python floats and ints): the first
+  lowering of a program then meets a filled table instead of paying ~30 us per operator it has not seen."""
+  tiles = [np.dtype(t) for t in (np.float32, np.float64, np.int64, np.int32, np.bool_)]
+  weak = [1.5, 1]
+  with np.errstate(all='ignore'):
+    for fn in list(MAP_RULES):
+      if not isinstance(fn, np.ufunc):
+        continue
+      combos = []
+      if fn.nin == 1:
+        combos = [(t,) for t in tiles]
+      elif fn.nin == 2:
+        combos = [(a, b) for a in tiles for b in tiles if a == b or a.kind != b.kind]
+        combos += [(a, w) for a in tiles for w in weak] + [(w, a) for a in tiles for w in weak]
+      for combo in combos:
+        key = (fn, tuple([_weak_key(c) if not isinstance(c, np.dtype) else c for c in combo]))
+        if key in _result_dtypes:
+          continue
+        try:
+          res = fn(*[np.zeros((), c) if isinstance(c, np.dtype) else c for c in combo])
+          _result_dtypes[key] = np.asarray(res).dtype
+        except Exception:   # noqa: BLE001  (a combination NumPy refuses is refused again when a program asks)
+          pass
+
+
 def _bshape(*shapes):
   return tuple(np.broadcast_shapes(*shapes))
 
@@ -87,7 +123,7 @@ def apply(opname, np_fn, args):
   # NumPy's own answer, asked once per (function, operand types): the dummy call costs tens of microseconds
   # (np.errstate alone ~10), a fused tree has one per operator, and a driver loop lowers the same trees for ever
   try:
-    key = (np_fn, tuple([(type(a.value), a.value) if (a.kind == 'const' and a.weak) else a.dtype for a in args]))
+    key = (np_fn, tuple([_weak_key(a.value) if (a.kind == 'const' and a.weak) else a.dtype for a in args]))
     dt = _result_dtypes.get(key)
   except TypeError:
     key = dt = None
