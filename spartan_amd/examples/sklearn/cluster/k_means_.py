@@ -106,15 +106,33 @@ class KMeans(object):
       sums[empty, :] = _replicated(lambda: np.random.randn(n_empty, sums.shape[1]))
     return sums, counts
 
-  def _accumulate_join(self, X, labels, reducer):
+  def _accumulate_join(self, X, labels, reducer, keep_on_worker=False):
+    """counts and per-cluster sums of the labelled points -> the new centers.
+
+    keep_on_worker: the caller feeds the centers straight into the next assignment (the 'map2' loop).  The division
+    sums / counts then runs where the sums are -- NumPy's own arithmetic on the backend's tiles, float32 / int64 ->
+    float64 like the host's -- and the centers never visit the driver: only the k counts do, because an empty cluster
+    is re-seeded from the driver's random stream (rare; that iteration takes the host route below).  Per iteration
+    this removes a 1 MB download, a host division and a 2 MB upload from the chain between the segment sums and the
+    next assignment (configs[3]: 78 + 72 + 81 us of 6.1 ms, the device idle meanwhile)."""
     k, dim = self.n_clusters, X.shape[1]
     counts = expr.map2(labels, 0, fn=kmeans_count_mapper, fn_kw={'centers_count': k}, shape=(k,),
                        reducer=reducer)
     sums = expr.map2((X, labels), (0, 0), fn=kmeans_center_mapper, fn_kw={'centers_count': k},
                      shape=(k, dim), reducer=reducer)
     counts, sums = counts.optimized(), sums.optimized()
-    counts.evaluate()
-    sums.evaluate()            # both joins are launched before the first glom() waits for the device
+    counts_arr = counts.evaluate()
+    sums_arr = sums.evaluate()     # both joins are launched before anything waits for the device
+    if keep_on_worker:
+      be = context.get().backend
+      count_t = counts_arr.fetch(extent.from_shape(counts_arr.shape))     # replicated: every rank holds all of it
+      sum_t = sums_arr.fetch(extent.from_shape(sums_arr.shape))
+      plain = not any(type(t).__name__ in ('MaskedBlob', 'EmptyBlob') for t in (count_t, sum_t))
+      if plain:
+        with np.errstate(all='ignore'):                # (an empty cluster divides by zero: that result is not used)
+          ahead = sum_t / count_t.reshape(k, 1)        # enqueued before the driver waits for the counts
+        if not np.any(be.to_numpy(count_t) == 0):
+          return ahead
     counts, sums = counts.glom(), sums.glom()
     sums, counts = self._finish(sums, counts)
     return sums / counts.reshape(k, 1)
@@ -122,7 +140,7 @@ class KMeans(object):
   # ---- one iteration per implementation: (X, centers) -> (centers, labels) -----------------------------------
   def _step_map2(self, X, centers, reducer):
     labels = expr.map2(X, 0, fn=kmeans_map2_dist_mapper, fn_kw={'centers': centers}, shape=(X.shape[0],))
-    return self._accumulate_join(X, labels, reducer), labels
+    return self._accumulate_join(X, labels, reducer, keep_on_worker=True), labels
 
   def _step_outer(self, X, centers, reducer):
     labels = expr.outer((X, centers), (0, None), fn=kmeans_outer_dist_mapper, shape=(X.shape[0],))
@@ -172,6 +190,8 @@ class KMeans(object):
           centers, labels = self._step_map2(X, centers, reducer)
         else:
           centers = self._step_shuffle(X, centers, labels)
+      if not isinstance(centers, np.ndarray):          # the 'map2' loop keeps them on the workers between iterations
+        centers = context.get().backend.to_numpy(centers)
       return centers, labels
     if implementation in ('outer', 'broadcast'):
       if centers is None:

@@ -71,6 +71,8 @@ def _describe_value(v, pins):
             v.written is None)
   if isinstance(v, np.ndarray):
     return ('N', v.shape, v.dtype.str)
+  if hasattr(v, 'data_ptr') and hasattr(v, 'strides'):       # a backend tensor used as a driver-side operand
+    return ('B', tuple(v.shape), np.dtype(v.dtype).str)
   if isinstance(v, np.generic):
     return ('G', v.dtype.str, v.item())
   if isinstance(v, _SIMPLE):
@@ -146,7 +148,7 @@ class _Walk(object):
       return (t, tuple([field(x) for x in v]))
     if t is dict:
       return ('dict', tuple([(k, self.field(x)) for k, x in sorted(v.items(), key=_by_name)]))
-    if isinstance(v, (np.ndarray, distarray.DistArrayImpl)):
+    if isinstance(v, (np.ndarray, distarray.DistArrayImpl)) or (hasattr(v, 'data_ptr') and hasattr(v, 'strides')):
       first = self.seen.get(id(v))
       if first is not None:
         return ('@', first)                 # the same object again: the recipe maps it to one slot
@@ -237,7 +239,7 @@ class Plan(object):
           d = v.__dict__
           n.fields = tuple((name, compile_(d[name])) for name in v.members)
         return n
-      if isinstance(v, (np.ndarray, distarray.DistArray)):
+      if isinstance(v, (np.ndarray, distarray.DistArray)) or hasattr(v, 'data_ptr'):
         raise Unplannable('the optimised DAG holds data of its own')
       if isinstance(v, (list, tuple)):
         return type(v)(compile_(x) for x in v) if type(v) in (list, tuple) else v
