@@ -574,6 +574,15 @@ int sp_event_synchronize(void* ev);
 int sp_event_query(void* ev, int32_t* done);
 int sp_event_elapsed_ms(void* start, void* stop, float* ms);
 
+/* Pinned host buffers and a device -> host copy that does NOT wait: a driver loop that needs a few bytes of a result
+ * on the host one iteration LATER (the cluster counts of a k-means iteration: is any cluster empty?) enqueues the copy
+ * on a side stream behind an event and reads the buffer after sp_event_synchronize, while the compute stream is
+ * already working on the next iteration.  (The reference's driver waits for every glom: blob_ctx.get, worker.py
+ * 172-179; this is what replaces the wait when the value is only a check.) */
+int sp_pinned_alloc(size_t bytes, void** host);
+int sp_pinned_free(void* host);
+int sp_copy_d2h_async(void* pinned_host, const void* d_src, size_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,39 @@ class HipBackend(object):
       return np.zeros(t.shape, t.dtype)
     return t.numpy() if isinstance(t, D.DevArray) else np.asarray(t.cpu().numpy())
 
+  def to_numpy_later(self, t):
+    """A handle whose get() is the host copy of the (small, contiguous) device tensor `t` AS IT IS ONCE EVERYTHING
+    ENQUEUED SO FAR HAS RUN -- without making the host wait now: the copy is put on a side stream behind an event
+    into a pinned buffer, the compute stream goes on (sp_copy_d2h_async).  For values a driver only CHECKS (the
+    cluster counts of a k-means iteration), one iteration later."""
+    t = self.contiguous(t)
+    ready = D.Event().record()
+    if getattr(self, '_side_copies', None) is None:
+      self._side_copies = D.Stream()
+    side = self._side_copies
+    side.wait_event(ready)
+    # pinned landing buffers are kept (hipHostMalloc maps memory, hipHostFree waits for the device): a free list by size
+    if getattr(self, '_pinned_free', None) is None:
+      self._pinned_free = {}
+    size = max(256, 1 << (max(t.nbytes, 1) - 1).bit_length())
+    free = self._pinned_free.setdefault(size, [])
+    if free:
+      host = free.pop()
+    else:
+      host = ctypes.c_void_p()
+      _hip.check(_hip.lib().sp_pinned_alloc(size, ctypes.byref(host)))
+    _hip.check(_hip.lib().sp_copy_d2h_async(host, ctypes.c_void_p(t.data_ptr()), t.nbytes, side.ptr))
+    done = D.Event().record(side)
+    shape, dtype = tuple(t.shape), np.dtype(t.dtype)
+
+    class Later(object):
+      def get(self_inner, keep=t):         # (`keep`: the tensor must outlive the copy)
+        done.synchronize()
+        out = np.frombuffer(ctypes.string_at(host, int(np.prod(shape, dtype=np.int64)) * dtype.itemsize), dtype).reshape(shape).copy()
+        free.append(host)
+        return out
+    return Later()
+
   def dtype_of(self, t):
     if isinstance(t, sparse_mod.CsrTile):
       return t.dtype

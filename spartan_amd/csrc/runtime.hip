@@ -337,6 +337,25 @@ extern "C" int sp_blob_slice_copy(uint64_t dst, const int64_t* dst_ul, uint64_t 
                        d.ndim, (int32_t)es, stream);
 }
 
+extern "C" int sp_pinned_alloc(size_t bytes, void** host) {
+  if (!host) SP_FAIL("sp_pinned_alloc: NULL argument");
+  *host = nullptr;
+  SP_HIP(hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault));
+  return 0;
+}
+
+extern "C" int sp_pinned_free(void* host) {
+  if (host) SP_HIP(hipHostFree(host));
+  return 0;
+}
+
+extern "C" int sp_copy_d2h_async(void* pinned_host, const void* d_src, size_t bytes, void* stream) {
+  if (!bytes) return 0;
+  if (!pinned_host || !d_src) SP_FAIL("sp_copy_d2h_async: NULL pointer");
+  SP_HIP(hipMemcpyAsync(pinned_host, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // collectives (RCCL)
 // --------------------------------------------------------------------------------------------------------------

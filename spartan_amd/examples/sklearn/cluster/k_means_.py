@@ -106,41 +106,80 @@ class KMeans(object):
       sums[empty, :] = _replicated(lambda: np.random.randn(n_empty, sums.shape[1]))
     return sums, counts
 
-  def _accumulate_join(self, X, labels, reducer, keep_on_worker=False):
-    """counts and per-cluster sums of the labelled points -> the new centers.
-
-    keep_on_worker: the caller feeds the centers straight into the next assignment (the 'map2' loop).  The division
-    sums / counts then runs where the sums are -- NumPy's own arithmetic on the backend's tiles, float32 / int64 ->
-    float64 like the host's -- and the centers never visit the driver: only the k counts do, because an empty cluster
-    is re-seeded from the driver's random stream (rare; that iteration takes the host route below).  Per iteration
-    this removes a 1 MB download, a host division and a 2 MB upload from the chain between the segment sums and the
-    next assignment (configs[3]: 78 + 72 + 81 us of 6.1 ms, the device idle meanwhile)."""
+  def _launch_join(self, X, labels, reducer):
+    """The two accumulate joins of an iteration, launched; nothing waits for the device."""
     k, dim = self.n_clusters, X.shape[1]
     counts = expr.map2(labels, 0, fn=kmeans_count_mapper, fn_kw={'centers_count': k}, shape=(k,),
                        reducer=reducer)
     sums = expr.map2((X, labels), (0, 0), fn=kmeans_center_mapper, fn_kw={'centers_count': k},
                      shape=(k, dim), reducer=reducer)
     counts, sums = counts.optimized(), sums.optimized()
-    counts_arr = counts.evaluate()
-    sums_arr = sums.evaluate()     # both joins are launched before anything waits for the device
-    if keep_on_worker:
-      be = context.get().backend
-      count_t = counts_arr.fetch(extent.from_shape(counts_arr.shape))     # replicated: every rank holds all of it
-      sum_t = sums_arr.fetch(extent.from_shape(sums_arr.shape))
-      plain = not any(type(t).__name__ in ('MaskedBlob', 'EmptyBlob') for t in (count_t, sum_t))
-      if plain:
-        with np.errstate(all='ignore'):                # (an empty cluster divides by zero: that result is not used)
-          ahead = sum_t / count_t.reshape(k, 1)        # enqueued before the driver waits for the counts
-        if not np.any(be.to_numpy(count_t) == 0):
-          return ahead
-    counts, sums = counts.glom(), sums.glom()
+    return counts.evaluate(), sums.evaluate()
+
+  def _centers_on_host(self, counts_arr, sums_arr):
+    """The reference's driver step: glom both, re-seed empty clusters, divide."""
+    counts, sums = counts_arr.glom(), sums_arr.glom()
     sums, counts = self._finish(sums, counts)
-    return sums / counts.reshape(k, 1)
+    return sums / counts.reshape(self.n_clusters, 1)
+
+  def _accumulate_join(self, X, labels, reducer):
+    return self._centers_on_host(*self._launch_join(X, labels, reducer))
+
+  def _centers_on_worker(self, counts_arr, sums_arr):
+    """(centers, check) with the division sums / counts done where the sums are -- NumPy's own arithmetic on the
+    backend's tiles, float32 / int64 -> float64 like the host's -- so that the centers never visit the driver; only
+    the k counts do, and LATER: `check()` says whether every cluster had points (an empty one is re-seeded from the
+    driver's random stream, which takes the host route).  (None, None) if the tiles are not plain."""
+    k = self.n_clusters
+    be = context.get().backend
+    count_t = counts_arr.fetch(extent.from_shape(counts_arr.shape))     # replicated: every rank holds all of it
+    sum_t = sums_arr.fetch(extent.from_shape(sums_arr.shape))
+    if any(type(t).__name__ in ('MaskedBlob', 'EmptyBlob') for t in (count_t, sum_t)):
+      return None, None
+    with np.errstate(all='ignore'):                # (an empty cluster divides by zero: that result is not used)
+      centers = sum_t / count_t.reshape(k, 1)
+    later = getattr(be, 'to_numpy_later', None)
+    if later is None or isinstance(count_t, np.ndarray):
+      ok = not np.any(be.to_numpy(count_t) == 0)
+      return centers, (lambda: ok)
+    handle = later(count_t)
+    return centers, (lambda: not np.any(handle.get() == 0))
+
+  def _fit_map2(self, X, centers, reducer):
+    """The 'map2' loop with the centers kept on the workers between iterations and the empty-cluster check of an
+    iteration made one iteration LATE: iteration i + 1 is launched with the centers iteration i produced before the
+    driver has seen i's counts, so the device queue never drains (configs[3]: the chain download 1 MB -> divide on
+    the host -> upload 2 MB -> build and launch cost 0.43 of 6.1 ms per iteration with the device idle).  If the late
+    check finds an empty cluster -- rare -- what was launched on those centers is dropped and the loop continues from
+    the reference's host step for iteration i: same centers, same draws from the driver's random stream, same order."""
+    labels = None
+    checked = None          # (check, counts_arr, sums_arr) of the iteration whose centers are in use, not yet verified
+    it = 0
+    while it < self.n_iter:
+      labels_try = expr.map2(X, 0, fn=kmeans_map2_dist_mapper, fn_kw={'centers': centers}, shape=(X.shape[0],))
+      counts_arr, sums_arr = self._launch_join(X, labels_try, reducer)
+      if checked is not None and not checked[0]():
+        # iteration it - 1 had an empty cluster: redo its driver step on the host, then this iteration again
+        centers = self._centers_on_host(checked[1], checked[2])
+        checked = None
+        continue
+      labels = labels_try
+      ahead, check = self._centers_on_worker(counts_arr, sums_arr)
+      if ahead is None:
+        centers, checked = self._centers_on_host(counts_arr, sums_arr), None
+      else:
+        centers, checked = ahead, (check, counts_arr, sums_arr)
+      it += 1
+    if checked is not None and not checked[0]():
+      centers = self._centers_on_host(checked[1], checked[2])
+    if not isinstance(centers, np.ndarray):
+      centers = context.get().backend.to_numpy(centers)
+    return centers, labels
 
   # ---- one iteration per implementation: (X, centers) -> (centers, labels) -----------------------------------
   def _step_map2(self, X, centers, reducer):
     labels = expr.map2(X, 0, fn=kmeans_map2_dist_mapper, fn_kw={'centers': centers}, shape=(X.shape[0],))
-    return self._accumulate_join(X, labels, reducer, keep_on_worker=True), labels
+    return self._accumulate_join(X, labels, reducer), labels
 
   def _step_outer(self, X, centers, reducer):
     labels = expr.outer((X, centers), (0, None), fn=kmeans_outer_dist_mapper, shape=(X.shape[0],))
@@ -185,13 +224,10 @@ class KMeans(object):
     if implementation in ('map2', 'shuffle'):
       if centers is None:
         centers = _replicated(lambda: np.random.rand(k, dim))
+      if implementation == 'map2':
+        return self._fit_map2(X, centers, reducer)
       for _ in range(self.n_iter):
-        if implementation == 'map2':
-          centers, labels = self._step_map2(X, centers, reducer)
-        else:
-          centers = self._step_shuffle(X, centers, labels)
-      if not isinstance(centers, np.ndarray):          # the 'map2' loop keeps them on the workers between iterations
-        centers = context.get().backend.to_numpy(centers)
+        centers = self._step_shuffle(X, centers, labels)
       return centers, labels
     if implementation in ('outer', 'broadcast'):
       if centers is None:

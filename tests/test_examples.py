@@ -143,6 +143,28 @@ def test_regressions_host_framework(cpu_ctx):
   _check_other_regressions(cpu_ctx, rtol=0)
 
 
+def _late_check_equals_stepwise(n_iter):
+  """The 'map2' loop checks an iteration's cluster counts one iteration late (and redoes what it launched on centers
+  that needed re-seeding): same centers, labels and draws from the driver's random stream as one step at a time."""
+  x, init = INPUTS['km_x'], INPUTS['km_init_empty']
+  X = sp.from_numpy(x)
+  np.random.seed(99)
+  centers, labels = KMeans(5, n_iter).fit(X, init.copy(), implementation='map2')
+  after = np.random.randn()
+  np.random.seed(99)
+  km, want_c, want_l = KMeans(5, n_iter), init.copy(), None
+  for _ in range(n_iter):
+    want_c, want_l = km._step_map2(X, want_c, None)
+  np.testing.assert_array_equal(_val(labels), _val(want_l))
+  np.testing.assert_array_equal(centers, want_c)
+  assert after == np.random.randn()
+
+
+@pytest.mark.parametrize('n_iter', [1, 2, 4])
+def test_kmeans_late_empty_check_host_framework(cpu_ctx, n_iter):
+  _late_check_equals_stepwise(n_iter)
+
+
 def test_kmeans_reducer_combines_tiles(cpu_ctx):
   """fit(reducer=np.add) is the true k-means update: equal to a NumPy Lloyd iteration for any tiling."""
   x, init = INPUTS['km_x'], INPUTS['km_init'].copy()
@@ -168,6 +190,22 @@ def gpu_ctx(request):
 def test_kmeans_hip(gpu_ctx, impl, tag):
   # 'broadcast' sums squares / matches with the LDS reduction tree, not NumPy's order
   _check_kmeans(gpu_ctx, impl, tag, exact_centers=(impl != 'broadcast'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_iter', [1, 2, 4])
+def test_kmeans_late_empty_check_hip(gpu_ctx, n_iter):
+  _late_check_equals_stepwise(n_iter)
+
+
+@pytest.mark.gpu
+def test_to_numpy_later_sees_the_value_at_the_time_of_the_call(gpu_ctx):
+  be = sp.context.get().backend
+  t = be.from_numpy(np.arange(1000, dtype=np.int64))
+  later = be.to_numpy_later(t)
+  t[:] = np.arange(1000, dtype=np.int64) + 5   # enqueued after the copy was ordered: not seen by it
+  np.testing.assert_array_equal(later.get(), np.arange(1000))
+  np.testing.assert_array_equal(be.to_numpy(t), np.arange(1000) + 5)
 
 
 @pytest.mark.gpu
