@@ -155,6 +155,16 @@ def hbm_section(ctx):
   out['map_5op_chain_jit_GBps'] = round(8.0 * n / ms / 1e6, 1)
   ms = event_time(lambda: sp.sum((Xv - 0.5) * (Xv - 0.5), axis=0).optimized().force(), 10)
   out['sum_sq_dev_axis0_jit_GBps'] = round(4.0 * n / ms / 1e6, 1)
+  # the same two programs on the interpreter tier (what a program nobody seeded runs on until hipRTC is done, and
+  # every small tile): run-time specialisation switched off around the measurement
+  _hip.lib().sp_jit_configure(0, -1)
+  try:
+    ms = event_time(chain, 10, section=('map 5-op chain, interpreted', 'DynProg', 8.0 * n, 'bytes', 'hbm'))
+    out['map_5op_chain_interpreter_GBps'] = round(8.0 * n / ms / 1e6, 1)
+    ms = event_time(lambda: sp.sum((Xv - 0.5) * (Xv - 0.5), axis=0).optimized().force(), 10)
+    out['sum_sq_dev_axis0_interpreter_GBps'] = round(4.0 * n / ms / 1e6, 1)
+  finally:
+    _hip.lib().sp_jit_configure(1, -1)
   for axis, kern in ((None, 'sp_reduce_rows_kernel'), (0, 'sp_reduce_cols_kernel'), (1, 'sp_reduce_rows_kernel')):
     ms = event_time(lambda: sp.sum(Xv, axis).force(), 10,
                     section=('sum axis=%s' % axis, kern, 4.0 * n, 'bytes', 'hbm'))

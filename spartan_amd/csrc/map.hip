@@ -33,6 +33,9 @@ int sp_validate_program(const sp_program* p) {
   if (p->ndim < 1 || p->ndim > SP_MAX_DIMS) SP_FAIL("ndim=%d out of range", p->ndim);
   if (p->result_reg < 0 || p->result_reg >= SP_NREG) SP_FAIL("result_reg=%d out of range", p->result_reg);
   if (p->n_inputs > SP_NREG) SP_FAIL("n_inputs=%d exceeds register file", p->n_inputs);
+  // registers 0 .. n_inputs-1 hold the operands; every other register must be written before it is read (the
+  // interpreter does not clear its register file: 32 moves per evaluation that no lowered program needs)
+  unsigned defined = (1u << p->n_inputs) - 1u;
   for (int i = 0; i < p->n_instr; ++i) {
     const sp_instr& I = p->instr[i];
     if (I.dst >= SP_NREG || I.c >= SP_NREG) SP_FAIL("instr %d: register out of range", i);
@@ -40,8 +43,16 @@ int sp_validate_program(const sp_program* p) {
       if (I.a >= SP_MAX_CONSTS) SP_FAIL("instr %d: const index out of range", i);
     } else if (I.a >= SP_NREG || I.b >= SP_NREG) {
       SP_FAIL("instr %d: register out of range", i);
+    } else if (I.op != SP_OP_NOP && I.op != SP_OP_IOTA) {
+      const bool binary = I.op >= SP_OP_ADD && I.op <= SP_OP_LXOR;
+      unsigned reads = 1u << I.a;
+      if (binary || I.op == SP_OP_WHERE) reads |= 1u << I.b;
+      if (I.op == SP_OP_WHERE) reads |= 1u << I.c;
+      if (reads & ~defined) SP_FAIL("instr %d: reads a register nothing has written", i);
     }
+    if (I.op != SP_OP_NOP) defined |= 1u << I.dst;
   }
+  if (!(defined & (1u << p->result_reg))) SP_FAIL("result_reg=%d is never written", p->result_reg);
   for (int j = 0; j < p->n_inputs; ++j)
     if (p->in_dtype[j] < 0 || p->in_dtype[j] >= SP_DTYPE_COUNT) SP_FAIL("input %d: bad dtype", j);
   for (int d = 0; d < p->ndim; ++d)
@@ -53,8 +64,14 @@ static inline unsigned sp_grid_for(int64_t nvec, int U) {
   int64_t blocks = (nvec + (int64_t)SP_BLOCK * U - 1) / ((int64_t)SP_BLOCK * U);
   // interpreter kernels pay a per-workgroup prologue (program + strides from the kernel
   // argument segment): a capped grid that strides measured faster than a full grid
-  const int64_t cap = (int64_t)SP_CUS * SP_BLOCKS_PER_CU;
-  if (blocks > cap) blocks = cap;
+  // (round 4, 2 GiB tile, 5-op chain: 8 / 16 / 32 workgroups per CU 1.23 / 1.18 / 1.16 ms, the whole tile 1.34)
+  static int per_cu = -1;
+  if (per_cu < 0) {
+    const char* e = getenv("SP_INTERP_WG_PER_CU");
+    per_cu = e ? atoi(e) : 4 * SP_BLOCKS_PER_CU;
+  }
+  const int64_t cap = (int64_t)SP_CUS * per_cu;
+  if (per_cu > 0 && blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
 }
@@ -76,7 +93,9 @@ static int sp_map_unroll() {
   static int u = -1;
   if (u < 0) {
     const char* e = getenv("SP_MAP_UNROLL");
-    u = e ? atoi(e) : 1;   // measured (profiles/r01_kbench_map_unroll.txt): 1 is fastest for the interpreter
+    // two groups per lane: the dispatch (fetch, decode, branch) is shared by both; four need > 256 VGPRs
+    // (profiles/r04_notes.md: 5-op chain on the 2 GiB tile 1.21 / 1.11 / 2.2 ms at 1 / 2 / 4)
+    u = e ? atoi(e) : 2;
     if (u != 1 && u != 2 && u != 4) u = 1;
   }
   return u;

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
                                                           void* __restrict__ out, int64_t start,
                                                           int64_t nvec) {
   const int64_t stride = (int64_t)gridDim.x * SP_BLOCK * U;
+  const sp_dyn dyn = sp_dyn_program<P>(p);
   if constexpr (RAGGED) {
     static_assert(U == 1 && !LINEAR, "ragged rows: strided programs, one group per lane");
     const int64_t inner = p.shape[p.ndim - 1];
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
           sp_eval_2d<T, V, P, MASK, NTM>(p, in, (uint32_t)row, (uint32_t)col, L0, res[0]);
         } else {
           const int64_t Ls[1] = {L0};
-          sp_eval_u<T, V, 1, false, P, NTM>(p, in, Ls, res);
+          sp_eval_u<T, V, 1, false, P, NTM>(p, in, Ls, res, nullptr, dyn);
         }
         if (SP_STREAMS(NTM, p)) sp_store_vec<T, V, true>(out, p.out_dtype, L0, res[0]);
         else sp_store_vec<T, V>(out, p.out_dtype, L0, res[0]);
@@ -52,13 +53,71 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
             sp_eval_2d<T, 1, P, MASK>(p, in, (uint32_t)row, (uint32_t)c, row * inner + c, one[0]);
           } else {
             const int64_t Ls[1] = {row * inner + c};
-            sp_eval_u<T, 1, 1, false, P>(p, in, Ls, one);
+            sp_eval_u<T, 1, 1, false, P>(p, in, Ls, one, nullptr, dyn);
           }
           sp_store_vec<T, 1>(out, p.out_dtype, row * inner + c, one[0]);
         }
       }
     }
     return;
+  }
+  if constexpr (!P::kStatic && LINEAR && V == 4) {
+    if (sp_ahead_applies<T, 2>(p) && nvec < (1LL << 31)) {
+      // Interpreted dense fp32 programs of one or two operands, software-pipelined over the trips of a lane: the
+      // operands of trip t + 1 are requested and the results of trip t - 1 stored between the moment trip t's operands
+      // reach the register file and the moment its program runs (sp_ahead).
+      sp_ahead<T, V, U, 2> ah;
+      const uint32_t n32 = (uint32_t)nvec, step = (uint32_t)stride;
+      uint32_t i = blockIdx.x * (SP_BLOCK * U) + threadIdx.x;
+      if (i >= n32) return;
+      auto place = [&](uint32_t at, int64_t (&Lo)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t k = at + (uint32_t)u * SP_BLOCK;
+          Lo[u] = start + (int64_t)(k < n32 ? k : at) * V;   // tail groups re-evaluate group 0 (never stored)
+        }
+      };
+      auto store = [&](uint32_t at, const int64_t (&Lo)[U], T (&val)[U][V]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (u == 0 || at + (uint32_t)u * SP_BLOCK < n32) {
+            if (SP_STREAMS(NTM, p)) sp_store_vec<T, V, true>(out, p.out_dtype, Lo[u], val[u]);
+            else sp_store_vec<T, V>(out, p.out_dtype, Lo[u], val[u]);
+          }
+      };
+      int64_t L[U];
+      place(i, L);
+      sp_fetch_ahead<T, V, U, NTM>(p, in, L, ah);
+      T held[U][V];
+      bool have_held = false;
+      for (;;) {
+        const bool more = n32 - i > step;            // (i < n32 here)
+        T res[U][V];
+        auto mid = [&]() {
+          if (more) {
+            int64_t Ln[U];
+            place(i + step, Ln);
+            sp_fetch_ahead<T, V, U, NTM>(p, in, Ln, ah);
+          }
+          if (have_held) {
+            int64_t Lp[U];
+            place(i - step, Lp);
+            store(i - step, Lp, held);
+          }
+        };
+        sp_eval_u<T, V, U, true, P, NTM>(p, in, L, res, nullptr, dyn, &ah, mid);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int v = 0; v < V; ++v) held[u][v] = res[u][v];
+        have_held = true;
+        if (!more) break;
+        i += step;
+        place(i, L);
+      }
+      store(i, L, held);
+      return;
+    }
   }
   for (int64_t i = (int64_t)blockIdx.x * SP_BLOCK * U + threadIdx.x; i < nvec; i += stride) {
     int64_t L[U];
@@ -77,7 +136,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
       const uint32_t row = l32 / cols;
       sp_eval_2d<T, V, P, MASK, NTM>(p, in, row, l32 - row * cols, L[0], res[0]);
     } else {
-      sp_eval_u<T, V, U, LINEAR, P, NTM>(p, in, L, res);
+      sp_eval_u<T, V, U, LINEAR, P, NTM>(p, in, L, res, nullptr, dyn);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)

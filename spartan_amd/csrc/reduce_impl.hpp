@@ -187,14 +187,14 @@ __device__ __forceinline__ void sp_load_partial(const RedOut& ro, int64_t slot, 
 // one element of the program at (row, col) / flat index L -- the scalar tails of the vector kernels
 template <typename T, bool LINEAR, typename P, int MASK>
 __device__ __forceinline__ T sp_eval_one(const sp_program& p, const sp_inputs& in, int64_t row, int64_t col, int64_t L,
-                                         bool have_rc) {
+                                         bool have_rc, const sp_dyn dyn) {
   T x[1][1];
   if constexpr (MASK >= 0) {
     sp_eval_2d<T, 1, P, MASK, SP_RED_NTM(P)>(p, in, (uint32_t)row, (uint32_t)col, L, x[0]);
   } else {
     const int64_t Ls[1] = {L};
     const int64_t rc[1][2] = {{row, col}};
-    sp_eval_u<T, 1, 1, LINEAR, P, SP_RED_NTM(P)>(p, in, Ls, x, have_rc ? rc : nullptr);
+    sp_eval_u<T, 1, 1, LINEAR, P, SP_RED_NTM(P)>(p, in, Ls, x, have_rc ? rc : nullptr, dyn);
   }
   return x[0][0];
 }
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
   using Acc = AccT<T>;
   __shared__ Acc sm[SP_BLOCK / 64];
   if constexpr (OP >= 0) op = OP;   // specialised kernels: the combine op is a constant too
+  const sp_dyn dyn = sp_dyn_program<P>(p);
   const int s = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int64_t o = blockIdx.y; o < O; o += gridDim.y) {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
         sp_eval_2d<T, V, P, MASK, SP_RED_NTM(P)>(p, in, (uint32_t)o, (uint32_t)a, L[0], x[0]);
       } else {
         const int64_t rc[1][2] = {{o, a}};   // (row, column) when the program space is [O, A]
-        sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr);
+        sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr, dyn);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
       const int rem = (int)((a1 - a0) % V);
       if ((int)threadIdx.x < rem) {
         const int64_t a = a1 - rem + threadIdx.x;
-        acc.add(op, sp_eval_one<T, LINEAR, P, MASK>(p, in, o, a, o * A + a, p.ndim == 2 && p.shape[1] == A), a);
+        acc.add(op, sp_eval_one<T, LINEAR, P, MASK>(p, in, o, a, o * A + a, p.ndim == 2 && p.shape[1] == A, dyn), a);
       }
     }
     acc = sp_wave_reduce(op, acc);
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
                                                                       int64_t O, int64_t A, RedOut ro) {
   using Acc = AccT<T>;
   if constexpr (OP >= 0) op = OP;
+  const sp_dyn dyn = sp_dyn_program<P>(p);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wstride = (int64_t)gridDim.x * (SP_BLOCK / 64);
   for (int64_t o = (int64_t)blockIdx.x * (SP_BLOCK / 64) + w; o < O; o += wstride) {
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
         sp_eval_2d<T, V, P, MASK, SP_RED_NTM(P)>(p, in, (uint32_t)o, (uint32_t)a, L[0], x[0]);
       } else {
         const int64_t rc[1][2] = {{o, a}};
-        sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr);
+        sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr, dyn);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
       const int rem = (int)(A % V);
       if (lane < rem) {
         const int64_t a = A - rem + lane;
-        acc.add(op, sp_eval_one<T, LINEAR, P, MASK>(p, in, o, a, o * A + a, p.ndim == 2 && p.shape[1] == A), a);
+        acc.add(op, sp_eval_one<T, LINEAR, P, MASK>(p, in, o, a, o * A + a, p.ndim == 2 && p.shape[1] == A, dyn), a);
       }
     }
     acc = sp_wave_reduce(op, acc);
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
   constexpr int NW = SP_BLOCK / 64;
   __shared__ Acc sm[NW - 1][64 * V];
   if constexpr (OP >= 0) op = OP;
+  const sp_dyn dyn = sp_dyn_program<P>(p);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int s = blockIdx.y;
   // columns c0 + ...: only whole groups of V (the I % V columns left over go to sp_reduce_cols_tail_kernel)
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
           sp_eval_2d<T, V, P, MASK, SP_RED_NTM(P)>(p, in, (uint32_t)(o * A + a), (uint32_t)c, L[0], x[0]);
         } else {
           const int64_t rc[1][2] = {{o * A + a, c}};   // (row, column) when the program space is [O*A, I]
-          sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr);
+          sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr, dyn);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_tail_kernel(const sp_
   using Acc = AccT<T>;
   constexpr int NR = SP_BLOCK / 4;
   __shared__ Acc sm[SP_BLOCK];
+  const sp_dyn dyn = sp_dyn_program<DynProg>(p);
   const int col = threadIdx.x & 3, r = threadIdx.x >> 2;
   const int s = blockIdx.y;
   const int64_t c = c0 + col;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_tail_kernel(const sp_
         const int64_t L[1] = {(o * A + a) * I + c};
         const int64_t rc[1][2] = {{o * A + a, c}};
         T x[1][1];
-        sp_eval_u<T, 1, 1, LINEAR, DynProg, 0>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr);
+        sp_eval_u<T, 1, 1, LINEAR, DynProg, 0>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr, dyn);
         acc.add(op, x[0][0], a);
       }
     }

@@ -441,8 +441,39 @@ SP_DEF_STATIC(12, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_MUL, 1, 1, 0),
 #define SP_NUM_STATIC 13
 #define SP_FOR_EACH_STATIC(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 
-// one interpreted / unrolled instruction on U register files
-template <typename T, int V, int U>
+// an instruction in a dword: op 8 | dst 3 | a 4 | b 3 | c 3 (register numbers < SP_NREG = 8, constant indices < 16)
+static_assert(SP_NREG <= 8 && SP_MAX_CONSTS <= 16 && SP_MAX_INSTR <= 64, "sp_pack_instr");
+__device__ __forceinline__ uint32_t sp_pack_instr(const sp_instr I) {
+  return (uint32_t)I.op | ((uint32_t)(I.dst & 7) << 8) | ((uint32_t)(I.a & 15) << 11) | ((uint32_t)(I.b & 7) << 15) |
+         ((uint32_t)(I.c & 7) << 18);
+}
+__device__ __forceinline__ sp_instr sp_unpack_instr(uint32_t w) {
+  return sp_instr{(uint8_t)(w & 255), (uint8_t)((w >> 8) & 7), (uint8_t)((w >> 11) & 15), (uint8_t)((w >> 15) & 7),
+                  (uint8_t)((w >> 18) & 7), 0, 0, 0};
+}
+
+// The interpreted program as the kernel holds it: lane k of `word` is instruction k.  Made ONCE, at kernel entry
+// (every lane of the wave active), by sp_dyn_program; the evaluators take it as their last argument.
+struct sp_dyn {
+  uint32_t word;
+  bool lanes_hold_program;
+};
+template <typename P>
+__device__ __forceinline__ sp_dyn sp_dyn_program(const sp_program& p) {
+  if constexpr (P::kStatic) {
+    return sp_dyn{0u, false};
+  } else {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t word = sp_pack_instr(p.instr[lane & (SP_MAX_INSTR - 1)]);
+    // (pinned HERE: sunk into a loop that only some lanes enter, the load would leave the other lanes' instructions
+    // unread -- v_readlane reads a lane whether or not it is active)
+    asm volatile("" : "+v"(word));
+    return sp_dyn{word, true};
+  }
+}
+
+// one interpreted (DYN) / unrolled instruction on U register files
+template <typename T, int V, int U, bool DYN = false>
 __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, const int64_t (&L)[U],
                                         T (&r0)[SP_NREG * V], T (&r1)[SP_NREG * V], T (&r2)[SP_NREG * V],
                                         T (&r3)[SP_NREG * V]) {
@@ -453,9 +484,30 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
   if constexpr (U > 2) { X(2) X(3) }
   T a[U][V], b[U][V], d[U][V];
   const int ra = (I.a & (SP_NREG - 1)) * V, rb = (I.b & (SP_NREG - 1)) * V;
-#define SP_RD(u) _Pragma("unroll") for (int v = 0; v < V; ++v) { a[u][v] = r##u[ra + v]; b[u][v] = r##u[rb + v]; }
+  const int rd = (I.dst & (SP_NREG - 1)) * V;
+#define SP_WR(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[rd + v] = d[u][v];
+  bool done = false;
+  if constexpr (DYN) {
+    // constants read no register
+    if (I.op == SP_OP_CONST) {
+      const T c = sp_const<T>(p, I.a);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < V; ++v) d[u][v] = c;
+      done = true;
+    }
+  }
+  if (!done) {
+  // (all of `a`, then all of `b`: reads that share an index share one s_set_gpr_idx_on / off bracket)
+#define SP_RD(u) _Pragma("unroll") for (int v = 0; v < V; ++v) a[u][v] = r##u[ra + v];
   SP_U_LIST(SP_RD)
 #undef SP_RD
+  if constexpr (DYN) __builtin_amdgcn_sched_barrier(0);
+#define SP_RD(u) _Pragma("unroll") for (int v = 0; v < V; ++v) b[u][v] = r##u[rb + v];
+  SP_U_LIST(SP_RD)
+#undef SP_RD
+  if constexpr (DYN) __builtin_amdgcn_sched_barrier(0);
 #define SP_EACH(expr)                               \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {   \
     _Pragma("unroll") for (int v = 0; v < V; ++v) { \
@@ -464,7 +516,19 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
       d[u][v] = (expr);                             \
     }                                               \
   }
-  switch (I.op) {
+  if constexpr (DYN) {
+    // the four arithmetic operators first: two scalar compares instead of the six levels of the full switch
+    const unsigned k = (unsigned)I.op - (unsigned)SP_OP_ADD;
+    if (k < 4u) {
+      done = true;
+      if (k < 2u) {
+        if (k == 0u) { SP_EACH(av + bv); } else { SP_EACH(av - bv); }
+      } else {
+        if (k == 2u) { SP_EACH(av * bv); } else { SP_EACH(M::div(av, bv)); }
+      }
+    }
+  }
+  if (!done) switch (I.op) {
     case SP_OP_CONST: { T c = sp_const<T>(p, I.a); SP_EACH(c); } break;
     case SP_OP_IOTA: SP_EACH((T)(L[u] + v)); break;
     case SP_OP_MOV: SP_EACH(av); break;
@@ -516,11 +580,68 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
     default: SP_EACH(av); break;
   }
 #undef SP_EACH
-  const int rd = (I.dst & (SP_NREG - 1)) * V;
-#define SP_WR(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[rd + v] = d[u][v];
+  }
   SP_U_LIST(SP_WR)
 #undef SP_WR
 #undef SP_U_LIST
+}
+
+// Operands of the NEXT evaluation, fetched while this one computes (interpreted dense programs: with 3 waves per
+// SIMD resident, load -> wait -> interpret -> store one after the other leaves HBM idle while the waves interpret).
+// The first NPRE operands of each of the U groups are held; sp_eval_u moves them into its register file, calls the
+// caller's `mid` -- which requests the next ones into the same slots and issues the stores of the PREVIOUS
+// evaluation, so that the wait at the top of an evaluation is for loads a whole evaluation old and never for a
+// store just issued -- and only then runs the program.
+struct sp_no_ahead {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <typename T, int V, int U, int NPRE>
+struct sp_ahead {
+  static constexpr int N = NPRE;
+  T v[U][NPRE][V];
+};
+
+// operand j of a dense (LINEAR) program at flat index L: V consecutive elements, or its one element V times
+template <typename T, int V, int NTM>
+__device__ __forceinline__ void sp_load_linear(const sp_program& p, const sp_inputs& in, int j, int32_t dt, int64_t L,
+                                               T* dst) {
+  if (p.in_stride[j][p.ndim - 1] != 0) {
+    if (SP_STREAMS(NTM, p)) sp_load_vec<T, V, true>(in.p[j], dt, L, dst);   // dense: read exactly once
+    else sp_load_vec<T, V>(in.p[j], dt, L, dst);
+  } else {
+    T s;
+    sp_load_vec<T, 1>(in.p[j], dt, 0, &s);
+#pragma unroll
+    for (int v = 0; v < V; ++v) dst[v] = s;
+  }
+}
+
+// (taken for operands that are all dense fp32 -- sp_ahead_applies: one vector load each, no dtype dispatch)
+template <typename T, int V, int U, int NTM, typename AH>
+__device__ __forceinline__ void sp_fetch_ahead(const sp_program& p, const sp_inputs& in, const int64_t (&L)[U], AH& ah) {
+  static_assert(sp_is_same<T, float>::value && V == 4, "operand prefetch: the fp32 class");
+  const bool streams = SP_STREAMS(NTM, p);
+#pragma unroll
+  for (int j = 0; j < AH::N; ++j)
+    if (j < p.n_inputs) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float* src = (const float*)in.p[j] + L[u];
+        sp_f32x4u x;
+        if (streams) x = __builtin_nontemporal_load((const sp_f32x4u*)src);
+        else x = *(const sp_f32x4u*)src;
+        ah.v[u][j][0] = x.x; ah.v[u][j][1] = x.y; ah.v[u][j][2] = x.z; ah.v[u][j][3] = x.w;
+      }
+    }
+}
+template <typename T, int N>
+__device__ __forceinline__ bool sp_ahead_applies(const sp_program& p) {
+  if (!sp_is_same<T, float>::value || p.n_inputs > N || p.n_inputs < 1) return false;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (j < p.n_inputs) ok = ok && p.in_dtype[j] == SP_F32 && p.in_stride[j][p.ndim - 1] != 0;
+  return ok;
 }
 
 // ---- the evaluator ----------------------------------------------------------
@@ -530,16 +651,29 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
 // Each group has its own 8 x V register file so that every dynamically indexed
 // array stays within the 32 dwords the s_set_gpr_idx path handles (a [U][32]
 // array would be one 32*U-dword alloca and go to scratch).
-template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int NTM = 2>
+// `ahead` / `mid`: see sp_ahead -- the operands come from `ahead`; `mid()` runs once they sit in the register file and
+// before the program does (the caller's place for the next fetch and for the stores it held back).
+template <typename T, int V, int U, bool LINEAR, typename P = DynProg, int NTM = 2, typename AH = sp_no_ahead,
+          typename MID = sp_no_ahead>
 __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& in, const int64_t (&L)[U],
-                                          T (&out)[U][V], const int64_t (*pre)[2] = nullptr) {
+                                          T (&out)[U][V], const int64_t (*pre)[2] = nullptr,
+                                          const sp_dyn dyn = sp_dyn{0u, false}, AH* ahead = nullptr,
+                                          const MID& mid = MID()) {
+  constexpr bool AHEAD = !sp_is_same<AH, sp_no_ahead>::value;
+  static_assert(!AHEAD || (LINEAR && !P::kStatic), "operand prefetch: interpreted dense programs");
   T r0[SP_NREG * V], r1[SP_NREG * V], r2[SP_NREG * V], r3[SP_NREG * V];
   static_assert(U == 1 || U == 2 || U == 4, "U must be 1, 2 or 4");
 #define SP_U_LIST(X)                 \
   X(0)                               \
   if constexpr (U > 1) { X(1) }      \
   if constexpr (U > 2) { X(2) X(3) }
-#define SP_ZERO(u) _Pragma("unroll") for (int k = 0; k < SP_NREG * V; ++k) r##u[k] = (T)0;
+  // Specialised programs: the zeros fold away.  Interpreted programs never read a register nothing has written
+  // (sp_validate_program), so their register files start as whatever the VGPRs hold: 32 moves per evaluation less.
+#define SP_ZERO(u)                                                     \
+  _Pragma("unroll") for (int k = 0; k < SP_NREG * V; ++k) {            \
+    if constexpr (P::kStatic) r##u[k] = (T)0;                          \
+    else asm volatile("" : "=v"(r##u[k]));                             \
+  }
   SP_U_LIST(SP_ZERO)
 #undef SP_ZERO
   (void)r1; (void)r2; (void)r3;
@@ -607,23 +741,19 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
       const int32_t dt = P::kStatic ? (int32_t)P::in_dtype(j) : p.in_dtype[j];
       if constexpr (LINEAR) {
         // dense operand (stride pattern == output) or scalar (all strides 0)
-        if (p.in_stride[j][p.ndim - 1] != 0) {
-          // dense: read exactly once
-#define SP_LD(u) sp_load_vec<T, V, true>(in.p[j], dt, L[u], &r##u[j * V]);
-#define SP_LDC(u) sp_load_vec<T, V>(in.p[j], dt, L[u], &r##u[j * V]);
-          if (SP_STREAMS(NTM, p)) {
-            SP_U_LIST(SP_LD)
-          } else {
-            SP_U_LIST(SP_LDC)
+        if constexpr (AHEAD) {
+          // fetched during the previous evaluation.  (The caller takes this path for programs of at most AH::N
+          // operands only: NO load may target the register file itself here -- with one pending, every indexed
+          // access of the dispatch loop would wait for vmcnt(0), i.e. for the operands just requested as well.)
+          if (j < AH::N) {
+#define SP_TAKE(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[j * V + v] = ahead->v[u][j < AH::N ? j : 0][v];
+            SP_U_LIST(SP_TAKE)
+#undef SP_TAKE
           }
-#undef SP_LD
-#undef SP_LDC
         } else {
-          T s;
-          sp_load_vec<T, 1>(in.p[j], dt, 0, &s);
-#define SP_BC(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[j * V + v] = s;
-          SP_U_LIST(SP_BC)
-#undef SP_BC
+#define SP_LD(u) sp_load_linear<T, V, NTM>(p, in, j, dt, L[u], &r##u[j * V]);
+          SP_U_LIST(SP_LD)
+#undef SP_LD
         }
       } else {
         const int64_t inner = p.in_stride[j][p.ndim - 1];
@@ -662,11 +792,22 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
     }
   }
 
+  if constexpr (AHEAD) mid();
   if constexpr (P::kStatic) {
 #pragma unroll
     for (int pc = 0; pc < P::N; ++pc) sp_step<T, V, U>(p, P::at(pc), L, r0, r1, r2, r3);
   } else {
-    for (int pc = 0; pc < p.n_instr; ++pc) sp_step<T, V, U>(p, p.instr[pc], L, r0, r1, r2, r3);
+    if (dyn.lanes_hold_program) {
+      // fetched with v_readlane from the kernel's lane-held copy of the stream (sp_dyn_program): no trip to the scalar
+      // cache, no s_waitcnt lgkmcnt(0) between fetch and execution
+      for (int pc = 0; pc < p.n_instr; ++pc) {
+        const sp_instr cur = sp_unpack_instr((uint32_t)__builtin_amdgcn_readlane((int)dyn.word, pc));
+        if (cur.op != SP_OP_NOP) sp_step<T, V, U, true>(p, cur, L, r0, r1, r2, r3);
+      }
+    } else {
+      for (int pc = 0; pc < p.n_instr; ++pc)
+        if (p.instr[pc].op != SP_OP_NOP) sp_step<T, V, U, true>(p, p.instr[pc], L, r0, r1, r2, r3);
+    }
   }
   const int rr = ((P::kStatic ? P::RESULT : p.result_reg) & (SP_NREG - 1)) * V;
 #define SP_OUT(u) _Pragma("unroll") for (int v = 0; v < V; ++v) out[u][v] = r##u[rr + v];

@@ -454,6 +454,87 @@ def test_transposing_slice_copy(shape):
     np.testing.assert_array_equal(host(out), a.T)
 
 
+# ---- interpreter tier: dispatch from the lane-held program, software-pipelined trips ----------------------------
+class _interpreted(object):
+  """Run-time specialisation off (none of the programs below is in the prebuilt library)."""
+
+  def __enter__(self):
+    _hip.lib().sp_jit_configure(0, -1)
+
+  def __exit__(self, *exc):
+    _hip.lib().sp_jit_configure(1, 1 << 22)
+
+
+def _long_body(n_inputs, rounds):
+  """((x0 * c + x1) - x2 ...) `rounds` times over the operands: 1 + 2 * rounds instructions (<= 64)."""
+  def body(p):
+    c = p.add_const(0.75)
+    p.emit('CONST', 6, c)
+    p.emit('MUL', 7, 0, 6)
+    for k in range(rounds - 1):
+      p.emit('ADD' if k % 3 else 'SUB', 7, 7, (k + 1) % n_inputs)
+      p.emit('MUL', 7, 7, 6)
+    return 7
+  return body
+
+
+def _long_numpy(xs, rounds):
+  c = np.float32(0.75)
+  acc = xs[0] * c
+  for k in range(rounds - 1):
+    y = xs[(k + 1) % len(xs)]
+    acc = (acc + y) if k % 3 else (acc - y)
+    acc = acc * c
+  return acc
+
+
+@pytest.mark.parametrize('n', [1, 5, 1023, 262144, 262144 + 4, 262144 * 2 + 1024 + 3, 3 * 1000 * 1000 + 1,
+                               8192 * 256 * 2 * 4 * 2 + 4096 + 8])
+@pytest.mark.parametrize('n_inputs', [1, 2, 3])
+def test_interpreter_dense_sizes_and_operand_counts(n, n_inputs):
+  """Every trip structure of the interpreted dense kernel: one lane, a partial first trip, exactly one trip per lane,
+  the second group of a lane cut by the end, several trips with the last one partial, more vectors than the capped
+  grid covers in one trip; one and two operands take the pipelined loop, three the plain one."""
+  xs = [RNG.rand(n).astype(np.float32) for _ in range(n_inputs)]
+  with _interpreted():
+    got = run_map(_hip.SP_F32, (n,), xs, _long_body(n_inputs, 4), np.float32)
+  np.testing.assert_array_equal(got, _long_numpy(xs, 4))
+
+
+@pytest.mark.parametrize('rounds', [1, 16, 31])
+def test_interpreter_long_programs(rounds):
+  """Up to 63 instructions: the program is held one instruction per lane of a wave."""
+  n = 300 * 1000
+  xs = [RNG.rand(n).astype(np.float32) for _ in range(2)]
+  with _interpreted():
+    got = run_map(_hip.SP_F32, (n,), xs, _long_body(2, rounds), np.float32)
+  np.testing.assert_array_equal(got, _long_numpy(xs, rounds))
+
+
+def test_interpreter_mixed_operand_dtypes_take_the_plain_loop():
+  n = 700 * 1000 + 2
+  x = RNG.rand(n).astype(np.float32)
+  y = RNG.randint(-5, 5, n).astype(np.int32)
+  with _interpreted():
+    got = run_map(_hip.SP_F32, (n,), [x, y], _long_body(2, 3), np.float32)
+  np.testing.assert_array_equal(got, _long_numpy([x, y.astype(np.float32)], 3))
+
+
+def test_program_that_reads_an_unwritten_register_is_refused():
+  x = RNG.rand(64).astype(np.float32)
+
+  def body(p):
+    p.emit('ADD', 2, 0, 5)        # register 5: not an operand, never written
+    return 2
+  with pytest.raises(Exception, match='nothing has written'):
+    run_map(_hip.SP_F32, (64,), [x], body, np.float32)
+
+  def body2(p):
+    p.emit('SQRT', 2, 0, 7)       # a unary operator does not read its `b`
+    return 2
+  np.testing.assert_array_equal(run_map(_hip.SP_F32, (64,), [x], body2, np.float32), np.sqrt(x))
+
+
 # ---- run-time specialised tier (sp_jit.hip) --------------------------------------
 def _both_tiers(fn):
   """fn() evaluated on the interpreter kernels and on run-time specialised ones."""
