@@ -54,7 +54,9 @@ enum sp_dtype {
  * double (SP_F64) or int64 (SP_I64).  Inputs are converted to the class on
  * load; SP_OP_TO_* ops re-normalise a value to a narrower NumPy dtype where
  * the reference's intermediate would have been narrower.  Register j <
- * n_inputs is pre-loaded with input j.
+ * n_inputs is pre-loaded with input j; every other register must be written
+ * before it is read and result_reg must have been written (the evaluators do
+ * not clear their register file: a program that breaks the rule is refused).
  */
 #define SP_MAX_INPUTS 8
 #define SP_MAX_INSTR 64

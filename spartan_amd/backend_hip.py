@@ -41,6 +41,10 @@ def _content_stamp(view):
   return (view.shape, view.dtype.str, _digest(memoryview(view).cast('B')))
 
 
+def _no_copy(t):
+  raise lower.NotLowerable('an operand the kernels cannot address in place')
+
+
 class HipBackend(object):
   name = 'hip'
 
@@ -275,20 +279,29 @@ class HipBackend(object):
     parent.args[idx] = lower.V('tensor', dtype=sub.dtype, shape=sub.shape, tensor=piece)
     return True
 
-  def _run_map(self, root, out_shape, out_dtype=None):
-    self._prepare(root)
+  def _emit_map(self, root, out_shape, out_dtype, launches_allowed=True):
+    """(program, operands, output dtype) of a lowered tree.  With launches_allowed (a tile is being evaluated) host
+    operands are uploaded, views the kernels cannot address are copied and a tree too large for one program is carved
+    into several launches; without (prelower_map: nothing may run yet) any of those raises NotLowerable."""
+    if launches_allowed:
+      self._prepare(root)
     if root.kind == 'const':
       root = lower.V('op', dtype=root.dtype, shape=(), op='FILL', args=[root])
     out_dtype = np.dtype(out_dtype or root.dtype)
     while True:
       cls = lower.choose_class(root, [class_of(out_dtype)] if out_dtype != np.bool_ else [])
-      em = lower.Emitter(cls, out_shape, self.contiguous)
+      em = lower.Emitter(cls, out_shape, self.contiguous if launches_allowed else _no_copy)
       try:
         prog, tensors = em.finish(root, out_dtype)
-        break
+        return prog, tensors, out_dtype
       except ProgramTooLarge:
+        if not launches_allowed:
+          raise lower.NotLowerable('needs more than one launch')
         if not self._carve(root):
           raise
+
+  def _run_map(self, root, out_shape, out_dtype=None):
+    prog, tensors, out_dtype = self._emit_map(root, out_shape, out_dtype)
     out = self.empty(out_shape, out_dtype)
     if out.numel():
       self.launches += 1
@@ -422,6 +435,32 @@ class HipBackend(object):
       return self._evaluate_split(op, inputs, ex)
     except lower.NotLowerable:
       return self._evaluate_eager(op, inputs, ex)
+
+  def prelower_map(self, op, inputs, ex):
+    """Lower NOW what evaluate_map(op, inputs, ex) will launch, into the table of lowered programs, without running or
+    allocating anything: the optimiser calls it for the maps of a DAG it has just optimised for the first time (the
+    reference generates the code of its fused operators in the optimiser too, optimize.py:1023-1076), so that the
+    first evaluation finds its program like every later one does.  Only what can be replayed from the table is
+    prepared -- device tiles and scalars in, one launch; anything else is left to evaluate_map.  Returns whether the
+    table now answers this key."""
+    fn = getattr(op, 'fn', None)
+    if getattr(fn, '_sp_random', None) is not None or getattr(fn, '_sp_tile_fn', False):
+      return False
+    if any(tile.is_sparse_blob(v) for v in inputs.values()) or self._materialise_random_needed(op):
+      return False
+    key = self._lowering_key(op, inputs, ex, None)
+    if key is None:
+      return False
+    if key in self._lowered:
+      return True
+    try:
+      root = lower.infer(op, inputs, ex, self.dtype_of)
+      prog, tensors, out_dtype = self._emit_map(root, root.shape if root.kind != 'const' else ex.shape, None,
+                                                launches_allowed=False)
+    except (ProgramTooLarge, lower.NotLowerable):
+      return False
+    self._remember(key, (prog, tensors, tuple(root.shape if root.kind != 'const' else ex.shape), out_dtype), inputs, op)
+    return key in self._lowered
 
   def map_result_meta(self, op, inputs, ex):
     """(dtype, is_sparse) of what evaluate_map(op, inputs, ex) will produce, from the operator tree and the operands'

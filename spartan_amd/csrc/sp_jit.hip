@@ -472,6 +472,10 @@ extern "C" int sp_jit_preload(int device) {
     (void)hipGetLastError();
     return 0;
   }
+  // (the identity of the sources -- a hash of six files' contents -- and the cache directory are worked out here, on
+  // this thread: left to the first sp_jit_get they were ~0.2 ms of the first launch of a seeded program)
+  (void)sources_id();
+  (void)cache_dir();
   int loaded = 0;
   // The first launch of a function pays for its set-up on the device (hundreds of microseconds measured for a
   // preloaded map kernel: 0.64 ms against 0.012 ms for every later launch).  Map kernels share one signature and do

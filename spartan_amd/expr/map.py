@@ -71,6 +71,40 @@ class MapExpr(Expr):
     return inputs[0].map_to_array(tile_mapper, kw={'children': inputs, 'child_to_var': names, 'op': self.op})
 
 
+def prelower(node, ctx):
+  """Hand the kernels of a map whose inputs all exist already to the backend BEFORE the map is evaluated
+  (`prelower_map`: lowered and remembered, not run) -- one tile per distinct tile shape.  Called by the optimiser for
+  a DAG it sees for the first time; the walk below is the prelude of MapExpr._evaluate and tile_mapper."""
+  hook = getattr(ctx.backend, 'prelower_map', None)
+  kids = getattr(node.children, 'vals', None)
+  if hook is None or ctx.world.size != 1 or not kids or not all(isinstance(k, base._Leaf) for k in kids):
+    return 0
+  values = [k.evaluate() for k in kids]
+  if not all(isinstance(v, distarray.LocalWrapper) or
+             (isinstance(v, distarray.DistArrayImpl) and not v.sparse and not v.bad_tiles) for v in values):
+    return 0
+  inputs = broadcast(values)
+  names = list(node.child_to_var)
+  lead = inputs.index(distarray.largest_value(inputs))
+  inputs[0], inputs[lead] = inputs[lead], inputs[0]
+  names[0], names[lead] = names[lead], names[0]
+  if not isinstance(inputs[0], distarray.DistArrayImpl):
+    return 0
+  # every other input cut like the lead (read in place) or stretched (its one slab): nothing is gathered or copied
+  cut = inputs[0].tiles.keys()
+  if not all(isinstance(v, Broadcast) or v.tiles.keys() == cut for v in inputs[1:]):
+    return 0
+  done, shapes = 0, set()
+  for ex in cut:
+    if ex.shape in shapes or len(shapes) >= 4:
+      continue
+    shapes.add(ex.shape)
+    operands = get_local_values(ex, inputs, names)
+    operands['extent'] = ex
+    done += bool(hook(node.op, operands, ex))
+  return done
+
+
 def _map_node(inputs, fn, numpy_expr, fn_kw, op_type, extra_vars=()):
   if fn is None:
     raise AssertionError('map needs a function')

@@ -44,6 +44,8 @@ FLAGS = {
     'opt_rowdot_fusion': True,
     # not a rewrite: DAGs with the structure of one seen before take its recorded result (expr/plan.py)
     'opt_plan_cache': True,
+    # not a rewrite: the maps of a DAG optimised for the first time are lowered to kernels here (see _prelower)
+    'opt_prelower': True,
 }
 
 # Results of builders whose value differs from call to call (rand, ...) must be computed exactly once: such a node
@@ -321,4 +323,40 @@ def optimize(dag):
   if not FLAGS['opt_plan_cache']:
     return _run_passes(dag)
   from . import plan
-  return plan.optimized(dag, tuple(FLAGS.values()), _run_passes)
+  first = plan.stats['misses']
+  out = plan.optimized(dag, tuple(FLAGS.values()), _run_passes)
+  if plan.stats['misses'] != first and FLAGS['opt_prelower']:
+    _prelower(out)
+  return out
+
+
+def _prelower(dag):
+  """A DAG optimised for the first time: its maps over arrays that exist already get their kernels lowered now
+  (expr/map.py prelower -> backend.prelower_map), where the reference generates the code of its fused operators
+  (optimize.py:1023-1076), instead of inside the first evaluation.  Later DAGs of the same structure come from the
+  plan table and find the programs in the backend's."""
+  from .map import prelower as prelower_map
+  from .base import CollectionExpr
+  from .. import context
+  ctx = context.get() if context.initialized() else None
+  if ctx is None or getattr(ctx.backend, 'prelower_map', None) is None:
+    return
+  seen = set()
+
+  def walk(v):
+    if isinstance(v, Expr):
+      if id(v) in seen:
+        return
+      seen.add(id(v))
+      if type(v) is MapExpr:
+        prelower_map(v, ctx)
+      if isinstance(v, CollectionExpr):
+        for x in (v.vals.values() if isinstance(v.vals, dict) else v.vals):
+          walk(x)
+      else:
+        for name in v.members:
+          walk(getattr(v, name))
+    elif isinstance(v, (list, tuple)):
+      for x in v:
+        walk(x)
+  walk(dag)

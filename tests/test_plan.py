@@ -165,3 +165,60 @@ def test_kmeans_iterations_through_plans(ctx):
       np.testing.assert_allclose(c_new, want, rtol=1e-6)
     c = c_new
   assert plan.stats['hits'] >= 4
+
+
+# ---- kernels lowered by the optimiser (optimize._prelower -> HipBackend.prelower_map) -----------------------------
+@pytest.fixture
+def hip_ctx():
+  c = sp.initialize('hip', num_workers=1)
+  plan.clear()
+  yield c
+  sp.shutdown()
+
+
+@pytest.mark.gpu
+def test_first_evaluation_finds_the_program_the_optimiser_lowered(hip_ctx):
+  be = hip_ctx.backend
+  a = _arr(21, (64, 48))
+  A = sp.from_numpy(a)
+  programs, hits = len(be._lowered), be.lowering_hits
+  e = (((A * A + A) * 0.375 - A) / (A + 2.5)).optimized()
+  assert len(be._lowered) == programs + 1          # lowered, not run: no launch was counted
+  launches = be.launches
+  got = e.glom()
+  assert be.lowering_hits == hits + 1 and be.launches == launches + 1
+  np.testing.assert_array_equal(got, ((a * a + a) * np.float32(0.375) - a) / (a + np.float32(2.5)))
+  # ragged tilings: one program per distinct tile shape
+  sp.shutdown()
+  c = sp.initialize('hip', num_workers=4)
+  plan.clear()
+  B = sp.from_numpy(_arr(22, (50, 7)))
+  programs = len(c.backend._lowered)
+  f = (B * 3.0 - B * B).optimized()
+  assert len(c.backend._lowered) > programs
+  hits = c.backend.lowering_hits
+  np.testing.assert_array_equal(f.glom(), _arr(22, (50, 7)) * np.float32(3) - _arr(22, (50, 7)) ** 2)
+  assert c.backend.lowering_hits > hits
+
+
+@pytest.mark.gpu
+def test_prelowering_can_be_switched_off_and_skips_what_cannot_be_replayed(hip_ctx):
+  be = hip_ctx.backend
+  A = sp.from_numpy(_arr(23, (64, 48)))
+  optimize.FLAGS['opt_prelower'] = False
+  try:
+    programs = len(be._lowered)
+    e = (A * 1.5 + A * A * A).optimized()
+    assert len(be._lowered) == programs
+    np.testing.assert_array_equal(e.glom(), _arr(23, (64, 48)) * np.float32(1.5) + _arr(23, (64, 48)) ** 3)
+  finally:
+    optimize.FLAGS['opt_prelower'] = True
+  # a driver-side NumPy operand is uploaded at evaluation time: left to evaluate_map, same values
+  w = np.arange(48, dtype=np.float32)
+  programs = len(be._lowered)
+  g = (A * w - 2.0).optimized()
+  assert len(be._lowered) == programs
+  np.testing.assert_array_equal(g.glom(), _arr(23, (64, 48)) * w - np.float32(2))
+  # inputs that are expressions themselves: the inner map is prepared, the outer one when its input exists
+  h = sp.sum(A * A + 1.0, axis=0).optimized()
+  np.testing.assert_allclose(h.glom(), (_arr(23, (64, 48)) ** 2 + 1).sum(axis=0), rtol=1e-6)
