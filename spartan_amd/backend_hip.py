@@ -170,6 +170,8 @@ class HipBackend(object):
     is taken when the same object comes back in a LATER evaluation, not at the first upload -- an iterative driver
     hands over a new array every step (`w = w - g * alpha`, `centers = sums / counts`) and never pays for a hash --
     and arrays above 4 MiB are not hashed at all: one upload per evaluation."""
+    if type(arr) is D.DevArray:        # a driver loop that keeps its operand on the device (examples/lreg.py)
+      return arr[tuple(slices)]
     from . import context
     ctx = context.get() if context.initialized() else None
     epoch = ctx.eval_epoch if ctx is not None and ctx.eval_depth > 0 else None     # (a direct backend call: no epoch)

@@ -60,6 +60,11 @@ def _dot(a, b):
   return be.dot(a, b)
 
 
+def _is_backend_tensor(v):
+  """A driver-side operand the driver keeps where the tiles are (examples/lreg.py: the weights between two steps)."""
+  return hasattr(v, 'data_ptr') and hasattr(v, 'strides')
+
+
 def dot_map2_np_mapper(extents, tiles, array2):
   """Row tile of `a` times the matching rows of the driver array (its rows follow a's LAST axis)."""
   be = context.get().backend
@@ -265,7 +270,7 @@ def dot(a, b, tile_hint=None):
   if a.shape[ra - 1] != b.shape[0]:
     raise ValueError('objects are not aligned %d %d' % (a.shape[ra - 1], b.shape[0]))
   shape = _product_shape(tuple(a.shape), tuple(b.shape)) or (1,)
-  if isinstance(b, np.ndarray):
+  if isinstance(b, np.ndarray) or _is_backend_tensor(b):
     return map_mod.map2(a, axes=[0], fn=dot_map2_np_mapper, fn_kw={'array2': b}, shape=shape, reducer=np.add)
   if ra == 1 and rb == 1:
     return map_mod.map2((a, b), (0, 0), fn=dot_map2_vec_mapper, shape=shape, reducer=np.add)

@@ -220,7 +220,8 @@ class RowDotColSumFusion(Pass):
       w = (e.fn_kw or {}).get('array2')
       if len(arrays) != 1 or arrays[0].expr_id != x.expr_id or e.update_region is not None:
         return None
-      if not isinstance(w, np.ndarray) or w.dtype != np.float32 or w.shape not in ((x.val.shape[1], 1), (x.val.shape[1],)):
+      if not (isinstance(w, np.ndarray) or dot_mod._is_backend_tensor(w)) or np.dtype(w.dtype) != np.float32 \
+          or tuple(w.shape) not in ((x.val.shape[1], 1), (x.val.shape[1],)):
         return None
       return w
 
@@ -236,7 +237,7 @@ class RowDotColSumFusion(Pass):
         continue
       if isinstance(b, LocalInput):                      # x * dot(x, w)
         w = as_dot(leaf(b), x)
-        if w is not None and (w.ndim == 2):
+        if w is not None and len(w.shape) == 2:
           return x, w, None
       elif isinstance(b, LocalMapExpr) and b.fn is np.subtract and len(b.deps) == 2:   # x * (dot(x, w) - y)
         t, yv = leaf(b.deps[0]), leaf(b.deps[1])
@@ -244,7 +245,7 @@ class RowDotColSumFusion(Pass):
           continue
         w = as_dot(t, x)
         y = as_y(yv, x)
-        if w is not None and w.ndim == 2 and y is not None:
+        if w is not None and len(w.shape) == 2 and y is not None:
           return x, w, y
     return None
 

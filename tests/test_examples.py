@@ -209,6 +209,26 @@ def test_to_numpy_later_sees_the_value_at_the_time_of_the_call(gpu_ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('wdtype', [np.float32, np.float64])
+def test_lreg_weights_kept_on_the_device_equal_the_glom_per_step_loop(gpu_ctx, wdtype):
+  """examples/lreg.fit updates w where the tiles are (NumPy's arithmetic on the backend's tensors); the reference's
+  loop gloms the gradient and updates on the driver (sgd.py:34-39): the same IEEE operations, the same weights.
+  float32 weights take the one-pass gradient kernel, float64 ones the two launches the expression states."""
+  rng = np.random.RandomState(5)
+  x = rng.rand(1000, 64).astype(np.float32)
+  y = rng.rand(1000, 1).astype(np.float32)
+  X, Y = sp.from_numpy(x), sp.from_numpy(y)
+  w0 = rng.rand(64, 1).astype(wdtype)
+  got = lreg.fit(X, Y, 4, alpha=1e-4, w=w0.copy())
+  w = w0.copy()
+  for _ in range(4):
+    g = lreg.gradient(X, Y, w).optimized().glom()
+    w = w - g.reshape((64, 1)) * 1e-4
+  assert isinstance(got, np.ndarray) and got.dtype == w.dtype == wdtype
+  np.testing.assert_array_equal(got, w)
+
+
+@pytest.mark.gpu
 def test_regressions_hip(gpu_ctx):
   _check_regressions(gpu_ctx, rtol=2e-6)
   _check_other_regressions(gpu_ctx, rtol=2e-6)
