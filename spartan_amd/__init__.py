@@ -133,6 +133,9 @@ def shutdown():
     if ctx.heartbeat is not None:
       ctx.heartbeat.stop()
       ctx.heartbeat = None
+    release = getattr(ctx.backend, 'release_pinned', None)
+    if release is not None:
+      release()
   _context.set(None)
 
 

@@ -41,6 +41,36 @@ def _content_stamp(view):
   return (view.shape, view.dtype.str, _digest(memoryview(view).cast('B')))
 
 
+class _HostCopyLater(object):
+  """What HipBackend.to_numpy_later hands out: get() waits for the copy (once) and returns the array."""
+
+  def __init__(self, tensor, host, free, done):
+    self._tensor, self._host, self._free, self._done = tensor, host, free, done      # (the tensor outlives the copy)
+    self._value = None
+
+  def get(self):
+    if self._value is None:
+      self._done.synchronize()
+      t = self._tensor
+      self._value = np.frombuffer(ctypes.string_at(self._host, t.nbytes), np.dtype(t.dtype)).reshape(tuple(t.shape)).copy()
+      self._release()
+    return self._value
+
+  def _release(self):
+    if self._host is not None:
+      self._free.append(self._host)
+      self._host = self._tensor = None
+
+  def __del__(self):
+    # dropped unread: the buffer may be handed out again only once the copy into it has landed
+    try:
+      if self._host is not None:
+        self._done.synchronize()
+        self._release()
+    except Exception:      # noqa: BLE001  (interpreter shutdown)
+      pass
+
+
 def _no_copy(t):
   raise lower.NotLowerable('an operand the kernels cannot address in place')
 
@@ -56,6 +86,7 @@ class HipBackend(object):
                           'there is no CPU fallback')
     self.device = 'hip'
     self._np_cache = collections.OrderedDict()   # bounded: iterative drivers pass a new array every step
+    self._side_copies, self._pinned_free = None, {}     # to_numpy_later
     self.launches = 0
     self.gemms = 0            # gemm_into launches (the K-split tests count them)
     self.host_round_trips = 0  # local functions that had to run on host copies of their tiles (call_local_fn)
@@ -96,19 +127,17 @@ class HipBackend(object):
     return t.numpy() if isinstance(t, D.DevArray) else np.asarray(t.cpu().numpy())
 
   def to_numpy_later(self, t):
-    """A handle whose get() is the host copy of the (small, contiguous) device tensor `t` AS IT IS ONCE EVERYTHING
-    ENQUEUED SO FAR HAS RUN -- without making the host wait now: the copy is put on a side stream behind an event
-    into a pinned buffer, the compute stream goes on (sp_copy_d2h_async).  For values a driver only CHECKS (the
-    cluster counts of a k-means iteration), one iteration later."""
+    """A handle whose get() is the host copy of the (small) device tensor `t` AS IT IS ONCE EVERYTHING ENQUEUED SO FAR
+    HAS RUN -- without making the host wait now: the copy is put on a side stream behind an event into a pinned
+    buffer, the compute stream goes on (sp_copy_d2h_async).  For values a driver only CHECKS (the cluster counts of
+    a k-means iteration), one iteration later."""
     t = self.contiguous(t)
     ready = D.Event().record()
-    if getattr(self, '_side_copies', None) is None:
+    if self._side_copies is None:
       self._side_copies = D.Stream()
     side = self._side_copies
     side.wait_event(ready)
-    # pinned landing buffers are kept (hipHostMalloc maps memory, hipHostFree waits for the device): a free list by size
-    if getattr(self, '_pinned_free', None) is None:
-      self._pinned_free = {}
+    # pinned landing buffers are kept (hipHostMalloc maps memory, hipHostFree waits for the device): free lists by size
     size = max(256, 1 << (max(t.nbytes, 1) - 1).bit_length())
     free = self._pinned_free.setdefault(size, [])
     if free:
@@ -117,16 +146,13 @@ class HipBackend(object):
       host = ctypes.c_void_p()
       _hip.check(_hip.lib().sp_pinned_alloc(size, ctypes.byref(host)))
     _hip.check(_hip.lib().sp_copy_d2h_async(host, ctypes.c_void_p(t.data_ptr()), t.nbytes, side.ptr))
-    done = D.Event().record(side)
-    shape, dtype = tuple(t.shape), np.dtype(t.dtype)
+    return _HostCopyLater(t, host, free, D.Event().record(side))
 
-    class Later(object):
-      def get(self_inner, keep=t):         # (`keep`: the tensor must outlive the copy)
-        done.synchronize()
-        out = np.frombuffer(ctypes.string_at(host, int(np.prod(shape, dtype=np.int64)) * dtype.itemsize), dtype).reshape(shape).copy()
-        free.append(host)
-        return out
-    return Later()
+  def release_pinned(self):
+    """Give the pooled landing buffers of to_numpy_later back (waits for the device: hipHostFree)."""
+    for free in self._pinned_free.values():
+      while free:
+        _hip.lib().sp_pinned_free(free.pop())
 
   def dtype_of(self, t):
     if isinstance(t, sparse_mod.CsrTile):

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v].init(op);
     if (active) {
-      constexpr int U = 1;
+      constexpr int U = P::kStatic ? 1 : 2;   // interpreted: two groups share a dispatch (as in the map kernel)
       for (int64_t a = a0 + w; a < a1; a += NW * U) {
         int64_t L[U];
 #pragma unroll

@@ -33,6 +33,7 @@ class _SeedBackend(HipBackend):
     self._rng_seed, self._rng_offset = 1, 0
     self._lowered = collections.OrderedDict()
     self.lowering_hits = 0
+    self._side_copies, self._pinned_free = None, {}
 
   def _lowering_key(self, op, inputs, ex, extra):
     return None          # every program is lowered (and its specialisation requested) afresh
