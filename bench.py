@@ -44,6 +44,7 @@ from spartan_amd import _hip, kernels  # noqa: E402
 from spartan_amd import devarray as D  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 SEED = 20150708
 SETUP_LAUNCHES = 8              # untimed set-up steps before the W warm-up steps (see main)
@@ -277,13 +278,33 @@ def kmeans_section(ctx):
   cdev = ctx.backend.from_numpy(centers)
   labels = D.empty((n,), np.int64)
   out = {'tile': '%dx%d fp32, k=%d' % (n, d, k)}
-  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels), 20, warmup=3,
-                  section=('k-means assign (first pass)', 'sp_nearest_nt_kernel<true, false, false>', 2.0 * n * k * d, 'flop', 'mfma'))
+  flop = 2.0 * n * k * d                                                # 2*N*K*D flop
+  # the default tier (csrc/kmeans_split.hpp): every fp32 operand cut into two bf16 numbers, the contraction as three
+  # exact-product bf16 MFMAs per 16 features with fp32 accumulation -- a FILTER with a proven error window; the points
+  # inside it are re-decided in fp64, so the labels are argmin(cdist)'s.  Timed as a fit runs it (the points' images
+  # made once: `prepared`) and as one stand-alone call (which cuts the points first).
+  prepared = kernels.prepare_points(x)
+  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels, prepared=prepared), 20, warmup=3,
+                  section=('k-means assign (first pass, bf16-split MFMA)', 'sp_nearest_split_kernel<false, false>', 3.0 * flop, 'flop', 'mfma_bf16'))
   out['assign_ms'] = round(ms, 3)
-  out['assign_TFLOPs'] = round(2.0 * n * k * d / ms / 1e9, 1)          # 2*N*K*D flop
-  out['assign_frac_of_mfma_peak'] = round(2.0 * n * k * d / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)
+  out['assign_TFLOPs'] = round(flop / ms / 1e9, 1)                      # useful fp32 flops per second
+  # (above 1: the contraction does not run on the fp32 matrix pipe this peak belongs to)
+  out['assign_frac_of_mfma_peak'] = round(flop / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)
+  out['assign_split'] = {'instruction': 'v_mfma_f32_32x32x16_bf16 x 3 per 16 features (hi*hi, hi*mid, mid*hi), fp32 accumulate',
+                         'issued_TFLOPs': round(3.0 * flop / ms / 1e9, 1), 'bf16_peak_TFLOPs': MFMA_BF16_PEAK_TFLOPS,
+                         'frac_of_bf16_peak': round(3.0 * flop / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)}
+  del prepared
+  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels), 10, warmup=2)
+  out['assign_standalone_ms'] = round(ms, 3)                            # + cutting the points (once per call)
+  kernels.nearest_center(x, cdev, labels, _hip.NEAREST_SPLIT_UNCHECKED)
+  out['assign_rechecked_points'] = int((labels < 0).sum().item())       # re-decided exactly (fp64 cdist)
+  # the fp32-MFMA filter of rounds 2-4 (SP_NEAREST_FUSED; SP_KM_SPLIT=0 makes it the default again)
+  ms = event_time(lambda: kernels.nearest_center(x, cdev, labels, _hip.NEAREST_FUSED), 10, warmup=2,
+                  section=('k-means assign (first pass, fp32 MFMA tier)', 'sp_nearest_nt_kernel<true, false, false>', flop, 'flop', 'mfma'))
   kernels.nearest_center(x, cdev, labels, _hip.NEAREST_FUSED_UNCHECKED)
-  out['assign_rechecked_points'] = int((labels < 0).sum().item())   # re-done by the exact fp64 kernel
+  out['assign_fp32_tier'] = {'ms': round(ms, 3), 'TFLOPs': round(flop / ms / 1e9, 1),
+                             'frac_of_fp32_mfma_peak': round(flop / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 3),
+                             'rechecked_points': int((labels < 0).sum().item())}
   kernels.nearest_center(x, cdev, labels)
   sums = D.empty((k, d), np.float32)
   counts = D.empty((k,), np.int64)
@@ -954,7 +975,9 @@ def main():
       line['roofline']['hbm_sections'] = {'measured_copy_GBps': copy, 'spec_GBps': HBM_PEAK_GBPS, 'sections': sections}
     km = line.get('kmeans')
     if km and 'assign_TFLOPs' in km:
-      line['roofline']['kmeans_assign'] = {'TFLOPs': km['assign_TFLOPs'], 'frac': km['assign_frac_of_mfma_peak'], 'ms': km['assign_ms']}
+      line['roofline']['kmeans_assign'] = {'TFLOPs': km['assign_TFLOPs'], 'frac': km['assign_frac_of_mfma_peak'], 'ms': km['assign_ms'],
+                                           'frac_is': 'useful fp32 flop/s over the FP32 matrix peak; the default tier runs on the bf16 pipe (assign_split), the fp32 tier is under fp32_tier',
+                                           'split': km.get('assign_split'), 'fp32_tier': km.get('assign_fp32_tier')}
     line['profile_table'] = PROFILE_TABLE
     live, pooled = D.blob_stats()
     line['tile_store'] = {'live_blobs': live, 'pooled_bytes': pooled, 'kernel_sources': _hip.source_sha()}

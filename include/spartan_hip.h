@@ -327,8 +327,13 @@ int sp_rowdot_colsum_f32(const float* d_x, int64_t ldx, int64_t n, int64_t d, co
  *   SP_NEAREST_FUSED (2): fp32 MFMA GEMM with the argmin fused into the epilogue
  *     (the n x k distance matrix is never written) + the exact kernel for the
  *     points whose two best scores are within the fp32 error bound: SAME labels;
- *   SP_NEAREST_AUTO (0): fused for fp32 points when n*k*d >= 2^24, else exact.
- *   SP_NEAREST_FUSED_UNCHECKED (3): diagnostics only -- the fused kernel alone; points it
+ *   SP_NEAREST_SPLIT (4): the same filter with every fp32 operand cut into two bf16 numbers and the
+ *     contraction on the bf16 matrix pipe (three exact-product MFMAs per 16 features, fp32 accumulation,
+ *     16 x the fp32 pipe's rate); its wider error window sends more points to the exact re-check: SAME labels
+ *     (csrc/kmeans_split.hpp);
+ *   SP_NEAREST_AUTO (0): split (>= 32 features; SP_KM_SPLIT=0: fused) for fp32 points when n*k*d >= 2^24,
+ *     else exact.
+ *   SP_NEAREST_FUSED_UNCHECKED (3) / SP_NEAREST_SPLIT_UNCHECKED (5): diagnostics only -- the filter alone; points it
  *     could not decide are left as -1 - (fp32 best) (used to report the re-check rate).
  * d_ws: sp_nearest_center_workspace_bytes(n, k, d) bytes of scratch.
  *
@@ -347,10 +352,24 @@ int sp_rowdot_colsum_f32(const float* d_x, int64_t ldx, int64_t n, int64_t d, co
 #define SP_NEAREST_EXACT 1
 #define SP_NEAREST_FUSED 2
 #define SP_NEAREST_FUSED_UNCHECKED 3
+#define SP_NEAREST_SPLIT 4
+#define SP_NEAREST_SPLIT_UNCHECKED 5
 size_t sp_nearest_center_workspace_bytes(int64_t n, int64_t k, int64_t d);
 int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ldx, const void* d_centers,
                       int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d, int64_t* d_labels,
                       int32_t tier, void* d_ws, size_t ws_bytes, void* stream);
+/* The points of a k-means fit do not change between its iterations: sp_kmeans_points_prepare cuts them ONCE into what
+ * the split tier reads (two bf16 images and |x|^2 per point, sp_kmeans_points_prepared_bytes(n, d) bytes) and
+ * sp_nearest_center_prepared is sp_nearest_center with that buffer handed in (its workspace is then
+ * sp_nearest_center_prepared_workspace_bytes(n, k, d): without room for the images).  The caller answers for the
+ * buffer matching the points it passes: same n, d, and contents not written since. */
+size_t sp_kmeans_points_prepared_bytes(int64_t n, int64_t d);
+int sp_kmeans_points_prepare(const float* d_points, int64_t ldx, int64_t n, int64_t d, void* d_prepared, size_t bytes,
+                             void* stream);
+size_t sp_nearest_center_prepared_workspace_bytes(int64_t n, int64_t k, int64_t d);
+int sp_nearest_center_prepared(const void* d_points, int32_t dtype, int64_t ldx, const void* d_prepared,
+                               const void* d_centers, int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
+                               int64_t* d_labels, int32_t tier, void* d_ws, size_t ws_bytes, void* stream);
 int sp_bincount_i64(const int64_t* d_labels, int64_t n, int64_t k, int64_t* d_counts, void* stream);
 size_t sp_segment_sum_workspace_bytes(int64_t n, int64_t k, int64_t d);
 int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, const int64_t* d_labels, int64_t n,

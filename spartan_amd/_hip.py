@@ -29,7 +29,7 @@ OP = dict(
 RED = dict(SUM=0, PROD=1, MAX=2, MIN=3, AND=4, OR=5)
 REDUCER = dict(NONE=0, ADD=1, MUL=2, MAX=3, MIN=4, AND=5, OR=6)
 MASK_ALL_CLEAR, MASK_ALL_SET, MASK_ARRAY = 0, 1, 2
-NEAREST_AUTO, NEAREST_EXACT, NEAREST_FUSED, NEAREST_FUSED_UNCHECKED = 0, 1, 2, 3
+NEAREST_AUTO, NEAREST_EXACT, NEAREST_FUSED, NEAREST_FUSED_UNCHECKED, NEAREST_SPLIT, NEAREST_SPLIT_UNCHECKED = 0, 1, 2, 3, 4, 5
 
 _NP2SP = {
     np.dtype(np.float32): SP_F32, np.dtype(np.float64): SP_F64, np.dtype(np.int32): SP_I32,
@@ -115,6 +115,12 @@ def _declare(lib):
   lib.sp_nearest_center_workspace_bytes.argtypes = [i64, i64, i64]
   lib.sp_nearest_center_workspace_bytes.restype = sz
   lib.sp_nearest_center.argtypes = [vp, i32, i64, vp, i32, i64, i64, i64, i64, vp, i32, vp, sz, vp]
+  lib.sp_kmeans_points_prepared_bytes.argtypes = [i64, i64]
+  lib.sp_kmeans_points_prepared_bytes.restype = sz
+  lib.sp_kmeans_points_prepare.argtypes = [vp, i64, i64, i64, vp, sz, vp]
+  lib.sp_nearest_center_prepared_workspace_bytes.argtypes = [i64, i64, i64]
+  lib.sp_nearest_center_prepared_workspace_bytes.restype = sz
+  lib.sp_nearest_center_prepared.argtypes = [vp, i32, i64, vp, vp, i32, i64, i64, i64, i64, vp, i32, vp, sz, vp]
   lib.sp_bincount_i64.argtypes = [vp, i64, i64, vp, vp]
   lib.sp_segment_sum_workspace_bytes.argtypes = [i64, i64, i64]
   lib.sp_segment_sum_workspace_bytes.restype = sz
@@ -200,7 +206,7 @@ EXPORTS = [
     'sp_abi_version', 'sp_last_error', 'sp_device_count', 'sp_device_info', 'sp_map_fused',
     'sp_program_static_id', 'sp_jit_configure', 'sp_jit_wait', 'sp_jit_compiled_count', 'sp_jit_compile_check', 'sp_jit_seed_begin', 'sp_jit_seed_end',
     'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
-    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_rowdot_colsum_workspace_bytes', 'sp_rowdot_colsum_f32', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center',
+    'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_rowdot_colsum_workspace_bytes', 'sp_rowdot_colsum_f32', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center', 'sp_kmeans_points_prepared_bytes', 'sp_kmeans_points_prepare', 'sp_nearest_center_prepared_workspace_bytes', 'sp_nearest_center_prepared',
     'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_random_fill', 'sp_cumscan',
     'sp_coo_to_csr_workspace_bytes', 'sp_coo_to_csr', 'sp_csr_rows', 'sp_coo_box', 'sp_coo_reshape', 'sp_csr_spmm_workspace_bytes', 'sp_csr_spmv_plan_entries', 'sp_csr_spmv_plan', 'sp_csr_spmv_blockplan_bytes', 'sp_csr_spmv_blockplan', 'sp_csr_spmv_blocked', 'sp_csr_spmm', 'sp_csr_scatter',
     'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',

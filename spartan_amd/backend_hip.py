@@ -41,6 +41,20 @@ def _content_stamp(view):
   return (view.shape, view.dtype.str, _digest(memoryview(view).cast('B')))
 
 
+class _FixedPoints(object):
+  def __init__(self, backend):
+    self.backend = backend
+
+  def __enter__(self):
+    self.outer = self.backend._fixed_points
+    if self.outer is None:
+      self.backend._fixed_points = {}
+    return self
+
+  def __exit__(self, *exc):
+    self.backend._fixed_points = self.outer
+
+
 class _HostCopyLater(object):
   """What HipBackend.to_numpy_later hands out: get() waits for the copy (once) and returns the array."""
 
@@ -87,6 +101,7 @@ class HipBackend(object):
     self.device = 'hip'
     self._np_cache = collections.OrderedDict()   # bounded: iterative drivers pass a new array every step
     self._side_copies, self._pinned_free = None, {}     # to_numpy_later
+    self._fixed_points = None                            # fixed_points()
     self.launches = 0
     self.gemms = 0            # gemm_into launches (the K-split tests count them)
     self.host_round_trips = 0  # local functions that had to run on host copies of their tiles (call_local_fn)
@@ -902,7 +917,23 @@ class HipBackend(object):
     points, centers = self._rows(self._as_device(points)), self._rows(self._as_device(centers))
     out = self.empty((points.shape[0],), np.int64)
     self.launches += 1
-    return kernels.nearest_center(points, centers, out, tier)
+    prepared = None
+    if self._fixed_points is not None and self.dtype_of(points) == np.float32 and points.shape[0] >= 1024:
+      # inside a fit (fixed_points): the points' bf16 images are made on their first use and kept to its end
+      key = (points.data_ptr(), tuple(points.shape), tuple(points.strides))
+      prepared = self._fixed_points.get(key)
+      if prepared is None:
+        if len(self._fixed_points) >= 64:      # (points that are re-made every iteration: keep nothing of them)
+          self._fixed_points.clear()
+        prepared = self._fixed_points[key] = (kernels.prepare_points(points), points)     # (the tile stays alive)
+      prepared = prepared[0]
+    return kernels.nearest_center(points, centers, out, tier, prepared)
+
+  def fixed_points(self):
+    """with be.fixed_points(): -- the caller promises that the point tiles it passes to nearest_center are not
+    written inside the block (the iterations of one k-means fit): what the kernels derive from the points alone is
+    then derived once per tile.  Nothing outlives the block."""
+    return _FixedPoints(self)
 
   def bincount(self, labels, k):
     """np.bincount(labels.astype(int), minlength=k) -> int64 (k,)  (k_means_.py:69-72)."""

@@ -142,13 +142,65 @@ __global__ __launch_bounds__(256) void sp_nearest_exact_kernel(const TX* __restr
   }
 }
 
-// Last step of the fused tier: cdist's exact distance (sequential fp64 sum of squared differences in feature
-// order, sqrt) of the centers sp_nearest_nt_kernel<.., true> marked for each listed point -- typically the two
-// or three that tied -- and the lexicographic (distance, index) minimum = np.argmin's first minimum.
-// A wavefront serves P = 64 / W' listed points at a time (W' = mask words per point rounded up to a power of
-// two, P = 1 and a loop over the words beyond 64): a lane owns one mask word and walks its set bits in ascending
-// center order, reading the point and the center row (straight from the caller's centers: both contiguous) eight
-// features ahead of the sequential sum.
+// Last step of the MFMA tiers: cdist's exact distance (sequential fp64 sum of squared differences in feature
+// order, sqrt) of the centers the re-check pass marked for each listed point, and the lexicographic (distance,
+// index) minimum = np.argmin's first minimum.
+// ONE WAVEFRONT PER LISTED POINT, ONE LANE PER CANDIDATE (round 4; before: a lane walked the set bits of one mask
+// word one after the other, 91 - 256 us for 17 - 38 thousand points of configs[3]): the lanes first write the numbers
+// of the marked centers, in ascending order, into a list (a lane owns the mask words lane, lane + 64, ...; a wave scan
+// of the popcounts places them), then lane j runs the chain of candidate j -- the point's row is the same address for
+// every lane, the center rows come straight from the caller's centers, both read J features ahead of the sum -- and a
+// wave reduction picks the minimum.  More than 64 candidates: 64 at a time.  A point with ONE candidate (its window
+// holds the first pass's best only) is settled without reading a row; one with more than the list holds falls back to
+// every lane walking its own mask words.
+// cdist 'euclidean' of one (point, center) pair on doubles: the squared differences added in feature order, sqrt;
+// the rows are read J features ahead of the sum
+template <typename TC>
+__device__ __forceinline__ double km_exact_distance(const float* __restrict__ xr, const TC* __restrict__ cr, int d) {
+  constexpr int J = 8;
+  double s = 0.0;
+  int jj = 0;
+  if (J <= d) {
+    float xa[J];
+    TC ca[J];
+#pragma unroll
+    for (int u = 0; u < J; ++u) {
+      xa[u] = xr[u];
+      ca[u] = cr[u];
+    }
+    for (; jj + 2 * J <= d; jj += J) {
+      float xb[J];
+      TC cb[J];
+#pragma unroll
+      for (int u = 0; u < J; ++u) {
+        xb[u] = xr[jj + J + u];
+        cb[u] = cr[jj + J + u];
+      }
+#pragma unroll
+      for (int u = 0; u < J; ++u) {
+        const double diff = (double)xa[u] - (double)ca[u];
+        s += diff * diff;
+      }
+#pragma unroll
+      for (int u = 0; u < J; ++u) {
+        xa[u] = xb[u];
+        ca[u] = cb[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < J; ++u) {
+      const double diff = (double)xa[u] - (double)ca[u];
+      s += diff * diff;
+    }
+    jj += J;
+  }
+  for (; jj < d; ++jj) {
+    const double diff = (double)xr[jj] - (double)cr[jj];
+    s += diff * diff;
+  }
+  return sqrt(s);
+}
+
 template <typename TC>
 __global__ __launch_bounds__(256) void sp_nearest_candidates_kernel(const float* __restrict__ X, int64_t ldx,
                                                                     const TC* __restrict__ C, int64_t ldc, int kp,
@@ -156,67 +208,86 @@ __global__ __launch_bounds__(256) void sp_nearest_candidates_kernel(const float*
                                                                     const int* __restrict__ rows,
                                                                     const int* __restrict__ n_rows, int64_t cap,
                                                                     const unsigned* __restrict__ cand_mask) {
-  constexpr int J = 8;
-  const int lane = threadIdx.x & 63;
+  constexpr int LIST = 512;
+  __shared__ int list_s[4][LIST];                 // per wave: the candidates of its point
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int* list = list_s[wv];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t count = *n_rows;
   if (count > cap) return;                        // no masks were written: the exact kernel re-does the list
   const int words = kp / 32;
-  int wp = 1;
-  while (wp < words && wp < 64) wp <<= 1;         // lanes per point
-  const int P = 64 / wp;                          // points per wavefront and trip
-  const int sub = lane / wp, wl = lane - sub * wp;
-  for (int64_t it0 = wave * P; it0 < count; it0 += nwaves * P) {
-    const int64_t it = it0 + sub < count ? it0 + sub : count - 1;   // tail: repeat the last listed point
+  for (int64_t it = wave; it < count; it += nwaves) {
     const int64_t row = rows[it];
+    const unsigned* __restrict__ mw = cand_mask + it * words;
     const float* __restrict__ xr = X + row * ldx;
-    double best = INFINITY;
-    int best_k = 0x7fffffff;
-    for (int w0 = 0; w0 < words; w0 += wp) {
-      const int wi = w0 + wl;
-      unsigned m = wi < words ? cand_mask[it * words + wi] : 0u;
+    // ---- the list: word w of the mask holds centers 32 w .. 32 w + 31
+    int total = 0;
+    for (int w0 = 0; w0 < words; w0 += 64) {
+      const int wi = w0 + lane;
+      unsigned m = wi < words ? mw[wi] : 0u;
+      if (wi * 32 + 32 > k) m &= wi * 32 < k ? ((1u << (k - wi * 32)) - 1u) : 0u;   // (padding centers)
+      const int mine = __builtin_popcount(m);
+      int inc = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      int at = total + inc - mine;
       while (m) {
-        const int c = wi * 32 + __builtin_ctz(m);
+        if (at < LIST) list[at] = wi * 32 + __builtin_ctz(m);
         m &= m - 1;
-        if (c >= k) break;
-        const TC* __restrict__ cr = C + (int64_t)c * ldc;
-        double s = 0.0;
-        int jj = 0;
-        for (; jj + J <= d; jj += J) {
-          double xv[J], cv[J];
-#pragma unroll
-          for (int u = 0; u < J; ++u) {
-            xv[u] = (double)xr[jj + u];
-            cv[u] = (double)cr[jj + u];
-          }
-#pragma unroll
-          for (int u = 0; u < J; ++u) {
-            const double diff = xv[u] - cv[u];
-            s += diff * diff;
-          }
-        }
-        for (; jj < d; ++jj) {
-          const double diff = (double)xr[jj] - (double)cr[jj];
-          s += diff * diff;
-        }
-        s = sqrt(s);
-        if (s < best) {                           // ascending center index per lane: `<` keeps the first minimum
+        ++at;
+      }
+      total += __shfl(inc, 63);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int best_k = 0x7fffffff;
+    double best = INFINITY;
+    if (total == 1) {
+      best_k = list[0];
+    } else if (total > 1 && total <= LIST) {
+      for (int c0 = 0; c0 < total; c0 += 64) {
+        const bool live = c0 + lane < total;
+        const int c = list[live ? c0 + lane : 0];
+        const double s = km_exact_distance<TC>(xr, C + (int64_t)c * ldc, d);
+        if (live && (s < best || (s == best && c < best_k))) {
           best = s;
           best_k = c;
         }
       }
+    } else if (total > LIST) {
+      // more candidates than the list holds (a mass of coincident centers): every lane walks the set bits of its
+      // own words, one after the other
+      for (int wi = lane; wi < words; wi += 64) {
+        unsigned m = mw[wi];
+        while (m) {
+          const int c = wi * 32 + __builtin_ctz(m);
+          m &= m - 1;
+          if (c >= k) break;
+          const double s = km_exact_distance<TC>(xr, C + (int64_t)c * ldc, d);
+          if (s < best || (s == best && c < best_k)) {
+            best = s;
+            best_k = c;
+          }
+        }
+      }
     }
-    for (int off = wp >> 1; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off);
-      const int ok = __shfl_xor(best_k, off);
-      if (ob < best || (ob == best && ok < best_k)) {
-        best = ob;
-        best_k = ok;
+    if (total > 1) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int ok = __shfl_xor(best_k, off);
+        if (ob < best || (ob == best && ok < best_k)) {
+          best = ob;
+          best_k = ok;
+        }
       }
     }
     // (the window always contains the first pass's own best center; the guard is for NaN input)
-    if (wl == 0 && it0 + sub < count) labels[row] = best_k == 0x7fffffff ? -1 - labels[row] : best_k;
+    if (lane == 0) labels[row] = best_k == 0x7fffffff ? -1 - labels[row] : best_k;
+    __builtin_amdgcn_wave_barrier();              // the list is rewritten for the next point
   }
 }
 
@@ -526,14 +597,62 @@ static int sort_block_rows(int64_t n, int64_t k) {
 }  // namespace
 
 #include "kmeans_mfma.hpp"
+#include "kmeans_split.hpp"
 
 extern "C" size_t sp_nearest_center_workspace_bytes(int64_t n, int64_t k, int64_t d) {
   return sp_nearest_fused_ws_bytes(n, k, d);
 }
 
+// Which MFMA filter the AUTO / explicit tiers mean: the split tier wherever the fused one applies (fp32 points),
+// unless SP_KM_SPLIT=0 (A/B measurements) or the tier names the fp32 filter.
+static bool km_use_split(int32_t tier, int64_t d) {
+  static const bool off = getenv("SP_KM_SPLIT") && atoi(getenv("SP_KM_SPLIT")) == 0;
+  if (tier == SP_NEAREST_SPLIT || tier == SP_NEAREST_SPLIT_UNCHECKED) return true;
+  if (tier == SP_NEAREST_FUSED || tier == SP_NEAREST_FUSED_UNCHECKED) return false;
+  return !off && d >= 32;      // (few features: the terms the split leaves out outweigh the roundings it saves)
+}
+
+extern "C" size_t sp_kmeans_points_prepared_bytes(int64_t n, int64_t d) { return 256 + km_points_split_bytes(n, d); }
+
+extern "C" int sp_kmeans_points_prepare(const float* d_points, int64_t ldx, int64_t n, int64_t d, void* d_prepared,
+                                        size_t bytes, void* stream) {
+  if (n < 0 || d < 0 || ldx < d) SP_FAIL("sp_kmeans_points_prepare: bad sizes");
+  if (n == 0) return 0;
+  if (!d_points || !d_prepared || bytes < sp_kmeans_points_prepared_bytes(n, d)) SP_FAIL("sp_kmeans_points_prepare: buffer too small");
+  KmWorkspace w;
+  w.dp = km_padded_features(d);
+  km_carve_points((void*)(((uintptr_t)d_prepared + 255) & ~(uintptr_t)255), n, d, &w);
+  if (km_col_means<float>(d_points, ldx, n, d, w, (hipStream_t)stream)) return 1;     // the shift: the points' own mean
+  return km_split_points(d_points, ldx, n, d, w, (hipStream_t)stream);
+}
+
+extern "C" size_t sp_nearest_center_prepared_workspace_bytes(int64_t n, int64_t k, int64_t d) {
+  return sp_nearest_fused_ws_bytes(n, k, d, false);
+}
+
+static int km_nearest_center(const void* d_points, int32_t dtype, int64_t ldx, const void* d_prepared,
+                             const void* d_centers, int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
+                             int64_t* d_labels, int32_t tier, void* d_ws, size_t ws_bytes, void* stream);
+
+extern "C" int sp_nearest_center_prepared(const void* d_points, int32_t dtype, int64_t ldx, const void* d_prepared,
+                                          const void* d_centers, int32_t cdtype, int64_t ldc, int64_t n, int64_t k,
+                                          int64_t d, int64_t* d_labels, int32_t tier, void* d_ws, size_t ws_bytes,
+                                          void* stream) {
+  if (!d_prepared) SP_FAIL("sp_nearest_center_prepared: d_prepared is NULL");
+  return km_nearest_center(d_points, dtype, ldx, d_prepared, d_centers, cdtype, ldc, n, k, d, d_labels, tier, d_ws,
+                           ws_bytes, stream);
+}
+
 extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ldx, const void* d_centers,
                                  int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
                                  int64_t* d_labels, int32_t tier, void* d_ws, size_t ws_bytes, void* stream) {
+  return km_nearest_center(d_points, dtype, ldx, nullptr, d_centers, cdtype, ldc, n, k, d, d_labels, tier, d_ws, ws_bytes,
+                           stream);
+}
+
+static int km_nearest_center(const void* d_points, int32_t dtype, int64_t ldx, const void* d_prepared,
+                             const void* d_centers, int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
+                             int64_t* d_labels, int32_t tier, void* d_ws, size_t ws_bytes, void* stream) {
   if (n < 0 || k < 1 || d < 0) SP_FAIL("sp_nearest_center: bad sizes n=%lld k=%lld d=%lld", (long long)n, (long long)k, (long long)d);
   if (n == 0) return 0;
   if (!d_points || !d_centers || !d_labels) SP_FAIL("sp_nearest_center: NULL pointer");
@@ -541,9 +660,10 @@ extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ld
   if (k > 2147483647LL || d > 2147483647LL) SP_FAIL("sp_nearest_center: k or d too large");
   if (ldx < d || ldc < d) SP_FAIL("sp_nearest_center: leading dimension too small");
   hipStream_t st = (hipStream_t)stream;
-  const size_t need = sp_nearest_fused_ws_bytes(n, k, d);
+  const size_t need = sp_nearest_fused_ws_bytes(n, k, d, d_prepared == nullptr);
   if (!d_ws || ws_bytes < need) SP_FAIL("sp_nearest_center: workspace too small (%zu < %zu)", ws_bytes, need);
   KmWorkspace w = km_carve(d_ws, n, k, d);
+  if (d_prepared) km_carve_points((void*)(((uintptr_t)d_prepared + 255) & ~(uintptr_t)255), n, d, &w);
   // fp64 transposed centers for the exact kernel
   {
     const int64_t tot = d * w.kp;
@@ -562,8 +682,18 @@ extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ld
   const int* n_rows = nullptr;
   int64_t handled = -1;
   if (tier != SP_NEAREST_EXACT && dtype == SP_F32 && sp_nearest_fused_applicable(n, k, d, tier)) {
-    if (sp_nearest_fused_launch((const float*)d_points, ldx, d_centers, cdtype, ldc, n, k, d, d_labels, w, st)) return 1;
-    if (tier == SP_NEAREST_FUSED_UNCHECKED) return 0;   // diagnostics: leave the marks (-1 - best) in place
+    const bool split = km_use_split(tier, d);
+    if (split) {
+      if (!d_prepared) {      // the shift of a stand-alone call: the centers' mean (no extra pass over the points)
+        if (cdtype == SP_F32 ? km_col_means<float>((const float*)d_centers, ldc, k, d, w, st)
+                             : km_col_means<double>((const double*)d_centers, ldc, k, d, w, st)) return 1;
+        if (km_split_points((const float*)d_points, ldx, n, d, w, st)) return 1;
+      }
+      if (sp_nearest_split_launch(d_centers, cdtype, ldc, n, k, d, d_labels, w, st)) return 1;
+    } else {
+      if (sp_nearest_fused_launch((const float*)d_points, ldx, d_centers, cdtype, ldc, n, k, d, d_labels, w, st)) return 1;
+    }
+    if (tier == SP_NEAREST_FUSED_UNCHECKED || tier == SP_NEAREST_SPLIT_UNCHECKED) return 0;   // diagnostics: leave the marks (-1 - best) in place
     // the points the fused kernel listed as undecided: fp32 window over all centers, exact fp64 distance
     // for the few inside it (SP_KM_FULL_RECHECK=1: the full exact kernel instead, for A/B measurements)
     static int recheck_mode = -1;   // 0: MFMA candidate masks (default); SP_KM_RECHECK=2: the exact kernel on the list
@@ -574,7 +704,7 @@ extern "C" int sp_nearest_center(const void* d_points, int32_t dtype, int64_t ld
     rows = w.amb_rows;
     n_rows = w.amb_count;
     if (recheck_mode == 0) {
-      if (sp_nearest_mark_candidates((const float*)d_points, ldx, d, w, st)) return 1;
+      if (split ? sp_nearest_split_mark_candidates(d, w, st) : sp_nearest_mark_candidates((const float*)d_points, ldx, d, w, st)) return 1;
       if (cdtype == SP_F32)
         hipLaunchKernelGGL((sp_nearest_candidates_kernel<float>), dim3(SP_CUS * 8), dim3(256), 0, st, (const float*)d_points,
                            ldx, (const float*)d_centers, ldc, (int)w.kp, (int)k, (int)d, d_labels, rows, n_rows, w.cand_cap,

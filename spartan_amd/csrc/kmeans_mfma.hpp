@@ -83,12 +83,14 @@ static_assert(KN_BM == KM_BN_MAX, "kp must be a multiple of the center block");
 
 // The verdict on one point from its fp32 (best, second best) halved scores: the label when the gap clears the error
 // bound, else -1 - label and a place in the list the re-check works through.
-__device__ __forceinline__ void km_decide(float b, float s, int ix, float xn, int point, int d, float cmax,
+// `ef`: the tier's error factor (this file: 2 D + 4, km_fp32_factor; kmeans_split.hpp: km_split_factor).
+__device__ __forceinline__ float km_fp32_factor(int d) { return 2.0f * (float)d + 4.0f; }
+__device__ __forceinline__ void km_decide(float b, float s, int ix, float xn, int point, float ef, float cmax,
                                           float cmax2, int64_t* __restrict__ labels, int* __restrict__ amb_rows,
                                           float* __restrict__ amb_best, int* __restrict__ amb_count) {
   const float u = 5.9604645e-8f;                     // 2^-24
   const float xnorm = sqrtf(xn) * 1.001f;            // fp32 sum of squares: generous slack
-  const float E = u * ((2.0f * (float)d + 4.0f) * xnorm * cmax + 2.0f * cmax2);
+  const float E = u * (ef * xnorm * cmax + 2.0f * cmax2);
   const bool sure = 2.0f * (s - b) > 4.0f * E;       // (scores are halved) false for NaN / inf-inf as well
   labels[point] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
   if (!sure) {   // (order-free: each listed point is re-done on its own)
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
           ((int*)part)[at + 2 * (int64_t)ldp] = ix;
           if (blockIdx.y == 0) part[(int64_t)gridDim.y * 3 * ldp + m0 + col] = xn[j];
         } else {
-          km_decide(b, s, ix, xn[j], m0 + col, d, cmax, cmax2, labels, amb_rows, amb_best, amb_count);
+          km_decide(b, s, ix, xn[j], m0 + col, km_fp32_factor(d), cmax, cmax2, labels, amb_rows, amb_best, amb_count);
         }
       }
     }
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
 
 // Combines the per-center-range parts of the PARTIAL launch for tail point t (global point first + t).
 __global__ __launch_bounds__(256) void sp_nearest_merge_parts_kernel(const float* __restrict__ part, int S, int ldp,
-                                                                     int n_tail, int first, int d,
+                                                                     int n_tail, int first, float ef,
                                                                      const unsigned* __restrict__ cmax2_bits,
                                                                      int64_t* __restrict__ labels,
                                                                      int* __restrict__ amb_rows,
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(256) void sp_nearest_merge_parts_kernel(const float
     }
   }
   const float cmax2 = __uint_as_float(*cmax2_bits);
-  km_decide(b, s, ix, part[(int64_t)S * 3 * ldp + t], first + t, d, sqrtf(cmax2) * 1.0000002f, cmax2, labels, amb_rows,
+  km_decide(b, s, ix, part[(int64_t)S * 3 * ldp + t], first + t, ef, sqrtf(cmax2) * 1.0000002f, cmax2, labels, amb_rows,
             amb_best, amb_count);
 }
 
@@ -490,7 +492,14 @@ struct KmWorkspace {
   int64_t cand_cap;  //           listed points the candidate masks have room for
   unsigned* cand_mask;   // [cand_cap][kp / 32]  centers inside the error window of a listed point
   float* part;       // [KM_TAIL_SPLIT][3][KM_TAIL_POINTS] + [KM_TAIL_POINTS]   parts of the tail points
+  // the split tier (kmeans_split.hpp): hi / mid bf16 images of the centers and of the points, |x|^2 per point
+  __bf16 *Ch, *Cm;   // [kp][dp] each
+  float* colsum;     // [KM_MEAN_BLOCKS][dp]  partial column sums behind `mu`
+  float* mu;         // [dp]      the shift: both operands are taken relative to it (kmeans_split.hpp)
+  float* xn2;        // [n]       |x - mu|^2
+  __bf16 *Xh, *Xm;   // [n][dp] each -- LAST: a caller that brings prepared points leaves them (mu, xn2 too) out
 };
+constexpr int KM_MEAN_BLOCKS = 256;
 
 // The last round of first-pass workgroups is rarely full (configs[3]: 9 766 workgroups over 512 slots = 19 rounds and
 // 38 workgroups that cost a 20th).  The points of that round are split over up to KM_TAIL_SPLIT ranges of center
@@ -515,11 +524,34 @@ static inline int64_t km_cand_cap(int64_t n) {
   return cap > n ? (n < 1 ? 1 : n) : cap;
 }
 
-static size_t sp_nearest_fused_ws_bytes(int64_t n, int64_t k, int64_t d) {
+// bytes of the hi / mid images and the norms of n points (what sp_kmeans_points_prepare fills)
+static size_t km_points_split_bytes(int64_t n, int64_t d) {
+  const int64_t dp = km_padded_features(d), rows = n < 1 ? 1 : n;
+  return km_align((size_t)KM_MEAN_BLOCKS * dp * 4) + km_align((size_t)dp * 4) + km_align((size_t)rows * 4) +
+         2 * km_align((size_t)rows * dp * 2);
+}
+
+static size_t sp_nearest_fused_ws_bytes(int64_t n, int64_t k, int64_t d, bool with_points = true) {
   const int64_t kp = km_round_up(k < 1 ? 1 : k, KM_BN_MAX), dp = km_padded_features(d);
   return 256 + km_align((size_t)(d < 1 ? 1 : d) * kp * 8) + km_align((size_t)dp * kp * 4) + km_align((size_t)kp * 4) + 256 + 256 +
          2 * km_align((size_t)(n < 1 ? 1 : n) * 4) + km_align((size_t)km_cand_cap(n) * (kp / 32) * 4) +
-         km_align((size_t)KM_TAIL_POINTS * (3 * KM_TAIL_SPLIT + 1) * 4);
+         km_align((size_t)KM_TAIL_POINTS * (3 * KM_TAIL_SPLIT + 1) * 4) + 2 * km_align((size_t)dp * kp * 2) +
+         (with_points ? km_points_split_bytes(n, d) : 0);
+}
+
+// the points' part (norms, hi image, mid image) of a workspace or of a prepared buffer
+static void km_carve_points(void* at, int64_t n, int64_t d, KmWorkspace* w) {
+  const int64_t dp = km_padded_features(d), rows = n < 1 ? 1 : n;
+  char* p = (char*)at;
+  w->colsum = (float*)p;
+  p += km_align((size_t)KM_MEAN_BLOCKS * dp * 4);
+  w->mu = (float*)p;
+  p += km_align((size_t)dp * 4);
+  w->xn2 = (float*)p;
+  p += km_align((size_t)rows * 4);
+  w->Xh = (__bf16*)p;
+  p += km_align((size_t)rows * dp * 2);
+  w->Xm = (__bf16*)p;
 }
 
 static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
@@ -545,13 +577,19 @@ static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
   w.cand_mask = (unsigned*)p;
   p += km_align((size_t)w.cand_cap * (w.kp / 32) * 4);
   w.part = (float*)p;
+  p += km_align((size_t)KM_TAIL_POINTS * (3 * KM_TAIL_SPLIT + 1) * 4);
+  w.Ch = (__bf16*)p;
+  p += km_align((size_t)w.dp * w.kp * 2);
+  w.Cm = (__bf16*)p;
+  p += km_align((size_t)w.dp * w.kp * 2);
+  km_carve_points(p, n, d, &w);
   return w;
 }
 
 // the fused tier pays once the contraction is big enough to hide its fixed costs
 static bool sp_nearest_fused_applicable(int64_t n, int64_t k, int64_t d, int tier) {
   if (n > 2147483647LL - KN_BN || d < 1 || k > (1LL << 20)) return false;
-  if (tier == SP_NEAREST_FUSED || tier == SP_NEAREST_FUSED_UNCHECKED) return true;
+  if (tier == SP_NEAREST_FUSED || tier == SP_NEAREST_FUSED_UNCHECKED || tier == SP_NEAREST_SPLIT || tier == SP_NEAREST_SPLIT_UNCHECKED) return true;
   return n >= 1024 && k >= 16 && d >= 8 && n * k * d >= (1LL << 24);
 }
 
@@ -607,7 +645,7 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
   if (rem > 0) {
     const int n_tail = (int)(n - n_whole);
     hipLaunchKernelGGL(sp_nearest_merge_parts_kernel, dim3((unsigned)((n_tail + 255) / 256)), dim3(256), 0, st, w.part,
-                       (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, (int)d, w.cmax2, labels, w.amb_rows, w.amb_best,
+                       (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, 2.0f * (float)d + 4.0f, w.cmax2, labels, w.amb_rows, w.amb_best,
                        w.amb_count);
     SP_CHECK_LAUNCH();
   }

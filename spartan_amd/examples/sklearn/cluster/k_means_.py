@@ -219,6 +219,14 @@ class KMeans(object):
       see the module docstring; np.add: the real update).
     Returns (centers, labels); `labels` is an expression of the last assignment.
     """
+    # the points are not written between the iterations of a fit: a backend may derive what it needs of them once
+    fixed = getattr(context.get().backend, 'fixed_points', None) if context.initialized() else None
+    if fixed is not None:
+      with fixed():
+        return self._fit(X, centers, implementation, reducer)
+    return self._fit(X, centers, implementation, reducer)
+
+  def _fit(self, X, centers, implementation, reducer):
     k, dim = self.n_clusters, X.shape[1]
     labels = expr.zeros((X.shape[0], 1), dtype=np.int64)
     if implementation in ('map2', 'shuffle'):

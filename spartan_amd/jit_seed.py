@@ -34,6 +34,7 @@ class _SeedBackend(HipBackend):
     self._lowered = collections.OrderedDict()
     self.lowering_hits = 0
     self._side_copies, self._pinned_free = None, {}
+    self._fixed_points = None
 
   def _lowering_key(self, op, inputs, ex, extra):
     return None          # every program is lowered (and its specialisation requested) afresh

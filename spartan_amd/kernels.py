@@ -163,13 +163,34 @@ def _ld(t):
   return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
-def nearest_center(points, centers, labels, tier=_hip.NEAREST_AUTO):
+def prepare_points(points):
+  """What the split tier of nearest_center reads of fp32 points -- two bf16 images and |x|^2 per point -- as a
+  buffer to hand to nearest_center(prepared=...) for as long as the points are not written (one k-means fit)."""
+  _require_device(points)
+  n, d = points.shape
+  assert np_dtype_of(points) == np.float32
+  lib = _hip.lib()
+  out = devarray.empty((max(int(lib.sp_kmeans_points_prepared_bytes(n, d)), 1),), np.uint8)
+  check(lib.sp_kmeans_points_prepare(C.c_void_p(points.data_ptr()), _ld(points), n, d, C.c_void_p(out.data_ptr()),
+                                     out.numel(), _stream()))
+  return out
+
+
+def nearest_center(points, centers, labels, tier=_hip.NEAREST_AUTO, prepared=None):
   """labels[i] = argmin_c |points[i] - centers[c]| (cdist + argmin; k_means_.py:61-66)."""
   _require_device(points, centers, labels)
   n, d = points.shape
   k, d2 = centers.shape
   assert d == d2 and np_dtype_of(labels) == np.int64 and labels.numel() == n and labels.is_contiguous()
   lib = _hip.lib()
+  if prepared is not None:
+    ws = _ws.get(lib.sp_nearest_center_prepared_workspace_bytes(n, k, d), points.device)
+    check(lib.sp_nearest_center_prepared(C.c_void_p(points.data_ptr()), _hip.sp_dtype(np_dtype_of(points)), _ld(points),
+                                         C.c_void_p(prepared.data_ptr()),
+                                         C.c_void_p(centers.data_ptr()), _hip.sp_dtype(np_dtype_of(centers)), _ld(centers),
+                                         n, k, d, C.c_void_p(labels.data_ptr()), tier, C.c_void_p(ws.data_ptr()),
+                                         ws.numel(), _stream()))
+    return labels
   need = lib.sp_nearest_center_workspace_bytes(n, k, d)
   ws = _ws.get(need, points.device)
   check(lib.sp_nearest_center(C.c_void_p(points.data_ptr()), _hip.sp_dtype(np_dtype_of(points)), _ld(points),

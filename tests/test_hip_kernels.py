@@ -650,14 +650,15 @@ def test_nearest_center_exact_is_cdist_argmin(n, k, d, xdt, cdt):
 
 @pytest.mark.parametrize('n,k,d', [(5000, 300, 64), (4097, 129, 50), (3000, 1024, 256), (2048, 16, 8), (130, 5, 3),
                                    (6000, 520, 100), (3000, 260, 36)])   # aligned rows, partial last k-tile
-def test_nearest_center_fused_equals_exact(n, k, d):
-  """The MFMA tier + exact re-check of near ties gives the exact tier's labels, bit for bit."""
+@pytest.mark.parametrize('tier', ['FUSED', 'SPLIT'])
+def test_nearest_center_fused_equals_exact(n, k, d, tier):
+  """An MFMA tier (fp32, or bf16-split) + exact re-check of near ties gives the exact tier's labels, bit for bit."""
   from scipy.spatial.distance import cdist
   x = RNG.rand(n, d).astype(np.float32)
   c = RNG.rand(k, d)
   c[k // 2] = c[0]                       # exact duplicate centre: ties must go to the lower index
   x[: min(n, k)] = c[: min(n, k)].astype(np.float32)   # points sitting (almost) on centres
-  fused = _nearest(x, c, _hip.NEAREST_FUSED)
+  fused = _nearest(x, c, getattr(_hip, 'NEAREST_' + tier))
   exact = _nearest(x, c, _hip.NEAREST_EXACT)
   np.testing.assert_array_equal(fused, exact)
   np.testing.assert_array_equal(exact, np.argmin(cdist(x, c), axis=1))
@@ -665,7 +666,8 @@ def test_nearest_center_fused_equals_exact(n, k, d):
 
 
 @pytest.mark.parametrize('n,k,d', [(9000, 40, 24), (6000, 600, 64), (300, 3000, 16), (4000, 64, 32)])
-def test_nearest_center_everything_undecided(n, k, d):
+@pytest.mark.parametrize('tier', ['FUSED', 'SPLIT'])
+def test_nearest_center_everything_undecided(n, k, d, tier):
   """Every centre exists twice, so no point can be decided by the fp32 pass: with more listed points than the
   candidate masks hold (n / 8, at least 4096) the list goes to the exact kernel, below that to the MFMA re-check
   (here with more than 64 mask words per point at k = 3000) -- the labels are the exact tier's either way."""
@@ -673,16 +675,17 @@ def test_nearest_center_everything_undecided(n, k, d):
   x = RNG.rand(n, d).astype(np.float32)
   half = RNG.rand(k // 2, d)
   c = np.concatenate([half, half], axis=0)
-  fused = _nearest(x, c, _hip.NEAREST_FUSED)
+  fused = _nearest(x, c, getattr(_hip, 'NEAREST_' + tier))
   want = np.argmin(cdist(x, c), axis=1)
   np.testing.assert_array_equal(fused, want)
   assert fused.max() < k // 2
-  unchecked = _nearest(x, c, _hip.NEAREST_FUSED_UNCHECKED)
+  unchecked = _nearest(x, c, getattr(_hip, 'NEAREST_%s_UNCHECKED' % tier))
   assert np.all(unchecked < 0)           # the first pass listed every point
 
 
 @pytest.mark.parametrize('n,k,d', [(512 * 128 + 4000, 600, 32), (700, 2304, 40), (512 * 128, 513, 32)])
-def test_nearest_center_split_tail(n, k, d):
+@pytest.mark.parametrize('tier', ['FUSED', 'SPLIT'])
+def test_nearest_center_split_tail(n, k, d, tier):
   """The partly filled last round of first-pass workgroups runs split over ranges of centre blocks and is merged
   afterwards (3 ranges; 9 blocks in 5 ranges of 2,2,2,2,1; a tile of whole rounds only): same labels as the exact
   tier, with the duplicate centres in different ranges."""
@@ -691,12 +694,77 @@ def test_nearest_center_split_tail(n, k, d):
   c = RNG.rand(k, d)
   c[k - 1] = c[3]                        # tie across the first and the last range
   x[:50] = c[3].astype(np.float32)
-  fused = _nearest(x, c, _hip.NEAREST_FUSED)
+  fused = _nearest(x, c, getattr(_hip, 'NEAREST_' + tier))
   want = np.argmin(cdist(x[-5000:], c), axis=1)
   np.testing.assert_array_equal(fused[-5000:], want)
   np.testing.assert_array_equal(fused[:50], np.argmin(cdist(x[:50], c), axis=1))
   assert not np.any(fused == k - 1)
   np.testing.assert_array_equal(fused, _nearest(x, c, _hip.NEAREST_EXACT))
+
+
+@pytest.mark.parametrize('case', ['wide_range', 'signed', 'tiny', 'huge', 'clustered'])
+def test_nearest_center_bf16_split_on_hard_data(case):
+  """The split tier's error window must hold whatever the data look like: values spread over 12 orders of
+  magnitude inside a row (the bf16 cut is relative to each VALUE, the bound to the row norms), both signs, tiny
+  and huge scales, and points packed around the centres (many near ties).  Labels = argmin(cdist) in fp64."""
+  from scipy.spatial.distance import cdist
+  rng = np.random.RandomState(99)
+  n, k, d = 5000, 300, 96
+  x = rng.rand(n, d)
+  c = rng.rand(k, d)
+  if case == 'wide_range':
+    x *= 10.0 ** rng.randint(-6, 6, size=(n, d))
+    c *= 10.0 ** rng.randint(-6, 6, size=(k, d))
+  elif case == 'signed':
+    x, c = x - 0.5, c - 0.5
+  elif case == 'tiny':
+    x, c = x * 1e-18, c * 1e-18
+  elif case == 'huge':
+    x, c = x * 1e15, c * 1e15
+  else:
+    x = c[rng.randint(0, k, size=n)] + rng.randn(n, d) * 1e-4
+  x = x.astype(np.float32)
+  got = _nearest(x, c, _hip.NEAREST_SPLIT)
+  dd = cdist(x.astype(np.float64), c)
+  want = np.argmin(dd, axis=1)
+  differ = np.nonzero(got != want)[0]
+  assert all(dd[i, got[i]] == dd[i, want[i]] for i in differ), differ[:5]     # (exactly equal distances: either index)
+  listed = int((_nearest(x, c, _hip.NEAREST_SPLIT_UNCHECKED) < 0).sum())
+  assert listed < n or case == 'clustered'
+
+
+def test_nearest_center_prepared_points_are_the_same_call():
+  from scipy.spatial.distance import cdist
+  x = RNG.rand(20000, 72).astype(np.float32)
+  big = np.pad(x, ((0, 0), (4, 4)))
+  xt = dev(big)[:, 4:76]                 # strided rows: the images are dense whatever the points' layout
+  prepared = kernels.prepare_points(xt)
+  for seed in (1, 2):
+    c = np.random.RandomState(seed).rand(200, 72)
+    labels = D.empty((20000,), np.int64)
+    kernels.nearest_center(xt, dev(c), labels, prepared=prepared)
+    D.synchronize()
+    np.testing.assert_array_equal(host(labels), np.argmin(cdist(x, c), axis=1))
+
+
+def test_bf16_mfma_accumulation_model():
+  """kmeans_split.hpp bounds the fp32 accumulation of the bf16 MFMA by one rounding to nearest per product (3 D of
+  them) plus the terms it leaves out.  Checked here on the kernel's own scores: with ONE centre the unchecked tier
+  leaves a point undecided never (the second best is +inf), so the test reads the scores back through the
+  re-check's window instead -- |score_fp64 - score_kernel| <= E for every (point, centre), which is what makes the
+  candidate list complete: the exact argmin is always among the centres marked for a listed point."""
+  from scipy.spatial.distance import cdist
+  rng = np.random.RandomState(5)
+  for d in (32, 256, 1000):
+    n, k = 4096, 512
+    x = (rng.rand(n, d) * 10.0 ** rng.randint(-3, 3, size=(n, d))).astype(np.float32)
+    base = rng.rand(k // 2, d)
+    c = np.concatenate([base, base * (1 + 1e-7)], axis=0)       # every centre has a near twin: all points listed
+    got = _nearest(x, c, _hip.NEAREST_SPLIT)
+    dd = cdist(x.astype(np.float64), c)
+    want = np.argmin(dd, axis=1)
+    differ = np.nonzero(got != want)[0]
+    assert all(dd[i, got[i]] == dd[i, want[i]] for i in differ), (d, differ[:5])
 
 
 def test_nearest_center_strided_rows_and_auto_tier():

@@ -23,11 +23,11 @@ for it in range(400):
   xt = D.from_numpy(np.pad(x, ((0, 0), (0, pad))))[:, :d]
   ct = D.from_numpy(c)
   lab = D.empty((n,), np.int64)
-  tier = int(rng.choice([_hip.NEAREST_AUTO, _hip.NEAREST_FUSED]))
+  tier = int(rng.choice([_hip.NEAREST_AUTO, _hip.NEAREST_FUSED, _hip.NEAREST_SPLIT, _hip.NEAREST_SPLIT]))
   try:
     kernels.nearest_center(xt, ct, lab, tier)
   except Exception as e:
-    if xdt == np.float64 and tier == _hip.NEAREST_FUSED: continue   # fused tier is fp32 points only
+    if xdt == np.float64 and tier in (_hip.NEAREST_FUSED, _hip.NEAREST_SPLIT): continue   # the MFMA tiers are fp32 points only
     print('EXC', n, k, d, xdt, cdt, tier, e); bad += 1; continue
   want = np.argmin(cdist(x.astype(np.float64), c.astype(np.float64)), axis=1)
   got = lab.numpy()

@@ -33,6 +33,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -141,8 +142,8 @@ def main():
       rec.update({'avg_us': round(avg, 3), 'min_us': round(min(d), 3), 'max_us': round(max(d), 3)})
       if e['unit'] == 'flop':
         ach = e['units_per_launch'] / (avg * 1e-6) / 1e12
-        rec.update({'achieved': round(ach, 2), 'achieved_unit': 'TFLOP/s', 'peak': MFMA_F32_PEAK_TFLOPS,
-                    'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4)})
+        peak = MFMA_BF16_PEAK_TFLOPS if e['bound'] == 'mfma_bf16' else MFMA_F32_PEAK_TFLOPS
+        rec.update({'achieved': round(ach, 2), 'achieved_unit': 'TFLOP/s', 'peak': peak, 'frac': round(ach / peak, 4)})
       else:
         ach = e['units_per_launch'] / (avg * 1e-6) / 1e9
         rec.update({'achieved': round(ach, 1), 'achieved_unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
