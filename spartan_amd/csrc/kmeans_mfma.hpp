@@ -499,7 +499,7 @@ struct KmWorkspace {
   float* xn2;        // [n]       |x - mu|^2
   __bf16 *Xh, *Xm;   // [n][dp] each -- LAST: a caller that brings prepared points leaves them (mu, xn2 too) out
 };
-constexpr int KM_MEAN_BLOCKS = 256;
+constexpr int KM_MEAN_BLOCKS = 2048;
 
 // The last round of first-pass workgroups is rarely full (configs[3]: 9 766 workgroups over 512 slots = 19 rounds and
 // 38 workgroups that cost a 20th).  The points of that round are split over up to KM_TAIL_SPLIT ranges of center

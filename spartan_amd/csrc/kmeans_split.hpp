@@ -42,16 +42,33 @@
 #pragma once
 
 typedef __bf16 km_bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef KS_ABLATE
+#define KS_ABLATE 0     // timing-only builds (tools/_exp): 1 no k-tile loads, 2 no fragment reads, 4 no epilogue, 8 no MFMAs
+#endif
 
 namespace {
 
+// Workgroup tile: 256 centers x (64 WN) points, 2 x WN waves of 128 centers x 64 points each.  WN = 2 (the fp32
+// kernel's 256 x 128, two workgroups per CU) is the default; WN = 4 (512 lanes, ONE workgroup per CU, a third fewer
+// k-tile bytes per MFMA) measures the same (SP_KM_SPLIT_WN=4).  Timed with parts removed at configs[3] (2.42 ms):
+// without the k-tile loads 1.47, without the fragment reads 2.32, without the epilogue 2.01, without the MFMAs 2.00,
+// without all of them 0.57 -- the MFMAs themselves are a third of the time; neither fewer bytes (WN = 4) nor requests
+// two k-steps ahead (three LDS stages) shortened it.
 constexpr int KS_BK = 16;
-constexpr int KS_BM = KN_BM, KS_BN = KN_BN;                    // 256 centers x 128 points, as the fp32 kernel
+constexpr int KS_BM = KN_BM;
 constexpr int KS_A_BYTES = KS_BM * KS_BK * 2;                  // 8 KiB per image
-constexpr int KS_B_BYTES = KS_BN * KS_BK * 2;                  // 4 KiB per image
-constexpr int KS_STAGE_BYTES = 2 * KS_A_BYTES + 2 * KS_B_BYTES;   // Ah | Am | Bh | Bm
-constexpr int KS_SMEM_BYTES = 2 * KS_STAGE_BYTES + 2 * KS_BM * 4;  // two stages + two |c|^2/2 slices (51 200 B)
-static_assert(KS_SMEM_BYTES <= 65536, "static LDS limit");
+template <int WN>
+struct KsCfg {
+  static constexpr int BN = 64 * WN, NW = 2 * WN, THREADS = 64 * NW;
+  static constexpr int B_BYTES = BN * KS_BK * 2;
+  static constexpr int STAGE_BYTES = 2 * KS_A_BYTES + 2 * B_BYTES;     // Ah | Am | Bh | Bm
+  static constexpr int STAGES = 2;                                     // (three -- k-tiles requested two k-steps ahead -- measured: no gain)
+  static constexpr int SMEM_BYTES = STAGES * STAGE_BYTES + 2 * KS_BM * 4;   // + two |c|^2/2 slices
+  static constexpr int APW = 8 / NW;                                   // 1-KiB pieces of a center image per wave
+  static constexpr int SLOTS = SP_CUS * (WN == 2 ? 2 : 1);             // resident workgroups
+  static_assert(SMEM_BYTES * (WN == 2 ? 2 : 1) <= 160 * 1024, "LDS budget of a CU");
+  static_assert(SLOTS * BN == KM_TAIL_POINTS, "the tail buffer is sized for one round of either geometry");
+};
 
 __device__ __forceinline__ float km_split_factor(int d) { return 6.1f * (float)d + 1550.0f; }
 
@@ -64,8 +81,17 @@ __global__ __launch_bounds__(256) void sp_col_partial_kernel(const T* __restrict
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
   for (int j = threadIdx.x; j < dp; j += blockDim.x) {
     float s = 0.f;
-    if (j < d)
-      for (int64_t r = r0; r < r1; ++r) s += (float)X[r * ldx + j];
+    if (j < d) {
+      int64_t r = r0;
+      for (; r + 8 <= r1; r += 8) {          // eight rows in flight per lane
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (float)X[(r + u) * ldx + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; r < r1; ++r) s += (float)X[r * ldx + j];
+    }
     part[(int64_t)blockIdx.x * dp + j] = s;
   }
 }
@@ -74,7 +100,15 @@ __global__ __launch_bounds__(256) void sp_col_finish_kernel(const float* __restr
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= dp) return;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += part[(int64_t)b * dp + j];
+  int b = 0;
+  for (; b + 8 <= blocks; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + u) * dp + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < blocks; ++b) s += part[(int64_t)b * dp + j];
   mu[j] = n > 0 ? s / (float)n : 0.f;
 }
 
@@ -89,13 +123,34 @@ __global__ __launch_bounds__(256) void sp_split_rows_kernel(const float* __restr
   if (row >= n) return;
   const float* __restrict__ x = X + row * ldx;
   float s = 0.f;
-  for (int j = lane; j < dp; j += 64) {
-    const float v = j < d ? (mu ? x[j] - mu[j] : x[j]) : 0.f;
-    const __bf16 h = (__bf16)v;
-    const __bf16 m = (__bf16)(v - (float)h);
-    Xh[row * dp + j] = h;
-    Xm[row * dp + j] = m;
-    s = __builtin_fmaf(v, v, s);
+  typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+  const bool wide = (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0) && (d % 4 == 0);   // (dp % 16 == 0 always)
+  if (wide) {
+    for (int j = 4 * lane; j < dp; j += 256) {
+      km_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (j < d) {
+        v = *(const km_f32x4*)(x + j);
+        if (mu) v -= *(const km_f32x4*)(mu + j);
+      }
+      bf4 h, m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)v[e];
+        m[e] = (__bf16)(v[e] - (float)h[e]);
+        s = __builtin_fmaf(v[e], v[e], s);
+      }
+      *(bf4*)(Xh + row * dp + j) = h;
+      *(bf4*)(Xm + row * dp + j) = m;
+    }
+  } else {
+    for (int j = lane; j < dp; j += 64) {
+      const float v = j < d ? (mu ? x[j] - mu[j] : x[j]) : 0.f;
+      const __bf16 h = (__bf16)v;
+      const __bf16 m = (__bf16)(v - (float)h);
+      Xh[row * dp + j] = h;
+      Xm[row * dp + j] = m;
+      s = __builtin_fmaf(v, v, s);
+    }
   }
   if (xn2) {
 #pragma unroll
@@ -134,18 +189,21 @@ __global__ __launch_bounds__(256) void sp_centers_prep_shifted_kernel(const TC* 
 }
 
 // The kernel.  Same roles as sp_nearest_nt_kernel's template parameters; same outputs.
-template <bool RECHECK, bool PARTIAL>
-__global__ __launch_bounds__(256, 2) void sp_nearest_split_kernel(
+template <bool RECHECK, bool PARTIAL, int WN>
+__global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel(
     const __bf16* __restrict__ Xh, const __bf16* __restrict__ Xm, const float* __restrict__ xn2,
     const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cm, const float* __restrict__ chalf,
     const unsigned* __restrict__ cmax2_bits, int n, int d, int dp, int kp, int64_t* __restrict__ labels,
     int* __restrict__ amb_rows, float* __restrict__ amb_best, int* __restrict__ amb_count,
     unsigned* __restrict__ cand_mask, float* __restrict__ part, int ldp, int per_tiles, int first_point) {
-  __shared__ __attribute__((aligned(16))) char smem[KS_SMEM_BYTES];
-  float* chs = (float*)(smem + 2 * KS_STAGE_BYTES);
+  using K = KsCfg<WN>;
+  constexpr int KS_BN = K::BN, KS_B_BYTES = K::B_BYTES, KS_STAGE_BYTES = K::STAGE_BYTES, KS_SMEM_BYTES = K::SMEM_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // KS_SMEM_BYTES (above 64 KiB for WN = 4)
+  (void)KS_SMEM_BYTES;
+  float* chs = (float*)(smem + K::STAGES * KS_STAGE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;          // wm: center half (128 rows), wn: point half (64 columns)
+  const int wm = wid / WN, wn = wid % WN;         // wm: center half (128 rows), wn: which 64 point columns
   const int l31 = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * KS_BN;              // first point (RECHECK: first list slot) of this workgroup
   int listed = 0;
@@ -154,12 +212,13 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_split_kernel(
     if (listed > n || m0 >= listed) return;       // (n: the capacity of the candidate masks)
   }
 
-  // ---- k-tile pieces: 1 KiB = one wave-wide 16-B load = 32 rows of one image.  Wave `wid` brings pieces 2 wid and
-  // 2 wid + 1 of each center image and piece wid of each point image.
-  unsigned a_off[2];
+  // ---- k-tile pieces: 1 KiB = one wave-wide 16-B load = 32 rows of one image.  Wave `wid` brings pieces
+  // APW wid .. APW wid + APW - 1 of each center image and piece wid of each point image.
+  constexpr int APW = K::APW;
+  unsigned a_off[APW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int slot = (wid * 2 + j) * 64 + lane, row = slot >> 1;
+  for (int j = 0; j < APW; ++j) {
+    const int slot = (wid * APW + j) * 64 + lane, row = slot >> 1;
     a_off[j] = (unsigned)(row * dp * 2 + (((slot & 1) ^ ((row >> 2) & 1)) * 16));
   }
   typename std::conditional<RECHECK, int64_t, unsigned>::type b_off;
@@ -185,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_split_kernel(
   const int steps = nt * tiles_m;
 
   int ld_tr = 0, ld_kt = 0;
-#define KS_LOAD(step)                                                                                  \
+#define KS_LOAD(stage_of)                                                                              \
   do {                                                                                                 \
     const int tr_ = ld_tr, kt_ = ld_kt;                                                                \
     if (++ld_kt == nt) {                                                                               \
@@ -194,10 +253,10 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_split_kernel(
     }                                                                                                  \
     const int tm_ = tm_first + tr_;                                                                    \
     const int64_t ka_ = ((int64_t)tm_ * KS_BM * dp + kt_ * KS_BK) * 2;                                 \
-    const unsigned st_ = s_base + ((step) & 1) * KS_STAGE_BYTES;                                       \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-      SP_GLDS_S((const char*)Ch + ka_, a_off[j], st_ + (wid * 2 + j) * 1024);                          \
-      SP_GLDS_S((const char*)Cm + ka_, a_off[j], st_ + KS_A_BYTES + (wid * 2 + j) * 1024);             \
+    const unsigned st_ = s_base + (unsigned)(stage_of) * KS_STAGE_BYTES;                               \
+    _Pragma("unroll") for (int j = 0; j < APW; ++j) {                                                  \
+      SP_GLDS_S((const char*)Ch + ka_, a_off[j], st_ + (wid * APW + j) * 1024);                        \
+      SP_GLDS_S((const char*)Cm + ka_, a_off[j], st_ + KS_A_BYTES + (wid * APW + j) * 1024);           \
     }                                                                                                  \
     if constexpr (RECHECK) {                                                                           \
       SP_GLDS_V(Xh_blk + kt_ * (KS_BK * 2) + b_off, st_ + 2 * KS_A_BYTES + wid * 1024);                \
@@ -213,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_split_kernel(
   float best[2] = {INFINITY, INFINITY}, second[2] = {INFINITY, INFINITY};
   int bpos[2] = {0, 0}, bblk[2] = {0, 0};
 
+  int cur = 0, nxt = 1;
   KS_LOAD(0);
   SP_GLDS_LANDED();
   __syncthreads();
@@ -224,19 +284,30 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_split_kernel(
   int t = 0;
   auto kstep = [&](auto first_of_block) {
     constexpr bool FIRST = decltype(first_of_block)::value;
-    if (t + 1 < steps) KS_LOAD(t + 1);
-    const char* st = smem + (t & 1) * KS_STAGE_BYTES;
+    if (!(KS_ABLATE & 1) && t + 1 < steps) KS_LOAD(nxt);
+    const char* st = smem + cur * KS_STAGE_BYTES;
     km_bf16x8 ah[4], am[4], bh[2], bm[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (KS_ABLATE & 2) {
+        ah[i] = am[i] = *(const km_bf16x8*)(smem + a_frag);
+        asm volatile("" : "+v"(ah[i]), "+v"(am[i]));
+        continue;
+      }
       ah[i] = *(const km_bf16x8*)(st + a_frag + i * 1024);
       am[i] = *(const km_bf16x8*)(st + KS_A_BYTES + a_frag + i * 1024);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      if (KS_ABLATE & 2) {
+        bh[j] = bm[j] = *(const km_bf16x8*)(smem + b_frag);
+        asm volatile("" : "+v"(bh[j]), "+v"(bm[j]));
+        continue;
+      }
       bh[j] = *(const km_bf16x8*)(st + b_frag + j * 1024);
       bm[j] = *(const km_bf16x8*)(st + KS_B_BYTES + b_frag + j * 1024);
     }
+    if (!(KS_ABLATE & 8)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -256,9 +327,17 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_split_kernel(
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]) : "v"(ah[i]), "v"(am[i]), "v"(bh[j]), "v"(bm[j]));
+    }
     if (t + 1 < steps) SP_GLDS_LANDED();
     __syncthreads();
     ++t;
+    cur ^= 1;
+    nxt ^= 1;
   };
 
   const float cmax2 = __uint_as_float(*cmax2_bits);
@@ -305,9 +384,9 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_split_kernel(
     }
     const float before[2] = {best[0], best[1]};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < ((KS_ABLATE & 4) ? 1 : 4); ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < ((KS_ABLATE & 4) ? 1 : 4); ++q) {
         const km_f32x4 ch4 = *(const km_f32x4*)(chb + i * 32 + 8 * q);   // rows i*32 + 8q + 4lh + (0..3)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -409,10 +488,36 @@ static int km_split_points(const float* X, int64_t ldx, int64_t n, int64_t d, co
   return 0;
 }
 
-// First pass of the split tier: centers prepared as for the fp32 tier (Cf, |c|^2/2, max |c|^2) and cut into their two
-// images, then the whole rounds, the split last round and its merge -- the launch plan of sp_nearest_fused_launch.
-static int sp_nearest_split_launch(const void* C, int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
-                                   int64_t* labels, const KmWorkspace& w, hipStream_t st) {
+// First pass of the split tier: centers shifted, prepared as for the fp32 tier (Cf, |c|^2/2, max |c|^2) and cut into
+// their two images, then the whole rounds, the split last round and its merge -- the launch plan of
+// sp_nearest_fused_launch for this kernel's geometry.
+template <bool RECHECK, bool PARTIAL, int WN, typename... Args>
+static int km_split_go(dim3 grid, hipStream_t st, Args... args) {
+  using K = KsCfg<WN>;
+  auto kern = sp_nearest_split_kernel<RECHECK, PARTIAL, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, K::SMEM_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(K::THREADS), K::SMEM_BYTES, st, args...);
+  SP_CHECK_LAUNCH();
+  return 0;
+}
+
+static int km_split_wn() {
+  static int wn = -1;
+  if (wn < 0) {
+    const char* e = getenv("SP_KM_SPLIT_WN");
+    wn = e && atoi(e) == 4 ? 4 : 2;     // (measured equal at configs[3]: 2.53 / 2.54 ms)
+  }
+  return wn;
+}
+
+template <int WN>
+static int sp_nearest_split_launch_wn(const void* C, int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
+                                      int64_t* labels, const KmWorkspace& w, hipStream_t st) {
+  using K = KsCfg<WN>;
   const int64_t kp = w.kp, dp = w.dp;
   if (dp * 2 * (int64_t)KS_BM > (1LL << 31) / 2) SP_FAIL("sp_nearest_center: too many features for the split tier");
   SP_HIP(hipMemsetAsync(w.Cf, 0, km_align((size_t)dp * kp * 4), st));
@@ -427,44 +532,60 @@ static int sp_nearest_split_launch(const void* C, int32_t cdtype, int64_t ldc, i
   hipLaunchKernelGGL(sp_split_rows_kernel, dim3(pblocks), dim3(256), 0, st, (const float*)w.Cf, dp, kp, (int)dp, (int)dp,
                      (const float*)nullptr, w.Ch, w.Cm, (float*)nullptr);
   SP_CHECK_LAUNCH();
-  const int64_t blocks = (n + KS_BN - 1) / KS_BN, tiles = kp / KS_BM;
-  int64_t rem = blocks % KM_WG_SLOTS, split = 1, per = tiles;
+  const int64_t blocks = (n + K::BN - 1) / K::BN, tiles = kp / KS_BM;
+  int64_t rem = blocks % K::SLOTS, split = 1, per = tiles;
   static const bool tail_off = getenv("SP_KM_TAIL_SPLIT") && atoi(getenv("SP_KM_TAIL_SPLIT")) == 0;
   if (rem > 0 && tiles > 1 && !tail_off) {
     split = tiles < KM_TAIL_SPLIT ? tiles : KM_TAIL_SPLIT;
     per = (tiles + split - 1) / split;
     split = (tiles + per - 1) / per;
-    const int64_t rounds = (rem * split + KM_WG_SLOTS - 1) / KM_WG_SLOTS;
+    const int64_t rounds = (rem * split + K::SLOTS - 1) / K::SLOTS;
     if (rounds * per >= tiles) split = 1;     // no shorter than the plain round
   }
   if (split == 1) rem = 0;
-  const int64_t whole = blocks - rem, n_whole = whole * KS_BN < n ? whole * KS_BN : n;
-  if (whole > 0)
-    hipLaunchKernelGGL((sp_nearest_split_kernel<false, false>), dim3((unsigned)whole), dim3(256), 0, st, w.Xh, w.Xm, w.xn2,
-                       w.Ch, w.Cm, w.cn, w.cmax2, (int)n_whole, (int)d, (int)dp, (int)kp, labels, w.amb_rows, w.amb_best,
-                       w.amb_count, (unsigned*)nullptr, (float*)nullptr, 0, 0, 0);
+  const int64_t whole = blocks - rem, n_whole = whole * K::BN < n ? whole * K::BN : n;
+  if (whole > 0 &&
+      km_split_go<false, false, WN>(dim3((unsigned)whole), st, (const __bf16*)w.Xh, (const __bf16*)w.Xm, (const float*)w.xn2,
+                                    (const __bf16*)w.Ch, (const __bf16*)w.Cm, (const float*)w.cn, (const unsigned*)w.cmax2,
+                                    (int)n_whole, (int)d, (int)dp, (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count,
+                                    (unsigned*)nullptr, (float*)nullptr, 0, 0, 0))
+    return 1;
   if (rem > 0) {
     const int n_tail = (int)(n - n_whole);
-    hipLaunchKernelGGL((sp_nearest_split_kernel<false, true>), dim3((unsigned)rem, (unsigned)split), dim3(256), 0, st,
-                       w.Xh + n_whole * dp, w.Xm + n_whole * dp, w.xn2 + n_whole, w.Ch, w.Cm, w.cn, w.cmax2, n_tail, (int)d,
-                       (int)dp, (int)kp, (int64_t*)nullptr, (int*)nullptr, (float*)nullptr, (int*)nullptr,
-                       (unsigned*)nullptr, w.part, KM_TAIL_POINTS, (int)per, 0);
+    if (km_split_go<false, true, WN>(dim3((unsigned)rem, (unsigned)split), st, (const __bf16*)(w.Xh + n_whole * dp),
+                                     (const __bf16*)(w.Xm + n_whole * dp), (const float*)(w.xn2 + n_whole),
+                                     (const __bf16*)w.Ch, (const __bf16*)w.Cm, (const float*)w.cn,
+                                     (const unsigned*)w.cmax2, n_tail, (int)d, (int)dp, (int)kp, (int64_t*)nullptr,
+                                     (int*)nullptr, (float*)nullptr, (int*)nullptr, (unsigned*)nullptr, w.part,
+                                     KM_TAIL_POINTS, (int)per, 0))
+      return 1;
     hipLaunchKernelGGL(sp_nearest_merge_parts_kernel, dim3((unsigned)((n_tail + 255) / 256)), dim3(256), 0, st, w.part,
                        (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, 6.1f * (float)d + 1550.0f, w.cmax2, labels,
                        w.amb_rows, w.amb_best, w.amb_count);
+    SP_CHECK_LAUNCH();
   }
-  SP_CHECK_LAUNCH();
   return 0;
 }
 
+static int sp_nearest_split_launch(const void* C, int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
+                                   int64_t* labels, const KmWorkspace& w, hipStream_t st) {
+  return km_split_wn() == 2 ? sp_nearest_split_launch_wn<2>(C, cdtype, ldc, n, k, d, labels, w, st)
+                            : sp_nearest_split_launch_wn<4>(C, cdtype, ldc, n, k, d, labels, w, st);
+}
+
 // Second pass over the listed points: marks the centers inside each point's error window.
+template <int WN>
+static int sp_nearest_split_mark_wn(int64_t d, const KmWorkspace& w, hipStream_t st) {
+  using K = KsCfg<WN>;
+  const dim3 grid((unsigned)((w.cand_cap + K::BN - 1) / K::BN), (unsigned)(w.kp / KS_BM));
+  return km_split_go<true, false, WN>(grid, st, (const __bf16*)w.Xh, (const __bf16*)w.Xm, (const float*)w.xn2,
+                                      (const __bf16*)w.Ch, (const __bf16*)w.Cm, (const float*)w.cn,
+                                      (const unsigned*)w.cmax2, (int)w.cand_cap, (int)d, (int)w.dp, (int)w.kp,
+                                      (int64_t*)nullptr, w.amb_rows, w.amb_best, w.amb_count, w.cand_mask, (float*)nullptr,
+                                      0, 0, 0);
+}
 static int sp_nearest_split_mark_candidates(int64_t d, const KmWorkspace& w, hipStream_t st) {
-  const dim3 grid((unsigned)((w.cand_cap + KS_BN - 1) / KS_BN), (unsigned)(w.kp / KS_BM));
-  hipLaunchKernelGGL((sp_nearest_split_kernel<true, false>), grid, dim3(256), 0, st, w.Xh, w.Xm, w.xn2, w.Ch, w.Cm, w.cn,
-                     w.cmax2, (int)w.cand_cap, (int)d, (int)w.dp, (int)w.kp, (int64_t*)nullptr, w.amb_rows, w.amb_best,
-                     w.amb_count, w.cand_mask, (float*)nullptr, 0, 0, 0);
-  SP_CHECK_LAUNCH();
-  return 0;
+  return km_split_wn() == 2 ? sp_nearest_split_mark_wn<2>(d, w, st) : sp_nearest_split_mark_wn<4>(d, w, st);
 }
 
 }  // namespace

@@ -1,7 +1,7 @@
 cd /root/repo/tools
-for s in 2 3 4 5; do timeout 900 python fuzz_kmeans.py $s 2>&1 | tail -3; done
+timeout 900 python fuzz_kmeans.py 11 2>&1 | tail -3
 cd /root/repo
-timeout 300 python bench.py --only kmeans 2>/dev/null | python -c "
+for wn in 4 2; do SP_KM_SPLIT_WN=$wn timeout 300 python bench.py --only kmeans 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
   if l.startswith('{'):
@@ -12,5 +12,5 @@ for l in sys.stdin:
         for v in o.values():
           r=find(v)
           if r: return r
-    h=find(d); print(json.dumps({k:v for k,v in h.items() if 'assign' in k or 'iteration_ms' in k}))
-"
+    h=find(d); print($wn, json.dumps({k:v for k,v in h.items() if k in ('assign_ms','assign_standalone_ms','assign_rechecked_points','iteration_ms')}))
+"; done
