@@ -481,7 +481,7 @@ static inline int64_t km_round_up(int64_t v, int64_t m) { return (v + m - 1) / m
 
 // scratch layout of sp_nearest_center (all 256-B aligned)
 struct KmWorkspace {
-  int64_t kp, dp;
+  int64_t kp, dp, n_points;
   double* Ct64;      // [d][kp]   fp64 transposed centers (exact kernel)
   float* Cf;         // [kp][dp]  fp32 row-major centers (sp_nearest_nt_kernel)
   float* cn;         // [kp]      |c|^2
@@ -556,6 +556,7 @@ static void km_carve_points(void* at, int64_t n, int64_t d, KmWorkspace* w) {
 
 static KmWorkspace km_carve(void* ws, int64_t n, int64_t k, int64_t d) {
   KmWorkspace w;
+  w.n_points = n;
   w.kp = km_round_up(k, KM_BN_MAX);
   w.dp = km_padded_features(d);
   char* p = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);

@@ -34,11 +34,13 @@
 // vector is a valid shift.  The exact stage reads the caller's x and c.
 //
 // Operand images: the points are cut once per call -- or once per fit: sp_kmeans_points_prepare -- into two bf16
-// arrays [n][dp] (dp = features padded to 16, zeros beyond d) plus |x|^2 per point; the centers once per call.  A
-// k-tile is 16 features = 32 bytes per row and image; the LDS images are [row][2 chunks of 16 B], chunk q of row r
-// in slot q ^ ((r >> 2) & 1) (conflict-free 16-B fragment reads), filled by global_load_lds_dwordx4 like the fp32
-// kernel's.  A lane's fragment is 8 consecutive features of one row for both operands, so whatever order the
-// instruction gives the 16 features of its K dimension, A and B agree on it.
+// arrays (features padded to 16, zeros beyond d) plus |x - mu|^2 per point; the centers once per call.  An image is
+// stored k-tile-major, [dp / 16][rows][16] (see sp_split_rows_kernel: with row-major images every 128-byte line of a
+// point was fetched by four different k-steps -- 2.48 -> 1.97 ms at configs[3] for the layout alone).  A k-tile is 16
+// features = 32 bytes per row and image; the LDS images are [row][2 chunks of 16 B], chunk q of row r in slot
+// q ^ ((r >> 2) & 1) (conflict-free 16-B fragment reads), filled by global_load_lds_dwordx4 like the fp32 kernel's, the
+// pieces of a request spread over the MFMAs of the k-step before.  A lane's fragment is 8 consecutive features of one
+// row for both operands, so whatever order the instruction gives the 16 features of its K dimension, A and B agree.
 #pragma once
 
 typedef __bf16 km_bf16x8 __attribute__((ext_vector_type(8)));
@@ -53,7 +55,8 @@ namespace {
 // k-tile bytes per MFMA) measures the same (SP_KM_SPLIT_WN=4).  Timed with parts removed at configs[3] (2.42 ms):
 // without the k-tile loads 1.47, without the fragment reads 2.32, without the epilogue 2.01, without the MFMAs 2.00,
 // without all of them 0.57 -- the MFMAs themselves are a third of the time; neither fewer bytes (WN = 4) nor requests
-// two k-steps ahead (three LDS stages) shortened it.
+// two k-steps ahead (three LDS stages) shortened it, the order of issue inside a k-step 2 %, the k-tile-major layout
+// of the images 20 % (the loads were waiting for lines the L2 had dropped, not for bytes or issue slots).
 constexpr int KS_BK = 16;
 constexpr int KS_BM = KN_BM;
 constexpr int KS_A_BYTES = KS_BM * KS_BK * 2;                  // 8 KiB per image
@@ -114,6 +117,11 @@ __global__ __launch_bounds__(256) void sp_col_finish_kernel(const float* __restr
 
 // hi / mid images of the fp32 rows MINUS the shift `mu` (NULL: none): one wavefront per row, zeros beyond d;
 // optionally the squared norm of the shifted row (fp32 sum, any order: the bound takes it with slack)
+// Layout of an image: [dp / 16 k-tiles][n rows][16 features] -- the 16 features x 128 rows a workgroup brings per
+// k-step are ONE contiguous 4 KiB block (row-major [n][dp] images made it 32 bytes out of every row's 512: each
+// 128-byte line was fetched by four different k-steps, and between them the L2 of an XCD, 64 workgroups' worth of
+// such lines plus the centers, had usually dropped it).
+__device__ __forceinline__ int64_t ks_at(int64_t row, int j, int64_t n) { return ((int64_t)(j >> 4) * n + row) * 16 + (j & 15); }
 __global__ __launch_bounds__(256) void sp_split_rows_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int d,
                                                             int dp, const float* __restrict__ mu,
                                                             __bf16* __restrict__ Xh, __bf16* __restrict__ Xm,
@@ -139,16 +147,16 @@ __global__ __launch_bounds__(256) void sp_split_rows_kernel(const float* __restr
         m[e] = (__bf16)(v[e] - (float)h[e]);
         s = __builtin_fmaf(v[e], v[e], s);
       }
-      *(bf4*)(Xh + row * dp + j) = h;
-      *(bf4*)(Xm + row * dp + j) = m;
+      *(bf4*)(Xh + ks_at(row, j, n)) = h;
+      *(bf4*)(Xm + ks_at(row, j, n)) = m;
     }
   } else {
     for (int j = lane; j < dp; j += 64) {
       const float v = j < d ? (mu ? x[j] - mu[j] : x[j]) : 0.f;
       const __bf16 h = (__bf16)v;
       const __bf16 m = (__bf16)(v - (float)h);
-      Xh[row * dp + j] = h;
-      Xm[row * dp + j] = m;
+      Xh[ks_at(row, j, n)] = h;
+      Xm[ks_at(row, j, n)] = m;
       s = __builtin_fmaf(v, v, s);
     }
   }
@@ -195,7 +203,8 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
     const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cm, const float* __restrict__ chalf,
     const unsigned* __restrict__ cmax2_bits, int n, int d, int dp, int kp, int64_t* __restrict__ labels,
     int* __restrict__ amb_rows, float* __restrict__ amb_best, int* __restrict__ amb_count,
-    unsigned* __restrict__ cand_mask, float* __restrict__ part, int ldp, int per_tiles, int first_point) {
+    unsigned* __restrict__ cand_mask, float* __restrict__ part, int ldp, int per_tiles, int first_point,
+    int n_total) {
   using K = KsCfg<WN>;
   constexpr int KS_BN = K::BN, KS_B_BYTES = K::B_BYTES, KS_STAGE_BYTES = K::STAGE_BYTES, KS_SMEM_BYTES = K::SMEM_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];      // KS_SMEM_BYTES (above 64 KiB for WN = 4)
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
     const int slot = (wid * APW + j) * 64 + lane, row = slot >> 1;
-    a_off[j] = (unsigned)(row * dp * 2 + (((slot & 1) ^ ((row >> 2) & 1)) * 16));
+    a_off[j] = (unsigned)(row * 32 + (((slot & 1) ^ ((row >> 2) & 1)) * 16));     // (bytes inside a k-tile slab)
   }
   typename std::conditional<RECHECK, int64_t, unsigned>::type b_off;
   {
@@ -228,14 +237,16 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
     const int chunk = (slot & 1) ^ ((row >> 2) & 1);
     if constexpr (RECHECK) {
       const int listed_row = m0 + row < listed ? m0 + row : listed - 1;   // tail: repeat the last listed point
-      b_off = ((int64_t)amb_rows[listed_row] * dp) * 2 + chunk * 16;
+      b_off = (int64_t)amb_rows[listed_row] * 32 + chunk * 16;
     } else {
       if (m0 + row > n - 1) row = n - 1 - m0;     // clamp: results of points >= n are discarded
-      b_off = (unsigned)(row * dp * 2 + chunk * 16);
+      b_off = (unsigned)(row * 32 + chunk * 16);
     }
   }
-  const char* __restrict__ Xh_blk = (const char*)(RECHECK ? Xh : Xh + (int64_t)m0 * dp);
-  const char* __restrict__ Xm_blk = (const char*)(RECHECK ? Xm : Xm + (int64_t)m0 * dp);
+  // (PARTIAL launches pass the whole images and where their points start: first_point)
+  const char* __restrict__ Xh_blk = (const char*)(RECHECK ? Xh : Xh + (int64_t)(first_point + m0) * 16);
+  const char* __restrict__ Xm_blk = (const char*)(RECHECK ? Xm : Xm + (int64_t)(first_point + m0) * 16);
+  const int64_t x_slab = (int64_t)n_total * 32, c_slab = (int64_t)kp * 32;       // bytes per k-tile of an image
   const unsigned s_base = SP_LDS_ADDR(smem);
   const unsigned chs_w = SP_LDS_ADDR(chs);
   const int nt = dp / KS_BK;
@@ -243,29 +254,36 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
   const int tiles_m = RECHECK ? 1 : PARTIAL ? min(per_tiles, kp / KS_BM - tm_first) : kp / KS_BM;
   const int steps = nt * tiles_m;
 
+  // The request for a k-tile is 2 APW center pieces + 2 point pieces (+ the |c|^2/2 slice at the first k-tile of a
+  // block, wave 0).  KS_LOAD_BEGIN fixes which k-tile and where; KS_PIECE(i) issues piece i -- the k-step spreads them
+  // over its MFMAs (each is an M0 write and a ~100-cycle issue the matrix pipe works through; issued in one run
+  // ahead of the fragment reads, as the fp32 kernel does, they were a third of this kernel's time).
   int ld_tr = 0, ld_kt = 0;
-#define KS_LOAD(stage_of)                                                                              \
+  constexpr int NPIECES = 2 * APW + 3;
+#define KS_LOAD_BEGIN(stage_of)                                                                        \
+  const int tr_ = ld_tr, kt_ = ld_kt;                                                                  \
+  if (++ld_kt == nt) {                                                                                 \
+    ld_kt = 0;                                                                                         \
+    ++ld_tr;                                                                                           \
+  }                                                                                                    \
+  const int tm_ = tm_first + tr_;                                                                      \
+  const int64_t ka_ = kt_ * c_slab + (int64_t)tm_ * (KS_BM * 32);                                      \
+  const unsigned st_ = s_base + (unsigned)(stage_of) * KS_STAGE_BYTES;
+#define KS_PIECE(i)                                                                                    \
   do {                                                                                                 \
-    const int tr_ = ld_tr, kt_ = ld_kt;                                                                \
-    if (++ld_kt == nt) {                                                                               \
-      ld_kt = 0;                                                                                       \
-      ++ld_tr;                                                                                         \
+    if ((i) < 2 * APW) {                                                                               \
+      const int j_ = (i) >> 1;                                                                         \
+      if (((i) & 1) == 0) SP_GLDS_S((const char*)Ch + ka_, a_off[j_], st_ + (wid * APW + j_) * 1024);  \
+      else SP_GLDS_S((const char*)Cm + ka_, a_off[j_], st_ + KS_A_BYTES + (wid * APW + j_) * 1024);    \
+    } else if ((i) == 2 * APW) {                                                                       \
+      if constexpr (RECHECK) SP_GLDS_V(Xh_blk + kt_ * x_slab + b_off, st_ + 2 * KS_A_BYTES + wid * 1024); \
+      else SP_GLDS_S(Xh_blk + kt_ * x_slab, b_off, st_ + 2 * KS_A_BYTES + wid * 1024);            \
+    } else if ((i) == 2 * APW + 1) {                                                                   \
+      if constexpr (RECHECK) SP_GLDS_V(Xm_blk + kt_ * x_slab + b_off, st_ + 2 * KS_A_BYTES + KS_B_BYTES + wid * 1024); \
+      else SP_GLDS_S(Xm_blk + kt_ * x_slab, b_off, st_ + 2 * KS_A_BYTES + KS_B_BYTES + wid * 1024); \
+    } else if (kt_ == 0 && wid == 0) {                                                                 \
+      SP_GLDS_S(chalf + tm_ * KS_BM, (unsigned)lane * 16u, chs_w + (tr_ & 1) * (KS_BM * 4));           \
     }                                                                                                  \
-    const int tm_ = tm_first + tr_;                                                                    \
-    const int64_t ka_ = ((int64_t)tm_ * KS_BM * dp + kt_ * KS_BK) * 2;                                 \
-    const unsigned st_ = s_base + (unsigned)(stage_of) * KS_STAGE_BYTES;                               \
-    _Pragma("unroll") for (int j = 0; j < APW; ++j) {                                                  \
-      SP_GLDS_S((const char*)Ch + ka_, a_off[j], st_ + (wid * APW + j) * 1024);                        \
-      SP_GLDS_S((const char*)Cm + ka_, a_off[j], st_ + KS_A_BYTES + (wid * APW + j) * 1024);           \
-    }                                                                                                  \
-    if constexpr (RECHECK) {                                                                           \
-      SP_GLDS_V(Xh_blk + kt_ * (KS_BK * 2) + b_off, st_ + 2 * KS_A_BYTES + wid * 1024);                \
-      SP_GLDS_V(Xm_blk + kt_ * (KS_BK * 2) + b_off, st_ + 2 * KS_A_BYTES + KS_B_BYTES + wid * 1024);   \
-    } else {                                                                                           \
-      SP_GLDS_S(Xh_blk + kt_ * (KS_BK * 2), b_off, st_ + 2 * KS_A_BYTES + wid * 1024);                 \
-      SP_GLDS_S(Xm_blk + kt_ * (KS_BK * 2), b_off, st_ + 2 * KS_A_BYTES + KS_B_BYTES + wid * 1024);    \
-    }                                                                                                  \
-    if (kt_ == 0 && wid == 0) SP_GLDS_S(chalf + tm_ * KS_BM, (unsigned)lane * 16u, chs_w + (tr_ & 1) * (KS_BM * 4)); \
   } while (0)
 
   km_f32x16 acc[4][2];
@@ -273,7 +291,11 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
   int bpos[2] = {0, 0}, bblk[2] = {0, 0};
 
   int cur = 0, nxt = 1;
-  KS_LOAD(0);
+  {
+    KS_LOAD_BEGIN(0)
+#pragma unroll
+    for (int i = 0; i < NPIECES; ++i) KS_PIECE(i);
+  }
   SP_GLDS_LANDED();
   __syncthreads();
   // fragments: row (wave tile row + l31 [+ 32 i]), 16-B chunk lh ^ ((row >> 2) & 1) -- the same xor for both operands
@@ -284,7 +306,8 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
   int t = 0;
   auto kstep = [&](auto first_of_block) {
     constexpr bool FIRST = decltype(first_of_block)::value;
-    if (!(KS_ABLATE & 1) && t + 1 < steps) KS_LOAD(nxt);
+    const bool more = !(KS_ABLATE & 1) && t + 1 < steps;
+    KS_LOAD_BEGIN(nxt)
     const char* st = smem + cur * KS_STAGE_BYTES;
     km_bf16x8 ah[4], am[4], bh[2], bm[2];
 #pragma unroll
@@ -307,33 +330,33 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
       bh[j] = *(const km_bf16x8*)(st + b_frag + j * 1024);
       bm[j] = *(const km_bf16x8*)(st + KS_B_BYTES + b_frag + j * 1024);
     }
-    if (!(KS_ABLATE & 8)) {
+    // 24 MFMAs (mid x hi, hi x mid, hi x hi for the 4 x 2 tiles of the wave), a piece of the next k-tile's request
+    // after every third
+    int piece = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if constexpr (FIRST) {
+    for (int idx = 0; idx < 24; ++idx) {
+      const int term = idx >> 3, i = (idx & 7) >> 1, j = idx & 1;
+      if (!(KS_ABLATE & 8)) {
+        const km_bf16x8 a = term == 0 ? am[i] : ah[i];
+        const km_bf16x8 b = term == 1 ? bm[j] : bh[j];
+        if (FIRST && term == 0) {
           const km_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], zero, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, zero, 0, 0, 0);
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
         }
+      } else {
+        asm volatile("" : "+v"(acc[i][j]) : "v"(ah[i]), "v"(am[i]), "v"(bh[j]), "v"(bm[j]));
       }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]) : "v"(ah[i]), "v"(am[i]), "v"(bh[j]), "v"(bm[j]));
+      if (idx % 3 == 2 && piece < NPIECES) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) KS_PIECE(piece);
+        __builtin_amdgcn_sched_barrier(0);
+        ++piece;
+      }
     }
-    if (t + 1 < steps) SP_GLDS_LANDED();
+    static_assert(NPIECES <= 8, "one piece after every third of the 24 MFMAs");
+    if (more) SP_GLDS_LANDED();
     __syncthreads();
     ++t;
     cur ^= 1;
@@ -402,7 +425,8 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
 #pragma unroll
     for (int j = 0; j < 2; ++j) bblk[j] = best[j] < before[j] ? tm : bblk[j];
   }
-#undef KS_LOAD
+#undef KS_LOAD_BEGIN
+#undef KS_PIECE
 
   // ---- merge: the two lane halves of a column (rows differ by 4), then the two center waves (LDS)
   float* mb_s = (float*)smem;         // [128]   (the stages are dead: every wave passed the last barrier)
@@ -458,9 +482,9 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
           part[at] = b;
           part[at + ldp] = s;
           ((int*)part)[at + 2 * (int64_t)ldp] = ix;
-          if (blockIdx.y == 0) part[(int64_t)gridDim.y * 3 * ldp + m0 + col] = xn2[m0 + col];
+          if (blockIdx.y == 0) part[(int64_t)gridDim.y * 3 * ldp + m0 + col] = xn2[first_point + m0 + col];
         } else {
-          km_decide(b, s, ix, xn2[m0 + col], first_point + m0 + col, ef, cmax, cmax2, labels, amb_rows, amb_best,
+          km_decide(b, s, ix, xn2[first_point + m0 + col], first_point + m0 + col, ef, cmax, cmax2, labels, amb_rows, amb_best,
                     amb_count);
         }
       }
@@ -519,7 +543,6 @@ static int sp_nearest_split_launch_wn(const void* C, int32_t cdtype, int64_t ldc
                                       int64_t* labels, const KmWorkspace& w, hipStream_t st) {
   using K = KsCfg<WN>;
   const int64_t kp = w.kp, dp = w.dp;
-  if (dp * 2 * (int64_t)KS_BM > (1LL << 31) / 2) SP_FAIL("sp_nearest_center: too many features for the split tier");
   SP_HIP(hipMemsetAsync(w.Cf, 0, km_align((size_t)dp * kp * 4), st));
   SP_HIP(hipMemsetAsync(w.cmax2, 0, 512, st));   // cmax2 and amb_count
   const unsigned pblocks = (unsigned)((kp + 3) / 4);   // one wavefront per center
@@ -548,16 +571,16 @@ static int sp_nearest_split_launch_wn(const void* C, int32_t cdtype, int64_t ldc
       km_split_go<false, false, WN>(dim3((unsigned)whole), st, (const __bf16*)w.Xh, (const __bf16*)w.Xm, (const float*)w.xn2,
                                     (const __bf16*)w.Ch, (const __bf16*)w.Cm, (const float*)w.cn, (const unsigned*)w.cmax2,
                                     (int)n_whole, (int)d, (int)dp, (int)kp, labels, w.amb_rows, w.amb_best, w.amb_count,
-                                    (unsigned*)nullptr, (float*)nullptr, 0, 0, 0))
+                                    (unsigned*)nullptr, (float*)nullptr, 0, 0, 0, (int)n))
     return 1;
   if (rem > 0) {
     const int n_tail = (int)(n - n_whole);
-    if (km_split_go<false, true, WN>(dim3((unsigned)rem, (unsigned)split), st, (const __bf16*)(w.Xh + n_whole * dp),
-                                     (const __bf16*)(w.Xm + n_whole * dp), (const float*)(w.xn2 + n_whole),
+    if (km_split_go<false, true, WN>(dim3((unsigned)rem, (unsigned)split), st, (const __bf16*)w.Xh,
+                                     (const __bf16*)w.Xm, (const float*)w.xn2,
                                      (const __bf16*)w.Ch, (const __bf16*)w.Cm, (const float*)w.cn,
                                      (const unsigned*)w.cmax2, n_tail, (int)d, (int)dp, (int)kp, (int64_t*)nullptr,
                                      (int*)nullptr, (float*)nullptr, (int*)nullptr, (unsigned*)nullptr, w.part,
-                                     KM_TAIL_POINTS, (int)per, 0))
+                                     KM_TAIL_POINTS, (int)per, (int)n_whole, (int)n))
       return 1;
     hipLaunchKernelGGL(sp_nearest_merge_parts_kernel, dim3((unsigned)((n_tail + 255) / 256)), dim3(256), 0, st, w.part,
                        (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, 6.1f * (float)d + 1550.0f, w.cmax2, labels,
@@ -582,7 +605,7 @@ static int sp_nearest_split_mark_wn(int64_t d, const KmWorkspace& w, hipStream_t
                                       (const __bf16*)w.Ch, (const __bf16*)w.Cm, (const float*)w.cn,
                                       (const unsigned*)w.cmax2, (int)w.cand_cap, (int)d, (int)w.dp, (int)w.kp,
                                       (int64_t*)nullptr, w.amb_rows, w.amb_best, w.amb_count, w.cand_mask, (float*)nullptr,
-                                      0, 0, 0);
+                                      0, 0, 0, (int)w.n_points);
 }
 static int sp_nearest_split_mark_candidates(int64_t d, const KmWorkspace& w, hipStream_t st) {
   return km_split_wn() == 2 ? sp_nearest_split_mark_wn<2>(d, w, st) : sp_nearest_split_mark_wn<4>(d, w, st);

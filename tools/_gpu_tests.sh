@@ -1,7 +1,7 @@
 cd /root/repo/tools
 timeout 900 python fuzz_kmeans.py 11 2>&1 | tail -3
 cd /root/repo
-for wn in 4 2; do SP_KM_SPLIT_WN=$wn timeout 300 python bench.py --only kmeans 2>/dev/null | python -c "
+for wn in 2 4; do SP_KM_SPLIT_WN=$wn timeout 300 python bench.py --only kmeans 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
   if l.startswith('{'):
