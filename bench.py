@@ -285,7 +285,7 @@ def kmeans_section(ctx):
   # made once: `prepared`) and as one stand-alone call (which cuts the points first).
   prepared = kernels.prepare_points(x)
   ms = event_time(lambda: kernels.nearest_center(x, cdev, labels, prepared=prepared), 20, warmup=3,
-                  section=('k-means assign (first pass, bf16-split MFMA)', 'sp_nearest_split_kernel<false, false>', 3.0 * flop, 'flop', 'mfma_bf16'))
+                  section=('k-means assign (first pass, bf16-split MFMA)', 'sp_nearest_split_kernel<false, false,', 3.0 * flop, 'flop', 'mfma_bf16'))
   out['assign_ms'] = round(ms, 3)
   out['assign_TFLOPs'] = round(flop / ms / 1e9, 1)                      # useful fp32 flops per second
   # (above 1: the contraction does not run on the fp32 matrix pipe this peak belongs to)
