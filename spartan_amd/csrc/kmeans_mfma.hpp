@@ -91,7 +91,11 @@ __device__ __forceinline__ void km_decide(float b, float s, int ix, float xn, in
   const float u = 5.9604645e-8f;                     // 2^-24
   const float xnorm = sqrtf(xn) * 1.001f;            // fp32 sum of squares: generous slack
   const float E = u * (ef * xnorm * cmax + 2.0f * cmax2);
-  const bool sure = 2.0f * (s - b) > 4.0f * E;       // (scores are halved) false for NaN / inf-inf as well
+  // (magnitudes at which products, the bound itself or the bf16 halves of the split tier leave the normal range: no
+  //  verdict from the filter, the exact stage decides)
+  const float pn = xnorm * cmax;
+  const bool underflows = pn > 0.f && pn < 1e-28f;
+  const bool sure = !underflows && 2.0f * (s - b) > 4.0f * E;       // (scores are halved) false for NaN / inf-inf as well
   labels[point] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
   if (!sure) {   // (order-free: each listed point is re-done on its own)
     const int pos = atomicAdd(amb_count, 1);

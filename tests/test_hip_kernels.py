@@ -702,7 +702,7 @@ def test_nearest_center_split_tail(n, k, d, tier):
   np.testing.assert_array_equal(fused, _nearest(x, c, _hip.NEAREST_EXACT))
 
 
-@pytest.mark.parametrize('case', ['wide_range', 'signed', 'tiny', 'huge', 'clustered'])
+@pytest.mark.parametrize('case', ['wide_range', 'signed', 'tiny', 'denormal', 'huge', 'clustered'])
 def test_nearest_center_bf16_split_on_hard_data(case):
   """The split tier's error window must hold whatever the data look like: values spread over 12 orders of
   magnitude inside a row (the bf16 cut is relative to each VALUE, the bound to the row norms), both signs, tiny
@@ -719,6 +719,8 @@ def test_nearest_center_bf16_split_on_hard_data(case):
     x, c = x - 0.5, c - 0.5
   elif case == 'tiny':
     x, c = x * 1e-18, c * 1e-18
+  elif case == 'denormal':               # (below fp32's / bf16's normal range: the filter must not decide anything)
+    x, c = x * 1e-38, c * 1e-38
   elif case == 'huge':
     x, c = x * 1e15, c * 1e15
   else:
@@ -730,7 +732,7 @@ def test_nearest_center_bf16_split_on_hard_data(case):
   differ = np.nonzero(got != want)[0]
   assert all(dd[i, got[i]] == dd[i, want[i]] for i in differ), differ[:5]     # (exactly equal distances: either index)
   listed = int((_nearest(x, c, _hip.NEAREST_SPLIT_UNCHECKED) < 0).sum())
-  assert listed < n or case == 'clustered'
+  assert listed < n or case in ('clustered', 'tiny', 'denormal')   # (below 1e-28 in |x||c| the filter leaves every point to the exact stage)
 
 
 def test_nearest_center_prepared_points_are_the_same_call():
