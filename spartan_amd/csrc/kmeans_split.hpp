@@ -45,7 +45,8 @@
 
 typedef __bf16 km_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KS_ABLATE
-#define KS_ABLATE 0     // timing-only builds (-DKS_ABLATE=n, tools/km_first.py): 1 no k-tile loads, 2 no fragment reads, 4 no epilogue, 8 no MFMAs
+#define KS_ABLATE 0     // timing-only builds (-DKS_ABLATE=n, tools/km_first.py): 1 no k-tile loads, 2 no fragment reads, 4 a
+                        // sixteenth of the epilogue (NB: the MFMAs whose results it no longer reads are dropped too), 8 no MFMAs
 #endif
 
 namespace {
@@ -53,8 +54,7 @@ namespace {
 // Workgroup tile: 256 centers x (64 WN) points, 2 x WN waves of 128 centers x 64 points each.  WN = 2 (the fp32
 // kernel's 256 x 128, two workgroups per CU) is the default; WN = 4 (512 lanes, ONE workgroup per CU, a third fewer
 // k-tile bytes per MFMA) measures the same (SP_KM_SPLIT_WN=4).  Timed with parts removed at configs[3] (2.42 ms):
-// without the k-tile loads 1.47, without the fragment reads 2.32, without the epilogue 2.01, without the MFMAs 2.00,
-// without all of them 0.57 -- the MFMAs themselves are a third of the time; neither fewer bytes (WN = 4) nor requests
+// without the k-tile loads 1.47, without the fragment reads 2.32, without the MFMAs 2.00, without all of them 0.57 -- the MFMAs themselves are a third of the time; neither fewer bytes (WN = 4) nor requests
 // two k-steps ahead (three LDS stages) shortened it, the order of issue inside a k-step 2 %, the k-tile-major layout
 // of the images 20 % (the loads were waiting for lines the L2 had dropped, not for bytes or issue slots).
 constexpr int KS_BK = 16;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
             const bool better = v < best[j];
             second[j] = __builtin_amdgcn_fmed3f(best[j], second[j], v);
             bpos[j] = better ? 16 * i + 4 * q + e : bpos[j];
-            best[j] = fminf(best[j], v);
+            best[j] = better ? v : best[j];          // (a select on the compare's result: fminf costs a canonicalising v_max first)
           }
       }
 #pragma unroll
