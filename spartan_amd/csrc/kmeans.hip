@@ -605,11 +605,14 @@ extern "C" size_t sp_nearest_center_workspace_bytes(int64_t n, int64_t k, int64_
 
 // Which MFMA filter the AUTO / explicit tiers mean: the split tier wherever the fused one applies (fp32 points),
 // unless SP_KM_SPLIT=0 (A/B measurements) or the tier names the fp32 filter.
-static bool km_use_split(int32_t tier, int64_t d) {
+static bool km_use_split(int32_t tier, int64_t k, int64_t d, bool prepared) {
   static const bool off = getenv("SP_KM_SPLIT") && atoi(getenv("SP_KM_SPLIT")) == 0;
   if (tier == SP_NEAREST_SPLIT || tier == SP_NEAREST_SPLIT_UNCHECKED) return true;
   if (tier == SP_NEAREST_FUSED || tier == SP_NEAREST_FUSED_UNCHECKED) return false;
-  return !off && d >= 32;      // (few features: the terms the split leaves out outweigh the roundings it saves)
+  // few features: the terms the split leaves out outweigh the roundings it saves.  A stand-alone call also pays for
+  // cutting the points, which few centers do not earn back (tools/km_tier_sweep.py: 1 250 000 x 64, k = 64: 0.42 ms
+  // fp32 / 0.50 split / 0.21 with prepared points; from k = 256 on the split wins either way)
+  return !off && d >= 32 && (prepared || k >= 192);
 }
 
 extern "C" size_t sp_kmeans_points_prepared_bytes(int64_t n, int64_t d) { return 256 + km_points_split_bytes(n, d); }
@@ -682,7 +685,7 @@ static int km_nearest_center(const void* d_points, int32_t dtype, int64_t ldx, c
   const int* n_rows = nullptr;
   int64_t handled = -1;
   if (tier != SP_NEAREST_EXACT && dtype == SP_F32 && sp_nearest_fused_applicable(n, k, d, tier)) {
-    const bool split = km_use_split(tier, d);
+    const bool split = km_use_split(tier, k, d, d_prepared != nullptr);
     if (split) {
       if (!d_prepared) {      // the shift of a stand-alone call: the centers' mean (no extra pass over the points)
         if (cdtype == SP_F32 ? km_col_means<float>((const float*)d_centers, ldc, k, d, w, st)
