@@ -331,8 +331,8 @@ int sp_rowdot_colsum_f32(const float* d_x, int64_t ldx, int64_t n, int64_t d, co
  *     contraction on the bf16 matrix pipe (three exact-product MFMAs per 16 features, fp32 accumulation,
  *     16 x the fp32 pipe's rate); its wider error window sends more points to the exact re-check: SAME labels
  *     (csrc/kmeans_split.hpp);
- *   SP_NEAREST_AUTO (0): split (>= 32 features; SP_KM_SPLIT=0: fused) for fp32 points when n*k*d >= 2^24,
- *     else exact.
+ *   SP_NEAREST_AUTO (0): split (>= 32 features, and >= 192 centers unless the points come prepared;
+ *     SP_KM_SPLIT=0: fused) or fused for fp32 points when n*k*d >= 2^24, else exact.
  *   SP_NEAREST_FUSED_UNCHECKED (3) / SP_NEAREST_SPLIT_UNCHECKED (5): diagnostics only -- the filter alone; points it
  *     could not decide are left as -1 - (fp32 best) (used to report the re-check rate).
  * d_ws: sp_nearest_center_workspace_bytes(n, k, d) bytes of scratch.
