@@ -517,8 +517,7 @@ static inline size_t km_align(size_t v) { return (v + 255) & ~(size_t)255; }
 // features padded to whole k-steps, and to at least TWO of them: the |c|^2/2 slice of center block tm is stored
 // during the last k-step of block tm - 1, which must lie behind a barrier that follows the epilogue of block tm - 2
 static inline int64_t km_padded_features(int64_t d) {
-  const int64_t dp = km_round_up(d < 1 ? 1 : d, KM_BK);
-  return dp < 2 * KM_BK ? 2 * KM_BK : dp;
+  return km_round_up(d < 1 ? 1 : d, 2 * KM_BK);      // (whole k-steps of either tier: 16, or 32 for the split tier's wide one)
 }
 
 // The MFMA re-check has room for n / 8 listed points (1.4 % are listed at configs[3]); a longer list -- degenerate

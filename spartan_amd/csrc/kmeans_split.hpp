@@ -35,10 +35,10 @@
 //
 // Operand images: the points are cut once per call -- or once per fit: sp_kmeans_points_prepare -- into two bf16
 // arrays (features padded to 16, zeros beyond d) plus |x - mu|^2 per point; the centers once per call.  An image is
-// stored k-tile-major, [dp / 16][rows][16] (see sp_split_rows_kernel: with row-major images every 128-byte line of a
-// point was fetched by four different k-steps -- 2.48 -> 1.97 ms at configs[3] for the layout alone).  A k-tile is 16
-// features = 32 bytes per row and image; the LDS images are [row][2 chunks of 16 B], chunk q of row r in slot
-// q ^ ((r >> 2) & 1) (conflict-free 16-B fragment reads), filled by global_load_lds_dwordx4 like the fp32 kernel's, the
+// stored k-tile-major, [dp / KS_BK][rows][KS_BK] (see sp_split_rows_kernel: with row-major images every 128-byte line of a
+// point was fetched by four different k-steps -- 2.48 -> 1.97 ms at configs[3] for the layout alone).  A k-tile is
+// KS_BK = 32 features = 64 bytes per row and image; the LDS images are [row][4 chunks of 16 B], chunk q of row r in
+// slot q ^ ((r >> 2) & 3) -- the fp32 kernel's image, bank for bank (conflict-free 16-B fragment reads), filled by global_load_lds_dwordx4 like the fp32 kernel's, the
 // pieces of a request spread over the MFMAs of the k-step before.  A lane's fragment is 8 consecutive features of one
 // row for both operands, so whatever order the instruction gives the 16 features of its K dimension, A and B agree.
 #pragma once
@@ -51,25 +51,36 @@ typedef __bf16 km_bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-// Workgroup tile: 256 centers x (64 WN) points, 2 x WN waves of 128 centers x 64 points each.  WN = 2 (the fp32
-// kernel's 256 x 128, two workgroups per CU) is the default; WN = 4 (512 lanes, ONE workgroup per CU, a third fewer
-// k-tile bytes per MFMA) measures the same (SP_KM_SPLIT_WN=4).  Timed with parts removed at configs[3] (2.42 ms):
-// without the k-tile loads 1.47, without the fragment reads 2.32, without the MFMAs 2.00, without all of them 0.57 -- the MFMAs themselves are a third of the time; neither fewer bytes (WN = 4) nor requests
-// two k-steps ahead (three LDS stages) shortened it, the order of issue inside a k-step 2 %, the k-tile-major layout
-// of the images 20 % (the loads were waiting for lines the L2 had dropped, not for bytes or issue slots).
-constexpr int KS_BK = 16;
+// Workgroup tile: 256 centers x (64 WN) points, 2 x WN waves of 128 centers x 64 points each, KS_BK features per
+// k-step.  Default: WN = 4 (512 lanes, ONE workgroup per CU, 130 KB of LDS) with 32 features per k-step -- 48 MFMAs per
+// wave and barrier; first pass at configs[3], one box: 1.74 ms against 1.82 for the fp32 kernel's geometry (WN = 2, 16
+// features, two workgroups per CU; 1.78 with a third LDS stage, k-tiles requested two k-steps ahead) and 1.86 for
+// WN = 4 with 16 features: what the wider tile loses to its 8-wave barrier the halved number of barriers more than
+// returns.  History of the kernel at configs[3] (profiles/r04_notes.md): 2.42 ms with row-major images; timed with
+// parts removed 1.47 without the k-tile loads, 2.32 without the fragment reads, 2.00 without the MFMAs, 0.57 without all
+// of them; the k-tile-major layout of the images gave 20 % (the loads were waiting for lines the L2 had dropped, not
+// for bytes or issue slots).
+#ifndef KS_BK_FEATURES
+#define KS_BK_FEATURES 32     // (-DKS_BK_FEATURES=16: the round's first geometry, 256 x 128 tiles on two workgroups per CU)
+#endif
+constexpr int KS_BK = KS_BK_FEATURES;                          // features per k-step (and per slab of an image): 16 or 32
+constexpr int KS_RB = KS_BK * 2;                               // bytes of a row of a k-tile
+constexpr int KS_CH = KS_BK / 8;                               // its 16-byte chunks
 constexpr int KS_BM = KN_BM;
-constexpr int KS_A_BYTES = KS_BM * KS_BK * 2;                  // 8 KiB per image
+constexpr int KS_A_BYTES = KS_BM * KS_RB;                      // one center image of a k-tile
+static_assert(KS_BK == 16 || KS_BK == 32, "k-tile");
 template <int WN>
 struct KsCfg {
   static constexpr int BN = 64 * WN, NW = 2 * WN, THREADS = 64 * NW;
-  static constexpr int B_BYTES = BN * KS_BK * 2;
+  static constexpr int B_BYTES = BN * KS_RB;
   static constexpr int STAGE_BYTES = 2 * KS_A_BYTES + 2 * B_BYTES;     // Ah | Am | Bh | Bm
   static constexpr int STAGES = 2;                                     // (three -- k-tiles requested two k-steps ahead -- measured: no gain)
   static constexpr int SMEM_BYTES = STAGES * STAGE_BYTES + 2 * KS_BM * 4;   // + two |c|^2/2 slices
-  static constexpr int APW = 8 / NW;                                   // 1-KiB pieces of a center image per wave
+  static constexpr int APW = KS_A_BYTES / 1024 / NW;                    // 1-KiB pieces of a center image per wave
+  static constexpr int BPW = B_BYTES / 1024 / NW;                       // ... of a point image
   static constexpr int SLOTS = SP_CUS * (WN == 2 ? 2 : 1);             // resident workgroups
   static_assert(SMEM_BYTES * (WN == 2 ? 2 : 1) <= 160 * 1024, "LDS budget of a CU");
+  static_assert(APW >= 1 && BPW >= 1, "every wave brings pieces of both operands");
   static_assert(SLOTS * BN == KM_TAIL_POINTS, "the tail buffer is sized for one round of either geometry");
 };
 
@@ -117,11 +128,11 @@ __global__ __launch_bounds__(256) void sp_col_finish_kernel(const float* __restr
 
 // hi / mid images of the fp32 rows MINUS the shift `mu` (NULL: none): one wavefront per row, zeros beyond d;
 // optionally the squared norm of the shifted row (fp32 sum, any order: the bound takes it with slack)
-// Layout of an image: [dp / 16 k-tiles][n rows][16 features] -- the 16 features x 128 rows a workgroup brings per
-// k-step are ONE contiguous 4 KiB block (row-major [n][dp] images made it 32 bytes out of every row's 512: each
+// Layout of an image: [dp / KS_BK k-tiles][n rows][KS_BK features] -- the k-tile of the rows a workgroup brings per
+// k-step is ONE contiguous block (row-major [n][dp] images made it 32 bytes out of every row's 512: each
 // 128-byte line was fetched by four different k-steps, and between them the L2 of an XCD, 64 workgroups' worth of
 // such lines plus the centers, had usually dropped it).
-__device__ __forceinline__ int64_t ks_at(int64_t row, int j, int64_t n) { return ((int64_t)(j >> 4) * n + row) * 16 + (j & 15); }
+__device__ __forceinline__ int64_t ks_at(int64_t row, int j, int64_t n) { return ((int64_t)(j / KS_BK) * n + row) * KS_BK + (j % KS_BK); }
 __global__ __launch_bounds__(256) void sp_split_rows_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int d,
                                                             int dp, const float* __restrict__ mu,
                                                             __bf16* __restrict__ Xh, __bf16* __restrict__ Xm,
@@ -227,26 +238,28 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
   unsigned a_off[APW];
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
-    const int slot = (wid * APW + j) * 64 + lane, row = slot >> 1;
-    a_off[j] = (unsigned)(row * 32 + (((slot & 1) ^ ((row >> 2) & 1)) * 16));     // (bytes inside a k-tile slab)
+    const int slot = (wid * APW + j) * 64 + lane, row = slot / KS_CH;
+    a_off[j] = (unsigned)(row * KS_RB + (((slot % KS_CH) ^ ((row >> 2) & (KS_CH - 1))) * 16));   // (bytes inside a k-tile slab)
   }
-  typename std::conditional<RECHECK, int64_t, unsigned>::type b_off;
-  {
-    const int slot = wid * 64 + lane;
-    int row = slot >> 1;
-    const int chunk = (slot & 1) ^ ((row >> 2) & 1);
+  constexpr int BPW = K::BPW;
+  typename std::conditional<RECHECK, int64_t, unsigned>::type b_off[BPW];
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    const int slot = (wid * BPW + j) * 64 + lane;
+    int row = slot / KS_CH;
+    const int chunk = (slot % KS_CH) ^ ((row >> 2) & (KS_CH - 1));
     if constexpr (RECHECK) {
       const int listed_row = m0 + row < listed ? m0 + row : listed - 1;   // tail: repeat the last listed point
-      b_off = (int64_t)amb_rows[listed_row] * 32 + chunk * 16;
+      b_off[j] = (int64_t)amb_rows[listed_row] * KS_RB + chunk * 16;
     } else {
       if (m0 + row > n - 1) row = n - 1 - m0;     // clamp: results of points >= n are discarded
-      b_off = (unsigned)(row * 32 + chunk * 16);
+      b_off[j] = (unsigned)(row * KS_RB + chunk * 16);
     }
   }
   // (PARTIAL launches pass the whole images and where their points start: first_point)
-  const char* __restrict__ Xh_blk = (const char*)(RECHECK ? Xh : Xh + (int64_t)(first_point + m0) * 16);
-  const char* __restrict__ Xm_blk = (const char*)(RECHECK ? Xm : Xm + (int64_t)(first_point + m0) * 16);
-  const int64_t x_slab = (int64_t)n_total * 32, c_slab = (int64_t)kp * 32;       // bytes per k-tile of an image
+  const char* __restrict__ Xh_blk = (const char*)(RECHECK ? Xh : Xh + (int64_t)(first_point + m0) * KS_BK);
+  const char* __restrict__ Xm_blk = (const char*)(RECHECK ? Xm : Xm + (int64_t)(first_point + m0) * KS_BK);
+  const int64_t x_slab = (int64_t)n_total * KS_RB, c_slab = (int64_t)kp * KS_RB;   // bytes per k-tile of an image
   const unsigned s_base = SP_LDS_ADDR(smem);
   const unsigned chs_w = SP_LDS_ADDR(chs);
   const int nt = dp / KS_BK;
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
   // over its MFMAs (each is an M0 write and a ~100-cycle issue the matrix pipe works through; issued in one run
   // ahead of the fragment reads, as the fp32 kernel does, they were a third of this kernel's time).
   int ld_tr = 0, ld_kt = 0;
-  constexpr int NPIECES = 2 * APW + 3;
+  constexpr int NPIECES = 2 * APW + 2 * BPW + 1;
 #define KS_LOAD_BEGIN(stage_of)                                                                        \
   const int tr_ = ld_tr, kt_ = ld_kt;                                                                  \
   if (++ld_kt == nt) {                                                                                 \
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
     ++ld_tr;                                                                                           \
   }                                                                                                    \
   const int tm_ = tm_first + tr_;                                                                      \
-  const int64_t ka_ = kt_ * c_slab + (int64_t)tm_ * (KS_BM * 32);                                      \
+  const int64_t ka_ = kt_ * c_slab + (int64_t)tm_ * (KS_BM * KS_RB);                                   \
   const unsigned st_ = s_base + (unsigned)(stage_of) * KS_STAGE_BYTES;
 #define KS_PIECE(i)                                                                                    \
   do {                                                                                                 \
@@ -275,12 +288,12 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
       const int j_ = (i) >> 1;                                                                         \
       if (((i) & 1) == 0) SP_GLDS_S((const char*)Ch + ka_, a_off[j_], st_ + (wid * APW + j_) * 1024);  \
       else SP_GLDS_S((const char*)Cm + ka_, a_off[j_], st_ + KS_A_BYTES + (wid * APW + j_) * 1024);    \
-    } else if ((i) == 2 * APW) {                                                                       \
-      if constexpr (RECHECK) SP_GLDS_V(Xh_blk + kt_ * x_slab + b_off, st_ + 2 * KS_A_BYTES + wid * 1024); \
-      else SP_GLDS_S(Xh_blk + kt_ * x_slab, b_off, st_ + 2 * KS_A_BYTES + wid * 1024);            \
-    } else if ((i) == 2 * APW + 1) {                                                                   \
-      if constexpr (RECHECK) SP_GLDS_V(Xm_blk + kt_ * x_slab + b_off, st_ + 2 * KS_A_BYTES + KS_B_BYTES + wid * 1024); \
-      else SP_GLDS_S(Xm_blk + kt_ * x_slab, b_off, st_ + 2 * KS_A_BYTES + KS_B_BYTES + wid * 1024); \
+    } else if ((i) < 2 * APW + 2 * BPW) {                                                              \
+      const int j_ = ((i) - 2 * APW) >> 1;                                                             \
+      const unsigned dst_ = st_ + 2 * KS_A_BYTES + ((((i) - 2 * APW) & 1) ? KS_B_BYTES : 0) + (wid * BPW + j_) * 1024; \
+      const char* src_ = ((((i) - 2 * APW) & 1) ? Xm_blk : Xh_blk) + kt_ * x_slab;                     \
+      if constexpr (RECHECK) SP_GLDS_V(src_ + b_off[j_], dst_);                                        \
+      else SP_GLDS_S(src_, b_off[j_], dst_);                                                           \
     } else if (kt_ == 0 && wid == 0) {                                                                 \
       SP_GLDS_S(chalf + tm_ * KS_BM, (unsigned)lane * 16u, chs_w + (tr_ & 1) * (KS_BM * 4));           \
     }                                                                                                  \
@@ -298,10 +311,15 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
   }
   SP_GLDS_LANDED();
   __syncthreads();
-  // fragments: row (wave tile row + l31 [+ 32 i]), 16-B chunk lh ^ ((row >> 2) & 1) -- the same xor for both operands
-  const int sw = (l31 >> 2) & 1;
-  const int a_frag = (wm * 128 + l31) * 32 + ((lh ^ sw) * 16);
-  const int b_frag = 2 * KS_A_BYTES + (wn * 64 + l31) * 32 + ((lh ^ sw) * 16);
+  // fragments: row (wave tile row + l31 [+ 32 i]), 16-B chunk (2 kk + lh) ^ ((row >> 2) & (KS_CH - 1)) -- the same
+  // xor for both operands; kk: which 16 of the k-tile's features
+  const int sw = (l31 >> 2) & (KS_CH - 1);
+  int a_frag[KS_BK / 16], b_frag[KS_BK / 16];
+#pragma unroll
+  for (int kk = 0; kk < KS_BK / 16; ++kk) {
+    a_frag[kk] = (wm * 128 + l31) * KS_RB + (((2 * kk + lh) ^ sw) * 16);
+    b_frag[kk] = 2 * KS_A_BYTES + (wn * 64 + l31) * KS_RB + (((2 * kk + lh) ^ sw) * 16);
+  }
 
   int t = 0;
   auto kstep = [&](auto first_of_block) {
@@ -309,53 +327,56 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
     const bool more = !(KS_ABLATE & 1) && t + 1 < steps;
     KS_LOAD_BEGIN(nxt)
     const char* st = smem + cur * KS_STAGE_BYTES;
-    km_bf16x8 ah[4], am[4], bh[2], bm[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (KS_ABLATE & 2) {
-        ah[i] = am[i] = *(const km_bf16x8*)(smem + a_frag);
-        asm volatile("" : "+v"(ah[i]), "+v"(am[i]));
-        continue;
-      }
-      ah[i] = *(const km_bf16x8*)(st + a_frag + i * 1024);
-      am[i] = *(const km_bf16x8*)(st + KS_A_BYTES + a_frag + i * 1024);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (KS_ABLATE & 2) {
-        bh[j] = bm[j] = *(const km_bf16x8*)(smem + b_frag);
-        asm volatile("" : "+v"(bh[j]), "+v"(bm[j]));
-        continue;
-      }
-      bh[j] = *(const km_bf16x8*)(st + b_frag + j * 1024);
-      bm[j] = *(const km_bf16x8*)(st + KS_B_BYTES + b_frag + j * 1024);
-    }
-    // 24 MFMAs (mid x hi, hi x mid, hi x hi for the 4 x 2 tiles of the wave), a piece of the next k-tile's request
-    // after every third
+    // per 16 features of the k-tile: 24 MFMAs (mid x hi, hi x mid, hi x hi for the 4 x 2 tiles of the wave); a piece of
+    // the next k-tile's request after every third MFMA
     int piece = 0;
 #pragma unroll
-    for (int idx = 0; idx < 24; ++idx) {
-      const int term = idx >> 3, i = (idx & 7) >> 1, j = idx & 1;
-      if (!(KS_ABLATE & 8)) {
-        const km_bf16x8 a = term == 0 ? am[i] : ah[i];
-        const km_bf16x8 b = term == 1 ? bm[j] : bh[j];
-        if (FIRST && term == 0) {
-          const km_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, zero, 0, 0, 0);
-        } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+    for (int kk = 0; kk < KS_BK / 16; ++kk) {
+      km_bf16x8 ah[4], am[4], bh[2], bm[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (KS_ABLATE & 2) {
+          ah[i] = am[i] = *(const km_bf16x8*)(smem + a_frag[0]);
+          asm volatile("" : "+v"(ah[i]), "+v"(am[i]));
+          continue;
         }
-      } else {
-        asm volatile("" : "+v"(acc[i][j]) : "v"(ah[i]), "v"(am[i]), "v"(bh[j]), "v"(bm[j]));
+        ah[i] = *(const km_bf16x8*)(st + a_frag[kk] + i * 32 * KS_RB);
+        am[i] = *(const km_bf16x8*)(st + KS_A_BYTES + a_frag[kk] + i * 32 * KS_RB);
       }
-      if (idx % 3 == 2 && piece < NPIECES) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) KS_PIECE(piece);
-        __builtin_amdgcn_sched_barrier(0);
-        ++piece;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (KS_ABLATE & 2) {
+          bh[j] = bm[j] = *(const km_bf16x8*)(smem + b_frag[0]);
+          asm volatile("" : "+v"(bh[j]), "+v"(bm[j]));
+          continue;
+        }
+        bh[j] = *(const km_bf16x8*)(st + b_frag[kk] + j * 32 * KS_RB);
+        bm[j] = *(const km_bf16x8*)(st + KS_B_BYTES + b_frag[kk] + j * 32 * KS_RB);
+      }
+#pragma unroll
+      for (int idx = 0; idx < 24; ++idx) {
+        const int term = idx >> 3, i = (idx & 7) >> 1, j = idx & 1;
+        if (!(KS_ABLATE & 8)) {
+          const km_bf16x8 a = term == 0 ? am[i] : ah[i];
+          const km_bf16x8 b = term == 1 ? bm[j] : bh[j];
+          if (FIRST && kk == 0 && term == 0) {
+            const km_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, zero, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+          }
+        } else {
+          asm volatile("" : "+v"(acc[i][j]) : "v"(ah[i]), "v"(am[i]), "v"(bh[j]), "v"(bm[j]));
+        }
+        if (idx % 3 == 2 && piece < NPIECES) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) KS_PIECE(piece);
+          __builtin_amdgcn_sched_barrier(0);
+          ++piece;
+        }
       }
     }
-    static_assert(NPIECES <= 8, "one piece after every third of the 24 MFMAs");
+    static_assert(NPIECES <= 8 * (KS_BK / 16), "one piece after every third MFMA");
     if (more) SP_GLDS_LANDED();
     __syncthreads();
     ++t;
@@ -533,7 +554,7 @@ static int km_split_wn() {
   static int wn = -1;
   if (wn < 0) {
     const char* e = getenv("SP_KM_SPLIT_WN");
-    wn = e && atoi(e) == 4 ? 4 : 2;     // (measured equal at configs[3]: 2.53 / 2.54 ms)
+    wn = e && atoi(e) == 2 ? 2 : 4;     // (2: only with -DKS_BK_FEATURES=16)
   }
   return wn;
 }
@@ -592,8 +613,10 @@ static int sp_nearest_split_launch_wn(const void* C, int32_t cdtype, int64_t ldc
 
 static int sp_nearest_split_launch(const void* C, int32_t cdtype, int64_t ldc, int64_t n, int64_t k, int64_t d,
                                    int64_t* labels, const KmWorkspace& w, hipStream_t st) {
-  return km_split_wn() == 2 ? sp_nearest_split_launch_wn<2>(C, cdtype, ldc, n, k, d, labels, w, st)
-                            : sp_nearest_split_launch_wn<4>(C, cdtype, ldc, n, k, d, labels, w, st);
+#if KS_BK_FEATURES == 16
+  if (km_split_wn() == 2) return sp_nearest_split_launch_wn<2>(C, cdtype, ldc, n, k, d, labels, w, st);
+#endif
+  return sp_nearest_split_launch_wn<4>(C, cdtype, ldc, n, k, d, labels, w, st);   // (32-feature k-tiles: this geometry only)
 }
 
 // Second pass over the listed points: marks the centers inside each point's error window.
@@ -608,7 +631,10 @@ static int sp_nearest_split_mark_wn(int64_t d, const KmWorkspace& w, hipStream_t
                                       0, 0, 0, (int)w.n_points);
 }
 static int sp_nearest_split_mark_candidates(int64_t d, const KmWorkspace& w, hipStream_t st) {
-  return km_split_wn() == 2 ? sp_nearest_split_mark_wn<2>(d, w, st) : sp_nearest_split_mark_wn<4>(d, w, st);
+#if KS_BK_FEATURES == 16
+  if (km_split_wn() == 2) return sp_nearest_split_mark_wn<2>(d, w, st);
+#endif
+  return sp_nearest_split_mark_wn<4>(d, w, st);
 }
 
 }  // namespace
