@@ -153,3 +153,27 @@ def test_rccl_is_found_in_the_documented_order():
     text = out.stdout.decode('utf-8', 'replace')
     assert out.returncode == 0 and 'LOADED' in text, text[-2000:]
     assert expect in text.split('LOADED', 1)[1], text[-500:]
+
+
+def test_bench_self_launch_reports_a_failed_rank_without_a_gpu():
+  """`python bench.py --gpus 2` as a plain process starts its own ranks; on a machine without a GPU every rank fails
+  loudly (there is no CPU fallback) and the launcher must say so: ONE JSON line of the contract's shape with the reason,
+  and a non-zero exit code."""
+  import json
+  import subprocess
+  import sys
+  try:
+    import torch
+    if torch.cuda.is_available():
+      pytest.skip('a GPU is visible: the ranks would run')
+  except ImportError:
+    pass
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                      '--deadline', '240'], capture_output=True, text=True, timeout=300, cwd=root)
+  assert p.returncode != 0
+  lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1
+  line = json.loads(lines[0])
+  assert line['n_gpus'] == 2 and line['value'] is None and 'FAILED' in line['error']
+  assert 'self-launch' in line['launcher']
