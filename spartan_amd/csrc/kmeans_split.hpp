@@ -18,9 +18,9 @@
 // and the score |c|^2 - 2 x.c, in whose units km_decide and the candidate window work, by twice that: the error
 // factor of this tier is
 //   F = 6.1 D + 1550,    E = u (F |x| |c|max + 2 |c|max^2),
-// in the place of the fp32 kernel's 2 D + 4.  At D = 256 the window is 6 x as wide and 8 % of the points of configs[3]
-// instead of 1.4 % go to the re-check -- whose first stage is this same kernel -- while the pass itself needs half the
-// time.  (Other cuts end at the same width: a fourth product, xm cm, trades 512 u of left-out terms for 2 D u of
+// in the place of the fp32 kernel's 2 D + 4.  At D = 256 the window is 6 x as wide: without the shift below 8 % of the
+// points of configs[3] instead of 1.4 % would go to the re-check (16-27 % inside a fit), with it 2-4 % do -- and the pass
+// itself needs a third of the fp32 kernel's time.  (Other cuts end at the same width: a fourth product, xm cm, trades 512 u of left-out terms for 2 D u of
 // roundings; all 24 bits -- three bf16 per operand, six products -- 1536 u for 6 D u.)  The labels are the exact
 // tier's, as before: tools/fuzz_kmeans.py, tests/test_hip_kernels.py::test_nearest_center_*.
 //
@@ -74,7 +74,7 @@ struct KsCfg {
   static constexpr int BN = 64 * WN, NW = 2 * WN, THREADS = 64 * NW;
   static constexpr int B_BYTES = BN * KS_RB;
   static constexpr int STAGE_BYTES = 2 * KS_A_BYTES + 2 * B_BYTES;     // Ah | Am | Bh | Bm
-  static constexpr int STAGES = 2;                                     // (three -- k-tiles requested two k-steps ahead -- measured: no gain)
+  static constexpr int STAGES = 2;                                     // (a third gave 2 % with 16-feature k-tiles; with 32 it does not fit)
   static constexpr int SMEM_BYTES = STAGES * STAGE_BYTES + 2 * KS_BM * 4;   // + two |c|^2/2 slices
   static constexpr int APW = KS_A_BYTES / 1024 / NW;                    // 1-KiB pieces of a center image per wave
   static constexpr int BPW = B_BYTES / 1024 / NW;                       // ... of a point image
