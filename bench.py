@@ -23,7 +23,8 @@ stream), `profile_table` (what every timed section launched: kernel, launches, a
 key tools/roofline.py uses to recompute each fraction from a rocprofv3 kernel trace of this very command), and the
 CPU baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thread worker processes.
 
-No torch in this process at N = 1; with N > 1 torch.distributed (gloo) is the control plane only.
+No torch in this process at any N: the control plane of a multi-rank run is the rendezvous hub of rank 0
+(spartan_amd/rendezvous.py, standard library sockets); the data plane is RCCL called from libspartan_hip.so.
 """
 import argparse
 import os as _os
@@ -465,10 +466,20 @@ def rccl_report(world):
       version = v.value
   except Exception:
     pass
+  from spartan_amd import comm
+  rep = {'ranks': 0, 'version': version, 'visible_gpus': comm_gpu_count(),
+         'control_plane': getattr(world.control, 'name', None), 'torch_in_process': 'torch' in sys.modules}
+  try:
+    rep.update(comm.rccl_paths())            # lib_path, hip_runtime_path (RCCL's), own_hip_runtime_path
+  except Exception as e:
+    rep['lib_path'] = rep['hip_runtime_path'] = None
+    rep['paths_error'] = str(e)[:300]
+  rep['mapped'] = comm.mapped_runtimes()     # one file per library when the process is single-runtime
   if getattr(t, 'name', '') == 'rccl':
-    return {'ranks': t.size, 'version': version, 'self_test': 'passed', 'visible_gpus': comm_gpu_count()}
-  return {'ranks': 0, 'version': version, 'self_test': 'not run: transport is %s (ranks share devices)' % getattr(t, 'name', '?'),
-          'visible_gpus': comm_gpu_count()}
+    rep.update({'ranks': t.size, 'self_test': 'passed'})
+  else:
+    rep['self_test'] = 'not run: transport is %s (ranks share devices)' % getattr(t, 'name', '?')
+  return rep
 
 
 def comm_gpu_count():
@@ -748,7 +759,7 @@ def self_launch(n, argv, deadline_s):
   base.update({'WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
                'SPARTAN_BENCH_LAUNCHER': 'self', 'SPARTAN_BENCH_VISIBLE_GPUS': str(gpus)})
   if gpus < n and 'SPARTAN_DIST_BACKEND' not in base:
-    base['SPARTAN_DIST_BACKEND'] = 'gloo'        # RCCL wants one device per rank
+    base['SPARTAN_DIST_BACKEND'] = 'socket'      # RCCL wants one device per rank
   out0 = tempfile.TemporaryFile()
   procs = []
   for rank in range(n):
@@ -903,7 +914,7 @@ def main():
       'config': {'workload': workload, 'parallelism': parallelism, 'flop_per_step': flop_step,
                  'setup_launches': setup,
                  'inputs': 'uniform[-1,1) fp32 generated on device (sp_random_fill, Philox), resident in HBM',
-                 'host': 'no torch in this process' if 'torch' not in sys.modules else 'torch.distributed (gloo) control plane'},
+                 'host': 'no torch in this process' if 'torch' not in sys.modules else 'torch is loaded in this process'},
       'roofline': {'bound': 'mfma', 'kernel': 'sp_gemm_glds_kernel<256x128x16, 4 waves> (v_mfma_f32_32x32x2_f32, k-tiles by global_load_lds)',
                    'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
@@ -999,10 +1010,12 @@ def main():
   world.barrier()
   _emit(line, world.rank)
   sp.shutdown()
+  distributed = world.distributed
   world.close()
-  if world.distributed:
-    import torch.distributed
-    torch.distributed.destroy_process_group()
+  if distributed and 'torch.distributed' in sys.modules:      # only a caller that brought torch.distributed itself
+    dist = sys.modules['torch.distributed']
+    if dist.is_initialized():
+      dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -553,9 +553,14 @@ int sp_blob_slice_copy(uint64_t dst, const int64_t* dst_ul, uint64_t src, const 
  * channel the host has (the reference's workers register with the master over TCP, worker.py:98-124); every
  * rank then calls sp_comm_init with the device it computes on current.  reducer: enum sp_reducer (ADD MUL MAX
  * MIN; AND / OR for SP_BOOL).  All calls are asynchronous on `stream`; RCCL is bound at run time
- * (sp_comm_available() == 0 when the host has none). */
+ * (sp_comm_available() == 0 when the host has none): $SPARTAN_RCCL_LIB, then the librccl.so.1 installed beside the
+ * HIP runtime this library is bound to, then the loader's search path.  A copy linked against ANOTHER HIP runtime
+ * than this library's (a process can hold two) is refused with the reason in sp_last_error(): the pointers,
+ * streams and events a collective is handed must belong to the runtime it runs on.  sp_comm_paths reports the
+ * files in use (each buffer each_bytes long): the RCCL bound, the HIP runtime it calls, this library's own. */
 int sp_comm_available(void);
 int sp_comm_version(int* version);
+int sp_comm_paths(char* rccl_path, char* rccl_runtime_path, char* own_runtime_path, size_t each_bytes);
 int sp_comm_unique_id(void* uid, size_t uid_bytes);
 int sp_comm_init(int32_t world, int32_t rank, const void* uid, void** comm);
 int sp_comm_destroy(void* comm);

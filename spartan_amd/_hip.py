@@ -172,6 +172,7 @@ def _declare(lib):
   lib.sp_blob_slice_copy.argtypes = [u64, p64, u64, p64, p64, vp]
   lib.sp_comm_available.argtypes = []
   lib.sp_comm_version.argtypes = [C.POINTER(C.c_int)]
+  lib.sp_comm_paths.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, sz]
   lib.sp_comm_unique_id.argtypes = [vp, sz]
   lib.sp_comm_init.argtypes = [i32, i32, vp, pp]
   lib.sp_comm_destroy.argtypes = [vp]
@@ -212,7 +213,7 @@ EXPORTS = [
     'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',
     'sp_blob_create', 'sp_blob_destroy', 'sp_blob_trim', 'sp_blob_info', 'sp_blob_stats', 'sp_blob_h2d', 'sp_blob_h2d_staged', 'sp_blob_d2h', 'sp_blob_d2h_staged', 'sp_pinned_alloc', 'sp_pinned_free', 'sp_copy_d2h_async',
-    'sp_blob_slice_copy', 'sp_comm_available', 'sp_comm_version', 'sp_comm_unique_id', 'sp_comm_init',
+    'sp_blob_slice_copy', 'sp_comm_available', 'sp_comm_version', 'sp_comm_paths', 'sp_comm_unique_id', 'sp_comm_init',
     'sp_comm_destroy', 'sp_comm_abort', 'sp_comm_async_error', 'sp_comm_all_reduce', 'sp_comm_reduce_scatter',
     'sp_comm_reduce', 'sp_comm_all_gather', 'sp_comm_bcast', 'sp_comm_all_to_all_blocks', 'sp_set_device', 'sp_get_device', 'sp_jit_preload', 'sp_jit_shutdown',
     'sp_stream_create', 'sp_stream_create_priority', 'sp_device_synchronize', 'sp_memset', 'sp_stream_copy_wg',

@@ -12,19 +12,24 @@ primitives below are collective calls made by all ranks in the same order:
   all_gather      `glom` / replicated fetch of one-tile-per-rank arrays
   broadcast       replicated fetch of a single tile
 
-Two transports carry them:
+Transports:
 
   RcclTransport   HBM blobs between GPUs: the collective entry points of libspartan_hip.so (sp_comm_*,
                   include/spartan_hip.h), i.e. RCCL over xGMI called straight from the C-ABI.  Blocking calls
                   are enqueued on the compute stream (stream order is the only synchronisation); `async_` calls
                   run on a communication stream of their own, ordered against the compute stream by events, so
-                  that kernels launched meanwhile overlap with the transfer.
-  TorchTransport  a torch.distributed gloo group: the CPU tests (NumPy tile backend), and -- with host staging --
-                  a debug transport for several ranks sharing one GPU.  There is no second GPU data plane: if the
-                  direct RCCL binding does not come up or fails its start-up self-test the job fails, loudly.
+                  that kernels launched meanwhile overlap with the transfer.  There is no second GPU data plane:
+                  if the RCCL binding does not come up or fails its start-up self-test the job fails, loudly.
+  SocketTransport host arrays through the rendezvous hub (rendezvous.py): the NumPy tile backend of the CPU tests
+                  and -- device arrays staged through the host -- a debug transport for several ranks sharing one
+                  GPU.  Standard library only.
+  TorchTransport  the same over a torch.distributed gloo group, for a caller that brought torch.distributed
+                  (backend 'gloo'; the CPU tests cover it).
 
-Small host objects (tile metadata, driver-level random draws, the RCCL rendezvous token) always travel over a
-gloo group: that is control plane, not tile data.
+Small host objects (tile metadata, driver-level random draws, the RCCL rendezvous token), barriers and the
+heartbeat's store are control plane: `SocketControl` (the rendezvous hub of rank 0; a job started this way never
+imports torch, so the process holds ONE HIP runtime -- the one libspartan_hip.so and the RCCL it binds are linked
+against) or `TorchControl` when the caller's process already runs an initialised torch.distributed group.
 """
 import ctypes as C
 import os
@@ -44,6 +49,32 @@ def _torch_red(reducer):
   dist = _dist()
   return {'ADD': dist.ReduceOp.SUM, 'MUL': dist.ReduceOp.PRODUCT, 'MAX': dist.ReduceOp.MAX,
           'MIN': dist.ReduceOp.MIN}[reducer]
+
+
+def rccl_paths():
+  """{'lib_path', 'hip_runtime_path', 'own_hip_runtime_path'} of the RCCL data plane as libspartan_hip.so bound it
+  (sp_comm_paths): the RCCL file, the HIP runtime that copy calls into, the HIP runtime of the library itself."""
+  from . import _hip
+  bufs = [C.create_string_buffer(4096) for _ in range(3)]
+  _hip.check(_hip.lib().sp_comm_paths(bufs[0], bufs[1], bufs[2], 4096))
+  vals = [b.value.decode('utf-8', 'replace') for b in bufs]
+  return {'lib_path': vals[0], 'hip_runtime_path': vals[1], 'own_hip_runtime_path': vals[2]}
+
+
+def mapped_runtimes():
+  """Files of the HIP / HSA runtimes and of RCCL mapped into this process (/proc/self/maps), by library:
+  {'libamdhip64': [...], 'libhsa-runtime64': [...], 'librccl': [...]} -- a job's process should show one of each."""
+  import re
+  found = {'libamdhip64': set(), 'libhsa-runtime64': set(), 'librccl': set()}
+  try:
+    with open('/proc/self/maps') as fh:
+      for line in fh:
+        m = re.search(r'(/\S*/(libamdhip64|libhsa-runtime64|librccl)[^/\s]*)$', line.strip())
+        if m:
+          found[m.group(2)].add(os.path.realpath(m.group(1)))
+  except OSError:
+    pass
+  return {k: sorted(v) for k, v in found.items()}
 
 
 def gpu_count():
@@ -303,16 +334,154 @@ class TorchTransport(object):
     self._unstage(tensor, h)
 
 
+class SocketTransport(object):
+  """Host arrays through the rendezvous hub: reductions are done by the hub in rank order, blocks between two
+  ranks go through its mailbox in the order they were sent.  Payloads are the NumPy backend's arrays (CPU tests)
+  or device arrays copied through the host (`staged`: several ranks sharing one GPU).  A debug / test transport --
+  never the data plane of a GPU job, which is RcclTransport or nothing."""
+  device_native = False
+
+  def __init__(self, client, size, rank, staged):
+    self.client, self.size, self.rank, self.staged = client, size, rank, staged
+    self.name = 'socket-staged' if staged else 'socket'
+
+  def close(self, abort=False):
+    pass
+
+  @staticmethod
+  def _host(t):
+    return np.ascontiguousarray(t if isinstance(t, np.ndarray) else t.numpy())
+
+  @staticmethod
+  def _put(dst, got):
+    if isinstance(dst, np.ndarray):
+      dst[...] = np.asarray(got).reshape(dst.shape)
+    else:
+      dst.upload(np.ascontiguousarray(np.asarray(got).reshape(tuple(dst.shape))))
+
+  def exchange(self, sends, recvs, async_=False):
+    for dst, t in sends:
+      self.client.send(dst, self._host(t))
+    for src, t in recvs:
+      self._put(t, self.client.recv(src))
+    return None
+
+  def all_gather_into(self, out, tensor, async_=False):
+    parts = self.client._round('data', ('gather',), self._host(tensor))
+    self._put(out, np.concatenate([np.asarray(p).reshape(-1) for p in parts]))
+    return None
+
+  def reduce_scatter(self, out, inp, reducer, async_=False):
+    self._put(out, self.client.reduce_scatter(self._host(inp), reducer))
+    return None
+
+  def all_reduce(self, tensor, reducer):
+    self._put(tensor, self.client.all_reduce(self._host(tensor), reducer))
+
+  def reduce(self, tensor, dst, reducer):
+    got = self.client.reduce(self._host(tensor), dst, reducer)
+    if self.rank == dst:
+      self._put(tensor, got)
+
+  def broadcast(self, tensor, src):
+    self._put(tensor, self.client.broadcast_object(self._host(tensor) if self.rank == src else None, src))
+
+
+class SocketControl(object):
+  """Control plane over the rendezvous hub (rendezvous.py): standard library only."""
+  name = 'socket'
+
+  def __init__(self, rank, size):
+    import atexit
+    from . import rendezvous
+    self.client, self.hub = rendezvous.join(rank, size)
+    self.rank, self.size = rank, size
+    # a process that ends without World.close() still says goodbye, and rank 0 keeps serving until the others
+    # have: its exit must not cut off a reply another rank is waiting for
+    atexit.register(self.close)
+
+  def barrier(self):
+    self.client.barrier()
+
+  def broadcast_object(self, obj, src):
+    return self.client.broadcast_object(obj, src)
+
+  def all_gather_object(self, obj):
+    return self.client.all_gather_object(obj)
+
+  def store(self):
+    return self.client                      # set / get / delete; get of a key never set returns None
+
+  def close(self):
+    if self.client is not None:
+      self.client.close()
+      self.client = None
+    if self.hub is not None:
+      self.hub.close()
+      self.hub = None
+
+
+class _TorchStore(object):
+  """The process group's rendezvous store (TCPStore); reads of a key that was never set must not block."""
+
+  def __init__(self):
+    self._store = _dist().distributed_c10d._get_default_store()
+
+  def set(self, key, value):
+    self._store.set(key, value)
+
+  def get(self, key):
+    if not self._store.check([key]):
+      return None
+    return self._store.get(key).decode()
+
+  def delete(self, key):
+    try:
+      self._store.delete_key(key)
+    except Exception:
+      pass
+
+
+class TorchControl(object):
+  """Control plane of a caller that runs torch.distributed: its default (gloo) group."""
+  name = 'torch'
+
+  def __init__(self, group=None):
+    self.group = group
+
+  def barrier(self):
+    _dist().barrier(group=self.group)
+
+  def broadcast_object(self, obj, src):
+    box = [obj]
+    _dist().broadcast_object_list(box, src=src, group=self.group)
+    return box[0]
+
+  def all_gather_object(self, obj):
+    dist = _dist()
+    out = [None] * dist.get_world_size(self.group)
+    dist.all_gather_object(out, obj, group=self.group)
+    return out
+
+  def store(self):
+    return _TorchStore()
+
+  def close(self):
+    pass
+
+
 class World(object):
-  """The set of worker processes: a transport for tile payloads, a gloo group for host objects, and counters
-  of what crossed ranks (the tests assert on them)."""
+  """The set of worker processes: a transport for tile payloads, a control plane for host objects and barriers, and
+  counters of what crossed ranks (the tests assert on them)."""
 
   def __init__(self, rank=0, size=1, group=None, transport=None, control=None):
     self.rank = rank
     self.size = size
     self.group = group
-    self.control = control                  # gloo group for objects / barriers (None: the default group)
+    self.control = control                  # SocketControl / TorchControl (None in a 1-process world)
     self.transport = transport
+    if size > 1 and control is None:
+      self.control = TorchControl(group)    # a caller that built the world around its own torch.distributed group
     if transport is None and size > 1:
       self.transport = TorchTransport(group, size, rank, staged=False)
     self.stats = {'p2p_bytes': 0, 'collective_bytes': 0, 'p2p_msgs': 0, 'collectives': 0, 'sparse_blocks': 0}
@@ -329,61 +498,71 @@ class World(object):
 
   @staged.setter
   def staged(self, value):
-    if isinstance(self.transport, TorchTransport):
+    if isinstance(self.transport, (TorchTransport, SocketTransport)):
+      kind = 'torch' if isinstance(self.transport, TorchTransport) else 'socket'
       self.transport.staged = bool(value)
-      self.transport.device_native = not value
-      self.transport.name = 'torch-staged' if value else 'torch'
+      self.transport.name = kind + '-staged' if value else kind
 
   # -- construction -----------------------------------------------------------
   @staticmethod
   def from_env(backend=None):
-    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run), or
-    return the 1-process world.  backend: 'rccl' (sp_comm_* of the C-ABI: the data plane of a GPU job; if it does
-    not come up or fails its self-test the job STOPS -- there is no second GPU transport to fall back to) or
-    'gloo' (CPU tensors; device arrays are staged through the host -- a debug transport for ranks sharing one GPU).
-    SPARTAN_DIST_BACKEND overrides."""
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (what torch.distributed.run or
+    bench.py's own launcher set), or return the 1-process world.  backend:
+
+      'rccl'    sp_comm_* of the C-ABI: the data plane of a GPU job; if it does not come up or fails its self-test
+                the job STOPS -- there is no second GPU transport to fall back to.  Control plane: the rendezvous
+                hub (no torch in the process).
+      'socket'  host arrays through the rendezvous hub: CPU tile backend, or device arrays staged through the host
+                -- a debug transport for ranks sharing one GPU.  No torch in the process.
+      'gloo'    the same over torch.distributed (imports torch; for callers that live in a torch job).
+
+    Default: 'rccl' with GPUs, 'socket' without.  SPARTAN_DIST_BACKEND overrides.  A caller whose process already
+    runs an initialised torch.distributed group keeps it as the control plane."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = _initialized_torch_dist()
+    if dist is not None:
+      if dist.get_world_size() <= 1:
+        return World(dist.get_rank(), dist.get_world_size(), None)
+      return World._join(backend, dist.get_world_size(), dist.get_rank())
     if ws <= 1:
-      try:
-        import sys
-        dist = sys.modules.get('torch.distributed')
-        if dist is not None and dist.is_available() and dist.is_initialized():
-          return World(dist.get_rank(), dist.get_world_size(), None) if dist.get_world_size() <= 1 else \
-              World._join(backend, dist.get_world_size(), dist.get_rank())
-      except Exception:
-        pass
       return World(0, 1, None)
-    dist = _dist()
-    rank = dist.get_rank() if dist.is_initialized() else int(os.environ['RANK'])
-    if dist.is_initialized():
-      ws = dist.get_world_size()
-    return World._join(backend, ws, rank)
+    return World._join(backend, ws, int(os.environ['RANK']))
 
   @staticmethod
   def _join(backend, ws, rank):
-    dist = _dist()
     gpus = gpu_count()
-    backend = backend or os.environ.get('SPARTAN_DIST_BACKEND') or ('rccl' if gpus else 'gloo')
-    if backend not in ('rccl', 'gloo'):
-      raise ValueError("unknown data-plane backend %r (known: 'rccl', 'gloo')" % backend)
+    backend = backend or os.environ.get('SPARTAN_DIST_BACKEND') or ('rccl' if gpus else 'socket')
+    if backend not in ('rccl', 'socket', 'gloo'):
+      raise ValueError("unknown data-plane backend %r (known: 'rccl', 'socket', 'gloo')" % backend)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     local = int(os.environ.get('LOCAL_RANK', rank))
     if gpus:
       from . import _hip
       _hip.check(_hip.lib().sp_set_device(local % gpus))
-    if not dist.is_initialized():
-      # the default group is gloo: host objects, barriers, and the CPU / staged data plane
-      dist.init_process_group('gloo', rank=rank, world_size=ws)
+    if backend == 'gloo' or _initialized_torch_dist() is not None:
+      dist = _dist()
+      if not dist.is_initialized():
+        dist.init_process_group('gloo', rank=rank, world_size=ws)
+      control = TorchControl(None)
+    else:
+      control = SocketControl(rank, ws)
     if backend == 'gloo':
-      w = World(rank, ws, None, TorchTransport(None, ws, rank, staged=bool(gpus)))
+      w = World(rank, ws, None, TorchTransport(None, ws, rank, staged=bool(gpus)), control=control)
       w.note = 'gloo'
       return w
-    transport, note = _try_rccl(ws, rank)
+    if backend == 'socket':
+      if not isinstance(control, SocketControl):
+        raise RuntimeError("backend 'socket' in a process that runs torch.distributed: use 'gloo' there")
+      w = World(rank, ws, None, SocketTransport(control.client, ws, rank, staged=bool(gpus)), control=control)
+      w.note = 'socket'
+      return w
+    transport, note = _try_rccl(ws, rank, control)
     if transport is None:
+      control.close()
       raise RuntimeError('the RCCL data plane (sp_comm_* of libspartan_hip.so) did not come up: %s.  There is no '
-                         'fallback transport for tiles in HBM; set SPARTAN_DIST_BACKEND=gloo only to debug on '
+                         'fallback transport for tiles in HBM; set SPARTAN_DIST_BACKEND=socket only to debug on '
                          'one GPU.' % note)
-    w = World(rank, ws, None, transport)
+    w = World(rank, ws, None, transport, control=control)
     w.note = note
     return w
 
@@ -391,11 +570,14 @@ class World(object):
     if self.transport is not None:
       self.transport.close()
       self.transport = None
+    if self.control is not None:
+      self.control.close()                  # (rank 0 keeps its hub up until the other ranks have said goodbye)
+      self.control = None
 
   # -- primitives -------------------------------------------------------------
   def barrier(self):
     if self.distributed:
-      _dist().barrier(group=self.control)
+      self.control.barrier()
 
   def exchange(self, sends, recvs):
     """sends: [(dst_rank, tensor)], recvs: [(src_rank, tensor)]; contiguous tensors.  All ranks call this with
@@ -460,28 +642,31 @@ class World(object):
   def broadcast_object(self, obj, src):
     if not self.distributed:
       return obj
-    box = [obj if self.rank == src else None]
-    _dist().broadcast_object_list(box, src=src, group=self.control)
-    return box[0]
+    return self.control.broadcast_object(obj if self.rank == src else None, src)
 
   def all_gather_object(self, obj):
     if not self.distributed:
       return [obj]
-    out = [None] * self.size
-    _dist().all_gather_object(out, obj, group=self.control)
-    return out
+    return self.control.all_gather_object(obj)
+
+  def store(self):
+    """The job's key-value store (the heartbeat's counters and verdicts): set / get / delete, reads never block."""
+    return self.control.store()
 
 
-def _agree(ok):
-  """True iff every rank says ok (gloo)."""
-  import torch
-  dist = _dist()
-  flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-  dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-  return bool(flag.item())
+def _initialized_torch_dist():
+  """torch.distributed if the CALLER imported and initialised it; never imports torch."""
+  import sys
+  dist = sys.modules.get('torch.distributed')
+  try:
+    if dist is not None and dist.is_available() and dist.is_initialized():
+      return dist
+  except Exception:
+    pass
+  return None
 
 
-def _try_rccl(ws, rank):
+def _try_rccl(ws, rank, control):
   """Bring up the direct RCCL transport and make it prove itself; (transport, note) or (None, why not)."""
   why = ''
   transport = None
@@ -491,12 +676,22 @@ def _try_rccl(ws, rank):
       why = _hip.lib().sp_last_error().decode('utf-8', 'replace')
   except Exception as e:
     why = str(e)
+  def _agree(ok):
+    return all(control.all_gather_object(bool(ok)))
+
   if not _agree(not why):
     return None, 'sp_comm unavailable: %s' % (why or 'on another rank')
-  box = [RcclTransport.unique_id() if rank == 0 else None]
-  _dist().broadcast_object_list(box, src=0)
+  token = None
+  if rank == 0:
+    try:
+      token = ('uid', RcclTransport.unique_id())
+    except Exception as e:                 # reported to every rank: all of them stop with the reason
+      token = ('error', 'sp_comm_unique_id on rank 0: %s' % (e,))
+  kind, uid = control.broadcast_object(token, 0)
+  if kind == 'error':
+    return None, uid
   try:
-    transport = RcclTransport(ws, rank, box[0])
+    transport = RcclTransport(ws, rank, uid)
   except Exception as e:
     why = 'sp_comm_init: %s' % (e,)
   if not _agree(transport is not None):

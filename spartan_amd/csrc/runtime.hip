@@ -4,16 +4,23 @@
 // Reference counterparts: the tile store of a worker, `Worker._blobs` with create / get / update / destroy
 // (spartan/worker.py:70,126-185, spartan/blob_ctx.py:103-254) and the ZeroMQ `get` / `update` exchange between
 // workers (spartan/blob_ctx.py:163-179, spartan/rpc/zeromq.py).  A host that brings no device allocator and no
-// communication layer of its own (INTEGRATION.md's ctypes host) gets both from here; the Python host in this
-// repository uses the collectives (spartan_amd/comm.py) and lets torch's caching allocator own tile memory.
+// communication layer of its own (INTEGRATION.md's ctypes host) gets both from here; so does the Python host in this
+// repository: its tiles are blobs of this store (spartan_amd/devarray.py) and its data plane between ranks is the
+// collectives below (spartan_amd/comm.py).
 //
-// RCCL is bound at run time (dlopen "librccl.so.1"): the library keeps loading on a host without RCCL, and in a
-// process that already carries one (PyTorch bundles its own) that copy is the one used.
+// RCCL is bound at run time (dlopen): the library keeps loading on a host without RCCL.  The copy that is bound is
+// the one installed beside the HIP runtime THIS library runs on, and a copy that is linked against another HIP
+// runtime (a process may hold two: PyTorch bundles its own libamdhip64 and librccl) is refused -- device pointers,
+// streams and events handed to a collective must belong to the runtime the collective runs on.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -390,18 +397,57 @@ bool bind(void* h, const char* name, F* out) {
   return *out != nullptr;
 }
 
+// file that holds the code at `addr` (resolved: no symlinks), "" when unknown
+std::string file_of(const void* addr) {
+  Dl_info info;
+  if (!addr || !dladdr(addr, &info) || !info.dli_fname) return "";
+  char real[4096];
+  return realpath(info.dli_fname, real) ? std::string(real) : std::string(info.dli_fname);
+}
+
+// the HIP runtime this library's own calls go to
+std::string own_runtime() { return file_of((const void*)&hipGetDeviceCount); }
+
+std::string g_rccl_path, g_rccl_runtime;
+
 // 0 on success
 int rccl_load() {
   std::lock_guard<std::mutex> lock(g_rccl_mu);
   if (g_rccl.handle) return 0;
-  const char* names[] = {getenv("SPARTAN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // search order: $SPARTAN_RCCL_LIB; librccl.so.1 in the directory of the HIP runtime this library is bound to (by
+  // full path: a bare soname would resolve to whatever copy the process has mapped already -- e.g. the one PyTorch
+  // ships, linked against PyTorch's second HIP runtime); then the loader's search; then the default ROCm prefix
+  const std::string mine = own_runtime();
+  std::string beside;
+  if (!mine.empty() && mine.rfind('/') != std::string::npos) beside = mine.substr(0, mine.rfind('/')) + "/librccl.so.1";
+  const char* names[] = {getenv("SPARTAN_RCCL_LIB"), beside.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  std::string refused, last_err;
   for (const char* n : names) {
     if (!n || !*n) continue;
-    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (h) break;
+    void* cand = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!cand) {
+      const char* e = dlerror();
+      last_err = e ? e : "";
+      continue;
+    }
+    // the HIP runtime THAT copy calls into: the symbol as its own dependency tree resolves it
+    const std::string theirs = file_of(dlsym(cand, "hipGetDeviceCount"));
+    if (!mine.empty() && !theirs.empty() && theirs != mine) {
+      refused += std::string(refused.empty() ? "" : "; ") + n + " (" + file_of(dlsym(cand, "ncclGetVersion")) + ") runs on " + theirs;
+      dlclose(cand);
+      if (n == names[0]) break;          // the copy the user named: do not quietly take another one
+      continue;
+    }
+    h = cand;
+    g_rccl_runtime = theirs;
+    break;
   }
-  if (!h) SP_FAIL("RCCL is not available: dlopen(librccl.so.1) failed: %s", dlerror());
+  if (!h && !refused.empty())
+    SP_FAIL("RCCL: every copy found is linked against another HIP runtime than this library's (%s): %s.  Device "
+            "pointers and streams of one runtime mean nothing to the other; load the RCCL of this ROCm "
+            "(SPARTAN_RCCL_LIB) or keep the second runtime out of the process", mine.c_str(), refused.c_str());
+  if (!h) SP_FAIL("RCCL is not available: dlopen(librccl.so.1) failed: %s", last_err.c_str());
   Rccl r;
   r.handle = h;
   const bool ok = bind(h, "ncclGetUniqueId", &r.GetUniqueId) && bind(h, "ncclCommInitRank", &r.CommInitRank) &&
@@ -416,6 +462,7 @@ int rccl_load() {
     dlclose(h);
     SP_FAIL("the RCCL library found lacks an expected entry point");
   }
+  g_rccl_path = file_of((const void*)r.GetVersion);
   g_rccl = r;
   return 0;
 }
@@ -470,6 +517,17 @@ Comm* as_comm(void* c) { return (Comm*)c; }
 }  // namespace
 
 extern "C" int sp_comm_available(void) { return rccl_load() == 0 ? 1 : 0; }
+
+// Which files the data plane runs on: the RCCL bound, the HIP runtime that copy calls into, and the HIP runtime
+// of this library (the last two are the same file, or sp_comm_* would have refused to load it).
+extern "C" int sp_comm_paths(char* rccl_path, char* rccl_runtime_path, char* own_runtime_path, size_t each_bytes) {
+  if (!rccl_path || !rccl_runtime_path || !own_runtime_path || each_bytes < 2) SP_FAIL("sp_comm_paths: NULL / empty buffer");
+  if (rccl_load()) return 1;
+  snprintf(rccl_path, each_bytes, "%s", g_rccl_path.c_str());
+  snprintf(rccl_runtime_path, each_bytes, "%s", g_rccl_runtime.c_str());
+  snprintf(own_runtime_path, each_bytes, "%s", own_runtime().c_str());
+  return 0;
+}
 
 extern "C" int sp_comm_version(int* version) {
   if (rccl_load()) return 1;

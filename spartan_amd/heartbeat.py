@@ -9,7 +9,8 @@ worker_failed_heartbeat_threshold` (spartan/master.py:142-146), recording every 
 Here a worker is a GPU driven by one process, and "alive" means that GPU still completes work: the beat of a rank
 is a round trip through its device (an event recorded on a stream of its own and waited for -- a hung or reset GPU
 stops the beats even if the process lives).  Beats are counters in a key-value store every rank can read: the
-rendezvous store of torch.distributed when there are several ranks, a dictionary for one process.  Every rank
+store of the job's control plane when there are several ranks (`World.store()`: the rendezvous hub of rank 0,
+spartan_amd/rendezvous.py), a dictionary for one process.  Every rank
 watches every other rank, so all of them reach the same verdict without a master; a verdict is QUEUED and applied by
 the driver thread at its next safe point (`Context.apply_failures`, called when an expression starts to evaluate) --
 tile tables are never touched from the watcher thread.  Applying it is `Context.mark_failed_worker` for each logical
@@ -37,28 +38,6 @@ class _LocalStore(object):
       self._d.pop(key, None)
 
 
-class _DistStore(object):
-  """The process group's rendezvous store (TCPStore); reads of a key that was never set must not block."""
-
-  def __init__(self):
-    import torch.distributed as dist
-    self._store = dist.distributed_c10d._get_default_store()
-
-  def set(self, key, value):
-    self._store.set(key, value)
-
-  def get(self, key):
-    if not self._store.check([key]):
-      return None
-    return self._store.get(key).decode()
-
-  def delete(self, key):
-    try:
-      self._store.delete_key(key)
-    except Exception:
-      pass
-
-
 class Heartbeat(object):
   """interval: seconds between beats; threshold: missed beats after which a rank is declared failed
   (reference flags heartbeat_interval = 3, worker_failed_heartbeat_threshold = 10, spartan/cluster.py:62-63)."""
@@ -68,9 +47,10 @@ class Heartbeat(object):
     self.interval = float(interval)
     self.threshold = int(threshold)
     self.rank, self.size = ctx.world.rank, ctx.world.size
-    self.store = store if store is not None else (_DistStore() if ctx.world.distributed else _LocalStore())
+    self.store = store if store is not None else (ctx.world.store() if ctx.world.distributed else _LocalStore())
     self.probe = probe if probe is not None else getattr(ctx.backend, 'liveness_probe', lambda: True)
     self.failed_ranks = set()
+    self._given_up = set()                    # ranks in a verdict so far (agree(); identical on every rank)
     self.agree_floor_s = 15.0                 # least time the ranks wait for each other's verdicts at a safe point
     self._pending = []
     self._lock = threading.Lock()
@@ -152,7 +132,8 @@ class Heartbeat(object):
 
     The posts of safe point N - 2 are deleted when N is posted (one small key per rank and phase is alive at a time).
     Deadlines are generous -- 3 x interval x threshold, at least `agree_floor_s`: a rank that is merely slow must
-    not be declared dead; a really dead one costs the survivors this wait once."""
+    not be declared dead; a really dead one costs the survivors this wait once: ranks of an earlier verdict are
+    not waited for at later safe points, and are not reported again unless a watcher flags them anew."""
     self._round = getattr(self, '_round', 0) + 1
     n = self._round
     key = lambda phase, rnd, rank: 'spartan_hb_agree/%d/%d/%d' % (rnd, phase, rank)     # noqa: E731
@@ -183,15 +164,23 @@ class Heartbeat(object):
           union.update(int(x) for x in value.split(',') if x != '-')
       return union, waiting
 
+    # Ranks every rank gave up on at an earlier safe point (`_given_up` only changes here, by the verdict all ranks
+    # share, so it is the same set everywhere) are not waited for again: a dead rank costs the survivors the
+    # deadline ONCE.  If such a rank is still there -- it only stopped beating, or it was late -- it keeps running
+    # the same program, waits for the others itself, and its phase-1 posts are read when they happen to be there;
+    # whatever one rank read in them reaches the others through the phase-2 unions.
+    given_up = self._given_up
     others = [r for r in range(self.size) if r != self.rank]
+    counted_on = [r for r in others if r not in given_up]
     mine = set(mine)
     post(1, mine)
-    seen, absent = collect(1, others, ())
+    seen, absent = collect(1, counted_on, [r for r in others if r in given_up])
     union = mine | seen | set(absent)
     post(2, union)
-    # the unions of the ranks this one still counts on are waited for; those it gave up on are read if they exist
-    final, absent2 = collect(2, [r for r in others if r not in union], [r for r in others if r in union])
+    # the unions of the ranks this one still counts on are waited for (ranks in `union` are in everybody's union)
+    final, absent2 = collect(2, [r for r in counted_on if r not in union], ())
     verdict = union | final | set(absent2)
+    given_up.update(verdict)
     self.failed_ranks.update(r for r in verdict if r != self.rank)
     return sorted(verdict)
 

@@ -1,4 +1,5 @@
-"""One rank of an N-process CPU run (gloo, NumPy tile backend) of the K-split dot pipeline and the collective
+"""One rank of an N-process run (NumPy tile backend on CPU; with the argument `hip`: the HIP backend, all ranks
+sharing GPU 0 over the staged transport) of the K-split dot pipeline and the collective
 combines at world sizes other than 2: dot.ksplit_plan with p blocks per chunk, reduce-scatter into p pieces, the
 reductions' reduce-scatter + all-gather, a row-tiled map with a broadcast operand.  Launched by
 tests/test_multiprocess.py::test_ksplit_pipeline_more_ranks."""
@@ -15,9 +16,15 @@ from oracle.np_backend import NumpyBackend  # noqa: E402
 
 
 def main():
-  world = sp.World.from_env(backend='gloo')
+  world = sp.World.from_env(backend=os.environ.get('SPARTAN_TEST_BACKEND', 'socket'))
   p = world.size
-  ctx = sp.initialize(backend=NumpyBackend(), num_workers=p, world=world)
+  use_hip = len(sys.argv) > 1 and sys.argv[1] == 'hip'
+  if use_hip:
+    world.staged = True
+    ctx = sp.initialize('hip', num_workers=p, world=world)
+    assert ctx.backend.name == 'hip'
+  else:
+    ctx = sp.initialize(backend=NumpyBackend(), num_workers=p, world=world)
   rng = np.random.RandomState(5)
   m, k, n = 6 * p, 8 * p, 40            # (a wide or square left operand takes the map2 join; a tall one the outer path)
   a = rng.randint(-4, 5, size=(m, k)).astype(np.float32)
@@ -51,13 +58,17 @@ def main():
   # one k-means iteration with the points over p ranks against NumPy
   from scipy.spatial.distance import cdist
   from spartan_amd.examples.sklearn.cluster import KMeans
-  pts = rng.rand(16 * p, 6)
+  pts = rng.rand(16 * p, 6).astype(np.float32 if use_hip else np.float64)
   c0 = pts[:5].copy()
   centers, labels = KMeans(5, 1).fit(sp.from_numpy(pts, tile_hint=(16, 6)), c0, implementation='map2', reducer=np.add)
   want_labels = np.argmin(cdist(pts, c0), axis=1)
   np.testing.assert_array_equal(labels.glom().reshape(-1), want_labels)
   want = np.stack([pts[want_labels == c].sum(0) / max(1, (want_labels == c).sum()) for c in range(5)])
-  np.testing.assert_allclose(centers, want, rtol=1e-12)
+  np.testing.assert_allclose(centers, want, rtol=2e-6 if use_hip else 1e-12)
+  if use_hip:
+    assert ctx.backend.launches > 0
+  if world.control.name == 'socket':
+    assert 'torch' not in sys.modules, 'the socket control plane must not bring torch in'
   world.barrier()
   print('RANK %d OK' % world.rank)
   sys.stdout.flush()

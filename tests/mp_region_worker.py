@@ -13,7 +13,7 @@ from oracle.np_backend import NumpyBackend  # noqa: E402
 def main():
   workers = int(sys.argv[1])
   use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
-  world = sp.World.from_env(backend='gloo')
+  world = sp.World.from_env(backend=os.environ.get('SPARTAN_TEST_BACKEND', 'socket'))
   assert world.size == 2
   if use_hip:
     world.staged = True

@@ -212,7 +212,7 @@ def run_rowdot(ctx):
 def main():
   workers = int(sys.argv[1])
   use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
-  world = sp.World.from_env(backend='gloo')
+  world = sp.World.from_env(backend=os.environ.get('SPARTAN_TEST_BACKEND', 'socket'))
   assert world.size == 2
   if use_hip:
     # two ranks sharing GPU 0, HBM blobs staged through the host by the debug transport
@@ -280,6 +280,8 @@ def main():
   n += run_rowdot(ctx)
   if not use_hip:
     n += run_heartbeat(world)
+  if world.control.name == 'socket':
+    assert 'torch' not in sys.modules, 'the socket control plane must not bring torch in'
   world.barrier()
   print('RANK %d OK %d' % (world.rank, n))
   sys.stdout.flush()

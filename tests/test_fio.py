@@ -262,6 +262,13 @@ def test_heartbeat_second_failure_of_a_recovered_rank_and_agreement_without_the_
     [t.join(10) for t in ts]
     assert out[0] == out[1] == [1, 2], out                               # union of the posts + the rank that never came
     assert time.time() - t0 < 5
+    # the dead rank costs that wait ONCE: the next safe point does not wait for it and reports nothing new
+    ts = [threading.Thread(target=lambda i=i: out.__setitem__(i, hbs[i].agree([]))) for i in range(2)]
+    t0 = time.time()
+    [t.start() for t in ts]
+    [t.join(10) for t in ts]
+    assert out[0] == out[1] == [], out
+    assert time.time() - t0 < 0.3, time.time() - t0
     # (iii) a live rank that reaches the safe point AFTER the others gave up on it finds their posts, reads that it
     # was given up on, and arrives at the same verdict (it marks its own workers' tiles bad like everyone else)
     store = heartbeat._LocalStore()
