@@ -43,6 +43,7 @@ _EXTRAS = {
     'partial_load': 'expr.fio', 'partial_unpickle': 'expr.fio', 'pickle': 'expr.fio', 'save': 'expr.fio',
     'unpickle': 'expr.fio', 'tile_operation': 'expr.tile_operation', 'checkpoint': 'expr.checkpoint',
     'stencil': 'expr.stencil', 'maxpool': 'expr.stencil', '_convolve': 'expr.stencil',
+    'assign': 'expr.region', 'region_map': 'expr.region', 'retile': 'expr.region',
 }
 
 

@@ -925,7 +925,11 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
   try:
     for tile_id in tile_ids:
       ctx.current_worker = tile_id.worker          # (Context.on_worker, without the context manager)
-      res = invoke(tile_id, blobs.get(tile_id), mapper_fn, kw)
+      blob = blobs.get(tile_id)
+      if blob is None and ctx.is_local(tile_id):
+        raise KeyError('tile %r of a worker of this rank is not in the tile store (dropped by a failure that the '
+                       'array has not recorded as a bad tile?)' % (tile_id,))
+      res = invoke(tile_id, blob, mapper_fn, kw)
       if res is None:
         continue
       results[tile_id] = res.result

@@ -620,8 +620,11 @@ class DevArray(object):
     return impl(*args, **kwargs)
 
   def __getattr__(self, name):
-    # (only reached for names the class does not define)
-    raise DeviceTileCannot('device arrays have no attribute %r' % name)
+    # (only reached for names the class does not define)  An ndarray attribute that has no device form sends a
+    # user's tile function to the host path; anything else is a mistake in the caller and says so.
+    if hasattr(np.ndarray, name):
+      raise DeviceTileCannot('ndarray.%s is not implemented for device arrays' % name)
+    raise AttributeError('%s object has no attribute %r' % (type(self).__name__, name))
 
 
 _UFUNC_REDUCE = {np.add: 'SUM', np.multiply: 'PROD', np.maximum: 'MAX', np.minimum: 'MIN',

@@ -163,6 +163,8 @@ def region_join_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target
   function returns ONE (extent, data) pair and `data` overwrites the cell's part under the first box it meets."""
   ctx = context.get()
   cell = extent.change_partition_axis(ex, axes[0])
+  if cell is None:                                   # more tiles than grid cells: nothing to do for this one
+    return LocalKernelResult(result=[])
   data = arrays[0].fetch(cell)
   for box in region:
     hit = extent.intersection(box, cell)

@@ -59,6 +59,16 @@ def layout_token(array):
   return tok
 
 
+def _scalar_key(v):
+  """A Python / NumPy scalar by VALUE as the kernels see it: floats by their bits (0.0 and -0.0 are two operands, and
+  a NaN equals itself here)."""
+  if isinstance(v, float):
+    return v.hex()
+  if isinstance(v, complex):
+    return (v.real.hex(), v.imag.hex())
+  return v
+
+
 def _describe_value(v, pins):
   """Key of a leaf VALUE (what the rewrites may depend on, not the data)."""
   if isinstance(v, distarray.DistArrayImpl):
@@ -74,9 +84,9 @@ def _describe_value(v, pins):
   if hasattr(v, 'data_ptr') and hasattr(v, 'strides'):       # a backend tensor used as a driver-side operand
     return ('B', tuple(v.shape), np.dtype(v.dtype).str)
   if isinstance(v, np.generic):
-    return ('G', v.dtype.str, v.item())
+    return ('G', v.dtype.str, _scalar_key(v.item()))
   if isinstance(v, _SIMPLE):
-    return ('S', type(v).__name__, v)
+    return ('S', type(v).__name__, _scalar_key(v))
   raise Unplannable('leaf value of type %s' % type(v).__name__)
 
 
@@ -88,6 +98,7 @@ class _Walk(object):
     self.seen = {}            # id(node) -> position (a node reached twice is one node)
     self.values = {}          # id(array at a leaf) -> order of appearance (the same array behind two leaves)
     self.names = {}           # variable name -> order of appearance
+    self.in_local = 0         # > 0 while inside an operator tree (those are SHARED between the instances of a plan)
 
   def alias(self, value):
     if not isinstance(value, (np.ndarray, distarray.DistArray)):
@@ -128,7 +139,16 @@ class _Walk(object):
     if isinstance(op, FnCallExpr):
       self.pins.append(op.fn)
       local = self.local
-      return (type(op), id(op.fn), self.field(op.kw) if op.kw else None, tuple([local(d) for d in op.deps]))
+      # An operator tree is shared by every instance of the plan (the backend keys its lowered programs by the
+      # operator object), so nothing inside it may differ between two DAGs with one key: scalars are in the key
+      # by value; an ARRAY among the keyword values (fn_kw={'w': array}) has no place in the key and cannot be
+      # swapped per instance -- such a DAG is optimised the long way every time.
+      self.in_local += 1
+      try:
+        kw = self.field(op.kw) if op.kw else None
+      finally:
+        self.in_local -= 1
+      return (type(op), id(op.fn), kw, tuple([local(d) for d in op.deps]))
     if isinstance(op, LocalInput):
       return ('i', self.var(op.idx) if op.idx.startswith('key_') else op.idx)
     raise Unplannable('local expression %s' % type(op).__name__)
@@ -138,6 +158,8 @@ class _Walk(object):
     if t in _SIMPLE_SET:
       if t is str and v.startswith('key_'):
         return ('v', self.var(v))
+      if t is float or t is complex:
+        return (t, _scalar_key(v))
       return (t, v)
     if isinstance(v, Expr):
       return self.node(v)
@@ -149,6 +171,8 @@ class _Walk(object):
     if t is dict:
       return ('dict', tuple([(k, self.field(x)) for k, x in sorted(v.items(), key=_by_name)]))
     if isinstance(v, (np.ndarray, distarray.DistArrayImpl)) or (hasattr(v, 'data_ptr') and hasattr(v, 'strides')):
+      if self.in_local:
+        raise Unplannable('an array inside the keywords of an operator tree')
       first = self.seen.get(id(v))
       if first is not None:
         return ('@', first)                 # the same object again: the recipe maps it to one slot
@@ -156,7 +180,7 @@ class _Walk(object):
       self.leaves.append(v)
       return ('L', _describe_value(v, self.pins), self.alias(v))
     if isinstance(v, _SIMPLE):
-      return (t, v)
+      return (t, _scalar_key(v))
     if isinstance(v, (tuple, list)):
       return (t, tuple([self.field(x) for x in v]))
     if isinstance(v, dict):
@@ -166,7 +190,7 @@ class _Walk(object):
     if isinstance(v, slice):
       return ('sl', v.start, v.stop, v.step)
     if isinstance(v, np.generic):
-      return ('G', v.dtype.str, v.item())
+      return ('G', v.dtype.str, _scalar_key(v.item()))
     if isinstance(v, (np.dtype, type)):
       return ('T', str(v))
     if callable(v):

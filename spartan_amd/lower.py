@@ -71,13 +71,19 @@ def _dummy(v):
 _result_dtypes = {}
 
 
-def _weak_key(value):
+def _weak_key(value, by_value=False):
   """What a weak Python scalar contributes to a result dtype (NEP 50): its kind -- its value only where it could
-  overflow the other operand's integer type."""
+  overflow the other operand's integer type (by_value: an operand narrower than int32, unsigned or bool is in the
+  operation: uint8 + 300 and uint8 + (-1) are refused by NumPy, uint8 + 1 is uint8)."""
   t = type(value)
-  if t is float or t is bool or (t is int and -2147483648 <= value < 2147483648):
+  if t is float or t is bool or (t is int and not by_value and -2147483648 <= value < 2147483648):
     return ('weak', t)
   return (t, value)
+
+
+def _narrow_int(dtype):
+  dt = np.dtype(dtype)
+  return dt.kind in 'ub' or (dt.kind == 'i' and dt.itemsize < 4)
 
 
 def warm_result_dtypes():
@@ -123,7 +129,8 @@ def apply(opname, np_fn, args):
   # NumPy's own answer, asked once per (function, operand types): the dummy call costs tens of microseconds
   # (np.errstate alone ~10), a fused tree has one per operator, and a driver loop lowers the same trees for ever
   try:
-    key = (np_fn, tuple([_weak_key(a.value) if (a.kind == 'const' and a.weak) else a.dtype for a in args]))
+    by_value = any(_narrow_int(a.dtype) for a in args if not (a.kind == 'const' and a.weak))
+    key = (np_fn, tuple([_weak_key(a.value, by_value) if (a.kind == 'const' and a.weak) else a.dtype for a in args]))
     dt = _result_dtypes.get(key)
   except TypeError:
     key = dt = None

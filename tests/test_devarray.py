@@ -116,7 +116,10 @@ def test_device_tile_cannot_is_the_only_fallback_signal():
   with pytest.raises(D.DeviceTileCannot):
     d[np.array([0, 2])]                     # index arrays
   with pytest.raises(D.DeviceTileCannot):
-    d.no_such_method
+    d.cumsum                                # an ndarray attribute without a device form
+  with pytest.raises(AttributeError) as info:
+    d.no_such_method                        # a typo is the caller's error, not a reason to fall back to the host
+  assert not isinstance(info.value, D.DeviceTileCannot)
   with pytest.raises(D.DeviceTileCannot):
     np.add.accumulate(d)                    # a ufunc method without a kernel
   assert not hasattr(d, 'no_such_method') and hasattr(d, 'reshape')

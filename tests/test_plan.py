@@ -222,3 +222,32 @@ def test_prelowering_can_be_switched_off_and_skips_what_cannot_be_replayed(hip_c
   # inputs that are expressions themselves: the inner map is prepared, the outer one when its input exists
   h = sp.sum(A * A + 1.0, axis=0).optimized()
   np.testing.assert_allclose(h.glom(), (_arr(23, (64, 48)) ** 2 + 1).sum(axis=0), rtol=1e-6)
+
+
+def test_an_array_inside_fn_kw_is_never_answered_from_a_plan(ctx):
+  """A map whose keywords hold an array (fn_kw={'w': array}): the operator tree of a plan is shared between its
+  instances, so the array cannot be swapped per instance -- every such DAG is optimised the long way and computes
+  with ITS array, plain and fused into a larger tree."""
+  a = _arr(7, (6, 8))
+  A = sp.from_numpy(a)
+
+  def f(x, w):
+    return x + w
+  for i in range(3):
+    w = np.full((1, 8), i, np.float32)
+    np.testing.assert_array_equal(sp.map(A, fn=f, fn_kw={'w': w}).optimized().glom(), a + i)
+    np.testing.assert_array_equal(((sp.map(A, fn=f, fn_kw={'w': w}) * 2) + A).optimized().glom(), (a + i) * 2 + a)
+  assert plan.stats['hits'] == 0 and plan.stats['unplannable'] == 6, plan.stats
+
+
+def test_signed_zero_and_nan_scalars_are_keyed_by_their_bits(ctx):
+  a = np.array([[1.0, -2.0, 0.0]], np.float32)
+  A = sp.from_numpy(a)
+  pos = (A * 0.0).optimized().glom()
+  neg = (A * -0.0).optimized().glom()
+  np.testing.assert_array_equal(np.signbit(pos), np.signbit(a * np.float32(0.0)))
+  np.testing.assert_array_equal(np.signbit(neg), np.signbit(a * np.float32(-0.0)))
+  assert plan.stats['misses'] == 2 and plan.stats['hits'] == 0
+  for _ in range(2):
+    assert np.isnan((A + float('nan')).optimized().glom()).all()
+  assert plan.stats['misses'] == 3 and plan.stats['hits'] == 1          # a NaN equals itself in the key

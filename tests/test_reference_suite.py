@@ -96,6 +96,27 @@ def check_manipulation():
   np.testing.assert_array_equal(x.ravel().glom(), np.arange(100 * 100).astype(x.glom().dtype))
 
 
+def check_assign():
+  """The cases of the reference's tests/test_assign.py:10-83."""
+  a, b = np.zeros((20, 10)), np.ones((10,))
+  got = expr.assign(expr.from_numpy(a), np.s_[10, ], b).glom()
+  a[np.s_[10, ]] = b
+  np.testing.assert_array_equal(got, a)
+  b = RNG.randn(100)
+  sp_b = expr.from_numpy(b)
+  for ra, rb in [(np.s_[0:100], np.s_[0:100]), (np.s_[0], np.s_[1]), (np.s_[0:10], np.s_[20:30]), (np.s_[30:60], np.s_[0:30])]:
+    a = RNG.randn(100)
+    got = expr.assign(expr.from_numpy(a), ra, sp_b[rb]).glom()
+    a[ra] = b[rb]
+    np.testing.assert_array_equal(got, a)
+  for shape, region, vshape in [((20, 10), np.s_[10, ], (10,)), ((200, 100), np.s_[50, ], (100,)),
+                                ((200, 100), np.s_[99:102, 25:75], (3, 50))]:
+    a, v = RNG.randn(*shape), RNG.randn(*vshape)
+    got = expr.assign(expr.from_numpy(a), region, expr.from_numpy(v)).glom()
+    a[region] = v
+    np.testing.assert_array_equal(got, a)
+
+
 def check_write():
   """tests/test_write.py:30-70 (the from_file cases :9-28 live in test_fio.py)."""
   npa = RNG.rand(100, 100)
@@ -122,7 +143,7 @@ def check_write():
 
 
 def check_transpose_and_region_map(workers):
-  """tests/test_transpose.py:9-38 (dense cases)."""
+  """tests/test_transpose.py:9-38 (dense cases), test_tile_sharing.py:8-19."""
   t1 = expr.arange((372, 134))
   np.testing.assert_array_equal(expr.transpose(t1).glom(), np.arange(372 * 134, dtype=np.float64).reshape(372, 134).T)
   t3 = expr.arange((11, 12, 13))
@@ -130,6 +151,13 @@ def check_transpose_and_region_map(workers):
   m1, m2 = RNG.rand(401, 97), RNG.rand(401, 97)
   got = expr.dot(expr.from_numpy(m1), expr.transpose(expr.from_numpy(m2))).glom()
   assert np.all(np.isclose(got, np.dot(m1, m2.T)))
+  n = 5 * workers
+  x = expr.ones((n, 1), tile_hint=(n // workers, 1))
+  y = expr.region_map(x, extent.create((0, 0), (3, 1), (n, 1)), fn=lambda data, ex, a: data + a, fn_kw={'a': 1})
+  want = np.ones((n, 1), np.float32)
+  np.testing.assert_array_equal(x.glom(), want)
+  want[0:3, 0] += 1
+  np.testing.assert_array_equal(y.glom(), want)
 
 
 def check_slices_and_user_functions():
@@ -240,7 +268,7 @@ def check_array_indexing():
 
 
 CHECKS = [check_array_indexing, check_scan, check_reshape, check_example_runs, check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
-          check_statistics, check_manipulation, check_write]
+          check_statistics, check_manipulation, check_assign, check_write]
 
 
 @pytest.mark.parametrize('workers', [1, 4])
@@ -268,14 +296,14 @@ def test_reference_suite_hip(check, workers):
 def test_every_name_the_reference_exports_exists():
   """spartan/expr/__init__.py:26-65 (the flat builder namespace), listed here so the check needs no reference tree;
   without the manipulation / statistics helpers that are outside the tile path (diagonal, diag, diagflat,
-  concatenate, bincount, normalize, norm; assign, region_map, retile)."""
+  concatenate, bincount, normalize, norm)."""
   names = '''astype tocoo size empty sparse_empty empty_like zeros zeros_like ones ones_like eye identity full full_like
   arange sparse_diagonal all any equal not_equal greater greater_equal less less_equal
   logical_and logical_or logical_xor ravel add sub multiply divide true_divide floor_divide reciprocal
   negative fmod mod remainder power ln log square sqrt exp abs maximum minimum sum prod set_random_seed rand randn
-  randint sparse_rand max min mean std norm_cdf argmin argmax count_nonzero count_zero
-  dot save load pickle unpickle partial_load partial_unpickle Expr evaluate optimized_dag eager lazify as_array
-  glom NotShapeable newaxis broadcast checkpoint map map2 map_with_location ndarray outer optimize reshape
+  randint sparse_rand max min mean std norm_cdf argmin argmax count_nonzero count_zero assign
+  retile dot save load pickle unpickle partial_load partial_unpickle Expr evaluate optimized_dag eager lazify as_array
+  glom NotShapeable newaxis broadcast checkpoint map map2 map_with_location ndarray outer optimize region_map reshape
   reduce sort argsort argpartition partition shuffle scan stencil maxpool _convolve tile_operation transpose write
   from_numpy from_file from_file_parallel'''.split()
   import spartan_amd
