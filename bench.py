@@ -113,6 +113,11 @@ def event_time(fn, iters, warmup=4, section=None):
     fn()
   e1.record()
   e1.synchronize()
+  if os.environ.get('SP_BENCH_TRACE'):
+    import gc
+    live, pooled = D.blob_stats()
+    sys.stderr.write('event_time %s: %.3f ms/call, live blobs %d, pooled %.1f GiB, gc %s\n'
+                     % (section[0] if section else '-', e0.elapsed_ms(e1) / iters, live, pooled / 2.0 ** 30, gc.get_count()))
   if section is not None:
     per_call = section[5] if len(section) > 5 else 1
     note_section(section[0], section[1], (warmup + 1 + iters) * per_call, section[2], section[3], section[4], t0, clocks())
@@ -155,6 +160,17 @@ def hbm_section(ctx):
   del pending
   ms = event_time(chain, 10)
   out['map_5op_chain_jit_GBps'] = round(8.0 * n / ms / 1e6, 1)
+  # the fused map -> reduce the same way: its first launch of the process, alone on an idle device (seeded by
+  # build(): specialised at once; an unseeded program starts on the interpreter tier below)
+  first = sp.sum((Xv - 0.5) * (Xv - 0.5), axis=0).optimized()
+  D.synchronize()
+  e0, e1 = D.Event(), D.Event()
+  e0.record()
+  first.force()
+  e1.record()
+  e1.synchronize()
+  out['sum_sq_dev_axis0_first_call_GBps'] = round(4.0 * n / e0.elapsed_ms(e1) / 1e6, 1)
+  del first
   ms = event_time(lambda: sp.sum((Xv - 0.5) * (Xv - 0.5), axis=0).optimized().force(), 10)
   out['sum_sq_dev_axis0_jit_GBps'] = round(4.0 * n / ms / 1e6, 1)
   # the same two programs on the interpreter tier (what a program nobody seeded runs on until hipRTC is done, and
@@ -174,6 +190,13 @@ def hbm_section(ctx):
   ms = event_time(lambda: sp.argmax(Xv, 1).force(), 10,
                   section=('argmax axis=1', 'sp_reduce_rows_kernel', 4.0 * n, 'bytes', 'hbm'))
   out['argmax_axis1_GBps'] = round(4.0 * n / ms / 1e6, 1)
+  # the rest of SURVEY 8d's C3 list: the index reductions along the other axes, max / min (4*E bytes each)
+  for name, build in (('argmax_axisNone', lambda: sp.argmax(Xv)), ('argmax_axis0', lambda: sp.argmax(Xv, 0)),
+                      ('argmin_axis1', lambda: sp.argmin(Xv, 1)), ('max_axisNone', lambda: sp.max(Xv)),
+                      ('max_axis0', lambda: sp.max(Xv, 0)), ('max_axis1', lambda: sp.max(Xv, 1)),
+                      ('min_axisNone', lambda: sp.min(Xv)), ('min_axis0', lambda: sp.min(Xv, 0))):
+    ms = event_time(lambda: build().force(), 10)
+    out[name + '_GBps'] = round(4.0 * n / ms / 1e6, 1)
   del X, Xv, x
   D.trim_pool()
   # the reference's DEFAULT dtype is float64 (its builders make np.float arrays): same tile shape halved
@@ -191,6 +214,55 @@ def hbm_section(ctx):
                                   if k.endswith('_GBps') and k != 'stream_copy_GBps'}
   out['hbm_peak_GBps'] = HBM_PEAK_GBPS
   out['tile'] = '%dx%d fp32' % (rows, cols)
+  return out
+
+
+def probed_peaks():
+  """Dense matrix-pipe rates measured on THIS GPU by tools/mfma_peak_probe (built by __graft_entry__.build()): every CU
+  issuing nothing but independent MFMAs.  {} when the probe is not there."""
+  import subprocess
+  exe = os.path.join(ROOT, 'tools', 'mfma_peak_probe')
+  if not os.path.exists(exe):
+    return {}
+  D.synchronize()
+  try:
+    text = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120).stdout.decode()
+  except Exception:
+    return {}
+  best = {}
+  for line in text.splitlines():
+    if line.startswith('PROBE '):
+      f = dict(kv.split('=') for kv in line.split()[2:])
+      name = line.split()[1]
+      best[name] = max(best.get(name, 0.0), float(f['TFLOPs']))
+  return best
+
+
+MFMA_F64_SPEC_TFLOPS = 78.6     # AMD's MI355X figure for the fp64 matrix pipe (not in MI355X_MICROARCH.md: probed below)
+
+
+def dot_f64_section(ctx):
+  """The reference's own dot benchmark is float64 (tests/benchmark_dot.py:17-27, np.double on a sqrt(p) x sqrt(p)
+  grid; its builders default to float64): spartan.dot 8192^3 fp64 on one tile and on the benchmark's 2 x 2 grid of
+  4096^2 tiles, against the fp64 matrix rate PROBED on this GPU (a loop of v_mfma_f64_16x16x4_f64 on every CU)."""
+  n = 8192
+  mk = lambda seed, hint=None: sp.astype(sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, seed),   # noqa: E731
+                                                          tile_hint=hint), np.float64).force()
+  peaks = probed_peaks()
+  probed = peaks.get('v_mfma_f64_16x16x4_f64')
+  peak = probed or MFMA_F64_SPEC_TFLOPS
+  A, B = mk(SEED + 51), mk(SEED + 52)
+  Av, Bv = sp.Val(val=A), sp.Val(val=B)
+  flop = 2.0 * n * n * n
+  ms = event_time(lambda: sp.dot(Av, Bv).force(), 5, warmup=2, section=('dot 8192^3 fp64', 'sp_dgemm_kernel', flop, 'flop', 'mfma_f64'))
+  out = {'workload': 'spartan.dot %dx%dx%d fp64, one tile' % (n, n, n), 'ms_per_call': round(ms, 3),
+         'TFLOPs': round(flop / ms / 1e9, 2), 'peak_TFLOPs': round(peak, 2),
+         'peak_is': ('probed on this GPU (tools/mfma_peak_probe: v_mfma_f64_16x16x4_f64 on every CU; the same probe gives '
+                     '%.1f TFLOP/s for v_mfma_f32_32x32x2_f32)' % peaks.get('v_mfma_f32_32x32x2_f32', float('nan')))
+         if probed else 'spec (probe binary not built)',
+         'frac_of_f64_mfma_peak': round(flop / ms / 1e9 / peak, 4)}
+  del A, B, Av, Bv
+  D.trim_pool()
   return out
 
 
@@ -289,8 +361,9 @@ def kmeans_section(ctx):
                   section=('k-means assign (first pass, bf16-split MFMA)', 'sp_nearest_split_kernel<false, false,', 3.0 * flop, 'flop', 'mfma_bf16'))
   out['assign_ms'] = round(ms, 3)
   out['assign_TFLOPs'] = round(flop / ms / 1e9, 1)                      # useful fp32 flops per second
-  # (above 1: the contraction does not run on the fp32 matrix pipe this peak belongs to)
-  out['assign_frac_of_mfma_peak'] = round(flop / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)
+  # information only, NOT a roofline fraction (above 1: the contraction does not run on the fp32 matrix pipe this
+  # peak belongs to); the fraction of the pipe it does run on is assign_split.frac_of_bf16_peak
+  out['assign_useful_flops_over_fp32_mfma_peak'] = round(flop / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 3)
   out['assign_split'] = {'instruction': 'v_mfma_f32_32x32x16_bf16 x 3 per 16 features (hi*hi, hi*mid, mid*hi), fp32 accumulate',
                          'issued_TFLOPs': round(3.0 * flop / ms / 1e9, 1), 'bf16_peak_TFLOPs': MFMA_BF16_PEAK_TFLOPS,
                          'frac_of_bf16_peak': round(3.0 * flop / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)}
@@ -378,12 +451,12 @@ def sparse_section(ctx):
   return out
 
 
-def dist_section(ctx):
-  """N > 1: BASELINE configs[2] -- an array of N row tiles of 8192 x 65536 fp32 (2 GiB per GPU), reduced along
+def dist_section(ctx, p=None):
+  """N > 1 (p = None) or ONE GPU hosting p logical workers: BASELINE configs[2] -- an array of N row tiles of 8192 x 65536 fp32 (2 GiB per GPU), reduced along
   every axis through the expression API: the per-tile kernels plus the RCCL combine (reduce to the owner for
   axis=None, reduce-scatter for axis=0, nothing for axis=1 / argmax axis=1 / the fused map).  GB/s = whole-job
   algorithmic bytes / wall-clock, barrier + synchronize on both sides, max over ranks."""
-  p = ctx.world.size
+  p = p or ctx.world.size
   R = int(os.environ.get('SPARTAN_BENCH_DIST_ROWS', '8192'))
   C = 65536
   X = sp.from_tile_fn((R * p, C), np.float32, lambda ex: device_uniform(ex, 0.0, 1.0, SEED + 41), tile_hint=(R, C)).force()
@@ -392,7 +465,8 @@ def dist_section(ctx):
   out = {'array': '%d x %d fp32, %d row tiles of %d x %d' % (R * p, C, p, R, C)}
   keep = []
   progs = (('sum_axisNone', lambda: sp.sum(Xv), 4.0), ('sum_axis0', lambda: sp.sum(Xv, 0), 4.0),
-           ('sum_axis1', lambda: sp.sum(Xv, 1), 4.0), ('argmax_axis1', lambda: sp.argmax(Xv, 1), 4.0),
+           ('sum_axis1', lambda: sp.sum(Xv, 1), 4.0), ('argmax_axisNone', lambda: sp.argmax(Xv), 4.0),
+           ('argmax_axis0', lambda: sp.argmax(Xv, 0), 4.0), ('argmax_axis1', lambda: sp.argmax(Xv, 1), 4.0),
            ('map_xx_plus_x', lambda: (Xv * Xv + Xv).optimized(), 8.0))
   for name, build, bpe in progs:
     def step():
@@ -403,12 +477,12 @@ def dist_section(ctx):
   return out
 
 
-def lreg_dist_section(ctx):
-  """N > 1: BASELINE configs[4] -- X 1 000 000 x 4096 fp32 row-tiled over the N GPUs (strong scaling: rows / N per
+def lreg_dist_section(ctx, p=None, steps=None):
+  """N > 1 (p = None) or one GPU hosting p logical workers: BASELINE configs[4] -- X 1 000 000 x 4096 fp32 row-tiled over the N GPUs (strong scaling: rows / N per
   GPU), 100 gradient steps after 2 untimed ones through examples/lreg.fit: per step one pass over the rank's rows,
   the (D,) partial gradients combined by reduce-scatter + all-gather (glom), w updated on every rank's driver."""
   from spartan_amd.examples import lreg
-  p = ctx.world.size
+  p = p or ctx.world.size
   N = int(os.environ.get('SPARTAN_BENCH_LREG_ROWS', '1000000'))
   Dm = int(os.environ.get('SPARTAN_BENCH_LREG_COLS', '4096'))
   N -= N % p
@@ -419,7 +493,7 @@ def lreg_dist_section(ctx):
   w = ctx.world.broadcast_object(np.random.RandomState(SEED).rand(Dm, 1).astype(np.float32), 0)
   alpha = 1e-11
   w = lreg.fit(Xv, yv, 2, alpha=alpha, w=w)
-  steps = int(os.environ.get('SPARTAN_BENCH_LREG_STEPS', '100'))
+  steps = steps or int(os.environ.get('SPARTAN_BENCH_LREG_STEPS', '100'))
   box = [w]
 
   def run():
@@ -432,12 +506,12 @@ def lreg_dist_section(ctx):
           'weights_finite': bool(np.isfinite(box[0]).all())}
 
 
-def kmeans_dist_section(ctx):
-  """N > 1: BASELINE configs[3] -- 10 000 000 x 256 fp32 points row-tiled over the N GPUs, k = 1024: 10 timed
+def kmeans_dist_section(ctx, p=None):
+  """N > 1 (p = None) or one GPU hosting p logical workers: BASELINE configs[3] -- 10 000 000 x 256 fp32 points row-tiled over the N GPUs, k = 1024: 10 timed
   Lloyd iterations after 2 untimed ones through KMeans.fit ('map2', reducer np.add): assign + accumulate per tile,
   counts and sums combined across the ranks, centers re-derived on every rank's driver."""
   from spartan_amd.examples.sklearn.cluster import KMeans
-  p = ctx.world.size
+  p = p or ctx.world.size
   n = int(os.environ.get('SPARTAN_BENCH_KMEANS_POINTS', '10000000'))
   k, d = int(os.environ.get('SPARTAN_BENCH_KMEANS_K', '1024')), 256
   n -= n % p
@@ -717,6 +791,44 @@ def cpu_baseline():
           'wall_seconds': round(time.perf_counter() - t_all, 1)}
 
 
+def one_gpu_8_tiles_section(line):
+  """The WHOLE arrays of BASELINE configs[2] / [3] / [4] on this one GPU as 8 logical workers (16 GiB, 10 GB and
+  16 GB: they fit 288 GB): the per-tile kernels PLUS the combine between tiles (update / merge with the reducer,
+  the gather of glom) that the one-tile sections never run -- what the reference's runner does when it sweeps the
+  worker count on one machine (tests/test_common.py:98-120).  Rates are whole-array algorithmic bytes / wall-clock;
+  `vs_one_tile` divides them by the same program's one-tile rate from the sections above, so the cost of the
+  combine is a number the driver sees."""
+  sp.shutdown()
+  D.trim_pool()
+  ctx8 = sp.initialize('hip', num_workers=8)
+  out = {'workers': 8}
+  try:
+    out['hbm'] = dist_section(ctx8, 8)
+    D.trim_pool()
+    out['lreg'] = lreg_dist_section(ctx8, 8, steps=20)
+    D.trim_pool()
+    out['kmeans'] = kmeans_dist_section(ctx8, 8)
+    D.trim_pool()
+    hbm1 = line.get('hbm') or {}
+    rel = {}
+    for key, one in (('sum_axisNone_GBps', 'sum_axisNone_GBps'), ('sum_axis0_GBps', 'sum_axis0_GBps'),
+                     ('sum_axis1_GBps', 'sum_axis1_GBps'), ('argmax_axisNone_GBps', 'argmax_axisNone_GBps'),
+                     ('argmax_axis0_GBps', 'argmax_axis0_GBps'), ('argmax_axis1_GBps', 'argmax_axis1_GBps'),
+                     ('map_xx_plus_x_GBps', 'map_xx_plus_x_GBps')):
+      if key in out['hbm'] and hbm1.get(one):
+        rel[key[:-5]] = round(out['hbm'][key] / hbm1[one], 3)
+    if (line.get('lreg') or {}).get('GBps'):
+      rel['lreg_streamed'] = round(out['lreg']['streamed_GBps'] / line['lreg']['GBps'], 3)
+    if (line.get('kmeans') or {}).get('iteration_ms'):
+      # 8 tiles of the one-tile section's size: 8 x its iteration time is the no-overhead figure
+      rel['kmeans_iteration'] = round(8 * line['kmeans']['iteration_ms'] / out['kmeans']['iteration_ms'], 3)
+    out['vs_one_tile'] = rel
+  finally:
+    sp.shutdown()
+    D.trim_pool()
+  return out
+
+
 def measured_traffic(n):
   """HBM bytes per GEMM launch from the PMC passes tools/profile_round.sh took (profiles/roofline_traffic.json),
   quoted only if those passes ran on THIS tree (the kernel sources' hash matches); else None + why."""
@@ -839,7 +951,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--size', type=int, default=0, help='matrix order (default: 8192 on one GPU, 32768 on several)')
   ap.add_argument('--no-extras', action='store_true', help='headline only: skip the HBM / workload / emulation / CPU sections')
-  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,host,lreg,kmeans,sparse,ksplit,cpu; N > 1: hbm_dist,lreg_dist,kmeans_dist)')
+  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,dot_f64,host,lreg,kmeans,sparse,ksplit,tiles8,cpu; N > 1: hbm_dist,lreg_dist,kmeans_dist)')
   ap.add_argument('--deadline', type=int, default=1500, help='seconds the self-launched ranks of --gpus N > 1 may take')
   args = ap.parse_args()
 
@@ -948,6 +1060,9 @@ def main():
     if want('hbm'):
       line['hbm'] = hbm_section(ctx)
       D.trim_pool()
+    if want('dot_f64'):
+      line['dot_f64'] = dot_f64_section(ctx)
+      D.trim_pool()
     if want('host'):
       line['host'] = host_section(ctx)
     if want('lreg'):
@@ -965,6 +1080,7 @@ def main():
       D.trim_pool()
     if want('cpu'):
       line['cpu_baseline'] = cpu_baseline()
+    tiles8 = want('tiles8')
     # the second half of the metric and the north-star shape, inside `roofline` (the object the driver keeps whole):
     # every HBM-bound section as GB/s and as a fraction of the copy rate measured in this run and of the 8 TB/s spec
     ns = line.get('northstar_%d' % NORTH_STAR)
@@ -986,12 +1102,21 @@ def main():
       line['roofline']['hbm_sections'] = {'measured_copy_GBps': copy, 'spec_GBps': HBM_PEAK_GBPS, 'sections': sections}
     km = line.get('kmeans')
     if km and 'assign_TFLOPs' in km:
-      line['roofline']['kmeans_assign'] = {'TFLOPs': km['assign_TFLOPs'], 'frac': km['assign_frac_of_mfma_peak'], 'ms': km['assign_ms'],
-                                           'frac_is': 'useful fp32 flop/s over the FP32 matrix peak; the default tier runs on the bf16 pipe (assign_split), the fp32 tier is under fp32_tier',
-                                           'split': km.get('assign_split'), 'fp32_tier': km.get('assign_fp32_tier')}
+      split = km.get('assign_split') or {}
+      line['roofline']['kmeans_assign'] = {'bound': 'mfma_bf16', 'achieved': split.get('issued_TFLOPs'), 'peak': MFMA_BF16_PEAK_TFLOPS,
+                                           'unit': 'TFLOP/s', 'frac': split.get('frac_of_bf16_peak'), 'ms': km['assign_ms'],
+                                           'frac_is': 'bf16 flops the kernel ISSUES (3 x 2nkd: three exact-product MFMAs per 16 features) over the dense bf16 matrix peak',
+                                           'useful_fp32_TFLOPs': km['assign_TFLOPs'],
+                                           'useful_flops_over_fp32_mfma_peak': km['assign_useful_flops_over_fp32_mfma_peak'],
+                                           'fp32_tier': km.get('assign_fp32_tier')}
     line['profile_table'] = PROFILE_TABLE
     live, pooled = D.blob_stats()
     line['tile_store'] = {'live_blobs': live, 'pooled_bytes': pooled, 'kernel_sources': _hip.source_sha()}
+    if tiles8:
+      # (last: it replaces the context with one of 8 logical workers)
+      del A, B
+      line['one_gpu_8_tiles'] = one_gpu_8_tiles_section(line)
+      ctx = None
   if world.distributed:
     line['comm'] = dict(world.stats)
     line['comm']['transport'] = world.note or getattr(world.transport, 'name', '?')

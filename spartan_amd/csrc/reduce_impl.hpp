@@ -27,6 +27,19 @@
 // Streaming policy of the evaluators inside the reduction kernels (SP_STREAMS, sp_interp.hpp): the specialised
 // kernels follow the program's flag at run time, the interpreter kernels (dispatch-bound) do without the hint.
 #define SP_RED_NTM(P) (P::kStatic ? 2 : 0)
+// the software-pipelined walk of the interpreted column kernel (sp_reduce_cols_kernel): groups of rows per dispatch
+// and operands held ahead (A/B builds: -DSP_RED_AHEAD_UP=.. -DSP_RED_AHEAD_N=..).  Measured on the 8192 x 65536 tile,
+// GB/s of sum((x - 0.5)^2, 0) / sum(x, 0) / max(2x + 1, 0) on the interpreter (tools/interp_reduce_time.py):
+//   no pipeline (round 4)  2196 / 3856 / 1709       UP 2, N 2 (174 VGPRs: 2 waves per SIMD)  1744 / 3856 / 1709
+//   UP 2, N 1 (167: 3)     2229 / 5181 / 2261       UP 1, N 1   1810 / 4350 / 1879           UP 4, N 1 (256: 1)  1283 / 2515 / 1170
+// -- one operand ahead at three waves per SIMD; programs of two operands take the plain walk.  What is left is the
+// dispatch itself (the interpreted instructions of one trip cost more than its 16 bytes per lane take to arrive).
+#ifndef SP_RED_AHEAD_UP
+#define SP_RED_AHEAD_UP 2
+#endif
+#ifndef SP_RED_AHEAD_N
+#define SP_RED_AHEAD_N 1
+#endif
 
 #ifndef __HIPCC_RTC__
 int sp_validate_program(const sp_program* p);
@@ -351,7 +364,55 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
     Acc acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v].init(op);
-    if (active) {
+    bool walked = false;
+    if constexpr (!P::kStatic && LINEAR && V == 4 && sp_is_same<T, float>::value && MASK < 0) {
+      // Interpreted dense fp32 programs of one or two operands: the walk down the axis is software-pipelined like
+      // the interpreted map (sp_ahead, map_kernel.hpp) -- the operands of trip t + 1 are requested once trip t's sit
+      // in the register file and before its program is dispatched, so HBM works while the wave interprets.  UP groups
+      // of rows share a dispatch.
+      if (sp_ahead_applies<T, SP_RED_AHEAD_N>(p)) {
+        walked = true;
+        constexpr int UP = SP_RED_AHEAD_UP;
+        if (active && a0 + w < a1) {
+          sp_ahead<T, V, UP, SP_RED_AHEAD_N> ah;
+          auto place = [&](int64_t at, int64_t (&Lo)[UP]) {
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+              const int64_t au = at + (int64_t)u * NW;
+              Lo[u] = (o * A + (au < a1 ? au : at)) * I + c;      // rows past the chunk re-read row `at` (not added)
+            }
+          };
+          int64_t a = a0 + w;
+          int64_t L[UP];
+          place(a, L);
+          sp_fetch_ahead<T, V, UP, 0>(p, in, L, ah);
+          for (;;) {
+            const bool more = a + NW * UP < a1;
+            auto mid = [&]() {
+              if (more) {
+                int64_t Ln[UP];
+                place(a + NW * UP, Ln);
+                sp_fetch_ahead<T, V, UP, 0>(p, in, Ln, ah);
+              }
+            };
+            T x[UP][V];
+            sp_eval_u<T, V, UP, true, P, 0>(p, in, L, x, nullptr, dyn, &ah, mid);
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+              const int64_t au = a + (int64_t)u * NW;
+              if (u == 0 || au < a1) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v].add(op, x[u][v], au);
+              }
+            }
+            if (!more) break;
+            a += NW * UP;
+            place(a, L);
+          }
+        }
+      }
+    }
+    if (active && !walked) {
       constexpr int U = P::kStatic ? 1 : 2;   // interpreted: two groups share a dispatch (as in the map kernel)
       for (int64_t a = a0 + w; a < a1; a += NW * U) {
         int64_t L[U];

@@ -275,29 +275,32 @@ class Plan(object):
     self.pins = pins                    # objects the key names by identity stay alive (their ids stay theirs)
 
   def instantiate(self, leaves, ids):
-    made = [None] * self.n_nodes
+    return self._build(self.recipe, leaves, ids, [None] * self.n_nodes)
 
-    def build(r):
-      t = type(r)
-      if t is _Slot:
-        return leaves[r.k]
-      if t is _Node:
-        done = made[r.index]
-        if done is None:
-          fields = {name: build(x) for name, x in r.fields}
-          done = r.type(expr_id=None if r.at is None else ids[r.at], shape_cache=r.shape_cache, **fields)
-          if done.needs_cache != r.needs_cache:
-            done.needs_cache = r.needs_cache
-          made[r.index] = done
-        return done
-      if t is list:
-        return [build(x) for x in r]
-      if t is tuple:
-        return tuple(build(x) for x in r)
-      if t is dict:
-        return {k: build(x) for k, x in r.items()}
-      return r
-    return build(self.recipe)
+  def _build(self, r, leaves, ids, made):
+    # (a method, not a closure that calls itself: such a function is a reference cycle with its own cell, and the
+    # `made` / `leaves` lists it closes over -- hence the new DAG, and through its id the multi-GiB value computed
+    # for it -- would live until the cyclic collector next runs)
+    t = type(r)
+    if t is _Slot:
+      return leaves[r.k]
+    build = self._build
+    if t is _Node:
+      done = made[r.index]
+      if done is None:
+        fields = {name: build(x, leaves, ids, made) for name, x in r.fields}
+        done = r.type(expr_id=None if r.at is None else ids[r.at], shape_cache=r.shape_cache, **fields)
+        if done.needs_cache != r.needs_cache:
+          done.needs_cache = r.needs_cache
+        made[r.index] = done
+      return done
+    if t is list:
+      return [build(x, leaves, ids, made) for x in r]
+    if t is tuple:
+      return tuple(build(x, leaves, ids, made) for x in r)
+    if t is dict:
+      return {k: build(x, leaves, ids, made) for k, x in r.items()}
+    return r
 
 
 def optimized(dag, flags, optimize_fn):

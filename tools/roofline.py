@@ -142,7 +142,7 @@ def main():
       rec.update({'avg_us': round(avg, 3), 'min_us': round(min(d), 3), 'max_us': round(max(d), 3)})
       if e['unit'] == 'flop':
         ach = e['units_per_launch'] / (avg * 1e-6) / 1e12
-        peak = MFMA_BF16_PEAK_TFLOPS if e['bound'] == 'mfma_bf16' else MFMA_F32_PEAK_TFLOPS
+        peak = {'mfma_bf16': MFMA_BF16_PEAK_TFLOPS, 'mfma_f64': line.get('dot_f64', {}).get('peak_TFLOPs', 78.6)}.get(e['bound'], MFMA_F32_PEAK_TFLOPS)
         rec.update({'achieved': round(ach, 2), 'achieved_unit': 'TFLOP/s', 'peak': peak, 'frac': round(ach / peak, 4)})
       else:
         ach = e['units_per_launch'] / (avg * 1e-6) / 1e9
