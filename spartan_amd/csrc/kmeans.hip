@@ -145,12 +145,13 @@ __global__ __launch_bounds__(256) void sp_nearest_exact_kernel(const TX* __restr
 // Last step of the MFMA tiers: cdist's exact distance (sequential fp64 sum of squared differences in feature
 // order, sqrt) of the centers the re-check pass marked for each listed point, and the lexicographic (distance,
 // index) minimum = np.argmin's first minimum.
-// ONE WAVEFRONT PER LISTED POINT, ONE LANE PER CANDIDATE (round 4; before: a lane walked the set bits of one mask
-// word one after the other, 91 - 256 us for 17 - 38 thousand points of configs[3]): the lanes first write the numbers
-// of the marked centers, in ascending order, into a list (a lane owns the mask words lane, lane + 64, ...; a wave scan
-// of the popcounts places them), then lane j runs the chain of candidate j -- the point's row is the same address for
+// SIXTEEN LANES PER LISTED POINT, ONE LANE PER CANDIDATE (round 4: a whole wavefront per point; before that a lane
+// walked the set bits of one mask word one after the other, 91 - 256 us for 17 - 38 thousand points of configs[3]):
+// the lanes of a group first write the numbers
+// of the marked centers, in ascending order, into a list (a lane owns the mask words gl, gl + 16, ...; a scan
+// of the popcounts over the group places them), then lane j runs the chain of candidate j -- the point's row is the same address for
 // every lane, the center rows come straight from the caller's centers, both read J features ahead of the sum -- and a
-// wave reduction picks the minimum.  More than 64 candidates: 64 at a time.  A point with ONE candidate (its window
+// reduction over the group picks the minimum.  More than 16 candidates: 16 at a time.  A point with ONE candidate (its window
 // holds the first pass's best only) is settled without reading a row; one with more than the list holds falls back to
 // every lane walking its own mask words.
 // cdist 'euclidean' of one (point, center) pair on doubles: the squared differences added in feature order, sqrt;
@@ -208,31 +209,37 @@ __global__ __launch_bounds__(256) void sp_nearest_candidates_kernel(const float*
                                                                     const int* __restrict__ rows,
                                                                     const int* __restrict__ n_rows, int64_t cap,
                                                                     const unsigned* __restrict__ cand_mask) {
-  constexpr int LIST = 512;
-  __shared__ int list_s[4][LIST];                 // per wave: the candidates of its point
+  // A listed point has a handful of candidates (the centers inside its error window), and a candidate's distance is a
+  // serial chain of d fused multiply-adds in cdist's order: a whole wave per point kept 2-8 of its 64 lanes busy.  GL
+  // lanes take a point instead, 64 / GL points per wave (136 -> see profiles/r05_notes.md at configs[3]).
+  constexpr int GL = 16, GROUPS = 64 / GL, LIST = 128;
+  __shared__ int list_s[4][GROUPS][LIST];         // per group of lanes: the candidates of its point
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int* list = list_s[wv];
+  const int gl = lane & (GL - 1), grp = lane / GL;
+  int* list = list_s[wv][grp];
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t count = *n_rows;
   if (count > cap) return;                        // no masks were written: the exact kernel re-does the list
   const int words = kp / 32;
-  for (int64_t it = wave; it < count; it += nwaves) {
-    const int64_t row = rows[it];
-    const unsigned* __restrict__ mw = cand_mask + it * words;
+  for (int64_t it0 = wave * GROUPS; it0 < count; it0 += nwaves * GROUPS) {
+    const int64_t it = it0 + grp;
+    const bool have = it < count;                 // (the groups of a wave walk together: shuffles and the wave barriers below)
+    const int64_t row = have ? rows[it] : 0;
+    const unsigned* __restrict__ mw = cand_mask + (have ? it : 0) * words;
     const float* __restrict__ xr = X + row * ldx;
     // ---- the list: word w of the mask holds centers 32 w .. 32 w + 31
     int total = 0;
-    for (int w0 = 0; w0 < words; w0 += 64) {
-      const int wi = w0 + lane;
-      unsigned m = wi < words ? mw[wi] : 0u;
+    for (int w0 = 0; w0 < words; w0 += GL) {
+      const int wi = w0 + gl;
+      unsigned m = (have && wi < words) ? mw[wi] : 0u;
       if (wi * 32 + 32 > k) m &= wi * 32 < k ? ((1u << (k - wi * 32)) - 1u) : 0u;   // (padding centers)
       const int mine = __builtin_popcount(m);
       int inc = mine;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
+      for (int off = 1; off < GL; off <<= 1) {
+        const int o = __shfl_up(inc, off, GL);
+        if (gl >= off) inc += o;
       }
       int at = total + inc - mine;
       while (m) {
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void sp_nearest_candidates_kernel(const float*
         m &= m - 1;
         ++at;
       }
-      total += __shfl(inc, 63);
+      total += __shfl(inc, GL - 1, GL);
     }
     __builtin_amdgcn_wave_barrier();
     int best_k = 0x7fffffff;
@@ -248,9 +255,9 @@ __global__ __launch_bounds__(256) void sp_nearest_candidates_kernel(const float*
     if (total == 1) {
       best_k = list[0];
     } else if (total > 1 && total <= LIST) {
-      for (int c0 = 0; c0 < total; c0 += 64) {
-        const bool live = c0 + lane < total;
-        const int c = list[live ? c0 + lane : 0];
+      for (int c0 = 0; c0 < total; c0 += GL) {
+        const bool live = c0 + gl < total;
+        const int c = list[live ? c0 + gl : 0];
         const double s = km_exact_distance<TC>(xr, C + (int64_t)c * ldc, d);
         if (live && (s < best || (s == best && c < best_k))) {
           best = s;
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256) void sp_nearest_candidates_kernel(const float*
     } else if (total > LIST) {
       // more candidates than the list holds (a mass of coincident centers): every lane walks the set bits of its
       // own words, one after the other
-      for (int wi = lane; wi < words; wi += 64) {
+      for (int wi = gl; wi < words; wi += GL) {
         unsigned m = mw[wi];
         while (m) {
           const int c = wi * 32 + __builtin_ctz(m);
@@ -274,19 +281,18 @@ __global__ __launch_bounds__(256) void sp_nearest_candidates_kernel(const float*
         }
       }
     }
-    if (total > 1) {
+    // (every group joins the shuffles: a group with one candidate or none brings its (best, best_k) as they are)
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(best, off);
-        const int ok = __shfl_xor(best_k, off);
-        if (ob < best || (ob == best && ok < best_k)) {
-          best = ob;
-          best_k = ok;
-        }
+    for (int off = GL / 2; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off, GL);
+      const int ok = __shfl_xor(best_k, off, GL);
+      if (total > 1 && (ob < best || (ob == best && ok < best_k))) {
+        best = ob;
+        best_k = ok;
       }
     }
     // (the window always contains the first pass's own best center; the guard is for NaN input)
-    if (lane == 0) labels[row] = best_k == 0x7fffffff ? -1 - labels[row] : best_k;
+    if (have && gl == 0) labels[row] = best_k == 0x7fffffff ? -1 - labels[row] : best_k;
     __builtin_amdgcn_wave_barrier();              // the list is rewritten for the next point
   }
 }

@@ -566,7 +566,11 @@ class ArgReduceExpr(Expr):
   def _evaluate(self, ctx, deps):
     array = deps['array']
     shape = extent.shape_for_reduction(array.shape, self.axis)
-    val_out = distarray.create(shape, array.dtype, reducer=np.maximum if self.which == 0 else np.minimum)
+    # the extreme values are a scratch array of this node: ONE tile (each source tile then merges its partial with one
+    # launch and reads the combined values back in place, instead of a cut into num_workers pieces on both ways);
+    # the indices are the result and are tiled like any reduction's (reduce.py:117-118)
+    val_out = distarray.create(shape, array.dtype, reducer=np.maximum if self.which == 0 else np.minimum,
+                               tile_hint=tuple(shape) if len(shape) else None)
     idx_out = distarray.create(shape, np.int64, reducer=np.minimum)
     state = {}
     array.foreach_tile(_argreduce_mapper1, kw=dict(src=array, axis=self.axis, which=self.which,
