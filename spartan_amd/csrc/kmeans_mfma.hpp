@@ -83,20 +83,19 @@ static_assert(KN_BM == KM_BN_MAX, "kp must be a multiple of the center block");
 
 // The verdict on one point from its fp32 (best, second best) halved scores: the label when the gap clears the error
 // bound, else -1 - label and a place in the list the re-check works through.
-// `ef`, `eg`: the tier's error factors, E = u (ef |x| |c|max + eg |c|max^2) (this file: 2 D + 4 and 2, km_fp32_factor;
-// kmeans_split.hpp: km_split_factor, km_split_cfactor).
+// `ef`: the tier's error factor (this file: 2 D + 4, km_fp32_factor; kmeans_split.hpp: km_split_factor).
 __device__ __forceinline__ float km_fp32_factor(int d) { return 2.0f * (float)d + 4.0f; }
-__device__ __forceinline__ void km_decide(float b, float s, int ix, float xn, int point, float ef, float eg, float cmax,
+__device__ __forceinline__ void km_decide(float b, float s, int ix, float xn, int point, float ef, float cmax,
                                           float cmax2, int64_t* __restrict__ labels, int* __restrict__ amb_rows,
                                           float* __restrict__ amb_best, int* __restrict__ amb_count) {
   const float u = 5.9604645e-8f;                     // 2^-24
   const float xnorm = sqrtf(xn) * 1.001f;            // fp32 sum of squares: generous slack
-  const float E = u * (ef * xnorm * cmax + eg * cmax2);
+  const float E = u * (ef * xnorm * cmax + 2.0f * cmax2);
   // (magnitudes at which products, the bound itself or the bf16 halves of the split tier leave the normal range: no
-  //  verdict from the filter, the exact stage decides; so it does when the best score is a padding row's sentinel)
+  //  verdict from the filter, the exact stage decides)
   const float pn = xnorm * cmax;
   const bool underflows = pn > 0.f && pn < 1e-28f;
-  const bool sure = !underflows && b < 1e37f && 2.0f * (s - b) > 4.0f * E;   // (scores are halved) false for NaN / inf-inf as well
+  const bool sure = !underflows && 2.0f * (s - b) > 4.0f * E;       // (scores are halved) false for NaN / inf-inf as well
   labels[point] = sure ? (int64_t)ix : (int64_t)(-1 - ix);
   if (!sure) {   // (order-free: each listed point is re-done on its own)
     const int pos = atomicAdd(amb_count, 1);
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
           ((int*)part)[at + 2 * (int64_t)ldp] = ix;
           if (blockIdx.y == 0) part[(int64_t)gridDim.y * 3 * ldp + m0 + col] = xn[j];
         } else {
-          km_decide(b, s, ix, xn[j], m0 + col, km_fp32_factor(d), 2.0f, cmax, cmax2, labels, amb_rows, amb_best, amb_count);
+          km_decide(b, s, ix, xn[j], m0 + col, km_fp32_factor(d), cmax, cmax2, labels, amb_rows, amb_best, amb_count);
         }
       }
     }
@@ -455,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void sp_nearest_nt_kernel(const float* __re
 
 // Combines the per-center-range parts of the PARTIAL launch for tail point t (global point first + t).
 __global__ __launch_bounds__(256) void sp_nearest_merge_parts_kernel(const float* __restrict__ part, int S, int ldp,
-                                                                     int n_tail, int first, float ef, float eg,
+                                                                     int n_tail, int first, float ef,
                                                                      const unsigned* __restrict__ cmax2_bits,
                                                                      int64_t* __restrict__ labels,
                                                                      int* __restrict__ amb_rows,
@@ -478,7 +477,7 @@ __global__ __launch_bounds__(256) void sp_nearest_merge_parts_kernel(const float
     }
   }
   const float cmax2 = __uint_as_float(*cmax2_bits);
-  km_decide(b, s, ix, part[(int64_t)S * 3 * ldp + t], first + t, ef, eg, sqrtf(cmax2) * 1.0000002f, cmax2, labels, amb_rows,
+  km_decide(b, s, ix, part[(int64_t)S * 3 * ldp + t], first + t, ef, sqrtf(cmax2) * 1.0000002f, cmax2, labels, amb_rows,
             amb_best, amb_count);
 }
 
@@ -650,7 +649,7 @@ static int sp_nearest_fused_launch(const float* X, int64_t ldx, const void* C, i
   if (rem > 0) {
     const int n_tail = (int)(n - n_whole);
     hipLaunchKernelGGL(sp_nearest_merge_parts_kernel, dim3((unsigned)((n_tail + 255) / 256)), dim3(256), 0, st, w.part,
-                       (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, 2.0f * (float)d + 4.0f, 2.0f, w.cmax2, labels, w.amb_rows, w.amb_best,
+                       (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, 2.0f * (float)d + 4.0f, w.cmax2, labels, w.amb_rows, w.amb_best,
                        w.amb_count);
     SP_CHECK_LAUNCH();
   }

@@ -14,22 +14,15 @@
 //     (tools/mfma_bf16_probe.hip, 20 000 random operand sets with exponents spread over 30 binades): it is
 //     neither a k-ordered chain nor an exact sum rounded once, and errs by at most 2.5 u (|c| + sum|p|) per MFMA of
 //     16 products -- a seventh of what this bound grants it
-//   * |c|^2/2 rounded once                                         (as in the fp32 kernel)
-// The accumulators of a center block START from -|c|^2/2 (the value the epilogue used to subtract: one VALU
-// operation per score less), so that number is one more addend of the fp32 sum -- 3 D + 1 addends, bounded as above by
-// 3.03 D u (S + |c|^2/2) -- and the epilogue marks each score with its row (6 mantissa bits: at most 64 ulp = 128 u of
-// its magnitude, <= S + |c|^2/2).  In the units km_decide and the candidate window work in (the score |c|^2 - 2 x.c,
-// twice the halved one) the error factors of this tier are
-//   F = 6.1 D + 1810,   G = 3.1 D + 132,    E = u (F |x| |c|max + G |c|max^2),
-// in the place of the fp32 kernel's 2 D + 4 and 2 (F: 2 (768.1 + 3.03 D + 128 + 5 for the shift's roundings); G:
-// 2 (3.03 D / 2 + 64 + 1/2)).  The |c|max^2 term matters for a stand-alone call on arbitrary centers (|c| ~ |x|: the
-// window is a quarter wider than with G = 2); inside a fit the shifted centers are means of points, |c| << |x|, and it
-// vanishes next to F |x| |c|max.  At D = 256 the window is 6 x the fp32 tier's: without the shift below 8 % of the
+//   * |c|^2/2 rounded once, the final subtraction rounded once     (as in the fp32 kernel)
+// and the score |c|^2 - 2 x.c, in whose units km_decide and the candidate window work, by twice that: the error
+// factor of this tier is
+//   F = 6.1 D + 1550,    E = u (F |x| |c|max + 2 |c|max^2),
+// in the place of the fp32 kernel's 2 D + 4.  At D = 256 the window is 6 x as wide: without the shift below 8 % of the
 // points of configs[3] instead of 1.4 % would go to the re-check (16-27 % inside a fit), with it 2-4 % do -- and the pass
 // itself needs a third of the fp32 kernel's time.  (Other cuts end at the same width: a fourth product, xm cm, trades 512 u of left-out terms for 2 D u of
 // roundings; all 24 bits -- three bf16 per operand, six products -- 1536 u for 6 D u.)  The labels are the exact
-// tier's, as before: tools/fuzz_kmeans.py, tests/test_hip_kernels.py::test_nearest_center_*; the window itself is
-// restated in NumPy and checked against exact scores in tests/test_kmeans_split_bound.py.
+// tier's, as before: tools/fuzz_kmeans.py, tests/test_hip_kernels.py::test_nearest_center_*.
 //
 // THE SHIFT.  E is proportional to |x| |c|max, and the distances do not change when the same vector mu is taken off
 // points and centers: the tier works on x~ = fl32(x - mu), c~ = fl32(c - mu) with mu the column means of the points
@@ -91,8 +84,7 @@ struct KsCfg {
   static_assert(SLOTS * BN == KM_TAIL_POINTS, "the tail buffer is sized for one round of either geometry");
 };
 
-__device__ __host__ __forceinline__ float km_split_factor(int d) { return 6.1f * (float)d + 1810.0f; }    // F
-__device__ __host__ __forceinline__ float km_split_cfactor(int d) { return 3.1f * (float)d + 132.0f; }    // G
+__device__ __forceinline__ float km_split_factor(int d) { return 6.1f * (float)d + 1550.0f; }
 
 // Column means of the rows of X (any dtype the tiers take), two launches: KM_MEAN_BLOCKS partial sums, then their sum
 // over the row count.  (The value is a SHIFT, not a result: whatever it is, the labels are the same.)
@@ -186,10 +178,8 @@ __global__ __launch_bounds__(256) void sp_split_rows_kernel(const float* __restr
   }
 }
 
-// sp_centers_prep_kernel for shifted centers: Cf[c][j] = fl32(C[c][j] - mu[j]) (zero padded), cn[c] = -|Cf[c]|^2 / 2
-// (of the ROUNDED row: the number the contraction multiplies; fp64 sum, rounded; NEGATED: it is what the accumulators
-// of a center block start from; -3e38 on padding rows: a finite score no real center can lose to -- km_decide sends a
-// point whose best score is that sentinel to the exact stage), *cmax2 = max |Cf[c]|^2
+// sp_centers_prep_kernel for shifted centers: Cf[c][j] = fl32(C[c][j] - mu[j]) (zero padded), cn[c] = |Cf[c]|^2 / 2
+// (of the ROUNDED row: the number the contraction multiplies; fp64 sum, rounded; +inf on padding), *cmax2 = max |Cf[c]|^2
 template <typename TC>
 __global__ __launch_bounds__(256) void sp_centers_prep_shifted_kernel(const TC* __restrict__ C, int64_t ldc, int k, int d,
                                                                       int kp, int dp, const float* __restrict__ mu,
@@ -199,7 +189,7 @@ __global__ __launch_bounds__(256) void sp_centers_prep_shifted_kernel(const TC* 
   const int c = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (c >= kp) return;
   if (c >= k) {
-    if (lane == 0) cn[c] = -3.0e38f;
+    if (lane == 0) cn[c] = INFINITY;
     return;
   }
   double s = 0.0;
@@ -212,7 +202,7 @@ __global__ __launch_bounds__(256) void sp_centers_prep_shifted_kernel(const TC* 
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (lane == 0) {
     const float sf = (float)s;
-    cn[c] = -0.5f * sf;
+    cn[c] = 0.5f * sf;
     atomicMax(cmax2, __float_as_uint(sf * 1.0000002f));
   }
 }
@@ -309,13 +299,9 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
     }                                                                                                  \
   } while (0)
 
-  // Scores are kept NEGATED and halved: s = x.c - |c|^2/2, the accumulators of a center block start from -|c|^2/2 (the
-  // chs slice) and the best center is the one with the LARGEST s.  The epilogue writes the position of a value inside
-  // the wave's block of 64 rows (as 63 - position) into the 6 lowest bits of its mantissa and keeps max / median:
-  // three VALU operations per value (and_or, med3, max) in the place of five (subtract, compare, med3, two selects).
   km_f32x16 acc[4][2];
-  float best[2] = {-INFINITY, -INFINITY}, second[2] = {-INFINITY, -INFINITY};
-  int bblk[2] = {0, 0};
+  float best[2] = {INFINITY, INFINITY}, second[2] = {INFINITY, INFINITY};
+  int bpos[2] = {0, 0}, bblk[2] = {0, 0};
 
   int cur = 0, nxt = 1;
   {
@@ -336,7 +322,7 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
   }
 
   int t = 0;
-  auto kstep = [&](auto first_of_block, const float* chb) {
+  auto kstep = [&](auto first_of_block) {
     constexpr bool FIRST = decltype(first_of_block)::value;
     const bool more = !(KS_ABLATE & 1) && t + 1 < steps;
     KS_LOAD_BEGIN(nxt)
@@ -374,14 +360,8 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
           const km_bf16x8 a = term == 0 ? am[i] : ah[i];
           const km_bf16x8 b = term == 1 ? bm[j] : bh[j];
           if (FIRST && kk == 0 && term == 0) {
-            // rows i*32 + 8q + 4lh + (0..3) of the wave's 128: -|c|^2/2 of the centers this lane's 16 values belong to
-            km_f32x16 from;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const km_f32x4 ch4 = *(const km_f32x4*)(chb + i * 32 + 8 * q);
-              from[4 * q + 0] = ch4[0]; from[4 * q + 1] = ch4[1]; from[4 * q + 2] = ch4[2]; from[4 * q + 3] = ch4[3];
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, from, 0, 0, 0);
+            const km_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, zero, 0, 0, 0);
           } else {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
           }
@@ -406,18 +386,14 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
 
   const float cmax2 = __uint_as_float(*cmax2_bits);
   const float cmax = sqrtf(cmax2) * 1.0000002f;
-  const float ef = km_split_factor(d), eg = km_split_cfactor(d);
-  const unsigned keep_bits = __builtin_amdgcn_readfirstlane(0xffffffc0u);     // (a scalar operand of v_and_or_b32)
-  // max(a, b) as med3(a, b, +inf): fmaxf is two instructions here (the compiler puts a canonicalising v_max in front,
-  // as it did for fminf); the constant comes out of an asm statement so that the median is not folded back into one
-  float pinf;
-  asm volatile("s_mov_b32 %0, 0x7f800000" : "=s"(pinf));
+  const float ef = km_split_factor(d);
   for (int tr = 0; tr < tiles_m; ++tr) {
     const int tm = tm_first + tr;
+    kstep(std::true_type());
+    for (int kt = 1; kt < nt; ++kt) kstep(std::false_type());
+    // ---- epilogue of center block tm (as sp_nearest_nt_kernel's: halved scores h = |c|^2/2 - x.c; the rows of a
+    // lane ascend with (i, q, e), `<` keeps the first minimum, the new second best is the median of (best, second, h))
     const float* chb = chs + (tr & 1) * KS_BM + wm * 128 + 4 * lh;
-    kstep(std::true_type(), chb);
-    for (int kt = 1; kt < nt; ++kt) kstep(std::false_type(), chb);
-    // ---- epilogue of center block tm: acc = x.c - |c|^2/2 for the lane's 4 x 4 x 4 rows (i, q, e) of two points
     if constexpr (RECHECK) {
       float thr[2];
       int slot[2];
@@ -426,19 +402,21 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
         slot[j] = m0 + wn * 64 + j * 32 + l31;
         const int at = slot[j] < listed ? slot[j] : listed - 1;
         const float xnorm = sqrtf(xn2[amb_rows[at]]) * 1.001f;
-        const float E = 5.9604645e-8f * (ef * xnorm * cmax + eg * cmax2);
-        thr[j] = -(amb_best[at] + E * 1.001f + 1e-30f);        // (amb_best: the halved score as km_decide keeps it, smaller = nearer)
+        const float E = 5.9604645e-8f * (ef * xnorm * cmax + 2.0f * cmax2);
+        thr[j] = amb_best[at] + E * 1.001f + 1e-30f;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         unsigned bits[2] = {0u, 0u};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+          const km_f32x4 ch4 = *(const km_f32x4*)(chb + i * 32 + 8 * q);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              bits[j] |= (acc[i][j][4 * q + e] >= thr[j]) ? (1u << (8 * q + e)) : 0u;   // (+ 4 lh below)
+              bits[j] |= (ch4[e] - acc[i][j][4 * q + e] <= thr[j]) ? (1u << (8 * q + e)) : 0u;   // (+ 4 lh below)
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           unsigned w = bits[j] << (4 * lh);
@@ -452,24 +430,26 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
 #pragma unroll
     for (int i = 0; i < ((KS_ABLATE & 4) ? 1 : 4); ++i)
 #pragma unroll
-      for (int q = 0; q < ((KS_ABLATE & 4) ? 1 : 4); ++q)
+      for (int q = 0; q < ((KS_ABLATE & 4) ? 1 : 4); ++q) {
+        const km_f32x4 ch4 = *(const km_f32x4*)(chb + i * 32 + 8 * q);   // rows i*32 + 8q + 4lh + (0..3)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            // the rows of a lane ascend with (i, q, e): an earlier row carries the larger tag, so among values that agree
-            // above the tag bits the first one is the maximum (any such pair is inside the window and re-decided anyway)
-            const float v = __uint_as_float((__float_as_uint(acc[i][j][4 * q + e]) & keep_bits) | (unsigned)(63 - (16 * i + 4 * q + e)));
+            const float v = ch4[e] - acc[i][j][4 * q + e];
+            const bool better = v < best[j];
             second[j] = __builtin_amdgcn_fmed3f(best[j], second[j], v);
-            best[j] = __builtin_amdgcn_fmed3f(best[j], v, pinf);
+            bpos[j] = better ? 16 * i + 4 * q + e : bpos[j];
+            best[j] = better ? v : best[j];          // (a select on the compare's result: fminf costs a canonicalising v_max first)
           }
+      }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bblk[j] = best[j] > before[j] ? tm : bblk[j];
+    for (int j = 0; j < 2; ++j) bblk[j] = best[j] < before[j] ? tm : bblk[j];
   }
 #undef KS_LOAD_BEGIN
 #undef KS_PIECE
 
-  // ---- merge: the two lane halves of a column (rows differ by 4), then the two center waves (LDS); larger = nearer
+  // ---- merge: the two lane halves of a column (rows differ by 4), then the two center waves (LDS)
   float* mb_s = (float*)smem;         // [128]   (the stages are dead: every wave passed the last barrier)
   float* ms_s = mb_s + KS_BN;
   int* mi_s = (int*)(mb_s + 2 * KS_BN);
@@ -478,16 +458,15 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     float b = best[j], s = second[j];
-    const int pos = 63 - (int)(__float_as_uint(b) & 63u);
-    int ix = bblk[j] * KS_BM + wm * 128 + (pos >> 4) * 32 + ((pos >> 2) & 3) * 8 + (pos & 3) + 4 * lh;
+    int ix = bblk[j] * KS_BM + wm * 128 + (bpos[j] >> 4) * 32 + ((bpos[j] >> 2) & 3) * 8 + (bpos[j] & 3) + 4 * lh;
     const float ob = __shfl_xor(b, 32), os = __shfl_xor(s, 32);
     const int oi = __shfl_xor(ix, 32);
-    if (ob > b || (ob == b && oi < ix)) {
-      s = fmaxf(b, os);
+    if (ob < b || (ob == b && oi < ix)) {
+      s = fminf(b, os);
       b = ob;
       ix = oi;
     } else {
-      s = fmaxf(ob, s);
+      s = fminf(ob, s);
     }
     bb[j] = b;
     ss[j] = s;
@@ -511,24 +490,23 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
       int ix = ii[j];
       const float ob = mb_s[col], os = ms_s[col];
       const int oi = mi_s[col];
-      if (ob > b || (ob == b && oi < ix)) {
-        s = fmaxf(b, os);
+      if (ob < b || (ob == b && oi < ix)) {
+        s = fminf(b, os);
         b = ob;
         ix = oi;
       } else {
-        s = fmaxf(ob, s);
+        s = fminf(ob, s);
       }
       if (m0 + col < n) {
-        // handed on as the halved scores |c|^2/2 - x.c of the other tier (smaller = nearer)
         if constexpr (PARTIAL) {
           const int64_t at = (int64_t)blockIdx.y * 3 * ldp + m0 + col;
-          part[at] = -b;
-          part[at + ldp] = -s;
+          part[at] = b;
+          part[at + ldp] = s;
           ((int*)part)[at + 2 * (int64_t)ldp] = ix;
           if (blockIdx.y == 0) part[(int64_t)gridDim.y * 3 * ldp + m0 + col] = xn2[first_point + m0 + col];
         } else {
-          km_decide(-b, -s, ix, xn2[first_point + m0 + col], first_point + m0 + col, ef, eg, cmax, cmax2, labels, amb_rows,
-                    amb_best, amb_count);
+          km_decide(b, s, ix, xn2[first_point + m0 + col], first_point + m0 + col, ef, cmax, cmax2, labels, amb_rows, amb_best,
+                    amb_count);
         }
       }
     }
@@ -626,7 +604,7 @@ static int sp_nearest_split_launch_wn(const void* C, int32_t cdtype, int64_t ldc
                                      KM_TAIL_POINTS, (int)per, (int)n_whole, (int)n))
       return 1;
     hipLaunchKernelGGL(sp_nearest_merge_parts_kernel, dim3((unsigned)((n_tail + 255) / 256)), dim3(256), 0, st, w.part,
-                       (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, km_split_factor((int)d), km_split_cfactor((int)d), w.cmax2, labels,
+                       (int)split, KM_TAIL_POINTS, n_tail, (int)n_whole, 6.1f * (float)d + 1550.0f, w.cmax2, labels,
                        w.amb_rows, w.amb_best, w.amb_count);
     SP_CHECK_LAUNCH();
   }

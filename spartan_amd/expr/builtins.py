@@ -566,11 +566,14 @@ class ArgReduceExpr(Expr):
   def _evaluate(self, ctx, deps):
     array = deps['array']
     shape = extent.shape_for_reduction(array.shape, self.axis)
-    # the extreme values are a scratch array of this node: ONE tile (each source tile then merges its partial with one
-    # launch and reads the combined values back in place, instead of a cut into num_workers pieces on both ways);
-    # the indices are the result and are tiled like any reduction's (reduce.py:117-118)
+    # The extreme values are a scratch array of this node.  When every source tile reduces onto the WHOLE result (the
+    # reduced axis is the one the array is cut along, or axis=None) it is ONE tile: each source tile merges its partial
+    # with one launch and reads the combined values back in place, instead of a cut into num_workers pieces on both
+    # ways.  Otherwise it is tiled like the result (reduce.py:117-118) and every partial meets exactly its own tile.
+    targets = {extent.index_for_reduction(ex, self.axis) for ex in array.tiles}
+    whole = len(targets) == 1 and len(shape) > 0
     val_out = distarray.create(shape, array.dtype, reducer=np.maximum if self.which == 0 else np.minimum,
-                               tile_hint=tuple(shape) if len(shape) else None)
+                               tile_hint=tuple(shape) if whole else None)
     idx_out = distarray.create(shape, np.int64, reducer=np.minimum)
     state = {}
     array.foreach_tile(_argreduce_mapper1, kw=dict(src=array, axis=self.axis, which=self.which,
