@@ -7,35 +7,39 @@ from ..array import distarray, extent
 from ..context import LocalKernelResult
 
 
+def _right_hand_slabs(right, axis, fetch_whole):
+  """The pieces of the right-hand array a left tile is paired with, as (extent, data) in tile order: the whole array
+  once (axis None) or each DISTINCT slab its tiles turn into when they are re-cut along `axis` -- a vector re-cut
+  along its other axis yields the same whole-vector slab for every tile, and a cut finer than the new axis yields
+  nothing for some (reference outer.py:33-47)."""
+  if axis is None:
+    everything = extent.from_shape(right.shape)
+    yield everything, (fetch_whole(right, everything) if fetch_whole is not None else right.fetch(everything))
+    return
+  met = set()
+  for tile_extent in right.tiles:
+    slab = extent.change_partition_axis(tile_extent, axis)
+    if slab is None or slab in met:
+      continue
+    met.add(slab)
+    yield slab, right.fetch(slab)
+
+
 def outer_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target):
-  """outer.py:12-59."""
-  first_extent = extent.change_partition_axis(ex, axes[0])
-  first_tile = arrays[0].fetch(first_extent)
-  if local_user_fn_kw is None:
-    local_user_fn_kw = {}
-  fresh = bool(getattr(local_user_fn, 'yields_fresh_tensors', False))   # see map.join_mapper
-  if axes[1] is None:
-    outer_extent = extent.from_shape(arrays[1].shape)
-    # a mapper may bring its own way of fetching the whole right-hand array (dot: column chunks
-    # gathered asynchronously so the gather overlaps the GEMM); default: one replicated fetch
-    fetch_rhs = getattr(local_user_fn, 'fetch_rhs', None)
-    outer_tile = fetch_rhs(arrays[1], outer_extent) if fetch_rhs is not None else arrays[1].fetch(outer_extent)
-    result = local_user_fn(first_extent, first_tile, outer_extent, outer_tile, **local_user_fn_kw)
-    if result is not None:
-      for tex, v in result:
-        target.update(tex, v, wait=False, owned=fresh)
-  else:
-    done_extent = {}
-    for key in arrays[1].tiles.keys():
-      outer_extent = extent.change_partition_axis(key, axes[1])
-      if outer_extent is None or done_extent.get(outer_extent, None) is not None:
-        continue
-      outer_tile = arrays[1].fetch(outer_extent)
-      result = local_user_fn(first_extent, first_tile, outer_extent, outer_tile, **local_user_fn_kw)
-      if result is not None:
-        for tex, v in result:
-          target.update(tex, v, wait=False, owned=fresh)
-      done_extent[outer_extent] = True
+  """One tile of the left array against every slab of the right one (kernel-function protocol of the reference's
+  outer_mapper, outer.py:12-59): the user function gets (left extent, left data, right extent, right data) and what it
+  yields -- (target extent, data) pairs -- is pushed into `target`."""
+  left, right = arrays[0], arrays[1]
+  here = extent.change_partition_axis(ex, axes[0])
+  mine = left.fetch(here)
+  kw = local_user_fn_kw or {}
+  owned = bool(getattr(local_user_fn, 'yields_fresh_tensors', False))   # see map.join_mapper
+  # a mapper may bring its own way of fetching the whole right-hand array (dot: column chunks gathered
+  # asynchronously so that the gather overlaps the GEMM); default: one replicated fetch
+  fetch_whole = getattr(local_user_fn, 'fetch_rhs', None)
+  for there, theirs in _right_hand_slabs(right, axes[1], fetch_whole):
+    for where, data in (local_user_fn(here, mine, there, theirs, **kw) or ()):
+      target.update(where, data, wait=False, owned=owned)
   return LocalKernelResult(result=[])
 
 

@@ -24,29 +24,30 @@ def shuffle(v, fn, cost_hint=None, shape_hint=None, target=None, kw=None):
                      fn_kw=kw)
 
 
+def _produced(map_fn, source, ex, fn_kw):
+  """What the user function yields for tile `ex` of `source`: (extent, data) pairs (None: nothing)."""
+  return list(map_fn(source, ex, **(fn_kw or {})) or ())
+
+
 def target_mapper(ex, map_fn=None, source=None, target=None, fn_kw=None):
-  """shuffle.py:41-66: scatter-with-reduce into `target`."""
-  result = map_fn(source, ex, **fn_kw)
-  if result is not None:
-    for tex, v in list(result):
-      target.update(tex, v, wait=False)
+  """Scatter with the target's reducer (protocol of the reference's target_mapper, shuffle.py:41-66)."""
+  for where, data in _produced(map_fn, source, ex, fn_kw):
+    target.update(where, data, wait=False)
   return LocalKernelResult(result=[])
 
 
 def notarget_mapper(ex, array=None, map_fn=None, source=None, fn_kw=None):
-  """shuffle.py:69-96: outputs become new tiles."""
+  """Every piece the function yields becomes a tile of a new array (shuffle.py:69-96).  Every rank walks the same
+  pieces so that tile ids advance alike; only the rank that runs this worker's kernels holds data."""
   ctx = context.get()
-  results = []
-  user_result = map_fn(source, ex, **fn_kw)
-  if user_result is not None:
-    for tex, v in user_result:
-      if ctx.executing:
-        Assert.eq(tex.shape, tuple(v.shape), 'Bad shape from %s' % map_fn)
-        tile_id = ctx.create(tile.from_data(v, dtype=ctx.backend.dtype_of(v)))
-      else:
-        tile_id = ctx.create(None)
-      results.append((tex, tile_id))
-  return LocalKernelResult(result=results, futures=None)
+  table = []
+  for where, data in _produced(map_fn, source, ex, fn_kw):
+    piece = None
+    if ctx.executing:
+      Assert.eq(where.shape, tuple(data.shape), 'Bad shape from %s' % map_fn)
+      piece = tile.from_data(data, dtype=ctx.backend.dtype_of(data))
+    table.append((where, ctx.create(piece)))
+  return LocalKernelResult(result=table, futures=None)
 
 
 class ShuffleExpr(Expr):
