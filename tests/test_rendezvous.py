@@ -249,3 +249,23 @@ def test_rccl_linked_against_another_runtime_is_refused():
   out = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=240).stdout.decode('utf-8', 'replace')
   assert 'AVAILABLE 0' in out and 'another HIP runtime' in out, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_communicator_in_a_torch_free_process():
+  """tools/rccl_one_rank.py in a fresh interpreter on the GPU: sp_comm_* binds the RCCL beside the library's own HIP
+  runtime, every primitive passes the start-up self-test on a one-rank communicator, one runtime of each kind is
+  mapped and torch is never imported."""
+  import json
+  env = dict(os.environ)
+  for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SPARTAN_RCCL_LIB'):
+    env.pop(k, None)
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_one_rank.py')], env=env, cwd=ROOT,
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+  out = p.stdout.decode('utf-8', 'replace')
+  assert p.returncode == 0, (out[-2000:], p.stderr.decode('utf-8', 'replace')[-3000:])
+  rec = json.loads(out[out.index('{'):out.rindex('}') + 1])
+  assert rec['self_test'] == [True, 'ok'] and rec['torch_in_process'] is False
+  assert all(len(v) == 1 for v in rec['mapped'].values()), rec['mapped']
+  assert os.path.dirname(rec['paths']['lib_path']) == os.path.dirname(rec['paths']['own_hip_runtime_path'])
+  assert rec['paths']['hip_runtime_path'] == rec['paths']['own_hip_runtime_path']
