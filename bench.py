@@ -162,6 +162,9 @@ def hbm_section(ctx):
   out['map_5op_chain_jit_GBps'] = round(8.0 * n / ms / 1e6, 1)
   # the fused map -> reduce the same way: its first launch of the process, alone on an idle device (seeded by
   # build(): specialised at once; an unseeded program starts on the interpreter tier below)
+  # (the first REDUCTION of a process pays ~12 ms of one-time host work -- module imports, the first workspace --
+  # whatever it reduces: a 64 x 64 one takes that, so that the figure below is about the program, not the process)
+  sp.sum(sp.ones((64, 64)) * 2.0, axis=0).optimized().glom()
   first = sp.sum((Xv - 0.5) * (Xv - 0.5), axis=0).optimized()
   D.synchronize()
   e0, e1 = D.Event(), D.Event()

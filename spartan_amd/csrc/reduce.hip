@@ -1,6 +1,8 @@
 // sp_reduce: C-ABI entry for the fused map->reduce kernels (see reduce_impl.hpp).
 #include "reduce_impl.hpp"
 
+static_assert(sizeof(RedOut) == 56, "sp_jit_preload (sp_jit.hip) warms the reduce kernels with a zeroed RedOut of this size");
+
 extern "C" size_t sp_reduce_workspace_bytes(int32_t cls, int64_t outer, int64_t axis_len, int64_t inner) {
   return sp_ws_bytes(cls, outer, axis_len, inner, false);
 }

@@ -480,7 +480,9 @@ extern "C" int sp_jit_preload(int device) {
   // The first launch of a function pays for its set-up on the device (hundreds of microseconds measured for a
   // preloaded map kernel: 0.64 ms against 0.012 ms for every later launch).  Map kernels share one signature and do
   // nothing for nvec = 0, so each is launched once, empty, on a stream of this thread: the first real launch of a
-  // seeded program is then an ordinary launch.  (Reduce kernels have other signatures and are left alone.)
+  // seeded program is then an ordinary launch.  The reduce kernels do nothing for an empty outer range (O = 0) and
+  // get the same treatment (round 5: the first launch of a seeded fused reduction on the 2 GiB tile took 0.75 ms for
+  // a 0.33 ms kernel).
   hipStream_t warm = nullptr;
   if (hipStreamCreateWithFlags(&warm, hipStreamNonBlocking) != hipSuccess) warm = nullptr;
   (void)hipGetLastError();
@@ -515,6 +517,34 @@ extern "C" int sp_jit_preload(int device) {
         int64_t start0 = 0, nvec0 = 0;
         void* args[] = {&p0, &in0, &out0, &start0, &nvec0};
         (void)hipModuleLaunchKernel(fn, 1, 1, 1, SP_BLOCK, 1, 1, 0, warm, args, nullptr);
+        (void)hipGetLastError();
+      }
+      if (warm && symbol.find("sp_reduce_") != std::string::npos) {
+        // (p, in, op, O, A[, I], [chunk, nsplit,] RedOut[, c0]): see reduce_impl.hpp; RedOut is 56 bytes of pointers
+        // and integers (reduce.hip asserts the size), all zero here
+        sp_program p0;
+        sp_inputs in0;
+        memset(&p0, 0, sizeof p0);
+        memset(&in0, 0, sizeof in0);
+        p0.ndim = 1;
+        p0.shape[0] = 1;
+        int op0 = 0, nsplit0 = 1;
+        int64_t zero = 0, one = 1;
+        unsigned char ro0[56];
+        memset(ro0, 0, sizeof ro0);
+        const bool cols = symbol.find("sp_reduce_cols_kernel") != std::string::npos;
+        const bool wave = symbol.find("sp_reduce_rows_wave_kernel") != std::string::npos;
+        const bool rows = !cols && !wave && symbol.find("sp_reduce_rows_kernel") != std::string::npos;
+        if (cols) {
+          void* args[] = {&p0, &in0, &op0, &zero, &one, &one, &one, &nsplit0, ro0, &zero};
+          (void)hipModuleLaunchKernel(fn, 1, 1, 1, SP_BLOCK, 1, 1, 0, warm, args, nullptr);
+        } else if (rows) {
+          void* args[] = {&p0, &in0, &op0, &zero, &one, &one, &nsplit0, ro0};
+          (void)hipModuleLaunchKernel(fn, 1, 1, 1, SP_BLOCK, 1, 1, 0, warm, args, nullptr);
+        } else if (wave) {
+          void* args[] = {&p0, &in0, &op0, &zero, &one, ro0};
+          (void)hipModuleLaunchKernel(fn, 1, 1, 1, SP_BLOCK, 1, 1, 0, warm, args, nullptr);
+        }
         (void)hipGetLastError();
       }
       std::lock_guard<std::mutex> lock(g_mu);
