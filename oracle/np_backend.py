@@ -357,6 +357,9 @@ class NumpyBackend(object):
   def sparse_to_dense(self, b):
     return self.from_numpy(np.asarray(b.todense()))
 
+  def dense_to_sparse(self, t, dtype=None):
+    return sps.csr_matrix(np.asarray(t, dtype=dtype))
+
   def sparse_transpose(self, b):
     return b.transpose()
 

@@ -892,7 +892,12 @@ class DistArrayImpl(DistArray):
         data = ctx.backend.sparse_to_dense(ctx.backend.sparse_blob(data, self.dtype))
         owned = True
     elif self.sparse and not isinstance(data, Absent):
-      raise NotImplementedError('a dense update of a sparse array is not supported; yield a sparse block')
+      # A dense block for a sparse target (tile.pyx:284-297: the reference turns the tile into LIL and assigns the
+      # slice, "this is SLOW"): its non-zero cells travel and merge as a sparse block.  That is the same array for
+      # the two reducers a sparse tile has -- None replaces the cells of the box (zeros of the block clear what was
+      # there: the box's old entries are dropped) and np.add adds, to which zeros contribute nothing.
+      data = ctx.backend.dense_to_sparse(data, self.dtype)
+      owned = True
     if ctx.pending is not None:
       ctx.pending.add(self, region, data, owned)
       return None

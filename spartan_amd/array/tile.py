@@ -291,6 +291,6 @@ def _merge_sparse(backend, old_tile, subslice, update, reducer):
     old_tile.data = backend.sparse_update(old_tile.data, ul, lr, update, reducer)
     return old_tile
   # dense update of a sparse tile: the reference converts the tile to lil and assigns the slice
-  # (tile.pyx:283-295, marked "this is SLOW")
-  raise NotImplementedError('a dense update of a sparse tile is not supported; make the target dense '
-                            'or yield a sparse block')
+  # (tile.pyx:283-295, marked "this is SLOW").  Here the block's non-zero cells merge as a sparse block: the same
+  # result for reducer None (the box is replaced, zeros of the block included) and for np.add.
+  return _merge_sparse(backend, old_tile, subslice, backend.dense_to_sparse(update, old_tile.dtype), reducer)

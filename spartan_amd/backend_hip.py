@@ -1105,6 +1105,11 @@ class HipBackend(object):
     self.launches += 1
     return sparse_mod.to_dense(b)
 
+  def dense_to_sparse(self, t, dtype=None):
+    """The non-zero cells of a dense block as a sparse tile (a dense update of a sparse array, tile.pyx:284-297)."""
+    self.launches += 4
+    return sparse_mod.from_dense(t, dtype)
+
   def sparse_transpose(self, b):
     self.launches += 1
     return sparse_mod.transpose(b)

@@ -163,6 +163,24 @@ def from_scipy(mat, device, dtype=None):
   return from_coo(coo.shape, dtype, rows, cols, vals)
 
 
+def from_dense(x, dtype=None):
+  """The non-zero cells of a dense (m, n) device array as a tile (what scipy makes of `csr_matrix(dense)`): row and
+  column numbers are built on the device by broadcasting two small index vectors, cells equal to zero get row -1,
+  which sp_coo_to_csr drops."""
+  m, n = int(x.shape[0]), int(x.shape[1])
+  dtype = _check_dtype(np_dtype_of(x) if dtype is None else dtype)
+  if m == 0 or n == 0:
+    return empty((m, n), dtype, None)
+  be = _be()
+  x = _cast(x.contiguous(), dtype)
+  row_of = D.from_numpy(np.arange(m, dtype=np.int32).reshape(m, 1))
+  col_of = D.from_numpy(np.arange(n, dtype=np.int32).reshape(1, n))
+  stored = be.evaluate_fn(np.not_equal, [x, dtype.type(0)], {}, (m, n))
+  rows = be.evaluate_fn(np.where, [stored, row_of, np.int32(-1)], {}, (m, n))
+  cols = be.evaluate_fn(np.add, [col_of, D.zeros((m, 1), np.int32)], {}, (m, n))
+  return from_coo((m, n), dtype, rows.reshape(m * n).contiguous(), cols.reshape(m * n).contiguous(), x.reshape(m * n))
+
+
 def to_scipy(t):
   import scipy.sparse
   return scipy.sparse.csr_matrix((t.data.numpy(), t.indices.numpy(), t.indptr.numpy()),

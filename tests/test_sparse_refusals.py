@@ -1,7 +1,9 @@
-"""The merge branches of sparse tiles the product does NOT implement say so, with the reason, instead of computing
-something else (reference: spartan/array/tile.pyx:236-247 applies `reducer(old, update)` to two scipy matrices --
-only np.add has a sparse meaning there -- and :284-297 converts the tile to LIL and assigns a dense slice, marked
-"this is SLOW").  Pinned here so that a caller who hits one of them reads what to do."""
+"""The merge branches of sparse tiles next to the main one (reference: spartan/array/tile.pyx:236-247 applies
+`reducer(old, update)` to two scipy matrices -- only np.add has a sparse meaning there -- and :284-297 converts the
+tile to LIL and assigns a dense slice, marked "this is SLOW").  A DENSE update of a sparse array is carried out (its
+non-zero cells merge as a sparse block: the same array for the reducers None and np.add); what the product does not
+implement -- sparse reducers other than np.add, integer sparse tiles -- says so with the reason, pinned here so that
+a caller who hits one of them reads what to do."""
 import numpy as np
 import pytest
 import scipy.sparse
@@ -18,15 +20,55 @@ def ctx():
   sp.shutdown()
 
 
-def test_dense_update_of_a_sparse_tile_is_refused_with_the_way_out(ctx):
-  t = tile.from_shape((4, 6), np.float32, tile.TYPE_SPARSE)
-  with pytest.raises(NotImplementedError, match='dense update of a sparse tile is not supported; make the target dense'):
-    tile.merge(ctx.backend, t, None, np.ones((4, 6), np.float32), np.add)
-  # ... and one level up, before anything travels between workers
-  a = sp.sparse_rand((8, 6), density=0.5, format='csr', dtype=np.float32).evaluate()
-  assert a.sparse
-  with pytest.raises(NotImplementedError, match='dense update of a sparse array is not supported; yield a sparse block'):
-    a.update(extent.create((0, 0), (4, 6), (8, 6)), ctx.backend.from_numpy(np.ones((4, 6), np.float32)))
+def _dense_updates_of_a_sparse_array(workers):
+  """Dense blocks written into a sparse array, tile boundaries crossed, against the same assignments on a dense
+  NumPy copy: reducer None replaces the cells of the box (zeros of the block included), np.add adds."""
+  from tests import sparse_programs as SP
+  ctx = sp.get_context()
+  be = ctx.backend
+  shape = (24, 18)
+  for reducer in (None, np.add):
+    target = sp.ndarray(shape, dtype=np.float32, sparse=True, tile_hint=(24 // workers, 18))
+    a = sp.shuffle(target, SP._make_links, target=target, kw={'seed': 3}).evaluate()
+    assert a.sparse
+    a.reducer_fn = reducer
+    want = np.asarray(a.glom().todense())
+    rng = np.random.RandomState(5)
+    for ul, lr in (((2, 3), (9, 11)), ((0, 0), (24, 18)), ((10, 0), (14, 18)), ((23, 17), (24, 18))):
+      block = rng.randint(-2, 3, size=(lr[0] - ul[0], lr[1] - ul[1])).astype(np.float32)      # (about a fifth zeros)
+      a.update(extent.create(ul, lr, shape), be.from_numpy(block))
+      box = (slice(ul[0], lr[0]), slice(ul[1], lr[1]))
+      want[box] = block if reducer is None else want[box] + block
+      got = a.glom()
+      assert scipy.sparse.issparse(got)
+      np.testing.assert_array_equal(np.asarray(got.todense()), want)
+      if reducer is None:
+        assert got.nnz == np.count_nonzero(want)            # no explicit zeros left behind by a replaced box
+
+
+@pytest.mark.parametrize('workers', [1, 3])
+def test_dense_update_of_a_sparse_array(workers):
+  from oracle.np_backend import NumpyBackend
+  sp.initialize(backend=NumpyBackend(), num_workers=workers)
+  try:
+    _dense_updates_of_a_sparse_array(workers)
+    t = tile.from_shape((4, 6), np.float32, tile.TYPE_SPARSE)
+    tile.merge(sp.get_context().backend, t, None, np.eye(4, 6, dtype=np.float32), np.add)       # the tile level, directly
+    np.testing.assert_array_equal(np.asarray(t.data.todense()), np.eye(4, 6, dtype=np.float32))
+  finally:
+    sp.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workers', [1, 3])
+def test_dense_update_of_a_sparse_array_hip(workers):
+  ctx = sp.initialize('hip', num_workers=workers)
+  try:
+    before = ctx.backend.launches
+    _dense_updates_of_a_sparse_array(workers)
+    assert ctx.backend.launches > before
+  finally:
+    sp.shutdown()
 
 
 def test_hip_backend_combines_sparse_tiles_with_add_only():
