@@ -269,6 +269,9 @@ def lib():
       raise HipLibraryMissing(
           '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
           '(or `make -C spartan_amd/csrc`). The HIP tile backend has no CPU fallback.' % LIB_PATH)
+    # dmabuf IPC between the per-GPU processes of a job (RCCL over xGMI): the host driver supports nothing else, and
+    # the HSA runtime reads the variable when it comes up -- i.e. with the first HIP call this library makes
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     _lib = _declare(C.CDLL(LIB_PATH))
     if _lib.sp_abi_version() != 1:
       raise HipError('libspartan_hip.so ABI version mismatch')

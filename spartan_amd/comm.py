@@ -77,6 +77,16 @@ def mapped_runtimes():
   return {k: sorted(v) for k, v in found.items()}
 
 
+def _need_dense(*tensors):
+  """Collectives take whole dense buffers: the RCCL transport hands RCCL a base pointer and a count.  (The host
+  transports would copy a strided view and hide the mistake: `World` checks for every transport, so that the CPU
+  tests see what a GPU job would do.)"""
+  for t in tensors:
+    ok = t.is_contiguous() if hasattr(t, 'is_contiguous') else t.flags['C_CONTIGUOUS']
+    if not ok:
+      raise AssertionError('a collective was handed a strided view of shape %s: make it contiguous first' % (tuple(t.shape),))
+
+
 def gpu_count():
   """HIP devices visible to libspartan_hip.so (0 when the library is not built or no device answers)."""
   try:
@@ -178,24 +188,29 @@ class RcclTransport(object):
                         [t for _, t in sends] + [t for _, t in recvs], async_)
 
   def all_gather_into(self, out, tensor, async_=False):
+    _need_dense(out, tensor)
     return self._launch(lambda st: self.lib.sp_comm_all_gather(self.comm, self._p(tensor), self._p(out),
                                                                tensor.size, self._dt(tensor), st),
                         [out, tensor], async_)
 
   def reduce_scatter(self, out, inp, reducer, async_=False):
+    _need_dense(out, inp)
     return self._launch(lambda st: self.lib.sp_comm_reduce_scatter(self.comm, self._p(inp), self._p(out), out.size,
                                                                    self._dt(inp), self._red(reducer), st),
                         [out, inp], async_)
 
   def all_reduce(self, tensor, reducer):
+    _need_dense(tensor)
     self._launch(lambda st: self.lib.sp_comm_all_reduce(self.comm, self._p(tensor), self._p(tensor), tensor.size,
                                                         self._dt(tensor), self._red(reducer), st), [tensor], False)
 
   def reduce(self, tensor, dst, reducer):
+    _need_dense(tensor)
     self._launch(lambda st: self.lib.sp_comm_reduce(self.comm, self._p(tensor), self._p(tensor), tensor.size,
                                                     self._dt(tensor), self._red(reducer), dst, st), [tensor], False)
 
   def broadcast(self, tensor, src):
+    _need_dense(tensor)
     self._launch(lambda st: self.lib.sp_comm_bcast(self.comm, self._p(tensor), tensor.size, self._dt(tensor),
                                                    src, st), [tensor], False)
 
@@ -607,6 +622,7 @@ class World(object):
     self.stats['collective_bytes'] += int(nbytes)
 
   def all_gather_into(self, out, tensor):
+    _need_dense(out, tensor)
     self._count(tensor.nbytes * (self.size - 1))
     self.transport.all_gather_into(out, tensor)
 
@@ -614,27 +630,33 @@ class World(object):
     """all_gather_into without waiting: returns a handle whose wait() makes the CURRENT STREAM wait for the
     result (the collective runs on a communication stream, so kernels launched meanwhile overlap with it).
     Host-side transports complete immediately and return None."""
+    _need_dense(out, tensor)
     self._count(tensor.nbytes * (self.size - 1))
     return self.transport.all_gather_into(out, tensor, async_=True)
 
   def reduce_scatter(self, out, inp, reducer):
     """out[rank piece] = reduce over ranks of inp (inp = size equal pieces)."""
+    _need_dense(out, inp)
     self._count(inp.nbytes * (self.size - 1) // self.size)
     self.transport.reduce_scatter(out, inp, reducer)
 
   def reduce_scatter_async(self, out, inp, reducer):
+    _need_dense(out, inp)
     self._count(inp.nbytes * (self.size - 1) // self.size)
     return self.transport.reduce_scatter(out, inp, reducer, async_=True)
 
   def all_reduce(self, tensor, reducer):
+    _need_dense(tensor)
     self._count(2 * tensor.nbytes * (self.size - 1) // self.size)
     self.transport.all_reduce(tensor, reducer)
 
   def reduce(self, tensor, dst, reducer):
+    _need_dense(tensor)
     self._count(tensor.nbytes)
     self.transport.reduce(tensor, dst, reducer)
 
   def broadcast(self, tensor, src):
+    _need_dense(tensor)
     self._count(tensor.nbytes)
     self.transport.broadcast(tensor, src)
 
