@@ -245,9 +245,11 @@ MFMA_F64_SPEC_TFLOPS = 78.6     # AMD's MI355X figure for the fp64 matrix pipe (
 
 
 def dot_f64_section(ctx):
-  """The reference's own dot benchmark is float64 (tests/benchmark_dot.py:17-27, np.double on a sqrt(p) x sqrt(p)
-  grid; its builders default to float64): spartan.dot 8192^3 fp64 on one tile and on the benchmark's 2 x 2 grid of
-  4096^2 tiles, against the fp64 matrix rate PROBED on this GPU (a loop of v_mfma_f64_16x16x4_f64 on every CU)."""
+  """The reference's own dot benchmark is float64 (tests/benchmark_dot.py:17-27; its builders default to float64):
+  spartan.dot 8192^3 fp64 on one tile against the fp64 matrix rate PROBED on this GPU (a loop of
+  v_mfma_f64_16x16x4_f64 on every CU).  The benchmark's sqrt(p) x sqrt(p) GRID tiling is not timed: on grid tiles
+  the reference's join multiplies one-index-thick slabs (extent.pyx:545-552) -- not the matrix product, reproduced
+  bit for bit and pinned by tests/test_dot_grid_tiles.py -- so there is no GEMM there to price."""
   n = 8192
   mk = lambda seed, hint=None: sp.astype(sp.from_tile_fn((n, n), np.float32, lambda ex: device_uniform(ex, -1.0, 1.0, seed),   # noqa: E731
                                                           tile_hint=hint), np.float64).force()

@@ -725,7 +725,40 @@ def region_goldens(sp, workers):
   return arrays
 
 
+def dot_grid_goldens(sp):
+  """spartan.dot on operands cut into a 2-D GRID of tiles -- the tiling of the reference's own tests/benchmark_dot.py
+  (tile_hint=(T, T)) -- as the reference computes it.  (What it computes is NOT the matrix product: the join turns
+  grid cell number b into a slab ONE index thick, extent.pyx:545-552, so only the first <number of cells> indices
+  of the contraction take part; the benchmark never looks at the values.  Recorded so that the build reproduces the
+  reference here as everywhere else, and says so.)"""
+  rng = np.random.RandomState(20150708)
+  out = {}
+  for name, (m, k, n, t) in (('sq16', (16, 16, 16, (8, 8))), ('wide', (12, 24, 8, (6, 8)))):
+    a = rng.randint(-3, 4, size=(m, k)).astype(np.float64)
+    b = rng.randint(-3, 4, size=(k, n)).astype(np.float64)
+    out[name + '__a'], out[name + '__b'] = a, b
+    out[name + '__hint'] = np.asarray(t)
+    for workers in (1, 4):
+      start_cluster(sp, workers)
+      A = sp.from_numpy(a, tile_hint=t)
+      B = sp.from_numpy(b, tile_hint=(t[1], t[1]) if name == 'wide' else t)
+      out['%s__w%d' % (name, workers)] = np.asarray(sp.dot(A, B).glom())
+  return out
+
+
 if __name__ == '__main__':
+  if '--dotgrid' in sys.argv:
+    if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
+      prepare_tree()
+      build_cython()
+    prepare_examples()
+    install_stubs()
+    sp = import_reference()
+    res = dot_grid_goldens(sp)
+    np.savez_compressed(os.path.join(OUT, 'dot_grid.npz'), **res)
+    print('dot on grid tiles:', sorted(res))
+    sys.stdout.flush()
+    os._exit(0)
   if '--region' in sys.argv:
     if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
       prepare_tree()
