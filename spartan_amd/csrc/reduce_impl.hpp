@@ -127,10 +127,16 @@ struct ArgAcc {
   // Per-lane accumulation: every caller feeds one accumulator with INCREASING
   // positions `a`, so "first occurrence" only needs a strict value comparison
   // (the full (value, index) order is needed only when lanes are merged).
+  // Branch-free (round 5; the short-circuit form compiled to an exec-mask region and a branch on `op` per element):
+  // `!(x <= v)` holds when x is larger OR either is NaN, so with "v is not NaN" it is exactly "x is larger, or x is
+  // the first NaN"; an empty accumulator (i < 0: the sign of the index's high word) takes anything.
   __device__ __forceinline__ void add(int op, T x, int64_t a) {
-    const bool xn = sp_math<T>::isnan_(x), vn = sp_math<T>::isnan_(v);
-    const bool take = (i < 0) || (!vn && (xn || (op == 0 ? (x > v) : (x < v))));
-    if (take) { v = x; i = a; }
+    const bool beats_max = !(x <= v), beats_min = !(x >= v);
+    const bool beats = op == 0 ? beats_max : beats_min;
+    const bool keeps = !sp_math<T>::isnan_(v);
+    const bool take = ((int32_t)(i >> 32) < 0) | (beats & keeps);
+    v = take ? x : v;
+    i = take ? a : i;
   }
   __device__ __forceinline__ void merge(int op, const ArgAcc& o) {
     if (better(op, o.v, o.i, v, i)) { v = o.v; i = o.i; }
@@ -651,12 +657,20 @@ static int sp_reduce_launch(const sp_program* p, const sp_inputs& in, const void
   const bool jit_ok = vec && sid < 0 && sp_jit_enabled() && O * A * I >= sp_jit_min_elems();
   int jit_mask = -1;
   if (jit_ok && !lin && p->shape[1] == ((I == 1) ? A : I)) jit_mask = sp_mask_2d(p, p->n_inputs);
-  const int sop = (!kArg && (op == SP_RED_SUM || op == SP_RED_MAX || op == SP_RED_MIN)) ? op : -1;
+  // the combine op as a template constant: SUM / MAX / MIN of the plain reductions, and BOTH ops of the index
+  // reductions (0 argmax, 1 argmin: with `op` a run-time value ArgAcc::add selects between two comparison results
+  // per element, which the compiler does in vector registers)
+  const int sop = kArg ? ((op == 0 || op == 1) ? op : -1)
+                       : ((op == SP_RED_SUM || op == SP_RED_MAX || op == SP_RED_MIN) ? op : -1);
 #define SP_GO(KERNEL, GRID, LIN, PROG, OPC, MSK, ...) \
   hipLaunchKernelGGL((KERNEL<T, VV, LIN, AccT, PROG, OPC, MSK>), GRID, dim3(SP_BLOCK), 0, st, __VA_ARGS__)
 #define SP_LAUNCH_OP(KERNEL, GRID, LIN, PROG, MSK, ...)                                   \
   do {                                                                                    \
-    if constexpr (kArg) { SP_GO(KERNEL, GRID, LIN, PROG, -1, MSK, __VA_ARGS__); }         \
+    if constexpr (kArg) {                                                                 \
+      if (sop == 0) SP_GO(KERNEL, GRID, LIN, PROG, 0, MSK, __VA_ARGS__);                  \
+      else if (sop == 1) SP_GO(KERNEL, GRID, LIN, PROG, 1, MSK, __VA_ARGS__);             \
+      else SP_GO(KERNEL, GRID, LIN, PROG, -1, MSK, __VA_ARGS__);                          \
+    }                                                                                     \
     else {                                                                                \
       if (sop == SP_RED_SUM) SP_GO(KERNEL, GRID, LIN, PROG, SP_RED_SUM, MSK, __VA_ARGS__); \
       else if (sop == SP_RED_MAX) SP_GO(KERNEL, GRID, LIN, PROG, SP_RED_MAX, MSK, __VA_ARGS__); \
