@@ -476,8 +476,8 @@ def dist_section(ctx, p=None):
   for name, build, bpe in progs:
     def step():
       keep[:] = [build().force()]
-    dt = time_steps(ctx, step, 5, 2)
-    out[name + '_GBps'] = round(bpe * E * 5 / dt / 1e9, 1)
+    dt = time_steps(ctx, step, 10, 3)
+    out[name + '_GBps'] = round(bpe * E * 10 / dt / 1e9, 1)
     del keep[:]
   return out
 
