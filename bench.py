@@ -148,6 +148,10 @@ def hbm_section(ctx):
   # the process's first two launches of the program, one at a time on an idle device.  The expression is built and
   # optimised before the events (host work, ~0.3 ms, that a loop overlaps with the previous launch): the timed
   # force() lowers it, finds the code object (preloaded from csrc/jit_seed by the backend) and launches.
+  # (both results stay alive while they are timed: two free tiles in the store first, so that neither call measures
+  #  a 2 GiB hipMalloc -- results die with their last reference now, the pool no longer holds leftovers)
+  spare = [D.empty(x.shape, x.dtype) for _ in range(2)]
+  del spare
   pending = [(((Xv * Xv + Xv) * 0.5 - Xv) / (Xv + 2.0)).optimized() for _ in range(2)]
   for tag, e in zip(('first', 'second'), pending):
     D.synchronize()
