@@ -126,6 +126,24 @@ def test_a_rank_that_leaves_fails_the_round_it_never_joined(job_env):
   assert _threads(2, body) == ['saw it', 'left']
 
 
+def test_a_rank_that_never_arrives_times_the_round_out_with_its_number(job_env):
+  """A hung rank (connected, silent) must not block the others for ever: the round fails after the deadline and
+  names who was missing."""
+  from spartan_amd import rendezvous
+  hub = rendezvous.Hub(2, timeout_s=0.6)
+  try:
+    c0 = rendezvous.Client(0, 2, 5.0, port=hub.port)
+    c1 = rendezvous.Client(1, 2, 5.0, port=hub.port)          # joins, then never calls the barrier
+    t0 = time.time()
+    with pytest.raises(rendezvous.RendezvousError, match=r'timed out after 1 s waiting for ranks \[1\]|timed out after 0 s waiting for ranks \[1\]'):
+      c0.barrier()
+    assert time.time() - t0 < 5
+    c0.close()
+    c1.close()
+  finally:
+    hub.close(1.0)
+
+
 def test_hub_moves_past_a_taken_port_and_clients_pass_over_strangers(job_env):
   """MASTER_PORT is held by something that is not our hub (it accepts and says nothing useful): rank 0 binds the
   next port, and the clients find it there by the handshake."""
