@@ -21,6 +21,11 @@ holds MASTER_PORT; it is never touched).  If that port is taken rank 0 moves up 
 same ports and recognises its hub by a handshake carrying a key derived from MASTER_ADDR / MASTER_PORT / WORLD_SIZE
 / the launcher's run id, so a neighbouring job's hub (or anything else that listens there) is passed over.
 
+Messages are pickles, as the reference's RPC payloads are (spartan/rpc/serialization*.pyx, cloudpickle): the hub is for
+the ranks of ONE job on a trusted network.  It listens on the loopback interface when MASTER_ADDR is local; anything
+that connects must present the job key before a single message is read, and SPARTAN_JOB_ID (any string, the same on
+every rank) makes that key unguessable where the address is shared.
+
 A rank whose connection drops without saying goodbye is recorded as gone: every round it has not joined and every
 receive from it fail on the ranks waiting for them with the reason, instead of blocking them for ever.
 """
