@@ -113,7 +113,18 @@ enum sp_opcode {
   SP_OP_TO_I32 = 51,  /* C cast to int32 (wraps / truncates toward zero) */
   SP_OP_TO_I64 = 52,  /* truncate toward zero */
   SP_OP_TO_BOOL = 53, /* x != 0 */
-  SP_OP_TO_U8 = 54
+  SP_OP_TO_U8 = 54,
+  /* one operand a constant: dst = reg[b] (op) consts[a] -- the emitter folds `x + 1`, `x * 0.5`, `2 - x` ... into ONE
+   * instruction instead of a CONST into a register followed by the operator (a third fewer dispatches for the
+   * interpreter tier on typical fused trees; the specialised tiers compile to the same code either way). */
+  SP_OP_ADDC = 60,
+  SP_OP_SUBC = 61,  /* reg - const */
+  SP_OP_RSUBC = 62, /* const - reg */
+  SP_OP_MULC = 63,
+  SP_OP_DIVC = 64,  /* reg / const */
+  SP_OP_RDIVC = 65, /* const / reg */
+  SP_OP_MAXC = 66,
+  SP_OP_MINC = 67
 };
 
 typedef struct sp_instr {

@@ -24,7 +24,8 @@ OP = dict(
     ADD=10, SUB=11, MUL=12, DIV=13, FLOORDIV=14, MOD=15, FMOD=16, POW=17, MAX=18, MIN=19,
     EQ=20, NE=21, LT=22, LE=23, GT=24, GE=25, LAND=26, LOR=27, LXOR=28, LNOT=29,
     NEG=30, ABS=31, SQRT=32, SQUARE=33, EXP=34, LOG=35, RECIP=36, SIGN=37, FLOOR=38, CEIL=39,
-    TANH=40, NORM_CDF=41, WHERE=45, TO_F32=50, TO_I32=51, TO_I64=52, TO_BOOL=53, TO_U8=54)
+    TANH=40, NORM_CDF=41, WHERE=45, TO_F32=50, TO_I32=51, TO_I64=52, TO_BOOL=53, TO_U8=54,
+    ADDC=60, SUBC=61, RSUBC=62, MULC=63, DIVC=64, RDIVC=65, MAXC=66, MINC=67)
 
 RED = dict(SUM=0, PROD=1, MAX=2, MIN=3, AND=4, OR=5)
 REDUCER = dict(NONE=0, ADD=1, MUL=2, MAX=3, MIN=4, AND=5, OR=6)

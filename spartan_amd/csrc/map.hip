@@ -41,6 +41,10 @@ int sp_validate_program(const sp_program* p) {
     if (I.dst >= SP_NREG || I.c >= SP_NREG) SP_FAIL("instr %d: register out of range", i);
     if (I.op == SP_OP_CONST) {
       if (I.a >= SP_MAX_CONSTS) SP_FAIL("instr %d: const index out of range", i);
+    } else if (I.op >= SP_OP_ADDC && I.op <= SP_OP_MINC) {      // reg[b] (op) consts[a]
+      if (I.a >= SP_MAX_CONSTS) SP_FAIL("instr %d: const index out of range", i);
+      if (I.b >= SP_NREG) SP_FAIL("instr %d: register out of range", i);
+      if ((1u << I.b) & ~defined) SP_FAIL("instr %d: reads a register nothing has written", i);
     } else if (I.a >= SP_NREG || I.b >= SP_NREG) {
       SP_FAIL("instr %d: register out of range", i);
     } else if (I.op != SP_OP_NOP && I.op != SP_OP_IOTA) {
@@ -64,11 +68,13 @@ static inline unsigned sp_grid_for(int64_t nvec, int U) {
   int64_t blocks = (nvec + (int64_t)SP_BLOCK * U - 1) / ((int64_t)SP_BLOCK * U);
   // interpreter kernels pay a per-workgroup prologue (program + strides from the kernel
   // argument segment): a capped grid that strides measured faster than a full grid
-  // (round 4, 2 GiB tile, 5-op chain: 8 / 16 / 32 workgroups per CU 1.23 / 1.18 / 1.16 ms, the whole tile 1.34)
+  // (round 4, 2 GiB tile, 5-op chain: 8 / 16 / 32 workgroups per CU 1.23 / 1.18 / 1.16 ms, the whole tile 1.34;
+  // round 5, after the trip lost its hoisted index conversions: 16 / 32 / 64 / 128 / 256 per CU and the whole tile
+  // 1.00 / 0.97 / 0.93 / 0.98 / 1.01 / 1.20 ms, `x + 1` 0.85 / 0.84 / 0.77 / 0.77 / 0.74 / 0.90)
   static int per_cu = -1;
   if (per_cu < 0) {
     const char* e = getenv("SP_INTERP_WG_PER_CU");
-    per_cu = e ? atoi(e) : 4 * SP_BLOCKS_PER_CU;
+    per_cu = e ? atoi(e) : 8 * SP_BLOCKS_PER_CU;
   }
   const int64_t cap = (int64_t)SP_CUS * per_cu;
   if (per_cu > 0 && blocks > cap) blocks = cap;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_map_kernel(const sp_program p, co
                                                           void* __restrict__ out, int64_t start,
                                                           int64_t nvec) {
   const int64_t stride = (int64_t)gridDim.x * SP_BLOCK * U;
-  const sp_dyn dyn = sp_dyn_program<P>(p);
+  const sp_dyn dyn = sp_dyn_program<P, T>(p);
   if constexpr (RAGGED) {
     static_assert(U == 1 && !LINEAR, "ragged rows: strided programs, one group per lane");
     const int64_t inner = p.shape[p.ndim - 1];

@@ -90,6 +90,26 @@ __device__ __forceinline__ T sp_shfl_down(T v, int delta) {
 }
 
 // Plain reduction state.
+// The combine op as a compile-time constant around a block of adds: ONE scalar switch per trip.  With `op` a run-time
+// value inside Acc::add, the interpreted kernels (OP = -1) went through the switch once per ELEMENT -- 8 x (15 scalar
+// instructions, a handful of branches, one dynamically indexed read of the result) per trip, which is what bound the
+// interpreted column reduction (202 scalar instructions per trip of 512 elements; profiles/r05_notes.md section 11).
+template <int K>
+struct sp_op_c {
+  static constexpr int value = K;
+};
+template <typename F>
+__device__ __forceinline__ void sp_with_op(int op, F&& body) {
+  switch (op) {
+    case 1: body(sp_op_c<1>{}); break;
+    case 2: body(sp_op_c<2>{}); break;
+    case 3: body(sp_op_c<3>{}); break;
+    case 4: body(sp_op_c<4>{}); break;
+    case 5: body(sp_op_c<5>{}); break;
+    default: body(sp_op_c<0>{}); break;
+  }
+}
+
 template <typename T>
 struct PlainAcc {
   T v;
@@ -225,7 +245,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
   using Acc = AccT<T>;
   __shared__ Acc sm[SP_BLOCK / 64];
   if constexpr (OP >= 0) op = OP;   // specialised kernels: the combine op is a constant too
-  const sp_dyn dyn = sp_dyn_program<P>(p);
+  const sp_dyn dyn = sp_dyn_program<P, T>(p);
   const int s = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int64_t o = blockIdx.y; o < O; o += gridDim.y) {
@@ -234,8 +254,59 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
     if (a1 > A) a1 = A;
     Acc acc;
     acc.init(op);
+    bool walked = false;
+    if constexpr (!P::kStatic && LINEAR && V == 4 && sp_is_same<T, float>::value && MASK < 0) {
+      // Interpreted dense fp32 programs: the walk along the row pipelined as in sp_reduce_cols_kernel (the operands of
+      // trip t + 1 requested before trip t's program is dispatched; UP groups share a dispatch).  The plain loop below
+      // issued 0.8 scalar instructions per ELEMENT (addressing and operand-type decisions of every trip) and was bound
+      // by scalar issue, not by HBM or the vector ALU (profiles/r05_notes.md section 11).
+      if (sp_ahead_applies<T, SP_RED_AHEAD_N>(p)) {
+        walked = true;
+        constexpr int UP = SP_RED_AHEAD_UP;
+        constexpr int64_t step = (int64_t)SP_BLOCK * V;
+        int64_t a = a0 + (int64_t)threadIdx.x * V;
+        if (a + V <= a1) {
+          sp_ahead<T, V, UP, SP_RED_AHEAD_N> ah;
+          auto place = [&](int64_t at, int64_t (&Lo)[UP]) {
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+              const int64_t au = at + (int64_t)u * step;
+              Lo[u] = o * A + (au + V <= a1 ? au : at);      // groups past the chunk re-read group `at` (not added)
+            }
+          };
+          int64_t L[UP];
+          place(a, L);
+          sp_fetch_ahead<T, V, UP, 0>(p, in, L, ah);
+          for (;;) {
+            const bool more = a + step * UP + V <= a1;
+            auto mid = [&]() {
+              if (more) {
+                int64_t Ln[UP];
+                place(a + step * UP, Ln);
+                sp_fetch_ahead<T, V, UP, 0>(p, in, Ln, ah);
+              }
+            };
+            T x[UP][V];
+            sp_eval_u<T, V, UP, true, P, 0>(p, in, L, x, nullptr, dyn, &ah, mid);
+            sp_with_op(op, [&](auto k) {
+#pragma unroll
+              for (int u = 0; u < UP; ++u) {
+                const int64_t au = a + (int64_t)u * step;
+                if (u == 0 || au + V <= a1) {
+#pragma unroll
+                  for (int v = 0; v < V; ++v) acc.add(decltype(k)::value, x[u][v], au + v);
+                }
+              }
+            });
+            if (!more) break;
+            a += step * UP;
+            place(a, L);
+          }
+        }
+      }
+    }
     constexpr int U = 1;   // measured: more groups per lane do not help (profiles/r01_notes.md)
-    for (int64_t a = a0 + (int64_t)threadIdx.x * V; a + V <= a1; a += (int64_t)SP_BLOCK * V * U) {
+    for (int64_t a = a0 + (int64_t)threadIdx.x * V; !walked && a + V <= a1; a += (int64_t)SP_BLOCK * V * U) {
       int64_t L[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -249,14 +320,16 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
         const int64_t rc[1][2] = {{o, a}};   // (row, column) when the program space is [O, A]
         sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr, dyn);
       }
+      sp_with_op(op, [&](auto k) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t au = a + (int64_t)u * SP_BLOCK * V;
-        if (u == 0 || au < a1) {
+        for (int u = 0; u < U; ++u) {
+          const int64_t au = a + (int64_t)u * SP_BLOCK * V;
+          if (u == 0 || au < a1) {
 #pragma unroll
-          for (int v = 0; v < V; ++v) acc.add(op, x[u][v], au + v);
+            for (int v = 0; v < V; ++v) acc.add(decltype(k)::value, x[u][v], au + v);
+          }
         }
-      }
+      });
     }
     if constexpr (V > 1) {
       // the row's last (a1 - a0) % V elements (only when the row length is not a multiple of V)
@@ -286,7 +359,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
                                                                       int64_t O, int64_t A, RedOut ro) {
   using Acc = AccT<T>;
   if constexpr (OP >= 0) op = OP;
-  const sp_dyn dyn = sp_dyn_program<P>(p);
+  const sp_dyn dyn = sp_dyn_program<P, T>(p);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wstride = (int64_t)gridDim.x * (SP_BLOCK / 64);
   for (int64_t o = (int64_t)blockIdx.x * (SP_BLOCK / 64) + w; o < O; o += wstride) {
@@ -307,14 +380,16 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_wave_kernel(const sp_
         const int64_t rc[1][2] = {{o, a}};
         sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == A ? rc : nullptr, dyn);
       }
+      sp_with_op(op, [&](auto k) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t au = a + (int64_t)u * 64 * V;
-        if (u == 0 || au < A) {
+        for (int u = 0; u < U; ++u) {
+          const int64_t au = a + (int64_t)u * 64 * V;
+          if (u == 0 || au < A) {
 #pragma unroll
-          for (int v = 0; v < V; ++v) acc.add(op, x[u][v], au + v);
+            for (int v = 0; v < V; ++v) acc.add(decltype(k)::value, x[u][v], au + v);
+          }
         }
-      }
+      });
     }
     if constexpr (V > 1) {
       const int rem = (int)(A % V);
@@ -357,7 +432,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
   constexpr int NW = SP_BLOCK / 64;
   __shared__ Acc sm[NW - 1][64 * V];
   if constexpr (OP >= 0) op = OP;
-  const sp_dyn dyn = sp_dyn_program<P>(p);
+  const sp_dyn dyn = sp_dyn_program<P, T>(p);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int s = blockIdx.y;
   // columns c0 + ...: only whole groups of V (the I % V columns left over go to sp_reduce_cols_tail_kernel)
@@ -403,14 +478,16 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
             };
             T x[UP][V];
             sp_eval_u<T, V, UP, true, P, 0>(p, in, L, x, nullptr, dyn, &ah, mid);
+            sp_with_op(op, [&](auto k) {
 #pragma unroll
-            for (int u = 0; u < UP; ++u) {
-              const int64_t au = a + (int64_t)u * NW;
-              if (u == 0 || au < a1) {
+              for (int u = 0; u < UP; ++u) {
+                const int64_t au = a + (int64_t)u * NW;
+                if (u == 0 || au < a1) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) acc[v].add(op, x[u][v], au);
+                  for (int v = 0; v < V; ++v) acc[v].add(decltype(k)::value, x[u][v], au);
+                }
               }
-            }
+            });
             if (!more) break;
             a += NW * UP;
             place(a, L);
@@ -434,14 +511,16 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_kernel(const sp_progr
           const int64_t rc[1][2] = {{o * A + a, c}};   // (row, column) when the program space is [O*A, I]
           sp_eval_u<T, V, U, LINEAR, P, SP_RED_NTM(P)>(p, in, L, x, p.ndim == 2 && p.shape[1] == I ? rc : nullptr, dyn);
         }
+        sp_with_op(op, [&](auto k) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int64_t au = a + (int64_t)u * NW;
-          if (u == 0 || au < a1) {
+          for (int u = 0; u < U; ++u) {
+            const int64_t au = a + (int64_t)u * NW;
+            if (u == 0 || au < a1) {
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[v].add(op, x[u][v], au);
+              for (int v = 0; v < V; ++v) acc[v].add(decltype(k)::value, x[u][v], au);
+            }
           }
-        }
+        });
       }
     }
     if (w > 0) {
@@ -472,7 +551,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_cols_tail_kernel(const sp_
   using Acc = AccT<T>;
   constexpr int NR = SP_BLOCK / 4;
   __shared__ Acc sm[SP_BLOCK];
-  const sp_dyn dyn = sp_dyn_program<DynProg>(p);
+  const sp_dyn dyn = sp_dyn_program<DynProg, T>(p);
   const int col = threadIdx.x & 3, r = threadIdx.x >> 2;
   const int s = blockIdx.y;
   const int64_t c = c0 + col;

@@ -426,10 +426,10 @@ struct StaticProg;
 // the named expression (tests/test_hip_kernels.py::test_static_program_library
 // asserts that each of them is recognised).
 SP_DEF_STATIC(0, 1, 0, 0, SP_NOPI, SP_NOPI, SP_NOPI, SP_NOPI)                                        // x (reduce / argreduce of a tile)
-SP_DEF_STATIC(1, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_ADD, 1, 0, 1), SP_NOPI, SP_NOPI)    // x + c
-SP_DEF_STATIC(2, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_SUB, 1, 0, 1), SP_NOPI, SP_NOPI)    // x - c
-SP_DEF_STATIC(3, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_MUL, 1, 0, 1), SP_NOPI, SP_NOPI)    // x * c
-SP_DEF_STATIC(4, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_DIV, 1, 0, 1), SP_NOPI, SP_NOPI)    // x / c
+SP_DEF_STATIC(1, 1, 1, 1, SP_I(SP_OP_ADDC, 1, 0, 0), SP_NOPI, SP_NOPI, SP_NOPI)                      // x + c  (c + x)
+SP_DEF_STATIC(2, 1, 1, 1, SP_I(SP_OP_SUBC, 1, 0, 0), SP_NOPI, SP_NOPI, SP_NOPI)                      // x - c
+SP_DEF_STATIC(3, 1, 1, 1, SP_I(SP_OP_MULC, 1, 0, 0), SP_NOPI, SP_NOPI, SP_NOPI)                      // x * c  (c * x)
+SP_DEF_STATIC(4, 1, 1, 1, SP_I(SP_OP_DIVC, 1, 0, 0), SP_NOPI, SP_NOPI, SP_NOPI)                      // x / c
 SP_DEF_STATIC(5, 2, 2, 1, SP_I(SP_OP_ADD, 2, 0, 1), SP_NOPI, SP_NOPI, SP_NOPI)                       // a + b
 SP_DEF_STATIC(6, 2, 2, 1, SP_I(SP_OP_SUB, 2, 0, 1), SP_NOPI, SP_NOPI, SP_NOPI)                       // a - b
 SP_DEF_STATIC(7, 2, 2, 1, SP_I(SP_OP_MUL, 2, 0, 1), SP_NOPI, SP_NOPI, SP_NOPI)                       // a * b (also matrix.vector)
@@ -437,7 +437,7 @@ SP_DEF_STATIC(8, 2, 2, 1, SP_I(SP_OP_DIV, 2, 0, 1), SP_NOPI, SP_NOPI, SP_NOPI)  
 SP_DEF_STATIC(9, 1, 1, 2, SP_I(SP_OP_MUL, 1, 0, 0), SP_I(SP_OP_ADD, 1, 1, 0), SP_NOPI, SP_NOPI)      // x*x + x
 SP_DEF_STATIC(10, 3, 3, 2, SP_I(SP_OP_SUB, 3, 1, 2), SP_I(SP_OP_MUL, 3, 0, 3), SP_NOPI, SP_NOPI)     // x * (yp - y) (lreg gradient)
 SP_DEF_STATIC(11, 1, 1, 1, SP_I(SP_OP_MUL, 1, 0, 0), SP_NOPI, SP_NOPI, SP_NOPI)                      // x * x
-SP_DEF_STATIC(12, 1, 1, 2, SP_I(SP_OP_CONST, 1, 0, 0), SP_I(SP_OP_MUL, 1, 1, 0), SP_NOPI, SP_NOPI)   // c * x
+SP_DEF_STATIC(12, 1, 1, 1, SP_I(SP_OP_RSUBC, 1, 0, 0), SP_NOPI, SP_NOPI, SP_NOPI)                    // c - x
 #define SP_NUM_STATIC 13
 #define SP_FOR_EACH_STATIC(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
 
@@ -457,18 +457,42 @@ __device__ __forceinline__ sp_instr sp_unpack_instr(uint32_t w) {
 struct sp_dyn {
   uint32_t word;
   bool lanes_hold_program;
+  // constant k of the program, already of the kernel's arithmetic type, in lane k (low / high dword): an operator with
+  // a constant operand gets it with v_readlane instead of s_load_dwordx2 + s_waitcnt lgkmcnt(0) + v_cvt on every trip
+  uint32_t c_lo = 0u, c_hi = 0u;
 };
-template <typename P>
+template <typename P, typename T = float>
 __device__ __forceinline__ sp_dyn sp_dyn_program(const sp_program& p) {
   if constexpr (P::kStatic) {
     return sp_dyn{0u, false};
   } else {
     const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     uint32_t word = sp_pack_instr(p.instr[lane & (SP_MAX_INSTR - 1)]);
+    const T c = sp_const<T>(p, (int)(lane & (SP_MAX_CONSTS - 1)));
+    uint32_t lo, hi = 0u;
+    if constexpr (sizeof(T) == 4) {
+      lo = __builtin_bit_cast(uint32_t, c);
+    } else {
+      const uint64_t w = __builtin_bit_cast(uint64_t, c);
+      lo = (uint32_t)w;
+      hi = (uint32_t)(w >> 32);
+    }
     // (pinned HERE: sunk into a loop that only some lanes enter, the load would leave the other lanes' instructions
     // unread -- v_readlane reads a lane whether or not it is active)
-    asm volatile("" : "+v"(word));
-    return sp_dyn{word, true};
+    asm volatile("" : "+v"(word), "+v"(lo), "+v"(hi));
+    return sp_dyn{word, true, lo, hi};
+  }
+}
+// constant i as the interpreter reads it: from the lanes when the kernel holds the program there
+template <typename T>
+__device__ __forceinline__ T sp_const_of(const sp_program& p, const sp_dyn& dyn, int i) {
+  if (!dyn.lanes_hold_program) return sp_const<T>(p, i);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)dyn.c_lo, i);
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, lo);
+  } else {
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)dyn.c_hi, i);
+    return __builtin_bit_cast(T, (uint64_t)lo | ((uint64_t)hi << 32));
   }
 }
 
@@ -476,7 +500,7 @@ __device__ __forceinline__ sp_dyn sp_dyn_program(const sp_program& p) {
 template <typename T, int V, int U, bool DYN = false>
 __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, const int64_t (&L)[U],
                                         T (&r0)[SP_NREG * V], T (&r1)[SP_NREG * V], T (&r2)[SP_NREG * V],
-                                        T (&r3)[SP_NREG * V]) {
+                                        T (&r3)[SP_NREG * V], const sp_dyn dyn = sp_dyn{0u, false}) {
   using M = sp_math<T>;
 #define SP_U_LIST(X)                 \
   X(0)                               \
@@ -486,16 +510,38 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
   const int ra = (I.a & (SP_NREG - 1)) * V, rb = (I.b & (SP_NREG - 1)) * V;
   const int rd = (I.dst & (SP_NREG - 1)) * V;
 #define SP_WR(u) _Pragma("unroll") for (int v = 0; v < V; ++v) r##u[rd + v] = d[u][v];
+#define SP_EACH(expr)                               \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {   \
+    _Pragma("unroll") for (int v = 0; v < V; ++v) { \
+      const T av = a[u][v], bv = b[u][v];           \
+      (void)av; (void)bv;                           \
+      d[u][v] = (expr);                             \
+    }                                               \
+  }
   bool done = false;
   if constexpr (DYN) {
-    // constants read no register
-    if (I.op == SP_OP_CONST) {
-      const T c = sp_const<T>(p, I.a);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int v = 0; v < V; ++v) d[u][v] = c;
+    // operator with a constant operand (reg[b] op consts[a]): one register read, tested for before the plain operators
+    const unsigned kc = (unsigned)I.op - (unsigned)SP_OP_ADDC;
+    if (kc < 8u) {
       done = true;
+#define SP_RD(u) _Pragma("unroll") for (int v = 0; v < V; ++v) b[u][v] = r##u[rb + v];
+      SP_U_LIST(SP_RD)
+#undef SP_RD
+      __builtin_amdgcn_sched_barrier(0);
+      const T cv = sp_const_of<T>(p, dyn, I.a);
+      if (kc < 4u) {
+        if (kc < 2u) {
+          if (kc == 0u) { SP_EACH(bv + cv); } else { SP_EACH(bv - cv); }
+        } else {
+          if (kc == 2u) { SP_EACH(cv - bv); } else { SP_EACH(bv * cv); }
+        }
+      } else {
+        if (kc < 6u) {
+          if (kc == 4u) { SP_EACH(M::div(bv, cv)); } else { SP_EACH(M::div(cv, bv)); }
+        } else {
+          if (kc == 6u) { SP_EACH(sp_nanmax<T>(bv, cv)); } else { SP_EACH(sp_nanmin<T>(bv, cv)); }
+        }
+      }
     }
   }
   if (!done) {
@@ -508,14 +554,6 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
   SP_U_LIST(SP_RD)
 #undef SP_RD
   if constexpr (DYN) __builtin_amdgcn_sched_barrier(0);
-#define SP_EACH(expr)                               \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {   \
-    _Pragma("unroll") for (int v = 0; v < V; ++v) { \
-      const T av = a[u][v], bv = b[u][v];           \
-      (void)av; (void)bv;                           \
-      d[u][v] = (expr);                             \
-    }                                               \
-  }
   if constexpr (DYN) {
     // the four arithmetic operators first: two scalar compares instead of the six levels of the full switch
     const unsigned k = (unsigned)I.op - (unsigned)SP_OP_ADD;
@@ -529,8 +567,23 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
     }
   }
   if (!done) switch (I.op) {
-    case SP_OP_CONST: { T c = sp_const<T>(p, I.a); SP_EACH(c); } break;
-    case SP_OP_IOTA: SP_EACH((T)(L[u] + v)); break;
+    case SP_OP_CONST: { const T c = sp_const_of<T>(p, dyn, I.a); SP_EACH(c); } break;
+    case SP_OP_IOTA:
+      if constexpr (DYN) {
+        // The index -> T conversions depend on nothing the dispatch loop changes: left alone, the compiler computes
+        // them ahead of the loop, i.e. in EVERY trip of EVERY interpreted program (8 conversions of a 64-bit integer,
+        // 125 of the 223 VALU instructions a trip of `x + 1` issued).  An asm statement is not moved.
+        int64_t at[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          at[u] = L[u];
+          asm volatile("" : "+v"(at[u]));
+        }
+        SP_EACH((T)(at[u] + v));
+      } else {
+        SP_EACH((T)(L[u] + v));
+      }
+      break;
     case SP_OP_MOV: SP_EACH(av); break;
     case SP_OP_ADD: SP_EACH(av + bv); break;
     case SP_OP_SUB: SP_EACH(av - bv); break;
@@ -577,6 +630,14 @@ __device__ __forceinline__ void sp_step(const sp_program& p, const sp_instr I, c
     case SP_OP_TO_I64: SP_EACH(M::to_i64(av)); break;
     case SP_OP_TO_BOOL: SP_EACH((T)(av != (T)0)); break;
     case SP_OP_TO_U8: SP_EACH((T)(uint8_t)(int64_t)av); break;
+    case SP_OP_ADDC: { const T cv = sp_const<T>(p, I.a); SP_EACH(bv + cv); } break;
+    case SP_OP_SUBC: { const T cv = sp_const<T>(p, I.a); SP_EACH(bv - cv); } break;
+    case SP_OP_RSUBC: { const T cv = sp_const<T>(p, I.a); SP_EACH(cv - bv); } break;
+    case SP_OP_MULC: { const T cv = sp_const<T>(p, I.a); SP_EACH(bv * cv); } break;
+    case SP_OP_DIVC: { const T cv = sp_const<T>(p, I.a); SP_EACH(M::div(bv, cv)); } break;
+    case SP_OP_RDIVC: { const T cv = sp_const<T>(p, I.a); SP_EACH(M::div(cv, bv)); } break;
+    case SP_OP_MAXC: { const T cv = sp_const<T>(p, I.a); SP_EACH(sp_nanmax<T>(bv, cv)); } break;
+    case SP_OP_MINC: { const T cv = sp_const<T>(p, I.a); SP_EACH(sp_nanmin<T>(bv, cv)); } break;
     default: SP_EACH(av); break;
   }
 #undef SP_EACH
@@ -802,7 +863,7 @@ __device__ __forceinline__ void sp_eval_u(const sp_program& p, const sp_inputs& 
       // cache, no s_waitcnt lgkmcnt(0) between fetch and execution
       for (int pc = 0; pc < p.n_instr; ++pc) {
         const sp_instr cur = sp_unpack_instr((uint32_t)__builtin_amdgcn_readlane((int)dyn.word, pc));
-        if (cur.op != SP_OP_NOP) sp_step<T, V, U, true>(p, cur, L, r0, r1, r2, r3);
+        if (cur.op != SP_OP_NOP) sp_step<T, V, U, true>(p, cur, L, r0, r1, r2, r3, dyn);
       }
     } else {
       for (int pc = 0; pc < p.n_instr; ++pc)

@@ -467,6 +467,9 @@ def trace(op, args, ex):
 
 # -------------------------------------------------------------------- emission
 _NORMALISE = {np.dtype(np.float32): 'TO_F32', np.dtype(np.int32): 'TO_I32', np.dtype(np.uint8): 'TO_U8'}
+# operator -> (name when the RIGHT operand is the constant, name when the LEFT one is): reg[b] (op) consts[a]
+_WITH_CONST = {'ADD': ('ADDC', 'ADDC'), 'SUB': ('SUBC', 'RSUBC'), 'MUL': ('MULC', 'MULC'), 'DIV': ('DIVC', 'RDIVC'),
+               'MAX': ('MAXC', 'MAXC'), 'MIN': ('MINC', 'MINC')}
 _NO_NORMALISE_OPS = set(['EQ', 'NE', 'LT', 'LE', 'GT', 'GE', 'LAND', 'LOR', 'LXOR', 'LNOT', 'WHERE'])
 
 
@@ -515,6 +518,62 @@ class Emitter(object):
     self.in_vals = []      # (V, strides) per input
     self.free = []
     self.next_temp = None
+    # common subexpressions (finish): structural key -> small integer, uses left per key, key <-> register holding it
+    self.share = False
+    self._key_of_node = {}
+    self._key_ids = {}
+    self._uses = {}
+    self._reg_of_key = {}
+    self._key_of_reg = {}
+    self._same_as = {}
+
+  # ---- common subexpressions ---------------------------------------------------------------------------------
+  # `(x - m) * (x - m)` is two SUB nodes: emitted once, its register kept until the last use (one instruction less
+  # per repeated subtree; the compiled tiers fold them anyway, the interpreter pays per instruction).
+  def _key(self, v):
+    k = self._key_of_node.get(id(v))
+    if k is not None:
+      return k
+    if v.kind == 'tensor':
+      t = ('t', self.input_reg(v))
+    elif v.kind == 'const':
+      val = v.value
+      t = ('c', int(val)) if self.cls == _hip.SP_I64 else ('c', float(val).hex())
+    elif v.kind == 'iota':
+      t = ('i',)
+    elif v.kind == 'op' and v.op == 'FILL':
+      k = self._key(v.args[0])
+      self._key_of_node[id(v)] = k
+      return k
+    elif v.kind == 'op':
+      t = (v.op, v.dtype, v.args[0].dtype if v.op == 'CAST' else None) + tuple(self._key(a) for a in v.args)
+    else:
+      t = ('?', id(v))
+    k = self._key_ids.setdefault(t, len(self._key_ids))
+    self._key_of_node[id(v)] = k
+    return k
+
+  def _operands(self, v):
+    """The children emit() evaluates into registers for `v`."""
+    if v.kind != 'op':
+      return []
+    if v.op in _WITH_CONST and len(v.args) == 2:
+      lhs, rhs = v.args
+      if rhs.kind == 'const' and lhs.kind != 'const':
+        return [lhs]
+      if lhs.kind == 'const' and rhs.kind != 'const':
+        return [rhs]
+    return v.args
+
+  def _count_uses(self, v):
+    while v.kind == 'op' and v.op == 'FILL':
+      v = v.args[0]
+    k = self._key(v)
+    n = self._uses.get(k, 0)
+    self._uses[k] = n + 1
+    if n == 0:
+      for a in self._operands(v):
+        self._count_uses(a)
 
   def input_reg(self, v):
     for i, t in enumerate(self.tensors):
@@ -556,21 +615,53 @@ class Emitter(object):
     return r
 
   def release(self, r):
+    k = self._key_of_reg.get(r)
+    if k is not None:
+      self._uses[k] -= 1
+      if self._uses[k] > 0:
+        return                                 # another consumer of the same value is still to come
+      del self._key_of_reg[r]
+      del self._reg_of_key[k]
     if r >= len(self.tensors) and r not in self.free:
       self.free.append(r)
 
+  def const_index(self, v):
+    val = v.value
+    if self.cls == _hip.SP_I64:
+      val = int(val)
+    elif self.cls == _hip.SP_F32 and not v.weak and v.dtype == np.float64:
+      raise AssertionError('float64 constant in a float32 program')
+    return self.prog.add_const(float(val) if self.cls != _hip.SP_I64 else int(val))
+
   def emit(self, v):
+    if v.kind == 'tensor':
+      return self.input_reg(v)
+    if not self.share or (v.kind == 'op' and v.op == 'FILL'):
+      return self._emit(v)
+    k = self._key(v)
+    k = self._same_as.get(k, k)
+    r = self._reg_of_key.get(k)
+    if r is None:
+      r = self._emit(v)
+      if r >= len(self.tensors):
+        other = self._key_of_reg.get(r)
+        if other is None:
+          self._reg_of_key[k] = r
+          self._key_of_reg[r] = k
+        elif other != k:
+          # (a cast that changes nothing returned its operand's register: this node is one more name for that value,
+          #  and all its consumers release that register)
+          self._same_as[k] = other
+          self._uses[other] += self._uses.get(k, 1) - 1
+    return r
+
+  def _emit(self, v):
     p = self.prog
     if v.kind == 'tensor':
       return self.input_reg(v)
     if v.kind == 'const':
       r = self.alloc()
-      val = v.value
-      if self.cls == _hip.SP_I64:
-        val = int(val)
-      elif self.cls == _hip.SP_F32 and not v.weak and v.dtype == np.float64:
-        raise AssertionError('float64 constant in a float32 program')
-      p.emit('CONST', r, p.add_const(float(val) if self.cls != _hip.SP_I64 else int(val)))
+      p.emit('CONST', r, self.const_index(v))
       return r
     if v.kind == 'iota':
       r = self.alloc()
@@ -596,14 +687,32 @@ class Emitter(object):
         op = 'TO_F32' if self.cls != _hip.SP_F32 else None
       if op is None:
         return r
-      dst = r if r >= len(self.tensors) else self.alloc()
+      self.release(r)
+      dst = self.alloc()                      # (r itself when this was its last use)
       p.emit(op, dst, r)
       return dst
-    regs = [self.emit(a) for a in v.args]
-    for r in regs:
-      self.release(r)
-    dst = self.alloc()
-    if v.op == 'WHERE':
+    # an operator with ONE constant operand is one instruction (`x + c` -> ADDC): no CONST into a register first
+    with_const = None
+    if v.op in _WITH_CONST and len(v.args) == 2:
+      lhs, rhs = v.args
+      if rhs.kind == 'const' and lhs.kind != 'const':
+        with_const = (_WITH_CONST[v.op][0], lhs, rhs)
+      elif lhs.kind == 'const' and rhs.kind != 'const':
+        with_const = (_WITH_CONST[v.op][1], rhs, lhs)
+    if with_const is not None:
+      name, operand, const = with_const
+      regs = [self.emit(operand)]
+      self.release(regs[0])
+      dst = self.alloc()
+      p.emit(name, dst, self.const_index(const), regs[0])
+    else:
+      regs = [self.emit(a) for a in v.args]
+      for r in regs:
+        self.release(r)
+      dst = self.alloc()
+    if with_const is not None:
+      pass
+    elif v.op == 'WHERE':
       p.emit('WHERE', dst, regs[0], regs[1], regs[2])
     elif len(regs) == 1:
       p.emit(v.op, dst, regs[0])
@@ -621,7 +730,20 @@ class Emitter(object):
   def finish(self, root, out_dtype):
     self.collect_inputs(root)   # inputs first: they own registers 0..n-1
     self.next_temp = len(self.tensors)
-    result = self.emit(root)
+    try:
+      self.share = True
+      self._count_uses(root)
+      result = self.emit(root)
+    except ProgramTooLarge:
+      # a shared value holds its register until its last use: when that is what does not fit, evaluate every
+      # occurrence on its own, as the tree says
+      self.share = False
+      self.prog = Program()
+      self.free = []
+      self.next_temp = len(self.tensors)
+      self._reg_of_key.clear()
+      self._key_of_reg.clear()
+      result = self.emit(root)
     self.prog.result_reg = result
     self.prog.inputs = []
     strides = [st for (_, st) in self.in_vals]

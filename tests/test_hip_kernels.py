@@ -427,8 +427,12 @@ def test_static_program_library():
       9: ap('ADD', np.add, [ap('MUL', np.multiply, [T(x), T(x)]), T(x)]),
       10: ap('MUL', np.multiply, [T(x), ap('SUB', np.subtract, [T(yp), T(yy)])]),
       11: ap('MUL', np.multiply, [T(x), T(x)]),
-      12: ap('MUL', np.multiply, [lower.const(3.0), T(x)]),
+      12: ap('SUB', np.subtract, [lower.const(3.0), T(x)]),
   }
+  also = [(3, ap('MUL', np.multiply, [lower.const(3.0), T(x)])), (1, ap('ADD', np.add, [lower.const(0.25), T(x)]))]
+  for sid, root in also:
+    prog, _ = lower.Emitter(_hip.SP_F32, root.shape).finish(root, np.float32)
+    assert _hip.lib().sp_program_static_id(C.byref(prog), _hip.SP_F32) == sid, sid
   for sid, root in cases.items():
     em = lower.Emitter(_hip.SP_F32, root.shape)
     prog, tensors = em.finish(root, np.float32)
@@ -440,6 +444,71 @@ def test_static_program_library():
   prog, _ = lower.Emitter(_hip.SP_F32, root.shape).finish(root, np.float32)
   assert _hip.lib().sp_program_static_id(C.byref(prog), _hip.SP_F32) == -1
   np.testing.assert_array_equal(host(be._run_map(root, x.shape)), host(x) * host(y) + (host(x) - 2))
+
+
+@pytest.mark.parametrize('tier', ['specialised', 'interpreted'])
+@pytest.mark.parametrize('dt', [np.float32, np.float64, np.int64, np.int32])
+def test_operators_with_a_constant_operand(dt, tier):
+  """`x op c` / `c op x` lower to ONE instruction (SP_OP_ADDC .. SP_OP_MINC: reg[b] op consts[a]); every form, every
+  arithmetic class, interpreter and specialised code, against NumPy -- and a chain of them, so the constant table
+  holds several entries and registers are reused."""
+  import ctypes as C
+  from spartan_amd import lower
+  from spartan_amd.backend_hip import HipBackend
+  be = HipBackend()
+  rng = np.random.RandomState(11)
+  a = (rng.rand(129, 515) * 20 - 10).astype(dt)
+  if np.dtype(dt).kind == 'i':
+    a[a == 0] = 3
+  x = dev(a)
+  T = lambda: lower.V('tensor', dtype=np.dtype(dt), shape=a.shape, tensor=x)
+  ap = lower.apply
+  c = 3 if np.dtype(dt).kind == 'i' else 2.5
+  forms = [('ADD', np.add), ('SUB', np.subtract), ('MUL', np.multiply), ('MAX', np.maximum), ('MIN', np.minimum)]
+  if np.dtype(dt).kind == 'f':
+    forms.append(('DIV', np.divide))
+  cls = lower.class_of(np.dtype(dt))
+  seen = set()
+  with (_interpreted() if tier == 'interpreted' else _nothing()):
+    for name, fn in forms:
+      for const_first in (False, True):
+        args = [lower.const(c), T()] if const_first else [T(), lower.const(c)]
+        root = ap(name, fn, args)
+        prog, _ = lower.Emitter(cls, root.shape).finish(root, np.dtype(dt))
+        ops = [prog.instr[i].op for i in range(prog.n_instr)]
+        assert _hip.OP['CONST'] not in ops and 60 <= ops[0] <= 67, ops
+        seen.add(ops[0])
+        want = fn(np.asarray(c, dt), a) if const_first else fn(a, np.asarray(c, dt))
+        np.testing.assert_array_equal(host(be._run_map(root, a.shape)), want.astype(dt))
+    # ((x * c1 + c2) max c3) - then c4 - that: four constants, one input
+    root = ap('SUB', np.subtract, [lower.const(c + 4), ap('MAX', np.maximum, [
+        ap('ADD', np.add, [ap('MUL', np.multiply, [T(), lower.const(c)]), lower.const(c + 1)]), lower.const(c + 2)])])
+    prog, _ = lower.Emitter(cls, root.shape).finish(root, np.dtype(dt))
+    assert _hip.OP['CONST'] not in [prog.instr[i].op for i in range(prog.n_instr)]
+    k = lambda v: np.asarray(v, dt)
+    want = k(c + 4) - np.maximum(a * k(c) + k(c + 1), k(c + 2))
+    np.testing.assert_array_equal(host(be._run_map(root, a.shape)), want.astype(dt))
+  assert len(seen) == (8 if np.dtype(dt).kind == 'f' else 6)
+
+
+def test_constant_operand_instructions_are_validated():
+  """A const index past the table and an unwritten source register are refused by the library."""
+  x = RNG.rand(64).astype(np.float32)
+  for a, b, why in ((16, 0, 'const index'), (0, 3, 'nothing has written')):
+    def body(p, a=a, b=b):
+      p.add_const(1.0)
+      p.emit('ADDC', 1, a, b)
+      return 1
+    with pytest.raises(Exception, match=why):
+      run_map(_hip.SP_F32, (64,), [x], body, np.float32)
+
+
+class _nothing(object):
+  def __enter__(self):
+    pass
+
+  def __exit__(self, *exc):
+    pass
 
 
 @pytest.mark.parametrize('shape', [(64, 64), (100, 37), (1000, 513), (17, 4096)])

@@ -16,8 +16,11 @@ cases = [('x+1', lambda: (Xv + 1).force()),
          ('5op', lambda: (((Xv * Xv + Xv) * 0.5 - Xv) / (Xv + 2.0)).optimized().force()),
          ('12op', lambda: ((((((Xv * Xv + Xv) * 0.5 - Xv) / (Xv + 2.0)) * Xv + 1.0) * Xv - 3.0) * (Xv + 0.25) + Xv * 0.125).optimized().force()),
          ('sqrt_exp', lambda: sp.sqrt(sp.exp(Xv) + 1.0).optimized().force())]
+only = [c for c in os.environ.get('INTERP_CASES', '').split(',') if c]
 out = []
 for name, fn in cases:
+  if only and name not in only:
+    continue
   ms = event_time(fn, 5)
   out.append('%s %.3f ms %.0f GB/s' % (name, ms, 8.0 * n / ms / 1e6))
 print(os.environ.get('SP_MAP_UNROLL', '1'), ' | '.join(out))
