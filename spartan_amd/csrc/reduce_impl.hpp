@@ -93,7 +93,7 @@ __device__ __forceinline__ T sp_shfl_down(T v, int delta) {
 // The combine op as a compile-time constant around a block of adds: ONE scalar switch per trip.  With `op` a run-time
 // value inside Acc::add, the interpreted kernels (OP = -1) went through the switch once per ELEMENT -- 8 x (15 scalar
 // instructions, a handful of branches, one dynamically indexed read of the result) per trip, which is what bound the
-// interpreted column reduction (202 scalar instructions per trip of 512 elements; profiles/r05_notes.md section 11).
+// interpreted column reduction (202 scalar instructions per trip of 512 elements; profiles/r05_notes.md section 10).
 template <int K>
 struct sp_op_c {
   static constexpr int value = K;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(SP_BLOCK) void sp_reduce_rows_kernel(const sp_progr
       // Interpreted dense fp32 programs: the walk along the row pipelined as in sp_reduce_cols_kernel (the operands of
       // trip t + 1 requested before trip t's program is dispatched; UP groups share a dispatch).  The plain loop below
       // issued 0.8 scalar instructions per ELEMENT (addressing and operand-type decisions of every trip) and was bound
-      // by scalar issue, not by HBM or the vector ALU (profiles/r05_notes.md section 11).
+      // by scalar issue, not by HBM or the vector ALU (profiles/r05_notes.md section 10).
       if (sp_ahead_applies<T, SP_RED_AHEAD_N>(p)) {
         walked = true;
         constexpr int UP = SP_RED_AHEAD_UP;
