@@ -228,6 +228,8 @@ def probed_peaks():
   """Dense matrix-pipe rates measured on THIS GPU by tools/mfma_peak_probe (built by __graft_entry__.build()): every CU
   issuing nothing but independent MFMAs.  {} when the probe is not there."""
   import subprocess
+  if _PROBED:
+    return _PROBED
   exe = os.path.join(ROOT, 'tools', 'mfma_peak_probe')
   if not os.path.exists(exe):
     return {}
@@ -242,7 +244,11 @@ def probed_peaks():
       f = dict(kv.split('=') for kv in line.split()[2:])
       name = line.split()[1]
       best[name] = max(best.get(name, 0.0), float(f['TFLOPs']))
+  _PROBED.update(best)
   return best
+
+
+_PROBED = {}
 
 
 MFMA_F64_SPEC_TFLOPS = 78.6     # AMD's MI355X figure for the fp64 matrix pipe (not in MI355X_MICROARCH.md: probed below)
@@ -376,6 +382,12 @@ def kmeans_section(ctx):
   out['assign_split'] = {'instruction': 'v_mfma_f32_32x32x16_bf16 x 3 per 16 features (hi*hi, hi*mid, mid*hi), fp32 accumulate',
                          'issued_TFLOPs': round(3.0 * flop / ms / 1e9, 1), 'bf16_peak_TFLOPs': MFMA_BF16_PEAK_TFLOPS,
                          'frac_of_bf16_peak': round(3.0 * flop / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 3)}
+  # beside the guide's figure: what this GPU's bf16 pipe delivers when every CU issues nothing but that MFMA
+  # (tools/mfma_peak_probe) -- information; frac_of_bf16_peak above stays the roofline fraction
+  probed = probed_peaks().get('v_mfma_f32_32x32x16_bf16')
+  if probed:
+    out['assign_split']['probed_bf16_TFLOPs'] = round(probed, 1)
+    out['assign_split']['frac_of_probed_bf16'] = round(3.0 * flop / ms / 1e9 / probed, 3)
   del prepared
   ms = event_time(lambda: kernels.nearest_center(x, cdev, labels), 10, warmup=2)
   out['assign_standalone_ms'] = round(ms, 3)                            # + cutting the points (once per call)
