@@ -80,7 +80,10 @@ class Tree(object):
     name, fn = recipe[0], recipe[1]
     parts = [self.rebuild(r) for r in recipe[2:]]
     with np.errstate(all='ignore'):
-      val = fn(*[np.asarray(p[1], self.dtype) if not np.isscalar(p[1]) else self.dtype.type(p[1]) for p in parts])
+      vals = [np.asarray(p[1], self.dtype) if not np.isscalar(p[1]) else self.dtype.type(p[1]) for p in parts]
+      if name == 'WHERE':
+        vals[0] = np.asarray(parts[0][1]) != 0
+      val = fn(*vals)
     return lower.apply(name, fn, [p[0] for p in parts]), val
 
   def grow(self, depth):
@@ -97,6 +100,22 @@ class Tree(object):
     if self.dtype.kind == 'f':
       binary.append(('DIV', np.divide))
     unary = [('NEG', np.negative), ('ABS', np.abs)]
+    if self.rng.rand() < 0.15:
+      # where(a > b, c, d): the comparison lives inside this node only (booleans do not subtract or negate in NumPy)
+      a, b = self.grow(depth - 1), self.grow(depth - 1)
+      c = self.const() if self.rng.rand() < 0.3 else self.grow(depth - 1)
+      d = self.grow(depth - 1)
+      cmp_name, cmp_fn = [('GT', np.greater), ('LT', np.less)][self.rng.randint(2)]
+      if a[2][0] == 'const' and b[2][0] == 'const':
+        a = self.leaf()
+      cond = lower.apply(cmp_name, cmp_fn, [a[0], b[0]])
+      with np.errstate(all='ignore'):
+        cval = cmp_fn(np.asarray(a[1], self.dtype), np.asarray(b[1], self.dtype))
+        val = np.where(cval, np.asarray(c[1], self.dtype), np.asarray(d[1], self.dtype))
+      node = (lower.apply('WHERE', np.where, [cond, c[0], d[0]]), np.asarray(val, self.dtype),
+              ('WHERE', np.where, (cmp_name, cmp_fn, a[2], b[2]), c[2], d[2]))
+      self.pool.append(node)
+      return node
     if self.rng.rand() < 0.2:
       name, fn = unary[self.rng.randint(len(unary))]
       a = self.grow(depth - 1)
@@ -138,7 +157,7 @@ def test_random_trees_with_repeated_subtrees(dtype):
     got = run_stream(prog, tensors, dtype)
     np.testing.assert_array_equal(got, np.asarray(want, dtype), err_msg='trial %d' % trial)
     ops = [NAMES[prog.instr[i].op] for i in range(prog.n_instr)]
-    assert 'CONST' not in ops, ops              # every constant here sits beside a non-constant operand
+    assert 'CONST' not in ops or 'WHERE' in ops, ops       # (only where() takes a constant through a register)
   assert fitted > 150 and shared > 100, (fitted, shared)
 
 
