@@ -504,6 +504,7 @@ struct KmWorkspace {
   __bf16 *Xh, *Xm;   // [n][dp] each -- LAST: a caller that brings prepared points leaves them (mu, xn2 too) out
 };
 constexpr int KM_MEAN_BLOCKS = 2048;
+constexpr int64_t KM_MEAN_SAMPLE = 65536;     // rows behind the shift of a prepared buffer (sp_kmeans_points_prepare)
 
 // The last round of first-pass workgroups is rarely full (configs[3]: 9 766 workgroups over 512 slots = 19 rounds and
 // 38 workgroups that cost a 20th).  The points of that round are split over up to KM_TAIL_SPLIT ranges of center

@@ -25,7 +25,7 @@
 // tier's, as before: tools/fuzz_kmeans.py, tests/test_hip_kernels.py::test_nearest_center_*.
 //
 // THE SHIFT.  E is proportional to |x| |c|max, and the distances do not change when the same vector mu is taken off
-// points and centers: the tier works on x~ = fl32(x - mu), c~ = fl32(c - mu) with mu the column means of the points
+// points and centers: the tier works on x~ = fl32(x - mu), c~ = fl32(c - mu) with mu the column means of the points (of 65 536 of them spread over a larger tile)
 // (a prepared buffer: computed once with it) or of the centers (a stand-alone call) -- for k-means data, whose centers
 // ARE means of points, that takes the common offset out of both norms (configs[3], uniform [0, 1)^256: |x| |c|max
 // 74 -> 4.6 once the centers have settled, and with it the share of points inside the window 16-27 % -> 1-2 %).  The two
@@ -109,21 +109,26 @@ __global__ __launch_bounds__(256) void sp_col_partial_kernel(const T* __restrict
     part[(int64_t)blockIdx.x * dp + j] = s;
   }
 }
+// (one wave per column: lane l adds partials l, l + 64, ...; one thread per column walked the 2048 partials in 256
+// dependent batches -- 113 us for 2 MB in a fit's set-up)
 __global__ __launch_bounds__(256) void sp_col_finish_kernel(const float* __restrict__ part, int blocks, int dp, int64_t n,
                                                             float* __restrict__ mu) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= dp) return;
   float s = 0.f;
-  int b = 0;
-  for (; b + 8 <= blocks; b += 8) {
+  int b = lane;
+  for (; b + 7 * 64 < blocks; b += 8 * 64) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + u) * dp + j];
+    for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + u * 64) * dp + j];
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u];
   }
-  for (; b < blocks; ++b) s += part[(int64_t)b * dp + j];
-  mu[j] = n > 0 ? s / (float)n : 0.f;
+  for (; b < blocks; b += 64) s += part[(int64_t)b * dp + j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) mu[j] = n > 0 ? s / (float)n : 0.f;
 }
 
 // hi / mid images of the fp32 rows MINUS the shift `mu` (NULL: none): one wavefront per row, zeros beyond d;
@@ -518,7 +523,7 @@ template <typename T>
 static int km_col_means(const T* X, int64_t ldx, int64_t rows, int64_t d, const KmWorkspace& w, hipStream_t st) {
   const int blocks = rows < KM_MEAN_BLOCKS ? (int)(rows < 1 ? 1 : rows) : KM_MEAN_BLOCKS;
   hipLaunchKernelGGL((sp_col_partial_kernel<T>), dim3(blocks), dim3(256), 0, st, X, ldx, rows, (int)d, (int)w.dp, w.colsum);
-  hipLaunchKernelGGL(sp_col_finish_kernel, dim3((unsigned)((w.dp + 255) / 256)), dim3(256), 0, st, (const float*)w.colsum,
+  hipLaunchKernelGGL(sp_col_finish_kernel, dim3((unsigned)((w.dp + 3) / 4)), dim3(256), 0, st, (const float*)w.colsum,
                      blocks, (int)w.dp, rows, w.mu);
   SP_CHECK_LAUNCH();
   return 0;

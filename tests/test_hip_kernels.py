@@ -818,6 +818,31 @@ def test_nearest_center_prepared_points_are_the_same_call():
     np.testing.assert_array_equal(host(labels), np.argmin(cdist(x, c), axis=1))
 
 
+@pytest.mark.parametrize('layout', ['shuffled', 'every_third_row_far_away'])
+def test_nearest_center_prepared_points_shift_from_a_sample_of_the_rows(layout):
+  """A prepared buffer of more than 131 072 points takes its shift from every (n / 65 536)-th row (kmeans.hip:
+  sp_kmeans_points_prepare).  The shift is free -- labels are argmin(cdist) whatever it is -- including when the sampled
+  rows are NOT representative: here every third row (exactly the sampled ones, n / 65536 = 3) sits 50 units away from
+  the rest, strided rows on top."""
+  from scipy.spatial.distance import cdist
+  rng = np.random.RandomState(12)
+  n, d, k = 3 * 65536 + 11, 40, 300
+  x = rng.rand(n, d).astype(np.float32)
+  if layout == 'every_third_row_far_away':
+    x[::3] += 50.0
+  c = x[rng.choice(n, k, replace=False)].astype(np.float64) + rng.randn(k, d) * 1e-3
+  xt = dev(np.pad(x, ((0, 0), (0, 8))))[:, :d]
+  prepared = kernels.prepare_points(xt)
+  labels = D.empty((n,), np.int64)
+  kernels.nearest_center(xt, dev(c), labels, prepared=prepared)
+  D.synchronize()
+  got = host(labels)
+  want = np.empty(n, np.int64)
+  for a in range(0, n, 32768):
+    want[a:a + 32768] = np.argmin(cdist(x[a:a + 32768].astype(np.float64), c), axis=1)
+  np.testing.assert_array_equal(got, want)
+
+
 def test_bf16_mfma_accumulation_model():
   """kmeans_split.hpp bounds the fp32 accumulation of the bf16 MFMA by one rounding to nearest per product (3 D of
   them) plus the terms it leaves out.  Checked here on the kernel's own scores: with ONE centre the unchecked tier
