@@ -19,9 +19,12 @@ launches -> merge into the target), operands already resident in HBM:
              max-over-ranks wall time; `dot_breakdown` gives kernel-only time and the bytes each GPU moved per step.
 
 The line also carries the roofline of the dominant kernel (MFMA-bound GEMM; durations from HIP events on the launch
-stream), `profile_table` (what every timed section launched: kernel, launches, algorithmic units per launch -- the
-key tools/roofline.py uses to recompute each fraction from a rocprofv3 kernel trace of this very command), and the
-CPU baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thread worker processes.
+stream) and the CPU baseline: the oracle's tile bodies on W = min(physical cores, 64) pinned one-thread worker
+processes.  stdout gets the COMPACT line (tools/bench_line.py, < 10 KB: contract keys, compact roofline with every
+HBM section as [GB/s, fraction of measured copy], cpu_baseline, one summary per extra section); the detailed record
+-- raw sections, every emulation case, and `profile_table` (what every timed section launched: kernel, launches,
+algorithmic units per launch -- the key tools/roofline.py uses to recompute each fraction from a rocprofv3 kernel
+trace of this very command) -- goes to gpurun_out/bench_detail_n<N>.json ($SP_BENCH_DETAIL) and to stderr.
 
 No torch in this process at any N: the control plane of a multi-rank run is the rendezvous hub of rank 0
 (spartan_amd/rendezvous.py, standard library sockets); the data plane is RCCL called from libspartan_hip.so.
@@ -43,6 +46,7 @@ sys.path.insert(0, ROOT)
 import spartan_amd as sp  # noqa: E402
 from spartan_amd import _hip, kernels  # noqa: E402
 from spartan_amd import devarray as D  # noqa: E402
+from tools import bench_line  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
@@ -958,11 +962,40 @@ def _claim_stdout():
     os.dup2(2, 1)
 
 
-def _emit(line, rank):
-  """The ONE line of stdout, from rank 0."""
+def _detail_path(p):
+  """Where the detailed record of this run goes: gpurun_out/ when the tree has one (it is merged back from a GPU
+  box), else the system temp directory.  tools/roofline.py and profiles/rNN_bench_n1.json are fed from this file."""
+  if os.environ.get('SP_BENCH_DETAIL'):
+    return os.environ['SP_BENCH_DETAIL']
+  base = os.path.join(ROOT, 'gpurun_out')
+  if not os.path.isdir(base):
+    import tempfile
+    base = tempfile.gettempdir()
+  return os.path.join(base, 'bench_detail_n%d.json' % p)
+
+
+def _emit(record, rank):
+  """The ONE line of stdout, from rank 0: tools/bench_line.compact(record), bounded at bench_line.LIMIT bytes.
+  The detailed record (launch table with clock readings, every emulation case, the raw sections) goes to a side
+  file and to stderr -- a 21 KB stdout line was not parsed by the driver."""
   sys.stdout.flush()
-  if rank == 0:
-    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + '\n').encode())
+  if rank != 0:
+    return
+  record = dict(record)
+  record['profile_table'] = PROFILE_TABLE
+  path = _detail_path(record.get('n_gpus') or 1)
+  try:
+    with open(path, 'w') as f:
+      json.dump(record, f)
+    record['detail'] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+  except (IOError, OSError) as e:
+    record['detail'] = 'not written: %s' % e
+  sys.stderr.write('bench detail: ' + json.dumps(record) + '\n')
+  sys.stderr.flush()
+  line = bench_line.compact(record)
+  text = json.dumps(line)
+  assert len(text) < bench_line.LIMIT, len(text)
+  os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (text + '\n').encode())
 
 
 def main():
@@ -1130,7 +1163,6 @@ def main():
                                            'useful_fp32_TFLOPs': km['assign_TFLOPs'],
                                            'useful_flops_over_fp32_mfma_peak': km['assign_useful_flops_over_fp32_mfma_peak'],
                                            'fp32_tier': km.get('assign_fp32_tier')}
-    line['profile_table'] = PROFILE_TABLE
     live, pooled = D.blob_stats()
     line['tile_store'] = {'live_blobs': live, 'pooled_bytes': pooled, 'kernel_sources': _hip.source_sha()}
     if tiles8:
