@@ -531,7 +531,8 @@ class World(object):
                 -- a debug transport for ranks sharing one GPU.  No torch in the process.
       'gloo'    the same over torch.distributed (imports torch; for callers that live in a torch job).
 
-    Default: 'rccl' with GPUs, 'socket' without.  SPARTAN_DIST_BACKEND overrides.  A caller whose process already
+    Default: 'rccl' with GPUs; without, 'gloo' in a process that already runs torch.distributed, else 'socket'.
+    SPARTAN_DIST_BACKEND overrides.  A caller whose process already
     runs an initialised torch.distributed group keeps it as the control plane."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     dist = _initialized_torch_dist()
@@ -546,7 +547,10 @@ class World(object):
   @staticmethod
   def _join(backend, ws, rank):
     gpus = gpu_count()
-    backend = backend or os.environ.get('SPARTAN_DIST_BACKEND') or ('rccl' if gpus else 'socket')
+    # (the default follows the control plane: a caller that brought an initialised torch.distributed group keeps it,
+    # and on a box without GPUs its data plane is gloo over that group, not the hub's sockets)
+    backend = backend or os.environ.get('SPARTAN_DIST_BACKEND') or (
+        'rccl' if gpus else ('gloo' if _initialized_torch_dist() is not None else 'socket'))
     if backend not in ('rccl', 'socket', 'gloo'):
       raise ValueError("unknown data-plane backend %r (known: 'rccl', 'socket', 'gloo')" % backend)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -50,7 +50,8 @@ class Heartbeat(object):
     self.store = store if store is not None else (ctx.world.store() if ctx.world.distributed else _LocalStore())
     self.probe = probe if probe is not None else getattr(ctx.backend, 'liveness_probe', lambda: True)
     self.failed_ranks = set()
-    self._given_up = set()                    # ranks in a verdict so far (agree(); identical on every rank)
+    self._given_up = set()                    # ranks of earlier verdicts not heard from since (agree(); identical on every rank)
+    self._carry = set()                       # a follower's own findings no verdict has taken up yet (agree())
     self.agree_floor_s = 15.0                 # least time the ranks wait for each other's verdicts at a safe point
     self._pending = []
     self._lock = threading.Lock()
@@ -133,7 +134,9 @@ class Heartbeat(object):
     The posts of safe point N - 2 are deleted when N is posted (one small key per rank and phase is alive at a time).
     Deadlines are generous -- 3 x interval x threshold, at least `agree_floor_s`: a rank that is merely slow must
     not be declared dead; a really dead one costs the survivors this wait once: ranks of an earlier verdict are
-    not waited for at later safe points, and are not reported again unless a watcher flags them anew."""
+    not waited for at later safe points, and are not reported again unless a watcher flags them anew.  A rank of an
+    earlier verdict that posts again is counted on again from the safe point after one where a counted-on rank read
+    its post (the `heard` lists of phase 2); until then it follows the others' verdict and decides nothing itself."""
     self._round = getattr(self, '_round', 0) + 1
     n = self._round
     key = lambda phase, rnd, rank: 'spartan_hb_agree/%d/%d/%d' % (rnd, phase, rank)     # noqa: E731
@@ -142,18 +145,29 @@ class Heartbeat(object):
         self.store.delete(key(phase, n - 2, self.rank))
     wait_s = max(3 * self.interval * self.threshold, self.agree_floor_s)
 
-    def post(phase, ranks):
-      self.store.set(key(phase, n, self.rank), ','.join(str(r) for r in sorted(ranks)) or '-')
+    ints = lambda text: set(int(x) for x in text.split(',') if x not in ('-', ''))     # noqa: E731
+
+    def post(phase, ranks, heard=()):
+      text = ','.join(str(r) for r in sorted(ranks)) or '-'
+      if phase == 2:
+        text += '|' + (','.join(str(r) for r in sorted(heard)) or '-')
+      self.store.set(key(phase, n, self.rank), text)
 
     def collect(phase, wait_for, also_read):
       """Posts of phase `phase`: waits (with the deadline) for the ranks in wait_for, takes what is there of the
-      ranks in also_read; returns (union of what was read, ranks that never posted)."""
-      union, waiting, deadline = set(), list(wait_for), time.time() + wait_s
+      ranks in also_read; returns (union of what was read, ranks that never posted, the `heard` lists of the
+      phase-2 posts read, the ranks of also_read whose post was there)."""
+      union, heard, there, waiting, deadline = set(), set(), set(), list(wait_for), time.time() + wait_s
+
+      def take(value):
+        failed, _, back = value.partition('|')
+        union.update(ints(failed))
+        heard.update(ints(back))
       while waiting:
         for r in list(waiting):
           value = self._read(key(phase, n, r))
           if value is not None:
-            union.update(int(x) for x in value.split(',') if x != '-')
+            take(value)
             waiting.remove(r)
         if not waiting or time.time() > deadline:
           break
@@ -161,25 +175,40 @@ class Heartbeat(object):
       for r in also_read:
         value = self._read(key(phase, n, r))
         if value is not None:
-          union.update(int(x) for x in value.split(',') if x != '-')
-      return union, waiting
+          take(value)
+          there.add(r)
+      return union, waiting, heard, there
 
-    # Ranks every rank gave up on at an earlier safe point (`_given_up` only changes here, by the verdict all ranks
-    # share, so it is the same set everywhere) are not waited for again: a dead rank costs the survivors the
-    # deadline ONCE.  If such a rank is still there -- it only stopped beating, or it was late -- it keeps running
-    # the same program, waits for the others itself, and its phase-1 posts are read when they happen to be there;
-    # whatever one rank read in them reaches the others through the phase-2 unions.
+    # Ranks every rank gave up on at an earlier safe point (`_given_up` only changes here, by what all ranks read in
+    # the same phase-2 posts, so it is the same set everywhere) are not waited for: a dead rank costs the survivors
+    # the deadline ONCE.  A given-up rank that is still there -- it only stopped beating, or it was late -- keeps
+    # running the same program and keeps posting.  Nobody waits for its posts, so nothing may depend on them alone:
+    #   * it is a FOLLOWER: its verdict is what the ranks still counted on posted in phase 2, nothing of its own
+    #     (what its watcher flagged is offered in phase 1 and carried to the next safe point until a verdict has it);
+    #   * a counted-on rank that happened to read its phase-1 post takes the content into its own union (so it
+    #     reaches everyone through phase 2) and names the rank in the `heard` list of its phase-2 post; the union of
+    #     those lists is the same on every rank, and the ranks in it are counted on again from the next safe point.
     given_up = self._given_up
     others = [r for r in range(self.size) if r != self.rank]
     counted_on = [r for r in others if r not in given_up]
-    mine = set(mine)
+    follower = self.rank in given_up
+    mine = set(mine) | self._carry
     post(1, mine)
-    seen, absent = collect(1, counted_on, [r for r in others if r in given_up])
-    union = mine | seen | set(absent)
-    post(2, union)
-    # the unions of the ranks this one still counts on are waited for (ranks in `union` are in everybody's union)
-    final, absent2 = collect(2, [r for r in counted_on if r not in union], ())
-    verdict = union | final | set(absent2)
+    seen, absent, _, there = collect(1, counted_on, [r for r in others if r in given_up])
+    if follower:
+      post(2, (), ())                          # (nobody reads it; keeps the store's key pattern uniform)
+      final, absent2, heard, _ = collect(2, counted_on, ())
+      verdict = final | set(absent2)
+      self._carry = mine - verdict - {self.rank}
+    else:
+      union = mine | seen | set(absent)
+      post(2, union, there)
+      # the unions of the ranks this one still counts on are waited for (ranks in `union` are in everybody's union)
+      final, absent2, heard, _ = collect(2, [r for r in counted_on if r not in union], ())
+      verdict = union | final | set(absent2)
+      heard |= there
+      self._carry = set()
+    given_up.difference_update(heard)
     given_up.update(verdict)
     self.failed_ranks.update(r for r in verdict if r != self.rank)
     return sorted(verdict)

@@ -212,7 +212,17 @@ def run_rowdot(ctx):
 def main():
   workers = int(sys.argv[1])
   use_hip = len(sys.argv) > 2 and sys.argv[2] == 'hip'
-  world = sp.World.from_env(backend=os.environ.get('SPARTAN_TEST_BACKEND', 'socket'))
+  which = os.environ.get('SPARTAN_TEST_BACKEND', 'socket')
+  if which == 'own-torch':
+    # a caller that lives in a torch job: it brought its own initialised group and names no backend; on a box
+    # without GPUs the world keeps that group as control plane AND data plane (gloo), not the hub's sockets
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+    os.environ.pop('SPARTAN_DIST_BACKEND', None)
+    world = sp.World.from_env()
+    assert world.note == 'gloo', world.note
+  else:
+    world = sp.World.from_env(backend=which)
   assert world.size == 2
   if use_hip:
     # two ranks sharing GPU 0, HBM blobs staged through the host by the debug transport

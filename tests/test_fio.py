@@ -292,5 +292,45 @@ def test_heartbeat_second_failure_of_a_recovered_rank_and_agreement_without_the_
       [t.start() for t in ts]
       [t.join(10) for t in ts]
     assert len([k for k in store._d if k.startswith('spartan_hb_agree/')]) <= 2 * 2 * 3, sorted(store._d)
+    # (v) a rank the others once gave up on (it was late, case iii) is counted on again once its posts are read, and
+    # until then it FOLLOWS: a failure only ITS watcher flags must not make its verdict differ from the others'
+    store = heartbeat._LocalStore()
+    hbs = [heartbeat.Heartbeat(C(r), interval=0.02, threshold=5, probe=lambda: True, store=store) for r in range(3)]
+    for h in hbs:
+      h.agree_floor_s = 0.4
+    out = [None, None, None]
+
+    def late2(i):
+      if i == 2:
+        time.sleep(1.2)
+      out[i] = hbs[i].agree([])
+    ts = [threading.Thread(target=late2, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join(10) for t in ts]
+    assert out[0] == out[1] == out[2] == [2] and all(h._given_up == {2} for h in hbs)
+    # rank 2 posts AFTER the others have left the safe point (nobody waits for it): its finding about rank 1 is in
+    # nobody's verdict, its own included, and it stays given up on every rank
+    def unheard(i):
+      if i == 2:
+        time.sleep(0.3)
+      out[i] = hbs[i].agree([1] if i == 2 else [])
+    ts = [threading.Thread(target=unheard, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join(10) for t in ts]
+    assert out[0] == out[1] == out[2] == [], out
+    assert all(h._given_up == {2} for h in hbs), [h._given_up for h in hbs]
+    assert hbs[2]._carry == {1}
+    # next safe point: rank 2 posts first, the others read it: the carried finding reaches every verdict through
+    # the counted-on ranks' unions, and rank 2 is counted on again everywhere
+    def heard(i):
+      if i != 2:
+        time.sleep(0.2)
+      out[i] = hbs[i].agree([])
+    ts = [threading.Thread(target=heard, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join(10) for t in ts]
+    assert out[0] == out[1] == out[2] == [1], out
+    assert all(h._given_up == {1} for h in hbs), [h._given_up for h in hbs]
+    assert hbs[2]._carry == set()
   finally:
     sp.shutdown()

@@ -59,6 +59,12 @@ def test_two_ranks_gloo():
   _run_two_ranks(2, backend='gloo')
 
 
+def test_two_ranks_bring_their_own_torch_group():
+  """`World.from_env()` with no backend argument in a process whose torch.distributed group is already initialised
+  (CPU box): the default data plane is gloo over that group (it used to pick 'socket' and refuse)."""
+  _run_two_ranks(2, backend='own-torch')
+
+
 @pytest.mark.parametrize('size,backend', [(3, 'socket'), (4, 'socket'), (8, 'socket'), (4, 'gloo')])
 def test_ksplit_pipeline_more_ranks(size, backend):
   """The K-split dot pipeline, the reductions' collectives and a k-means iteration at 3, 4 and 8 ranks."""
