@@ -28,6 +28,9 @@ class OArr(object):
 
   evaluate = force
 
+  def diagonal(self):
+    return self.api.diagonal(self)
+
   def _bin(self, other, fn, swap=False):
     a, b = (other, self) if swap else (self, other)
     return self.api.map((a, b), fn)
@@ -159,6 +162,109 @@ class Facade(object):
   def std(self, a, axis=None):                                  # statistics.py:86-102
     c = self.astype(a, np.float64)
     return self.sqrt(self.mean(c ** 2, axis) - self.mean(c, axis) ** 2)
+
+  # -- the rest of the builder namespace: statistics.py:105-219, creation.py:225-330, manipulation.py:44-80 ------
+  def bincount(self, v, weights=None, minlength=None):          # statistics.py:105-137
+    minval, maxval = self.min(v).glom(), self.max(v).glom()
+    assert minval > 0
+    minlength = int(maxval) + 1 if minlength is None else max(int(maxval) + 1, int(minlength))
+
+    def mapper(ex, tiles):
+      if len(tiles) > 1:
+        res = np.bincount(tiles[0], weights=tiles[1], minlength=minlength)
+        # tile.pyx:46: a tile that is not written whole is built around the float64 data with the int dtype
+        assert ex.shape == ex.array_shape, 'Failed: float64 == %s' % tiles[0].dtype
+      else:
+        res = np.bincount(tiles[0], minlength=minlength)
+      yield O.Extent((0,), res.shape, res.shape), res
+    arrays = [self._u(v)] + ([self._u(weights)] if weights is not None else [])
+    return self._w(self.c.map2(arrays, (), mapper, (minlength,), np.add))
+
+  def normalize(self, array, axis=None):                         # statistics.py:140-182
+    norm_value = self.sum(array, axis).glom()
+
+    def mapper(tile, ex):
+      tile = np.array(tile)              # (the reference divides the fetched tile in place)
+      if axis is None:
+        tile /= norm_value
+      elif axis == 0:
+        tile[:, 0] /= norm_value[ex.ul[1]]
+      elif axis == 1:
+        tile[0, :] /= norm_value[ex.ul[0]]
+      return tile
+    return self._w(self.c.map_with_location(mapper, self._u(array)))
+
+  def norm(self, array, ord=2):                                  # statistics.py:185-219
+    assert ord == 1 or ord == 2
+    x = self._u(array)
+    if ord == 1:
+      return np.max(self.c.reduce(x, 0, x.dtype, lambda ex, d, a: np.abs(d).sum(a), np.add).glom())
+    assert len(x.shape) == 1 or len(x.shape) == 2 and x.shape[1] == 1, 'matrix norm-2 is not support!'
+    return np.sqrt(self.c.reduce(x, 0, x.dtype, lambda ex, d, a: np.square(d).sum(a), np.add).glom())
+
+  def diagflat(self, array):                                      # creation.py:225-262
+    x = self._u(array)
+    n = int(np.prod(x.shape))
+    shape = (n, n)
+
+    def mapper(extents, tiles):
+      ex, tile = extents[0], tiles[0]
+      head = O.ravelled_pos(ex.ul, ex.array_shape)
+      tail = O.ravelled_pos([l - 1 for l in ex.lr], ex.array_shape)
+      result = np.diagflat(tile)
+      if head != 0:
+        result = np.hstack((np.zeros(((tail - head + 1), head)), result))
+      if tail + 1 != shape[0]:
+        result = np.hstack((result, np.zeros((tail - head + 1, shape[0] - (tail + 1)))))
+      yield O.ex_create((head, 0), (tail + 1, shape[1]), shape), result
+    return self._w(self.c.map2([x], (0,), mapper, shape))
+
+  def diagonal(self, a):                                          # creation.py:265-302
+    x = self._u(a)
+    if len(x.shape) < 2:
+      raise ValueError('diag requires an array of at least two dimensions')
+    shape = (min(x.shape),)
+
+    def mapper(ex, tiles):
+      first = max(*ex.ul)
+      slices = []
+      for i in range(len(ex.ul)):
+        if first >= ex.lr[i]:
+          return
+        slices.append(slice(first - ex.ul[i], ex.shape[i]))
+      result = tiles[0][tuple(slices)].diagonal()
+      yield O.ex_create((first,), (first + result.shape[0],), shape), result
+    return self._w(self.c.map2([x], (), mapper, shape))
+
+  def diag(self, array, offset=0):                                # creation.py:305-330
+    if offset != 0:
+      raise NotImplementedError
+    if len(array.shape) == 1:
+      return self.diagflat(array)
+    if len(array.shape) == 2:
+      return self.diagonal(array)
+    raise ValueError('Input must be 1- or 2-d.')
+
+  def concatenate(self, a, b, axis=0):                            # manipulation.py:44-80
+    xa, xb = self._u(a), self._u(b)
+    shape = [d1 + d2 if i == axis else d1 for i, (d1, d2) in enumerate(zip(xa.shape, xb.shape))]
+    if any(d1 != d2 for i, (d1, d2) in enumerate(zip(xa.shape, xb.shape)) if i != axis):
+      raise ValueError('all the input array dimensions except for the concatenation axis must match exactly')
+    if len(xa.shape) > 1:                                         # extent.pyx largest_dim_axis, the join axis excluded
+      part = max((i for i in range(len(xa.shape)) if i != axis), key=lambda i: (xa.shape[i], -i))
+    else:
+      part = 0
+
+    def mapper(extents, tiles):
+      if len(extents[0].shape) > 1:
+        lr = list(extents[0].lr)
+        lr[axis] += extents[1].shape[axis]
+        yield O.ex_create(extents[0].ul, lr, shape), np.concatenate((tiles[0], tiles[1]), axis=axis)
+      else:
+        yield O.ex_create(extents[0].ul, extents[0].lr, shape), tiles[0]
+        off = extents[0].array_shape[0]
+        yield O.ex_create((off + extents[1].ul[0],), (off + extents[1].lr[0],), shape), tiles[1]
+    return self._w(self.c.map2([xa, xb], (part, part), mapper, shape))
 
   def dot(self, a, b, tile_hint=None):
     return self._w(self.c.dot(self._u(a), b if isinstance(b, np.ndarray) else self._u(b), tile_hint))

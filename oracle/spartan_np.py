@@ -438,6 +438,29 @@ class Cluster(object):
   def argmin(self, x, axis=None):
     return self._arg(x, axis, self.min)
 
+  # -- map2 (map.py:243-375) ----------------------------------------------------------------
+  def map2(self, arrays, axes, fn, shape, reducer=None, fn_kw=None):
+    """join_mapper, map.py:243-286: every tile of arrays[0] is re-read as the slab that cuts axes[0]
+    (change_partition_axis), the other arrays give the slab with the same range on their join axis; what
+    fn(extents, slabs) yields is pushed into a target of `shape` with arrays[0]'s dtype (map.py:316-334)."""
+    target = self.empty(shape, arrays[0].dtype, reducer)
+    for ex, _, t in arrays[0].tiles:
+      if not axes:
+        extents, slabs = ex, [a.fetch(ex) for a in arrays]
+      else:
+        lead = change_partition_axis(ex, axes[0])
+        if lead is None:
+          continue
+        extents = [lead]
+        for arr, axis in zip(arrays[1:], axes[1:]):
+          ul, lr = [0] * len(arr.shape), list(arr.shape)
+          ul[axis], lr[axis] = lead.ul[axes[0]], lead.lr[axes[0]]
+          extents.append(ex_create(ul, lr, arr.shape))
+        slabs = [a.fetch(e) for a, e in zip(arrays, extents)]
+      for where, data in fn(extents, slabs, **(fn_kw or {})) or ():
+        target.update(where, data)
+    return target
+
   # -- dot (dot.py:172-299, map.py:243-334, outer.py:12-99) -----------------------------
   def dot(self, a, b, tile_hint=None):
     if isinstance(b, np.ndarray):                            # dot_map2_np_mapper, dot.py:172-187

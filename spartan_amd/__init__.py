@@ -27,6 +27,7 @@ from .expr.builtins import *  # noqa: F401,F403
 from .expr.builtins import (abs, all, any, max, min, sum)  # noqa: F401  (shadow the builtins, like spartan.expr)
 from .expr.dot import dot  # noqa: F401
 from .expr.map import map, map2, map_with_location  # noqa: F401
+from .expr.manip import bincount, concatenate, diag, diagflat, diagonal, norm, normalize  # noqa: F401
 from .expr.ndarray import ndarray  # noqa: F401
 from .expr.optimize import optimize  # noqa: F401
 from .expr.outer import outer  # noqa: F401
@@ -88,6 +89,13 @@ for _name, _fn in dict(
 distarray.DistArray.T = property(transpose)
 Expr.fill = full_like  # noqa: F405
 Expr.flatten = ravel
+Expr.diagonal = diagonal
+# (spartan/expr/__init__.py:70-85 binds these names too: three of them to None, the sort family to its builders)
+Expr.flat = None
+Expr.outer = None
+Expr.nonzero = None
+for _name in ('argsort', 'argpartition', 'partition'):
+  setattr(Expr, _name, (lambda _n: lambda self, *a, **kw: __getattr__(_n)(self, *a, **kw))(_name))
 
 
 def _export_expr_namespace():

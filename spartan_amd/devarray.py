@@ -434,6 +434,21 @@ class DevArray(object):
   def ravel(self):
     return self.reshape(-1)
 
+  def diagonal(self, offset=0, axis1=0, axis2=1):
+    """ndarray.diagonal: a view; the diagonal becomes the last axis."""
+    nd = len(self.shape)
+    if nd < 2:
+      raise ValueError('diag requires an array of at least two dimensions')
+    axis1, axis2 = axis1 % nd, axis2 % nd
+    if axis1 == axis2:
+      raise ValueError('axis1 and axis2 cannot be the same')
+    n1, n2, s1, s2 = self.shape[axis1], self.shape[axis2], self.strides[axis1], self.strides[axis2]
+    start = self.offset + (offset * s2 if offset >= 0 else -offset * s1)
+    count = max(0, min(n1, n2 - offset) if offset >= 0 else min(n1 + offset, n2))
+    keep = [i for i in range(nd) if i not in (axis1, axis2)]
+    return self._view(start if count else self.offset, [self.shape[i] for i in keep] + [count],
+                      [self.strides[i] for i in keep] + [s1 + s2])
+
   flatten = ravel
 
   def squeeze(self, axis=None):

@@ -321,6 +321,10 @@ def _count_zero(data, axis, ex):
 
 register_reduce_rule(B._countnonzero_local, _count_nonzero)
 register_reduce_rule(B._countzero_local, _count_zero)
+# norm (statistics.py:203-215): np.abs(data).sum(axis) and np.square(data).sum(axis) as one fused map -> reduce
+from .expr import manip as _M  # noqa: E402
+register_reduce_rule(_M._abs_sum_local, lambda data, axis, ex: ('SUM', apply('ABS', np.abs, [data]), _sum_dtype(data.dtype)))
+register_reduce_rule(_M._square_sum_local, lambda data, axis, ex: ('SUM', apply('SQUARE', np.square, [data]), _sum_dtype(data.dtype)))
 
 
 # ------------------------------------------------------------------- inference

@@ -103,7 +103,9 @@ def prepare_tree():
   sub(S + '__init__.py', [("import core", "from . import core")])
   sub(S + 'expr/__init__.py', [("import mathematics", "from . import mathematics")])
   sub(S + 'expr/operator/ndarray.py', [("dtype=np.float,", "dtype=float,")])
-  sub(S + 'expr/creation.py', [("dtype=np.float,", "dtype=float,")])
+  sub(S + 'expr/creation.py', [("dtype=np.float,", "dtype=float,"),
+                               # a LIST of slices as an index meant the tuple of them until NumPy 1.23
+                               ("result = tile[slices].diagonal()", "result = tile[tuple(slices)].diagonal()")])
   # `a / b` on expressions: only __div__/__rdiv__ exist (base.py:348-349,387-388)
   sub(S + 'expr/operator/base.py', [
       ("  def __eq__(self, other):\n    return _map(self, other, fn=np.equal)",

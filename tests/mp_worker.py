@@ -232,7 +232,7 @@ def main():
     ctx = sp.initialize(backend=NumpyBackend(), num_workers=workers, world=world)
   n = 0
   for name, build, expected, tol in programs.programs():
-    got = build(sp).glom()
+    got = programs.run(name, build, sp, ctx.num_workers)
     programs.check(name, got, expected(), tol)
     n += 1
   # the regular patterns must have been carried by collectives, not per-tile messages

@@ -21,7 +21,7 @@ def ctx(request):
 @pytest.mark.parametrize('prog', PROGS, ids=[p[0] for p in PROGS])
 def test_program(ctx, prog):
   name, build, expected, tol = prog
-  got = build(sp).glom()
+  got = programs.run(name, build, sp, ctx.num_workers)
   programs.check(name, got, expected(), tol)
 
 
