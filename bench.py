@@ -553,6 +553,56 @@ def kmeans_dist_section(ctx, p=None):
           'assign_TFLOPs_whole_job_incl_everything': round(10 * 2.0 * n * k * d / dt / 1e12, 1)}
 
 
+def collectives_section(ctx):
+  """N > 1: every collective of the data plane timed ONCE PER KIND on the message size the workloads give it, before
+  the pipeline runs -- so that the first multi-GPU run says which exchange is slow (or hangs: the section runs under
+  `guarded`) instead of only a low headline.  Per kind: [ms, GB/s one GPU sends (its share of the algorithm's
+  traffic / time), fraction of the 7 x 153 GB/s a GPU's xGMI links carry together].  Sizes are those of the north
+  star at p ranks: reduce-scatter of a 512 MiB partial chunk (dot.ksplit_pipeline), all-to-all of 64 MiB A blocks,
+  all-gather of a (4096,) gradient (lreg), broadcast of a 16 KiB centre block; on the staged debug transport
+  (ranks sharing a GPU) everything is 1/64 of that.  Stands where the reference sends UpdateReq / GetReq messages
+  over ZeroMQ (spartan/array/distarray.py:372-422, blob_ctx.py:163-179)."""
+  world = ctx.world
+  p = world.size
+  real = getattr(world.transport, 'name', '') == 'rccl'
+  scale = 1 if real else 64
+  MiB = 1 << 20
+  out = {'is': '{kind: [bytes per GPU message, ms, GB/s sent per GPU, fraction of 7 links]}',
+         'links_GBps': {'one': XGMI_LINK_GBPS, 'seven': 7 * XGMI_LINK_GBPS}, 'transport': world.note or '?',
+         'message_scale': '1' if real else '1/64 (staged transport)'}
+
+  def timed(fn, reps=3):
+    fn()                                        # (first call: communicator channels, staging buffers)
+    return time_steps(ctx, fn, reps, 0) / reps
+
+  def entry(name, nbytes, sent, dt):
+    gbps = sent / dt / 1e9
+    out[name] = [int(nbytes), round(dt * 1e3, 3), round(gbps, 1), round(gbps / (7 * XGMI_LINK_GBPS), 3)]
+  # reduce-scatter: every rank holds a 512 MiB partial, keeps the sum of its 1/p
+  n = 512 * MiB // scale // 4 // p * p
+  inp, res = D.full((n,), 1.0, np.float32), D.empty((n // p,), np.float32)
+  entry('reduce_scatter', n * 4, n * 4 * (p - 1) / p, timed(lambda: world.reduce_scatter(res, inp, 'ADD')))
+  ok = bool((res[:4].numpy() == p).all())
+  del inp, res
+  # all-to-all: one 64 MiB block to and from every other rank, one grouped launch
+  b = 64 * MiB // scale // 4
+  send = [D.full((b,), float(world.rank), np.float32) for _ in range(p)]
+  recv = [D.empty((b,), np.float32) for _ in range(p)]
+  sends = [(r, send[r]) for r in range(p) if r != world.rank]
+  recvs = [(r, recv[r]) for r in range(p) if r != world.rank]
+  entry('all_to_all', b * 4, b * 4 * (p - 1), timed(lambda: world.exchange(sends, recvs)))
+  ok = ok and all(float(recv[r][:1].numpy()[0]) == r for r in range(p) if r != world.rank)
+  del send, recv, sends, recvs
+  # all-gather of the (4096,) pieces of a gradient; broadcast of 16 KiB
+  g, gall = D.full((4096 // p * p // p,), 1.0, np.float32), D.empty((4096 // p * p,), np.float32)
+  entry('all_gather', g.nbytes, g.nbytes * (p - 1), timed(lambda: world.all_gather_into(gall, g), reps=20))
+  small = D.full((4096,), 3.0, np.float32)
+  entry('broadcast', small.nbytes, small.nbytes, timed(lambda: world.broadcast(small, 0), reps=20))
+  out['values_ok'] = ok
+  D.trim_pool()
+  return out
+
+
 def rccl_report(world):
   """What carried the tile payloads between the ranks: `ranks` is the size of the RCCL communicator every rank
   joined and self-tested (0 when the job ran on the staged debug transport)."""
@@ -752,10 +802,10 @@ def _host_memory_gib():
 def cpu_baseline():
   """The reference's execution model on the host cores of this box: W = min(physical
   cores, 64) worker processes, one per core, pinned, one BLAS thread each (spartan/worker.py:40,385-387), running
-  the oracle's NumPy tile bodies ON THE BASELINE SHAPES -- configs[1] whole, configs[2] whole, configs[4] / [3] on
-  the per-GPU tile the GPU numbers of this line are quoted on -- scaled down only where the host's free memory
-  forces it (the reason is printed); the parent merges like the owner of the target tile.  A reported baseline, not
-  a target."""
+  the oracle's NumPy tile bodies ON THE BASELINE SHAPES -- configs[1] whole, configs[2] whole, configs[4] whole
+  for 3 steps, configs[3] on one per-GPU tile for 2 iterations (the bounded sample: the whole array is ~45 s per
+  iteration) -- scaled down only where the host's free memory forces it (the reason is printed); the parent
+  merges like the owner of the target tile.  A reported baseline, not a target."""
   from oracle import cpu_workers
   t_all = time.perf_counter()
   avail, total = _host_memory_gib()
@@ -782,10 +832,18 @@ def cpu_baseline():
         rows //= 2
       scaled.append('map / sum: %d x %d instead of 65536 x 65536 (%.0f GiB free, %.0f GiB needed)' % (rows, cols, avail, need))
     t_map, t_sum, rows = pool.map_and_sum(rows, cols)
-    ln, ld = 125000, 4096                                        # configs[4]: the per-GPU tile of the 8-GPU run
-    t_lreg, ln = pool.lreg_step(ln, ld)
-    kn, kd, kk = 1250000, 256, 1024                              # configs[3]: the per-GPU tile of the 8-GPU run
-    t_km, kn = pool.kmeans_iteration(kn, kd, kk)
+    # configs[4]: the WHOLE 1 000 000 x 4096 array (16 GB over the W workers), 3 gradient steps
+    ln, ld, lsteps = 1000000, 4096, 3
+    need = 2.2 * ln * ld * 4 / float(1 << 30)
+    if avail and need > 0.6 * avail:
+      while ln > 125000 and 2.2 * ln * ld * 4 / float(1 << 30) > 0.6 * avail:
+        ln //= 2
+      scaled.append('lreg: %d rows instead of 1000000 (%.0f GiB free, %.0f GiB needed)' % (ln, avail, need))
+    t_lreg, ln = pool.lreg_steps(ln, ld, lsteps)
+    # configs[3]: scipy's cdist of the whole 10 000 000 points takes ~45 s per iteration on 64 cores, outside the
+    # bounded sample a default run may spend: the per-GPU tile of the 8-GPU run (1 250 000 points), 2 iterations
+    kn, kd, kk, kiters = 1250000, 256, 1024, 2
+    t_km, kn = pool.kmeans_iterations(kn, kd, kk, kiters)
   finally:
     pool.close()
   e = float(rows) * cols
@@ -802,16 +860,16 @@ def cpu_baseline():
                   'TFLOPs_end_to_end': round(end_to_end, 4), 'TFLOPs_gemm_only': round(gemm_only, 4)},
           'map_xx_plus_x_GBps': round(8.0 * e / t_map / 1e9, 2), 'sum_axis0_GBps': round(4.0 * e / t_sum / 1e9, 2),
           'map_sum_shape': '%dx%d fp32 in %d row tiles' % (rows, cols, W),
-          'lreg_step': {'shape': '%dx%d fp32' % (ln, ld), 'seconds': round(t_lreg, 4),
-                        'GBps': round(2 * 4.0 * ln * ld / t_lreg / 1e9, 2)},
-          'kmeans_iteration': {'shape': '%dx%d points, k=%d' % (kn, kd, kk), 'seconds': round(t_km, 3),
-                               'TFLOPs_of_2nkd': round(2.0 * kn * kk * kd / t_km / 1e12, 4)},
+          'lreg': {'shape': '%dx%d fp32 (whole array of configs[4]) in %d row tiles' % (ln, ld, W), 'steps': lsteps,
+                   'seconds_per_step': round(t_lreg, 4), 'GBps': round(2 * 4.0 * ln * ld / t_lreg / 1e9, 2)},
+          'kmeans': {'shape': '%dx%d points, k=%d (one per-GPU tile of configs[3])' % (kn, kd, kk), 'iterations': kiters,
+                     'seconds_per_iteration': round(t_km, 3), 'TFLOPs_of_2nkd': round(2.0 * kn * kk * kd / t_km / 1e12, 4)},
           'host_memory_GiB': {'available': round(avail, 1), 'total': round(total, 1)},
           'scaled_for_memory': scaled,
           'sample': 'oracle tile bodies (NumPy / BLAS / scipy cdist) on %d pinned one-thread workers: configs[1] dot '
-                    '%d^3 K-split, one target tile; configs[2] x*x+x and sum(axis=0) on %dx%d; one lreg step on the '
-                    'per-GPU tile %dx%d of configs[4]; one k-means iteration on the per-GPU tile %dx%d, k=%d of '
-                    'configs[3]%s' % (W, n, rows, cols, ln, ld, kn, kd, kk,
+                    '%d^3 K-split, one target tile; configs[2] x*x+x and sum(axis=0) on %dx%d; configs[4] %d lreg '
+                    'steps on the WHOLE %dx%d array; configs[3] %d k-means iterations on one per-GPU tile %dx%d, '
+                    'k=%d (the whole 10M points: ~45 s per iteration)%s' % (W, n, rows, cols, lsteps, ln, ld, kiters, kn, kd, kk,
                                       '' if not scaled else ' -- scaled for host memory: ' + '; '.join(scaled)),
           'wall_seconds': round(time.perf_counter() - t_all, 1)}
 
@@ -1040,6 +1098,13 @@ def main():
     scaling = 'strong'
   A.force()
   B.force()
+  collectives = None
+  if p > 1 and not args.no_extras:
+    # every collective once, on its real message size, BEFORE the pipeline (a slow or hanging exchange shows here)
+    collectives = guarded(lambda: collectives_section(ctx), 240, world.rank,
+                          {'metric': 'spartan.dot TFLOP/s (+ map/reduce HBM GB/s)', 'value': None, 'unit': 'TFLOP/s',
+                           'n_gpus': p, 'higher_is_better': True, 'config': {'workload': workload},
+                           'error': 'FAILED: the collectives self-timing before the pipeline did not complete'})
 
   keep = []
 
@@ -1088,6 +1153,13 @@ def main():
                    'launches_per_step': per_step, 'traffic': None},
   }
   line['roofline']['traffic'], line['roofline']['traffic_source'] = measured_traffic(n)
+  if collectives is not None:
+    line['collectives'] = collectives
+  if world.rank == 0:
+    # the headline as soon as it is measured (stderr; stdout keeps its ONE line, printed at the end or by the
+    # watchdog of a section that hangs)
+    sys.stderr.write('bench headline: %s\n' % json.dumps({k: line[k] for k in ('value', 'unit', 'n_gpus', 'ms_per_step')}))
+    sys.stderr.flush()
   if p > 1:
     # this rank's share of a step: kernel-only time vs wall, and the bytes it moved against the xGMI rates
     sent = {k: (stats1[k] - stats0[k]) / float(args.steps + args.warmup) for k in stats0}

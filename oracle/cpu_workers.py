@@ -232,33 +232,39 @@ class Workers(object):
     t_sum = time.perf_counter() - t0
     return t_map, t_sum, rows * self.count
 
-  def lreg_step(self, rows_total, dim):
+  def lreg_steps(self, rows_total, dim, steps=3):
+    """`steps` gradient steps on the WHOLE array, row-tiled over the workers (sgd.py:34-39): per step every worker
+    runs its tile body, the owner adds the (dim,) partials and steps w.  Returns (seconds per step, rows)."""
     import numpy as np
     rows = rows_total // self.count
     self.all('make_lreg', rows, dim)
     w = np.random.RandomState(SEED).rand(dim, 1).astype(np.float32)
     t0 = time.perf_counter()
-    parts = self.all('lreg', w)
-    grad = parts[0]
-    for p in parts[1:]:
-      grad = np.add(grad, p)
-    w = w - grad.reshape(dim, 1) * 1e-6
-    return time.perf_counter() - t0, rows * self.count
+    for _ in range(steps):
+      parts = self.all('lreg', w)
+      grad = parts[0]
+      for p in parts[1:]:
+        grad = np.add(grad, p)
+      w = w - grad.reshape(dim, 1) * 1e-6
+    return (time.perf_counter() - t0) / steps, rows * self.count
 
-  def kmeans_iteration(self, rows_total, dim, k):
+  def kmeans_iterations(self, rows_total, dim, k, iterations=1):
+    """Lloyd iterations (k_means_.py:52-97): labels, counts and per-cluster sums per worker, combined by the owner.
+    Returns (seconds per iteration, rows)."""
     import numpy as np
     rows = rows_total // self.count
     self.all('make_kmeans', rows, dim)
     centers = np.random.RandomState(SEED).rand(k, dim)
     t0 = time.perf_counter()
-    parts = self.all('kmeans', centers)
-    counts, sums = parts[0]
-    for c, s in parts[1:]:
-      counts = counts + c
-      sums = sums + s
-    counts[counts == 0] = 1
-    centers = sums / counts.reshape(k, 1)
-    return time.perf_counter() - t0, rows * self.count
+    for _ in range(iterations):
+      parts = self.all('kmeans', centers)
+      counts, sums = parts[0]
+      for c, s in parts[1:]:
+        counts = counts + c
+        sums = sums + s
+      counts[counts == 0] = 1
+      centers = sums / counts.reshape(k, 1)
+    return (time.perf_counter() - t0) / iterations, rows * self.count
 
 
 if __name__ == '__main__':

@@ -682,7 +682,9 @@ class HipBackend(object):
     return (int(np.prod(shape[:axis], dtype=np.int64)), int(shape[axis]),
             int(np.prod(shape[axis + 1:], dtype=np.int64)))
 
-  def _run_reduce(self, data, red_op, nat_dtype, shape, axis):
+  def _build_reduce(self, data, red_op, nat_dtype, shape, axis):
+    """The launch recipe of a fused map -> reduce over one tile: (prog, tensors, result shape, natural dtype,
+    red_op, O, A, I).  Nothing runs and nothing is allocated."""
     self._prepare(data)
     if data.kind in ('const', 'shape'):
       raise lower.NotLowerable('reduction over a constant')
@@ -693,18 +695,51 @@ class HipBackend(object):
     em = lower.Emitter(cls, full_shape, self.contiguous)
     prog, tensors = em.finish(data, None)
     O, A, I = self._axis_split(full_shape, axis)
-    out = self.empty((O * I,), nat_dtype)
     if A == 0 or O * I == 0:
       raise _hip.HipError('reduction over an empty axis')
-    self.launches += 1
-    kernels.reduce(prog, tensors, red_op, O, A, I, out)
     if axis is None:
       shape = ()
     else:
       ax = axis if axis >= 0 else axis + len(full_shape)
       shape = full_shape[:ax] + full_shape[ax + 1:]
-    self._last_reduce = (prog, tensors, shape, nat_dtype, red_op, O, A, I)
+    return (prog, tensors, shape, nat_dtype, red_op, O, A, I)
+
+  def _run_reduce(self, data, red_op, nat_dtype, shape, axis):
+    recipe = self._build_reduce(data, red_op, nat_dtype, shape, axis)
+    prog, tensors, shape, nat_dtype, red_op, O, A, I = recipe
+    out = self.empty((O * I,), nat_dtype)
+    self.launches += 1
+    kernels.reduce(prog, tensors, red_op, O, A, I, out)
+    self._last_reduce = recipe
     return out.reshape(shape)
+
+  def prelower_reduce(self, op, inputs, ex, axis):
+    """prelower_map for the local reduction of a ReduceExpr: the fused map -> reduce program of evaluate_reduce(op,
+    inputs, ex, axis) lowered into the table now (the optimiser calls it for a DAG it sees for the first time), so
+    that the first evaluation replays it like every later one, with the partials' workspace already at its size
+    (`kernels.reduce_warm`)."""
+    rule = lower.REDUCE_RULES.get(op.fn)
+    if rule is None or any(tile.is_sparse_blob(v) for v in inputs.values()):
+      return False
+    data_deps = [d for d in op.deps if not (isinstance(d, LocalInput) and d.idx in ('extent', 'axis'))]
+    if len(data_deps) != 1 or self._materialise_random_needed(op):
+      return False
+    key = self._lowering_key(op, inputs, ex, ('reduce', axis))
+    if key is None:
+      return False
+    if key in self._lowered:
+      return True
+    try:
+      data = lower.infer(data_deps[0], inputs, ex, self.dtype_of)
+      red_op, data, nat = rule(data, axis, ex)
+      recipe = self._build_reduce(data, red_op, nat, ex.shape, axis)
+    except (ProgramTooLarge, lower.NotLowerable, _hip.HipError):
+      return False
+    self._remember(key, recipe, inputs, op)
+    if key in self._lowered:
+      prog, tensors, _, nat_dtype, red_op, O, A, I = recipe
+      kernels.reduce_warm(prog, tensors, red_op, O, A, I, nat_dtype)
+    return key in self._lowered
 
   def evaluate_reduce(self, op, inputs, ex, axis):
     """_reduce_mapper's local reduction (reduce.py:54) incl. the fused map prologue."""

@@ -337,6 +337,7 @@ def _prelower(dag):
   (optimize.py:1023-1076), instead of inside the first evaluation.  Later DAGs of the same structure come from the
   plan table and find the programs in the backend's."""
   from .map import prelower as prelower_map
+  from .reduce import ReduceExpr, prelower as prelower_reduce
   from .base import CollectionExpr
   from .. import context
   ctx = context.get() if context.initialized() else None
@@ -351,6 +352,8 @@ def _prelower(dag):
       seen.add(id(v))
       if type(v) is MapExpr:
         prelower_map(v, ctx)
+      elif type(v) is ReduceExpr:
+        prelower_reduce(v, ctx)
       if isinstance(v, CollectionExpr):
         for x in (v.vals.values() if isinstance(v.vals, dict) else v.vals):
           walk(x)

@@ -31,6 +31,37 @@ def _reduce_mapper(ex, children, child_to_var, op, axis, output):
   return LocalKernelResult(result=[])
 
 
+def prelower(node, ctx):
+  """expr/map.prelower for a ReduceExpr whose inputs exist already: the fused map -> reduce program of its local
+  reduction is handed to the backend before the first evaluation (`prelower_reduce`: lowered and remembered, not
+  run), one tile per distinct tile shape.  The walk is the prelude of ReduceExpr._evaluate and _reduce_mapper."""
+  from .map import get_local_values
+  hook = getattr(ctx.backend, 'prelower_reduce', None)
+  kids = getattr(node.children, 'vals', None)
+  if hook is None or ctx.world.size != 1 or not kids or not all(isinstance(k, base._Leaf) for k in kids):
+    return 0
+  values = [k.evaluate() for k in kids]
+  if not all(isinstance(v, distarray.LocalWrapper) or
+             (isinstance(v, distarray.DistArrayImpl) and not v.sparse and not v.bad_tiles) for v in values):
+    return 0
+  children = broadcast.broadcast(values)
+  largest = distarray.largest_value(children)
+  if not isinstance(largest, distarray.DistArrayImpl):
+    return 0
+  cut = largest.tiles.keys()
+  if not all(isinstance(v, broadcast.Broadcast) or v is largest or v.tiles.keys() == cut for v in children):
+    return 0
+  done, shapes = 0, set()
+  for ex in cut:
+    if ex.shape in shapes or len(shapes) >= 4:
+      continue
+    shapes.add(ex.shape)
+    local_values = get_local_values(ex, children, node.child_to_var)
+    local_values.update(extent=ex, axis=node.axis)
+    done += bool(hook(node.op, local_values, ex, node.axis))
+  return done
+
+
 class ReduceExpr(Expr):
   """reduce.py:73-127."""
   members = ('children', 'child_to_var', 'axis', 'dtype_fn', 'op', 'accumulate_fn', 'tile_hint')

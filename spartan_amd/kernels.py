@@ -75,6 +75,12 @@ def reduce(prog, inputs, red_op, outer, axis_len, inner, out):
   return out
 
 
+def reduce_warm(prog, inputs, red_op, outer, axis_len, inner, out_dtype):
+  """What the first reduce() of this program would set up besides the launch: the partials' workspace at its size."""
+  need = _hip.lib().sp_reduce_workspace_bytes(prog.cls, outer, axis_len, inner)
+  _ws.get(need)
+
+
 def argreduce(prog, inputs, which, outer, axis_len, inner, index_offset, nan_index, out_idx, out_val=None):
   _require_device(out_idx, out_val, *inputs)
   lib = _hip.lib()

@@ -99,6 +99,8 @@ _NP_RED = {'ADD': np.add, 'MUL': np.multiply, 'MAX': np.maximum, 'MIN': np.minim
 
 
 def _reduce_in_rank_order(vals, reducer):
+  if reducer not in _NP_RED:
+    raise RendezvousError('unknown reducer %r (known: %s)' % (reducer, ', '.join(sorted(_NP_RED))))
   fn = _NP_RED[reducer]
   acc = np.array(vals[0], copy=True)
   for v in vals[1:]:
@@ -245,12 +247,26 @@ class Hub(object):
           rnd = self.rounds[key] = _Round()
         rnd.vals[rank] = payload
         if len(rnd.vals) == self.size:
-          rnd.results = self._finish(kind, [rnd.vals[r] for r in range(self.size)])
+          try:
+            rnd.results = self._finish(kind, [rnd.vals[r] for r in range(self.size)])
+          except Exception as e:       # a bad request (unknown reducer, ragged payloads): every rank of the round hears it
+            rnd.results = _Failed('collective %r: %s: %s' % (key, type(e).__name__, e))
           rnd.vals, rnd.done = None, True
           self.cond.notify_all()
         else:
-          self._wait(lambda: rnd.done, 'collective %r' % (key,),
-                     lambda: [r for r in range(self.size) if rnd.vals is not None and r not in rnd.vals])
+          try:
+            self._wait(lambda: rnd.done, 'collective %r' % (key,),
+                       lambda: [r for r in range(self.size) if rnd.vals is not None and r not in rnd.vals])
+          except RendezvousError:
+            # a rank of the round has gone or the wait timed out: `taken` can never reach `size`, so the round (and
+            # the payloads it holds) is dropped by the first rank that gives up on it
+            self.rounds.pop(key, None)
+            raise
+        if isinstance(rnd.results, _Failed):
+          rnd.taken += 1
+          if rnd.taken == self.size:
+            self.rounds.pop(key, None)
+          raise RendezvousError(rnd.results.why)
         out = rnd.results[rank] if isinstance(rnd.results, _PerRank) else rnd.results
         rnd.taken += 1
         if rnd.taken == self.size:
@@ -291,6 +307,13 @@ class Hub(object):
 
 class _PerRank(list):
   """Result of a round that differs by rank."""
+
+
+class _Failed(object):
+  """Result of a round whose reduction raised: every participant gets the error instead of a value."""
+
+  def __init__(self, why):
+    self.why = why
 
 
 class Client(object):

@@ -95,6 +95,21 @@ def test_rounds_mailbox_and_store(job_env):
   assert _threads(3, body) == ['ok'] * 3
 
 
+def test_a_round_whose_reduction_fails_tells_every_rank_and_the_hub_lives_on(job_env):
+  """An unknown reducer (a caller passing np.add for 'ADD') used to raise inside the hub's connection thread: rank 0
+  lost its hub and every other rank its connection.  Now every rank of the round gets the error, the round is
+  dropped, and the next round works."""
+  from spartan_amd import rendezvous
+
+  def body(c, r):
+    x = np.arange(4, dtype=np.float32)
+    with pytest.raises(rendezvous.RendezvousError, match='unknown reducer'):
+      c.reduce_scatter(x, np.add)
+    np.testing.assert_array_equal(c.all_reduce(x, 'ADD'), 2 * x)
+    return 'ok'
+  assert _threads(2, body) == ['ok'] * 2
+
+
 def test_store_from_a_second_thread_while_the_driver_waits_in_a_round(job_env):
   """The heartbeat's watcher talks to the store while the driver thread is inside a collective round."""
   def body(c, r):
@@ -124,6 +139,22 @@ def test_a_rank_that_leaves_fails_the_round_it_never_joined(job_env):
       c.barrier()
     return 'saw it'
   assert _threads(2, body) == ['saw it', 'left']
+
+
+def test_a_failed_wait_drops_its_round(job_env):
+  """A round that times out (a rank never joins it) is removed from the hub's table by the rank that gives up: its
+  payloads do not stay for the life of the hub."""
+  from spartan_amd import rendezvous
+  client, hub = rendezvous.join(0, 2, timeout_s=0.6)
+  other, _ = rendezvous.join(1, 2, timeout_s=0.6)
+  try:
+    with pytest.raises(rendezvous.RendezvousError, match='timed out'):
+      client.all_reduce(np.zeros(1 << 16, np.float32), 'ADD')
+    assert not hub.rounds
+  finally:
+    other.close()
+    client.close()
+    hub.close(1.0)
 
 
 def test_a_rank_that_never_arrives_times_the_round_out_with_its_number(job_env):
