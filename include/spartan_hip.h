@@ -358,6 +358,9 @@ int sp_rowdot_colsum_f32(const float* d_x, int64_t ldx, int64_t n, int64_t d, co
  * no floating-point atomics, and for a label with <= 512 rows exactly NumPy's axis-0
  * order (bit-identical); larger labels differ from it by rounding only.
  * d_out [k, d] of the points' dtype; k <= 16384.
+ * sp_segment_sum_counts: the same, and d_counts[c] (NULL: not wanted) = the number of rows with label c =
+ * sp_bincount_i64 of the labels -- the counting sort has the number anyway, so a k-means iteration that needs
+ * both (k_means_.py:69-72 and :75-97) reads the labels once less and launches two kernels fewer.
  */
 #define SP_NEAREST_AUTO 0
 #define SP_NEAREST_EXACT 1
@@ -385,6 +388,9 @@ int sp_bincount_i64(const int64_t* d_labels, int64_t n, int64_t k, int64_t* d_co
 size_t sp_segment_sum_workspace_bytes(int64_t n, int64_t k, int64_t d);
 int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, const int64_t* d_labels, int64_t n,
                    int64_t k, int64_t d, void* d_out, void* d_ws, size_t ws_bytes, void* stream);
+int sp_segment_sum_counts(const void* d_points, int32_t dtype, int64_t ldx, const int64_t* d_labels, int64_t n,
+                          int64_t k, int64_t d, void* d_out, int64_t* d_counts, void* d_ws, size_t ws_bytes,
+                          void* stream);
 
 /* sp_random_fill: the per-tile bodies of the reference's random builders
  * (spartan/expr/srandom.py:38-55, np.random.rand / randn / randint per tile) as a

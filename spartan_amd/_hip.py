@@ -126,6 +126,7 @@ def _declare(lib):
   lib.sp_segment_sum_workspace_bytes.argtypes = [i64, i64, i64]
   lib.sp_segment_sum_workspace_bytes.restype = sz
   lib.sp_segment_sum.argtypes = [vp, i32, i64, vp, i64, i64, i64, vp, vp, sz, vp]
+  lib.sp_segment_sum_counts.argtypes = [vp, i32, i64, vp, i64, i64, i64, vp, vp, vp, sz, vp]
   lib.sp_random_fill.argtypes = [vp, i32, i64, i32, C.c_uint64, C.c_uint64, i64, i64, vp]
   lib.sp_cumscan.argtypes = [vp, vp, i32, i64, i64, i64, i32, vp]
   lib.sp_coo_to_csr_workspace_bytes.argtypes = [i64]
@@ -209,7 +210,7 @@ EXPORTS = [
     'sp_program_static_id', 'sp_jit_configure', 'sp_jit_wait', 'sp_jit_compiled_count', 'sp_jit_compile_check', 'sp_jit_seed_begin', 'sp_jit_seed_end',
     'sp_reduce_workspace_bytes', 'sp_reduce', 'sp_argreduce_workspace_bytes', 'sp_argreduce',
     'sp_update', 'sp_slice_copy', 'sp_gemm_f32', 'sp_gemm_f64', 'sp_gemm_workspace_bytes', 'sp_gemm_ws', 'sp_rowdot_colsum_workspace_bytes', 'sp_rowdot_colsum_f32', 'sp_nearest_center_workspace_bytes', 'sp_nearest_center', 'sp_kmeans_points_prepared_bytes', 'sp_kmeans_points_prepare', 'sp_nearest_center_prepared_workspace_bytes', 'sp_nearest_center_prepared',
-    'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_random_fill', 'sp_cumscan',
+    'sp_bincount_i64', 'sp_segment_sum_workspace_bytes', 'sp_segment_sum', 'sp_segment_sum_counts', 'sp_random_fill', 'sp_cumscan',
     'sp_coo_to_csr_workspace_bytes', 'sp_coo_to_csr', 'sp_csr_rows', 'sp_coo_box', 'sp_coo_reshape', 'sp_csr_spmm_workspace_bytes', 'sp_csr_spmv_plan_entries', 'sp_csr_spmv_plan', 'sp_csr_spmv_blockplan_bytes', 'sp_csr_spmv_blockplan', 'sp_csr_spmv_blocked', 'sp_csr_spmm', 'sp_csr_scatter',
     'sp_spgemm_count_workspace_bytes', 'sp_spgemm_count', 'sp_spgemm_expand', 'sp_tiling_solve', 'sp_gather_rows', 'sp_stream_copy', 'sp_event_create',
     'sp_event_destroy', 'sp_event_record', 'sp_event_synchronize', 'sp_event_elapsed_ms',

@@ -49,10 +49,13 @@ class _FixedPoints(object):
     self.outer = self.backend._fixed_points
     if self.outer is None:
       self.backend._fixed_points = {}
+      self.backend._fit_labels = collections.OrderedDict()
     return self
 
   def __exit__(self, *exc):
     self.backend._fixed_points = self.outer
+    if self.outer is None:
+      self.backend._fit_labels = None
 
 
 class _HostCopyLater(object):
@@ -102,6 +105,10 @@ class HipBackend(object):
     self._np_cache = collections.OrderedDict()   # bounded: iterative drivers pass a new array every step
     self._side_copies, self._pinned_free = None, {}     # to_numpy_later
     self._fixed_points = None                            # fixed_points()
+    # inside a fit: what is known about label tiles -- {address of a tile: (the tile, the int64 labels it was cast
+    # from or None, their np.bincount or None)}; the last few entries only, each holding its arrays alive (an
+    # address cannot be re-used for something else while its entry is there)
+    self._fit_labels = None
     self.launches = 0
     self.gemms = 0            # gemm_into launches (the K-split tests count them)
     self.host_round_trips = 0  # local functions that had to run on host copies of their tiles (call_local_fn)
@@ -203,6 +210,55 @@ class HipBackend(object):
     v = lower.cast(lower.V('tensor', dtype=self.dtype_of(t), shape=tuple(t.shape), tensor=t), dtype)
     return self._run_map(v, tuple(t.shape))
 
+  def _note_labels(self, tile_, origin=None, counts=None):
+    known = self._fit_labels
+    key = tile_.data_ptr()
+    old = known.pop(key, None)
+    if old is not None and self._same_view(old[0], tile_):
+      origin = origin if origin is not None else old[1]
+      counts = counts if counts is not None else old[2]
+    known[key] = (tile_, origin, counts)
+    # an iteration notes two tiles per worker (the int64 labels and their float32 image): two iterations' worth stay
+    from . import context
+    cap = 4 * (context.get().num_workers if context.initialized() else 1) + 4
+    while len(known) > cap:
+      known.popitem(last=False)
+
+  @staticmethod
+  def _same_view(a, b):
+    return a.shape == b.shape and a.strides == b.strides and a.dtype == b.dtype and a.data_ptr() == b.data_ptr()
+
+  def _known_labels(self, labels):
+    """(int64 labels, their counts or None) of a label tile this fit produced, or (None, None)."""
+    known = self._fit_labels
+    if known is None or not isinstance(labels, D.DevArray):
+      return None, None
+    hit = known.get(labels.data_ptr())
+    if hit is None or not self._same_view(hit[0], labels):
+      return None, None
+    tile_, origin, counts = hit
+    if origin is None:
+      return (tile_ if tile_.dtype == np.int64 else None), counts
+    # counts noted under the origin's own entry (segment_sum sees the int64 array) count for the cast tile too
+    if counts is None:
+      o = known.get(origin.data_ptr())
+      counts = o[2] if o is not None and self._same_view(o[0], origin) else None
+    return origin, counts
+
+  def _take_counts(self, labels):
+    """The counts this fit's segment_sum noted for these labels, handed over ONCE (the caller owns the array: a
+    target tile adopts it and may add to it in place)."""
+    origin, counts = self._known_labels(labels)
+    if counts is None:
+      return None
+    known = self._fit_labels
+    for t in (labels, origin):
+      if t is not None:
+        e = known.get(t.data_ptr())
+        if e is not None and e[2] is counts:
+          known[t.data_ptr()] = (e[0], e[1], None)
+    return counts
+
   def cached_numpy(self, arr, slices):
     """A (slice of a) driver-side NumPy operand in HBM (the reference pickles it into every RunKernelReq,
     dot.py:172-187).  All tiles of ONE top-level evaluation share one upload, found by object identity alone (the
@@ -276,6 +332,17 @@ class HipBackend(object):
     if not dst.is_contiguous():
       raise _hip.HipError('update target must be a dense tile')
     kernels.update(dst, ul, lr, src, self.reducer_name(reducer), mask_mode, mask)
+    known = self._fit_labels
+    if known is not None:
+      if (reducer is None and dst.dtype == np.float32 and src.dtype == np.int64 and tuple(src.shape) == tuple(dst.shape)
+          and tuple(lr) == tuple(dst.shape) and not any(ul) and src.data_ptr() in known
+          and self._same_view(known[src.data_ptr()][0], src)):
+        # the int64 labels of a fit's assignment written over a whole float32 target tile (map2 targets take the
+        # points' dtype, map.py:317-318): remember which labels these floats ARE -- exact, nearest_center registers
+        # labels below 2^24 only -- so that the joins that read the target back need not convert them again
+        self._note_labels(dst, origin=src)
+      elif dst.data_ptr() in known:
+        known.pop(dst.data_ptr(), None)        # anything else written into a known label tile: forget it
 
   def mask_all_set(self, mask, subslice):
     return bool(self.evaluate_reduce_tensor(mask[subslice], 'AND').item())
@@ -944,6 +1011,9 @@ class HipBackend(object):
     return t
 
   def _labels_i64(self, labels, n):
+    origin, _ = self._known_labels(labels)
+    if origin is not None and origin.numel() == n:
+      return self.contiguous(origin).reshape(n)
     labels = self.astype(labels, np.int64) if self.dtype_of(labels) != np.int64 else labels
     return self.contiguous(labels).reshape(n)
 
@@ -962,7 +1032,10 @@ class HipBackend(object):
           self._fixed_points.clear()
         prepared = self._fixed_points[key] = (kernels.prepare_points(points), points)     # (the tile stays alive)
       prepared = prepared[0]
-    return kernels.nearest_center(points, centers, out, tier, prepared)
+    out = kernels.nearest_center(points, centers, out, tier, prepared)
+    if self._fit_labels is not None and centers.shape[0] <= (1 << 24):
+      self._note_labels(out)           # (labels below 2^24: their float32 image is exact)
+    return out
 
   def fixed_points(self):
     """with be.fixed_points(): -- the caller promises that the point tiles it passes to nearest_center are not
@@ -972,6 +1045,9 @@ class HipBackend(object):
 
   def bincount(self, labels, k):
     """np.bincount(labels.astype(int), minlength=k) -> int64 (k,)  (k_means_.py:69-72)."""
+    counts = self._take_counts(labels) if self._fit_labels is not None else None
+    if counts is not None and counts.numel() == int(k):
+      return counts                    # counted by this fit's segment_sum of the same labels (sp_segment_sum_counts)
     labels = self._labels_i64(labels, int(np.prod(labels.shape)))
     self.launches += 1
     return kernels.bincount(labels, int(k), self.empty((int(k),), np.int64))
@@ -979,10 +1055,20 @@ class HipBackend(object):
   def segment_sum(self, points, labels, k):
     """out[c] = points[labels == c].sum(axis=0), in the points' dtype (k_means_.py:75-97)."""
     points = self._rows(points)
+    given = labels
     labels = self._labels_i64(labels, points.shape[0])
     out = self.empty((int(k), points.shape[1]), self.dtype_of(points))
     self.launches += 1
-    return kernels.segment_sum(points, labels, int(k), out)
+    if self._fit_labels is None:
+      return kernels.segment_sum(points, labels, int(k), out)
+    # inside a fit the counts of the same labels are wanted too (kmeans_count_mapper): the counting sort has them
+    counts = self.empty((int(k),), np.int64)
+    kernels.segment_sum(points, labels, int(k), out, counts)
+    if isinstance(given, D.DevArray):
+      self._note_labels(given, counts=counts)
+    if labels is not given:
+      self._note_labels(labels, counts=counts)
+    return out
 
   def concat(self, a, b, axis=0):
     """np.concatenate((a, b), axis) as two box copies (manipulation.py:51)."""

@@ -406,7 +406,8 @@ constexpr int RANK_AHEAD = 8;
 __global__ __launch_bounds__(64) void sp_label_rank_kernel(const int64_t* __restrict__ labels, int64_t n, int k,
                                                            int rb, int nblk, const int* __restrict__ colpre,
                                                            const int* __restrict__ totals, int* __restrict__ perm,
-                                                           int* __restrict__ seg_start, int* __restrict__ slot_first) {
+                                                           int* __restrict__ seg_start, int* __restrict__ slot_first,
+                                                           int64_t* __restrict__ counts) {
   extern __shared__ int cur[];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(64) void sp_label_rank_kernel(const int64_t* __rest
           if (b == 0) {
             seg_start[c] = carry + inc - v;
             slot_first[c] = carry2 + inc2 - v2;
+            if (counts) counts[c] = v;       // (np.bincount of the labels: the column totals of the histogram)
           }
         }
         carry += __shfl(inc, 63);
@@ -776,6 +778,12 @@ extern "C" size_t sp_segment_sum_workspace_bytes(int64_t n, int64_t k, int64_t d
 
 extern "C" int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, const int64_t* d_labels, int64_t n,
                               int64_t k, int64_t d, void* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+  return sp_segment_sum_counts(d_points, dtype, ldx, d_labels, n, k, d, d_out, nullptr, d_ws, ws_bytes, stream);
+}
+
+extern "C" int sp_segment_sum_counts(const void* d_points, int32_t dtype, int64_t ldx, const int64_t* d_labels, int64_t n,
+                                     int64_t k, int64_t d, void* d_out, int64_t* d_counts, void* d_ws, size_t ws_bytes,
+                                     void* stream) {
   if (n < 0 || k < 1 || d < 0) SP_FAIL("sp_segment_sum: bad sizes");
   if (dtype != SP_F32 && dtype != SP_F64) SP_FAIL("sp_segment_sum: points must be f32 or f64");
   if (k > 16384) SP_FAIL("sp_segment_sum: k=%lld exceeds the LDS cursor table (16384)", (long long)k);
@@ -786,7 +794,7 @@ extern "C" int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, 
   const size_t esz = dtype == SP_F32 ? 4 : 8;
   if (n == 0 || d == 0) {
     SP_HIP(hipMemsetAsync(d_out, 0, (size_t)k * (size_t)d * esz, st));
-    return 0;
+    return d_counts ? sp_bincount_i64(d_labels, n, k, d_counts, stream) : 0;
   }
   if (!d_ws || ws_bytes < sp_segment_sum_workspace_bytes(n, k, d)) SP_FAIL("sp_segment_sum: workspace too small");
   const int rb = sort_block_rows(n, k);
@@ -803,7 +811,7 @@ extern "C" int sp_segment_sum(const void* d_points, int32_t dtype, int64_t ldx, 
                      hist, nblk, (int)k, totals);
   SP_CHECK_LAUNCH();
   hipLaunchKernelGGL(sp_label_rank_kernel, dim3(nblk), dim3(64), (size_t)k * 4, st, d_labels, n, (int)k, rb, nblk,
-                     hist, totals, perm, seg, slot_first);
+                     hist, totals, perm, seg, slot_first, d_counts);
   SP_CHECK_LAUNCH();
   const int64_t max_slots = seg_max_slots(n, k);
   // V columns per lane: as wide as alignment allows while the launch still has >= 2048 waves

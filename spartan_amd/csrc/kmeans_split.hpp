@@ -46,7 +46,7 @@
 typedef __bf16 km_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef KS_ABLATE
 #define KS_ABLATE 0     // timing-only builds (-DKS_ABLATE=n, tools/km_first.py): 1 no k-tile loads, 2 no fragment reads, 4 a
-                        // sixteenth of the epilogue (NB: the MFMAs whose results it no longer reads are dropped too), 8 no MFMAs
+                        // sixteenth of the epilogue (NB: the MFMAs whose results it no longer reads are dropped too), 8 no MFMAs, 16 point tiles from the L2
 #endif
 
 namespace {
@@ -183,32 +183,51 @@ __global__ __launch_bounds__(256) void sp_split_rows_kernel(const float* __restr
   }
 }
 
-// sp_centers_prep_kernel for shifted centers: Cf[c][j] = fl32(C[c][j] - mu[j]) (zero padded), cn[c] = |Cf[c]|^2 / 2
-// (of the ROUNDED row: the number the contraction multiplies; fp64 sum, rounded; +inf on padding), *cmax2 = max |Cf[c]|^2
+// The three center launches of a first pass in one (a fit runs them every iteration): memset of Cf, the shifted
+// fp32 copy Cf[c][j] = fl32(C[c][j] - mu[j]) and its cut into the two bf16 images (sp_split_rows_kernel).  One
+// wavefront per center row of the padded table: v = fl32(C[c][j] - mu[j]) (0 beyond d, and on the padding rows),
+// hi / mid images written straight from the registers -- the fp32 copy is never stored: nothing but the cut read it --
+// cn[c] = |v|^2 / 2 (fp64 sum, rounded; +inf on padding), and ONE atomicMax per workgroup for max |v|^2 (one per
+// center was 1024 same-address atomics: most of the old kernel's 15 us).  Values identical to the three launches'.
 template <typename TC>
-__global__ __launch_bounds__(256) void sp_centers_prep_shifted_kernel(const TC* __restrict__ C, int64_t ldc, int k, int d,
-                                                                      int kp, int dp, const float* __restrict__ mu,
-                                                                      float* __restrict__ Cf, float* __restrict__ cn,
-                                                                      unsigned* __restrict__ cmax2) {
-  const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void sp_centers_split_prep_kernel(const TC* __restrict__ C, int64_t ldc, int k, int d,
+                                                                    int kp, int dp, const float* __restrict__ mu,
+                                                                    __bf16* __restrict__ Ch, __bf16* __restrict__ Cm,
+                                                                    float* __restrict__ cn, unsigned* __restrict__ cmax2) {
+  __shared__ unsigned wave_max[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (c >= kp) return;
-  if (c >= k) {
-    if (lane == 0) cn[c] = INFINITY;
-    return;
-  }
-  double s = 0.0;
-  for (int j = lane; j < d; j += 64) {
-    const float v = (float)((double)C[(int64_t)c * ldc + j] - (double)mu[j]);
-    s += (double)v * (double)v;
-    Cf[(int64_t)c * dp + j] = v;
-  }
+  unsigned mine = 0u;
+  if (c < kp) {
+    double s = 0.0;
+    for (int j = lane; j < dp; j += 64) {
+      float v = 0.f;
+      if (c < k && j < d) {
+        v = (float)((double)C[(int64_t)c * ldc + j] - (double)mu[j]);
+        s += (double)v * (double)v;
+      }
+      const __bf16 h = (__bf16)v;
+      Ch[ks_at(c, j, kp)] = h;
+      Cm[ks_at(c, j, kp)] = (__bf16)(v - (float)h);
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) {
-    const float sf = (float)s;
-    cn[c] = 0.5f * sf;
-    atomicMax(cmax2, __float_as_uint(sf * 1.0000002f));
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+      if (c < k) {
+        const float sf = (float)s;
+        cn[c] = 0.5f * sf;
+        mine = __float_as_uint(sf * 1.0000002f);
+      } else {
+        cn[c] = INFINITY;
+      }
+    }
+  }
+  if (lane == 0) wave_max[wv] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned m = wave_max[0];
+    for (int i = 1; i < 4; ++i) m = wave_max[i] > m ? wave_max[i] : m;
+    if (m) atomicMax(cmax2, m);
   }
 }
 
@@ -572,17 +591,14 @@ static int sp_nearest_split_launch_wn(const void* C, int32_t cdtype, int64_t ldc
                                       int64_t* labels, const KmWorkspace& w, hipStream_t st) {
   using K = KsCfg<WN>;
   const int64_t kp = w.kp, dp = w.dp;
-  SP_HIP(hipMemsetAsync(w.Cf, 0, km_align((size_t)dp * kp * 4), st));
   SP_HIP(hipMemsetAsync(w.cmax2, 0, 512, st));   // cmax2 and amb_count
   const unsigned pblocks = (unsigned)((kp + 3) / 4);   // one wavefront per center
   if (cdtype == SP_F32)
-    hipLaunchKernelGGL((sp_centers_prep_shifted_kernel<float>), dim3(pblocks), dim3(256), 0, st, (const float*)C, ldc,
-                       (int)k, (int)d, (int)kp, (int)dp, (const float*)w.mu, w.Cf, w.cn, w.cmax2);
+    hipLaunchKernelGGL((sp_centers_split_prep_kernel<float>), dim3(pblocks), dim3(256), 0, st, (const float*)C, ldc,
+                       (int)k, (int)d, (int)kp, (int)dp, (const float*)w.mu, w.Ch, w.Cm, w.cn, w.cmax2);
   else
-    hipLaunchKernelGGL((sp_centers_prep_shifted_kernel<double>), dim3(pblocks), dim3(256), 0, st, (const double*)C, ldc,
-                       (int)k, (int)d, (int)kp, (int)dp, (const float*)w.mu, w.Cf, w.cn, w.cmax2);
-  hipLaunchKernelGGL(sp_split_rows_kernel, dim3(pblocks), dim3(256), 0, st, (const float*)w.Cf, dp, kp, (int)dp, (int)dp,
-                     (const float*)nullptr, w.Ch, w.Cm, (float*)nullptr);
+    hipLaunchKernelGGL((sp_centers_split_prep_kernel<double>), dim3(pblocks), dim3(256), 0, st, (const double*)C, ldc,
+                       (int)k, (int)d, (int)kp, (int)dp, (const float*)w.mu, w.Ch, w.Cm, w.cn, w.cmax2);
   SP_CHECK_LAUNCH();
   const int64_t blocks = (n + K::BN - 1) / K::BN, tiles = kp / KS_BM;
   int64_t rem = blocks % K::SLOTS, split = 1, per = tiles;

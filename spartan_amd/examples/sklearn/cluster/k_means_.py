@@ -114,7 +114,10 @@ class KMeans(object):
     sums = expr.map2((X, labels), (0, 0), fn=kmeans_center_mapper, fn_kw={'centers_count': k},
                      shape=(k, dim), reducer=reducer)
     counts, sums = counts.optimized(), sums.optimized()
-    return counts.evaluate(), sums.evaluate()
+    # (the sums first: a backend's segment sum has the counts of the same labels for nothing, and hands them to the
+    #  count join -- HipBackend.segment_sum / bincount inside fixed_points(); the two joins are independent)
+    sums_arr = sums.evaluate()
+    return counts.evaluate(), sums_arr
 
   def _centers_on_host(self, counts_arr, sums_arr):
     """The reference's driver step: glom both, re-seed empty clusters, divide."""

@@ -216,18 +216,22 @@ def bincount(labels, k, counts):
   return counts
 
 
-def segment_sum(points, labels, k, out):
-  """out[c] = points[labels == c].sum(axis=0) (k_means_.py:75-97)."""
-  _require_device(points, labels, out)
+def segment_sum(points, labels, k, out, counts=None):
+  """out[c] = points[labels == c].sum(axis=0) (k_means_.py:75-97); counts (int64 [k], optional) = np.bincount(labels,
+  minlength=k): the counting sort inside has the number anyway."""
+  _require_device(points, labels, out, counts)
   n, d = points.shape
   assert np_dtype_of(labels) == np.int64 and labels.numel() == n and labels.is_contiguous()
   assert np_dtype_of(out) == np_dtype_of(points) and tuple(out.shape) == (k, d) and out.is_contiguous()
   lib = _hip.lib()
   need = lib.sp_segment_sum_workspace_bytes(n, k, d)
   ws = _ws.get(need, points.device)
-  check(lib.sp_segment_sum(C.c_void_p(points.data_ptr()), _hip.sp_dtype(np_dtype_of(points)), _ld(points),
-                           C.c_void_p(labels.data_ptr()), n, k, d, C.c_void_p(out.data_ptr()),
-                           C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
+  if counts is not None:
+    assert np_dtype_of(counts) == np.int64 and counts.numel() == k and counts.is_contiguous()
+  check(lib.sp_segment_sum_counts(C.c_void_p(points.data_ptr()), _hip.sp_dtype(np_dtype_of(points)), _ld(points),
+                                  C.c_void_p(labels.data_ptr()), n, k, d, C.c_void_p(out.data_ptr()),
+                                  C.c_void_p(counts.data_ptr() if counts is not None else 0),
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream()))
   return out
 
 

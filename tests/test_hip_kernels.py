@@ -922,6 +922,53 @@ def test_segment_sum_is_deterministic_and_balanced():
   np.testing.assert_allclose(outs[0], want, rtol=2e-5)
 
 
+@pytest.mark.parametrize('n,k,d', [(1, 1, 1), (5000, 7, 3), (70000, 1024, 16), (3000, 16384, 4)])
+def test_segment_sum_counts_are_numpy_bincount(n, k, d):
+  """sp_segment_sum_counts: the same sums as sp_segment_sum, and np.bincount(labels, minlength=k) (labels outside
+  [0, k) ignored, as sp_bincount_i64) out of the counting sort -- k_means_.py:69-72 and :75-97 in one call."""
+  x = (RNG.rand(n, d) * 10).astype(np.float32)
+  lab = RNG.randint(0, k, size=n).astype(np.int64)
+  if n > 10:
+    lab[3], lab[7] = -1, k + 5             # ignored
+  plain, both, counts = D.empty((k, d), np.float32), D.empty((k, d), np.float32), D.empty((k,), np.int64)
+  kernels.segment_sum(dev(x), dev(lab), k, plain)
+  kernels.segment_sum(dev(x), dev(lab), k, both, counts)
+  D.synchronize()
+  np.testing.assert_array_equal(host(both), host(plain))
+  ok = lab[(lab >= 0) & (lab < k)]
+  np.testing.assert_array_equal(host(counts), np.bincount(ok, minlength=k))
+  alone = D.empty((k,), np.int64)
+  kernels.bincount(dev(lab), k, alone)
+  np.testing.assert_array_equal(host(counts), host(alone))
+
+
+def test_a_fit_counts_with_its_segment_sums_and_converts_no_labels(monkeypatch):
+  """Inside KMeans.fit on the HIP backend the count join takes the counts the segment sum of the same labels made
+  (no bincount launch), and the joins read the int64 labels the assignment produced instead of converting the float32
+  target back (no astype launch) -- with centres bit-identical to the same fit with both shortcuts switched off."""
+  import spartan_amd as sp
+  from spartan_amd.examples.sklearn.cluster import KMeans
+  calls = {'bincount': 0}
+  real = kernels.bincount
+  monkeypatch.setattr(kernels, 'bincount', lambda *a, **kw: (calls.__setitem__('bincount', calls['bincount'] + 1), real(*a, **kw))[1])
+  x = RNG.rand(21000, 32).astype(np.float32)       # (3 x 7000: the label target is cut like the points)
+  init = RNG.rand(50, 32)
+  out = {}
+  for mode in ('shortcuts', 'plain'):
+    ctx = sp.initialize('hip', num_workers=3)
+    try:
+      if mode == 'plain':
+        monkeypatch.setattr(type(ctx.backend), 'fixed_points', None, raising=False)
+      calls['bincount'] = 0
+      c, lab = KMeans(50, 3).fit(sp.from_numpy(x), init.copy(), implementation='map2', reducer=np.add)
+      out[mode] = (np.asarray(c), lab.glom(), calls['bincount'])
+    finally:
+      sp.shutdown()
+  np.testing.assert_array_equal(out['shortcuts'][0], out['plain'][0])
+  np.testing.assert_array_equal(out['shortcuts'][1], out['plain'][1])
+  assert out['plain'][2] >= 3 * 3 and out['shortcuts'][2] == 0, (out['plain'][2], out['shortcuts'][2])
+
+
 # ---- fp64 GEMM (gemm_f64.hip) ------------------------------------------------------
 @pytest.mark.parametrize('mnk', [(1, 1, 1), (16, 16, 4), (128, 128, 8), (130, 70, 33), (257, 300, 129), (64, 2, 1024),
                                  (512, 384, 256)])
