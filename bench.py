@@ -409,11 +409,18 @@ def kmeans_section(ctx):
   counts = D.empty((k,), np.int64)
 
   def accumulate():
-    kernels.bincount(labels, k, counts)
-    kernels.segment_sum(x, labels, k, sums)
+    # counts and per-cluster sums of one assignment, as a fit's iteration gets them: ONE call (sp_segment_sum_counts:
+    # the counting sort inside has the counts), 5 launches -- histogram, column scan, rank, segment sums, combine
+    kernels.segment_sum(x, labels, k, sums, counts)
   ms = event_time(accumulate, 10, section=('k-means segment sums', 'sp_segment_sum_kernel', 4.0 * n * d, 'bytes', 'hbm'))
   out['accumulate_ms'] = round(ms, 3)
   out['accumulate_GBps'] = round(4.0 * n * d / ms / 1e6, 1)             # 4*N*D bytes
+  out['accumulate_launches'] = 5
+
+  def accumulate_two_calls():            # (rounds 1-5: sp_bincount_i64 + sp_segment_sum, 7 launches with the memset)
+    kernels.bincount(labels, k, counts)
+    kernels.segment_sum(x, labels, k, sums)
+  out['accumulate_two_calls_ms'] = round(event_time(accumulate_two_calls, 10), 3)
   # the benchmark as the reference runs it (tests/benchmark_kmeans.py -> KMeans(k, n_iter).fit): ONE fit of 10
   # iterations, after one of 2 -- inside a fit the centers stay on the worker between iterations (k_means_.py)
   c, _ = KMeans(k, 2).fit(Xv, centers, implementation='map2', reducer=np.add)

@@ -283,7 +283,10 @@ __global__ __launch_bounds__(KsCfg<WN>::THREADS, 2) void sp_nearest_split_kernel
   // (PARTIAL launches pass the whole images and where their points start: first_point)
   // (KS_ABLATE & 16: every workgroup reads the point tile of its XCD's first workgroup -- what the pass costs when the
   // point images come from the L2)
-  const int m0_ld = (KS_ABLATE & 16) ? (int)(blockIdx.x & 7) * KS_BN : m0;
+#ifndef KS_ABLATE_MOD
+#define KS_ABLATE_MOD 8
+#endif
+  const int m0_ld = (KS_ABLATE & 16) ? (int)(blockIdx.x % KS_ABLATE_MOD) * KS_BN : m0;
   const char* __restrict__ Xh_blk = (const char*)(RECHECK ? Xh : Xh + (int64_t)(first_point + m0_ld) * KS_BK);
   const char* __restrict__ Xm_blk = (const char*)(RECHECK ? Xm : Xm + (int64_t)(first_point + m0_ld) * KS_BK);
   const int64_t x_slab = (int64_t)n_total * KS_RB, c_slab = (int64_t)kp * KS_RB;   // bytes per k-tile of an image
