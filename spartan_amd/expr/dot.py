@@ -98,6 +98,9 @@ def dot_map2_mapper(extents, tiles, is_vec=None):
   yield extent.from_shape(shape), _dot(slab, rows)
 
 
+dot_map2_mapper.is_contraction = True       # (expr/map.py warns once when such a join meets grid-tiled operands)
+
+
 def dot_outer_mapper(ex_a, tile_a, ex_b, tile_b):
   """Row block of a times all of b: its own rows of the result, no reduction."""
   if len(tile_b.shape) == 1:

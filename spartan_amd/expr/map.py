@@ -187,6 +187,29 @@ def region_join_mapper(ex, arrays, axes, local_user_fn, local_user_fn_kw, target
   return LocalKernelResult(result=[])
 
 
+_warned_grid = []
+
+
+def _warn_if_grid_tiled(arrays):
+  """spartan.dot's join re-reads tile number b of a GRID-tiled operand as a slab ONE index thick (extent.pyx:545-552,
+  change_partition_axis), so only as many indices of the contraction as there are tiles take part: the result is the
+  reference's, bit for bit (tests/test_dot_grid_tiles.py), and it is not the matrix product.  Say so once."""
+  if _warned_grid:
+    return
+  for arr in arrays:
+    tiles = getattr(arr, 'tiles', None)
+    if not tiles or len(getattr(arr, 'shape', ())) != 2:
+      continue
+    if len({ex.ul[0] for ex in tiles}) > 1 and len({ex.ul[1] for ex in tiles}) > 1:
+      import warnings
+      _warned_grid.append(True)
+      warnings.warn('spartan.dot on an operand cut into a 2-D grid of tiles %s: the join takes one slab of ONE index per '
+                    'tile (as the reference does), so the result is not the matrix product; use row tiles (the '
+                    'default) or tile_hint=(rows, all columns)' % (sorted({ex.shape for ex in tiles})[:2],),
+                    RuntimeWarning, stacklevel=4)
+      return
+
+
 class Map2Expr(Expr):
   """A join of arrays on chosen axes whose per-tile function writes into a new target array."""
   members = ('arrays', 'axes', 'fn', 'fn_kw', 'shape_', 'update_region', 'tile_hint', 'dtype', 'reducer')
@@ -213,6 +236,8 @@ class Map2Expr(Expr):
     # a mapper may know how to run its whole join as one pipeline of transfers and kernels when operands and
     # target are laid out regularly (dot: the K-split with its all-to-all and reduce-scatter, dot.ksplit_plan)
     plan = getattr(self.fn, 'collective_plan', None)
+    if getattr(self.fn, 'is_contraction', False):
+      _warn_if_grid_tiled(arrays)
     if self.update_region is not None:
       arrays[0].foreach_tile(mapper_fn=region_join_mapper,
                              kw=dict(arrays=arrays, axes=self.axes, local_user_fn=self.fn,

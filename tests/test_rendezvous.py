@@ -141,6 +141,31 @@ def test_a_rank_that_leaves_fails_the_round_it_never_joined(job_env):
   assert _threads(2, body) == ['saw it', 'left']
 
 
+def test_a_peer_without_the_jobs_secret_is_not_admitted(job_env, monkeypatch):
+  """The handshake is a challenge: the hub sends a nonce, the peer answers HMAC(secret, nonce + job name).  A peer
+  that knows the job's name (it is sent in clear) but not $SPARTAN_JOB_SECRET never reaches the pickled protocol;
+  a hub that other hosts can reach refuses to start without a secret."""
+  from spartan_amd import rendezvous
+  monkeypatch.setenv('SPARTAN_JOB_SECRET', 'token-of-this-job')
+  client, hub = rendezvous.join(0, 2, timeout_s=5)
+  try:
+    monkeypatch.setenv('SPARTAN_JOB_SECRET', 'something-else')
+    with pytest.raises(rendezvous.RendezvousError, match='refused the proof'):
+      rendezvous.Client(1, 2, 0.5, port=hub.port)
+    monkeypatch.setenv('SPARTAN_JOB_SECRET', 'token-of-this-job')
+    other = rendezvous.Client(1, 2, 5.0, port=hub.port)
+    other.set('k', 'v')
+    assert client.get('k') == 'v'
+    other.close()
+  finally:
+    client.close()
+    hub.close(1.0)
+  monkeypatch.delenv('SPARTAN_JOB_SECRET')
+  monkeypatch.setenv('MASTER_ADDR', '10.1.2.3')
+  with pytest.raises(rendezvous.RendezvousError, match='SPARTAN_JOB_SECRET'):
+    rendezvous.Hub(2, 5.0)
+
+
 def test_a_failed_wait_drops_its_round(job_env):
   """A round that times out (a rank never joins it) is removed from the hub's table by the rank that gives up: its
   payloads do not stay for the life of the hub."""
