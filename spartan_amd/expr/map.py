@@ -198,7 +198,7 @@ def _warn_if_grid_tiled(arrays):
     return
   for arr in arrays:
     tiles = getattr(arr, 'tiles', None)
-    if not tiles or len(getattr(arr, 'shape', ())) != 2:
+    if not tiles or len(getattr(arr, 'shape', ())) != 2 or any(len(ex.ul) != 2 for ex in tiles):
       continue
     if len({ex.ul[0] for ex in tiles}) > 1 and len({ex.ul[1] for ex in tiles}) > 1:
       import warnings
