@@ -2,6 +2,8 @@
 (`map`, `map_with_location`, `map2`, `MapExpr`, `Map2Expr`, `tile_mapper`, `join_mapper`).  The per-tile body of a
 map -- the reference evaluates the operator tree node by node with NumPy -- is ONE fused HIP kernel launch issued
 through the backend."""
+import collections
+
 import numpy as np
 
 from . import base
@@ -62,6 +64,9 @@ class MapExpr(Expr):
     return common_shape([tuple(c.shape) for c in self.children])
 
   def _evaluate(self, ctx, deps):
+    fast = _evaluate_aligned(self, ctx, deps['children'], deps['child_to_var'])
+    if fast is not None:
+      return fast
     inputs = broadcast(list(deps['children']))
     names = list(deps['child_to_var'])
     # the largest input drives the tile walk (its tiles are read in place, the others are fetched to them)
@@ -69,6 +74,69 @@ class MapExpr(Expr):
     inputs[0], inputs[lead] = inputs[lead], inputs[0]
     names[0], names[lead] = names[lead], names[0]
     return inputs[0].map_to_array(tile_mapper, kw={'children': inputs, 'child_to_var': names, 'op': self.op})
+
+
+def _evaluate_aligned(node, ctx, values, names):
+  """MapExpr._evaluate for the case a driver loop hits every time: one process, every array operand dense, whole,
+  written everywhere and CUT THE SAME WAY (same shape, same tile table), the other operands scalars.  Then nothing
+  is stretched, fetched, gathered or combined: tile by tile the operands are the tiles' own tensors and the result is
+  a new tile on the same worker -- what tile_mapper / run_kernel / from_table arrive at through their general
+  machinery (broadcast views, fetch plans, update batches, shape discovery), with the same calls into the backend
+  in the same order.  Returns None, having done nothing, whenever any of that does not hold."""
+  if ctx.world.size != 1 or ctx.pending is not None:
+    return None
+  DA, LW = distarray.DistArrayImpl, distarray.LocalWrapper
+  lead = None
+  for v in values:
+    t = type(v)
+    if t is DA:
+      if v.sparse or v.bad_tiles:
+        return None
+      if lead is None:
+        lead = v
+      elif v.shape != lead.shape or (v.tiles is not lead.tiles and list(v.tiles) != list(lead.tiles)):
+        return None
+    elif t is LW:
+      if v._data.ndim != 0:
+        return None
+    else:
+      return None
+  if lead is None or not lead.tiles:
+    return None
+  blobs = ctx._blobs
+  ALL_SET, DENSE = tile.MASK_ALL_SET, tile.TYPE_DENSE
+  rows = []
+  for ex, tid in lead.tiles.items():
+    operands = {}
+    for v, name in zip(values, names):
+      if type(v) is LW:
+        operands[name] = v._scalar if v._scalar is not None else v._data
+        continue
+      t = blobs.get(v.tiles[ex])
+      if t is None or type(t.mask) is not int or t.mask != ALL_SET or t.type != DENSE or t.data is None or not t.shape:
+        return None
+      operands[name] = t.data
+    operands['extent'] = ex
+    rows.append((ex, tid.worker, operands))
+  backend, op = ctx.backend, node.op
+  table = collections.OrderedDict()
+  outer_worker = ctx.current_worker
+  dtype = None
+  try:
+    for ex, worker, operands in rows:
+      ctx.current_worker = worker
+      out = backend.evaluate_map(op, operands, ex)
+      if tuple(out.shape) != ex.shape:
+        raise AssertionError('Bad shape -- result = %s, op = (%s)' % (tuple(out.shape), op))
+      if tile.is_sparse_blob(out):
+        raise AssertionError('a map over dense tiles produced a sparse tile (op = %s)' % (op,))
+      dt = backend.dtype_of(out)
+      if dtype is None:
+        dtype = dt
+      table[ex] = ctx.create(tile.from_data(out, dtype=dt), hint=worker)
+  finally:
+    ctx.current_worker = outer_worker
+  return distarray.DistArrayImpl(shape=lead.shape, dtype=dtype, tiles=table, reducer_fn=None, sparse=False)
 
 
 def prelower(node, ctx):

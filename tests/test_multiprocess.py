@@ -110,7 +110,9 @@ def test_bench_eight_ranks_on_one_gpu_line():
     assert key in line, sorted(line)
   rccl = line['rccl']
   assert rccl['control_plane'] == 'socket' and rccl['torch_in_process'] is False, rccl
-  assert all(len(v) <= 1 for v in rccl['mapped'].values()), rccl['mapped']          # one HIP / HSA runtime (RCCL: 0 or 1)
+  assert all(n <= 1 for n in rccl['runtimes_mapped'].values()), rccl['runtimes_mapped']   # one HIP / HSA runtime (RCCL: 0 or 1)
+  assert 'collectives' in line and line['collectives']['values_ok'] is True, line.get('collectives')
+  assert len(out) < 7900
   if rccl['visible_gpus'] < 8:
     assert rccl['ranks'] == 0 and line['valid_scaling_measurement'] is False, line
   else:

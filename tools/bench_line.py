@@ -166,6 +166,9 @@ def compact(full):
     line['collectives'] = full['collectives']
   if isinstance(full.get('rccl'), dict):
     line['rccl'] = _flat(full['rccl'], width=120)
+    line['rccl'].pop('mapped', None)
+    if isinstance(full['rccl'].get('mapped'), dict):       # how many copies of each runtime library the process maps
+      line['rccl']['runtimes_mapped'] = {k: len(v) for k, v in full['rccl']['mapped'].items()}
   if isinstance(full.get('comm'), dict):
     line['comm'] = _flat(full['comm'], width=120)
   if 'launcher' in full:
