@@ -109,11 +109,17 @@ class KMeans(object):
   def _launch_join(self, X, labels, reducer):
     """The two accumulate joins of an iteration, launched; nothing waits for the device."""
     k, dim = self.n_clusters, X.shape[1]
+    # (both targets as ONE tile: every worker's partial covers the whole target, so a target cut over the workers --
+    #  the default, the reference's -- turns each partial into one merge per target tile: 2 x workers^2 small launches
+    #  per iteration where several workers share a GPU, 1.5 MB of reduce-scatter + all-gather instead of reduce +
+    #  broadcast where they do not.  Values are the same; with reducer=None the reference's own quirk -- the last
+    #  partial replaces the others -- is too.)
     counts = expr.map2(labels, 0, fn=kmeans_count_mapper, fn_kw={'centers_count': k}, shape=(k,),
-                       reducer=reducer)
+                       reducer=reducer, tile_hint=(k,))
     sums = expr.map2((X, labels), (0, 0), fn=kmeans_center_mapper, fn_kw={'centers_count': k},
-                     shape=(k, dim), reducer=reducer)
-    counts, sums = counts.optimized(), sums.optimized()
+                     shape=(k, dim), reducer=reducer, tile_hint=(k, dim))
+    # Evaluated as built: the reference optimises both joins here (k_means_.py:144-145), which fuses nothing (a join
+    # has no fusable body) but lets its auto-tiling pass cut the targets by rows again.
     # (the sums first: a backend's segment sum has the counts of the same labels for nothing, and hands them to the
     #  count join -- HipBackend.segment_sum / bincount inside fixed_points(); the two joins are independent)
     sums_arr = sums.evaluate()
