@@ -30,15 +30,19 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Tiles are walked m-fastest inside groups of SP_GEMM_GROUP_M tile rows.  Measured on 8192^3 (PMC, 2 x
-// FETCH_SIZE): group 32 / 16 / 8 / 4 / 2 / 1 -> 23.7 / 22.3 / 18.6 / 12.9 / 10.6 / 10.1 GB of L2 misses and
-// 137.5 -> 139.5 TFLOP/s: only the A panel shared by the WGs of one tile ROW is reliably served from the
-// XCD's L2, so the plain row-major walk (group 1: 64 resident WGs = one 256-row A panel x 64 B panels) wins.
+// Tiles are walked m-fastest inside groups of SP_GEMM_GROUP_M tile rows.  Measured on 8192^3 (PMC, 2 x FETCH_SIZE,
+// the direct-to-LDS kernel of rounds 3+; round 6, tools/_exp/gemm_group.sh): group 1 / 2 / 3 / 4 / 8 -> 9.19 / 6.76 /
+// 7.44 / 9.24 / 17.3 GB of L2 misses at the SAME speed (150.8 / 150.8 / 150.8 / 150.7 / 150.3 TFLOP/s; 32768^3,
+// 16384^3, 6144^3, 4096^3 and the pipeline's chunk shapes within 0.3 %): with two tile rows per group the 64
+// workgroups resident on an XCD are 2 A panels x 32 B panels instead of 1 x 64 -- half the B traffic for twice the
+// (small) A traffic; beyond 2 the workgroups of a group drift too far apart in k for the L2 to serve the shared
+// panels.  (Round 2, on the register-staged kernel, had measured 1 as the minimum: 10.1 GB against 10.6 for 2.)
+// 2 is the default since round 6: counter traffic at 8192^3 11.7 x -> 8.7 x the 12 n^2 floor.
 #ifndef SP_GEMM_ABLATE
 #define SP_GEMM_ABLATE 0      // build with -DSP_GEMM_ABLATE=1 for the timing-only variants (tools/gemm_variants.py)
 #endif
 #ifndef SP_GEMM_GROUP_M
-#define SP_GEMM_GROUP_M 1
+#define SP_GEMM_GROUP_M 2
 #endif
 
 template <int BM, int BN, int BK, int WM, int WN>
