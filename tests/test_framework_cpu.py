@@ -191,3 +191,49 @@ def test_partial_write_across_tiles_reads_masked_and_refuses_kernels():
     assert extent.largest_dim_axis(()) == 0
   finally:
     sp.shutdown()
+
+
+def test_aligned_map_path_is_the_general_path(ctx, monkeypatch):
+  """expr/map._evaluate_aligned (same-shape, same-tiling dense operands and scalars) against the general
+  tile_mapper / run_kernel / from_table path it short-cuts: same values, dtypes, tile tables and placements, and it
+  steps aside (None, nothing done) for what it does not cover -- stretched operands, driver-side arrays, sparse or
+  partly written arrays."""
+  import importlib
+  M = importlib.import_module('spartan_amd.expr.map')
+  taken = []
+  real = M._evaluate_aligned
+
+  def spy(node, c, values, names):
+    out = real(node, c, values, names)
+    taken.append(out is not None)
+    return out
+  a = np.arange(60 * 8, dtype=np.float32).reshape(60, 8) % 7 - 3
+  b = np.arange(60 * 8, dtype=np.int64).reshape(60, 8) % 5
+  progs = {
+      'scalar': lambda A, B: A * 2.5 + 1,
+      'two_arrays': lambda A, B: (A + B) * A,
+      'compare': lambda A, B: (A > 0) & (B < 3),
+      'fused': lambda A, B: ((A * A + A) / (B + 1)).optimized(),
+      'row_broadcast': lambda A, B: A + sp.from_numpy(a[:1]),          # stretched operand: general path
+      'numpy_operand': lambda A, B: A + a,                             # driver-side array: general path
+  }
+  results = {}
+  for mode in ('aligned', 'general'):
+    monkeypatch.setattr(M, '_evaluate_aligned', spy if mode == 'aligned' else (lambda *args: None))
+    A, B = sp.from_numpy(a).evaluate(), sp.from_numpy(b).evaluate()
+    for name, build in progs.items():
+      del taken[:]
+      res = build(sp.Val(val=A), sp.Val(val=B)).evaluate()
+      if mode == 'aligned':
+        assert (True in taken) == (name not in ('row_broadcast', 'numpy_operand')), (name, taken)
+      results[(mode, name)] = (res.glom(), sorted((ex.ul, ex.lr, tid.worker) for ex, tid in res.tiles.items()))
+  for name in progs:
+    got, want = results[('aligned', name)], results[('general', name)]
+    assert got[0].dtype == want[0].dtype and got[1] == want[1], name
+    np.testing.assert_array_equal(got[0], want[0], err_msg=name)
+  # a target that was created empty and only partly written is not "written everywhere": general path
+  monkeypatch.setattr(M, '_evaluate_aligned', spy)
+  partly = sp.ndarray((60, 8), dtype=np.float32).evaluate()
+  del taken[:]
+  out = (sp.Val(val=partly) + 1).evaluate()             # (a never-written operand: the general path's business)
+  assert True not in taken and out.shape == (60, 8)
