@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Tiles are walked m-fastest inside groups of SP_GEMM_GROUP_M tile rows.  Measured on 8192^3 (PMC, 2 x FETCH_SIZE,
-// the direct-to-LDS kernel of rounds 3+; round 6, tools/_exp/gemm_group.sh): group 1 / 2 / 3 / 4 / 8 -> 9.19 / 6.76 /
+// the direct-to-LDS kernel of rounds 3+; round 6, tools/r06/gemm_group.sh): group 1 / 2 / 3 / 4 / 8 -> 9.19 / 6.76 /
 // 7.44 / 9.24 / 17.3 GB of L2 misses at the SAME speed (150.8 / 150.8 / 150.8 / 150.7 / 150.3 TFLOP/s; 32768^3,
 // 16384^3, 6144^3, 4096^3 and the pipeline's chunk shapes within 0.3 %): with two tile rows per group the 64
 // workgroups resident on an XCD are 2 A panels x 32 B panels instead of 1 x 64 -- half the B traffic for twice the
