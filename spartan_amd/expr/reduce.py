@@ -59,7 +59,75 @@ def prelower(node, ctx):
     local_values = get_local_values(ex, children, node.child_to_var)
     local_values.update(extent=ex, axis=node.axis)
     done += bool(hook(node.op, local_values, ex, node.axis))
+  if done:
+    # the cut of the result array (metadata: extents per shape / hint / worker count are remembered, distarray._cuts)
+    try:
+      distarray.compute_extents(tuple(extent.shape_for_reduction(children[0].shape, node.axis)), node.tile_hint,
+                                ctx.num_workers)
+    except Exception:      # noqa: BLE001 -- whatever is wrong with the shape, _evaluate will say it
+      pass
   return done
+
+
+def _evaluate_aligned(node, ctx, values):
+  """ReduceExpr._evaluate for one process and operands that are dense, whole, written everywhere and cut the same
+  way (or scalars) -- expr/map._evaluate_aligned's case: the tiles' own tensors go to the backend's fused
+  map -> reduce, tile after tile in table order, and each partial is merged into the result array by the same
+  `update` the general path issues, in the same order.  One difference in ORDER of host work, none in results: the
+  kernels are launched first and the result array (metadata: its cut, its empty tiles) is made while they run,
+  instead of before the first launch.  Returns None, having done nothing, when the case does not apply."""
+  from ..array import tile
+  if ctx.world.size != 1 or ctx.pending is not None or not len(values):
+    return None
+  DA, LW = distarray.DistArrayImpl, distarray.LocalWrapper
+  lead = values[0]
+  if type(lead) is not DA or lead.sparse or lead.bad_tiles or not lead.tiles or len(lead.tiles) > 256:
+    return None
+  for v in values[1:]:
+    t = type(v)
+    if t is DA:
+      if v.sparse or v.bad_tiles or v.shape != lead.shape or (v.tiles is not lead.tiles and list(v.tiles) != list(lead.tiles)):
+        return None
+    elif t is LW:
+      if v._data.ndim != 0:
+        return None
+    else:
+      return None
+  blobs = ctx._blobs
+  ALL_SET, DENSE = tile.MASK_ALL_SET, tile.TYPE_DENSE
+  names, axis = node.child_to_var, node.axis
+  rows = []
+  for ex, tid in lead.tiles.items():
+    operands = {}
+    for v, name in zip(values, names):
+      if type(v) is LW:
+        operands[name] = v._scalar if v._scalar is not None else v._data
+        continue
+      t = blobs.get(v.tiles[ex])
+      if t is None or type(t.mask) is not int or t.mask != ALL_SET or t.type != DENSE or t.data is None or not t.shape:
+        return None
+      operands[name] = t.data
+    operands['extent'] = ex
+    operands['axis'] = axis
+    rows.append((ex, tid.worker, operands))
+  backend, op = ctx.backend, node.op
+  outer_worker = ctx.current_worker
+  partials = []
+  try:
+    for ex, worker, operands in rows:
+      ctx.current_worker = worker
+      local = backend.evaluate_reduce(op, operands, ex, axis)
+      dst = extent.index_for_reduction(ex, axis)
+      Assert.eq(int(local.size), dst.size)
+      partials.append((worker, dst, local.reshape(dst.shape)))
+    output = distarray.create(extent.shape_for_reduction(lead.shape, axis), node.dtype_fn(lead),
+                              reducer=node.accumulate_fn, tile_hint=node.tile_hint)
+    for worker, dst, local in partials:
+      ctx.current_worker = worker
+      output.update(dst, local, owned=True)
+  finally:
+    ctx.current_worker = outer_worker
+  return output
 
 
 class ReduceExpr(Expr):
@@ -85,6 +153,9 @@ class ReduceExpr(Expr):
                                                  self.children.pretty_str(), self.tile_hint)
 
   def _evaluate(self, ctx, deps):
+    fast = _evaluate_aligned(self, ctx, deps['children'])
+    if fast is not None:
+      return fast
     children = deps['children']
     children = broadcast.broadcast(list(children))
     largest = distarray.largest_value(children)

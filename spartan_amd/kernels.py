@@ -63,10 +63,18 @@ def map_fused(prog, inputs, out):
   return out
 
 
+_reduce_ws_bytes = {}
+
+
 def reduce(prog, inputs, red_op, outer, axis_len, inner, out):
   _require_device(out, *inputs)
   lib = _hip.lib()
-  need = lib.sp_reduce_workspace_bytes(prog.cls, outer, axis_len, inner)
+  key = (prog.cls, outer, axis_len, inner)
+  need = _reduce_ws_bytes.get(key)
+  if need is None:                         # (a pure function of the plan's geometry: asked once per shape)
+    if len(_reduce_ws_bytes) > 4096:
+      _reduce_ws_bytes.clear()
+    need = _reduce_ws_bytes[key] = lib.sp_reduce_workspace_bytes(prog.cls, outer, axis_len, inner)
   ws = _ws.get(need, out.device)
   ptrs = _hip.ptr_array([t.data_ptr() for t in inputs])
   check(lib.sp_reduce(C.byref(prog), ptrs, _hip.RED[red_op] if isinstance(red_op, str) else red_op,

@@ -237,3 +237,41 @@ def test_aligned_map_path_is_the_general_path(ctx, monkeypatch):
   del taken[:]
   out = (sp.Val(val=partly) + 1).evaluate()             # (a never-written operand: the general path's business)
   assert True not in taken and out.shape == (60, 8)
+
+
+def test_aligned_reduce_path_is_the_general_path(ctx, monkeypatch):
+  """expr/reduce._evaluate_aligned against the foreach_tile / _reduce_mapper path it short-cuts: same values, dtypes,
+  tile tables and placements for every axis, fused prologues with several aligned operands, and a tile hint."""
+  import importlib
+  R = importlib.import_module('spartan_amd.expr.reduce')
+  real = R._evaluate_aligned
+  taken = []
+
+  def spy(node, c, values):
+    out = real(node, c, values)
+    taken.append(out is not None)
+    return out
+  a = (np.arange(96 * 10, dtype=np.float32).reshape(96, 10) % 11 - 5) / 4
+  b = np.arange(96 * 10, dtype=np.int64).reshape(96, 10) % 3
+  progs = {}
+  for axis in (None, 0, 1):
+    progs['sum_%s' % axis] = (lambda axis: lambda A, B: sp.sum(A, axis))(axis)
+    progs['max_%s' % axis] = (lambda axis: lambda A, B: sp.max(A * 2 - B, axis).optimized())(axis)
+    progs['count_%s' % axis] = (lambda axis: lambda A, B: sp.count_nonzero(B, axis))(axis)
+    progs['fused_%s' % axis] = (lambda axis: lambda A, B: sp.sum((A - 0.5) * (A - 0.5) + B, axis).optimized())(axis)
+  progs['hinted'] = lambda A, B: sp.sum(A, 0, tile_hint=(5,))
+  progs['row_broadcast'] = lambda A, B: sp.sum(A + sp.from_numpy(a[:1]), 0).optimized()      # general path
+  results = {}
+  for mode in ('aligned', 'general'):
+    monkeypatch.setattr(R, '_evaluate_aligned', spy if mode == 'aligned' else (lambda *args: None))
+    A, B = sp.from_numpy(a).evaluate(), sp.from_numpy(b).evaluate()
+    for name, build in progs.items():
+      del taken[:]
+      res = build(sp.Val(val=A), sp.Val(val=B)).evaluate()
+      if mode == 'aligned':
+        assert (True in taken) == (name != 'row_broadcast'), (name, taken)
+      results[(mode, name)] = (res.glom(), sorted((ex.ul, ex.lr, tid.worker) for ex, tid in res.tiles.items()))
+  for name in progs:
+    got, want = results[('aligned', name)], results[('general', name)]
+    assert got[0].dtype == want[0].dtype and got[1] == want[1], name
+    np.testing.assert_array_equal(got[0], want[0], err_msg=name)
