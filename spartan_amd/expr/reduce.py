@@ -122,9 +122,17 @@ def _evaluate_aligned(node, ctx, values):
       partials.append((worker, dst, local.reshape(dst.shape)))
     output = distarray.create(extent.shape_for_reduction(lead.shape, axis), node.dtype_fn(lead),
                               reducer=node.accumulate_fn, tile_hint=node.tile_hint)
-    for worker, dst, local in partials:
-      ctx.current_worker = worker
-      output.update(dst, local, owned=True)
+    # (the partials join ONE batch, as the updates of a kernel do: what is whole-array and regular is then merged
+    #  whole -- UpdateBatch._merge_whole_partials -- instead of piece by piece)
+    batch = distarray.UpdateBatch(ctx)
+    ctx.pending = batch
+    try:
+      for worker, dst, local in partials:
+        ctx.current_worker = worker
+        output.update(dst, local, owned=True)
+    finally:
+      ctx.pending = None
+    batch.flush()
   finally:
     ctx.current_worker = outer_worker
   return output

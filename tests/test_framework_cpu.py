@@ -275,3 +275,42 @@ def test_aligned_reduce_path_is_the_general_path(ctx, monkeypatch):
     got, want = results[('aligned', name)], results[('general', name)]
     assert got[0].dtype == want[0].dtype and got[1] == want[1], name
     np.testing.assert_array_equal(got[0], want[0], err_msg=name)
+
+
+def test_whole_partials_merged_at_once_equal_the_piecewise_merges(ctx, monkeypatch):
+  """UpdateBatch._merge_whole_partials (one process, several workers: p whole-array partials into a fresh target cut
+  by rows, combined whole and handed to the target tiles as views) against the piece-by-piece merges it replaces:
+  bit-identical values, same dtypes and tile tables -- float sums (order matters), max, integer counts, a 2-D
+  target."""
+  from spartan_amd.array import distarray
+  taken = []
+  real = distarray.UpdateBatch._merge_whole_partials
+
+  def spy(self, array, items):
+    out = real(self, array, items)
+    taken.append(out)
+    return out
+  rng = np.random.RandomState(3)
+  a = (rng.rand(640, 24).astype(np.float32) - 0.5) * 1e3
+  progs = {
+      'sum0': lambda A: sp.sum(A, 0),
+      'max0': lambda A: sp.max(A, 0),
+      'count0': lambda A: sp.count_nonzero(A > 0, 0),
+      'fused0': lambda A: sp.sum(A * A + 1, 0).optimized(),
+      'sum1': lambda A: sp.sum(A, 1),                      # partials cover their own rows only: piecewise as before
+      'gram': lambda A: sp.dot(sp.transpose(A), A),         # (24, 24) target of a join
+  }
+  results = {}
+  for mode in ('whole', 'piecewise'):
+    monkeypatch.setattr(distarray.UpdateBatch, '_merge_whole_partials', spy if mode == 'whole' else (lambda self, array, items: False))
+    A = sp.from_numpy(a).evaluate()
+    for name, build in progs.items():
+      del taken[:]
+      res = build(sp.Val(val=A)).evaluate()
+      if mode == 'whole' and ctx.num_workers > 1 and name in ('sum0', 'max0', 'count0', 'fused0'):
+        assert True in taken, name
+      results[(mode, name)] = (res.glom(), sorted((ex.ul, ex.lr, tid.worker) for ex, tid in res.tiles.items()))
+  for name in progs:
+    got, want = results[('whole', name)], results[('piecewise', name)]
+    assert got[0].dtype == want[0].dtype and got[1] == want[1], name
+    np.testing.assert_array_equal(got[0], want[0], err_msg=name)
