@@ -360,11 +360,12 @@ class UpdateBatch(object):
     for ex in array.tiles:
       if ex.ul[1:] != (0,) * (nd - 1) or ex.lr[1:] != shape[1:]:
         return False                   # (not cut by rows alone: a tile's part of the result would not be contiguous)
+    on_device = getattr(be, 'name', '') == 'hip'
     for (_, worker, region, data, _) in items:
-      if region.shape != shape or region.ul != (0,) * nd or isinstance(data, (Absent, np.ndarray, np.generic)) \
+      if region.shape != shape or region.ul != (0,) * nd or isinstance(data, (Absent, np.generic)) \
               or tile.is_sparse_blob(data) or isinstance(data, (tile.MaskedBlob, tile.EmptyBlob)) \
-              or tuple(getattr(data, 'shape', ())) != shape:
-        return False
+              or tuple(getattr(data, 'shape', ())) != shape or (on_device and not hasattr(data, 'data_ptr')):
+        return False                   # (placeholders, scalars, masked / sparse blocks, a host array on the device backend)
     first = items[0]
     acc = be.astype(first[3], array.dtype)
     if not first[4] and be.same_memory(acc, first[3]):
