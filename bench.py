@@ -285,6 +285,26 @@ def dot_f64_section(ctx):
   return out
 
 
+def gemm_shapes_section(ctx):
+  """sp_gemm_f32 (through kernels.gemm_f32, the call spartan.dot makes per tile) on shapes other than the headline's:
+  the per-chunk GEMMs of the 8-GPU north-star pipeline (a 4096-row tile times 4096 / 8192-column chunks over the
+  whole K), and cubes whose 256 x 128 tiles do not fill the 512 resident workgroups (the balanced kernel + fix-up
+  launch, where its cost model picks it).  {shape: [TFLOP/s, fraction of the fp32 MFMA peak]}; HIP events."""
+  out = {}
+  for m, n, k in ((4096, 4096, 32768), (4096, 8192, 32768), (4096, 4096, 4096), (2048, 2048, 2048), (2304, 2304, 2304),
+                  (3072, 3072, 3072), (5000, 5000, 5000)):
+    a = device_uniform(type('E', (), {'shape': (m, k), 'ul': (0, 0)})(), -1.0, 1.0, SEED + 61)
+    b = device_uniform(type('E', (), {'shape': (k, n), 'ul': (0, 0)})(), -1.0, 1.0, SEED + 62)
+    c = D.empty((m, n), np.float32)
+    iters = max(3, min(200, int(4e12 / (2.0 * m * n * k))))
+    ms = event_time(lambda: kernels.gemm_f32(a, b, c), iters, warmup=3)
+    tf = 2.0 * m * n * k / ms / 1e9
+    out['%dx%dx%d' % (m, n, k)] = [round(tf, 1), round(tf / MFMA_F32_PEAK_TFLOPS, 3)]
+    del a, b, c
+    D.trim_pool()
+  return out
+
+
 def host_section(ctx):
   """Host time of the driver-side paths (what the device waits for between launches): microseconds until force()
   RETURNS on a 16 MiB tile (launches are asynchronous; the tile is small enough for the queue never to fill), and the
@@ -1070,7 +1090,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--size', type=int, default=0, help='matrix order (default: 8192 on one GPU, 32768 on several)')
   ap.add_argument('--no-extras', action='store_true', help='headline only: skip the HBM / workload / emulation / CPU sections')
-  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,dot_f64,host,lreg,kmeans,sparse,ksplit,tiles8,cpu; N > 1: hbm_dist,lreg_dist,kmeans_dist)')
+  ap.add_argument('--only', default='', help='comma-separated extras to run (northstar,hbm,dot_f64,gemm_shapes,host,lreg,kmeans,sparse,ksplit,tiles8,cpu; N > 1: hbm_dist,lreg_dist,kmeans_dist)')
   ap.add_argument('--deadline', type=int, default=1500, help='seconds the self-launched ranks of --gpus N > 1 may take')
   args = ap.parse_args()
 
@@ -1195,6 +1215,9 @@ def main():
       D.trim_pool()
     if want('dot_f64'):
       line['dot_f64'] = dot_f64_section(ctx)
+      D.trim_pool()
+    if want('gemm_shapes'):
+      line['roofline']['gemm_shapes'] = gemm_shapes_section(ctx)
       D.trim_pool()
     if want('host'):
       line['host'] = host_section(ctx)
