@@ -91,9 +91,45 @@ def check_statistics():
 
 
 def check_manipulation():
-  """tests/test_manipulation.py:12-36."""
+  """tests/test_manipulation.py:12-37."""
   x = spartan.arange((100, 100))
   np.testing.assert_array_equal(x.ravel().glom(), np.arange(100 * 100).astype(x.glom().dtype))
+  np_1d = RNG.randn(10)
+  sp_1d = spartan.from_numpy(np_1d)
+  np.testing.assert_array_equal(spartan.concatenate(sp_1d, sp_1d).glom(), np.concatenate((np_1d, np_1d)))
+  np_2d = np.arange(1024).reshape(32, 32)
+  sp_2d = spartan.from_numpy(np_2d)
+  np.testing.assert_array_equal(spartan.concatenate(sp_2d, sp_2d).glom(), np.concatenate((np_2d, np_2d)))
+  np.testing.assert_array_equal(spartan.concatenate(sp_2d, sp_2d, 1).glom(), np.concatenate((np_2d, np_2d), 1))
+  a, b = RNG.randn(15, 5), RNG.randn(15, 7)
+  np.testing.assert_array_equal(spartan.concatenate(spartan.from_numpy(a), spartan.from_numpy(b), 1).glom(),
+                                np.concatenate((a, b), 1))
+  with pytest.raises(ValueError):
+    spartan.concatenate(spartan.from_numpy(a), spartan.from_numpy(b), 0)
+
+
+def check_diagonals_and_bincount():
+  """tests/test_creation.py:67-81 (diagonal of square / tall / wide arrays), tests/test_autotiling.py:37-42 (diag of a
+  vector, then diagonal of the result), tests/test_statistics.py:10-14 (bincount)."""
+  for shape in ((2, 2), (15, 10), (16, 16), (10, 15)):
+    v = RNG.randn(*shape)
+    np.testing.assert_array_equal(spartan.diagonal(spartan.from_numpy(v)).glom(), np.diagonal(v))
+    np.testing.assert_array_equal(spartan.from_numpy(v).diagonal().glom(), np.diagonal(v))
+    np.testing.assert_array_equal(spartan.diag(spartan.from_numpy(v)).glom(), np.diag(v))
+  g = spartan.diag(spartan.ones((10,))) + spartan.ones((10, 10))
+  np.testing.assert_array_equal(spartan.diagonal(g).glom(), np.full(10, 2.0))
+  with pytest.raises(ValueError):
+    spartan.diagonal(spartan.ones((10,)))
+  with pytest.raises(NotImplementedError):
+    spartan.diag(spartan.ones((10,)), 1)
+  src = np.asarray([1, 1, 1, 2, 2, 5, 5, 10])
+  np.testing.assert_array_equal(spartan.bincount(spartan.from_numpy(src)).glom(), np.bincount(src))
+  with pytest.raises(AssertionError):
+    spartan.bincount(spartan.from_numpy(np.asarray([0, 1, 2])))          # statistics.py:127: assert minval > 0
+  v = np.abs(RNG.randn(12, 9)) + 0.1
+  np.testing.assert_allclose(spartan.normalize(spartan.from_numpy(v)).glom().sum(), 1.0, rtol=1e-12)
+  np.testing.assert_allclose(spartan.norm(spartan.from_numpy(v), 1), np.linalg.norm(v, 1), rtol=1e-12)
+  np.testing.assert_allclose(spartan.norm(spartan.from_numpy(v[:, 0])), np.linalg.norm(v[:, 0]), rtol=1e-12)
 
 
 def check_assign():
@@ -268,7 +304,7 @@ def check_array_indexing():
 
 
 CHECKS = [check_array_indexing, check_scan, check_reshape, check_example_runs, check_slices_and_user_functions, check_numpy_interface, check_elementwise_broadcast, check_creation, check_newaxis_and_int_indices,
-          check_statistics, check_manipulation, check_assign, check_write]
+          check_statistics, check_manipulation, check_diagonals_and_bincount, check_assign, check_write]
 
 
 @pytest.mark.parametrize('workers', [1, 4])
@@ -294,9 +330,9 @@ def test_reference_suite_hip(check, workers):
 
 
 def test_every_name_the_reference_exports_exists():
-  """spartan/expr/__init__.py:26-65 (the flat builder namespace), listed here so the check needs no reference tree;
-  without the manipulation / statistics helpers that are outside the tile path (diagonal, diag, diagflat,
-  concatenate, bincount, normalize, norm)."""
+  """spartan/expr/__init__.py:26-65 (the flat builder namespace), all of it (round 6 added diagonal, diag, diagflat,
+  concatenate, bincount, normalize, norm), listed here so the check needs no reference tree; and the ndarray-style
+  methods it binds on Expr (:66-92; flat / outer / nonzero are bound to None there)."""
   names = '''astype tocoo size empty sparse_empty empty_like zeros zeros_like ones ones_like eye identity full full_like
   arange sparse_diagonal all any equal not_equal greater greater_equal less less_equal
   logical_and logical_or logical_xor ravel add sub multiply divide true_divide floor_divide reciprocal
@@ -305,9 +341,12 @@ def test_every_name_the_reference_exports_exists():
   retile dot save load pickle unpickle partial_load partial_unpickle Expr evaluate optimized_dag eager lazify as_array
   glom NotShapeable newaxis broadcast checkpoint map map2 map_with_location ndarray outer optimize region_map reshape
   reduce sort argsort argpartition partition shuffle scan stencil maxpool _convolve tile_operation transpose write
-  from_numpy from_file from_file_parallel'''.split()
+  from_numpy from_file from_file_parallel diagonal diag diagflat concatenate bincount normalize norm'''.split()
   import spartan_amd
   missing = [n for n in names if not hasattr(spartan_amd, n)]
   assert not missing, missing
   from spartan_amd import expr
   assert not [n for n in names if not n.startswith('_') and not hasattr(expr, n)]
+  methods = '''all any argmax argmin argpartition argsort astype diagonal dot fill flat flatten outer max mean min ndim
+  nonzero partition prod ravel reshape std sum transpose T'''.split()
+  assert not [m for m in methods if not hasattr(spartan_amd.Expr, m)]
