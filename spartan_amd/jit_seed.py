@@ -5,8 +5,9 @@ compiles its specialisation in the background (csrc/sp_jit.hip) -- on a fresh ma
 every such program.  `__graft_entry__.build()` calls `seed()`: the expressions the workloads are known to force are
 pushed through the REAL host path (builders -> optimiser -> lowering -> sp_map_fused / sp_reduce) with the library in
 seed mode (sp_jit_seed_begin): every specialisation a launch asks for is compiled on the spot and written next to
-the library instead of being loaded.  No GPU is needed: tiles are HostStorage stand-ins, the launches themselves fail
-and are ignored here.  At run time a code object found in jit_seed is loaded instead of compiled, so those programs
+the library instead of being loaded.  No GPU is needed: without one the tiles are HostStorage stand-ins and the launches
+themselves fail and are ignored here; on a machine WITH a GPU the tiles are ordinary device tiles (a host pointer handed
+to a launch that really runs is a memory fault, which aborts the process) and the launches simply run.  At run time a code object found in jit_seed is loaded instead of compiled, so those programs
 start specialised from their first launch; the file name carries a hash of the kernel headers' contents, so stale
 seeds are never used.
 """
@@ -42,12 +43,15 @@ class _SeedBackend(HipBackend):
 
 @contextlib.contextmanager
 def _seed_mode(directory=None):
-  """Launch errors ignored, tiles in host memory, library in seed mode."""
+  """Launch errors ignored, tiles in host memory unless a GPU would really run the launches, library in seed mode."""
   lib = _hip.lib()
+  count = C.c_int(0)
+  have_gpu = lib.sp_device_count(C.byref(count)) == 0 and count.value > 0
   saved = [(m, m.check) for m in (_hip, kernels, devarray, sparse)]
   for m, _ in saved:
     m.check = lambda rc: None
-  devarray._storage_cls[0] = devarray.HostStorage
+  if not have_gpu:
+    devarray._storage_cls[0] = devarray.HostStorage
   # code objects of earlier builds (other source hashes in their names) would only be loaded for nothing
   target = directory or os.path.join(os.path.dirname(os.path.abspath(_hip.__file__)), 'csrc', 'jit_seed')
   if os.path.isdir(target):
