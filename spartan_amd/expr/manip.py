@@ -15,6 +15,9 @@ HIP backend nothing of a tile visits the host.  The reference's quirks are kept 
     axis=1 only the first ROW by the sum at its row offset (statistics.py:157-160) -- axis=None is the useful
     case.  The reference divides the fetched tile IN PLACE (which also rewrites the source array's tile when the
     fetch aliases it); here the source is never written: the result is a new tile with the same values;
+  * concatenate of two VECTORS joins tile [lo, hi) of `a` with the slab [lo, hi) of `b` (map2 with axes (0, 0),
+    manipulation.py:44-57, 78-80): it is np.concatenate for vectors of one length only -- a longer `b` loses its end
+    (the rest of the result stays unwritten), a shorter one is an out-of-bounds fetch, here as there;
   * diagflat's blocks become float64 whenever the array has more than one tile (np.zeros pads, creation.py:247-250).
 """
 import builtins
