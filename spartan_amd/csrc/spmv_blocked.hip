@@ -25,23 +25,26 @@
 namespace {
 
 // Geometry (round 4): ONE workgroup of 1024 lanes per CU owning up to 4096 rows.  A staged slice then serves twice
-// the entries it served with two 512-lane workgroups of 2048 rows per CU (round 3: -DBSP_WIDE=0), so the slice
-// copies -- every row block of a site pulls the site's whole x through the L2 -- and the barriers around them halve
-// per entry: 42.2 -> 37.4 us on the 900 000-page tile.  (Timed with the slice loads / the run sums removed:
-// 32.3 / 29.7 us, both 23.9 us: what is left is the serial chunk pipeline, not bytes.)  Entry loads and gathers
-// without conditions (exact s_waitcnt counts, see the kernel) and the row of a direct entry packed into its key:
-// 35.8 us.
-#ifndef BSP_WIDE
-#define BSP_WIDE 1
-#endif
-constexpr int BSP_THREADS = BSP_WIDE ? 1024 : 512;
-constexpr int BSP_WGS_PER_CU = BSP_WIDE ? 1 : 2;
+// the entries it served with two 512-lane workgroups of 2048 rows per CU (round 3), so the slice copies -- every row
+// block of a site pulls the site's whole x through the L2 -- and the barriers around them halve per entry: 42.2 ->
+// 37.4 us on the 900 000-page tile; the row of a direct entry packed into its key: 35.8 us.
+// Round 6: the loop's loads really run ahead now (see the kernel: three entry sets, two gather sets and two slice sets
+// taking turns, nothing moved between them; two LDS slice buffers, so that a segment's slice is stored while the chunk
+// before is multiplied and needs no barrier of its own).  Timed with parts removed (-DBSP_ABLATE, one box, us):
+//   whole kernel 33.4 | no chunk loop at all 7.7 | loop without products and run sums 23.7 (27.1 before this round's
+//   pipeline) | ... and without its barriers 22.3 | loop without barriers only 28.9
+// i.e. 7.7 fixed + 16 for the loop's loads (72 MB of entries, 113 MB of slices through the L2, the direct gathers:
+// ~60 % of what a CU's 64 B/clk vector-memory path moves) + 9.7 for products and run sums, which do NOT overlap the
+// loads: all sixteen waves of a CU walk the same phase between the same barriers.  35.2 -> 32.2 us with the requests
+// issued around the run sums.
+constexpr int BSP_THREADS = 1024;
+constexpr int BSP_WGS_PER_CU = 1;
 constexpr int BSP_CAP = 4 * BSP_THREADS;  // products per pass: 4 per lane
 constexpr int BSP_PER = BSP_CAP / BSP_THREADS;
 constexpr int BSP_MAXSEG = 64;
 constexpr int BSP_XS_BYTES = 44 * 1024;
 constexpr int BSP_S = BSP_XS_BYTES / 4;   // columns per slice
-constexpr int BSP_MAX_RB = BSP_WIDE ? 4096 : 2048;   // rows per block (16-bit row ids; 4 B of accumulator each)
+constexpr int BSP_MAX_RB = 4096;         // rows per block (16-bit row ids; 4 B of accumulator each)
 constexpr int BSP_STAGE_MIN = 768;        // a 44 KB slice is 352 lines: staging pays from about twice as many gathers
 constexpr int BSP_MAX_SLICES = 16384;
 // direct segments: with at most 2^20 columns the row-in-block (12 bits) rides in the key above the column, and the
@@ -220,6 +223,9 @@ __global__ __launch_bounds__(BSP_THREADS) void sp_bsp_build_kernel(const int64_t
 }
 
 typedef float bsp_f4 __attribute__((ext_vector_type(4)));
+#ifndef BSP_ABLATE
+#define BSP_ABLATE 0    // timing-only builds (wrong results): 1 no chunk loop, 2 no run sums, 4 no products, 8 no barriers in the loop
+#endif
 
 // (second launch bound: waves per SIMD -- two workgroups of 8 waves per CU)
 template <bool PACKED>
@@ -232,8 +238,8 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
                                                                      const float* __restrict__ x, float* __restrict__ y,
                                                                      int64_t ldy, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  float* xs = (float*)lds;                                  // [BSP_S]
-  float* acc = xs + BSP_S;                                  // [BSP_MAX_RB]
+  float* xs = (float*)lds;                                  // [2][BSP_S]: the slice in use and the one before / after it
+  float* acc = xs + 2 * BSP_S;                              // [BSP_MAX_RB]
   float* prod = acc + BSP_MAX_RB + 4;                       // [2][BSP_CAP]   (acc[BSP_MAX_RB]: the spare slot of the run sums)
   uint16_t* rid = (uint16_t*)(prod + 2 * BSP_CAP);          // [2][BSP_CAP]
   __shared__ BspSeg segs[BSP_MAXSEG];
@@ -244,10 +250,13 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
   const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)b * rb, r1 = r0 + rb < m ? r0 + rb : m;
   const int nrows = (int)(r1 - r0);
+  // (the whole row of the segment table, whatever the block's count: one round trip for the count, the table and
+  //  the block's first entry together instead of two)
+  static_assert(BSP_MAXSEG * 4 <= BSP_THREADS, "one dword of the segment table per lane");
+  if (tid < BSP_MAXSEG * 4) ((int*)segs)[tid] = ((const int*)(segtab + (int64_t)b * BSP_MAXSEG))[tid];
   const int n = nseg[b];
-  for (int i = tid; i < n * 4; i += BSP_THREADS) ((int*)segs)[i] = ((const int*)(segtab + (int64_t)b * BSP_MAXSEG))[i];
-  for (int i = tid; i < nrows; i += BSP_THREADS) acc[i] = 0.f;
   const int64_t e0 = indptr[r0];
+  for (int i = tid; i < nrows; i += BSP_THREADS) acc[i] = 0.f;
   __syncthreads();
 
   // the chunk sequence: segment by segment, BSP_CAP entries at a time; entries are stored in that order from e0 on.
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
   struct Chunk {
     int seg, cnt, staged, before;      // before: entries of the block in the segments before `seg`
     int64_t e;
+    bool fresh;                        // first chunk of a staged segment: the one that needs a new slice of x
   };
   auto next_chunk = [&](const Chunk& c) {       // the chunk after c (seg == n: none)
     Chunk o;
@@ -273,6 +283,7 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
       o.cnt = left < BSP_CAP ? left : BSP_CAP;
       o.staged = segs[o.seg].staged;
     }
+    o.fresh = o.staged && used == o.before;
     return o;
   };
   Chunk c0;
@@ -281,23 +292,36 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
   c0.e = e0;
   c0.cnt = n > 0 ? (segs[0].count < BSP_CAP ? segs[0].count : BSP_CAP) : 0;
   c0.staged = n > 0 ? segs[0].staged : 0;
+  c0.fresh = c0.staged != 0;
 
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
   typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
   static_assert(BSP_PER == 4, "one 16-byte load per lane and chunk");
   const int i0 = tid * BSP_PER;
-  u32x4 kA = {0, 0, 0, 0}, kB = {0, 0, 0, 0};      // A: being gathered (next chunk), B: being loaded (the one after)
-  bsp_f4 vA = {0.f, 0.f, 0.f, 0.f}, vB = {0.f, 0.f, 0.f, 0.f}, xA = {0.f, 0.f, 0.f, 0.f};
-  u16x4 rA = {0, 0, 0, 0}, rB = {0, 0, 0, 0};
+  // THREE register sets of entries (keys, values, rows) and TWO of direct gathers that take turns: chunk j is
+  // multiplied from set j % 3 and gather set j % 2 while the gathers of chunk j + 2 and the entries of chunk j + 3 are
+  // requested -- every load has at least one whole iteration (a barrier, a pass over LDS) between its request and
+  // its first use.  (Round 4's pipeline asked for the gathers of chunk j + 1 while chunk j was multiplied and rotated
+  // the sets with register moves at the loop's latch: the moves waited with vmcnt(0) for the loads just issued, and
+  // without them -- two sets taking turns, round 6 -- the wait for the gathers, requested one short phase earlier,
+  // took their place: one memory latency per chunk either way, 36 us of which 24 were that.)
+  struct Entries {
+    u32x4 k;
+    bsp_f4 v;
+    u16x4 r;
+  };
+  Entries E0 = {{0, 0, 0, 0}, {0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0}}, E1 = E0, E2 = E0;
+  bsp_f4 X0 = {0.f, 0.f, 0.f, 0.f}, X1 = X0;
   // EVERY load of the loop below is issued by every lane in every iteration, with its address clamped into valid
   // memory where the lane has nothing to fetch -- no load sits under a condition.  That is what lets the compiler
   // count the loads in flight and wait for exactly the ones an instruction needs (s_waitcnt vmcnt(N > 0)): with
-  // conditional loads (round 3) it could not, every wait was vmcnt(0), and the entries "prefetched two chunks ahead"
-  // and the slice "requested one segment ahead" were in fact waited for as soon as they were issued -- each of the
-  // ~11 iterations of a row block paid a full memory latency (the 24 us floor of the round-4 ablation).
+  // conditional loads (round 3) it could not, and every wait was vmcnt(0).
   const int64_t e_first = e0;
-  auto load_entries = [&](const Chunk& c, u32x4& kk, bsp_f4& vv, u16x4& rr) {
+  auto load_entries = [&](const Chunk& c, Entries& E) {
+    u32x4& kk = E.k;
+    bsp_f4& vv = E.v;
+    u16x4& rr = E.r;
     // (a lane whose entries start inside the chunk loads all four: what lies behind the chunk's end is the next
     // chunk's, or the padding of the plan arrays, and is never used; a lane past the chunk re-reads its start)
     const int64_t at = c.seg < n ? c.e + (i0 < c.cnt ? i0 : 0) : e_first;
@@ -316,80 +340,94 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
       xx[u] = x[(live && i0 + u < c.cnt) ? col : 0u];
     }
   };
-  // slices of x travel global -> registers -> LDS, requested one staged segment ahead (two ahead, 48 more registers,
-  // measured slower: 44.5 vs 40.6 us).  16-byte loads; a vector past the slice's end reads the start of x instead
-  // (the plan stages a narrower last slice only when k is a multiple of 4: no vector straddles the end of x).
+  // slices of x travel global -> registers -> LDS, requested while the chunk before the segment's first is being
+  // multiplied and stored into the OTHER of two LDS buffers when that chunk comes up.  16-byte loads; a vector past
+  // the slice's end -- every vector, when no slice is due (`real` false) -- reads the start of x instead: one line
+  // per wave (the plan stages a narrower last slice only when k is a multiple of 4: no vector straddles the end of x).
   bsp_f4 xr0[BSP_XV_N];
-  auto prefetch_slice = [&](int s, bsp_f4* xr) {
-    const int lo = s < n ? segs[s].col_lo : 0, w = s < n ? segs[s].width : 4;
+  auto prefetch_slice = [&](int s, bool real, bsp_f4* xr) {
+    const int lo = real ? segs[s].col_lo : 0, w = real ? segs[s].width : 0;
     const float* __restrict__ xl = x + lo;
 #pragma unroll
     for (int u = 0; u < BSP_XV_N; ++u) {
       const int i = (u * BSP_THREADS + tid) * 4;
-      xr[u] = i < w ? *(const bsp_f4*)(xl + i) : *(const bsp_f4*)x;
+      xr[u] = *(const bsp_f4*)(i < w ? xl + i : x);
     }
   };
-  auto next_staged = [&](int s) {       // first staged segment after s (n: none)
-    for (++s; s < n; ++s)
-      if (segs[s].staged) return s;
-    return n;
-  };
 
-  // pipeline fill: chunk 0 in A (with its gathers), chunk 1 in B, the first staged slice in registers
-  Chunk cur = c0, nxt = next_chunk(c0);
-  load_entries(cur, kA, vA, rA);
-  load_entries(nxt, kB, vB, rB);
-  gather_direct(cur, kA, xA);
-  int slice_in_lds = -1;
-  int ahead0 = next_staged(-1);     // the segment whose slice is in xr0
-  prefetch_slice(ahead0, xr0);
+  // pipeline fill: the slice of chunk 0 into LDS, chunks 0 .. 2 into the three sets, the gathers of chunks 0 and 1,
+  // the slices chunks 1 and 2 may start into the two slice sets
+  Chunk cur = c0, c1 = next_chunk(c0), c2 = next_chunk(c1), c3 = next_chunk(c2);
+  int par = 0;
+  bsp_f4 xr1[BSP_XV_N];
+  load_entries(cur, E0);
+  load_entries(c1, E1);
+  load_entries(c2, E2);
+  prefetch_slice(cur.seg, cur.fresh, xr0);
+  gather_direct(cur, E0.k, X0);
+  gather_direct(c1, E1.k, X1);
+  if (cur.fresh) {
+#pragma unroll
+    for (int u = 0; u < BSP_XV_N; ++u) {
+      const int i = (u * BSP_THREADS + tid) * 4;
+      if (i < BSP_S) *(bsp_f4*)(xs + i) = xr0[u];
+    }
+  }
+  prefetch_slice(c1.seg, c1.fresh, xr1);
+  prefetch_slice(c2.seg, c2.fresh, xr0);
+  __syncthreads();
   int buf = 0;
-  while (cur.seg < n) {
-    if (cur.staged && slice_in_lds != cur.seg) {
-      // (xr0 holds this segment's slice: staged segments are met in order; every lane is past the barrier that
-      // followed the last products read from the previous slice)
+  // One chunk.  A: the set with the chunk's entries (reloaded with chunk j + 3's), C: the set with chunk j + 2's (the
+  // keys of its gathers), X: the chunk's direct gathers (reloaded with chunk j + 2's), XR: the slice chunk j + 1 may
+  // start (stored to LDS here, reloaded with the one chunk j + 3 may start).  Every global load of the loop is issued
+  // in every iteration, in the order slice / gathers / entries (a slice request that is not due reads x[0..3]), so
+  // the waits the compiler places are counts of younger loads -- and every load is requested two or three chunks
+  // before its first use.  products | slice store | barrier | slice request | run sums | gathers, entries.
+  auto step = [&](Entries& A, const Entries& C, bsp_f4& X, bsp_f4* XR) {
+    // (a fresh chunk's slice was stored into the other buffer while the chunk before was multiplied, ahead of that
+    //  iteration's barrier; chunk 0's by the fill above, into buffer 0)
+    if (cur.fresh && cur.e != e0) par ^= 1;
+    const float* xc = xs + par * BSP_S;
+    float* pb = prod + buf * BSP_CAP;
+    uint16_t* rbuf = rid + buf * BSP_CAP;
+    bsp_f4 p = {0.f, 0.f, 0.f, 0.f};
+    u16x4 r = {0, 0, 0, 0};
+    if (BSP_ABLATE & 4) {
+      asm volatile("" ::"v"(A.k), "v"(A.v), "v"(X), "v"(A.r));
+    } else if (i0 < cur.cnt) {
+#pragma unroll
+      for (int u = 0; u < BSP_PER; ++u) {
+        const float xv = cur.staged ? xc[A.k[u] & 0xffffu] : X[u];
+        p[u] = A.v[u] * xv;
+        r[u] = cur.staged ? (uint16_t)(A.k[u] >> 16) : (PACKED ? (uint16_t)(A.k[u] >> BSP_PACK_SHIFT) : A.r[u]);
+      }
+      *(bsp_f4*)(pb + i0) = p;       // (for the lanes before this one: a run of theirs may go on in these entries)
+      *(u16x4*)(rbuf + i0) = r;
+    }
+    // the slice the NEXT chunk starts (requested two iterations ago) goes to the buffer nobody reads: the slice before
+    // the current one was last read before the barrier of the iteration that switched away from it
+    if (c1.fresh) {
+      float* xw = xs + (par ^ 1) * BSP_S;
 #pragma unroll
       for (int u = 0; u < BSP_XV_N; ++u) {
         const int i = (u * BSP_THREADS + tid) * 4;
-        if (i < BSP_S) *(bsp_f4*)(xs + i) = xr0[u];
+        if (i < BSP_S) *(bsp_f4*)(xw + i) = XR[u];
       }
-      slice_in_lds = cur.seg;
-      __syncthreads();
-      // (requested only when a slice was taken: asking for the same slice again in every iteration, to have this
-      // load unconditional like the others, measured slower -- 37.1 against 35.8 us)
-      ahead0 = next_staged(ahead0);
-      prefetch_slice(ahead0, xr0);
     }
-    // products of the current chunk (entries and direct gathers were requested one / two chunks ago)
-    float* pb = prod + buf * BSP_CAP;
-    uint16_t* rbuf = rid + buf * BSP_CAP;
-    if (i0 < cur.cnt) {
-      bsp_f4 p;
-      u16x4 r;
-#pragma unroll
-      for (int u = 0; u < BSP_PER; ++u) {
-        const float xv = cur.staged ? xs[kA[u] & 0xffffu] : xA[u];
-        p[u] = vA[u] * xv;
-        r[u] = cur.staged ? (uint16_t)(kA[u] >> 16) : (PACKED ? (uint16_t)(kA[u] >> BSP_PACK_SHIFT) : rA[u]);
-      }
-      *(bsp_f4*)(pb + i0) = p;
-      *(u16x4*)(rbuf + i0) = r;
-    }
-    // rotate the pipeline: B -> A (+ its gathers), the chunk after that -> B
     const Chunk done = cur;
-    cur = nxt;
-    nxt = next_chunk(cur);
-    kA = kB;
-    vA = vB;
-    rA = rB;
-    gather_direct(cur, kA, xA);
-    load_entries(nxt, kB, vB, rB);
-    __syncthreads();                   // products of `done` are in LDS (and everybody is past the runs of the chunk before)
+    cur = c1;
+    c1 = c2;
+    c2 = c3;
+    c3 = next_chunk(c3);
+    if (!(BSP_ABLATE & 8)) __syncthreads();
+    // the iteration's requests, around the run sums rather than in one burst ahead of the barrier (33.0 -> 32.2 us:
+    // the vector-memory path works on the slice while the waves are busy in LDS)
+    prefetch_slice(c2.seg, c2.fresh, XR);
+    __builtin_amdgcn_sched_barrier(0);                   // products of `done` (and the next slice) are in LDS; everybody is past the runs before
     // Runs of equal rows: the lane holding a run's first entry adds the run, in order, to the row's accumulator --
     // its own entries from registers, what continues in later lanes' entries from LDS.
-    if (i0 < done.cnt) {
-      const bsp_f4 p = *(const bsp_f4*)(pb + i0);
-      const u16x4 r = *(const u16x4*)(rbuf + i0);
+    if (!(BSP_ABLATE & 2) && i0 < done.cnt) {
+      // (the lane's own products and rows are still in its registers; LDS holds them for the other lanes)
       const int nvalid = done.cnt - i0;                       // >= 1; entries u >= nvalid are not this chunk's
       const unsigned prev = i0 == 0 ? 0xffffffffu : (unsigned)rbuf[i0 - 1];
       // straight-line over the lane's four entries: selects instead of branches (a row's accumulator is read for
@@ -420,7 +458,26 @@ __global__ __launch_bounds__(BSP_THREADS, 4 / BSP_WGS_PER_CU * BSP_WGS_PER_CU) v
         acc[row] = sum;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    gather_direct(c1, C.k, X);
+    load_entries(c2, A);
     buf ^= 1;
+  };
+  // chunk j: entries in set j % 3, gathers in set j % 2; the six combinations in turn, no register ever moves
+  for (;;) {
+    if (BSP_ABLATE & 1) break;
+    if (!(cur.seg < n)) break;
+    step(E0, E2, X0, xr1);
+    if (!(cur.seg < n)) break;
+    step(E1, E0, X1, xr0);
+    if (!(cur.seg < n)) break;
+    step(E2, E1, X0, xr1);
+    if (!(cur.seg < n)) break;
+    step(E0, E2, X1, xr0);
+    if (!(cur.seg < n)) break;
+    step(E1, E0, X0, xr1);
+    if (!(cur.seg < n)) break;
+    step(E2, E1, X1, xr0);
   }
   __syncthreads();
   for (int i = tid; i < nrows; i += BSP_THREADS) {
@@ -470,7 +527,8 @@ extern "C" int sp_csr_spmv_blocked(int32_t dtype, int64_t m, int64_t k, int64_t 
   if (((uintptr_t)d_x & 15) != 0) SP_FAIL("sp_csr_spmv_blocked: x must be 16-byte aligned");
   if (ldy < 1) SP_FAIL("sp_csr_spmv_blocked: bad ldy");
   const char* P = (const char*)d_plan;
-  constexpr int lds_bytes = BSP_XS_BYTES + (BSP_MAX_RB + 4) * 4 + 2 * BSP_CAP * 4 + 2 * BSP_CAP * 2;
+  constexpr int lds_bytes = 2 * BSP_XS_BYTES + (BSP_MAX_RB + 4) * 4 + 2 * BSP_CAP * 4 + 2 * BSP_CAP * 2;
+  static_assert(lds_bytes + BSP_MAXSEG * (int)sizeof(BspSeg) <= 160 * 1024, "LDS budget of a CU");
   static bool attr_set = false;
   if (!attr_set) {
     SP_HIP(hipFuncSetAttribute((const void*)sp_bsp_spmv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
