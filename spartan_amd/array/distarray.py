@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-from . import extent, tile
+from . import extent, placement, tile
 from .. import context
 from ..context import LocalKernelResult, TileId
 from ..util import Assert
@@ -1007,7 +1007,6 @@ DistArrayImpl._invoke_mapper = _invoke_default
 def create(shape, dtype=float, sharder=None, reducer=None, tile_hint=None, sparse=False):
   """A new, empty array: cut into tiles (compute_extents), each tile given to a worker by the tile-assignment
   policy (array/placement.py; reference distarray.py:425-487)."""
-  from . import placement
   ctx = context.get()
   dtype = np.dtype(dtype)
   shape = tuple(int(s) for s in shape)

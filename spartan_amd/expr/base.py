@@ -199,9 +199,14 @@ class Expr(object):
     raise Exception('Expressions are read-only.')
 
 
+_map_builder = []        # expr.map.map (that module imports this one: bound on first use, not per call)
+
+
 def _elementwise(fn, *operands):
-  from .map import map
-  return map(operands, fn)
+  if not _map_builder:
+    from .map import map
+    _map_builder.append(map)
+  return _map_builder[0](operands, fn)
 
 
 def _install_operators():
@@ -332,12 +337,17 @@ class DictExpr(CollectionExpr):
     return '{ %s } ' % ',\n'.join('%s : %r' % kv for kv in self.vals.items())
 
 
+_optimize_fn = []        # expr.optimize.optimize, bound on first use (that module imports this one)
+
+
 # ---- module functions ----------------------------------------------------------------------------------------
 def optimized_dag(node):
   if not isinstance(node, Expr):
     raise TypeError('optimized_dag of %r' % type(node))
-  from .optimize import optimize
-  return optimize(node)
+  if not _optimize_fn:
+    from .optimize import optimize
+    _optimize_fn.append(optimize)
+  return _optimize_fn[0](node)
 
 
 def evaluate(node):

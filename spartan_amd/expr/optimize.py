@@ -23,6 +23,7 @@ import numpy as np
 
 from .base import AsArray, Expr, ListExpr, NotShapeable, Val, expr_like, lazify
 from .local import LocalInput, LocalMapLocationExpr, LocalReduceExpr, make_var
+from . import plan
 from .map import MapExpr
 from .ndarray import NdArrayExpr
 from .reduce import ReduceExpr
@@ -323,7 +324,6 @@ def optimize(dag):
     return dag
   if not FLAGS['opt_plan_cache']:
     return _run_passes(dag)
-  from . import plan
   first = plan.stats['misses']
   out = plan.optimized(dag, tuple(FLAGS.values()), _run_passes)
   if plan.stats['misses'] != first and FLAGS['opt_prelower']:

@@ -27,7 +27,7 @@ import collections
 import numpy as np
 
 from . import base
-from .base import AsArray, CollectionExpr, DictExpr, Expr, Val, eval_cache
+from .base import AsArray, CollectionExpr, DictExpr, Expr, ListExpr, Val, eval_cache
 from .local import FnCallExpr, LocalExpr, LocalInput
 from .. import context
 from ..array import distarray, extent
@@ -37,6 +37,8 @@ _plans = collections.OrderedDict()        # key -> Plan
 stats = {'hits': 0, 'misses': 0, 'unplannable': 0}
 
 _SIMPLE = (type(None), bool, int, float, str, bytes, complex)
+_keep_apart_ref = []
+_MapExpr = [None]                          # expr.map.MapExpr (map imports this module's users: set on first use)
 _layouts = {}                              # tile table -> small int
 
 
@@ -118,6 +120,8 @@ class _Walk(object):
       return ('@', pos)
     seen[id(e)] = len(seen)
     t = type(e)
+    if t is _MapExpr[0]:
+      return self.map_node(e)
     if t is Val or t is AsArray or isinstance(e, (Val, AsArray)):
       self.leaves.append(e)
       return ('V' if isinstance(e, Val) else 'A', _describe_value(e.val, self.pins), self.alias(e.val))
@@ -131,6 +135,41 @@ class _Walk(object):
       return (t, tuple([field(v) for v in e.vals]))
     d = e.__dict__
     return (t, tuple([field(d[name]) for name in e.members]), bool(e.needs_cache))
+
+  def map_node(self, e):
+    """node() for a MapExpr (already entered into `seen`): the nodes a driver loop's operators build -- a list of
+    children, one name per child, an operator call over those names without keywords -- described in ONE pass, with
+    the bookkeeping of the general walk in the general walk's order (children list and children first, then the
+    names, then the operator's variables); anything else about the node goes the general way."""
+    values = eval_cache._values
+    if e.expr_id in values:
+      raise Unplannable('a node already has a value')
+    self.ids.append(e.expr_id)
+    kids, names, op = e.children, e.child_to_var, e.op
+    seen = self.seen
+    if (type(kids) is ListExpr and type(names) is list and isinstance(op, FnCallExpr) and not op.kw
+            and id(kids) not in seen and kids.expr_id not in values):
+      deps = op.deps
+      plain = True
+      for d in deps:
+        if type(d) is not LocalInput:
+          plain = False
+          break
+      for n in names:
+        if type(n) is not str:
+          plain = False
+          break
+      if plain:
+        seen[id(kids)] = len(seen)
+        self.ids.append(kids.expr_id)
+        node, var = self.node, self.var
+        ck = tuple([node(c) for c in kids.vals])
+        nk = tuple([var(n) if n.startswith('key_') else n for n in names])
+        self.pins.append(op.fn)
+        dk = tuple([var(d.idx) if d.idx.startswith('key_') else d.idx for d in deps])
+        return ('M!', type(op), id(op.fn), ck, nk, dk, bool(e.needs_cache))
+    field, d = self.field, e.__dict__
+    return (type(e), tuple([field(d[name]) for name in e.members]), bool(e.needs_cache))
 
   def local(self, op):
     if type(op) is LocalInput:
@@ -208,7 +247,12 @@ _SIMPLE_SET = frozenset(_SIMPLE)
 
 def signature(dag, flags):
   """(key, leaves, ids, pins) of the DAG as built, or None when it cannot be planned."""
-  from .optimize import _keep_apart
+  if _MapExpr[0] is None:
+    from .map import MapExpr
+    from .optimize import _keep_apart as keep
+    _MapExpr[0] = MapExpr
+    _keep_apart_ref.append(keep)         # (the set object itself: optimize.py only ever mutates it)
+  _keep_apart = _keep_apart_ref[0]
   w = _Walk()
   try:
     body = w.node(dag)

@@ -7,8 +7,9 @@ import collections
 from . import base, broadcast
 from .base import Expr, ListExpr
 from .local import LocalInput, LocalReduceExpr, make_var
+from .map import get_local_values
 from .. import context
-from ..array import distarray, extent
+from ..array import distarray, extent, tile
 from ..context import LocalKernelResult
 from ..util import Assert
 
@@ -16,7 +17,6 @@ from ..util import Assert
 def _reduce_mapper(ex, children, child_to_var, op, axis, output):
   """reduce.py:21-70."""
   ctx = context.get()
-  from .map import get_local_values
   local_values = get_local_values(ex, children, child_to_var)
   local_values.update(extent=ex, axis=axis)
   dst_extent = extent.index_for_reduction(ex, axis)
@@ -35,7 +35,6 @@ def prelower(node, ctx):
   """expr/map.prelower for a ReduceExpr whose inputs exist already: the fused map -> reduce program of its local
   reduction is handed to the backend before the first evaluation (`prelower_reduce`: lowered and remembered, not
   run), one tile per distinct tile shape.  The walk is the prelude of ReduceExpr._evaluate and _reduce_mapper."""
-  from .map import get_local_values
   hook = getattr(ctx.backend, 'prelower_reduce', None)
   kids = getattr(node.children, 'vals', None)
   if hook is None or ctx.world.size != 1 or not kids or not all(isinstance(k, base._Leaf) for k in kids):
@@ -76,7 +75,6 @@ def _evaluate_aligned(node, ctx, values):
   `update` the general path issues, in the same order.  One difference in ORDER of host work, none in results: the
   kernels are launched first and the result array (metadata: its cut, its empty tiles) is made while they run,
   instead of before the first launch.  Returns None, having done nothing, when the case does not apply."""
-  from ..array import tile
   if ctx.world.size != 1 or ctx.pending is not None or not len(values):
     return None
   DA, LW = distarray.DistArrayImpl, distarray.LocalWrapper

@@ -289,3 +289,37 @@ def test_results_die_with_their_last_reference_without_the_cyclic_collector(ctx)
     assert not base.eval_cache._values, sorted(base.eval_cache._values)
   finally:
     gc.enable()
+
+
+def test_the_one_pass_description_of_operator_maps_agrees_with_the_general_walk(ctx):
+  """_Walk.map_node describes the maps operators build in one pass: it must enter the same leaves and node ids in the
+  same order as the general walk (a plan's slots and ids are positions in those lists), and tell two DAGs apart
+  exactly when the general walk does."""
+  a, b = _arr(11), _arr(12)
+  A, B = sp.from_numpy(a), sp.from_numpy(b)
+  w = np.arange(8, dtype=np.float32)
+  builders = [lambda: (A * A + A) * 0.5 - A, lambda: (B * B + B) * 0.5 - B, lambda: (A * B + A) * 0.5 - A,
+              lambda: (A * A + A) * 0.25 - A, lambda: A * A + 1, lambda: A * B + 1, lambda: B * A + 1,
+              lambda: -A + w, lambda: -B + (w + 1), lambda: sp.sum(A * A + B, axis=0), lambda: sp.sum(B * B + A, axis=0),
+              lambda: sp.sqrt(sp.abs(A)) * B, lambda: sp.maximum(A, 0) + B, lambda: sp.maximum(B, 0) + A, lambda: sp.minimum(A, B)]
+  flags = tuple(optimize.FLAGS.values())
+
+  def both(build):
+    dag = build()
+    plan.signature(dag, flags)                   # (binds the node type on first use)
+    fast = plan.signature(dag, flags)
+    kept = plan._MapExpr[0]
+    plan._MapExpr[0] = None.__class__            # no node has this type: every MapExpr goes the general way
+    try:
+      general = plan.signature(dag, flags)
+    finally:
+      plan._MapExpr[0] = kept
+    assert fast is not None and general is not None
+    assert [id(v) for v in fast[1]] == [id(v) for v in general[1]] and fast[2] == general[2]
+    assert 'M!' in repr(fast[0]) and 'M!' not in repr(general[0])
+    return dag, fast[0], general[0]
+  described = [both(bd) for bd in builders]      # (the DAGs stay alive: their ids are parts of nothing, but fns' are)
+  for i, (_, fi, gi) in enumerate(described):
+    for j, (_, fj, gj) in enumerate(described):
+      assert (fi == fj) == (gi == gj), (i, j)
+  assert described[0][1] == described[1][1] and described[0][1] != described[2][1] != described[3][1]
