@@ -684,7 +684,7 @@ class HipBackend(object):
     """Random sources fused INTO a tree (the reference's fusion does that despite @not_idempotent,
     because the marker is keyed by id() and the optimiser clones nodes: `(r - r).optimized()` draws
     twice there too) become tensor inputs, one fill per occurrence, like the reference's evaluation."""
-    if not isinstance(op, FnCallExpr):
+    if not isinstance(op, FnCallExpr) or getattr(op, '_no_random_below', False):
       return op, inputs
     new_deps, changed = [], False
     for i, d in enumerate(op.deps):
@@ -705,6 +705,7 @@ class HipBackend(object):
       else:
         new_deps.append(d)
     if not changed:
+      op._no_random_below = True         # (operator trees are not mutated once built: remembered on the tree)
       return op, inputs
     return op.__class__(fn=op.fn, kw=op.kw, pretty_fn=op.pretty_fn, deps=new_deps), inputs
 

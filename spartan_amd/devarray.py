@@ -284,6 +284,7 @@ class DevArray(object):
   __slots__ = ('storage', 'offset', 'shape', 'strides', 'dtype', '__weakref__')
   __array_priority__ = 1000.0
   is_cuda = True
+  is_sparse_tile = False        # (asked of every operand by tile.is_sparse_blob: a class attribute, not a trip through __getattr__)
 
   def __init__(self, storage, offset, shape, strides, dtype):
     self.storage = storage

@@ -263,6 +263,13 @@ class Val(_Leaf):
   def compute_shape(self):
     return self.val.shape
 
+  def evaluate(self):
+    # (inside an evaluation a leaf is its value: no cache entry to look for, no dependencies, nothing to record; at
+    #  top level the general entry runs, for its safe-point duties)
+    if context.get().eval_depth:
+      return self.val
+    return Expr.evaluate(self)
+
   def _evaluate(self, ctx, deps):
     return self.val
 
