@@ -779,7 +779,7 @@ if __name__ == '__main__':
     install_stubs()
     sp = import_reference()
     allmeta = {}
-    for n in (1, 4):
+    for n in (1, 3, 4, 8):
       arrays, meta = sparse_goldens(sp, n)
       np.savez_compressed(os.path.join(OUT, 'sparse_w%d.npz' % n), **arrays)
       allmeta[str(n)] = meta

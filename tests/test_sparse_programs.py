@@ -1,5 +1,5 @@
 """Sparse-tile programs (tests/sparse_programs.py) against golden outputs recorded by RUNNING
-THE REFERENCE (tests/golden/make_golden.py --sparse -> sparse_w{1,4}.npz):
+THE REFERENCE (tests/golden/make_golden.py --sparse -> sparse_w{1,3,4,8}.npz):
   * host logic + the NumPy/scipy tile backend on CPU (every pytest run) -- this pins the oracle;
   * the HIP backend (device CSR tiles, spartan_amd/csrc/sparse.hip) with -m gpu.
 All programs hold small-integer values, so results are bit-identical unless the program states a tolerance.
@@ -56,14 +56,14 @@ def _check(backend_factory, workers):
   assert pinned >= 18
 
 
-@pytest.mark.parametrize('workers', [1, 4])
+@pytest.mark.parametrize('workers', [1, 3, 4, 8])
 def test_sparse_programs_match_reference_cpu(workers):
   from oracle.np_backend import NumpyBackend
   _check(NumpyBackend, workers)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('workers', [1, 4])
+@pytest.mark.parametrize('workers', [1, 3, 4, 8])
 def test_sparse_programs_match_reference_gpu(workers):
   from spartan_amd.backend_hip import HipBackend
   _check(HipBackend, workers)
