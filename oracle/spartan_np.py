@@ -299,6 +299,14 @@ class Cluster(object):
   def __init__(self, num_workers=1):
     self.n = num_workers
 
+  @staticmethod
+  def kernel_order(array):
+    """The tiles of `array` in the order their mappers run: a kernel request goes to EVERY worker and each runs it
+    for the tiles it holds, in list order (blob_ctx.py:270-271, worker.py:255-263) -- concurrently in the reference;
+    one worker after the other, lowest first, in the serial runs its recorded outputs come from.  Only targets that
+    keep the LAST write (updates without a reducer) or add floats can tell."""
+    return sorted(array.tiles, key=lambda entry: entry[1])
+
   # -- creation (creation.py) --------------------------------------------------
   def empty(self, shape, dtype=np.float32, reducer=None, tile_hint=None):
     return DistArray(shape, dtype, reducer, tile_hint, self.n)
@@ -385,7 +393,7 @@ class Cluster(object):
       shape = list(x.shape)
       del shape[axis]
     out = self.empty(shape, dtype, accumulate)
-    for ex, _, t in x.tiles:
+    for ex, _, t in self.kernel_order(x):
       with np.errstate(all='ignore'):
         local = local_fn(ex, x.fetch(ex), axis)
       dst = ex_drop_axis(ex, axis)
@@ -444,7 +452,7 @@ class Cluster(object):
     (change_partition_axis), the other arrays give the slab with the same range on their join axis; what
     fn(extents, slabs) yields is pushed into a target of `shape` with arrays[0]'s dtype (map.py:316-334)."""
     target = self.empty(shape, arrays[0].dtype, reducer)
-    for ex, _, t in arrays[0].tiles:
+    for ex, _, t in self.kernel_order(arrays[0]):
       if not axes:
         extents, slabs = ex, [a.fetch(ex) for a in arrays]
       else:
@@ -469,7 +477,7 @@ class Cluster(object):
       else:
         shape = (a.shape[0], b.shape[1])
       target = self.empty(shape, a.dtype, np.add)
-      for ex, _, t in a.tiles:
+      for ex, _, t in self.kernel_order(a):
         blk = a.fetch(ex).dot(b[ex.ul[1]:ex.lr[1]])
         if len(b.shape) == 1:
           target.update(Extent((ex.ul[0],), (ex.lr[0],), shape), blk)
@@ -478,12 +486,12 @@ class Cluster(object):
       return target
     if len(a.shape) == 1 and len(b.shape) == 1:              # dot_map2_vec_mapper, dot.py:189-191
       target = self.empty((1,), a.dtype, np.add)
-      for ex, _, t in a.tiles:
+      for ex, _, t in self.kernel_order(a):
         target.update(Extent((0,), (1,), (1,)), a.fetch(ex).dot(b.fetch(Extent(ex.ul, ex.lr, b.shape))).reshape(1,))
       return target
     if len(a.shape) == 1:                                     # vector . matrix, dot.py:296-299: the vector as a
       target = self.empty((b.shape[1],), a.dtype, np.add, tile_hint)   # 1 x n row, K-split join, is_vec
-      for ex, _, t in a.tiles:
+      for ex, _, t in self.kernel_order(a):
         rows = Extent((ex.ul[0], 0), (ex.lr[0], b.shape[1]), b.shape)
         target.update(Extent((0,), (b.shape[1],), (b.shape[1],)), a.fetch(ex).dot(b.fetch(rows)))
       return target
@@ -496,7 +504,7 @@ class Cluster(object):
     target = self.empty(shape, a.dtype, np.add, tile_hint)
     if a.shape[0] > a.shape[1]:                               # outer, dot.py:281-285
       whole_b = b.fetch(Extent([0] * len(b.shape), b.shape, b.shape))
-      for ex, _, t in a.tiles:
+      for ex, _, t in self.kernel_order(a):
         first = change_partition_axis(ex, 0)
         blk = a.fetch(first).dot(whole_b)                    # dot_outer_mapper, dot.py:222-238
         if len(b.shape) == 1:
@@ -504,7 +512,7 @@ class Cluster(object):
         else:
           target.update(Extent((first.ul[0], 0), (first.lr[0], b.shape[1]), shape), blk)
       return target
-    for ex, _, t in a.tiles:                                  # map2 join, map.py:243-286
+    for ex, _, t in self.kernel_order(a):                     # map2 join, map.py:243-286
       first = change_partition_axis(ex, 1)
       if first is None:
         continue
@@ -527,23 +535,23 @@ def kmeans_fit_map2(cl, X, centers, n_clusters, n_iter, reducer=None):
   labels = argmin(cdist) per row tile (:61-66); per-tile counts (:69-72) and masked row sums (:75-97)
   written into ONE whole-array target tile -- with `reducer=None`, as the reference creates those
   targets (:135-141), every tile REPLACES the previous one (tile.pyx:263-268), so the last tile in
-  tile order wins; empty clusters re-seeded from np.random.randn (:145-155); centers = sums / counts."""
+  KERNEL order (Cluster.kernel_order: worker by worker) wins; empty clusters re-seeded from np.random.randn (:145-155); centers = sums / counts."""
   from scipy.spatial.distance import cdist
   num_dim = X.shape[1]
   labels = None
   for _ in range(n_iter):
     labels = cl.empty((X.shape[0],), X.dtype, None)
-    for ex, _, _t in X.tiles:
+    for ex, _, _t in cl.kernel_order(X):
       pts = X.fetch(ex)
       labels.update(Extent((ex.ul[0],), (ex.lr[0],), (X.shape[0],)),
                     np.argmin(cdist(pts, centers), axis=1))
     counts = cl.empty((n_clusters,), labels.dtype, reducer)
-    for ex, _, _t in labels.tiles:
+    for ex, _, _t in cl.kernel_order(labels):
       lab = labels.fetch(ex)
       counts.update(Extent((0,), (n_clusters,), (n_clusters,)),
                     np.bincount(lab.astype(np.int64), minlength=n_clusters))
     sums = cl.empty((n_clusters, num_dim), X.dtype, reducer)
-    for ex, _, _t in X.tiles:
+    for ex, _, _t in cl.kernel_order(X):
       pts = X.fetch(ex)
       lab = labels.fetch(Extent((ex.ul[0],), (ex.lr[0],), (X.shape[0],)))
       new_centers = np.zeros((n_clusters, num_dim))

@@ -955,6 +955,10 @@ class KernelResults(collections.OrderedDict):
   meta = None
 
 
+def _worker_of(tile_id):
+  return tile_id.worker
+
+
 def run_kernel(array, tile_ids, mapper_fn, kw):
   """blob_ctx.map + Worker._run_kernel: call the mapper for every tile (in a
   deterministic order, on every rank) and join the updates it issued."""
@@ -969,6 +973,12 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
   ctx.fetch_cache = {}
   outer_worker = ctx.current_worker
   blobs, invoke = ctx._blobs, array._invoke_mapper
+  # Worker by worker, each worker's tiles in list order: the request goes to EVERY worker and each runs the mapper
+  # for the tiles it holds (blob_ctx.py:270-271 `_send_all`, worker.py:255-263) -- concurrently there; one after the
+  # other, lowest worker first, is the linearisation the recorded reference outputs were produced with, and it shows
+  # wherever a target keeps the LAST write (updates without a reducer: the k-means drivers' count / sum targets).
+  if len(tile_ids) > 1:
+    tile_ids = sorted(tile_ids, key=_worker_of)
   try:
     for tile_id in tile_ids:
       ctx.current_worker = tile_id.worker          # (Context.on_worker, without the context manager)

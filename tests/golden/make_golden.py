@@ -824,7 +824,7 @@ if __name__ == '__main__':
     install_stubs()
     sp = import_reference()
     np.savez_compressed(os.path.join(OUT, 'examples_inputs.npz'), **example_inputs())
-    for n in (1, 4):
+    for n in (1, 3, 4, 8):
       res = example_goldens(sp, n)
       np.savez_compressed(os.path.join(OUT, 'examples_w%d.npz' % n), **res)
       print('workers', n, ':', sorted(res))

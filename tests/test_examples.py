@@ -19,7 +19,7 @@ from spartan_amd.examples.sklearn.cluster import KMeans
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 INPUTS = dict(np.load(os.path.join(G, 'examples_inputs.npz')))
-GOLD = {n: dict(np.load(os.path.join(G, 'examples_w%d.npz' % n))) for n in (1, 4)}
+GOLD = {n: dict(np.load(os.path.join(G, 'examples_w%d.npz' % n))) for n in (1, 3, 4, 8)}
 
 IMPLS = ('map2', 'outer', 'broadcast', 'shuffle')
 
@@ -124,7 +124,7 @@ def _check_other_regressions(workers, rtol):
 
 
 # ------------------------------------------------------------------ CPU: host framework on the oracle backend
-@pytest.fixture(params=[1, 4], ids=lambda n: 'workers%d' % n)
+@pytest.fixture(params=[1, 3, 4, 8], ids=lambda n: 'workers%d' % n)
 def cpu_ctx(request):
   from oracle.np_backend import NumpyBackend
   sp.initialize(backend=NumpyBackend(), num_workers=request.param)
@@ -177,7 +177,7 @@ def test_kmeans_reducer_combines_tiles(cpu_ctx):
 
 
 # ------------------------------------------------------------------ GPU: the same drivers on the HIP kernels
-@pytest.fixture(params=[1, 4], ids=lambda n: 'workers%d' % n)
+@pytest.fixture(params=[1, 3, 4, 8], ids=lambda n: 'workers%d' % n)
 def gpu_ctx(request):
   sp.initialize('hip', num_workers=request.param)
   yield request.param
