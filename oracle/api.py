@@ -112,7 +112,7 @@ class Facade(object):
       return np.eye(ex.lr[0] - ex.ul[0], M=ex.lr[1] - ex.ul[1], k=ex.ul[0] - ex.ul[1] + k, dtype=dtype)
     return self._w(self.c.map_with_location(fn, self.c.empty((N, M), dtype)))
 
-  def from_numpy(self, a, tile_hint=None): return self._w(self.c.from_numpy(a))
+  def from_numpy(self, a, tile_hint=None): return self._w(self.c.from_numpy(a, tile_hint))
   def transpose(self, x): return self.from_numpy(np.ascontiguousarray(x.glom().T))
   def reshape(self, x, shape): return self.from_numpy(np.ascontiguousarray(x.glom().reshape(shape)))
   def ravel(self, x): return self.from_numpy(np.ascontiguousarray(x.glom().ravel()))

@@ -301,11 +301,17 @@ class Cluster(object):
 
   @staticmethod
   def kernel_order(array):
-    """The tiles of `array` in the order their mappers run: a kernel request goes to EVERY worker and each runs it
-    for the tiles it holds, in list order (blob_ctx.py:270-271, worker.py:255-263) -- concurrently in the reference;
-    one worker after the other, lowest first, in the serial runs its recorded outputs come from.  Only targets that
-    keep the LAST write (updates without a reducer) or add floats can tell."""
-    return sorted(array.tiles, key=lambda entry: entry[1])
+    """The tiles of `array` in the order their mappers run: a kernel request goes to EVERY worker (blob_ctx.py:270-271)
+    and each collects the tiles it holds in list order, sorts them by np.size of their data (stable, ascending) and
+    pops them from the END (worker.py:246-256) -- largest first, tiles of one size in reverse list order.
+    Concurrently in the reference; one worker after the other, lowest first, in the serial runs its recorded outputs
+    come from.  Only targets that keep the LAST write (updates without a reducer) or add floats can tell."""
+    order = []
+    for worker in sorted(set(entry[1] for entry in array.tiles)):
+      mine = [entry for entry in array.tiles if entry[1] == worker]
+      mine.sort(key=lambda entry: 1 if entry[2].data is None else int(np.size(entry[2].data)))
+      order.extend(reversed(mine))
+    return order
 
   # -- creation (creation.py) --------------------------------------------------
   def empty(self, shape, dtype=np.float32, reducer=None, tile_hint=None):
@@ -535,7 +541,7 @@ def kmeans_fit_map2(cl, X, centers, n_clusters, n_iter, reducer=None):
   labels = argmin(cdist) per row tile (:61-66); per-tile counts (:69-72) and masked row sums (:75-97)
   written into ONE whole-array target tile -- with `reducer=None`, as the reference creates those
   targets (:135-141), every tile REPLACES the previous one (tile.pyx:263-268), so the last tile in
-  KERNEL order (Cluster.kernel_order: worker by worker) wins; empty clusters re-seeded from np.random.randn (:145-155); centers = sums / counts."""
+  KERNEL order (Cluster.kernel_order: worker by worker, a worker's tiles largest first / last listed first) wins; empty clusters re-seeded from np.random.randn (:145-155); centers = sums / counts."""
   from scipy.spatial.distance import cdist
   num_dim = X.shape[1]
   labels = None

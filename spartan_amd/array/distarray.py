@@ -955,8 +955,45 @@ class KernelResults(collections.OrderedDict):
   meta = None
 
 
-def _worker_of(tile_id):
-  return tile_id.worker
+def kernel_order(array, tile_ids, ctx):
+  """The order in which the mappers of one kernel run, as the reference's workers run them: the request goes to EVERY
+  worker (blob_ctx.py:270-271 `_send_all`) and each collects the tiles it holds in list order, sorts them by the size
+  of their data -- a stable sort, ascending -- and POPS them from the end (worker.py:246-256): largest tile first,
+  tiles of one size in REVERSE list order.  Concurrently there; worker after worker, lowest first, is the
+  linearisation its recorded outputs were produced with, and it shows wherever a target keeps the last write (updates
+  without a reducer: the k-means drivers' count / sum targets) or partial results are added in floating point.
+  Size: what np.size gives the reference -- stored values of a sparse tile, 1 for a tile nothing was written to --
+  when every tile is in this process; across ranks, where all must walk ONE order, the tile's extent."""
+  if len(tile_ids) < 2:
+    return list(tile_ids)
+  single = ctx.world.size == 1
+  blobs = ctx._blobs
+  by_worker = {}
+  for tid in tile_ids:
+    by_worker.setdefault(tid.worker, []).append(tid)
+  order = []
+  for worker in sorted(by_worker):
+    mine = by_worker[worker]
+    if len(mine) > 1:
+      sizes = {}
+      for tid in mine:
+        t = blobs.get(tid) if single else None
+        if t is None:
+          try:
+            ex = array.extent_for_blob(tid)
+          except KeyError:
+            ex = None
+          sizes[tid] = int(np.prod(ex.shape, dtype=np.int64)) if ex is not None else 0
+        elif t.data is None:
+          sizes[tid] = 1
+        elif tile.is_sparse_blob(t.data):
+          sizes[tid] = int(getattr(t.data, 'nnz', 0))
+        else:
+          sizes[tid] = int(np.prod(t.shape, dtype=np.int64))
+      mine = sorted(mine, key=sizes.__getitem__)
+      mine.reverse()
+    order.extend(mine)
+  return order
 
 
 def run_kernel(array, tile_ids, mapper_fn, kw):
@@ -973,12 +1010,7 @@ def run_kernel(array, tile_ids, mapper_fn, kw):
   ctx.fetch_cache = {}
   outer_worker = ctx.current_worker
   blobs, invoke = ctx._blobs, array._invoke_mapper
-  # Worker by worker, each worker's tiles in list order: the request goes to EVERY worker and each runs the mapper
-  # for the tiles it holds (blob_ctx.py:270-271 `_send_all`, worker.py:255-263) -- concurrently there; one after the
-  # other, lowest worker first, is the linearisation the recorded reference outputs were produced with, and it shows
-  # wherever a target keeps the LAST write (updates without a reducer: the k-means drivers' count / sum targets).
-  if len(tile_ids) > 1:
-    tile_ids = sorted(tile_ids, key=_worker_of)
+  tile_ids = kernel_order(array, tile_ids, ctx)
   try:
     for tile_id in tile_ids:
       ctx.current_worker = tile_id.worker          # (Context.on_worker, without the context manager)

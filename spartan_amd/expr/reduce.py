@@ -68,6 +68,10 @@ def prelower(node, ctx):
   return done
 
 
+def _first(pair):
+  return pair[0]
+
+
 def _evaluate_aligned(node, ctx, values):
   """ReduceExpr._evaluate for one process and operands that are dense, whole, written everywhere and cut the same
   way (or scalars) -- expr/map._evaluate_aligned's case: the tiles' own tensors go to the backend's fused
@@ -108,6 +112,11 @@ def _evaluate_aligned(node, ctx, values):
     operands['extent'] = ex
     operands['axis'] = axis
     rows.append((ex, tid.worker, operands))
+  if len(rows) > 1:
+    # the order run_kernel walks the tiles in (distarray.kernel_order): the order the partials meet in
+    at = {tid: k for k, tid in enumerate(distarray.kernel_order(lead, list(lead.tiles.values()), ctx))}
+    tids = list(lead.tiles.values())
+    rows = [row for _, row in sorted(zip([at[t] for t in tids], rows), key=_first)]
   backend, op = ctx.backend, node.op
   outer_worker = ctx.current_worker
   partials = []

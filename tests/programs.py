@@ -180,6 +180,21 @@ def programs():
        lambda: np.concatenate((_ar((15, 5)), _ar((15, 7)) - 3), 1), None))
   add(('concatenate_exprs', lambda sp: sp.concatenate(sp.arange((30, 8), dtype=F32) * 2, sp.ones((12, 8)), 0) + 1,
        lambda: np.concatenate((_ar((30, 8)) * 2, np.ones((12, 8), F32)), 0) + 1, None))
+  # ---- the ORDER in which the partials of a reduction meet (round 6): four row tiles whatever the worker count
+  # (tile_hint), ONE non-zero row each -- every per-tile partial is exact in any order --, magnitudes chosen so that
+  # float32 addition of the four partials gives different answers in different orders: 2^24 + 1 == 2^24.  The tiles
+  # sit on workers 0, 1, 2, 0 with three workers, and the reference's kernels run worker by worker (blob_ctx.py:
+  # 270-271): (t0 + t3) + t1 + t2 there, t0 + t1 + t2 + t3 with 1, 4 and 8 workers.  Values: the recorded ones.
+  def spikes(scale=1.0):
+    a = np.zeros((200, 3), F32)
+    a[0], a[70], a[140], a[199] = 16777216.0 * scale, 1.0 * scale, 1.0 * scale, -16777216.0 * scale
+    return a
+  add(('sum_axis0_partials_meet_in_worker_order', lambda sp: sp.sum(sp.from_numpy(spikes(), tile_hint=(50, 3)), 0),
+       lambda: None, None))
+  add(('sum_all_partials_meet_in_worker_order', lambda sp: sp.sum(sp.from_numpy(spikes(), tile_hint=(50, 3))) * sp.ones((2,)),
+       lambda: None, None))
+  add(('max_of_scaled_sum_in_worker_order', lambda sp: sp.max(sp.sum(sp.from_numpy(spikes(0.5), tile_hint=(50, 3)) * 2, 0).optimized()) * sp.ones((2,)),
+       lambda: None, None))
   return P
 
 
