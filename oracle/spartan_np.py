@@ -484,6 +484,12 @@ class Cluster(object):
         shape = (a.shape[0], b.shape[1])
       target = self.empty(shape, a.dtype, np.add)
       for ex, _, t in self.kernel_order(a):
+        # dot.py:254-262: map2(a, axes=[0], ...) -- every tile of `a` is re-read as the slab that cuts axis 0
+        # (join_mapper, map.py:243-286): a column tile of a wide matrix becomes some ROWS with ALL their columns,
+        # one full product per slab, nothing summed across slabs
+        ex = change_partition_axis(ex, 0)
+        if ex is None:
+          continue
         blk = a.fetch(ex).dot(b[ex.ul[1]:ex.lr[1]])
         if len(b.shape) == 1:
           target.update(Extent((ex.ul[0],), (ex.lr[0],), shape), blk)

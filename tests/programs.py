@@ -195,6 +195,20 @@ def programs():
        lambda: None, None))
   add(('max_of_scaled_sum_in_worker_order', lambda sp: sp.max(sp.sum(sp.from_numpy(spikes(0.5), tile_hint=(50, 3)) * 2, 0).optimized()) * sp.ones((2,)),
        lambda: None, None))
+  # the same for the K-split join of spartan.dot (dot.py:195-217): four K slabs of a wide matrix, one non-zero product
+  # per slab and output element, 2^12 * 2^12 + 1 + 1 - 2^12 * 2^12 in the order the slabs' partial products meet
+  def wide():
+    a = np.zeros((4, 200), F32)
+    a[:, 0], a[:, 70], a[:, 140], a[:, 199] = 4096.0, 1.0, 1.0, -4096.0
+    return a
+  def tall():
+    b = np.zeros((200, 2), F32)
+    b[0], b[70], b[140], b[199] = 4096.0, 1.0, 1.0, 4096.0
+    return b
+  add(('dot_ksplit_partials_meet_in_worker_order',
+       lambda sp: sp.dot(sp.from_numpy(wide(), tile_hint=(4, 50)), sp.from_numpy(tall(), tile_hint=(50, 2))), lambda: None, None))
+  add(('dot_ksplit_numpy_rhs_in_worker_order',
+       lambda sp: sp.dot(sp.from_numpy(wide(), tile_hint=(4, 50)), tall()), lambda: None, None))
   return P
 
 
