@@ -209,6 +209,19 @@ def programs():
        lambda sp: sp.dot(sp.from_numpy(wide(), tile_hint=(4, 50)), sp.from_numpy(tall(), tile_hint=(50, 2))), lambda: None, None))
   add(('dot_ksplit_numpy_rhs_in_worker_order',
        lambda sp: sp.dot(sp.from_numpy(wide(), tile_hint=(4, 50)), tall()), lambda: None, None))
+  # ties between tiles: the same extreme value in tiles 0, 1 and 3 (tiles 0 and 3 on one worker with three workers),
+  # reduced in kernel order -- which occurrence does the pairwise reducer keep?  (NumPy: the first.)
+  def ties():
+    a = np.zeros((200, 3), F32)
+    a[10], a[60], a[160] = 5.0, 5.0, 5.0
+    a[20], a[170] = -5.0, -5.0
+    return a
+  add(('argmax_ties_across_tiles_axis0', lambda sp: sp.argmax(sp.from_numpy(ties(), tile_hint=(50, 3)), 0), lambda: np.argmax(ties(), 0), None))
+  add(('argmin_ties_across_tiles_axis0', lambda sp: sp.argmin(sp.from_numpy(ties(), tile_hint=(50, 3)), 0), lambda: np.argmin(ties(), 0), None))
+  add(('argmax_ties_across_tiles_flat', lambda sp: sp.argmax(sp.from_numpy(ties(), tile_hint=(50, 3))) * sp.ones((2,), dtype=np.int64),
+       lambda: np.argmax(ties()) * np.ones((2,), np.int64), None))
+  add(('argmin_ties_across_tiles_flat', lambda sp: sp.argmin(sp.from_numpy(ties(), tile_hint=(50, 3))) * sp.ones((2,), dtype=np.int64),
+       lambda: np.argmin(ties()) * np.ones((2,), np.int64), None))
   return P
 
 
