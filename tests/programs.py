@@ -222,6 +222,34 @@ def programs():
        lambda: np.argmax(ties()) * np.ones((2,), np.int64), None))
   add(('argmin_ties_across_tiles_flat', lambda sp: sp.argmin(sp.from_numpy(ties(), tile_hint=(50, 3))) * sp.ones((2,), dtype=np.int64),
        lambda: np.argmin(ties()) * np.ones((2,), np.int64), None))
+  # NaN and infinities through the reductions and the element-wise extremes (NumPy's rules: max / min / sum propagate
+  # NaN, argmax / argmin take the first NaN, np.maximum propagates it, comparisons with it are false) -- per tile and
+  # across tiles, the NaN in one tile and the largest finite value in another
+  def holes():
+    a = (np.arange(200 * 3, dtype=F32).reshape(200, 3) % 13) - 6
+    a[30, 1] = np.nan
+    a[170, 2] = np.inf
+    a[120, 0] = -np.inf
+    return a
+  hx = lambda sp: sp.from_numpy(holes(), tile_hint=(50, 3))
+  for nm, fn in (('max', 'max'), ('min', 'min'), ('sum', 'sum'), ('argmax', 'argmax'), ('argmin', 'argmin')):
+    for axis in (None, 0, 1):
+      tag = 'nan_%s_axis%s' % (nm, axis)
+      if axis is None:
+        build = (lambda fn: lambda sp: getattr(sp, fn)(hx(sp)) * sp.ones((2,), dtype=np.int64 if fn.startswith('arg') else F32))(fn)
+        want = (lambda fn: lambda: getattr(np, fn)(holes()) * np.ones((2,), np.int64 if fn.startswith('arg') else F32))(fn)
+      else:
+        build = (lambda fn, axis: lambda sp: getattr(sp, fn)(hx(sp), axis))(fn, axis)
+        want = (lambda fn, axis: lambda: getattr(np, fn)(holes(), axis))(fn, axis)
+      # (an arg-reduction that meets a NaN returns the reference's SENTINEL, the array's size -- its pairwise reducer
+      #  never prefers a NaN and the first tile's own np.argmax index is folded away --, not NumPy's first NaN: the
+      #  recorded outputs define these, tests/test_golden.py)
+      add((tag, build, (lambda: None) if fn.startswith('arg') else want, None))
+  add(('nan_maximum_minimum', lambda sp: sp.maximum(hx(sp), 0.0) + sp.minimum(hx(sp), 1.0), lambda: np.maximum(holes(), F32(0)) + np.minimum(holes(), F32(1)), None))
+  add(('nan_comparisons', lambda sp: (hx(sp) > 0) * 1 + (hx(sp) == hx(sp)) * 2 + (hx(sp) < 2) * 4,
+       lambda: (holes() > 0) * 1 + (holes() == holes()) * 2 + (holes() < 2) * 4, None))
+  add(('nan_abs_sqrt_square', lambda sp: sp.sqrt(sp.abs(hx(sp))) + sp.square(hx(sp)), lambda: np.sqrt(np.abs(holes())) + np.square(holes()), None))
+  add(('nan_fused_sum_of_product', lambda sp: sp.sum(hx(sp) * hx(sp) + 1, 0).optimized(), lambda: (holes() * holes() + 1).sum(0), None))
   return P
 
 
