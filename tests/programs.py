@@ -250,6 +250,15 @@ def programs():
        lambda: (holes() > 0) * 1 + (holes() == holes()) * 2 + (holes() < 2) * 4, None))
   add(('nan_abs_sqrt_square', lambda sp: sp.sqrt(sp.abs(hx(sp))) + sp.square(hx(sp)), lambda: np.sqrt(np.abs(holes())) + np.square(holes()), None))
   add(('nan_fused_sum_of_product', lambda sp: sp.sum(hx(sp) * hx(sp) + 1, 0).optimized(), lambda: (holes() * holes() + 1).sum(0), None))
+  # a ragged last tile: the worker sorts its tiles by SIZE before popping them (worker.py:250), so the small tile of
+  # rows 200..202 runs last on its worker whatever its place in the list -- 2^24 in tile 0, 1 in tiles 1..3, -2^24 in
+  # the small one: the answer depends on where the small tile's partial arrives
+  def ragged_spikes():
+    a = np.zeros((203, 3), F32)
+    a[0], a[70], a[140], a[190], a[200] = 16777216.0, 1.0, 1.0, 1.0, -16777216.0
+    return a
+  add(('sum_axis0_ragged_tile_runs_last', lambda sp: sp.sum(sp.from_numpy(ragged_spikes(), tile_hint=(50, 3)), 0), lambda: None, None))
+  add(('sum_all_ragged_tile_runs_last', lambda sp: sp.sum(sp.from_numpy(ragged_spikes(), tile_hint=(50, 3))) * sp.ones((2,)), lambda: None, None))
   return P
 
 
