@@ -727,6 +727,19 @@ def region_goldens(sp, workers):
   return arrays
 
 
+def join_goldens(sp, workers):
+  """map2 / outer / shuffle with user tile functions (tests/join_programs.py), run by the reference."""
+  sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+  from tests import join_programs
+  arrays = {}
+  for name, build in join_programs.programs():
+    start_cluster(sp, workers)
+    res = build(sp).evaluate()
+    arrays[name] = np.asarray(res.glom())
+    arrays[name + '__tiles'] = np.asarray(sorted([list(ex.ul) + list(ex.lr) + [int(tid.worker)] for ex, tid in res.tiles.items()]))
+  return arrays
+
+
 def dot_grid_goldens(sp):
   """spartan.dot on operands cut into a 2-D GRID of tiles -- the tiling of the reference's own tests/benchmark_dot.py
   (tile_hint=(T, T)) -- as the reference computes it.  (What it computes is NOT the matrix product: the join turns
@@ -759,6 +772,18 @@ if __name__ == '__main__':
     res = dot_grid_goldens(sp)
     np.savez_compressed(os.path.join(OUT, 'dot_grid.npz'), **res)
     print('dot on grid tiles:', sorted(res))
+    sys.stdout.flush()
+    os._exit(0)
+  if '--joins' in sys.argv:
+    if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
+      prepare_tree()
+      build_cython()
+    install_stubs()
+    sp = import_reference()
+    for n in (1, 3, 4, 8):
+      res = join_goldens(sp, n)
+      np.savez_compressed(os.path.join(OUT, 'joins_w%d.npz' % n), **res)
+      print('workers', n, ':', {k: res[k].tolist() for k in sorted(res) if not k.endswith('__tiles') and res[k].size <= 3})
     sys.stdout.flush()
     os._exit(0)
   if '--region' in sys.argv:
