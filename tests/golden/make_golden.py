@@ -740,6 +740,43 @@ def join_goldens(sp, workers):
   return arrays
 
 
+FUZZ_SEEDS = range(5000, 5300)
+FUZZ_KEEP = 4096
+
+
+def fuzz_sample(val):
+  """What is kept of one program's output: all of it up to FUZZ_KEEP elements, else every k-th element of its ravel
+  (k = ceil(size / FUZZ_KEEP)); tests/test_fuzz_reference.py takes the same sample of what the product computes."""
+  flat = np.ascontiguousarray(val).ravel()
+  if flat.size > FUZZ_KEEP:
+    flat = flat[::-(-flat.size // FUZZ_KEEP)]
+  return flat
+
+
+def fuzz_goldens(sp, workers):
+  """The random expression DAGs of tests/test_fuzz_gpu.py (element-wise trees with broadcasting and dtype mixes,
+  views, reductions and arg-reductions over every axis, fused or not) built over the REFERENCE's builders and run by
+  it: the programs it can run (about two thirds: it has no >= / <= on expressions, and its updates assert equal
+  dtypes) become fixtures -- shape, dtype, float64 sum and a sample of the values per seed."""
+  sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+  import importlib
+  fz = importlib.import_module('tests.test_fuzz_gpu')
+  arrays, meta = {}, {}
+  for seed in FUZZ_SEEDS:
+    start_cluster(sp, workers)
+    try:
+      with np.errstate(all='ignore'):
+        val = np.asarray(fz._program(seed, sp))
+    except Exception as e:   # noqa: BLE001 -- a program the reference cannot run is not a fixture
+      meta[str(seed)] = {'skipped': '%s: %s' % (type(e).__name__, str(e)[:120])}
+      continue
+    arrays['s%d' % seed] = fuzz_sample(val)
+    with np.errstate(all='ignore'):
+      total = float(np.nansum(val.astype(np.float64))) if val.size else 0.0
+    meta[str(seed)] = {'shape': list(val.shape), 'dtype': val.dtype.str, 'sum': total if np.isfinite(total) else None}
+  return arrays, meta
+
+
 def dot_grid_goldens(sp):
   """spartan.dot on operands cut into a 2-D GRID of tiles -- the tiling of the reference's own tests/benchmark_dot.py
   (tile_hint=(T, T)) -- as the reference computes it.  (What it computes is NOT the matrix product: the join turns
@@ -772,6 +809,21 @@ if __name__ == '__main__':
     res = dot_grid_goldens(sp)
     np.savez_compressed(os.path.join(OUT, 'dot_grid.npz'), **res)
     print('dot on grid tiles:', sorted(res))
+    sys.stdout.flush()
+    os._exit(0)
+  if '--fuzz' in sys.argv:
+    if not os.path.exists(os.path.join(SCRATCH, 'spartan')):
+      prepare_tree()
+      build_cython()
+    install_stubs()
+    sp = import_reference()
+    allmeta = {}
+    for n in (1, 3, 4, 8):
+      arrays, meta = fuzz_goldens(sp, n)
+      np.savez_compressed(os.path.join(OUT, 'fuzz_w%d.npz' % n), **arrays)
+      allmeta[str(n)] = meta
+      print('workers', n, ':', len(arrays), 'of', len(meta), 'programs run by the reference')
+    json.dump(allmeta, open(os.path.join(OUT, 'fuzz_meta.json'), 'w'), indent=0, sort_keys=True)
     sys.stdout.flush()
     os._exit(0)
   if '--joins' in sys.argv:

@@ -88,7 +88,9 @@ def _build(rng, shape, depth, api, np_mode):
   return f(a, b)
 
 
-def _program(seed, api):
+def _program(seed, api, info=None):
+  """The random program of `seed` over the builders of `api`, evaluated.  `info` (a dict) receives what the program
+  ends in: info['tail'] in ('sum', 'max', 'argmax', 'mean', 'map'), info['axis'], info['optimized']."""
   rng = np.random.RandomState(seed)
   shape = SHAPES[rng.randint(len(SHAPES))]
   e = _build(rng, shape, 3 + (seed % 3 == 0), api, False)
@@ -110,8 +112,11 @@ def _program(seed, api):
     e = api.argmax(e, ax)
   elif tail == 3:
     e = api.mean(e, ax)
-  if rng.rand() < 0.5:
+  fused = rng.rand() < 0.5
+  if fused:
     e = e.optimized()
+  if info is not None:
+    info.update(tail=('sum', 'max', 'argmax', 'mean')[tail] if tail < 4 else 'map', axis=ax, optimized=bool(fused))
   return np.asarray(e.glom())
 
 
