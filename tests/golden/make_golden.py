@@ -742,6 +742,7 @@ def join_goldens(sp, workers):
 
 FUZZ_SEEDS = range(5000, 5300)
 FUZZ_KEEP = 4096
+FUZZ_DOT_SEEDS = range(7000, 7100)
 
 
 def fuzz_sample(val):
@@ -774,6 +775,17 @@ def fuzz_goldens(sp, workers):
     with np.errstate(all='ignore'):
       total = float(np.nansum(val.astype(np.float64))) if val.size else 0.0
     meta[str(seed)] = {'shape': list(val.shape), 'dtype': val.dtype.str, 'sum': total if np.isfinite(total) else None}
+  # ... and its random dots (every dispatch branch of dot.py:243-299: matrix.matrix, matrix.vector, vector.vector, a
+  # NumPy right-hand side, tile hints; integer-valued operands, so every product is exact)
+  for seed in FUZZ_DOT_SEEDS:
+    start_cluster(sp, workers)
+    try:
+      val = np.asarray(fz._dot_case(seed, sp))
+    except Exception as e:   # noqa: BLE001
+      meta['d%d' % seed] = {'skipped': '%s: %s' % (type(e).__name__, str(e)[:120])}
+      continue
+    arrays['d%d' % seed] = fuzz_sample(val)
+    meta['d%d' % seed] = {'shape': list(val.shape), 'dtype': val.dtype.str, 'sum': float(val.astype(np.float64).sum())}
   return arrays, meta
 
 
@@ -822,7 +834,8 @@ if __name__ == '__main__':
       arrays, meta = fuzz_goldens(sp, n)
       np.savez_compressed(os.path.join(OUT, 'fuzz_w%d.npz' % n), **arrays)
       allmeta[str(n)] = meta
-      print('workers', n, ':', len(arrays), 'of', len(meta), 'programs run by the reference')
+      print('workers', n, ':', len(arrays), 'of', len(meta), 'programs run by the reference;',
+            sum(1 for k in arrays if k.startswith('d')), 'dots')
     json.dump(allmeta, open(os.path.join(OUT, 'fuzz_meta.json'), 'w'), indent=0, sort_keys=True)
     sys.stdout.flush()
     os._exit(0)

@@ -23,7 +23,8 @@ KEEP = 4096
 # programs whose updates fail the reference's dtype assertion as soon as a target has a second tile -- and whose
 # one-worker answers show the same confusion (a fused arg-reduction keeps its extreme values in the dtype of the first
 # fused input; where that loses the value no element equals it and the sentinel comes back for every position).
-EVERYWHERE = set.intersection(*[{seed for seed, m in META[w].items() if 'skipped' not in m} for w in META])
+DOTS = sorted(k for k in META['1'] if k.startswith('d'))
+EVERYWHERE = set.intersection(*[{seed for seed, m in META[w].items() if 'skipped' not in m and not seed.startswith('d')} for w in META])
 
 
 def _sample(val):
@@ -37,7 +38,7 @@ def _run(workers, exact_floats):
   gold = np.load(os.path.join(HERE, 'fuzz_w%d.npz' % workers))
   meta = META[str(workers)]
   bad, ran, known, refused, truncated = [], 0, [0], [0], [0]
-  for seed, m in sorted(meta.items(), key=lambda kv: int(kv[0])):
+  for seed, m in sorted(((k, v) for k, v in meta.items() if not k.startswith('d')), key=lambda kv: int(kv[0])):
     if 'skipped' in m or seed not in EVERYWHERE:
       continue
     info = {}
@@ -117,3 +118,37 @@ def test_the_hip_backend_computes_what_the_reference_recorded(workers):
   finally:
     sp.shutdown()
   assert ran >= 175 and not bad, bad[:10]
+
+
+def _run_dots(workers):
+  """The 100 random dots (every dispatch branch of dot.py:243-299; integer-valued operands): exact on any backend."""
+  gold = np.load(os.path.join(HERE, 'fuzz_w%d.npz' % workers))
+  meta = META[str(workers)]
+  bad = []
+  for key in DOTS:
+    m = meta[key]
+    assert 'skipped' not in m, key
+    got = np.asarray(fz._dot_case(int(key[1:]), sp))
+    if list(got.shape) != m['shape'] or got.dtype.str != m['dtype'] or not np.array_equal(_sample(got), gold[key]):
+      bad.append((key, got.shape, got.dtype.str, m['shape'], m['dtype']))
+  return bad
+
+
+@pytest.mark.parametrize('workers', [1, 3, 4, 8])
+def test_random_dots_are_what_the_reference_recorded_cpu(workers):
+  from oracle.np_backend import NumpyBackend
+  sp.initialize(backend=NumpyBackend(), num_workers=workers)
+  try:
+    assert _run_dots(workers) == []
+  finally:
+    sp.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workers', [1, 3, 4, 8])
+def test_random_dots_are_what_the_reference_recorded_hip(workers):
+  sp.initialize('hip', num_workers=workers)
+  try:
+    assert _run_dots(workers) == []
+  finally:
+    sp.shutdown()
