@@ -25,6 +25,17 @@ Python 3.10 the script
   5. runs the tile-path programs with 1, 3, 4 and 8 workers and records inputs
      and outputs.
 
+Modes (each rewrites its own files; all of them are deterministic -- a second run leaves `git status` clean):
+  (none)      extent / merge / fusion known answers, the programs of tests/programs.py at 1, 3, 4, 8 workers
+  --examples  the k-means / regression drivers (examples_w{1,3,4,8}.npz, examples_inputs.npz)
+  --sparse    the sparse-tile programs (sparse_w{1,3,4,8}.npz, sparse_meta.json)
+  --joins     map2 / outer / shuffle with user tile functions, tests/join_programs.py (joins_w{1,3,4,8}.npz)
+  --fuzz      300 random expression DAGs and 100 random dots of tests/test_fuzz_gpu.py's generators, as the reference
+              computes them (fuzz_w{1,3,4,8}.npz, fuzz_meta.json)
+  --region    map2(update_region=...), 4 workers (region_w4.npz)
+  --dotgrid   spartan.dot on grid-tiled operands (dot_grid.npz)
+  --tiling    the reference's tiling.cc on the cost graphs of every program (tiling_golden.json)
+
 Everything the reference computes here is computed by the reference's own code:
 extent.pyx, tile.pyx (merge), distarray.py (tiling, fetch, update), map/reduce/
 dot/outer mappers, optimize.py (fusion), sorting.py (argmax/argmin).
