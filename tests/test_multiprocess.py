@@ -21,8 +21,8 @@ def _free_port():
   return port
 
 
-def _run_two_ranks(workers, extra=(), backend='socket'):
-  _run_ranks(2, 'mp_worker.py', [str(workers)] + list(extra), backend=backend)
+def _run_two_ranks(workers, extra=(), backend='socket', extra_env=None):
+  _run_ranks(2, 'mp_worker.py', [str(workers)] + list(extra), backend=backend, extra_env=extra_env)
 
 
 def _run_ranks(size, script, args=(), backend='socket', extra_env=None):
@@ -62,7 +62,8 @@ def test_two_ranks_gloo():
 def test_two_ranks_bring_their_own_torch_group():
   """`World.from_env()` with no backend argument in a process whose torch.distributed group is already initialised
   (CPU box): the default data plane is gloo over that group (it used to pick 'socket' and refuse)."""
-  _run_two_ranks(2, backend='own-torch')
+  # (the case is a box WITHOUT GPUs; on a GPU box the two ranks would share one device, which RCCL refuses: hide it)
+  _run_two_ranks(2, backend='own-torch', extra_env={'HIP_VISIBLE_DEVICES': '', 'ROCR_VISIBLE_DEVICES': '', 'CUDA_VISIBLE_DEVICES': ''})
 
 
 @pytest.mark.parametrize('size,backend', [(3, 'socket'), (4, 'socket'), (8, 'socket'), (4, 'gloo')])
