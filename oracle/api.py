@@ -113,6 +113,24 @@ class Facade(object):
     return self._w(self.c.map_with_location(fn, self.c.empty((N, M), dtype)))
 
   def from_numpy(self, a, tile_hint=None): return self._w(self.c.from_numpy(a, tile_hint))
+  def assign(self, a, idx, value):
+    """a[idx] = value as a new array (assign.py:32-52 -> region_map: every tile that meets the region is copied with
+    the region replaced, so the result keeps `a`'s dtype whatever the value's)."""
+    out = np.array(a.glom(), copy=True)
+    v = value.glom() if isinstance(value, OArr) else value
+    if np.isscalar(idx):
+      idx = slice(idx, idx + 1)
+    out[idx] = np.asarray(v).astype(out.dtype) if not np.isscalar(v) else v
+    return self.from_numpy(out)
+
+  def write(self, array, src_slices, data, dst_slices):
+    """array[src_slices] = data[dst_slices] (write_array.py:82-94: an update of the evaluated array's tiles, merged
+    into the TARGET's dtype, tile.pyx:267)."""
+    out = np.array(array.glom(), copy=True)
+    d = data.glom() if isinstance(data, OArr) else np.asarray(data)
+    out[src_slices] = d[dst_slices].astype(out.dtype)
+    return self.from_numpy(out)
+
   def transpose(self, x): return self.from_numpy(np.ascontiguousarray(x.glom().T))
   def reshape(self, x, shape): return self.from_numpy(np.ascontiguousarray(x.glom().reshape(shape)))
   def ravel(self, x): return self.from_numpy(np.ascontiguousarray(x.glom().ravel()))

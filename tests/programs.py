@@ -259,6 +259,22 @@ def programs():
     return a
   add(('sum_axis0_ragged_tile_runs_last', lambda sp: sp.sum(sp.from_numpy(ragged_spikes(), tile_hint=(50, 3)), 0), lambda: None, None))
   add(('sum_all_ragged_tile_runs_last', lambda sp: sp.sum(sp.from_numpy(ragged_spikes(), tile_hint=(50, 3))) * sp.ones((2,)), lambda: None, None))
+  # ---- assign / write (tests/test_assign.py:10-83, test_write.py:30-70): the values are NumPy's assignment; what the
+  # recordings add is the result's dtype when array and value differ, and its tile table
+  add(('assign_row_f64_into_f32', lambda sp: sp.assign(sp.from_numpy(_ar((20, 10))), np.s_[10, ], np.arange(10, dtype=np.float64) / 4),
+       lambda: None, None))
+  add(('assign_box_from_expr_slice', lambda sp: sp.assign(sp.from_numpy(_ar((200, 100))), np.s_[99:102, 25:75], sp.from_numpy(_ar((6, 100)) * 2)[2:5, 10:60]),
+       lambda: None, None))
+  add(('assign_int_into_float', lambda sp: sp.assign(sp.from_numpy(_ar((64, 8))), np.s_[5:9, 2:4], sp.from_numpy(np.arange(8, dtype=np.int64).reshape(4, 2))),
+       lambda: None, None))
+  def quadrants(sp):
+    q = [(slice(0, 50), slice(0, 50)), (slice(0, 50), slice(50, 100)), (slice(50, 100), slice(0, 50)), (slice(50, 100), slice(50, 100))]
+    t = sp.zeros((100, 100))
+    src = (_ar((100, 100)) % 13).astype(np.float64)
+    for k, box in enumerate(q):
+      t = sp.write(t, box, src + k, box)
+    return t
+  add(('write_quadrants_f64_into_f32', quadrants, lambda: None, None))
   return P
 
 
