@@ -53,6 +53,15 @@ def _rows_times_all(ex_a, tile_a, ex_b, tile_b):
   yield _ext(ex_a).create((ex_a.ul[0], 0), (ex_a.lr[0], ex_b.lr[1]), (ex_a.array_shape[0], ex_b.array_shape[1])), tile_a.dot(tile_b)
 
 
+def _pair_partial(ex_a, tile_a, ex_b, tile_b):
+  # both operands partitioned: one call per PAIR of tiles (outer.py:30-57); every pair adds into the whole target
+  yield _ext(ex_a).create((0,), (3,), (3,)), tile_a.sum(axis=0) * tile_b[0:1, :].reshape(3)
+
+
+def _pair_tag(ex_a, tile_a, ex_b, tile_b):
+  yield _ext(ex_a).create((0,), (3,), (3,)), tile_b[0:1, :].reshape(3) * 0 + (ex_a.ul[0] * 10 + ex_b.ul[0] + 1)
+
+
 # ---- shuffle tile functions: fn(source, ex, **kw) -> [(target extent, data)]
 def _transposed_block(source, ex):
   data = source.fetch(ex)
@@ -83,6 +92,10 @@ def programs():
             lambda sp: sp.map2(sp.from_numpy(_ramp((200, 3))), 0, fn=_whole_target_first_row_tag, shape=(3,))))
   P.append(('outer_rows_times_all', lambda sp: sp.outer((sp.from_numpy(_ramp((60, 5))), sp.from_numpy(_ramp((5, 4), 5, 2))), (0, None),
                                                         fn=_rows_times_all, shape=(60, 4))))
+  P.append(('outer_pairs_whole_target_add', lambda sp: sp.outer((sp.from_numpy(_spikes(), tile_hint=four), sp.from_numpy(np.ones((8, 3), F32), tile_hint=(4, 3))),
+                                                                (0, 0), fn=_pair_partial, shape=(3,), reducer=np.add)))
+  P.append(('outer_pairs_whole_target_last_write', lambda sp: sp.outer((sp.from_numpy(_spikes(), tile_hint=four), sp.from_numpy(np.ones((8, 3), F32), tile_hint=(4, 3))),
+                                                                       (0, 0), fn=_pair_tag, shape=(3,))))
   P.append(('shuffle_transpose', lambda sp: sp.shuffle(sp.from_numpy(_ramp((60, 28))), _transposed_block, shape_hint=(28, 60))))
   P.append(('shuffle_target_add', lambda sp: sp.shuffle(sp.from_numpy(_spikes(), tile_hint=four), _colsum_row,
                                                         target=sp.ndarray((1, 3), dtype=F32, reduce_fn=np.add))))

@@ -44,7 +44,7 @@ def test_join_programs_cpu(workers):
   from oracle.np_backend import NumpyBackend
   sp.initialize(backend=NumpyBackend(), num_workers=workers)
   try:
-    assert check_all(workers) == 8
+    assert check_all(workers) == 10
   finally:
     sp.shutdown()
 
@@ -55,7 +55,7 @@ def test_join_programs_hip(workers):
   ctx = sp.initialize('hip', num_workers=workers)
   try:
     before = ctx.backend.launches
-    assert check_all(workers) == 8
+    assert check_all(workers) == 10
     assert ctx.backend.launches > before
   finally:
     sp.shutdown()
