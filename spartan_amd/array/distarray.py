@@ -981,7 +981,7 @@ def kernel_order(array, tile_ids, ctx):
         if t is None:
           try:
             ex = array.extent_for_blob(tid)
-          except KeyError:
+          except (KeyError, AttributeError):
             ex = None
           sizes[tid] = int(np.prod(ex.shape, dtype=np.int64)) if ex is not None else 0
         elif t.data is None:
