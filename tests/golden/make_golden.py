@@ -752,7 +752,7 @@ def join_goldens(sp, workers):
 
 
 FUZZ_SEEDS = range(5000, 5300)
-FUZZ_KEEP = 4096
+FUZZ_KEEP = 1024
 FUZZ_DOT_SEEDS = range(7000, 7100)
 
 

@@ -18,7 +18,7 @@ from tests import test_fuzz_gpu as fz
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 META = json.load(open(os.path.join(HERE, 'fuzz_meta.json')))
-KEEP = 4096
+KEEP = 1024
 # A seed is a fixture if the reference runs it at EVERY worker count.  A dozen run with one worker only: mixed-dtype
 # programs whose updates fail the reference's dtype assertion as soon as a target has a second tile -- and whose
 # one-worker answers show the same confusion (a fused arg-reduction keeps its extreme values in the dtype of the first
@@ -80,6 +80,13 @@ def _run(workers, exact_floats):
       else:
         bad.append((seed, 'dtype', got.dtype.str, m['dtype'], info))
       continue
+    if exact_floats and m['sum'] is not None and got.size > KEEP:
+      # (beyond the sample: the float64 sum of ALL values, which identical values reproduce exactly)
+      with np.errstate(all='ignore'):
+        total = float(np.nansum(got.astype(np.float64)))
+      if total != m['sum']:
+        bad.append((seed, 'sum of all values', total, m['sum']))
+        continue
     if got.dtype.kind in 'iub' or exact_floats:
       if not np.array_equal(g, want, equal_nan=got.dtype.kind == 'f'):
         diff = np.abs(g.astype(np.float64) - want.astype(np.float64))
@@ -129,7 +136,8 @@ def _run_dots(workers):
     m = meta[key]
     assert 'skipped' not in m, key
     got = np.asarray(fz._dot_case(int(key[1:]), sp))
-    if list(got.shape) != m['shape'] or got.dtype.str != m['dtype'] or not np.array_equal(_sample(got), gold[key]):
+    if list(got.shape) != m['shape'] or got.dtype.str != m['dtype'] or not np.array_equal(_sample(got), gold[key]) \
+            or float(got.astype(np.float64).sum()) != m['sum']:      # (the sample, and the sum of ALL of it: exact)
       bad.append((key, got.shape, got.dtype.str, m['shape'], m['dtype']))
   return bad
 
