@@ -31,6 +31,9 @@ class OArr(object):
   def diagonal(self):
     return self.api.diagonal(self)
 
+  def prod(self, axis=None):
+    return self.api.prod(self, axis)
+
   def _bin(self, other, fn, swap=False):
     a, b = (other, self) if swap else (self, other)
     return self.api.map((a, b), fn)

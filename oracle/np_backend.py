@@ -114,7 +114,8 @@ class NumpyBackend(object):
     d = dst
     s = _np(src)
     if d.ndim == 0:
-      d[...] = reducer(d, s) if reducer is not None else s
+      # (cast as the reference's merge does, tile.pyx:267 `update.astype(old.dtype)`: an int32 target WRAPS)
+      d[...] = np.asarray(reducer(d, s) if reducer is not None else s).astype(d.dtype)
       return
     box = tuple(slice(u, l) for u, l in zip(ul, lr))
     s = s.reshape(d[box].shape)

@@ -275,6 +275,16 @@ def programs():
       t = sp.write(t, box, src + k, box)
     return t
   add(('write_quadrants_f64_into_f32', quadrants, lambda: None, None))
+  # ---- integer results keep the operand's width (reduce.py:102 dtype_fn = the input's dtype; tile.pyx:267 casts every
+  # partial to it): int32 sums and products WRAP where NumPy's own sum would have promoted to int64
+  def big32():
+    return (np.arange(40 * 6, dtype=np.int64).reshape(40, 6) % 7 + 2**29).astype(np.int32)
+  add(('int32_sum_wraps_axis0', lambda sp: sp.sum(sp.from_numpy(big32()), 0), lambda: None, None))
+  add(('int32_sum_wraps_all', lambda sp: sp.sum(sp.from_numpy(big32())) * sp.ones((2,), dtype=np.int32), lambda: None, None))
+  add(('int32_prod_wraps_axis1', lambda sp: sp.from_numpy((np.arange(12 * 5, dtype=np.int32).reshape(12, 5) % 5 + 300).astype(np.int32)).prod(1),
+       lambda: None, None))
+  add(('uint8_like_bool_sum', lambda sp: sp.sum(sp.from_numpy((np.arange(300 * 4).reshape(300, 4) % 3 == 0)), 0), lambda: None, None))
+  add(('int64_mean_axis0', lambda sp: sp.mean(sp.from_numpy(np.arange(50 * 4, dtype=np.int64).reshape(50, 4) * 3), 0), lambda: None, None))
   return P
 
 
