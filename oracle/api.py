@@ -290,6 +290,21 @@ class Facade(object):
   def dot(self, a, b, tile_hint=None):
     return self._w(self.c.dot(self._u(a), b if isinstance(b, np.ndarray) else self._u(b), tile_hint))
 
+  # user-function joins (tests/join_programs.py): the tile functions see the oracle's own arrays and extents
+  def ndarray(self, shape, dtype=np.float32, tile_hint=None, reduce_fn=None):
+    return self._w(self.c.empty(shape, dtype, reduce_fn, tile_hint))
+
+  def map2(self, arrays, axes=(), fn=None, fn_kw=None, shape=None, reducer=None, tile_hint=None):
+    arrays = list(arrays) if isinstance(arrays, (list, tuple)) else [arrays]
+    axes = tuple(axes) if isinstance(axes, (list, tuple)) else (axes,)
+    return self._w(self.c.map2([self._u(a) for a in arrays], axes, fn, shape, reducer, fn_kw))
+
+  def outer(self, arrays, axes, fn, fn_kw=None, shape=None, tile_hint=None, reducer=None, dtype=None):
+    return self._w(self.c.outer([self._u(a) for a in arrays], tuple(axes), fn, shape, reducer, fn_kw, tile_hint, dtype))
+
+  def shuffle(self, v, fn, shape_hint=None, target=None, kw=None):
+    return self._w(self.c.shuffle(self._u(v), fn, None if target is None else self._u(target), shape_hint, kw))
+
 
 def facade(num_workers=1):
   return Facade(num_workers)

@@ -53,6 +53,11 @@ class Extent(object):
     return 'ex(' + ','.join('%d:%d' % p for p in zip(self.ul, self.lr)) + ')'
 
 
+def create(ul, lr, array_shape):
+  """extent.create under the name user tile functions call it by."""
+  return ex_create(ul, lr, array_shape)
+
+
 def ex_create(ul, lr, array_shape):
   """extent.pyx:141-182: None when any ul >= lr."""
   for u, l in zip(ul, lr):
@@ -474,6 +479,51 @@ class Cluster(object):
       for where, data in fn(extents, slabs, **(fn_kw or {})) or ():
         target.update(where, data)
     return target
+
+  # -- outer (outer.py:12-99) -----------------------------------------------------------------
+  def outer(self, arrays, axes, fn, shape, reducer=None, fn_kw=None, tile_hint=None, dtype=None):
+    """outer_mapper, outer.py:12-59: every tile of arrays[0] (re-read on axes[0]) meets the WHOLE of arrays[1]
+    (axes[1] None) or each of its tiles in table order, re-read on axes[1] (one call per pair); what
+    fn(ex_a, tile_a, ex_b, tile_b) yields is pushed into a target of arrays[0]'s dtype (outer.py:91-97)."""
+    a, b = arrays
+    target = self.empty(shape, a.dtype if dtype is None else dtype, reducer, tile_hint)
+    for ex, _, t in self.kernel_order(a):
+      first = change_partition_axis(ex, axes[0])
+      tile_a = a.fetch(first)
+      if axes[1] is None:
+        whole = ex_create([0] * len(b.shape), b.shape, b.shape)
+        for where, data in fn(first, tile_a, whole, b.fetch(whole), **(fn_kw or {})) or ():
+          target.update(where, data)
+        continue
+      done = set()
+      for bex, _, _t in b.tiles:
+        other = change_partition_axis(bex, axes[1])
+        if other is None or other.key() in done:
+          continue
+        done.add(other.key())
+        for where, data in fn(first, tile_a, other, b.fetch(other), **(fn_kw or {})) or ():
+          target.update(where, data)
+    return target
+
+  # -- shuffle (shuffle.py:41-160) --------------------------------------------------------------
+  def shuffle(self, source, fn, target=None, shape_hint=None, fn_kw=None):
+    """target_mapper / notarget_mapper, shuffle.py:41-96: fn(source, extent, **kw) -> [(extent, data)] for every
+    tile of `source` in kernel order; the pieces are pushed into `target` (merged by ITS reducer) or become the
+    tiles of a new array (shape from the pieces' extents)."""
+    pieces = []
+    for ex, _, t in self.kernel_order(source):
+      for where, data in fn(source, ex, **(fn_kw or {})) or ():
+        if target is not None:
+          target.update(where, data)
+        else:
+          pieces.append((where, np.asarray(data)))
+    if target is not None:
+      return target
+    out = self.empty(pieces[0][0].array_shape, pieces[0][1].dtype, None, None)
+    full = np.zeros(out.shape, out.dtype)
+    for where, data in pieces:
+      full[where.to_slice()] = data.reshape(where.shape)
+    return self.from_numpy(full)
 
   # -- dot (dot.py:172-299, map.py:243-334, outer.py:12-99) -----------------------------
   def dot(self, a, b, tile_hint=None):
