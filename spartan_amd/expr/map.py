@@ -118,6 +118,12 @@ def _evaluate_aligned(node, ctx, values, names):
       operands[name] = t.data
     operands['extent'] = ex
     rows.append((ex, tid.worker, operands))
+  if len(rows) > 1:
+    # the tiles in the order run_kernel walks them (distarray.kernel_order): a map's tiles do not meet, but an operator
+    # tree with a random source draws from its worker's stream tile after tile -- the same draws on either path
+    at = {tid: k for k, tid in enumerate(distarray.kernel_order(lead, list(lead.tiles.values()), ctx))}
+    order = sorted(range(len(rows)), key=lambda i, tids=list(lead.tiles.values()): at[tids[i]])
+    rows = [rows[i] for i in order]
   backend, op = ctx.backend, node.op
   table = collections.OrderedDict()
   outer_worker = ctx.current_worker
@@ -136,6 +142,10 @@ def _evaluate_aligned(node, ctx, values, names):
       table[ex] = ctx.create(tile.from_data(out, dtype=dt), hint=worker)
   finally:
     ctx.current_worker = outer_worker
+  if len(table) > 1:
+    # (the result's tile table in the operands' order, whatever order the kernels ran in: arrays cut the same way
+    #  compare equal tile by tile)
+    table = collections.OrderedDict((ex, table[ex]) for ex in lead.tiles)
   return distarray.DistArrayImpl(shape=lead.shape, dtype=dtype, tiles=table, reducer_fn=None, sparse=False)
 
 
